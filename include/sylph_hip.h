@@ -1,0 +1,144 @@
+/*
+ * sylph_hip.h — C ABI of the MI355X (gfx950) sketch + profile engine.
+ *
+ * This is the drop-in boundary for the hot path of bluenote-1577/sylph v0.8.1.  The reference exposes no
+ * plugin/FFI API; each entry point below replaces one in-crate Rust function (cited as file:line under
+ * /root/reference/src) at the seam where a Rust `extern "C"` binding would be added (see INTEGRATION.md for
+ * the `rust/ffi.rs` stub).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions (mirroring the reference's calling conventions):
+ *  - inputs are borrowed for the duration of the call; outputs named `**out` are allocated by the library and
+ *    released with sylph_free(); handles are released with their *_destroy();
+ *  - every function returns SYLPH_OK (0) or a negative error code and never aborts/unwinds across the boundary
+ *    (the reference warn+skips or exit(1)s; a release build is panic=abort, Cargo.toml:40); the message for the
+ *    last error on the calling thread is sylph_last_error();
+ *  - a sylph_ctx may be used from several host threads (rayon workers call concurrently, sketch.rs:313,371;
+ *    contain.rs:267,284): calls on one ctx are serialised internally, use one ctx per worker for overlap;
+ *  - results never depend on thread interleaving: tables are returned in ascending k-mer order.
+ *  - `mem` says where the caller's input arrays live: SYLPH_MEM_HOST (pageable/pinned host memory, copied
+ *    H2D by the library) or SYLPH_MEM_DEVICE (already resident in this GPU's HBM; zero-copy).
+ */
+#ifndef SYLPH_HIP_H
+#define SYLPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYLPH_OK 0
+#define SYLPH_ERR_INVALID (-1)   /* bad argument (the reference would panic!/exit(1)) */
+#define SYLPH_ERR_HIP (-2)       /* HIP runtime error */
+#define SYLPH_ERR_NOMEM (-3)
+#define SYLPH_ERR_STATE (-4)     /* call made in the wrong session state */
+
+/* Which k-mers of a sequence are hashed.
+ * SYLPH_SEED_SCALAR      = seeding.rs:86-146 fmh_seeds (every k-mer).
+ * SYLPH_SEED_AVX2_COMPAT = avx2_seeding.rs:33-148 extract_markers_avx2, the path the reference takes on every
+ *                          AVX2 x86 host (sketch.rs:53-63): k-mers with start >= 4*((L-k+1)/4) are never hashed,
+ *                          sequences shorter than k+1 (reads) / 2k (genome contigs) yield nothing. Default. */
+#define SYLPH_SEED_SCALAR 0
+#define SYLPH_SEED_AVX2_COMPAT 1
+
+#define SYLPH_READS_SINGLE 0     /* sketch_sequences_needle, sketch.rs:897 */
+#define SYLPH_READS_PAIRED 1     /* sketch_pair_sequences with --fpr 0 (exact set), sketch.rs:771 */
+
+#define SYLPH_MEM_HOST 0
+#define SYLPH_MEM_DEVICE 1
+
+typedef struct sylph_ctx sylph_ctx;        /* one GPU + one HIP stream + scratch memory */
+typedef struct sylph_sketch sylph_sketch;  /* a read-sketch session (one sample) */
+typedef struct sylph_db sylph_db;          /* a genome database (shard) resident in HBM */
+
+int sylph_version(void);
+const char *sylph_last_error(void);
+void sylph_free(void *p);
+
+/* device < 0: current device.  stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a
+ * private stream. */
+int sylph_ctx_create(int device, void *stream, sylph_ctx **out);
+void sylph_ctx_destroy(sylph_ctx *ctx);
+int sylph_ctx_synchronize(sylph_ctx *ctx);
+
+/* Per-kernel timing (hipEvent pairs on the ctx stream around every launch of the named kernel family) for
+ * bench.py's roofline object.  enable=1 starts collecting and clears the totals. Families: "seeds", "annotate",
+ * "sort", "replay", "probe", "db_index". */
+int sylph_ctx_profile(sylph_ctx *ctx, int enable);
+int sylph_ctx_kernel_stats(sylph_ctx *ctx, const char *family, double *total_ms, uint64_t *launches);
+
+/* ---- seeding -------------------------------------------------------------------------------------------- */
+
+/* extract_markers(string, kmer_vec, c, k)  — sketch.rs:53-69 (-> avx2_seeding.rs:33 | seeding.rs:86).
+ * FracMinHash seeds of one sequence: mm_hash64 (seeding.rs:4-15) of the canonical k-mer, kept if
+ * hash < u64::MAX / c.  Output order: ascending k-mer start position (the reference's lane-interleaved push
+ * order is not observable through any caller).  k must be 21 or 31 (avx2_seeding.rs:46-52). */
+int sylph_seeds(sylph_ctx *ctx, const uint8_t *bases, uint64_t len, uint32_t c, uint32_t k, int seed_mode,
+                uint64_t **out_hashes, uint64_t *out_n);
+
+/* extract_markers_positions(string, kmer_vec, c, k, contig_number) — sketch.rs:71-93, for all contigs of one
+ * genome at once: contig i = bases[contig_off[i], contig_off[i+1]).  Returns (contig, pos, hash) triples in
+ * ascending (contig, pos) order, i.e. after the reference's `vec.sort()` (sketch.rs:593); pos is the index of
+ * the k-mer's LAST base inside its contig (seeding.rs:205, avx2_seeding.rs:253-264). */
+int sylph_seeds_positions(sylph_ctx *ctx, const uint8_t *bases, const uint64_t *contig_off, uint64_t n_contigs,
+                          uint32_t c, uint32_t k, int seed_mode, uint32_t **out_contig, uint64_t **out_pos,
+                          uint64_t **out_hash, uint64_t *out_n);
+
+/* sketch_genome(c, k, ref_file, min_spacing, pseudotax) — sketch.rs:550-622, after FASTA parsing: seeds with
+ * positions, genome-wide removal of every k-mer seen >= 2 times (:594-605), greedy min-spacing filter (:602-614).
+ * genome_kmers come back in (contig, pos) order; rejected-by-spacing k-mers in out_tracked if pseudotax != 0
+ * (out_tracked may be NULL otherwise). */
+int sylph_sketch_genome(sylph_ctx *ctx, const uint8_t *bases, const uint64_t *contig_off, uint64_t n_contigs,
+                        uint32_t c, uint32_t k, int seed_mode, uint64_t min_spacing, int pseudotax,
+                        uint64_t **out_genome_kmers, uint64_t *out_n, uint64_t **out_tracked,
+                        uint64_t *out_n_tracked);
+
+/* ---- read sketching (one session = one sample) --------------------------------------------------------- */
+
+/* Replaces sketch_sequences_needle (sketch.rs:897-959) / sketch_pair_sequences (sketch.rs:771-895) after record
+ * parsing.  The host keeps what is sequential or textual: mean_read_length (sketch.rs:941-943, :825-826), file
+ * and sample names.  Deduplication is the exact rule of dup_removal_lsh_full_exact (sketch.rs:690-731) with
+ * MAX_DEDUP_COUNT = 4 for single-end (constants.rs:14, sketch.rs:937) and no cut-off for pairs (:837). */
+int sylph_sketch_begin(sylph_ctx *ctx, uint32_t c, uint32_t k, int reads_mode, int no_dedup, int seed_mode,
+                       sylph_sketch **out);
+
+/* Append a batch of records in file order: record i = bases[rec_off[i], rec_off[i+1]), rec_off[0] == 0.
+ * SYLPH_READS_PAIRED: records are interleaved mate1, mate2, mate1, ... (n_records even).  A batch may hold up
+ * to 2^32-1 bases.  With SYLPH_MEM_DEVICE `bases` must be 16-byte aligned and readable up to
+ * rec_off[n_records] rounded up to 16 bytes. */
+int sylph_sketch_push(sylph_sketch *sk, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_records,
+                      int mem);
+
+/* Finish the sample: (k-mer, count) table in ascending k-mer order == SequencesSketch.kmer_counts
+ * (types.rs:145-155) as a keyed multiset, and the number of occurrences removed as duplicates
+ * (sketch.rs:886-892).  The *_device variant leaves the table in HBM (owned by the session, valid until
+ * sylph_sketch_destroy) so it can be handed to sylph_db_contain without a host round trip. */
+int sylph_sketch_finish(sylph_sketch *sk, uint64_t **out_kmers, uint32_t **out_counts, uint64_t *out_n,
+                        uint64_t *out_dup_removed);
+int sylph_sketch_finish_device(sylph_sketch *sk, const uint64_t **dev_kmers, const uint32_t **dev_counts,
+                               uint64_t *out_n, uint64_t *out_dup_removed);
+void sylph_sketch_destroy(sylph_sketch *sk);
+
+/* ---- containment (sample vs every genome of a resident DB shard) ----------------------------------------- */
+
+/* Load the genome_kmers of a set of GenomeSketch (types.rs:163-173; contain.rs:495 deserialises them) into HBM:
+ * genome g = kmers[genome_off[g], genome_off[g+1]).  Builds the k-mer -> genome postings index once.
+ * At most 2^32-1 k-mers and 2^32-1 genomes per shard. */
+int sylph_db_upload(sylph_ctx *ctx, const uint64_t *kmers, const uint64_t *genome_off, uint64_t n_genomes, int mem,
+                    sylph_db **out);
+uint64_t sylph_db_n_genomes(const sylph_db *db);
+uint64_t sylph_db_n_kmers(const sylph_db *db);
+
+/* Probe half of get_stats (contain.rs:601-656) for every genome of the shard against one sample table
+ * (k-mers distinct; entries with count 0 are ignored, :634).  Genomes with fewer than min_number_kmers k-mers
+ * report 0 (:627).  contain_count[g] and cov_off[g..g+1] are caller-allocated (n_genomes, n_genomes+1);
+ * *out_covs holds, for genome g, covs[cov_off[g] .. cov_off[g+1]) sorted ascending (the reference sorts them
+ * before use, contain.rs:661). */
+int sylph_db_contain(sylph_db *db, const uint64_t *sample_kmers, const uint32_t *sample_counts, uint64_t n, int mem,
+                     double min_number_kmers, uint32_t *contain_count, uint64_t *cov_off, uint32_t **out_covs);
+void sylph_db_destroy(sylph_db *db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYLPH_HIP_H */

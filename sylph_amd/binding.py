@@ -1,0 +1,238 @@
+"""ctypes binding of include/sylph_hip.h.  One class per handle type; method names mirror the reference functions
+each ABI entry point replaces (see the header for file:line citations).  No computation happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+SEED_SCALAR, SEED_AVX2_COMPAT = 0, 1
+READS_SINGLE, READS_PAIRED = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_LIB = None
+
+
+class SylphHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sylph_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsylph_hip.so")
+
+
+EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_ctx_create", "sylph_ctx_destroy",
+           "sylph_ctx_synchronize", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
+           "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_begin", "sylph_sketch_push",
+           "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
+           "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_destroy"]
+
+
+def load():
+    """Load libsylph_hip.so.  Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise SylphHipError(-100, f"{p} is missing: build it with `make -C sylph_amd/csrc` (no CPU fallback exists)")
+    L = C.CDLL(p)
+    vp, u64, u32, i32, dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+    P = C.POINTER
+    L.sylph_version.restype = i32
+    L.sylph_last_error.restype = C.c_char_p
+    L.sylph_free.argtypes = [vp]
+    L.sylph_free.restype = None
+    L.sylph_ctx_create.argtypes = [i32, vp, P(vp)]
+    L.sylph_ctx_destroy.argtypes = [vp]
+    L.sylph_ctx_destroy.restype = None
+    L.sylph_ctx_synchronize.argtypes = [vp]
+    L.sylph_ctx_profile.argtypes = [vp, i32]
+    L.sylph_ctx_kernel_stats.argtypes = [vp, C.c_char_p, P(dbl), P(u64)]
+    L.sylph_seeds.argtypes = [vp, vp, u64, u32, u32, i32, P(vp), P(u64)]
+    L.sylph_seeds_positions.argtypes = [vp, vp, vp, u64, u32, u32, i32, P(vp), P(vp), P(vp), P(u64)]
+    L.sylph_sketch_genome.argtypes = [vp, vp, vp, u64, u32, u32, i32, u64, i32, P(vp), P(u64), P(vp), P(u64)]
+    L.sylph_sketch_begin.argtypes = [vp, u32, u32, i32, i32, i32, P(vp)]
+    L.sylph_sketch_push.argtypes = [vp, vp, vp, u64, i32]
+    L.sylph_sketch_finish.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
+    L.sylph_sketch_finish_device.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
+    L.sylph_sketch_destroy.argtypes = [vp]
+    L.sylph_sketch_destroy.restype = None
+    L.sylph_db_upload.argtypes = [vp, vp, vp, u64, i32, P(vp)]
+    L.sylph_db_n_genomes.argtypes = [vp]
+    L.sylph_db_n_genomes.restype = u64
+    L.sylph_db_n_kmers.argtypes = [vp]
+    L.sylph_db_n_kmers.restype = u64
+    L.sylph_db_contain.argtypes = [vp, vp, vp, u64, i32, dbl, vp, vp, P(vp)]
+    L.sylph_db_destroy.argtypes = [vp]
+    L.sylph_db_destroy.restype = None
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SylphHipError(rc, load().sylph_last_error().decode("utf-8", "replace"))
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _take(ptr, n, dtype):
+    """Copy a library-allocated array into numpy and free it."""
+    n = int(n)
+    out = np.empty(n, dtype=dtype)
+    if n:
+        C.memmove(out.ctypes.data, ptr, n * out.itemsize)
+    load().sylph_free(ptr)
+    return out
+
+
+def _bases(b):
+    if isinstance(b, (bytes, bytearray)):
+        return np.frombuffer(bytes(b), dtype=np.uint8)
+    return _np(b, np.uint8)
+
+
+class Context:
+    """One GPU + one HIP stream.  stream: int handle of a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=-1, stream=None):
+        self._h = C.c_void_p()
+        _check(load().sylph_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().sylph_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(load().sylph_ctx_synchronize(self._h))
+
+    def profile(self, enable=True):
+        _check(load().sylph_ctx_profile(self._h, int(enable)))
+
+    def kernel_stats(self, family):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _check(load().sylph_ctx_kernel_stats(self._h, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # extract_markers, sketch.rs:53
+    def extract_markers(self, seq, c=200, k=31, seed_mode=SEED_AVX2_COMPAT):
+        a = _bases(seq)
+        out, n = C.c_void_p(), C.c_uint64(0)
+        _check(load().sylph_seeds(self._h, _ptr(a) if len(a) else None, len(a), c, k, seed_mode, C.byref(out), C.byref(n)))
+        return _take(out, n.value, np.uint64)
+
+    # extract_markers_positions for all contigs, sketch.rs:71 (+ vec.sort(), sketch.rs:593)
+    def extract_markers_positions(self, bases, contig_off, c=200, k=31, seed_mode=SEED_AVX2_COMPAT):
+        a, off = _bases(bases), _np(contig_off, np.uint64)
+        oc, op, oh, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        _check(load().sylph_seeds_positions(self._h, _ptr(a) if len(a) else None, _ptr(off), len(off) - 1, c, k, seed_mode,
+                                            C.byref(oc), C.byref(op), C.byref(oh), C.byref(n)))
+        return _take(oc, n.value, np.uint32), _take(op, n.value, np.uint64), _take(oh, n.value, np.uint64)
+
+    # sketch_genome, sketch.rs:550
+    def sketch_genome(self, bases, contig_off, c=200, k=31, seed_mode=SEED_AVX2_COMPAT, min_spacing=30, pseudotax=True):
+        a, off = _bases(bases), _np(contig_off, np.uint64)
+        ok, ot, n, nt = C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint64(0)
+        _check(load().sylph_sketch_genome(self._h, _ptr(a) if len(a) else None, _ptr(off), len(off) - 1, c, k, seed_mode,
+                                          min_spacing, int(pseudotax), C.byref(ok), C.byref(n), C.byref(ot), C.byref(nt)))
+        return dict(genome_kmers=_take(ok, n.value, np.uint64), tracked=_take(ot, nt.value, np.uint64),
+                    gn_size=int(off[-1]) if len(off) else 0)
+
+
+class ReadSketcher:
+    """Session for one sample: sketch_sequences_needle (sketch.rs:897) / sketch_pair_sequences --fpr 0 (sketch.rs:771)."""
+
+    def __init__(self, ctx, c=200, k=31, paired=False, no_dedup=False, seed_mode=SEED_AVX2_COMPAT):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        _check(load().sylph_sketch_begin(ctx._h, c, k, READS_PAIRED if paired else READS_SINGLE, int(no_dedup), seed_mode,
+                                         C.byref(self._h)))
+
+    def push(self, bases, rec_off):
+        a, off = _bases(bases), _np(rec_off, np.uint64)
+        _check(load().sylph_sketch_push(self._h, _ptr(a) if len(a) else None, _ptr(off), len(off) - 1, MEM_HOST))
+
+    def push_device(self, bases_ptr, rec_off_ptr, n_records):
+        """bases_ptr / rec_off_ptr: integer device addresses (e.g. torch tensor .data_ptr())."""
+        _check(load().sylph_sketch_push(self._h, C.c_void_p(bases_ptr), C.c_void_p(rec_off_ptr), n_records, MEM_DEVICE))
+
+    def finish(self):
+        ok, oc, n, d = C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint64(0)
+        _check(load().sylph_sketch_finish(self._h, C.byref(ok), C.byref(oc), C.byref(n), C.byref(d)))
+        return dict(kmers=_take(ok, n.value, np.uint64), counts=_take(oc, n.value, np.uint32), dup_removed=int(d.value))
+
+    def finish_device(self):
+        """-> (device address of kmers, device address of counts, n, dup_removed); valid until close()."""
+        ok, oc, n, d = C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint64(0)
+        _check(load().sylph_sketch_finish_device(self._h, C.byref(ok), C.byref(oc), C.byref(n), C.byref(d)))
+        return ok.value or 0, oc.value or 0, int(n.value), int(d.value)
+
+    def close(self):
+        if self._h:
+            load().sylph_sketch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Database:
+    """genome_kmers of many GenomeSketch resident in HBM + postings index; probe half of get_stats (contain.rs:601-656)."""
+
+    def __init__(self, ctx, kmers, genome_off, device_ptrs=False, n_genomes=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if device_ptrs:
+            _check(load().sylph_db_upload(ctx._h, C.c_void_p(kmers), C.c_void_p(genome_off), n_genomes, MEM_DEVICE,
+                                          C.byref(self._h)))
+        else:
+            k, off = _np(kmers, np.uint64), _np(genome_off, np.uint64)
+            _check(load().sylph_db_upload(ctx._h, _ptr(k) if len(k) else None, _ptr(off), len(off) - 1, MEM_HOST,
+                                          C.byref(self._h)))
+        self.n_genomes = int(load().sylph_db_n_genomes(self._h))
+        self.n_kmers = int(load().sylph_db_n_kmers(self._h))
+
+    def contain(self, sample_kmers, sample_counts, min_number_kmers=50.0, device_ptrs=False, n=None):
+        """-> (contain_count[G] uint32, cov_off[G+1] uint64, covs uint32 sorted ascending per genome)."""
+        G = self.n_genomes
+        cc = np.zeros(max(G, 1), dtype=np.uint32)
+        off = np.zeros(G + 1, dtype=np.uint64)
+        out = C.c_void_p()
+        if device_ptrs:
+            _check(load().sylph_db_contain(self._h, C.c_void_p(sample_kmers), C.c_void_p(sample_counts), n, MEM_DEVICE,
+                                           float(min_number_kmers), _ptr(cc), _ptr(off), C.byref(out)))
+        else:
+            k, c = _np(sample_kmers, np.uint64), _np(sample_counts, np.uint32)
+            _check(load().sylph_db_contain(self._h, _ptr(k) if len(k) else None, _ptr(c) if len(c) else None, len(k),
+                                           MEM_HOST, float(min_number_kmers), _ptr(cc), _ptr(off), C.byref(out)))
+        covs = _take(out, int(off[G]), np.uint32)
+        return cc[:G], off, covs
+
+    def close(self):
+        if self._h:
+            load().sylph_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,296 @@
+// contain.hip — sample-vs-database containment on gfx950 (probe half of get_stats, contain.rs:601-656).
+//
+// The reference walks every genome's k-mers and probes the sample's FxHashMap (contain.rs:632-652): ~1.4e9 random
+// probes per sample at GTDB-R220 scale.  Here the database lives in HBM as ONE postings array sorted by k-mer,
+//     db_kmer[N] ascending,  db_gid[N] (genome of each posting),  bucket_start[] (radix index on the top bits),
+// built once at upload, and the (much smaller, already sorted) sample table is streamed against it: each sample
+// k-mer finds its bucket (one 8 B index read), scans the few postings in it, and emits one (genome, count) hit per
+// matching posting.  Hits are radix-sorted by (genome, count): that yields contain_count[g] and the per-genome
+// coverage vectors already in the ascending order the reference sorts them into (contain.rs:661).
+// Same outputs, O(sample) instead of O(database) work per sample.  Pure integer work, HBM/L2-latency bound.
+#include <algorithm>
+#include <memory>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace sylph {
+namespace {
+
+__global__ __launch_bounds__(256) void fill_gid_kernel(const uint64_t* __restrict__ genome_off, uint64_t n_genomes,
+                                                       uint32_t* __restrict__ gid, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gid[i] = (uint32_t)find_record(genome_off, n_genomes, i);
+}
+
+__global__ __launch_bounds__(256) void genome_len_kernel(const uint64_t* __restrict__ genome_off, uint64_t n_genomes,
+                                                         uint32_t* __restrict__ glen) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_genomes) glen[g] = (uint32_t)(genome_off[g + 1] - genome_off[g]);
+}
+
+// bucket_start[b] = first posting whose (kmer >> shift) >= b, for b in [0, n_buckets]
+__global__ __launch_bounds__(256) void bucket_index_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+                                                           uint32_t n_buckets, uint32_t* __restrict__ bucket_start) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const uint64_t lo = (i == 0) ? 0 : (keys[i - 1] >> shift) + 1;          // first bucket not yet started
+    const uint64_t hi = (i == n) ? (uint64_t)n_buckets : (keys[i] >> shift);   // last bucket that starts at i
+    for (uint64_t b = lo; b <= hi && b <= n_buckets; b++) bucket_start[b] = i;
+}
+
+// Probe: one lane per sample k-mer.  Hits are (gid << 32 | count), staged per workgroup in LDS and flushed with
+// one global atomic per workgroup.
+constexpr int PROBE_TPB = 256;
+constexpr int PROBE_STAGE = 2048;
+
+__global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const uint64_t* __restrict__ s_kmers,
+                                                          const uint32_t* __restrict__ s_counts, uint32_t n_sample,
+                                                          const uint64_t* __restrict__ db_kmer,
+                                                          const uint32_t* __restrict__ db_gid,
+                                                          const uint32_t* __restrict__ bucket_start, int shift,
+                                                          uint32_t n_buckets, const uint32_t* __restrict__ glen,
+                                                          double min_number_kmers, uint64_t* __restrict__ hits,
+                                                          uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
+    __shared__ uint64_t stage[PROBE_STAGE];
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * PROBE_TPB + threadIdx.x;
+    if (i < n_sample) {
+        const uint64_t km = s_kmers[i];
+        const uint32_t cnt = s_counts[i];
+        const uint64_t b = km >> shift;
+        if (cnt != 0 && b < n_buckets) {                                     // contain.rs:634
+            uint32_t lo = bucket_start[b];
+            const uint32_t end = bucket_start[b + 1];
+            uint32_t hi = end;
+            while (lo < hi) {                                                // lower_bound inside the bucket
+                const uint32_t mid = (lo + hi) >> 1;
+                if (db_kmer[mid] < km) lo = mid + 1; else hi = mid;
+            }
+            for (uint32_t j = lo; j < end && db_kmer[j] == km; j++) {
+                const uint32_t g = db_gid[j];
+                if ((double)glen[g] < min_number_kmers) continue;            // contain.rs:627
+                const uint64_t hit = ((uint64_t)g << 32) | cnt;
+                const uint32_t slot = atomicAdd(&s_cnt, 1u);
+                if (slot < PROBE_STAGE) stage[slot] = hit;
+                else {
+                    const uint32_t o = atomicAdd(hit_count, 1u);
+                    if (o < hit_cap) hits[o] = hit;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = min(s_cnt, (uint32_t)PROBE_STAGE);
+    if (n) {
+        if (threadIdx.x == 0) s_base = atomicAdd(hit_count, n);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < n; t += PROBE_TPB) {
+            const uint32_t o = s_base + t;
+            if (o < hit_cap) hits[o] = stage[t];
+        }
+    }
+}
+
+// cov_off[g] = first sorted hit with genome id >= g; covs[i] = low 32 bits of hit i
+__global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __restrict__ hits, uint32_t n_hits,
+                                                          uint32_t n_genomes, uint64_t* __restrict__ cov_off,
+                                                          uint32_t* __restrict__ contain_count) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_genomes) return;
+    auto lower = [&](uint64_t key) {
+        uint32_t lo = 0, hi = n_hits;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (hits[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t a = lower((uint64_t)g << 32);
+    cov_off[g] = a;
+    if (g < n_genomes) contain_count[g] = lower(((uint64_t)g + 1) << 32) - a;
+}
+
+__global__ __launch_bounds__(256) void narrow_kernel(const uint64_t* __restrict__ hits, uint32_t n, uint32_t* __restrict__ covs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) covs[i] = (uint32_t)hits[i];
+}
+
+}  // namespace
+}  // namespace sylph
+
+using namespace sylph;
+
+struct sylph_db {
+    sylph_ctx* ctx;
+    uint64_t n_genomes = 0, n_kmers = 0;
+    int shift = 0;
+    uint32_t n_buckets = 0;
+    DevBuf kmer, gid, bucket_start, glen;
+    // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
+    DevBuf q_kmers, q_counts, hits, hits_sorted, cov_off, ccount, covs, counter;
+};
+
+static uint32_t grid_for64(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
+
+extern "C" {
+
+int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
+                    sylph_db** out) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && out, "null argument");
+        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+        SY_REQUIRE(n_genomes < (1ull << 32), "at most 2^32-1 genomes per shard");
+        SY_REQUIRE(n_genomes == 0 || genome_off, "null genome_off");
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        std::unique_ptr<sylph_db> db(new sylph_db());
+        db->ctx = ctx;
+        db->n_genomes = n_genomes;
+        db->counter.reserve(64);
+        uint64_t n = 0;
+        DevBuf d_off_buf, d_in;
+        const uint64_t* d_off = nullptr;
+        const uint64_t* d_kmers_in = nullptr;
+        if (n_genomes) {
+            if (mem == SYLPH_MEM_HOST) {
+                SY_REQUIRE(genome_off[0] == 0, "genome_off[0] must be 0");
+                n = genome_off[n_genomes];
+                d_off_buf.reserve((n_genomes + 1) * 8);
+                SY_HIP(hipMemcpyAsync(d_off_buf.p, genome_off, (n_genomes + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+                d_off = d_off_buf.as<uint64_t>();
+                if (n) {
+                    SY_REQUIRE(kmers, "null kmers");
+                    d_in.reserve(n * 8);
+                    SY_HIP(hipMemcpyAsync(d_in.p, kmers, n * 8, hipMemcpyHostToDevice, ctx->stream));
+                    d_kmers_in = d_in.as<uint64_t>();
+                }
+            } else {
+                SY_HIP(hipMemcpyAsync(&n, genome_off + n_genomes, 8, hipMemcpyDeviceToHost, ctx->stream));
+                SY_HIP(hipStreamSynchronize(ctx->stream));
+                d_off = genome_off;
+                d_kmers_in = kmers;
+            }
+        }
+        SY_REQUIRE(n < (1ull << 32), "at most 2^32-1 k-mers per shard (got %llu): shard the database", (unsigned long long)n);
+        db->n_kmers = n;
+        db->glen.reserve(std::max<uint64_t>(1, n_genomes) * 4);
+        if (n_genomes)
+            hipLaunchKernelGGL(genome_len_kernel, dim3(grid_for64(n_genomes)), dim3(256), 0, ctx->stream, d_off, n_genomes,
+                               db->glen.as<uint32_t>());
+        if (n) {
+            ScopedKernelTimer t(ctx, "db_index");
+            DevBuf gid_in;
+            gid_in.reserve(n * 4);
+            db->kmer.reserve(n * 8);
+            db->gid.reserve(n * 4);
+            hipLaunchKernelGGL(fill_gid_kernel, dim3(grid_for64(n)), dim3(256), 0, ctx->stream, d_off, n_genomes,
+                               gid_in.as<uint32_t>(), n);
+            sort_pairs_u64_u32(ctx, d_kmers_in, db->kmer.as<uint64_t>(), gid_in.as<uint32_t>(), db->gid.as<uint32_t>(), n, 0,
+                               64);
+            uint64_t max_key = 0;
+            SY_HIP(hipMemcpyAsync(&max_key, db->kmer.as<uint64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+            SY_HIP(hipStreamSynchronize(ctx->stream));
+            // ~8 postings per bucket on average (one or two 64 B sectors), index <= 2^28 entries
+            int b = bit_length(n / 8);
+            b = std::min(28, std::max(8, b));
+            const int bits = std::max(1, bit_length(max_key));
+            db->shift = std::max(0, bits - b);
+            db->n_buckets = (uint32_t)((max_key >> db->shift) + 1);
+            db->bucket_start.reserve(((size_t)db->n_buckets + 1) * 4);
+            hipLaunchKernelGGL(bucket_index_kernel, dim3(grid_for64(n + 1)), dim3(256), 0, ctx->stream,
+                               db->kmer.as<uint64_t>(), (uint32_t)n, db->shift, db->n_buckets,
+                               db->bucket_start.as<uint32_t>());
+            SY_HIP(hipGetLastError());
+            SY_HIP(hipStreamSynchronize(ctx->stream));   // d_in / gid_in are released on return
+        }
+        *out = db.release();
+    });
+}
+
+uint64_t sylph_db_n_genomes(const sylph_db* db) { return db ? db->n_genomes : 0; }
+uint64_t sylph_db_n_kmers(const sylph_db* db) { return db ? db->n_kmers : 0; }
+
+int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
+                     double min_number_kmers, uint32_t* contain_count, uint64_t* cov_off, uint32_t** out_covs) {
+    return guarded([&] {
+        SY_REQUIRE(db && contain_count && cov_off && out_covs, "null argument");
+        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+        SY_REQUIRE(n < (1ull << 32), "sample table larger than 2^32-1 entries");
+        sylph_ctx* ctx = db->ctx;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        const uint64_t G = db->n_genomes;
+        uint32_t n_hits = 0;
+        if (n && db->n_kmers) {
+            SY_REQUIRE(sample_kmers && sample_counts, "null sample");
+            const uint64_t* d_k = sample_kmers;
+            const uint32_t* d_c = sample_counts;
+            if (mem == SYLPH_MEM_HOST) {
+                db->q_kmers.reserve(n * 8);
+                db->q_counts.reserve(n * 4);
+                SY_HIP(hipMemcpyAsync(db->q_kmers.p, sample_kmers, n * 8, hipMemcpyHostToDevice, ctx->stream));
+                SY_HIP(hipMemcpyAsync(db->q_counts.p, sample_counts, n * 4, hipMemcpyHostToDevice, ctx->stream));
+                d_k = db->q_kmers.as<uint64_t>();
+                d_c = db->q_counts.as<uint32_t>();
+            }
+            uint64_t cap = std::max<uint64_t>(n * 2, 1u << 20);
+            uint32_t* d_cnt = db->counter.as<uint32_t>();
+            for (int attempt = 0; attempt < 2; attempt++) {
+                SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one sample");
+                db->hits.reserve(cap * 8);
+                SY_HIP(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+                {
+                    ScopedKernelTimer t(ctx, "probe");
+                    hipLaunchKernelGGL(probe_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k,
+                                       d_c, (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
+                                       db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->glen.as<uint32_t>(),
+                                       min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
+                    SY_HIP(hipGetLastError());
+                }
+                SY_HIP(hipMemcpyAsync(&n_hits, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+                SY_HIP(hipStreamSynchronize(ctx->stream));
+                if (n_hits <= cap) break;
+                SY_REQUIRE(attempt == 0, "hit buffer overflow persisted");
+                cap = n_hits;
+            }
+        }
+        db->cov_off.reserve((G + 1) * 8);
+        db->ccount.reserve(std::max<uint64_t>(1, G) * 4);
+        const uint64_t* d_sorted = nullptr;
+        if (n_hits) {
+            db->hits_sorted.reserve((size_t)n_hits * 8);
+            db->covs.reserve((size_t)n_hits * 4);
+            sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
+            d_sorted = db->hits_sorted.as<uint64_t>();
+            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
+                               db->covs.as<uint32_t>());
+        }
+        hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
+                           (uint32_t)G, db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
+        SY_HIP(hipGetLastError());
+        uint32_t* hcov = (uint32_t*)malloc(std::max<size_t>(1, n_hits) * 4);
+        if (!hcov) throw std::bad_alloc();
+        try {
+            SY_HIP(hipMemcpyAsync(cov_off, db->cov_off.p, (G + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (G) SY_HIP(hipMemcpyAsync(contain_count, db->ccount.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (n_hits) SY_HIP(hipMemcpyAsync(hcov, db->covs.p, (size_t)n_hits * 4, hipMemcpyDeviceToHost, ctx->stream));
+            SY_HIP(hipStreamSynchronize(ctx->stream));
+        } catch (...) { free(hcov); throw; }
+        *out_covs = hcov;
+    });
+}
+
+void sylph_db_destroy(sylph_db* db) {
+    if (!db) return;
+    {
+        std::lock_guard<std::mutex> lock(db->ctx->mu);
+        (void)hipStreamSynchronize(db->ctx->stream);
+    }
+    delete db;
+}
+
+}  // extern "C"

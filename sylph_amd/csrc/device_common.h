@@ -1,0 +1,81 @@
+// device_common.h — device-side building blocks shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sylph {
+
+// seeding.rs:4-15 mm_hash64 / avx2_seeding.rs:6-30 mm_hash256.  NB first step is ~(key + (key << 21)).
+__device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
+    key = ~(key + (key << 21));
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+// types.rs:50-59 BYTE_TO_SEQ for one byte, computed instead of looked up:
+// A/a=0 C/c=1 G/g=2 T/t/U/u=3; raw bytes 1,2,3 -> 1,2,3; everything else (N, IUPAC, gaps, ...) -> 0.
+__device__ __forceinline__ uint32_t byte_to_seq(uint32_t b) {
+    const uint32_t u = b & 0xDFu;
+    const uint32_t c = ((b >> 1) ^ (b >> 2)) & 3u;
+    const bool acgtu = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T') | (u == 'U');
+    return acgtu ? c : (b <= 3u ? b : 0u);
+}
+
+// 4 ASCII bytes -> 4 two-bit codes (one per byte lane).  Fast path valid when every byte is one of ACGTacgt:
+// code = ((b>>1)^(b>>2))&3; v_perm_b32 rebuilds the upper-case letter from the code and the comparison proves
+// the byte really was that letter.  `bad` accumulates non-zero if any byte needs the exact slow path.
+__device__ __forceinline__ uint32_t codes4_fast(uint32_t w, uint32_t& bad) {
+    const uint32_t c = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* 'T','G','C','A' */, c);
+    bad |= (w & 0xDFDFDFDFu) ^ expect;
+    return c;
+}
+__device__ __forceinline__ uint32_t codes4_exact(uint32_t w) {
+    return byte_to_seq(w & 0xFFu) | (byte_to_seq((w >> 8) & 0xFFu) << 8) | (byte_to_seq((w >> 16) & 0xFFu) << 16) |
+           (byte_to_seq(w >> 24) << 24);
+}
+
+// 4 byte-lane codes -> 8 packed bits.  Multiplying by a constant with four set bits moves the four 2-bit fields
+// into the top byte without overlaps (all partial products land on distinct bit pairs).
+__device__ __forceinline__ uint32_t fwd8(uint32_t c) { return (c * 0x40100401u) >> 24; }                   // c0<<6|c1<<4|c2<<2|c3
+__device__ __forceinline__ uint32_t rev8(uint32_t c) { return ((c ^ 0x03030303u) * 0x01041040u) >> 24; }   // ~c0|~c1<<2|~c2<<4|~c3<<6
+
+// 16 ASCII bases (memory order x,y,z,w) -> F: base j at bits 30-2j (big-endian), R: (3-base j) at bits 2j.
+__device__ __forceinline__ void pack16(uint4 v, uint32_t& F, uint32_t& R) {
+    uint32_t bad = 0;
+    uint32_t c0 = codes4_fast(v.x, bad), c1 = codes4_fast(v.y, bad), c2 = codes4_fast(v.z, bad), c3 = codes4_fast(v.w, bad);
+    if (bad) {   // rare: N / lower-case U / raw 1,2,3 / anything else
+        c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w);
+    }
+    F = (fwd8(c0) << 24) | (fwd8(c1) << 16) | (fwd8(c2) << 8) | fwd8(c3);
+    R = rev8(c0) | (rev8(c1) << 8) | (rev8(c2) << 16) | (rev8(c3) << 24);
+}
+
+// Number of k-mer start positions of a length-L sequence that the reference hashes.
+//   scalar  (seeding.rs:93,120):              L >= k ? L-k+1 : 0
+//   avx2    (avx2_seeding.rs:37-44,95):       4*((L-k+1)/4), nothing if L < min_len (k+1 reads, 2k contigs :160)
+__device__ __host__ __forceinline__ uint64_t n_hashed_kmers(uint64_t L, uint32_t k, int avx2_compat, int positions) {
+    if (L < k) return 0;
+    if (!avx2_compat) return L - k + 1;
+    const uint64_t min_len = positions ? 2ull * k : (uint64_t)k + 1;
+    if (L < min_len) return 0;
+    return ((L - k + 1) / 4) * 4;
+}
+
+// index of the record containing flat position p: largest r with off[r] <= p (off has n+1 entries, p < off[n]).
+__device__ __forceinline__ uint64_t find_record(const uint64_t* __restrict__ off, uint64_t n, uint64_t p) {
+    uint64_t lo = 0, hi = n;   // invariant: off[lo] <= p < off[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+}  // namespace sylph

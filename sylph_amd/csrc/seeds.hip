@@ -1,0 +1,177 @@
+// seeds.hip — FracMinHash seeding on gfx950: canonical k-mer -> mm_hash64 -> keep if hash < u64::MAX / c.
+//
+// Replaces the per-sequence loops of seeding.rs:86-146 (fmh_seeds) / avx2_seeding.rs:33-148
+// (extract_markers_avx2) for a whole batch of records at once.  Design:
+//   * the batch is ONE flat ASCII stream in HBM (records concatenated, no separators); a workgroup of 256
+//     threads owns a tile of 16384 consecutive k-mer start positions and grid-strides over tiles;
+//   * load phase: 16 B/lane coalesced global loads (1 KiB per wave instruction), ASCII -> 2-bit codes with the
+//     exact BYTE_TO_SEQ semantics (types.rs:50-59), packed 16 bases per dword into two LDS streams: F (forward,
+//     first base in the top bits) and R (complement, first base in the bottom bits);
+//   * hash phase: each lane reads 6+6 dwords from LDS and produces 64 k-mers; the forward k-mer and its reverse
+//     complement are funnel-shift extracts (v_alignbit) of the two streams at compile-time shifts, so there is
+//     no loop-carried rolling state and no per-base LUT access;
+//   * k-mers that straddle a record boundary are hashed too and rejected later (annotate kernel) — rejecting
+//     1 in c survivors is cheaper than testing every position;
+//   * survivors (hash, position) are staged in LDS and flushed with one global atomic per ~1000 survivors.
+// Pure integer work, no MFMA.  Algorithmic HBM traffic: 1 B per base in, 12 B per survivor out.
+#include "common.h"
+#include "device_common.h"
+
+namespace sylph {
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int WPT = 4;                        // packed dwords (16 bases each) per lane
+constexpr int TILE_WORDS = TPB * WPT;         // 1024
+constexpr int TILE_BASES = TILE_WORDS * 16;   // 16384
+constexpr int HALO_WORDS = 2;                 // k-1 <= 31 bases beyond the tile
+constexpr int STAGE_CAP = 1024;               // LDS survivor staging (12 KiB)
+constexpr int FLUSH_AT = 512;
+
+template <int S>
+__device__ __forceinline__ uint64_t shr96(uint32_t hi, uint32_t mid, uint32_t lo) {
+    // low 64 bits of ((hi:mid:lo) >> S), S compile-time in [0, 64)
+    uint32_t l, h;
+    if constexpr (S == 0) { l = lo; h = mid; }
+    else if constexpr (S < 32) { l = __builtin_amdgcn_alignbit(mid, lo, S); h = __builtin_amdgcn_alignbit(hi, mid, S); }
+    else if constexpr (S == 32) { l = mid; h = hi; }
+    else { l = __builtin_amdgcn_alignbit(hi, mid, S - 32); h = hi >> (S - 32); }
+    return ((uint64_t)h << 32) | l;
+}
+
+struct Stage {
+    uint64_t hash[STAGE_CAP];
+    uint32_t pos[STAGE_CAP];
+};
+
+template <int K>
+struct KmerConsts {
+    static constexpr uint64_t MASK = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
+};
+
+// One k-mer at in-word offset O (base index within the 16-base dword), from three consecutive dwords of each stream.
+template <int K, int O>
+__device__ __forceinline__ void kmer_at(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1, uint32_t r2,
+                                        uint64_t thr, uint32_t pos, Stage& st, uint32_t* s_cnt, uint64_t* out_hash,
+                                        uint32_t* out_pos, uint32_t out_cap, uint32_t* out_count) {
+    constexpr int SF = 96 - 2 * O - 2 * K;                 // forward: top-justified big-endian stream
+    const uint64_t f = shr96<SF>(f0, f1, f2) & KmerConsts<K>::MASK;
+    const uint64_t r = shr96<2 * O>(r2, r1, r0) & KmerConsts<K>::MASK;   // reverse complement: little-endian stream
+    const uint64_t canon = f < r ? f : r;                  // seeding.rs:134-139
+    const uint64_t h = mm_hash64(canon);
+    if (h < thr) {                                         // seeding.rs:142 (strict)
+        const uint32_t slot = atomicAdd(s_cnt, 1u);
+        if (slot < STAGE_CAP) {
+            st.hash[slot] = h;
+            st.pos[slot] = pos;
+        } else {                                           // staging full (pathological repeats): straight to HBM
+            const uint32_t g = atomicAdd(out_count, 1u);
+            if (g < out_cap) { out_hash[g] = h; out_pos[g] = pos; }
+        }
+    }
+}
+
+template <int K, int O>
+struct Unroll16 {
+    static __device__ __forceinline__ void run(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1,
+                                               uint32_t r2, uint64_t thr, uint32_t pos0, Stage& st, uint32_t* s_cnt,
+                                               uint64_t* out_hash, uint32_t* out_pos, uint32_t out_cap,
+                                               uint32_t* out_count) {
+        kmer_at<K, O>(f0, f1, f2, r0, r1, r2, thr, pos0 + O, st, s_cnt, out_hash, out_pos, out_cap, out_count);
+        if constexpr (O + 1 < 16)
+            Unroll16<K, O + 1>::run(f0, f1, f2, r0, r1, r2, thr, pos0, st, s_cnt, out_hash, out_pos, out_cap, out_count);
+    }
+};
+
+// K1.  n_bases < 2^32.  `bases` 16-byte aligned; chunks that start at or beyond n_bases are never read.
+template <int K>
+__global__ __launch_bounds__(TPB) void seeds_kernel(const uint8_t* __restrict__ bases, uint32_t n_bases, uint64_t thr,
+                                                    uint32_t n_tiles, uint64_t* __restrict__ out_hash,
+                                                    uint32_t* __restrict__ out_pos, uint32_t out_cap,
+                                                    uint32_t* __restrict__ out_count) {
+    __shared__ __attribute__((aligned(16))) uint32_t sF[TILE_WORDS + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t sR[TILE_WORDS + 8];
+    __shared__ Stage st;
+    __shared__ uint32_t s_cnt, s_base;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t tile_base = (uint64_t)tile * TILE_BASES;
+        // ---- load + pack ------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j <= WPT; j++) {
+            const uint32_t ci = tid + j * TPB;
+            if (j == WPT && tid >= HALO_WORDS) break;
+            const uint64_t b0 = tile_base + (uint64_t)ci * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b0 < n_bases) v = *reinterpret_cast<const uint4*>(bases + b0);
+            uint32_t F, R;
+            pack16(v, F, R);
+            sF[ci] = F;
+            sR[ci] = R;
+        }
+        __syncthreads();
+        // ---- hash ---------------------------------------------------------------------------------------
+        {
+            const uint32_t w0 = tid * WPT;
+            const uint4 fa = *reinterpret_cast<const uint4*>(&sF[w0]);
+            const uint2 fb = *reinterpret_cast<const uint2*>(&sF[w0 + 4]);
+            const uint4 ra = *reinterpret_cast<const uint4*>(&sR[w0]);
+            const uint2 rb = *reinterpret_cast<const uint2*>(&sR[w0 + 4]);
+            const uint32_t fw[6] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y};
+            const uint32_t rw[6] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y};
+            const uint32_t p0 = (uint32_t)tile_base + w0 * 16;
+#pragma unroll
+            for (int j = 0; j < WPT; j++) {
+                // positions at or beyond n_bases can never be valid; skip whole dwords of them (wave-uniform
+                // except in the single boundary wave)
+                if ((uint64_t)p0 + (uint64_t)j * 16 < n_bases)
+                    Unroll16<K, 0>::run(fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2], thr, p0 + j * 16, st,
+                                        &s_cnt, out_hash, out_pos, out_cap, out_count);
+            }
+        }
+        __syncthreads();
+        // ---- flush staged survivors ----------------------------------------------------------------------
+        const bool last = (tile + gridDim.x >= n_tiles);
+        const uint32_t n = min(s_cnt, (uint32_t)STAGE_CAP);
+        if (n >= FLUSH_AT || (last && n > 0)) {
+            if (tid == 0) s_base = atomicAdd(out_count, n);
+            __syncthreads();
+            const uint32_t base = s_base;
+            for (uint32_t i = tid; i < n; i += TPB) {
+                const uint32_t g = base + i;
+                if (g < out_cap) { out_hash[g] = st.hash[i]; out_pos[g] = st.pos[i]; }
+            }
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+        }
+        // (the __syncthreads after the next tile's pack phase orders the s_cnt reset before new survivors)
+    }
+}
+
+}  // namespace
+
+// Launch K1 on ctx->stream.  d_count must be zeroed by the caller.  Returns nothing; caller reads *d_count.
+void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint64_t* d_out_hash,
+                  uint32_t* d_out_pos, uint32_t out_cap, uint32_t* d_count) {
+    if (n_bases == 0) return;
+    const uint64_t thr = UINT64_MAX / (uint64_t)c;
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)n_bases + TILE_BASES - 1) / TILE_BASES);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);
+    ScopedKernelTimer t(ctx, "seeds");
+    if (k == 31)
+        hipLaunchKernelGGL(seeds_kernel<31>, dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles,
+                           d_out_hash, d_out_pos, out_cap, d_count);
+    else if (k == 21)
+        hipLaunchKernelGGL(seeds_kernel<21>, dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles,
+                           d_out_hash, d_out_pos, out_cap, d_count);
+    else
+        throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
+    SY_HIP(hipGetLastError());
+}
+
+}  // namespace sylph

@@ -1,0 +1,616 @@
+// sketch.hip — read-sketch sessions and genome sketches on gfx950.
+//
+//   push():   K1 seeds (seeds.hip) -> sort survivors by flat position -> K2 annotate (record lookup, boundary /
+//             AVX2-tail validation, locality markers) -> append to the session's occurrence arrays in file order
+//   finish(): stable radix sort of occurrences by hash -> K3 replay of dup_removal_lsh_full_exact
+//             (sketch.rs:690-731) as data-parallel segment kernels -> (k-mer, count) table in ascending k-mer order
+//
+// Replay formulation.  For one k-mer, let its occurrences in file order be i = 0..n-1, each with
+// an optional marker pair (m0_i, m1_i) (pair_kmer_single sketch.rs:625 / pair_kmer :659).  Every occurrence that
+// reaches the marker test inserts both of its markers, whether it is then counted or dropped (:709-722), so
+//     dropped_i  <=>  has_marker_i  AND  i is not the first processed occurrence (count > 0, :711,:718)
+//                     AND ( m0_i == m1_i  OR  {m0_i, m1_i} meets {m0_j, m1_j} for some processed j < i with a marker )
+// which needs no sequential state.  The single-end cut-off (`count < 4`, :706,:937) only makes a suffix of the
+// occurrences unconditional, handled by one short walk per k-mer.  Mate-2 occurrences whose hash also occurs in
+// mate 1 of the same pair are removed first (sketch.rs:852).
+#include <algorithm>
+#include <unordered_map>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace sylph {
+
+void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint64_t* d_out_hash,
+                  uint32_t* d_out_pos, uint32_t out_cap, uint32_t* d_count);
+
+namespace {
+
+constexpr uint64_t RID_MARKER_BIT = 1ull << 63;   // rid: bit63 = has marker, low bits = global record index
+constexpr uint64_t RID_MASK = RID_MARKER_BIT - 1;
+constexpr uint64_t INVALID_HASH = ~0ull;
+
+// ---- K2: annotate survivors of one batch (already sorted by flat position) ---------------------------------
+// Validates that the k-mer lies inside one record and among the k-mers the reference hashes, finds the record,
+// and computes the dedup markers.  Invalid survivors get hash = ~0 (sorts last, dropped in finish()).
+__global__ __launch_bounds__(256) void annotate_reads_kernel(
+    const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
+    const uint64_t* __restrict__ hash, uint32_t n, uint32_t k, int avx2_compat, int paired, int want_markers,
+    uint64_t rec_base, uint64_t* __restrict__ o_hash, uint64_t* __restrict__ o_rid, uint64_t* __restrict__ o_m0,
+    uint64_t* __restrict__ o_m1, unsigned long long* __restrict__ n_valid) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t p = pos[i];
+    uint64_t h = hash[i], rid = 0, m0 = 0, m1 = 0;
+    const uint64_t total = off[n_rec];
+    bool valid = false;
+    if (p < total) {
+        const uint64_t r = find_record(off, n_rec, p);
+        const uint64_t start = off[r], L = off[r + 1] - start;
+        valid = (p - start) < n_hashed_kmers(L, k, avx2_compat, 0);
+        if (valid) {
+            rid = rec_base + r;
+            if (want_markers) {
+                if (!paired) {
+                    // pair_kmer_single, sketch.rs:625-656; caller passes None above 400 bp (sketch.rs:922-927)
+                    if (L >= 66 && L <= 400) {
+                        const uint8_t* s = bases + start;
+                        const uint64_t half = L / 2;
+                        uint32_t f = 0, g = 0, rr = 0, t = 0;
+                        for (int j = 0; j < 16; j++) {
+                            f = (f << 2) | byte_to_seq(s[2 * j]);
+                            rr = (rr << 2) | byte_to_seq(s[2 * j + half]);
+                            g = (g << 2) | byte_to_seq(s[1 + 2 * j]);
+                            t = (t << 2) | byte_to_seq(s[1 + 2 * j + half]);
+                        }
+                        m0 = (uint64_t)f | ((uint64_t)rr << 32);
+                        m1 = (uint64_t)g | ((uint64_t)t << 32);
+                        rid |= RID_MARKER_BIT;
+                    }
+                } else {
+                    // pair_kmer, sketch.rs:659-688: both mates >= 33 bp
+                    const uint64_t r1 = r & ~1ull;
+                    const uint64_t s1 = off[r1], s2 = off[r1 + 1], e2 = off[r1 + 2];
+                    if (s2 - s1 >= 33 && e2 - s2 >= 33) {
+                        const uint8_t* a = bases + s1;
+                        const uint8_t* b = bases + s2;
+                        uint32_t f = 0, g = 0, rr = 0, t = 0;
+                        for (int j = 0; j < 16; j++) {
+                            f = (f << 2) | byte_to_seq(a[2 * j]);
+                            rr = (rr << 2) | byte_to_seq(b[2 * j]);
+                            g = (g << 2) | byte_to_seq(a[1 + 2 * j]);
+                            t = (t << 2) | byte_to_seq(b[1 + 2 * j]);
+                        }
+                        m0 = (uint64_t)f | ((uint64_t)rr << 32);
+                        m1 = (uint64_t)g | ((uint64_t)t << 32);
+                        rid |= RID_MARKER_BIT;
+                    }
+                }
+            }
+        }
+    }
+    if (!valid) h = INVALID_HASH;
+    o_hash[i] = h;
+    o_rid[i] = rid;
+    o_m0[i] = m0;
+    o_m1[i] = m1;
+    if (valid) atomicAdd(n_valid, 1ull);   // wave-aggregated by the compiler
+}
+
+// Genome flavour: (contig, end position, hash), validated with the positions-variant rules
+// (avx2_seeding.rs:160: nothing for contigs shorter than 2k).
+__global__ __launch_bounds__(256) void annotate_contigs_kernel(const uint64_t* __restrict__ off, uint64_t n_contigs,
+                                                               const uint32_t* __restrict__ pos,
+                                                               const uint64_t* __restrict__ hash, uint32_t n, uint32_t k,
+                                                               int avx2_compat, uint32_t* __restrict__ o_contig,
+                                                               uint64_t* __restrict__ o_pos, uint64_t* __restrict__ o_hash) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t p = pos[i];
+    uint64_t h = INVALID_HASH, endpos = 0;
+    uint32_t contig = 0;
+    if (p < off[n_contigs]) {
+        const uint64_t r = find_record(off, n_contigs, p);
+        const uint64_t start = off[r], L = off[r + 1] - start;
+        if ((p - start) < n_hashed_kmers(L, k, avx2_compat, 1)) {
+            h = hash[i];
+            contig = (uint32_t)r;
+            endpos = p - start + k - 1;   // index of the k-mer's last base (seeding.rs:205)
+        }
+    }
+    o_contig[i] = contig;
+    o_pos[i] = endpos;
+    o_hash[i] = h;
+}
+
+__global__ void iota_kernel(uint32_t* v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+// gather payload into hash-sorted order and mark segment heads
+__global__ __launch_bounds__(256) void gather_heads_kernel(const uint64_t* __restrict__ hs, const uint32_t* __restrict__ perm,
+                                                           const uint64_t* __restrict__ rid, const uint64_t* __restrict__ m0,
+                                                           const uint64_t* __restrict__ m1, uint32_t n,
+                                                           uint64_t* __restrict__ rid_s, uint64_t* __restrict__ m0_s,
+                                                           uint64_t* __restrict__ m1_s, uint32_t* __restrict__ head,
+                                                           uint32_t* __restrict__ headidx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = perm[i];
+    rid_s[i] = rid[p];
+    m0_s[i] = m0[p];
+    m1_s[i] = m1[p];
+    const bool hd = (i == 0) || (hs[i] != hs[i - 1]);
+    head[i] = hd ? 1u : 0u;
+    headidx[i] = hd ? i : 0u;
+}
+
+// K3a: mate-2 skip rule (sketch.rs:852): a mate-2 occurrence is not processed at all if the same hash was
+// produced by mate 1 of the same pair.  Occurrences are in file order inside a segment, so the pair's mate-1
+// occurrences sit immediately before its mate-2 occurrences.
+__global__ __launch_bounds__(256) void skip_kernel(const uint64_t* __restrict__ rid_s, const uint32_t* __restrict__ seg_start,
+                                                   uint32_t n, uint8_t* __restrict__ skip) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t rec = rid_s[i] & RID_MASK;
+    uint8_t s = 0;
+    if (rec & 1) {
+        const uint32_t s0 = seg_start[i];
+        for (uint32_t j = i; j > s0;) {
+            j--;
+            const uint64_t rj = rid_s[j] & RID_MASK;
+            if ((rj >> 1) != (rec >> 1)) break;
+            if ((rj & 1) == 0) { s = 1; break; }
+        }
+    }
+    skip[i] = s;
+}
+
+// K3b: dropped_i as defined in the file header.  flags[i]: bit0 = skip, bit1 = would-be-dropped.
+__global__ __launch_bounds__(256) void dup_flags_kernel(const uint64_t* __restrict__ rid_s, const uint64_t* __restrict__ m0_s,
+                                                        const uint64_t* __restrict__ m1_s,
+                                                        const uint32_t* __restrict__ seg_start,
+                                                        const uint8_t* __restrict__ skip, uint32_t n,
+                                                        uint8_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t fl = skip ? skip[i] : 0;
+    if (!fl && (rid_s[i] & RID_MARKER_BIT)) {
+        const uint64_t a = m0_s[i], b = m1_s[i];
+        bool any_prev = false, hit = false;
+        for (uint32_t j = seg_start[i]; j < i; j++) {
+            if (skip && skip[j]) continue;
+            any_prev = true;
+            if (rid_s[j] & RID_MARKER_BIT) {
+                const uint64_t x = m0_s[j], y = m1_s[j];
+                if (x == a || y == a || x == b || y == b) { hit = true; break; }
+            }
+        }
+        if (any_prev && (hit || a == b)) fl |= 2;
+    }
+    flags[i] = fl;
+}
+
+// K3c: one lane per k-mer walks its occurrences once (sketch.rs:701-730 count / cut-off logic).
+__global__ __launch_bounds__(256) void count_kernel(const uint64_t* __restrict__ hs, const uint32_t* __restrict__ head,
+                                                    const uint32_t* __restrict__ seg_id, const uint8_t* __restrict__ flags,
+                                                    uint32_t n, int no_dedup, uint32_t cutoff /*0 = none*/,
+                                                    uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
+                                                    unsigned long long* __restrict__ removed_total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const uint64_t h = hs[i];
+    uint32_t c = 0, removed = 0;
+    for (uint32_t j = i; j < n && hs[j] == h; j++) {
+        const uint8_t fl = flags[j];
+        if (fl & 1) continue;                                     // sketch.rs:852
+        if (no_dedup || (cutoff && c >= cutoff)) { c++; continue; }   // :706
+        if (fl & 2) removed++; else c++;                          // :723-730
+    }
+    out_k[seg_id[i]] = h;
+    out_c[seg_id[i]] = c;
+    if (removed) atomicAdd(removed_total, (unsigned long long)removed);
+}
+
+}  // namespace
+}  // namespace sylph
+
+using namespace sylph;
+
+struct sylph_sketch {
+    sylph_ctx* ctx;
+    uint32_t c, k;
+    int paired, no_dedup, avx2_compat;
+    bool finished = false;
+    uint64_t rec_base = 0;         // records pushed so far
+    uint64_t n_occ = 0;            // occurrences (valid + invalid) appended so far
+    DevBuf hash, rid, m0, m1;      // occurrence arrays, file order
+    DevBuf batch_bases, batch_off; // H2D staging for SYLPH_MEM_HOST pushes
+    DevBuf out_k, out_c;           // final table
+    uint64_t n_out = 0, dup_removed = 0;
+    DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
+};
+
+namespace sylph {
+
+static uint32_t grid_for(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
+
+// Runs K1 with capacity retry; returns survivors sorted by flat position in (ctx->scratch[2] = pos, [3] = hash).
+static uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uint32_t c, uint32_t k,
+                                    uint32_t* d_count) {
+    SY_REQUIRE(n_bases < (1ull << 32), "a batch may hold at most 2^32-1 bases (got %llu)", (unsigned long long)n_bases);
+    if (n_bases == 0) return 0;
+    uint64_t cap = n_bases / c + n_bases / (4ull * c) + 65536;
+    if (cap > n_bases) cap = n_bases;
+    uint32_t n = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ctx->scratch[0].reserve(cap * 8);   // hash (unsorted)
+        ctx->scratch[1].reserve(cap * 4);   // pos (unsorted)
+        SY_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+        launch_seeds(ctx, d_bases, (uint32_t)n_bases, c, k, ctx->scratch[0].as<uint64_t>(), ctx->scratch[1].as<uint32_t>(),
+                     (uint32_t)cap, d_count);
+        SY_HIP(hipMemcpyAsync(&n, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        if (n <= cap) break;
+        cap = n;                            // the counter kept counting: exact size for the retry
+        SY_REQUIRE(attempt == 0, "seed buffer overflow persisted");
+    }
+    if (n == 0) return 0;
+    ctx->scratch[2].reserve((size_t)n * 4);
+    ctx->scratch[3].reserve((size_t)n * 8);
+    sort_pairs_u32_u64(ctx, ctx->scratch[1].as<uint32_t>(), ctx->scratch[2].as<uint32_t>(), ctx->scratch[0].as<uint64_t>(),
+                       ctx->scratch[3].as<uint64_t>(), n, 0, std::max(1, bit_length(n_bases)));
+    return n;
+}
+
+static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, int mem) {
+    sylph_ctx* ctx = sk->ctx;
+    SY_REQUIRE(!sk->finished, "sylph_sketch_push after finish");
+    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+    SY_REQUIRE(!sk->paired || (n_records % 2 == 0), "paired batches must hold an even number of records");
+    if (n_records == 0) return;
+    SY_REQUIRE(bases && rec_off, "null input");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    const uint8_t* d_bases;
+    const uint64_t* d_off;
+    uint64_t n_bases;
+    if (mem == SYLPH_MEM_HOST) {
+        SY_REQUIRE(rec_off[0] == 0, "rec_off[0] must be 0");
+        n_bases = rec_off[n_records];
+        sk->batch_bases.reserve(n_bases + 64);
+        sk->batch_off.reserve((n_records + 1) * 8);
+        if (n_bases) SY_HIP(hipMemcpyAsync(sk->batch_bases.p, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
+        SY_HIP(hipMemcpyAsync(sk->batch_off.p, rec_off, (n_records + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_bases = sk->batch_bases.as<uint8_t>();
+        d_off = sk->batch_off.as<uint64_t>();
+    } else {
+        SY_REQUIRE(((uintptr_t)bases & 15) == 0, "device bases pointer must be 16-byte aligned");
+        SY_HIP(hipMemcpyAsync(&n_bases, rec_off + n_records, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        d_bases = bases;
+        d_off = rec_off;
+    }
+    uint32_t* d_count = sk->counters.as<uint32_t>();
+    const uint32_t n = seeds_sorted_by_pos(ctx, d_bases, n_bases, sk->c, sk->k, d_count);
+    if (n) {
+        const uint64_t need = sk->n_occ + n;
+        const size_t keep = sk->n_occ * 8;
+        sk->hash.grow_keep(need * 8, keep, ctx->stream);
+        sk->rid.grow_keep(need * 8, keep, ctx->stream);
+        sk->m0.grow_keep(need * 8, keep, ctx->stream);
+        sk->m1.grow_keep(need * 8, keep, ctx->stream);
+        ScopedKernelTimer t(ctx, "annotate");
+        hipLaunchKernelGGL(annotate_reads_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_bases, d_off, n_records,
+                           ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, sk->k, sk->avx2_compat,
+                           sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, sk->hash.as<uint64_t>() + sk->n_occ,
+                           sk->rid.as<uint64_t>() + sk->n_occ, sk->m0.as<uint64_t>() + sk->n_occ,
+                           sk->m1.as<uint64_t>() + sk->n_occ,
+                           reinterpret_cast<unsigned long long*>(sk->counters.as<uint8_t>() + 8));
+        SY_HIP(hipGetLastError());
+        sk->n_occ = need;
+    }
+    sk->rec_base += n_records;
+    // host staging buffers are reused by the next push: make sure this batch is consumed
+    if (mem == SYLPH_MEM_HOST) SY_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+static void sketch_finish_impl(sylph_sketch* sk) {
+    if (sk->finished) return;
+    sylph_ctx* ctx = sk->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    unsigned long long n_valid = 0;
+    SY_HIP(hipMemcpyAsync(&n_valid, sk->counters.as<uint8_t>() + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    SY_REQUIRE(sk->n_occ < (1ull << 32), "more than 2^32-1 seed occurrences in one sample");
+    const uint32_t n_all = (uint32_t)sk->n_occ, nv = (uint32_t)n_valid;
+    sk->n_out = 0;
+    sk->dup_removed = 0;
+    if (nv) {
+        // stable sort by hash; invalid occurrences carry ~0 and end up behind the nv valid ones
+        DevBuf &b_idx = ctx->scratch[0], &b_hs = ctx->scratch[1], &b_perm = ctx->scratch[2];
+        b_idx.reserve((size_t)n_all * 4);
+        b_hs.reserve((size_t)n_all * 8);
+        b_perm.reserve((size_t)n_all * 4);
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_all)), dim3(256), 0, ctx->stream, b_idx.as<uint32_t>(), n_all);
+        sort_pairs_u64_u32(ctx, sk->hash.as<uint64_t>(), b_hs.as<uint64_t>(), b_idx.as<uint32_t>(), b_perm.as<uint32_t>(),
+                           n_all, 0, 64);
+        DevBuf &b_rid = ctx->scratch[3], &b_m0 = ctx->scratch[4], &b_m1 = ctx->scratch[5], &b_u32 = ctx->scratch[6],
+               &b_fl = ctx->scratch[7];
+        b_rid.reserve((size_t)nv * 8);
+        b_m0.reserve((size_t)nv * 8);
+        b_m1.reserve((size_t)nv * 8);
+        b_u32.reserve((size_t)nv * 4 * 4);   // head | headidx | seg_start | seg_id
+        b_fl.reserve((size_t)nv * 2);        // skip | flags
+        uint32_t* head = b_u32.as<uint32_t>();
+        uint32_t* headidx = head + nv;
+        uint32_t* seg_start = headidx + nv;
+        uint32_t* seg_id = seg_start + nv;
+        uint8_t* skip = b_fl.as<uint8_t>();
+        uint8_t* flags = skip + nv;
+        const uint64_t* hs = b_hs.as<uint64_t>();
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            hipLaunchKernelGGL(gather_heads_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, hs, b_perm.as<uint32_t>(),
+                               sk->rid.as<uint64_t>(), sk->m0.as<uint64_t>(), sk->m1.as<uint64_t>(), nv,
+                               b_rid.as<uint64_t>(), b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), head, headidx);
+        }
+        inclusive_max_u32(ctx, headidx, seg_start, nv);
+        exclusive_sum_u32(ctx, head, seg_id, nv);
+        uint32_t last_id = 0, last_head = 0;
+        SY_HIP(hipMemcpyAsync(&last_id, seg_id + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync(&last_head, head + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        const uint32_t n_seg = last_id + last_head;
+        sk->out_k.reserve((size_t)n_seg * 8);
+        sk->out_c.reserve((size_t)n_seg * 4);
+        unsigned long long* d_removed = reinterpret_cast<unsigned long long*>(sk->counters.as<uint8_t>() + 16);
+        SY_HIP(hipMemsetAsync(d_removed, 0, 8, ctx->stream));
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            const uint8_t* skip_arg = nullptr;
+            if (sk->paired) {
+                hipLaunchKernelGGL(skip_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
+                                   seg_start, nv, skip);
+                skip_arg = skip;
+            }
+            if (!sk->no_dedup || sk->paired)
+                hipLaunchKernelGGL(dup_flags_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
+                                   b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), seg_start, skip_arg, nv, flags);
+            else
+                SY_HIP(hipMemsetAsync(flags, 0, nv, ctx->stream));
+            hipLaunchKernelGGL(count_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, hs, head, seg_id, flags, nv,
+                               sk->no_dedup, sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */,
+                               sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>(), d_removed);
+            SY_HIP(hipGetLastError());
+        }
+        unsigned long long removed = 0;
+        SY_HIP(hipMemcpyAsync(&removed, d_removed, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        sk->n_out = n_seg;
+        sk->dup_removed = removed;
+    }
+    sk->finished = true;
+}
+
+// ---- genome side -------------------------------------------------------------------------------------------
+
+struct ContigSeeds { std::vector<uint32_t> contig; std::vector<uint64_t> pos, hash; };
+
+static void seeds_positions_impl(sylph_ctx* ctx, const uint8_t* bases, const uint64_t* contig_off, uint64_t n_contigs,
+                                 uint32_t c, uint32_t k, int seed_mode, ContigSeeds& out) {
+    SY_REQUIRE(c >= 1, "c must be >= 1");
+    SY_REQUIRE(seed_mode == SYLPH_SEED_SCALAR || seed_mode == SYLPH_SEED_AVX2_COMPAT, "bad seed_mode %d", seed_mode);
+    SY_REQUIRE(k == 21 || k == 31, "k must be 21 or 31 (avx2_seeding.rs:46-52)");
+    if (n_contigs == 0) return;
+    SY_REQUIRE(bases && contig_off && contig_off[0] == 0, "bad contig offsets");
+    SY_REQUIRE(n_contigs < (1ull << 32), "too many contigs");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    const uint64_t n_bases = contig_off[n_contigs];
+    SY_REQUIRE(n_bases < (1ull << 32), "genome larger than 2^32-1 bases: split by contig");
+    DevBuf d_bases, d_off;
+    d_bases.reserve(n_bases + 64);
+    d_off.reserve((n_contigs + 1) * 8);
+    if (n_bases) SY_HIP(hipMemcpyAsync(d_bases.p, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
+    SY_HIP(hipMemcpyAsync(d_off.p, contig_off, (n_contigs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->counters.reserve(64);
+    const uint32_t n = seeds_sorted_by_pos(ctx, d_bases.as<uint8_t>(), n_bases, c, k, ctx->counters.as<uint32_t>());
+    if (!n) return;
+    DevBuf o_contig, o_pos, o_hash;
+    o_contig.reserve((size_t)n * 4);
+    o_pos.reserve((size_t)n * 8);
+    o_hash.reserve((size_t)n * 8);
+    {
+        ScopedKernelTimer t(ctx, "annotate");
+        hipLaunchKernelGGL(annotate_contigs_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_off.as<uint64_t>(),
+                           n_contigs, ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, k,
+                           seed_mode == SYLPH_SEED_AVX2_COMPAT, o_contig.as<uint32_t>(), o_pos.as<uint64_t>(),
+                           o_hash.as<uint64_t>());
+        SY_HIP(hipGetLastError());
+    }
+    std::vector<uint32_t> hc(n);
+    std::vector<uint64_t> hp(n), hh(n);
+    SY_HIP(hipMemcpyAsync(hc.data(), o_contig.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipMemcpyAsync(hp.data(), o_pos.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipMemcpyAsync(hh.data(), o_hash.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    out.contig.reserve(n); out.pos.reserve(n); out.hash.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (hh[i] == INVALID_HASH) continue;   // straddled a contig boundary / AVX2 tail / short contig
+        out.contig.push_back(hc[i]); out.pos.push_back(hp[i]); out.hash.push_back(hh[i]);
+    }
+}
+
+template <class T>
+static T* to_malloc(const std::vector<T>& v) {
+    T* p = (T*)malloc(std::max<size_t>(1, v.size()) * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+}  // namespace sylph
+
+extern "C" {
+
+int sylph_sketch_begin(sylph_ctx* ctx, uint32_t c, uint32_t k, int reads_mode, int no_dedup, int seed_mode,
+                       sylph_sketch** out) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && out, "null argument");
+        SY_REQUIRE(c >= 1, "c must be >= 1");
+        SY_REQUIRE(k == 21 || k == 31, "k must be 21 or 31 (avx2_seeding.rs:46-52)");
+        SY_REQUIRE(reads_mode == SYLPH_READS_SINGLE || reads_mode == SYLPH_READS_PAIRED, "bad reads_mode %d", reads_mode);
+        SY_REQUIRE(seed_mode == SYLPH_SEED_SCALAR || seed_mode == SYLPH_SEED_AVX2_COMPAT, "bad seed_mode %d", seed_mode);
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        sylph_sketch* sk = new sylph_sketch();
+        sk->ctx = ctx; sk->c = c; sk->k = k;
+        sk->paired = reads_mode == SYLPH_READS_PAIRED;
+        sk->no_dedup = no_dedup != 0;
+        sk->avx2_compat = seed_mode == SYLPH_SEED_AVX2_COMPAT;
+        try {
+            sk->counters.reserve(64);
+            SY_HIP(hipMemsetAsync(sk->counters.p, 0, 64, ctx->stream));
+        } catch (...) { delete sk; throw; }
+        *out = sk;
+    });
+}
+
+int sylph_sketch_push(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, int mem) {
+    return guarded([&] {
+        SY_REQUIRE(sk, "null session");
+        sketch_push_impl(sk, bases, rec_off, n_records, mem);
+    });
+}
+
+int sylph_sketch_finish_device(sylph_sketch* sk, const uint64_t** dev_kmers, const uint32_t** dev_counts, uint64_t* out_n,
+                               uint64_t* out_dup_removed) {
+    return guarded([&] {
+        SY_REQUIRE(sk && dev_kmers && dev_counts && out_n, "null argument");
+        sketch_finish_impl(sk);
+        *dev_kmers = sk->out_k.as<uint64_t>();
+        *dev_counts = sk->out_c.as<uint32_t>();
+        *out_n = sk->n_out;
+        if (out_dup_removed) *out_dup_removed = sk->dup_removed;
+    });
+}
+
+int sylph_sketch_finish(sylph_sketch* sk, uint64_t** out_kmers, uint32_t** out_counts, uint64_t* out_n,
+                        uint64_t* out_dup_removed) {
+    return guarded([&] {
+        SY_REQUIRE(sk && out_kmers && out_counts && out_n, "null argument");
+        sketch_finish_impl(sk);
+        const size_t n = sk->n_out;
+        uint64_t* hk = (uint64_t*)malloc(std::max<size_t>(1, n) * 8);
+        uint32_t* hc = (uint32_t*)malloc(std::max<size_t>(1, n) * 4);
+        if (!hk || !hc) { free(hk); free(hc); throw std::bad_alloc(); }
+        try {
+            if (n) {
+                std::lock_guard<std::mutex> lock(sk->ctx->mu);
+                DeviceGuard dg(sk->ctx->device);
+                SY_HIP(hipMemcpyAsync(hk, sk->out_k.p, n * 8, hipMemcpyDeviceToHost, sk->ctx->stream));
+                SY_HIP(hipMemcpyAsync(hc, sk->out_c.p, n * 4, hipMemcpyDeviceToHost, sk->ctx->stream));
+                SY_HIP(hipStreamSynchronize(sk->ctx->stream));
+            }
+        } catch (...) { free(hk); free(hc); throw; }
+        *out_kmers = hk; *out_counts = hc; *out_n = n;
+        if (out_dup_removed) *out_dup_removed = sk->dup_removed;
+    });
+}
+
+void sylph_sketch_destroy(sylph_sketch* sk) {
+    if (!sk) return;
+    {
+        std::lock_guard<std::mutex> lock(sk->ctx->mu);
+        (void)hipStreamSynchronize(sk->ctx->stream);
+    }
+    delete sk;
+}
+
+int sylph_seeds_positions(sylph_ctx* ctx, const uint8_t* bases, const uint64_t* contig_off, uint64_t n_contigs, uint32_t c,
+                          uint32_t k, int seed_mode, uint32_t** out_contig, uint64_t** out_pos, uint64_t** out_hash,
+                          uint64_t* out_n) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && out_contig && out_pos && out_hash && out_n, "null argument");
+        ContigSeeds s;
+        seeds_positions_impl(ctx, bases, contig_off, n_contigs, c, k, seed_mode, s);
+        *out_contig = to_malloc(s.contig);
+        *out_pos = to_malloc(s.pos);
+        *out_hash = to_malloc(s.hash);
+        *out_n = s.hash.size();
+    });
+}
+
+int sylph_seeds(sylph_ctx* ctx, const uint8_t* bases, uint64_t len, uint32_t c, uint32_t k, int seed_mode,
+                uint64_t** out_hashes, uint64_t* out_n) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && out_hashes && out_n, "null argument");
+        // one record; the read rule for short sequences (k+1, avx2_seeding.rs:42) differs from the contig rule
+        // (2k, :160), so run the read flavour through a throw-away session-less path
+        SY_REQUIRE(c >= 1, "c must be >= 1");
+        SY_REQUIRE(k == 21 || k == 31, "k must be 21 or 31 (avx2_seeding.rs:46-52)");
+        SY_REQUIRE(seed_mode == SYLPH_SEED_SCALAR || seed_mode == SYLPH_SEED_AVX2_COMPAT, "bad seed_mode %d", seed_mode);
+        std::vector<uint64_t> res;
+        if (len) {
+            SY_REQUIRE(bases, "null bases");
+            SY_REQUIRE(len < (1ull << 32), "sequence longer than 2^32-1 bases");
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            DeviceGuard dg(ctx->device);
+            DevBuf d_bases;
+            d_bases.reserve(len + 64);
+            SY_HIP(hipMemcpyAsync(d_bases.p, bases, len, hipMemcpyHostToDevice, ctx->stream));
+            ctx->counters.reserve(64);
+            const uint32_t n = seeds_sorted_by_pos(ctx, d_bases.as<uint8_t>(), len, c, k, ctx->counters.as<uint32_t>());
+            if (n) {
+                std::vector<uint32_t> hp(n);
+                std::vector<uint64_t> hh(n);
+                SY_HIP(hipMemcpyAsync(hp.data(), ctx->scratch[2].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+                SY_HIP(hipMemcpyAsync(hh.data(), ctx->scratch[3].p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+                SY_HIP(hipStreamSynchronize(ctx->stream));
+                const uint64_t nk = n_hashed_kmers(len, k, seed_mode == SYLPH_SEED_AVX2_COMPAT, 0);
+                for (uint32_t i = 0; i < n; i++)
+                    if (hp[i] < nk) res.push_back(hh[i]);
+            }
+        }
+        *out_hashes = to_malloc(res);
+        *out_n = res.size();
+    });
+}
+
+// sketch_genome, sketch.rs:550-622.  Seeds + validation + (contig,pos) ordering run on the GPU; the genome-wide
+// duplicate removal (:594-605) and the greedy spacing scan (:602-614) — a strictly sequential recurrence over
+// ~L/c seeds — run here on the host for single-genome calls.
+int sylph_sketch_genome(sylph_ctx* ctx, const uint8_t* bases, const uint64_t* contig_off, uint64_t n_contigs, uint32_t c,
+                        uint32_t k, int seed_mode, uint64_t min_spacing, int pseudotax, uint64_t** out_genome_kmers,
+                        uint64_t* out_n, uint64_t** out_tracked, uint64_t* out_n_tracked) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && out_genome_kmers && out_n, "null argument");
+        ContigSeeds s;
+        seeds_positions_impl(ctx, bases, contig_off, n_contigs, c, k, seed_mode, s);
+        const size_t n = s.hash.size();
+        std::unordered_map<uint64_t, uint32_t> seen;
+        seen.reserve(n * 2);
+        for (size_t i = 0; i < n; i++) seen[s.hash[i]]++;
+        std::vector<uint64_t> kept, tracked;
+        uint64_t last_pos = 0, last_contig = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (seen[s.hash[i]] > 1) continue;                                          // :605
+            if (last_pos == 0 || last_contig != s.contig[i] || s.pos[i] - last_pos > min_spacing) {   // :606
+                kept.push_back(s.hash[i]);
+                last_contig = s.contig[i];
+                last_pos = s.pos[i];
+            } else if (pseudotax) {
+                tracked.push_back(s.hash[i]);                                           // :610-611
+            }
+        }
+        *out_genome_kmers = to_malloc(kept);
+        *out_n = kept.size();
+        if (out_tracked) *out_tracked = to_malloc(tracked);
+        if (out_n_tracked) *out_n_tracked = tracked.size();
+    });
+}
+
+}  // extern "C"

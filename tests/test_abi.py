@@ -1,0 +1,54 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds, loads, exports every symbol include/sylph_hip.h
+declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import sylph_amd
+from sylph_amd import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "sylph_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sylph_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    lib = ctypes.CDLL(binding.lib_path())
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/sylph_hip.h but not exported"
+    assert sorted(binding.EXPORTS) == syms
+
+
+def test_version_and_error_string():
+    L = sylph_amd.load()
+    assert L.sylph_version() >= 100
+    assert isinstance(L.sylph_last_error(), bytes)
+
+
+def test_product_never_touches_the_oracle():
+    """The product path (sylph_amd/, include/) must not import, link or call anything under oracle/."""
+    bad = []
+    for d in ("sylph_amd", "include"):
+        for base, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                    txt = open(os.path.join(base, f), errors="replace").read()
+                    if re.search(r"oracle[/.]|liboracle|from oracle|import oracle", txt):
+                        bad.append(os.path.join(base, f))
+    assert not bad, bad
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sylph_amd.SylphHipError):
+        sylph_amd.Context(0)

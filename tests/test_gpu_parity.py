@@ -1,0 +1,344 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, through the C ABI, against the CPU oracle on the
+same inputs — bit-exact for hashes, seeds, (k-mer, count) tables, genome sketches, containment counts and coverage
+multisets — plus the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import sylph_amd as S
+from oracle import oracle as O
+
+from .helpers import ACGT, concat, random_seq, revcomp
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(S.SEED_SCALAR, O.MODE_SCALAR), (S.SEED_AVX2_COMPAT, O.MODE_AVX2_COMPAT)]
+
+
+# ---------------------------------------------------------------------------------------------- seeds
+@pytest.mark.parametrize("k", [21, 31])
+@pytest.mark.parametrize("c", [1, 7, 200])
+def test_extract_markers_random(ctx, k, c):
+    rng = np.random.default_rng(100 * k + c)
+    for L in [0, 1, 20, 21, 22, 30, 31, 32, 33, 34, 35, 61, 62, 63, 150, 151, 1000, 16383, 16384, 16385, 16414, 16415,
+              40000]:
+        seq = random_seq(rng, L)
+        for gm, om in MODES:
+            got = ctx.extract_markers(seq, c=c, k=k, seed_mode=gm)
+            exp = O.extract_markers(seq, c=c, k=k, mode=om)
+            # order: ABI returns ascending start position; reference's lane-interleaved order is not observable
+            pe, he = O.extract_markers_positions(seq, c=c, k=k, mode=om) if (om == O.MODE_SCALAR or L >= 2 * k) else (None, None)
+            assert sorted(got.tolist()) == sorted(exp.tolist()), (L, k, c, gm)
+            if pe is not None:
+                order = np.argsort(pe, kind="stable")
+                assert got.tolist() == he[order].tolist()
+
+
+def test_extract_markers_alphabet_exact(ctx):
+    """BYTE_TO_SEQ semantics for every byte value: N/IUPAC/gaps -> A, lower case, U/u, raw bytes 1,2,3 (types.rs:50-59)."""
+    rng = np.random.default_rng(5)
+    seq = rng.integers(0, 256, size=30000, dtype=np.uint8)
+    for gm, om in MODES:
+        got = ctx.extract_markers(seq, c=3, seed_mode=gm)
+        exp = O.extract_markers(seq, c=3, mode=om)
+        assert sorted(got.tolist()) == sorted(exp.tolist())
+    for alphabet in (b"ACGTN", b"acgtn", b"ACGU", b"\x01\x02\x03A", b"AC-GT.RYKM"):
+        seq = random_seq(rng, 5000, np.frombuffer(alphabet, dtype=np.uint8))
+        got = ctx.extract_markers(seq, c=2)
+        exp = O.extract_markers(seq, c=2)
+        assert sorted(got.tolist()) == sorted(exp.tolist())
+
+
+def test_extract_markers_rejects_bad_k(ctx):
+    with pytest.raises(S.SylphHipError):
+        ctx.extract_markers(b"ACGT" * 100, k=25)
+    with pytest.raises(S.SylphHipError):
+        ctx.extract_markers(b"ACGT" * 100, c=0)
+
+
+def test_golden_genome_slices(ctx, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ecoli_slices.npz"))
+    for gi in range(3):
+        b, off = z[f"g{gi}_bases"], z[f"g{gi}_off"]
+        for (gm, om), name in zip(MODES, ("scalar", "avx2")):
+            g = ctx.sketch_genome(b, off, seed_mode=gm)
+            assert np.array_equal(g["genome_kmers"], z[f"g{gi}_{name}_kmers"])
+            assert np.array_equal(g["tracked"], z[f"g{gi}_{name}_tracked"])
+            assert g["gn_size"] == int(off[-1])
+    # survey known answers on the EC590 slice: first seeds (end_pos, hash)
+    c, p, h = ctx.extract_markers_positions(z["g0_bases"][:2000], np.array([0, 2000], dtype=np.uint64))
+    assert list(zip(p.tolist(), h.tolist()))[:5] == [(149, 4659887629048781), (183, 83502980970892378),
+                                                     (186, 7394584420440650), (640, 54932856311185093),
+                                                     (1114, 35186119693294796)]
+    assert set(c.tolist()) == {0}
+
+
+def test_genome_sketch_synthetic_multicontig(ctx):
+    rng = np.random.default_rng(11)
+    contigs = [random_seq(rng, n) for n in (5000, 0, 61, 62, 63, 30, 200000, 1, 77777)]
+    # plant an exact repeat across contigs so the genome-wide duplicate rule (sketch.rs:594-605) fires
+    contigs[8][1000:6000] = contigs[6][500:5500]
+    b, off = concat(contigs)
+    for gm, om in MODES:
+        for c, spacing in ((50, 30), (200, 30), (10, 0), (10, 5)):
+            g = ctx.sketch_genome(b, off, c=c, seed_mode=gm, min_spacing=spacing)
+            e = O.sketch_genome(b, off, c=c, mode=om, min_spacing=spacing)
+            assert e["n_dup_kmers"] > 0
+            assert np.array_equal(g["genome_kmers"], e["genome_kmers"])
+            assert np.array_equal(g["tracked"], e["tracked"])
+            cc, pp, hh = ctx.extract_markers_positions(b, off, c=c, seed_mode=gm)
+            exp = []
+            for ci in range(len(contigs)):
+                p, h = O.extract_markers_positions(contigs[ci], c=c, mode=om)
+                exp += sorted((ci, int(a), int(x)) for a, x in zip(p, h))
+            assert list(zip(cc.tolist(), pp.tolist(), hh.tolist())) == exp
+
+
+# ---------------------------------------------------------------------------------------------- read sketches
+def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_AVX2_COMPAT, c=200, k=31, batches=1):
+    sk = S.ReadSketcher(ctx, c=c, k=k, paired=paired, no_dedup=no_dedup, seed_mode=seed_mode)
+    n = len(off) - 1
+    step = max(2, ((n // batches + 1) // 2) * 2)
+    for s in range(0, max(n, 1), step):
+        e = min(n, s + step)
+        lo, hi = int(off[s]), int(off[e])
+        sk.push(bases[lo:hi], off[s:e + 1] - off[s])
+    r = sk.finish()
+    sk.close()
+    return r
+
+
+def assert_same_sketch(g, e):
+    assert np.array_equal(g["kmers"], e["kmers"])
+    assert np.array_equal(g["counts"], e["counts"])
+    assert g["dup_removed"] == e["dup_removed"]
+
+
+def test_golden_read_sketches(ctx, golden_dir):
+    z = np.load(os.path.join(golden_dir, "k12_reads.npz"))
+    r1, o1, r2, o2 = z["r1_bases"], z["r1_off"], z["r2_bases"], z["r2_off"]
+
+    def rec(b, o):
+        return [b[int(o[i]):int(o[i + 1])] for i in range(len(o) - 1)]
+    R1, R2 = rec(r1, o1), rec(r2, o2)
+    T1, T2 = rec(z["t1_bases"], z["t1_off"]), rec(z["t2_bases"], z["t2_off"])
+    inter = lambda a, b: [x for p in zip(a, b) for x in p]
+    cases = {"k12_single": (R1, False, False), "k12_single_nodedup": (R1, False, True), "k12_single_x2": (R1 + R1, False, False),
+             "k12_single_x2_nodedup": (R1 + R1, False, True), "k12_single_x6": (R1 * 6, False, False),
+             "k12_paired": (inter(R1, R2), True, False), "k12_paired_nodedup": (inter(R1, R2), True, True),
+             "k12_paired_x2": (inter(R1 + R1, R2 + R2), True, False),
+             "k12_paired_x2_nodedup": (inter(R1 + R1, R2 + R2), True, True), "t_paired": (inter(T1, T2), True, False),
+             "t1_single": (T1, False, False), "t2_single": (T2, False, False)}
+    for name, (rr, paired, nd) in cases.items():
+        b, off = concat(rr)
+        for (gm, om), mname in zip(MODES, ("scalar", "avx2")):
+            for batches in (1, 3):
+                g = sketch_gpu(ctx, b, off, paired=paired, no_dedup=nd, seed_mode=gm, batches=batches)
+                assert np.array_equal(g["kmers"], z[f"{name}_{mname}_kmers"]), (name, mname)
+                assert np.array_equal(g["counts"], z[f"{name}_{mname}_counts"]), (name, mname)
+    # survey dedup known answers (A.2)
+    b, off = concat(R1 + R1)
+    g = sketch_gpu(ctx, b, off)
+    assert len(g["kmers"]) == 512 and int(g["counts"].sum()) == 515 and g["dup_removed"] == 515
+    b, off = concat(R1 * 6)
+    assert sketch_gpu(ctx, b, off)["dup_removed"] == 2575
+    b, off = concat(inter(R1 + R1, R2 + R2))
+    g = sketch_gpu(ctx, b, off, paired=True)
+    assert len(g["kmers"]) == 994 and int(g["counts"].sum()) == 1002 and g["dup_removed"] == 1002
+
+
+def make_reads(rng, genome, n, L, err=0.005, dup_frac=0.1, paired=False, insert=350, ragged=True):
+    recs = []
+    for _ in range(n):
+        if paired:
+            ins = int(rng.integers(max(L, insert - 60), insert + 60))
+            s = int(rng.integers(0, len(genome) - ins))
+            frag = genome[s:s + ins]
+            l1 = L if not ragged else int(rng.integers(20, L + 1))
+            l2 = L if not ragged else int(rng.integers(20, L + 1))
+            m1, m2 = frag[:l1].copy(), revcomp(frag)[:l2].copy()
+            for m in (m1, m2):
+                e = rng.random(len(m)) < err
+                m[e] = rng.choice(ACGT, size=int(e.sum()))
+            recs.append((m1, m2))
+        else:
+            l = L if not ragged else int(rng.integers(10, L + 1))
+            s = int(rng.integers(0, len(genome) - l))
+            m = genome[s:s + l].copy()
+            if rng.random() < 0.5:
+                m = revcomp(m)
+            e = rng.random(len(m)) < err
+            m[e] = rng.choice(ACGT, size=int(e.sum()))
+            recs.append(m)
+    # exact duplicates (PCR) appended at random positions, exercises dup_removal_lsh_full_exact
+    for _ in range(int(n * dup_frac)):
+        recs.insert(int(rng.integers(0, len(recs))), recs[int(rng.integers(0, len(recs)))])
+    if paired:
+        return [x for p in recs for x in p]
+    return recs
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("no_dedup", [False, True])
+def test_read_sketch_synthetic(ctx, paired, no_dedup):
+    rng = np.random.default_rng(42 + paired * 2 + no_dedup)
+    genome = random_seq(rng, 30000)
+    for c, n, L in ((20, 4000, 150), (5, 1500, 100), (200, 3000, 250)):
+        recs = make_reads(rng, genome, n, L, paired=paired, dup_frac=0.3)
+        b, off = concat(recs)
+        for gm, om in MODES:
+            e = O.sketch_reads(b, off, c=c, mode=om, paired=paired, no_dedup=no_dedup)
+            for batches in (1, 4):
+                g = sketch_gpu(ctx, b, off, paired=paired, no_dedup=no_dedup, seed_mode=gm, c=c, batches=batches)
+                assert_same_sketch(g, e)
+            if not no_dedup:
+                assert e["dup_removed"] > 0
+
+
+def test_read_sketch_deep_coverage_and_cutoff(ctx):
+    """Tiny genome, very deep coverage: long per-k-mer occurrence lists, single-end cut-off at 4 (sketch.rs:706,937),
+    partial marker overlaps."""
+    rng = np.random.default_rng(9)
+    genome = random_seq(rng, 600)
+    recs = make_reads(rng, genome, 6000, 120, err=0.0, dup_frac=0.5, ragged=True)
+    b, off = concat(recs)
+    for c in (3, 50):
+        e = O.sketch_reads(b, off, c=c, mode=O.MODE_AVX2_COMPAT)
+        assert_same_sketch(sketch_gpu(ctx, b, off, c=c), e)
+    recs = make_reads(rng, genome, 3000, 100, err=0.0, dup_frac=0.5, paired=True, insert=200, ragged=False)
+    b, off = concat(recs)
+    e = O.sketch_reads(b, off, c=10, mode=O.MODE_AVX2_COMPAT, paired=True)
+    assert_same_sketch(sketch_gpu(ctx, b, off, c=10, paired=True), e)
+
+
+def test_read_sketch_long_reads_and_edge_lengths(ctx):
+    rng = np.random.default_rng(13)
+    genome = random_seq(rng, 200000)
+    recs = []
+    for L in (0, 1, 30, 31, 32, 33, 34, 35, 65, 66, 67, 399, 400, 401, 5000, 20000, 0, 70000):
+        s = int(rng.integers(0, len(genome) - L)) if L else 0
+        recs.append(genome[s:s + L].copy())
+        recs.append(genome[s:s + L].copy())   # duplicate: dedup only applies for 66 <= L <= 400
+    b, off = concat(recs)
+    for gm, om in MODES:
+        for c in (100, 4):
+            e = O.sketch_reads(b, off, c=c, mode=om)
+            assert_same_sketch(sketch_gpu(ctx, b, off, c=c, seed_mode=gm, batches=2), e)
+    # homopolymer / doubled reads: both markers equal (self-hit rule)
+    dbl = [np.repeat(random_seq(rng, 60), 2) for _ in range(6)]
+    recs = [dbl[0], dbl[1], dbl[0], dbl[2], dbl[1], dbl[1]] + [np.full(100, ord("A"), dtype=np.uint8)] * 3
+    b, off = concat(recs)
+    e = O.sketch_reads(b, off, c=1, mode=O.MODE_SCALAR)
+    assert_same_sketch(sketch_gpu(ctx, b, off, c=1, seed_mode=S.SEED_SCALAR), e)
+
+
+def test_read_sketch_empty(ctx):
+    sk = S.ReadSketcher(ctx)
+    r = sk.finish()
+    assert len(r["kmers"]) == 0 and r["dup_removed"] == 0
+    sk.close()
+    sk = S.ReadSketcher(ctx)
+    sk.push(np.zeros(0, dtype=np.uint8), np.zeros(4, dtype=np.uint64))   # three empty records
+    sk.push(np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 4], dtype=np.uint64))
+    r = sk.finish()
+    assert len(r["kmers"]) == 0
+    with pytest.raises(S.SylphHipError):
+        sk.push(np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 4], dtype=np.uint64))
+    sk.close()
+    sk = S.ReadSketcher(ctx, paired=True)
+    with pytest.raises(S.SylphHipError):
+        sk.push(np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 4], dtype=np.uint64))   # odd record count
+    sk.close()
+
+
+# ---------------------------------------------------------------------------------------------- containment
+def check_contain(ctx, db_kmers, goff, sk, sc, min_kmers=50.0):
+    db = S.Database(ctx, db_kmers, goff)
+    cc, off, covs = db.contain(sk, sc, min_number_kmers=min_kmers)
+    db.close()
+    ecc, ecov, _ = O.contain(sk, sc, db_kmers, goff, min_number_kmers=min_kmers)
+    assert np.array_equal(cc, ecc)
+    assert int(off[-1]) == int(ecc.sum()) and off[0] == 0
+    assert np.array_equal(np.diff(off.astype(np.int64)), ecc.astype(np.int64))
+    for g in range(len(goff) - 1):
+        got = covs[int(off[g]):int(off[g + 1])]
+        assert np.array_equal(got, np.sort(ecov[g])), g   # contain.rs:661: the reference sorts covs before use
+    return cc
+
+
+def test_contain_golden(ctx, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ecoli_full_sketches.npz"))
+    r = np.load(os.path.join(golden_dir, "k12_reads.npz"))
+    cc = check_contain(ctx, z["db"], z["goff"], r["k12_single_avx2_kmers"], r["k12_single_avx2_counts"])
+    assert cc.tolist() == [200, 220, 131]
+    cc = check_contain(ctx, z["db"], z["goff"], r["k12_paired_avx2_kmers"], r["k12_paired_avx2_counts"])
+    assert cc.tolist() == [387, 439, 265]
+    cc = check_contain(ctx, z["db"], z["goff"], r["t_paired_avx2_kmers"], r["t_paired_avx2_counts"])
+    assert cc.tolist() == [0, 0, 0]
+
+
+def test_contain_synthetic(ctx):
+    rng = np.random.default_rng(21)
+    thr = O.threshold(200)
+    pool = np.unique(rng.integers(0, thr, size=200000, dtype=np.uint64))
+    lens = [0, 10, 49, 50, 51, 300, 5000, 20000, 1, 12345, 0, 777]
+    genomes = [rng.choice(pool, size=n, replace=False) for n in lens]
+    genomes[5][:100] = genomes[6][:100]           # shared k-mers between genomes
+    genomes[11] = np.concatenate([genomes[11][:700], genomes[11][:77]])   # duplicate k-mers inside one genome
+    db = np.concatenate(genomes)
+    goff = np.zeros(len(genomes) + 1, dtype=np.uint64)
+    goff[1:] = np.cumsum([len(g) for g in genomes])
+    sk = np.sort(rng.choice(pool, size=60000, replace=False))
+    sc = rng.integers(0, 40, size=len(sk)).astype(np.uint32)   # includes zero counts (contain.rs:634)
+    sc[rng.random(len(sk)) < 0.01] = 3_000_000_000              # large counts survive the 32-bit packing
+    for mk in (50.0, 0.0, 1000.5):
+        check_contain(ctx, db, goff, sk, sc, min_kmers=mk)
+    check_contain(ctx, db, goff, sk[:0], sc[:0])                # empty sample
+    check_contain(ctx, db[:0], np.zeros(4, dtype=np.uint64), sk, sc)   # three empty genomes
+    check_contain(ctx, db, goff, np.array([5, thr - 1, 2**64 - 1], dtype=np.uint64), np.array([1, 2, 3], dtype=np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------- end to end
+def test_end_to_end_sketch_then_contain_device_resident(ctx):
+    """Reads -> device-resident table -> containment without a host round trip; checked against the oracle end to end,
+    including the host statistics the reference derives from these integers (contain.rs:657-813)."""
+    import torch
+    rng = np.random.default_rng(77)
+    genomes = [random_seq(rng, 60000) for _ in range(6)]
+    genomes[3] = genomes[0].copy()
+    mut = rng.random(len(genomes[3])) < 0.02
+    genomes[3][mut] = rng.choice(ACGT, size=int(mut.sum()))
+    gk, lens = [], []
+    for g in genomes:
+        r = ctx.sketch_genome(g, np.array([0, len(g)], dtype=np.uint64), c=50)
+        e = O.sketch_genome(g, np.array([0, len(g)], dtype=np.uint64), c=50)
+        assert np.array_equal(r["genome_kmers"], e["genome_kmers"])
+        gk.append(r["genome_kmers"])
+        lens.append(len(r["genome_kmers"]))
+    db_k = np.concatenate(gk)
+    goff = np.zeros(len(gk) + 1, dtype=np.uint64)
+    goff[1:] = np.cumsum(lens)
+    recs = make_reads(rng, genomes[0], 3000, 150, paired=True, dup_frac=0.05, ragged=False) + \
+        make_reads(rng, genomes[1], 800, 150, paired=True, dup_frac=0.0, ragged=False)
+    b, off = concat(recs)
+    tb = torch.from_numpy(np.concatenate([b, np.zeros(64, dtype=np.uint8)])).cuda()
+    toff = torch.from_numpy(off.astype(np.int64)).cuda()
+    sk = S.ReadSketcher(ctx, c=50, paired=True)
+    sk.push_device(tb.data_ptr(), toff.data_ptr(), len(off) - 1)
+    dk, dc, n, dup = sk.finish_device()
+    e = O.sketch_reads(b, off, c=50, paired=True)
+    assert n == len(e["kmers"]) and dup == e["dup_removed"]
+    db = S.Database(ctx, db_k, goff)
+    cc, coff, covs = db.contain(dk, dc, device_ptrs=True, n=n)
+    ecc, ecov, _ = O.contain(e["kmers"], e["counts"], db_k, goff)
+    assert np.array_equal(cc, ecc)
+    for g in range(len(gk)):
+        mine = covs[int(coff[g]):int(coff[g + 1])]
+        assert np.array_equal(mine, np.sort(ecov[g]))
+        a, bb = O.stats(mine, lens[g]), O.stats(ecov[g], lens[g])
+        for f in ("naive_ani", "final_est_ani", "final_est_cov", "mean_cov", "median_cov"):
+            assert abs(getattr(a, f) - getattr(bb, f)) <= 1e-6   # north_star float tolerance
+    assert cc[0] > cc[3] > cc[2]
+    db.close()
+    sk.close()

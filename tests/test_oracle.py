@@ -1,0 +1,226 @@
+"""CPU tests: the oracle against (a) SURVEY Appendix A known answers (independent numpy restatement),
+(b) its own committed fixtures, (c) internal consistency (scalar vs AVX2-compat vs AVX2 intrinsics)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+from .helpers import hist, xor_sum
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with open(os.path.join(golden_dir, "survey_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def full(golden_dir):
+    with open(os.path.join(golden_dir, "full_genome_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def reads(golden_dir):
+    return np.load(os.path.join(golden_dir, "k12_reads.npz"))
+
+
+@pytest.fixture(scope="module")
+def slices(golden_dir):
+    return np.load(os.path.join(golden_dir, "ecoli_slices.npz"))
+
+
+def test_hash_known_answers(kat):
+    for k, v in kat["mm_hash64"].items():
+        assert O.mm_hash64(int(k)) == int(v)
+    # the shipped hash is NOT the textbook variant (SURVEY A.1 trap 1)
+    assert O.mm_hash64(19238239812933123) != int(kat["textbook_variant_first_key"])
+    for c, t in kat["threshold"].items():
+        assert O.threshold(int(c)) == int(t)
+
+
+def test_byte_to_seq_table():
+    lut = [O.lib().orc_byte_to_seq(b) for b in range(256)]
+    expect = [0] * 256
+    for ch, v in (("A", 0), ("C", 1), ("G", 2), ("T", 3), ("U", 3)):
+        expect[ord(ch)] = v
+        expect[ord(ch.lower())] = v
+    expect[1], expect[2], expect[3] = 1, 2, 3
+    assert lut == expect
+
+
+def test_full_genome_sketches_match_survey(kat, full):
+    for f, e in kat["genomes"].items():
+        for mode in ("scalar", "avx2"):   # identical under both modes for these files
+            g = full[f"{f}:{mode}"]
+            assert g["contigs"] == e["contigs"] and g["gn_size"] == e["gn_size"]
+            assert g["raw"] == e["raw"] and g["dup"] == e["dup"]
+            assert g["genome_kmers"] == e["genome_kmers"] and g["tracked"] == e["tracked"]
+            assert g["first3"] == e["first3"]
+
+
+def test_read_sketches_match_survey(kat, full):
+    for name, e in kat["reads"].items():
+        for mode in ("scalar", "avx2"):
+            s = full[f"{name}:{mode}"]
+            assert s["distinct"] == e["distinct"] and s["total"] == e["total"] and s["hist"] == e["hist"]
+            assert s["keys"][1] == e["keys_xor"] and s["keys"][2] == e["keys_sum"]
+            if "mean_read_length" in e:
+                assert s["mean_read_length"] == e["mean_read_length"]
+            assert s["dup_removed"] == 0
+    for name, e in kat["dedup"].items():
+        s = full[f"{name}:avx2"]
+        for key in ("distinct", "total", "dup_removed", "hist"):
+            if key in e:
+                assert s[key] == e[key], (name, key)
+
+
+def test_containment_and_stats_match_survey(kat, full):
+    for sname, per in kat["containment"].items():
+        for f, (cc, n, h, naive) in per.items():
+            r = full[f"contain:{sname}:{f}"]
+            assert r["contain_count"] == cc and r["n_kmers"] == n and r["cov_hist"] == h
+            assert abs(r["naive_ani"] - naive) < 1e-9
+    for f in kat["genomes"]:
+        assert full[f"contain:t_paired:{f}"]["contain_count"] == 0
+        # single-end k12_R1: lambda LOW -> final ANI = naive ANI (< 0.9)
+        r = full[f"contain:k12_single:{f}"]
+        assert r["lambda_status"] == 0 and r["final_est_ani"] == r["naive_ani"]
+    for f, e in kat["paired_stats"].items():
+        r = full[f"contain:k12_paired:{f}"]
+        assert r["lambda_status"] == 2
+        assert abs(r["lam"] - e["lambda"]) < 1e-9 and abs(r["final_est_ani"] - e["ani"]) < 1e-9
+        assert r["median_cov"] == e["median"] and abs(r["mean_cov_geq1"] - e["mean_cov_geq1"]) < 1e-9
+        assert r["final_est_ani"] >= 0.95   # trap 13: naive ANI must not be used as a pre-filter
+
+
+def test_per_read_seeds(kat, reads):
+    for name in ("t1", "t2"):
+        b, off = reads[name + "_bases"], reads[name + "_off"]
+        for i in range(len(off) - 1):
+            seq = b[int(off[i]):int(off[i + 1])]
+            pos, h = O.extract_markers_positions(seq, mode=O.MODE_SCALAR)
+            got = sorted(zip(pos.tolist(), h.tolist()))
+            assert got == [tuple(x) for x in kat["per_read_seeds"][name][str(i + 1)]]
+
+
+def test_poisson_cap_table(kat):
+    for med, cap in kat["poisson_cap"].items():
+        med = int(med)
+        x = med
+        while O.poisson_cdf(float(med), x + 1) < 0.9999999999:
+            x += 1
+        assert x == cap, (med, x, cap)
+
+
+def test_toy_statistics(kat):
+    t = kat["toy_stats"]
+    full = np.concatenate([np.full(n, int(v), dtype=np.uint32) for v, n in t["full_covs"].items()])
+    assert abs(O.ratio_lambda(full) - t["ratio_lambda"]) < 1e-12
+    covs = full[full > 0]
+    st = O.stats(covs, len(full))
+    assert st.lambda_status == 2 and abs(st.lambda_ - 1.0) < 1e-12
+    assert abs(st.final_est_ani - t["adjusted_ani"]) < 1e-9 and abs(st.naive_ani - t["naive_ani"]) < 1e-9
+
+
+def test_ratio_lambda_edge_cases():
+    assert O.ratio_lambda(np.array([1] * 30, dtype=np.uint32)) is None            # one distinct value
+    assert O.ratio_lambda(np.array([1] * 20 + [2] * 4, dtype=np.uint32)) is None   # < 25 non-zero
+    assert O.ratio_lambda(np.array([1] * 30 + [3] * 5, dtype=np.uint32)) is None   # mode+1 absent
+    assert O.ratio_lambda(np.array([1] * 30 + [2] * 2, dtype=np.uint32)) is None   # count(mode+1) < 3
+    assert O.ratio_lambda(np.array([0] * 100 + [1] * 30 + [2] * 3, dtype=np.uint32)) == pytest.approx(3 / 30 * 2)
+    # tie on counts -> larger value is the mode (sort of (count,value) descending, inference.rs:228-230)
+    assert O.ratio_lambda(np.array([1] * 15 + [2] * 15 + [3] * 5, dtype=np.uint32)) == pytest.approx(5 / 15 * 3)
+
+
+def test_avx2_tail_drop_and_guards(slices):
+    g = slices["g0_bases"]
+    s = g[33:184]   # L=151 -> 121 k-mers, the last one is dropped by the 4-lane split
+    ps, hs = O.extract_markers_positions(s, mode=O.MODE_SCALAR)
+    pa, ha = O.extract_markers_positions(s, mode=O.MODE_AVX2_COMPAT)
+    assert list(zip(ps.tolist(), hs.tolist())) == [(116, 4659887629048781), (150, 83502980970892378)]
+    assert list(zip(pa.tolist(), ha.tolist())) == [(116, 4659887629048781)]
+    rng = np.random.default_rng(1)
+    for L in list(range(0, 70)) + [100, 151, 152, 153, 154]:
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)
+        sc = O.extract_markers(seq, c=3, mode=O.MODE_SCALAR)
+        av = O.extract_markers(seq, c=3, mode=O.MODE_AVX2_COMPAT)
+        # AVX2 result == scalar result restricted to k-mer starts < 4*((L-k+1)/4), as a multiset
+        psc, hsc = O.extract_markers_positions(seq, c=3, mode=O.MODE_SCALAR)
+        nk = ((L - 31 + 1) // 4) * 4 if L >= 32 else 0
+        keep = sorted(h for p, h in zip(psc.tolist(), hsc.tolist()) if p - 30 < nk)
+        assert sorted(av.tolist()) == keep
+        assert len(sc) == len(hsc)
+        pav, _ = O.extract_markers_positions(seq, c=3, mode=O.MODE_AVX2_COMPAT)
+        if L < 62:
+            assert len(pav) == 0   # positions variant: nothing below 2k (avx2_seeding.rs:160)
+    with pytest.raises(ValueError):
+        O.extract_markers(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=100), k=25, mode=O.MODE_AVX2_COMPAT)
+
+
+@pytest.mark.skipif(not O.lib().orc_has_avx2(), reason="host has no AVX2")
+def test_avx2_intrinsics_equal_compat():
+    rng = np.random.default_rng(7)
+    alphabet = np.frombuffer(b"ACGTNacgtn", dtype=np.uint8)
+    for L in (31, 32, 35, 64, 150, 151, 1000, 10007):
+        seq = rng.choice(alphabet, size=L)
+        for k in (21, 31):
+            a = O.extract_markers(seq, c=5, k=k, mode=O.MODE_AVX2_COMPAT)
+            b = O.extract_markers(seq, c=5, k=k, mode=O.MODE_AVX2_FAST)
+            assert a.tolist() == b.tolist()   # same emission order too
+            pa = O.extract_markers_positions(seq, c=5, k=k, mode=O.MODE_AVX2_COMPAT)
+            pb = O.extract_markers_positions(seq, c=5, k=k, mode=O.MODE_AVX2_FAST)
+            assert pa[0].tolist() == pb[0].tolist() and pa[1].tolist() == pb[1].tolist()
+
+
+def test_dedup_cutoff_and_order_dependence(slices):
+    """MAX_DEDUP_COUNT cut-off vectors built from the K12 contig."""
+    k12 = slices["g1_bases"]
+    def reads_at(starts):
+        return O.concat([bytes(k12[s:s + 70]) for s in starts])
+    target = 41739749670497347
+    b, off = reads_at([252, 247, 242, 237, 252])
+    s = O.sketch_reads(b, off, mode=O.MODE_SCALAR)
+    i = s["kmers"].tolist().index(target)
+    assert s["counts"][i] == 5 and s["dup_removed"] == 0
+    b, off = reads_at([252, 252, 247, 242, 237])
+    s = O.sketch_reads(b, off, mode=O.MODE_SCALAR)
+    i = s["kmers"].tolist().index(target)
+    assert s["counts"][i] == 4 and s["dup_removed"] >= 1
+
+
+def test_self_hit_marker_rule():
+    """An occurrence whose two markers are equal is dropped whenever the k-mer was counted before
+    (sketch.rs:709-722: m1 is looked up after m0 was inserted)."""
+    rng = np.random.default_rng(3)
+    core = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=40)
+    def doubled(n, seed):   # s[2i]==s[2i+1] and periodic in halves -> f==g, r==t
+        r = np.random.default_rng(seed)
+        x = r.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n // 2)
+        return np.repeat(x, 2)
+    r1 = doubled(100, 1)
+    r2 = doubled(100, 2)
+    assert O.pair_kmer_single(r1)[0] == O.pair_kmer_single(r1)[2]
+    b, off = O.concat([bytes(r1), bytes(r2), bytes(r1)])
+    s = O.sketch_reads(b, off, c=1, mode=O.MODE_SCALAR)
+    # every k-mer of r1 appears in read 1 and read 3; read 3's occurrences are duplicates.  k-mers of r2 that also
+    # occur in r1 would be self-hit-dropped; just require consistency of totals here
+    assert s["dup_removed"] > 0
+    del core
+
+
+def test_golden_fixtures_reproduce(reads, slices):
+    for gi in range(3):
+        b, off = slices[f"g{gi}_bases"], slices[f"g{gi}_off"]
+        for mode, name in ((O.MODE_SCALAR, "scalar"), (O.MODE_AVX2_COMPAT, "avx2")):
+            g = O.sketch_genome(b, off, mode=mode)
+            assert np.array_equal(g["genome_kmers"], slices[f"g{gi}_{name}_kmers"])
+            assert np.array_equal(g["tracked"], slices[f"g{gi}_{name}_tracked"])
+    b, off = reads["r1_bases"], reads["r1_off"]
+    s = O.sketch_reads(b, off, mode=O.MODE_AVX2_COMPAT)
+    assert np.array_equal(s["kmers"], reads["k12_single_avx2_kmers"])
+    assert np.array_equal(s["counts"], reads["k12_single_avx2_counts"])
+    assert xor_sum(s["kmers"])[0] == 42090302901142153 and hist(s["counts"]) == {1: 509, 2: 3}
