@@ -216,6 +216,33 @@ def contain(sample_kmers, sample_counts, db_kmers, genome_off, min_number_kmers=
     return cc, covs, lost
 
 
+class LoadedSample:
+    """A sample table loaded once into the Fx-hashed map (what contain.rs:559 does when it deserialises a .sylsp);
+    probe() times only the genome loop (contain.rs:284-291), for bench.py's cpu_baseline leg."""
+
+    def __init__(self, kmers, counts):
+        self.k = np.ascontiguousarray(kmers, dtype=np.uint64)
+        self.c = np.ascontiguousarray(counts, dtype=np.uint32)
+        self.h = lib().orc_sample_load(_ptr(self.k), _ptr(self.c), len(self.k))
+
+    def probe(self, db_kmers, genome_off, min_number_kmers=50.0, n_threads=1):
+        db = np.ascontiguousarray(db_kmers, dtype=np.uint64)
+        go = np.ascontiguousarray(genome_off, dtype=np.uint64)
+        G = len(go) - 1
+        cc = np.zeros(G, dtype=np.uint32)
+        cov = np.zeros(max(1, len(db)), dtype=np.uint32)
+        import time
+        t = time.perf_counter()
+        lib().orc_contain(self.h, _ptr(db), _ptr(go), G, float(min_number_kmers), None, None, _ptr(cc), _ptr(cov), None,
+                          n_threads)
+        return cc, cov, time.perf_counter() - t
+
+    def close(self):
+        if self.h:
+            lib().orc_sample_free(self.h)
+            self.h = None
+
+
 def stats(covs, n_genome_kmers, k=31, min_count_correct=3.0, min_ani=0.0, no_adj=False, mean_coverage=False):
     """Statistics half of get_stats (contain.rs:657-813), default ratio estimator."""
     cv = np.ascontiguousarray(covs, dtype=np.uint32)

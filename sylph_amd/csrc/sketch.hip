@@ -270,7 +270,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
     SY_REQUIRE(!sk->paired || (n_records % 2 == 0), "paired batches must hold an even number of records");
     if (n_records == 0) return;
-    SY_REQUIRE(bases && rec_off, "null input");
+    SY_REQUIRE(rec_off, "null rec_off");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
     const uint8_t* d_bases;
@@ -279,6 +279,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     if (mem == SYLPH_MEM_HOST) {
         SY_REQUIRE(rec_off[0] == 0, "rec_off[0] must be 0");
         n_bases = rec_off[n_records];
+        SY_REQUIRE(bases || n_bases == 0, "null bases");
         sk->batch_bases.reserve(n_bases + 64);
         sk->batch_off.reserve((n_records + 1) * 8);
         if (n_bases) SY_HIP(hipMemcpyAsync(sk->batch_bases.p, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
@@ -289,6 +290,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         SY_REQUIRE(((uintptr_t)bases & 15) == 0, "device bases pointer must be 16-byte aligned");
         SY_HIP(hipMemcpyAsync(&n_bases, rec_off + n_records, 8, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
+        SY_REQUIRE(bases || n_bases == 0, "null bases");
         d_bases = bases;
         d_off = rec_off;
     }
