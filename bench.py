@@ -104,8 +104,9 @@ def build_database(ctx, device, wl, c, k, seed, rank, world):
     stats = dict(n_genomes=int(n_total), shard_genomes=int(len(mine)), shard_kmers=int(db.n_kmers),
                  seq_backed_sketch_s=round(t1 - t0, 2), generate_s=round(t2 - t1, 2), db_upload_index_s=round(t3 - t2, 2))
     lens_mine = lens[mine]
+    # NB: no torch.cuda.empty_cache() here — returning tens of GB to the driver (hipFree) queues page-table work
+    # that stalls this process's GPU queues for 15-40 ms at random moments over the next few hundred ms.
     del kmers, goff
-    torch.cuda.empty_cache()
     return db, mine, lens_mine, int(n_total), community, stats
 
 
@@ -139,6 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SYLPH_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline object)")
     ap.add_argument("--seed", type=int, default=20250711)
     args = ap.parse_args()
 
@@ -166,7 +168,6 @@ def main():
     bases, rec_off = synth.paired_reads(community, n_pairs, read_len=read_len, seed=args.seed + 1_000_003 * (rank + 1))
     torch.cuda.synchronize()
     del community
-    torch.cuda.empty_cache()
     n_bases = n_pairs * 2 * read_len
     log(f"[bench] db {dbstats}; reads {n_bases / 1e9:.3f} Gbp generated in {time.time() - t0:.1f}s")
 
@@ -177,12 +178,21 @@ def main():
     def step(collect=None):
         t_a = time.perf_counter()
         sk = S.ReadSketcher(ctx, c=c, k=k, paired=True)
+        t_a1 = time.perf_counter()
         sk.push_device(bases.data_ptr(), rec_off.data_ptr(), 2 * n_pairs)
+        t_a2 = time.perf_counter()
         dk, dc, n, dup = sk.finish_device()
         t_b = time.perf_counter()
+        if os.environ.get("SYLPH_BENCH_DEBUG"):
+            log(f"[bench] begin {1e3 * (t_a1 - t_a):.3f} push {1e3 * (t_a2 - t_a1):.3f} finish {1e3 * (t_b - t_a2):.3f} ms")
         occ_holder[0] = (dc, n, dup)
-        res = SH.profile_step(db, group, dk, dc, n, mine, n_total, device)
+        if os.environ.get("SYLPH_BENCH_SKIP_CONTAIN"):
+            res = {}
+        else:
+            res = SH.profile_step(db, group, dk, dc, n, mine, n_total, device)
         t_c = time.perf_counter()
+        if os.environ.get("SYLPH_BENCH_DEBUG"):
+            log(f"[bench] contain {1e3 * (t_c - t_b):.3f} ms")
         if collect is not None and len(collect) == 0:   # seed occurrences of the sample = sum(counts) + removed
             occ_holder.append(int(SH.device_view(dc, n, torch.int32, device).sum().item()) + dup)
         sk.close()
@@ -190,9 +200,16 @@ def main():
             collect.append((t_b - t_a, t_c - t_b, n, dup, res))
         return res
 
+    # settle: the setup above allocates/frees tens of GB; the driver finishes that page-table work asynchronously and
+    # the first few submissions afterwards can stall for 15-40 ms.  Two untimed settle steps + a short pause keep that
+    # out of both the warm-up and the timed region whatever --warmup is.
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    time.sleep(0.25)
     for _ in range(args.warmup):
         step()
-    ctx.profile(True)
+    ctx.profile(not args.no_kernel_timers)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

@@ -1,4 +1,6 @@
 // capi.hip — context, error reporting and profiling hooks of the C ABI (include/sylph_hip.h).
+#include <algorithm>
+
 #include "common.h"
 
 namespace sylph {
@@ -31,6 +33,41 @@ ScopedKernelTimer::~ScopedKernelTimer() {
     ctx->pending.push_back({fam, a, b});
 }
 
+void* pool_acquire(sylph_ctx* ctx, size_t bytes, size_t* cap_out) {
+    // size classes: 64 KiB granules below 8 MiB, 2 MiB granules above
+    const size_t g = bytes < (8u << 20) ? (64u << 10) : (2u << 20);
+    const size_t want = ((bytes + g - 1) / g) * g;
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool_free.size(); i++) {
+        const size_t c = ctx->pool_free[i].first;
+        if (c >= want && c <= 2 * want + (4u << 20) && (best < 0 || c < ctx->pool_free[best].first)) best = (int)i;
+    }
+    if (best >= 0) {
+        void* p = ctx->pool_free[best].second;
+        *cap_out = ctx->pool_free[best].first;
+        ctx->pool_free.erase(ctx->pool_free.begin() + best);
+        return p;
+    }
+    void* p = nullptr;
+    const double t0 = HostPhase::enabled() ? HostPhase::now() : 0;
+    hipError_t e = hipMalloc(&p, want);
+    if (HostPhase::enabled())
+        fprintf(stderr, "[sylph_hip] pool miss: hipMalloc(%zu KiB) %.3f ms (pool holds %zu free blocks)\n", want >> 10,
+                HostPhase::now() - t0, ctx->pool_free.size());
+    if (e != hipSuccess) {   // give cached blocks back to the driver and retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& b : ctx->pool_free) (void)hipFree(b.second);
+        ctx->pool_free.clear();
+        SY_HIP(hipMalloc(&p, want));
+    }
+    ctx->pool_bytes += want;
+    *cap_out = want;
+    return p;
+}
+
+void pool_release(sylph_ctx* ctx, void* p, size_t cap) { ctx->pool_free.emplace_back(cap, p); }
+
 void profile_collect(sylph_ctx* ctx) {
     for (auto& p : ctx->pending) {
         float ms = 0;
@@ -48,6 +85,70 @@ void profile_collect(sylph_ctx* ctx) {
 }  // namespace sylph
 
 using namespace sylph;
+
+void sylph_ctx::read_back(void* dst, const void* dev_src, size_t bytes) {
+    SY_REQUIRE(bytes <= 4096, "read_back too large");
+    SY_HIP(hipMemcpyAsync(pinned, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    SY_HIP(hipStreamSynchronize(stream));
+    memcpy(dst, pinned, bytes);
+    // every timing event recorded so far has completed: fold them into the totals and recycle the event objects
+    // (creating fresh hipEvents per launch costs far more than the kernels being timed)
+    if (!pending.empty()) sylph::profile_collect(this);
+}
+
+static void ensure_stage(sylph_ctx* c) {
+    for (int i = 0; i < 2; i++) {
+        if (!c->stage[i]) {
+            SY_HIP(hipHostMalloc(&c->stage[i], sylph_ctx::STAGE_BYTES, hipHostMallocDefault));
+            SY_HIP(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+        }
+    }
+}
+
+void sylph_ctx::d2h(void* dst, const void* dev_src, size_t bytes) {
+    if (!bytes) { SY_HIP(hipStreamSynchronize(stream)); return; }
+    ensure_stage(this);
+    // ping-pong: the device fills one pinned buffer while the host drains the other
+    size_t issued = 0, done = 0, len[2] = {0, 0};
+    int head = 0, tail = 0, inflight = 0;
+    while (done < bytes) {
+        while (issued < bytes && inflight < 2) {
+            len[tail] = std::min(STAGE_BYTES, bytes - issued);
+            SY_HIP(hipMemcpyAsync(stage[tail], (const char*)dev_src + issued, len[tail], hipMemcpyDeviceToHost, stream));
+            SY_HIP(hipEventRecord(stage_ev[tail], stream));
+            issued += len[tail];
+            tail ^= 1;
+            inflight++;
+        }
+        SY_HIP(hipEventSynchronize(stage_ev[head]));
+        memcpy((char*)dst + done, stage[head], len[head]);
+        done += len[head];
+        head ^= 1;
+        inflight--;
+    }
+    if (!pending.empty()) sylph::profile_collect(this);
+}
+
+void sylph_ctx::h2d(void* dev_dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    ensure_stage(this);
+    size_t done = 0;
+    int slot = 0;
+    bool used[2] = {false, false};
+    while (done < bytes) {
+        const size_t n = std::min(STAGE_BYTES, bytes - done);
+        if (used[slot]) SY_HIP(hipEventSynchronize(stage_ev[slot]));   // previous copy out of this buffer finished
+        memcpy(stage[slot], (const char*)src + done, n);
+        SY_HIP(hipMemcpyAsync((char*)dev_dst + done, stage[slot], n, hipMemcpyHostToDevice, stream));
+        SY_HIP(hipEventRecord(stage_ev[slot], stream));
+        used[slot] = true;
+        done += n;
+        slot ^= 1;
+    }
+    // both staging buffers must be free again before another h2d/d2h reuses them
+    for (int i = 0; i < 2; i++)
+        if (used[i]) SY_HIP(hipEventSynchronize(stage_ev[i]));
+}
 
 extern "C" {
 
@@ -72,7 +173,11 @@ int sylph_ctx_create(int device, void* stream, sylph_ctx** out) {
         DeviceGuard dg(device);
         sylph_ctx* ctx = new sylph_ctx();
         ctx->device = device;
+        ctx->tmp_sort.ctx = ctx;
+        ctx->counters.ctx = ctx;
+        for (auto& b : ctx->scratch) b.ctx = ctx;
         try {
+            SY_HIP(hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault));
             if (stream) ctx->stream = (hipStream_t)stream;
             else {
                 SY_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -85,14 +190,32 @@ int sylph_ctx_create(int device, void* stream, sylph_ctx** out) {
 }
 
 void sylph_ctx_destroy(sylph_ctx* ctx) {
-    if (!ctx) return;
+    if (ctx) sylph::ctx_unref(ctx);   // sessions / databases still alive keep the context (and its pool) alive
+}
+
+}  // extern "C"
+
+void sylph::ctx_unref(sylph_ctx* ctx) {
+    if (--ctx->refs > 0) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    ctx->tmp_sort.release();
+    ctx->counters.release();
+    for (auto& b : ctx->scratch) b.release();
+    for (auto& b : ctx->pool_free) (void)hipFree(b.second);
+    ctx->pool_free.clear();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+        if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
+
+extern "C" {
 
 int sylph_ctx_synchronize(sylph_ctx* ctx) {
     return guarded([&] {

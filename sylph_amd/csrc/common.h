@@ -2,17 +2,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/sylph_hip.h"
+
+struct sylph_ctx;
 
 namespace sylph {
 
@@ -58,41 +62,55 @@ int guarded(F&& f) {
     }
 }
 
-// Grow-only device buffer.  Sketch/DB state lives in these for the lifetime of a session; HBM is 288 GB, so
-// capacity is doubled rather than trimmed.
+// Device memory is recycled through a per-context pool: hipMalloc/hipFree cost 0.1-1 ms each and hipFree
+// synchronises the device, which at ~20 allocations per sample would dwarf the kernels (the whole 1 Gbp sketch is
+// ~5 ms of GPU time).  Blocks return to the pool on release and are handed out again to any request they fit;
+// everything runs on the one ctx stream, so stream order makes the reuse safe.  HBM is 288 GB: capacity is
+// rounded up generously rather than trimmed.
+void* pool_acquire(sylph_ctx* ctx, size_t bytes, size_t* cap_out);
+void pool_release(sylph_ctx* ctx, void* p, size_t cap);
+
+// Grow-only device buffer backed by the ctx pool (or plain hipMalloc when ctx == nullptr).
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    sylph_ctx* ctx = nullptr;
     DevBuf() = default;
+    explicit DevBuf(sylph_ctx* c) : ctx(c) {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (ctx) pool_release(ctx, p, cap);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
+    }
+    void alloc(size_t want) {
+        if (ctx) p = pool_acquire(ctx, want, &cap);
+        else { SY_HIP(hipMalloc(&p, want)); cap = want; }
     }
     // Ensure capacity >= bytes; contents are NOT preserved.
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
         release();
-        size_t want = bytes + bytes / 4 + 256;
-        SY_HIP(hipMalloc(&p, want));
-        cap = want;
+        alloc(bytes + bytes / 4 + 256);
     }
     // Ensure capacity >= bytes keeping the first `keep` bytes (device-to-device copy on `s`).
     void grow_keep(size_t bytes, size_t keep, hipStream_t s) {
         if (bytes <= cap) return;
-        size_t want = bytes * 2 + 256;
-        void* np = nullptr;
-        SY_HIP(hipMalloc(&np, want));
-        if (keep && p) {
-            SY_HIP(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, s));
-            SY_HIP(hipStreamSynchronize(s));
+        void* old = p;
+        const size_t old_cap = cap;
+        p = nullptr;
+        cap = 0;
+        alloc(bytes * 2 + 256);
+        if (keep && old) SY_HIP(hipMemcpyAsync(p, old, keep, hipMemcpyDeviceToDevice, s));
+        if (old) {
+            if (ctx) pool_release(ctx, old, old_cap);   // stream-ordered: the copy above is queued before any reuse
+            else { SY_HIP(hipStreamSynchronize(s)); (void)hipFree(old); }
         }
-        if (p) (void)hipFree(p);
-        p = np;
-        cap = want;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -106,17 +124,31 @@ struct sylph_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::mutex mu;                          // serialises calls on this ctx
+    std::atomic<int> refs{1};               // the creator + every live session / db; freed when it drops to 0
     // profiling
     bool profile = false;
     std::map<std::string, sylph::KernelStat> stats;
     struct Pending { std::string fam; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
+    // device memory pool (free blocks), see pool_acquire
+    std::vector<std::pair<size_t, void*>> pool_free;
+    size_t pool_bytes = 0;
     // scratch
     sylph::DevBuf tmp_sort;                 // rocPRIM temporary storage
     sylph::DevBuf scratch[8];
     sylph::DevBuf counters;                 // small device words (survivor counters etc.)
-    void* pinned = nullptr;                 // small pinned host mirror for counters
+    void* pinned = nullptr;                 // 4 KiB pinned host page for small read-backs
+    // small synchronous device->host read through the pinned page (pageable D2H copies are staged and slow)
+    void read_back(void* dst, const void* dev_src, size_t bytes);
+    // Bulk transfers between caller-owned PAGEABLE host memory and the device always go through two library-owned
+    // pinned staging buffers.  Handing pageable pointers to hipMemcpyAsync makes the runtime pin the caller's pages;
+    // when the caller then frees them (munmap) the driver evicts this process's GPU queues for ~20 ms.
+    static constexpr size_t STAGE_BYTES = 32u << 20;
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    void d2h(void* dst, const void* dev_src, size_t bytes);     // synchronous on return
+    void h2d(void* dev_dst, const void* src, size_t bytes);     // queued on `stream`; src may be reused on return
 };
 
 namespace sylph {
@@ -129,7 +161,19 @@ struct ScopedKernelTimer {
     ScopedKernelTimer(sylph_ctx* c, const char* family);
     ~ScopedKernelTimer();
 };
-void profile_collect(sylph_ctx* ctx);       // resolves pending event pairs into ctx->stats (synchronises them)
+void profile_collect(sylph_ctx* ctx);
+void ctx_unref(sylph_ctx* ctx);             // drops one reference; destroys the ctx at zero       // resolves pending event pairs into ctx->stats (synchronises them)
+
+// SYLPH_HIP_TRACE=1: print the wall time of each host-side phase (stream-synchronised) to stderr.
+struct HostPhase {
+    sylph_ctx* ctx;
+    const char* name;
+    double t0 = 0;
+    static bool enabled() { static const bool e = getenv("SYLPH_HIP_TRACE") != nullptr; return e; }
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    HostPhase(sylph_ctx* c, const char* n) : ctx(c), name(n) { if (enabled()) { (void)hipStreamSynchronize(c->stream); t0 = now(); } }
+    ~HostPhase() { if (enabled()) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[sylph_hip] %-28s %8.3f ms\n", name, now() - t0); } }
+};
 
 struct DeviceGuard {
     int prev = -1;

@@ -17,11 +17,13 @@
 namespace sylph {
 namespace {
 
+// gid[i] = genome of posting i: one workgroup per genome streams its id over the genome's range
 __global__ __launch_bounds__(256) void fill_gid_kernel(const uint64_t* __restrict__ genome_off, uint64_t n_genomes,
-                                                       uint32_t* __restrict__ gid, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    gid[i] = (uint32_t)find_record(genome_off, n_genomes, i);
+                                                       uint32_t* __restrict__ gid) {
+    for (uint64_t g = blockIdx.x; g < n_genomes; g += gridDim.x) {
+        const uint64_t b = genome_off[g], e = genome_off[g + 1];
+        for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) gid[i] = (uint32_t)g;
+    }
 }
 
 __global__ __launch_bounds__(256) void genome_len_kernel(const uint64_t* __restrict__ genome_off, uint64_t n_genomes,
@@ -132,6 +134,9 @@ struct sylph_db {
     DevBuf kmer, gid, bucket_start, glen;
     // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
     DevBuf q_kmers, q_counts, hits, hits_sorted, cov_off, ccount, covs, counter;
+    explicit sylph_db(sylph_ctx* cx)
+        : ctx(cx), kmer(cx), gid(cx), bucket_start(cx), glen(cx), q_kmers(cx), q_counts(cx), hits(cx), hits_sorted(cx),
+          cov_off(cx), ccount(cx), covs(cx), counter(cx) {}
 };
 
 static uint32_t grid_for64(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
@@ -147,12 +152,11 @@ int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genom
         SY_REQUIRE(n_genomes == 0 || genome_off, "null genome_off");
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard dg(ctx->device);
-        std::unique_ptr<sylph_db> db(new sylph_db());
-        db->ctx = ctx;
+        std::unique_ptr<sylph_db> db(new sylph_db(ctx));
         db->n_genomes = n_genomes;
         db->counter.reserve(64);
         uint64_t n = 0;
-        DevBuf d_off_buf, d_in;
+        DevBuf d_off_buf(ctx), d_in(ctx);
         const uint64_t* d_off = nullptr;
         const uint64_t* d_kmers_in = nullptr;
         if (n_genomes) {
@@ -160,17 +164,16 @@ int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genom
                 SY_REQUIRE(genome_off[0] == 0, "genome_off[0] must be 0");
                 n = genome_off[n_genomes];
                 d_off_buf.reserve((n_genomes + 1) * 8);
-                SY_HIP(hipMemcpyAsync(d_off_buf.p, genome_off, (n_genomes + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+                ctx->h2d(d_off_buf.p, genome_off, (n_genomes + 1) * 8);
                 d_off = d_off_buf.as<uint64_t>();
                 if (n) {
                     SY_REQUIRE(kmers, "null kmers");
                     d_in.reserve(n * 8);
-                    SY_HIP(hipMemcpyAsync(d_in.p, kmers, n * 8, hipMemcpyHostToDevice, ctx->stream));
+                    ctx->h2d(d_in.p, kmers, n * 8);
                     d_kmers_in = d_in.as<uint64_t>();
                 }
             } else {
-                SY_HIP(hipMemcpyAsync(&n, genome_off + n_genomes, 8, hipMemcpyDeviceToHost, ctx->stream));
-                SY_HIP(hipStreamSynchronize(ctx->stream));
+                ctx->read_back(&n, genome_off + n_genomes, 8);
                 d_off = genome_off;
                 d_kmers_in = kmers;
             }
@@ -183,17 +186,16 @@ int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genom
                                db->glen.as<uint32_t>());
         if (n) {
             ScopedKernelTimer t(ctx, "db_index");
-            DevBuf gid_in;
+            DevBuf gid_in(ctx);
             gid_in.reserve(n * 4);
             db->kmer.reserve(n * 8);
             db->gid.reserve(n * 4);
-            hipLaunchKernelGGL(fill_gid_kernel, dim3(grid_for64(n)), dim3(256), 0, ctx->stream, d_off, n_genomes,
-                               gid_in.as<uint32_t>(), n);
+            hipLaunchKernelGGL(fill_gid_kernel, dim3((uint32_t)std::min<uint64_t>(n_genomes, 1u << 20)), dim3(256), 0,
+                               ctx->stream, d_off, n_genomes, gid_in.as<uint32_t>());
             sort_pairs_u64_u32(ctx, d_kmers_in, db->kmer.as<uint64_t>(), gid_in.as<uint32_t>(), db->gid.as<uint32_t>(), n, 0,
                                64);
             uint64_t max_key = 0;
-            SY_HIP(hipMemcpyAsync(&max_key, db->kmer.as<uint64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-            SY_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->read_back(&max_key, db->kmer.as<uint64_t>() + (n - 1), 8);
             // ~8 postings per bucket on average (one or two 64 B sectors), index <= 2^28 entries
             int b = bit_length(n / 8);
             b = std::min(28, std::max(8, b));
@@ -207,6 +209,7 @@ int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genom
             SY_HIP(hipGetLastError());
             SY_HIP(hipStreamSynchronize(ctx->stream));   // d_in / gid_in are released on return
         }
+        ctx->refs++;
         *out = db.release();
     });
 }
@@ -232,8 +235,8 @@ int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t*
             if (mem == SYLPH_MEM_HOST) {
                 db->q_kmers.reserve(n * 8);
                 db->q_counts.reserve(n * 4);
-                SY_HIP(hipMemcpyAsync(db->q_kmers.p, sample_kmers, n * 8, hipMemcpyHostToDevice, ctx->stream));
-                SY_HIP(hipMemcpyAsync(db->q_counts.p, sample_counts, n * 4, hipMemcpyHostToDevice, ctx->stream));
+                ctx->h2d(db->q_kmers.p, sample_kmers, n * 8);
+                ctx->h2d(db->q_counts.p, sample_counts, n * 4);
                 d_k = db->q_kmers.as<uint64_t>();
                 d_c = db->q_counts.as<uint32_t>();
             }
@@ -251,8 +254,7 @@ int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t*
                                        min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
                     SY_HIP(hipGetLastError());
                 }
-                SY_HIP(hipMemcpyAsync(&n_hits, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-                SY_HIP(hipStreamSynchronize(ctx->stream));
+                ctx->read_back(&n_hits, d_cnt, 4);
                 if (n_hits <= cap) break;
                 SY_REQUIRE(attempt == 0, "hit buffer overflow persisted");
                 cap = n_hits;
@@ -275,10 +277,9 @@ int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t*
         uint32_t* hcov = (uint32_t*)malloc(std::max<size_t>(1, n_hits) * 4);
         if (!hcov) throw std::bad_alloc();
         try {
-            SY_HIP(hipMemcpyAsync(cov_off, db->cov_off.p, (G + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-            if (G) SY_HIP(hipMemcpyAsync(contain_count, db->ccount.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (n_hits) SY_HIP(hipMemcpyAsync(hcov, db->covs.p, (size_t)n_hits * 4, hipMemcpyDeviceToHost, ctx->stream));
-            SY_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->d2h(cov_off, db->cov_off.p, (G + 1) * 8);
+            ctx->d2h(contain_count, db->ccount.p, G * 4);
+            ctx->d2h(hcov, db->covs.p, (size_t)n_hits * 4);
         } catch (...) { free(hcov); throw; }
         *out_covs = hcov;
     });
@@ -286,11 +287,12 @@ int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t*
 
 void sylph_db_destroy(sylph_db* db) {
     if (!db) return;
+    sylph_ctx* ctx = db->ctx;
     {
-        std::lock_guard<std::mutex> lock(db->ctx->mu);
-        (void)hipStreamSynchronize(db->ctx->stream);
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        delete db;
     }
-    delete db;
+    ctx_unref(ctx);
 }
 
 }  // extern "C"

@@ -30,61 +30,84 @@ constexpr uint64_t RID_MARKER_BIT = 1ull << 63;   // rid: bit63 = has marker, lo
 constexpr uint64_t RID_MASK = RID_MARKER_BIT - 1;
 constexpr uint64_t INVALID_HASH = ~0ull;
 
+// 32 consecutive bases starting at p (any alignment) -> (even-position 16-mer, odd-position 16-mer), each base a
+// 2-bit BYTE_TO_SEQ code, first base most significant (the order pair_kmer[_single] builds them in,
+// sketch.rs:636-653,:668-685).  Four unaligned 8-byte loads instead of 32 byte loads.
+__device__ __forceinline__ void marker_halves(const uint8_t* __restrict__ p, uint32_t& even, uint32_t& odd) {
+    uint32_t e = 0, o = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint64_t x;
+        __builtin_memcpy(&x, p + 8 * w, 8);
+        uint32_t bad = 0;
+        uint32_t lo = codes4_fast((uint32_t)x, bad), hi = codes4_fast((uint32_t)(x >> 32), bad);
+        if (bad) { lo = codes4_exact((uint32_t)x); hi = codes4_exact((uint32_t)(x >> 32)); }
+        // byte lanes b0..b3 of lo, b4..b7 of hi hold bases 8w..8w+7
+        const uint32_t ev = ((lo & 3u) << 6) | (((lo >> 16) & 3u) << 4) | ((hi & 3u) << 2) | ((hi >> 16) & 3u);
+        const uint32_t od = (((lo >> 8) & 3u) << 6) | (((lo >> 24) & 3u) << 4) | (((hi >> 8) & 3u) << 2) | ((hi >> 24) & 3u);
+        e = (e << 8) | ev;
+        o = (o << 8) | od;
+    }
+    even = e;
+    odd = o;
+}
+
 // ---- K2: annotate survivors of one batch (already sorted by flat position) ---------------------------------
 // Validates that the k-mer lies inside one record and among the k-mers the reference hashes, finds the record,
 // and computes the dedup markers.  Invalid survivors get hash = ~0 (sorts last, dropped in finish()).
+// Survivors arrive sorted by position, so a workgroup's 256 survivors span a short run of records: two lanes do
+// the full binary search for the first and last survivor, everyone else searches only inside that run.
 __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
     const uint64_t* __restrict__ hash, uint32_t n, uint32_t k, int avx2_compat, int paired, int want_markers,
     uint64_t rec_base, uint64_t* __restrict__ o_hash, uint64_t* __restrict__ o_rid, uint64_t* __restrict__ o_m0,
     uint64_t* __restrict__ o_m1, unsigned long long* __restrict__ n_valid) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint64_t s_lo, s_hi;
+    const uint32_t first = blockIdx.x * blockDim.x;
+    const uint32_t i = first + threadIdx.x;
+    const uint64_t total = off[n_rec];
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+        const uint32_t j = threadIdx.x == 0 ? first : min(n, first + blockDim.x) - 1;
+        uint64_t p = pos[j];
+        if (total && p >= total) p = total - 1;
+        const uint64_t r = total ? find_record(off, n_rec, p) : 0;
+        if (threadIdx.x == 0) s_lo = r; else s_hi = r + 1;
+    }
+    __syncthreads();
     if (i >= n) return;
     const uint64_t p = pos[i];
     uint64_t h = hash[i], rid = 0, m0 = 0, m1 = 0;
-    const uint64_t total = off[n_rec];
     bool valid = false;
     if (p < total) {
-        const uint64_t r = find_record(off, n_rec, p);
+        uint64_t lo = s_lo, hi = s_hi;   // off[lo] <= p < off[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (off[mid] <= p) lo = mid; else hi = mid;
+        }
+        const uint64_t r = lo;
         const uint64_t start = off[r], L = off[r + 1] - start;
         valid = (p - start) < n_hashed_kmers(L, k, avx2_compat, 0);
         if (valid) {
             rid = rec_base + r;
             if (want_markers) {
+                const uint8_t* a = nullptr;
+                const uint8_t* b = nullptr;
                 if (!paired) {
                     // pair_kmer_single, sketch.rs:625-656; caller passes None above 400 bp (sketch.rs:922-927)
-                    if (L >= 66 && L <= 400) {
-                        const uint8_t* s = bases + start;
-                        const uint64_t half = L / 2;
-                        uint32_t f = 0, g = 0, rr = 0, t = 0;
-                        for (int j = 0; j < 16; j++) {
-                            f = (f << 2) | byte_to_seq(s[2 * j]);
-                            rr = (rr << 2) | byte_to_seq(s[2 * j + half]);
-                            g = (g << 2) | byte_to_seq(s[1 + 2 * j]);
-                            t = (t << 2) | byte_to_seq(s[1 + 2 * j + half]);
-                        }
-                        m0 = (uint64_t)f | ((uint64_t)rr << 32);
-                        m1 = (uint64_t)g | ((uint64_t)t << 32);
-                        rid |= RID_MARKER_BIT;
-                    }
+                    if (L >= 66 && L <= 400) { a = bases + start; b = a + L / 2; }
                 } else {
                     // pair_kmer, sketch.rs:659-688: both mates >= 33 bp
                     const uint64_t r1 = r & ~1ull;
                     const uint64_t s1 = off[r1], s2 = off[r1 + 1], e2 = off[r1 + 2];
-                    if (s2 - s1 >= 33 && e2 - s2 >= 33) {
-                        const uint8_t* a = bases + s1;
-                        const uint8_t* b = bases + s2;
-                        uint32_t f = 0, g = 0, rr = 0, t = 0;
-                        for (int j = 0; j < 16; j++) {
-                            f = (f << 2) | byte_to_seq(a[2 * j]);
-                            rr = (rr << 2) | byte_to_seq(b[2 * j]);
-                            g = (g << 2) | byte_to_seq(a[1 + 2 * j]);
-                            t = (t << 2) | byte_to_seq(b[1 + 2 * j]);
-                        }
-                        m0 = (uint64_t)f | ((uint64_t)rr << 32);
-                        m1 = (uint64_t)g | ((uint64_t)t << 32);
-                        rid |= RID_MARKER_BIT;
-                    }
+                    if (s2 - s1 >= 33 && e2 - s2 >= 33) { a = bases + s1; b = bases + s2; }
+                }
+                if (a) {
+                    uint32_t f, g, rr, t;
+                    marker_halves(a, f, g);    // f: bases 0,2,..,30   g: bases 1,3,..,31
+                    marker_halves(b, rr, t);
+                    m0 = (uint64_t)f | ((uint64_t)rr << 32);
+                    m1 = (uint64_t)g | ((uint64_t)t << 32);
+                    rid |= RID_MARKER_BIT;
                 }
             }
         }
@@ -192,25 +215,57 @@ __global__ __launch_bounds__(256) void dup_flags_kernel(const uint64_t* __restri
     flags[i] = fl;
 }
 
-// K3c: one lane per k-mer walks its occurrences once (sketch.rs:701-730 count / cut-off logic).
-__global__ __launch_bounds__(256) void count_kernel(const uint64_t* __restrict__ hs, const uint32_t* __restrict__ head,
-                                                    const uint32_t* __restrict__ seg_id, const uint8_t* __restrict__ flags,
-                                                    uint32_t n, int no_dedup, uint32_t cutoff /*0 = none*/,
-                                                    uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
-                                                    unsigned long long* __restrict__ removed_total) {
+// K3c.  With u_i = 1 if occurrence i would be counted were there no cut-off (processed and not dropped) and
+// P_i = number of such occurrences before i inside its k-mer (a segmented exclusive prefix sum), the reference's
+// walk (sketch.rs:701-730) reduces to:  counted_i = (cutoff && P_i >= cutoff) ? 1 : u_i   (once the count has
+// reached MAX_DEDUP_COUNT nothing is ever dropped again, :706), removed_i = processed_i && !counted_i.
+__global__ __launch_bounds__(256) void would_count_kernel(const uint8_t* __restrict__ flags, uint32_t n, int no_dedup,
+                                                          uint32_t* __restrict__ u) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !head[i]) return;
-    const uint64_t h = hs[i];
-    uint32_t c = 0, removed = 0;
-    for (uint32_t j = i; j < n && hs[j] == h; j++) {
-        const uint8_t fl = flags[j];
-        if (fl & 1) continue;                                     // sketch.rs:852
-        if (no_dedup || (cutoff && c >= cutoff)) { c++; continue; }   // :706
-        if (fl & 2) removed++; else c++;                          // :723-730
+    if (i > n) return;
+    if (i == n) { u[i] = 0; return; }   // sentinel so the exclusive scan has n+1 entries
+    const uint8_t fl = flags[i];
+    u[i] = (fl & 1) ? 0u : ((no_dedup || !(fl & 2)) ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(256) void counted_kernel(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ Eu,
+                                                      const uint32_t* __restrict__ seg_start, uint32_t n, int no_dedup,
+                                                      uint32_t cutoff, uint32_t* __restrict__ counted,
+                                                      unsigned long long* __restrict__ removed_total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t removed = 0;
+    if (i < n) {
+        const uint8_t fl = flags[i];
+        uint32_t c = 0;
+        if (!(fl & 1)) {
+            const uint32_t P = Eu[i] - Eu[seg_start[i]];
+            const bool u = no_dedup || !(fl & 2);
+            c = (cutoff && P >= cutoff) ? 1u : (u ? 1u : 0u);
+            removed = c ? 0u : 1u;
+        }
+        counted[i] = c;
+    } else if (i == n) {
+        counted[i] = 0;
     }
-    out_k[seg_id[i]] = h;
-    out_c[seg_id[i]] = c;
-    if (removed) atomicAdd(removed_total, (unsigned long long)removed);
+    if (removed) atomicAdd(removed_total, 1ull);   // wave-aggregated
+}
+
+// start[s] = index of the first occurrence of k-mer s (start[n_seg] = n)
+__global__ __launch_bounds__(256) void seg_starts_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ seg_id,
+                                                         uint32_t n, uint32_t n_seg, uint32_t* __restrict__ start) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && head[i]) start[seg_id[i]] = i;
+    if (i == 0) start[n_seg] = n;
+}
+
+__global__ __launch_bounds__(256) void emit_table_kernel(const uint64_t* __restrict__ hs, const uint32_t* __restrict__ start,
+                                                         const uint32_t* __restrict__ Ec, uint32_t n_seg,
+                                                         uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const uint32_t a = start[s], b = start[s + 1];
+    out_k[s] = hs[a];
+    out_c[s] = Ec[b] - Ec[a];
 }
 
 }  // namespace
@@ -230,6 +285,8 @@ struct sylph_sketch {
     DevBuf out_k, out_c;           // final table
     uint64_t n_out = 0, dup_removed = 0;
     DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
+    explicit sylph_sketch(sylph_ctx* cx)
+        : ctx(cx), hash(cx), rid(cx), m0(cx), m1(cx), batch_bases(cx), batch_off(cx), out_k(cx), out_c(cx), counters(cx) {}
 };
 
 namespace sylph {
@@ -245,18 +302,19 @@ static uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint
     if (cap > n_bases) cap = n_bases;
     uint32_t n = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
+        HostPhase ph(ctx, "push: seeds kernel");
         ctx->scratch[0].reserve(cap * 8);   // hash (unsorted)
         ctx->scratch[1].reserve(cap * 4);   // pos (unsorted)
         SY_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
         launch_seeds(ctx, d_bases, (uint32_t)n_bases, c, k, ctx->scratch[0].as<uint64_t>(), ctx->scratch[1].as<uint32_t>(),
                      (uint32_t)cap, d_count);
-        SY_HIP(hipMemcpyAsync(&n, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->read_back(&n, d_count, 4);
         if (n <= cap) break;
         cap = n;                            // the counter kept counting: exact size for the retry
         SY_REQUIRE(attempt == 0, "seed buffer overflow persisted");
     }
     if (n == 0) return 0;
+    HostPhase ph(ctx, "push: sort by position");
     ctx->scratch[2].reserve((size_t)n * 4);
     ctx->scratch[3].reserve((size_t)n * 8);
     sort_pairs_u32_u64(ctx, ctx->scratch[1].as<uint32_t>(), ctx->scratch[2].as<uint32_t>(), ctx->scratch[0].as<uint64_t>(),
@@ -273,6 +331,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     SY_REQUIRE(rec_off, "null rec_off");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
+    HostPhase ph_total(ctx, "push: total");
     const uint8_t* d_bases;
     const uint64_t* d_off;
     uint64_t n_bases;
@@ -282,14 +341,13 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         SY_REQUIRE(bases || n_bases == 0, "null bases");
         sk->batch_bases.reserve(n_bases + 64);
         sk->batch_off.reserve((n_records + 1) * 8);
-        if (n_bases) SY_HIP(hipMemcpyAsync(sk->batch_bases.p, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
-        SY_HIP(hipMemcpyAsync(sk->batch_off.p, rec_off, (n_records + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(sk->batch_bases.p, bases, n_bases);
+        ctx->h2d(sk->batch_off.p, rec_off, (n_records + 1) * 8);
         d_bases = sk->batch_bases.as<uint8_t>();
         d_off = sk->batch_off.as<uint64_t>();
     } else {
         SY_REQUIRE(((uintptr_t)bases & 15) == 0, "device bases pointer must be 16-byte aligned");
-        SY_HIP(hipMemcpyAsync(&n_bases, rec_off + n_records, 8, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->read_back(&n_bases, rec_off + n_records, 8);
         SY_REQUIRE(bases || n_bases == 0, "null bases");
         d_bases = bases;
         d_off = rec_off;
@@ -297,6 +355,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     uint32_t* d_count = sk->counters.as<uint32_t>();
     const uint32_t n = seeds_sorted_by_pos(ctx, d_bases, n_bases, sk->c, sk->k, d_count);
     if (n) {
+        HostPhase ph(ctx, "push: grow + annotate");
         const uint64_t need = sk->n_occ + n;
         const size_t keep = sk->n_occ * 8;
         sk->hash.grow_keep(need * 8, keep, ctx->stream);
@@ -314,7 +373,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         sk->n_occ = need;
     }
     sk->rec_base += n_records;
-    // host staging buffers are reused by the next push: make sure this batch is consumed
+    // device staging buffers are reused by the next push: make sure this batch is consumed
     if (mem == SYLPH_MEM_HOST) SY_HIP(hipStreamSynchronize(ctx->stream));
 }
 
@@ -323,33 +382,41 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     sylph_ctx* ctx = sk->ctx;
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
+    HostPhase ph_total(ctx, "finish: total incl. readback");
     unsigned long long n_valid = 0;
-    SY_HIP(hipMemcpyAsync(&n_valid, sk->counters.as<uint8_t>() + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SY_HIP(hipStreamSynchronize(ctx->stream));
-    SY_REQUIRE(sk->n_occ < (1ull << 32), "more than 2^32-1 seed occurrences in one sample");
+    ctx->read_back(&n_valid, sk->counters.as<uint8_t>() + 8, 8);
+    SY_REQUIRE(sk->n_occ < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
     const uint32_t n_all = (uint32_t)sk->n_occ, nv = (uint32_t)n_valid;
     sk->n_out = 0;
     sk->dup_removed = 0;
     if (nv) {
+        HostPhase ph_all(ctx, "finish: total");
         // stable sort by hash; invalid occurrences carry ~0 and end up behind the nv valid ones
         DevBuf &b_idx = ctx->scratch[0], &b_hs = ctx->scratch[1], &b_perm = ctx->scratch[2];
         b_idx.reserve((size_t)n_all * 4);
         b_hs.reserve((size_t)n_all * 8);
         b_perm.reserve((size_t)n_all * 4);
-        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_all)), dim3(256), 0, ctx->stream, b_idx.as<uint32_t>(), n_all);
-        sort_pairs_u64_u32(ctx, sk->hash.as<uint64_t>(), b_hs.as<uint64_t>(), b_idx.as<uint32_t>(), b_perm.as<uint32_t>(),
-                           n_all, 0, 64);
+        {
+            HostPhase ph(ctx, "finish: sort by hash");
+            hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_all)), dim3(256), 0, ctx->stream, b_idx.as<uint32_t>(), n_all);
+            sort_pairs_u64_u32(ctx, sk->hash.as<uint64_t>(), b_hs.as<uint64_t>(), b_idx.as<uint32_t>(),
+                               b_perm.as<uint32_t>(), n_all, 0, 64);
+        }
+        HostPhase ph_replay(ctx, "finish: replay");
         DevBuf &b_rid = ctx->scratch[3], &b_m0 = ctx->scratch[4], &b_m1 = ctx->scratch[5], &b_u32 = ctx->scratch[6],
                &b_fl = ctx->scratch[7];
+        const size_t nv1 = (size_t)nv + 1;
         b_rid.reserve((size_t)nv * 8);
         b_m0.reserve((size_t)nv * 8);
         b_m1.reserve((size_t)nv * 8);
-        b_u32.reserve((size_t)nv * 4 * 4);   // head | headidx | seg_start | seg_id
+        b_u32.reserve(nv1 * 4 * 6);          // head | headidx->Eu | seg_start | seg_id | u->counted | Ec/start
         b_fl.reserve((size_t)nv * 2);        // skip | flags
         uint32_t* head = b_u32.as<uint32_t>();
-        uint32_t* headidx = head + nv;
-        uint32_t* seg_start = headidx + nv;
-        uint32_t* seg_id = seg_start + nv;
+        uint32_t* headidx = head + nv1;      // reused as Eu (exclusive sum of u) once seg_start exists
+        uint32_t* seg_start = headidx + nv1;
+        uint32_t* seg_id = seg_start + nv1;
+        uint32_t* uc = seg_id + nv1;         // u, then counted
+        uint32_t* Ec = uc + nv1;             // exclusive sum of counted
         uint8_t* skip = b_fl.as<uint8_t>();
         uint8_t* flags = skip + nv;
         const uint64_t* hs = b_hs.as<uint64_t>();
@@ -361,15 +428,9 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         }
         inclusive_max_u32(ctx, headidx, seg_start, nv);
         exclusive_sum_u32(ctx, head, seg_id, nv);
-        uint32_t last_id = 0, last_head = 0;
-        SY_HIP(hipMemcpyAsync(&last_id, seg_id + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipMemcpyAsync(&last_head, head + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipStreamSynchronize(ctx->stream));
-        const uint32_t n_seg = last_id + last_head;
-        sk->out_k.reserve((size_t)n_seg * 8);
-        sk->out_c.reserve((size_t)n_seg * 4);
         unsigned long long* d_removed = reinterpret_cast<unsigned long long*>(sk->counters.as<uint8_t>() + 16);
         SY_HIP(hipMemsetAsync(d_removed, 0, 8, ctx->stream));
+        uint32_t* Eu = headidx;
         {
             ScopedKernelTimer t(ctx, "replay");
             const uint8_t* skip_arg = nullptr;
@@ -383,14 +444,34 @@ static void sketch_finish_impl(sylph_sketch* sk) {
                                    b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), seg_start, skip_arg, nv, flags);
             else
                 SY_HIP(hipMemsetAsync(flags, 0, nv, ctx->stream));
-            hipLaunchKernelGGL(count_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, hs, head, seg_id, flags, nv,
-                               sk->no_dedup, sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */,
-                               sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>(), d_removed);
+            hipLaunchKernelGGL(would_count_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, nv, sk->no_dedup, uc);
+        }
+        exclusive_sum_u32(ctx, uc, Eu, nv1);
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            hipLaunchKernelGGL(counted_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, Eu, seg_start, nv,
+                               sk->no_dedup, sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, uc, d_removed);
+        }
+        exclusive_sum_u32(ctx, uc, Ec, nv1);
+        uint32_t tail[2] = {0, 0};   // seg_id and head of the last occurrence -> number of distinct k-mers
+        SY_HIP(hipMemcpyAsync(ctx->pinned, seg_id + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 4, head + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 8, d_removed, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(tail, ctx->pinned, 8);
+        unsigned long long removed = 0;
+        memcpy(&removed, (uint8_t*)ctx->pinned + 8, 8);
+        const uint32_t n_seg = tail[0] + tail[1];
+        sk->out_k.reserve((size_t)n_seg * 8);
+        sk->out_c.reserve((size_t)n_seg * 4);
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            uint32_t* start = seg_start;   // seg_start is dead now: reuse as start[n_seg+1]
+            hipLaunchKernelGGL(seg_starts_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, head, seg_id, nv, n_seg, start);
+            hipLaunchKernelGGL(emit_table_kernel, dim3(grid_for(n_seg)), dim3(256), 0, ctx->stream, hs, start, Ec, n_seg,
+                               sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>());
             SY_HIP(hipGetLastError());
         }
-        unsigned long long removed = 0;
-        SY_HIP(hipMemcpyAsync(&removed, d_removed, 8, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipStreamSynchronize(ctx->stream));
         sk->n_out = n_seg;
         sk->dup_removed = removed;
     }
@@ -413,15 +494,15 @@ static void seeds_positions_impl(sylph_ctx* ctx, const uint8_t* bases, const uin
     DeviceGuard dg(ctx->device);
     const uint64_t n_bases = contig_off[n_contigs];
     SY_REQUIRE(n_bases < (1ull << 32), "genome larger than 2^32-1 bases: split by contig");
-    DevBuf d_bases, d_off;
+    DevBuf d_bases(ctx), d_off(ctx);
     d_bases.reserve(n_bases + 64);
     d_off.reserve((n_contigs + 1) * 8);
-    if (n_bases) SY_HIP(hipMemcpyAsync(d_bases.p, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
-    SY_HIP(hipMemcpyAsync(d_off.p, contig_off, (n_contigs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(d_bases.p, bases, n_bases);
+    ctx->h2d(d_off.p, contig_off, (n_contigs + 1) * 8);
     ctx->counters.reserve(64);
     const uint32_t n = seeds_sorted_by_pos(ctx, d_bases.as<uint8_t>(), n_bases, c, k, ctx->counters.as<uint32_t>());
     if (!n) return;
-    DevBuf o_contig, o_pos, o_hash;
+    DevBuf o_contig(ctx), o_pos(ctx), o_hash(ctx);
     o_contig.reserve((size_t)n * 4);
     o_pos.reserve((size_t)n * 8);
     o_hash.reserve((size_t)n * 8);
@@ -435,10 +516,9 @@ static void seeds_positions_impl(sylph_ctx* ctx, const uint8_t* bases, const uin
     }
     std::vector<uint32_t> hc(n);
     std::vector<uint64_t> hp(n), hh(n);
-    SY_HIP(hipMemcpyAsync(hc.data(), o_contig.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SY_HIP(hipMemcpyAsync(hp.data(), o_pos.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    SY_HIP(hipMemcpyAsync(hh.data(), o_hash.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    SY_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(hc.data(), o_contig.p, (size_t)n * 4);
+    ctx->d2h(hp.data(), o_pos.p, (size_t)n * 8);
+    ctx->d2h(hh.data(), o_hash.p, (size_t)n * 8);
     out.contig.reserve(n); out.pos.reserve(n); out.hash.reserve(n);
     for (uint32_t i = 0; i < n; i++) {
         if (hh[i] == INVALID_HASH) continue;   // straddled a contig boundary / AVX2 tail / short contig
@@ -468,8 +548,8 @@ int sylph_sketch_begin(sylph_ctx* ctx, uint32_t c, uint32_t k, int reads_mode, i
         SY_REQUIRE(seed_mode == SYLPH_SEED_SCALAR || seed_mode == SYLPH_SEED_AVX2_COMPAT, "bad seed_mode %d", seed_mode);
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard dg(ctx->device);
-        sylph_sketch* sk = new sylph_sketch();
-        sk->ctx = ctx; sk->c = c; sk->k = k;
+        sylph_sketch* sk = new sylph_sketch(ctx);
+        sk->c = c; sk->k = k;
         sk->paired = reads_mode == SYLPH_READS_PAIRED;
         sk->no_dedup = no_dedup != 0;
         sk->avx2_compat = seed_mode == SYLPH_SEED_AVX2_COMPAT;
@@ -477,6 +557,7 @@ int sylph_sketch_begin(sylph_ctx* ctx, uint32_t c, uint32_t k, int reads_mode, i
             sk->counters.reserve(64);
             SY_HIP(hipMemsetAsync(sk->counters.p, 0, 64, ctx->stream));
         } catch (...) { delete sk; throw; }
+        ctx->refs++;
         *out = sk;
     });
 }
@@ -513,9 +594,8 @@ int sylph_sketch_finish(sylph_sketch* sk, uint64_t** out_kmers, uint32_t** out_c
             if (n) {
                 std::lock_guard<std::mutex> lock(sk->ctx->mu);
                 DeviceGuard dg(sk->ctx->device);
-                SY_HIP(hipMemcpyAsync(hk, sk->out_k.p, n * 8, hipMemcpyDeviceToHost, sk->ctx->stream));
-                SY_HIP(hipMemcpyAsync(hc, sk->out_c.p, n * 4, hipMemcpyDeviceToHost, sk->ctx->stream));
-                SY_HIP(hipStreamSynchronize(sk->ctx->stream));
+                sk->ctx->d2h(hk, sk->out_k.p, n * 8);
+                sk->ctx->d2h(hc, sk->out_c.p, n * 4);
             }
         } catch (...) { free(hk); free(hc); throw; }
         *out_kmers = hk; *out_counts = hc; *out_n = n;
@@ -525,11 +605,12 @@ int sylph_sketch_finish(sylph_sketch* sk, uint64_t** out_kmers, uint32_t** out_c
 
 void sylph_sketch_destroy(sylph_sketch* sk) {
     if (!sk) return;
+    sylph_ctx* ctx = sk->ctx;
     {
-        std::lock_guard<std::mutex> lock(sk->ctx->mu);
-        (void)hipStreamSynchronize(sk->ctx->stream);
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        delete sk;   // buffers go back to the ctx pool; stream order protects in-flight work
     }
-    delete sk;
+    ctx_unref(ctx);
 }
 
 int sylph_seeds_positions(sylph_ctx* ctx, const uint8_t* bases, const uint64_t* contig_off, uint64_t n_contigs, uint32_t c,
@@ -561,17 +642,16 @@ int sylph_seeds(sylph_ctx* ctx, const uint8_t* bases, uint64_t len, uint32_t c, 
             SY_REQUIRE(len < (1ull << 32), "sequence longer than 2^32-1 bases");
             std::lock_guard<std::mutex> lock(ctx->mu);
             DeviceGuard dg(ctx->device);
-            DevBuf d_bases;
+            DevBuf d_bases(ctx);
             d_bases.reserve(len + 64);
-            SY_HIP(hipMemcpyAsync(d_bases.p, bases, len, hipMemcpyHostToDevice, ctx->stream));
+            ctx->h2d(d_bases.p, bases, len);
             ctx->counters.reserve(64);
             const uint32_t n = seeds_sorted_by_pos(ctx, d_bases.as<uint8_t>(), len, c, k, ctx->counters.as<uint32_t>());
             if (n) {
                 std::vector<uint32_t> hp(n);
                 std::vector<uint64_t> hh(n);
-                SY_HIP(hipMemcpyAsync(hp.data(), ctx->scratch[2].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-                SY_HIP(hipMemcpyAsync(hh.data(), ctx->scratch[3].p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-                SY_HIP(hipStreamSynchronize(ctx->stream));
+                ctx->d2h(hp.data(), ctx->scratch[2].p, (size_t)n * 4);
+                ctx->d2h(hh.data(), ctx->scratch[3].p, (size_t)n * 8);
                 const uint64_t nk = n_hashed_kmers(len, k, seed_mode == SYLPH_SEED_AVX2_COMPAT, 0);
                 for (uint32_t i = 0; i < n; i++)
                     if (hp[i] < nk) res.push_back(hh[i]);
