@@ -57,6 +57,10 @@ def build_database(ctx, device, wl, c, k, seed, rank, world):
     off1 = np.array([0, glen], dtype=np.uint64)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed + 17)
+    # One pinned host buffer for every genome: a pageable .cpu() copy makes the HIP runtime register the destination
+    # pages; when numpy later unmaps them the driver evicts this process's GPU queues (15-40 ms stalls at random
+    # points of the timed region).
+    host_seq = torch.empty(glen, dtype=torch.uint8, pin_memory=True)
     for g in range(n_seq):
         if g < n_comm:
             seq = community[g]
@@ -69,7 +73,9 @@ def build_database(ctx, device, wl, c, k, seed, rank, world):
             seq = torch.where(mask, lut[src.long()], src)
         else:
             seq = synth.random_genomes(1, glen, device, seed + 1000 + g, mutated_frac=0.0)[0]
-        sk = ctx.sketch_genome(seq.cpu().numpy(), off1, c=c, k=k)
+        host_seq.copy_(seq)
+        torch.cuda.current_stream().synchronize()
+        sk = ctx.sketch_genome(host_seq.numpy(), off1, c=c, k=k)
         sketches.append(sk["genome_kmers"])
     t1 = time.time()
     seq_k = np.concatenate(sketches)
@@ -159,8 +165,12 @@ def main():
 
     c, k, read_len = 200, 31, 150
     n_pairs = WORKLOADS[args.workload][0]
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = S.Context(local, stream=stream)
+    # One HIP stream for everything: the library launches on a torch-owned stream, so torch-side generation, the
+    # library's kernels and the timing events are stream-ordered without cross-queue synchronisation.
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    ctx = S.Context(local, stream=stream if not os.environ.get("BENCH_OWN_STREAM") else None)
 
     log(f"[bench] building workload {args.workload} on {world} GPU(s) ...")
     db, mine, lens_mine, n_total, community, dbstats = build_database(ctx, device, args.workload, c, k, args.seed, rank, world)
@@ -193,7 +203,7 @@ def main():
         t_c = time.perf_counter()
         if os.environ.get("SYLPH_BENCH_DEBUG"):
             log(f"[bench] contain {1e3 * (t_c - t_b):.3f} ms")
-        if collect is not None and len(collect) == 0:   # seed occurrences of the sample = sum(counts) + removed
+        if collect is not None and len(collect) == 0 and not os.environ.get("BENCH_NO_OCC"):   # seed occurrences of the sample = sum(counts) + removed
             occ_holder.append(int(SH.device_view(dc, n, torch.int32, device).sum().item()) + dup)
         sk.close()
         if collect is not None:
@@ -206,7 +216,8 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    time.sleep(0.25)
+    if not os.environ.get("BENCH_NO_SLEEP"):
+        time.sleep(0.25)
     for _ in range(args.warmup):
         step()
     ctx.profile(not args.no_kernel_timers)

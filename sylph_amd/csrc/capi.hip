@@ -88,8 +88,13 @@ using namespace sylph;
 
 void sylph_ctx::read_back(void* dst, const void* dev_src, size_t bytes) {
     SY_REQUIRE(bytes <= 4096, "read_back too large");
+    static const bool slowlog = getenv("SYLPH_HIP_SLOWLOG") != nullptr;
+    const double t0 = slowlog ? HostPhase::now() : 0;
     SY_HIP(hipMemcpyAsync(pinned, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    const double t1 = slowlog ? HostPhase::now() : 0;
     SY_HIP(hipStreamSynchronize(stream));
+    if (slowlog && HostPhase::now() - t0 > 3.0)
+        fprintf(stderr, "[sylph_hip] slow read_back: issue %.3f ms, wait %.3f ms\n", t1 - t0, HostPhase::now() - t1);
     memcpy(dst, pinned, bytes);
     // every timing event recorded so far has completed: fold them into the totals and recycle the event objects
     // (creating fresh hipEvents per launch costs far more than the kernels being timed)
@@ -108,6 +113,17 @@ static void ensure_stage(sylph_ctx* c) {
 void sylph_ctx::d2h(void* dst, const void* dev_src, size_t bytes) {
     if (!bytes) { SY_HIP(hipStreamSynchronize(stream)); return; }
     ensure_stage(this);
+    static const int mode = getenv("SYLPH_HIP_D2H_MODE") ? atoi(getenv("SYLPH_HIP_D2H_MODE")) : 0;
+    if (mode == 1) {   // experiment: plain stream syncs, no events
+        for (size_t done = 0; done < bytes;) {
+            const size_t n = std::min(STAGE_BYTES, bytes - done);
+            SY_HIP(hipMemcpyAsync(stage[0], (const char*)dev_src + done, n, hipMemcpyDeviceToHost, stream));
+            SY_HIP(hipStreamSynchronize(stream));
+            memcpy((char*)dst + done, stage[0], n);
+            done += n;
+        }
+        return;
+    }
     // ping-pong: the device fills one pinned buffer while the host drains the other
     size_t issued = 0, done = 0, len[2] = {0, 0};
     int head = 0, tail = 0, inflight = 0;

@@ -18,6 +18,29 @@ __device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
     return key;
 }
 
+// Same function with the instruction selection pinned for gfx950.  Left to itself the compiler folds every
+// "x + (x << n)" into a 64-bit multiply and lowers that to 2-3 v_mad_u64_u32 plus operand shuffling (~15 mads and
+// ~19 v_mov per k-mer).  Measured issue costs on MI355X (tools/valu_rates.hip; VOP2 32-bit op = 1): v_lshl_add_u64
+// 1.9, v_lshlrev/lshrrev_b64 1.6, v_mad_u64_u32 1.9, any VOP3 32-bit op 1.6.  v_lshl_add_u64 (shift <= 4) does
+// x*5 and x*21 in one/two instructions; the NOT of step 1 is folded into step 2 as one xor with a constant:
+//   ~t ^ (~t >> 24)  ==  (t ^ (t >> 24)) ^ 0xFFFFFF0000000000.
+template <int N>
+__device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {   // (a << N) + b, N in 0..4
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(N), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint64_t mm_hash64_gfx950(uint64_t key) {
+    uint64_t t = lshl_add_u64<0>(key << 21, key);                 // key + (key << 21)
+    t = (t ^ (t >> 24)) ^ 0xFFFFFF0000000000ull;                  // ~t, then ^= >> 24
+    t = (uint64_t)(uint32_t)t * 265u + ((uint64_t)((uint32_t)(t >> 32) * 265u) << 32);   // * 265: one v_mad_u64_u32
+    t = t ^ (t >> 14);
+    t = lshl_add_u64<4>(t, lshl_add_u64<2>(t, t));                // * 21
+    t = t ^ (t >> 28);
+    t = lshl_add_u64<0>(t << 31, t);                              // + (t << 31)
+    return t;
+}
+
 // types.rs:50-59 BYTE_TO_SEQ for one byte, computed instead of looked up:
 // A/a=0 C/c=1 G/g=2 T/t/U/u=3; raw bytes 1,2,3 -> 1,2,3; everything else (N, IUPAC, gaps, ...) -> 0.
 __device__ __forceinline__ uint32_t byte_to_seq(uint32_t b) {
@@ -66,6 +89,12 @@ __device__ __host__ __forceinline__ uint64_t n_hashed_kmers(uint64_t L, uint32_t
     const uint64_t min_len = positions ? 2ull * k : (uint64_t)k + 1;
     if (L < min_len) return 0;
     return ((L - k + 1) / 4) * 4;
+}
+
+// Adds the number of lanes with `pred` to *counter with ONE atomic per wavefront (64-bit ballot + s_bcnt1).
+__device__ __forceinline__ void wave_count_add(unsigned int* counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m && (__lane_id() == (unsigned)__ffsll((long long)m) - 1)) atomicAdd(counter, (unsigned int)__popcll(m));
 }
 
 // index of the record containing flat position p: largest r with off[r] <= p (off has n+1 entries, p < off[n]).

@@ -51,7 +51,7 @@ struct KmerConsts {
 };
 
 // One k-mer at in-word offset O (base index within the 16-base dword), from three consecutive dwords of each stream.
-template <int K, int O>
+template <int K, int O, int HV>
 __device__ __forceinline__ void kmer_at(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1, uint32_t r2,
                                         uint64_t thr, uint32_t pos, Stage& st, uint32_t* s_cnt, uint64_t* out_hash,
                                         uint32_t* out_pos, uint32_t out_cap, uint32_t* out_count) {
@@ -59,7 +59,7 @@ __device__ __forceinline__ void kmer_at(uint32_t f0, uint32_t f1, uint32_t f2, u
     const uint64_t f = shr96<SF>(f0, f1, f2) & KmerConsts<K>::MASK;
     const uint64_t r = shr96<2 * O>(r2, r1, r0) & KmerConsts<K>::MASK;   // reverse complement: little-endian stream
     const uint64_t canon = f < r ? f : r;                  // seeding.rs:134-139
-    const uint64_t h = mm_hash64(canon);
+    const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
     if (h < thr) {                                         // seeding.rs:142 (strict)
         const uint32_t slot = atomicAdd(s_cnt, 1u);
         if (slot < STAGE_CAP) {
@@ -72,20 +72,20 @@ __device__ __forceinline__ void kmer_at(uint32_t f0, uint32_t f1, uint32_t f2, u
     }
 }
 
-template <int K, int O>
+template <int K, int O, int HV>
 struct Unroll16 {
     static __device__ __forceinline__ void run(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1,
                                                uint32_t r2, uint64_t thr, uint32_t pos0, Stage& st, uint32_t* s_cnt,
                                                uint64_t* out_hash, uint32_t* out_pos, uint32_t out_cap,
                                                uint32_t* out_count) {
-        kmer_at<K, O>(f0, f1, f2, r0, r1, r2, thr, pos0 + O, st, s_cnt, out_hash, out_pos, out_cap, out_count);
+        kmer_at<K, O, HV>(f0, f1, f2, r0, r1, r2, thr, pos0 + O, st, s_cnt, out_hash, out_pos, out_cap, out_count);
         if constexpr (O + 1 < 16)
-            Unroll16<K, O + 1>::run(f0, f1, f2, r0, r1, r2, thr, pos0, st, s_cnt, out_hash, out_pos, out_cap, out_count);
+            Unroll16<K, O + 1, HV>::run(f0, f1, f2, r0, r1, r2, thr, pos0, st, s_cnt, out_hash, out_pos, out_cap, out_count);
     }
 };
 
 // K1.  n_bases < 2^32.  `bases` 16-byte aligned; chunks that start at or beyond n_bases are never read.
-template <int K>
+template <int K, int HV>
 __global__ __launch_bounds__(TPB) void seeds_kernel(const uint8_t* __restrict__ bases, uint32_t n_bases, uint64_t thr,
                                                     uint32_t n_tiles, uint64_t* __restrict__ out_hash,
                                                     uint32_t* __restrict__ out_pos, uint32_t out_cap,
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(TPB) void seeds_kernel(const uint8_t* __restrict__ 
                 // positions at or beyond n_bases can never be valid; skip whole dwords of them (wave-uniform
                 // except in the single boundary wave)
                 if ((uint64_t)p0 + (uint64_t)j * 16 < n_bases)
-                    Unroll16<K, 0>::run(fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2], thr, p0 + j * 16, st,
+                    Unroll16<K, 0, HV>::run(fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2], thr, p0 + j * 16, st,
                                         &s_cnt, out_hash, out_pos, out_cap, out_count);
             }
         }
@@ -162,15 +162,15 @@ void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);
+    static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
     ScopedKernelTimer t(ctx, "seeds");
-    if (k == 31)
-        hipLaunchKernelGGL(seeds_kernel<31>, dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles,
-                           d_out_hash, d_out_pos, out_cap, d_count);
-    else if (k == 21)
-        hipLaunchKernelGGL(seeds_kernel<21>, dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles,
-                           d_out_hash, d_out_pos, out_cap, d_count);
-    else
-        throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
+#define SY_LAUNCH_SEEDS(KK, HH)                                                                                         \
+    hipLaunchKernelGGL((seeds_kernel<KK, HH>), dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles, \
+                       d_out_hash, d_out_pos, out_cap, d_count)
+    if (k == 31) { if (hv) SY_LAUNCH_SEEDS(31, 1); else SY_LAUNCH_SEEDS(31, 0); }
+    else if (k == 21) { if (hv) SY_LAUNCH_SEEDS(21, 1); else SY_LAUNCH_SEEDS(21, 0); }
+    else throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
+#undef SY_LAUNCH_SEEDS
     SY_HIP(hipGetLastError());
 }
 

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
     const uint64_t* __restrict__ hash, uint32_t n, uint32_t k, int avx2_compat, int paired, int want_markers,
     uint64_t rec_base, uint64_t* __restrict__ o_hash, uint64_t* __restrict__ o_rid, uint64_t* __restrict__ o_m0,
-    uint64_t* __restrict__ o_m1, unsigned long long* __restrict__ n_valid) {
+    uint64_t* __restrict__ o_m1, unsigned int* __restrict__ n_valid) {
     __shared__ uint64_t s_lo, s_hi;
     const uint32_t first = blockIdx.x * blockDim.x;
     const uint32_t i = first + threadIdx.x;
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         if (threadIdx.x == 0) s_lo = r; else s_hi = r + 1;
     }
     __syncthreads();
-    if (i >= n) return;
-    const uint64_t p = pos[i];
-    uint64_t h = hash[i], rid = 0, m0 = 0, m1 = 0;
+    const bool live = i < n;
+    const uint64_t p = live ? pos[i] : ~0ull;
+    uint64_t h = live ? hash[i] : 0, rid = 0, m0 = 0, m1 = 0;
     bool valid = false;
     if (p < total) {
         uint64_t lo = s_lo, hi = s_hi;   // off[lo] <= p < off[hi]
@@ -112,12 +112,13 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
             }
         }
     }
-    if (!valid) h = INVALID_HASH;
-    o_hash[i] = h;
-    o_rid[i] = rid;
-    o_m0[i] = m0;
-    o_m1[i] = m1;
-    if (valid) atomicAdd(n_valid, 1ull);   // wave-aggregated by the compiler
+    if (live) {
+        o_hash[i] = valid ? h : INVALID_HASH;
+        o_rid[i] = rid;
+        o_m0[i] = m0;
+        o_m1[i] = m1;
+    }
+    wave_count_add(n_valid, valid);
 }
 
 // Genome flavour: (contig, end position, hash), validated with the positions-variant rules
@@ -173,10 +174,10 @@ __global__ __launch_bounds__(256) void gather_heads_kernel(const uint64_t* __res
 // produced by mate 1 of the same pair.  Occurrences are in file order inside a segment, so the pair's mate-1
 // occurrences sit immediately before its mate-2 occurrences.
 __global__ __launch_bounds__(256) void skip_kernel(const uint64_t* __restrict__ rid_s, const uint32_t* __restrict__ seg_start,
-                                                   uint32_t n, uint8_t* __restrict__ skip) {
+                                                   uint32_t n, uint8_t* __restrict__ skip,
+                                                   unsigned int* __restrict__ n_skipped) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t rec = rid_s[i] & RID_MASK;
+    const uint64_t rec = i < n ? (rid_s[i] & RID_MASK) : 0;
     uint8_t s = 0;
     if (rec & 1) {
         const uint32_t s0 = seg_start[i];
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void skip_kernel(const uint64_t* __restrict__ 
             if ((rj & 1) == 0) { s = 1; break; }
         }
     }
-    skip[i] = s;
+    if (i < n) skip[i] = s;
+    wave_count_add(n_skipped, s != 0);
 }
 
 // K3b: dropped_i as defined in the file header.  flags[i]: bit0 = skip, bit1 = would-be-dropped.
@@ -230,10 +232,9 @@ __global__ __launch_bounds__(256) void would_count_kernel(const uint8_t* __restr
 
 __global__ __launch_bounds__(256) void counted_kernel(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ Eu,
                                                       const uint32_t* __restrict__ seg_start, uint32_t n, int no_dedup,
-                                                      uint32_t cutoff, uint32_t* __restrict__ counted,
-                                                      unsigned long long* __restrict__ removed_total) {
+                                                      uint32_t cutoff, uint32_t* __restrict__ counted) {
+    // removed occurrences = processed - counted, taken from the scan total on the host side (no atomics here)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t removed = 0;
     if (i < n) {
         const uint8_t fl = flags[i];
         uint32_t c = 0;
@@ -241,13 +242,11 @@ __global__ __launch_bounds__(256) void counted_kernel(const uint8_t* __restrict_
             const uint32_t P = Eu[i] - Eu[seg_start[i]];
             const bool u = no_dedup || !(fl & 2);
             c = (cutoff && P >= cutoff) ? 1u : (u ? 1u : 0u);
-            removed = c ? 0u : 1u;
         }
         counted[i] = c;
     } else if (i == n) {
         counted[i] = 0;
     }
-    if (removed) atomicAdd(removed_total, 1ull);   // wave-aggregated
 }
 
 // start[s] = index of the first occurrence of k-mer s (start[n_seg] = n)
@@ -305,7 +304,11 @@ static uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint
         HostPhase ph(ctx, "push: seeds kernel");
         ctx->scratch[0].reserve(cap * 8);   // hash (unsorted)
         ctx->scratch[1].reserve(cap * 4);   // pos (unsorted)
+        static const bool slowlog = getenv("SYLPH_HIP_SLOWLOG") != nullptr;
+        const double t0 = slowlog ? HostPhase::now() : 0;
         SY_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+        const double t1 = slowlog ? HostPhase::now() : 0;
+        if (slowlog && t1 - t0 > 3.0) fprintf(stderr, "[sylph_hip] slow memset issue %.3f ms\n", t1 - t0);
         launch_seeds(ctx, d_bases, (uint32_t)n_bases, c, k, ctx->scratch[0].as<uint64_t>(), ctx->scratch[1].as<uint32_t>(),
                      (uint32_t)cap, d_count);
         ctx->read_back(&n, d_count, 4);
@@ -329,8 +332,12 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     SY_REQUIRE(!sk->paired || (n_records % 2 == 0), "paired batches must hold an even number of records");
     if (n_records == 0) return;
     SY_REQUIRE(rec_off, "null rec_off");
+    static const bool slowlog = getenv("SYLPH_HIP_SLOWLOG") != nullptr;
+    const double t_enter = slowlog ? HostPhase::now() : 0;
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
+    if (slowlog && HostPhase::now() - t_enter > 3.0)
+        fprintf(stderr, "[sylph_hip] slow push entry (lock/device): %.3f ms\n", HostPhase::now() - t_enter);
     HostPhase ph_total(ctx, "push: total");
     const uint8_t* d_bases;
     const uint64_t* d_off;
@@ -368,7 +375,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
                            sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, sk->hash.as<uint64_t>() + sk->n_occ,
                            sk->rid.as<uint64_t>() + sk->n_occ, sk->m0.as<uint64_t>() + sk->n_occ,
                            sk->m1.as<uint64_t>() + sk->n_occ,
-                           reinterpret_cast<unsigned long long*>(sk->counters.as<uint8_t>() + 8));
+                           reinterpret_cast<unsigned int*>(sk->counters.as<uint8_t>() + 8));
         SY_HIP(hipGetLastError());
         sk->n_occ = need;
     }
@@ -383,8 +390,8 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
     HostPhase ph_total(ctx, "finish: total incl. readback");
-    unsigned long long n_valid = 0;
-    ctx->read_back(&n_valid, sk->counters.as<uint8_t>() + 8, 8);
+    unsigned int n_valid = 0;   // < 2^32 because n_occ is
+    ctx->read_back(&n_valid, sk->counters.as<uint8_t>() + 8, 4);
     SY_REQUIRE(sk->n_occ < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
     const uint32_t n_all = (uint32_t)sk->n_occ, nv = (uint32_t)n_valid;
     sk->n_out = 0;
@@ -428,15 +435,15 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         }
         inclusive_max_u32(ctx, headidx, seg_start, nv);
         exclusive_sum_u32(ctx, head, seg_id, nv);
-        unsigned long long* d_removed = reinterpret_cast<unsigned long long*>(sk->counters.as<uint8_t>() + 16);
-        SY_HIP(hipMemsetAsync(d_removed, 0, 8, ctx->stream));
+        unsigned int* d_skipped = reinterpret_cast<unsigned int*>(sk->counters.as<uint8_t>() + 16);
+        SY_HIP(hipMemsetAsync(d_skipped, 0, 4, ctx->stream));
         uint32_t* Eu = headidx;
         {
             ScopedKernelTimer t(ctx, "replay");
             const uint8_t* skip_arg = nullptr;
             if (sk->paired) {
                 hipLaunchKernelGGL(skip_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
-                                   seg_start, nv, skip);
+                                   seg_start, nv, skip, d_skipped);
                 skip_arg = skip;
             }
             if (!sk->no_dedup || sk->paired)
@@ -450,18 +457,18 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(counted_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, Eu, seg_start, nv,
-                               sk->no_dedup, sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, uc, d_removed);
+                               sk->no_dedup, sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, uc);
         }
         exclusive_sum_u32(ctx, uc, Ec, nv1);
-        uint32_t tail[2] = {0, 0};   // seg_id and head of the last occurrence -> number of distinct k-mers
+        uint32_t tail[4] = {0, 0, 0, 0};   // seg_id, head of the last occurrence; total counted; skipped
         SY_HIP(hipMemcpyAsync(ctx->pinned, seg_id + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 4, head + (nv - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 8, d_removed, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 8, Ec + nv, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 12, d_skipped, 4, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
-        memcpy(tail, ctx->pinned, 8);
-        unsigned long long removed = 0;
-        memcpy(&removed, (uint8_t*)ctx->pinned + 8, 8);
+        memcpy(tail, ctx->pinned, 16);
         const uint32_t n_seg = tail[0] + tail[1];
+        const unsigned long long removed = (unsigned long long)nv - tail[3] - tail[2];   // processed - counted
         sk->out_k.reserve((size_t)n_seg * 8);
         sk->out_c.reserve((size_t)n_seg * 4);
         {
