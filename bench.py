@@ -155,13 +155,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    n_dev = torch.cuda.device_count()
+    local = local % max(1, n_dev)   # (debug aid: several ranks may share one GPU with SYLPH_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+        backend = os.environ.get("SYLPH_BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     c, k, read_len = 200, 31, 150
     n_pairs = WORKLOADS[args.workload][0]
@@ -170,7 +176,7 @@ def main():
     tstream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    ctx = S.Context(local, stream=stream if not os.environ.get("BENCH_OWN_STREAM") else None)
+    ctx = S.Context(local, stream=stream)
 
     log(f"[bench] building workload {args.workload} on {world} GPU(s) ...")
     db, mine, lens_mine, n_total, community, dbstats = build_database(ctx, device, args.workload, c, k, args.seed, rank, world)
@@ -196,28 +202,21 @@ def main():
         if os.environ.get("SYLPH_BENCH_DEBUG"):
             log(f"[bench] begin {1e3 * (t_a1 - t_a):.3f} push {1e3 * (t_a2 - t_a1):.3f} finish {1e3 * (t_b - t_a2):.3f} ms")
         occ_holder[0] = (dc, n, dup)
-        if os.environ.get("SYLPH_BENCH_SKIP_CONTAIN"):
-            res = {}
-        else:
-            res = SH.profile_step(db, group, dk, dc, n, mine, n_total, device)
+        res = SH.profile_step(db, group, dk, dc, n, mine, n_total, device)
         t_c = time.perf_counter()
         if os.environ.get("SYLPH_BENCH_DEBUG"):
             log(f"[bench] contain {1e3 * (t_c - t_b):.3f} ms")
-        if collect is not None and len(collect) == 0 and not os.environ.get("BENCH_NO_OCC"):   # seed occurrences of the sample = sum(counts) + removed
+        if collect == "occ":   # untimed extra step: seed occurrences of the sample = sum(counts) + removed
             occ_holder.append(int(SH.device_view(dc, n, torch.int32, device).sum().item()) + dup)
         sk.close()
-        if collect is not None:
+        if isinstance(collect, list):
             collect.append((t_b - t_a, t_c - t_b, n, dup, res))
         return res
 
-    # settle: the setup above allocates/frees tens of GB; the driver finishes that page-table work asynchronously and
-    # the first few submissions afterwards can stall for 15-40 ms.  Two untimed settle steps + a short pause keep that
-    # out of both the warm-up and the timed region whatever --warmup is.
+    # two untimed settle steps (first-use allocations of the library's pool, lazy kernel loading) whatever --warmup is
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    if not os.environ.get("BENCH_NO_SLEEP"):
-        time.sleep(0.25)
     for _ in range(args.warmup):
         step()
     ctx.profile(not args.no_kernel_timers)
@@ -241,6 +240,7 @@ def main():
     seeds_ms, seeds_launches = ctx.kernel_stats("seeds")
     fam = {f: ctx.kernel_stats(f) for f in ("seeds", "annotate", "sort", "replay", "probe")}
     ctx.profile(False)
+    step("occ")   # untimed: count the seed occurrences for the roofline's algorithmic bytes
     t_sketch = float(np.mean([r[0] for r in rows]))
     t_profile = float(np.mean([r[1] for r in rows]))
     n_table, dup = rows[-1][2], rows[-1][3]
@@ -277,7 +277,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "seeds_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and args.workload in ("c2", "c3"):   # measured on this read set (profiles/r01_seeds_traffic.md)
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
@@ -285,7 +285,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "seeds_kernel<31>", "achieved": round(achieved, 1), "peak": 8000.0,
                            "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
-                           "note": "integer-ALU bound (~50 VALU ops per k-mer); see DESIGN.md"}
+                           "note": "integer-VALU issue bound (38 VALU wave-instructions per 64 k-mers, 91 % VALU busy; profiles/r01_seeds_pmc.md)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import oracle as O  # noqa: F401  (cpu_baseline leg only)

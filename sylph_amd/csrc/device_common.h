@@ -22,7 +22,7 @@ __device__ __forceinline__ uint64_t mm_hash64(uint64_t key) {
 // "x + (x << n)" into a 64-bit multiply and lowers that to 2-3 v_mad_u64_u32 plus operand shuffling (~15 mads and
 // ~19 v_mov per k-mer).  Measured issue costs on MI355X (tools/valu_rates.hip; VOP2 32-bit op = 1): v_lshl_add_u64
 // 1.9, v_lshlrev/lshrrev_b64 1.6, v_mad_u64_u32 1.9, any VOP3 32-bit op 1.6.  v_lshl_add_u64 (shift <= 4) does
-// x*5 and x*21 in one/two instructions; the NOT of step 1 is folded into step 2 as one xor with a constant:
+// x*9, x*5 and x*21 in one/two instructions; the NOT of step 1 is folded into step 2 as one xor with a constant:
 //   ~t ^ (~t >> 24)  ==  (t ^ (t >> 24)) ^ 0xFFFFFF0000000000.
 template <int N>
 __device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {   // (a << N) + b, N in 0..4
@@ -33,7 +33,7 @@ __device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {   // 
 __device__ __forceinline__ uint64_t mm_hash64_gfx950(uint64_t key) {
     uint64_t t = lshl_add_u64<0>(key << 21, key);                 // key + (key << 21)
     t = (t ^ (t >> 24)) ^ 0xFFFFFF0000000000ull;                  // ~t, then ^= >> 24
-    t = (uint64_t)(uint32_t)t * 265u + ((uint64_t)((uint32_t)(t >> 32) * 265u) << 32);   // * 265: one v_mad_u64_u32
+    t = lshl_add_u64<0>(t << 8, lshl_add_u64<3>(t, t));           // * 265 = (t << 8) + 9t
     t = t ^ (t >> 14);
     t = lshl_add_u64<4>(t, lshl_add_u64<2>(t, t));                // * 21
     t = t ^ (t >> 28);

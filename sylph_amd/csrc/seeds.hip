@@ -50,39 +50,61 @@ struct KmerConsts {
     static constexpr uint64_t MASK = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
 };
 
-// One k-mer at in-word offset O (base index within the 16-base dword), from three consecutive dwords of each stream.
+// canonical k-mer hash at in-word offset O (compile-time) from three consecutive dwords of each stream
 template <int K, int O, int HV>
-__device__ __forceinline__ void kmer_at(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1, uint32_t r2,
-                                        uint64_t thr, uint32_t pos, Stage& st, uint32_t* s_cnt, uint64_t* out_hash,
-                                        uint32_t* out_pos, uint32_t out_cap, uint32_t* out_count) {
+__device__ __forceinline__ uint64_t hash_at(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1, uint32_t r2) {
     constexpr int SF = 96 - 2 * O - 2 * K;                 // forward: top-justified big-endian stream
     const uint64_t f = shr96<SF>(f0, f1, f2) & KmerConsts<K>::MASK;
     const uint64_t r = shr96<2 * O>(r2, r1, r0) & KmerConsts<K>::MASK;   // reverse complement: little-endian stream
     const uint64_t canon = f < r ? f : r;                  // seeding.rs:134-139
-    const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
-    if (h < thr) {                                         // seeding.rs:142 (strict)
-        const uint32_t slot = atomicAdd(s_cnt, 1u);
-        if (slot < STAGE_CAP) {
-            st.hash[slot] = h;
-            st.pos[slot] = pos;
-        } else {                                           // staging full (pathological repeats): straight to HBM
-            const uint32_t g = atomicAdd(out_count, 1u);
-            if (g < out_cap) { out_hash[g] = h; out_pos[g] = pos; }
-        }
-    }
+    return HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
 }
 
+// same with a run-time offset (only executed for the ~1/c k-mers that passed the threshold)
+template <int K>
+__device__ __forceinline__ uint64_t hash_at_dyn(uint32_t o, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1,
+                                                uint32_t r2) {
+    auto shr96d = [](uint32_t hi, uint32_t mid, uint32_t lo, uint32_t sh) -> uint64_t {   // sh in [0, 63]
+        const uint64_t a = ((uint64_t)mid << 32) | lo;
+        return sh == 0 ? a : ((a >> sh) | ((uint64_t)hi << (64 - sh)));
+    };
+    const uint64_t f = shr96d(f0, f1, f2, 96 - 2 * o - 2 * K) & KmerConsts<K>::MASK;
+    const uint64_t r = shr96d(r2, r1, r0, 2 * o) & KmerConsts<K>::MASK;
+    return mm_hash64(f < r ? f : r);
+}
+
+// 16 k-mers of one dword: accumulate "hash < threshold" into a bit mask (k-mer O -> bit 15-O) with two VALU ops per
+// k-mer and no control flow; the rare survivors are re-hashed and emitted afterwards.
 template <int K, int O, int HV>
 struct Unroll16 {
     static __device__ __forceinline__ void run(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1,
-                                               uint32_t r2, uint64_t thr, uint32_t pos0, Stage& st, uint32_t* s_cnt,
-                                               uint64_t* out_hash, uint32_t* out_pos, uint32_t out_cap,
-                                               uint32_t* out_count) {
-        kmer_at<K, O, HV>(f0, f1, f2, r0, r1, r2, thr, pos0 + O, st, s_cnt, out_hash, out_pos, out_cap, out_count);
-        if constexpr (O + 1 < 16)
-            Unroll16<K, O + 1, HV>::run(f0, f1, f2, r0, r1, r2, thr, pos0, st, s_cnt, out_hash, out_pos, out_cap, out_count);
+                                               uint32_t r2, uint64_t thr, uint32_t& mask) {
+        const uint64_t h = hash_at<K, O, HV>(f0, f1, f2, r0, r1, r2);
+        // mask = 2*mask + (h < thr): v_cmp_lt_u64 sets vcc, v_addc_co_u32 folds it in (seeding.rs:142, strict <)
+        asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(h), "s"(thr) : "vcc");
+        if constexpr (O + 1 < 16) Unroll16<K, O + 1, HV>::run(f0, f1, f2, r0, r1, r2, thr, mask);
     }
 };
+
+template <int K>
+__device__ __forceinline__ void emit_hits(uint32_t mask, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t r0, uint32_t r1,
+                                          uint32_t r2, uint32_t pos0, Stage& st, uint32_t* s_cnt, uint64_t* out_hash,
+                                          uint32_t* out_pos, uint32_t out_cap, uint32_t* out_count) {
+    while (mask) {
+        const uint32_t b = 31u - (uint32_t)__clz((int)mask);
+        mask &= ~(1u << b);
+        const uint32_t o = 15u - b;
+        const uint64_t h = hash_at_dyn<K>(o, f0, f1, f2, r0, r1, r2);
+        const uint32_t slot = atomicAdd(s_cnt, 1u);
+        if (slot < STAGE_CAP) {
+            st.hash[slot] = h;
+            st.pos[slot] = pos0 + o;
+        } else {                                           // staging full (pathological repeats): straight to HBM
+            const uint32_t g = atomicAdd(out_count, 1u);
+            if (g < out_cap) { out_hash[g] = h; out_pos[g] = pos0 + o; }
+        }
+    }
+}
 
 // K1.  n_bases < 2^32.  `bases` 16-byte aligned; chunks that start at or beyond n_bases are never read.
 template <int K, int HV>
@@ -127,9 +149,13 @@ __global__ __launch_bounds__(TPB) void seeds_kernel(const uint8_t* __restrict__ 
             for (int j = 0; j < WPT; j++) {
                 // positions at or beyond n_bases can never be valid; skip whole dwords of them (wave-uniform
                 // except in the single boundary wave)
-                if ((uint64_t)p0 + (uint64_t)j * 16 < n_bases)
-                    Unroll16<K, 0, HV>::run(fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2], thr, p0 + j * 16, st,
-                                        &s_cnt, out_hash, out_pos, out_cap, out_count);
+                if ((uint64_t)p0 + (uint64_t)j * 16 < n_bases) {
+                    uint32_t mask = 0;
+                    Unroll16<K, 0, HV>::run(fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2], thr, mask);
+                    if (mask)
+                        emit_hits<K>(mask, fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2], p0 + j * 16, st, &s_cnt,
+                                     out_hash, out_pos, out_cap, out_count);
+                }
             }
         }
         __syncthreads();

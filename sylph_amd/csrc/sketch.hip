@@ -32,13 +32,15 @@ constexpr uint64_t INVALID_HASH = ~0ull;
 
 // 32 consecutive bases starting at p (any alignment) -> (even-position 16-mer, odd-position 16-mer), each base a
 // 2-bit BYTE_TO_SEQ code, first base most significant (the order pair_kmer[_single] builds them in,
-// sketch.rs:636-653,:668-685).  Four unaligned 8-byte loads instead of 32 byte loads.
+// sketch.rs:636-653,:668-685).  Two unaligned 16-byte loads instead of 32 byte loads.
 __device__ __forceinline__ void marker_halves(const uint8_t* __restrict__ p, uint32_t& even, uint32_t& odd) {
     uint32_t e = 0, o = 0;
+    uint64_t xs[4];
+    __builtin_memcpy(&xs[0], p, 16);
+    __builtin_memcpy(&xs[2], p + 16, 16);
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        uint64_t x;
-        __builtin_memcpy(&x, p + 8 * w, 8);
+        const uint64_t x = xs[w];
         uint32_t bad = 0;
         uint32_t lo = codes4_fast((uint32_t)x, bad), hi = codes4_fast((uint32_t)(x >> 32), bad);
         if (bad) { lo = codes4_exact((uint32_t)x); hi = codes4_exact((uint32_t)(x >> 32)); }
@@ -61,8 +63,10 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
     const uint64_t* __restrict__ hash, uint32_t n, uint32_t k, int avx2_compat, int paired, int want_markers,
     uint64_t rec_base, uint64_t* __restrict__ o_hash, uint64_t* __restrict__ o_rid, uint64_t* __restrict__ o_m0,
-    uint64_t* __restrict__ o_m1, unsigned int* __restrict__ n_valid) {
+    uint64_t* __restrict__ o_m1) {
+    constexpr uint32_t WIN = 1024;           // record offsets staged in LDS (8 KiB)
     __shared__ uint64_t s_lo, s_hi;
+    __shared__ uint64_t s_off[WIN + 2];
     const uint32_t first = blockIdx.x * blockDim.x;
     const uint32_t i = first + threadIdx.x;
     const uint64_t total = off[n_rec];
@@ -74,6 +78,14 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         if (threadIdx.x == 0) s_lo = r; else s_hi = r + 1;
     }
     __syncthreads();
+    // stage off[s_lo .. s_hi + 1] (the run of records this workgroup's survivors fall into, +1 for the mate lookup)
+    const uint64_t w_lo = s_lo & ~1ull;      // even, so a pair's three offsets are inside the window too
+    const uint64_t w_n = min(s_hi + 2, n_rec + 1) - w_lo;
+    const bool in_lds = w_n <= WIN + 2;
+    if (in_lds)
+        for (uint32_t t = threadIdx.x; t < w_n; t += blockDim.x) s_off[t] = off[w_lo + t];
+    __syncthreads();
+    auto OFF = [&](uint64_t r) -> uint64_t { return in_lds ? s_off[r - w_lo] : off[r]; };
     const bool live = i < n;
     const uint64_t p = live ? pos[i] : ~0ull;
     uint64_t h = live ? hash[i] : 0, rid = 0, m0 = 0, m1 = 0;
@@ -82,10 +94,10 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         uint64_t lo = s_lo, hi = s_hi;   // off[lo] <= p < off[hi]
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
-            if (off[mid] <= p) lo = mid; else hi = mid;
+            if (OFF(mid) <= p) lo = mid; else hi = mid;
         }
         const uint64_t r = lo;
-        const uint64_t start = off[r], L = off[r + 1] - start;
+        const uint64_t start = OFF(r), L = OFF(r + 1) - start;
         valid = (p - start) < n_hashed_kmers(L, k, avx2_compat, 0);
         if (valid) {
             rid = rec_base + r;
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
                 } else {
                     // pair_kmer, sketch.rs:659-688: both mates >= 33 bp
                     const uint64_t r1 = r & ~1ull;
-                    const uint64_t s1 = off[r1], s2 = off[r1 + 1], e2 = off[r1 + 2];
+                    const uint64_t s1 = OFF(r1), s2 = OFF(r1 + 1), e2 = OFF(r1 + 2);
                     if (s2 - s1 >= 33 && e2 - s2 >= 33) { a = bases + s1; b = bases + s2; }
                 }
                 if (a) {
@@ -118,7 +130,8 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         o_m0[i] = m0;
         o_m1[i] = m1;
     }
-    wave_count_add(n_valid, valid);
+    // (no counter of valid survivors here: one atomic per wavefront on a single word runs at ~88 atomics/us and was
+    //  the whole 0.9 ms of this kernel; finish() finds the count by binary search in the hash-sorted array instead)
 }
 
 // Genome flavour: (contig, end position, hash), validated with the positions-variant rules
@@ -145,6 +158,16 @@ __global__ __launch_bounds__(256) void annotate_contigs_kernel(const uint64_t* _
     o_contig[i] = contig;
     o_pos[i] = endpos;
     o_hash[i] = h;
+}
+
+// number of valid occurrences = first index holding INVALID_HASH in the hash-sorted array (one lane, log n loads)
+__global__ void count_valid_kernel(const uint64_t* __restrict__ hs, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (hs[mid] < INVALID_HASH) lo = mid + 1; else hi = mid;
+    }
+    *out = lo;
 }
 
 __global__ void iota_kernel(uint32_t* v, uint32_t n) {
@@ -374,8 +397,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
                            ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, sk->k, sk->avx2_compat,
                            sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, sk->hash.as<uint64_t>() + sk->n_occ,
                            sk->rid.as<uint64_t>() + sk->n_occ, sk->m0.as<uint64_t>() + sk->n_occ,
-                           sk->m1.as<uint64_t>() + sk->n_occ,
-                           reinterpret_cast<unsigned int*>(sk->counters.as<uint8_t>() + 8));
+                           sk->m1.as<uint64_t>() + sk->n_occ);
         SY_HIP(hipGetLastError());
         sk->n_occ = need;
     }
@@ -390,25 +412,26 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
     HostPhase ph_total(ctx, "finish: total incl. readback");
-    unsigned int n_valid = 0;   // < 2^32 because n_occ is
-    ctx->read_back(&n_valid, sk->counters.as<uint8_t>() + 8, 4);
     SY_REQUIRE(sk->n_occ < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
-    const uint32_t n_all = (uint32_t)sk->n_occ, nv = (uint32_t)n_valid;
+    const uint32_t n_all = (uint32_t)sk->n_occ;
+    uint32_t nv = 0;
     sk->n_out = 0;
     sk->dup_removed = 0;
-    if (nv) {
-        HostPhase ph_all(ctx, "finish: total");
+    DevBuf &b_idx = ctx->scratch[0], &b_hs = ctx->scratch[1], &b_perm = ctx->scratch[2];
+    if (n_all) {
         // stable sort by hash; invalid occurrences carry ~0 and end up behind the nv valid ones
-        DevBuf &b_idx = ctx->scratch[0], &b_hs = ctx->scratch[1], &b_perm = ctx->scratch[2];
+        HostPhase ph(ctx, "finish: sort by hash");
         b_idx.reserve((size_t)n_all * 4);
         b_hs.reserve((size_t)n_all * 8);
         b_perm.reserve((size_t)n_all * 4);
-        {
-            HostPhase ph(ctx, "finish: sort by hash");
-            hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_all)), dim3(256), 0, ctx->stream, b_idx.as<uint32_t>(), n_all);
-            sort_pairs_u64_u32(ctx, sk->hash.as<uint64_t>(), b_hs.as<uint64_t>(), b_idx.as<uint32_t>(),
-                               b_perm.as<uint32_t>(), n_all, 0, 64);
-        }
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_all)), dim3(256), 0, ctx->stream, b_idx.as<uint32_t>(), n_all);
+        sort_pairs_u64_u32(ctx, sk->hash.as<uint64_t>(), b_hs.as<uint64_t>(), b_idx.as<uint32_t>(), b_perm.as<uint32_t>(),
+                           n_all, 0, 64);
+        uint32_t* d_nv = reinterpret_cast<uint32_t*>(sk->counters.as<uint8_t>() + 8);
+        hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1), 0, ctx->stream, b_hs.as<uint64_t>(), n_all, d_nv);
+        ctx->read_back(&nv, d_nv, 4);
+    }
+    if (nv) {
         HostPhase ph_replay(ctx, "finish: replay");
         DevBuf &b_rid = ctx->scratch[3], &b_m0 = ctx->scratch[4], &b_m1 = ctx->scratch[5], &b_u32 = ctx->scratch[6],
                &b_fl = ctx->scratch[7];

@@ -342,3 +342,16 @@ def test_end_to_end_sketch_then_contain_device_resident(ctx):
     assert cc[0] > cc[3] > cc[2]
     db.close()
     sk.close()
+
+
+# ---------------------------------------------------------------------------------------------- multi-process
+def test_sharded_containment_two_ranks_one_gpu():
+    """Two ranks (gloo rendezvous, both on cuda:0) run the genome-sharded exchange with the real HIP probe and check
+    their own sample against the oracle over the whole database."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
