@@ -136,6 +136,12 @@ uint64_t sylph_db_n_kmers(const sylph_db *db);
  * before use, contain.rs:661). */
 int sylph_db_contain(sylph_db *db, const uint64_t *sample_kmers, const uint32_t *sample_counts, uint64_t n, int mem,
                      double min_number_kmers, uint32_t *contain_count, uint64_t *cov_off, uint32_t **out_covs);
+/* Same computation, results left in pinned host memory owned by the database object: no allocation and no second copy.
+ * The three arrays stay valid until the next sylph_db_contain* call on this db or sylph_db_destroy (borrow semantics,
+ * like the `&GenomeSketch` / `&SequencesSketch` references get_stats works on). *out_n_covs == (*cov_off)[n_genomes]. */
+int sylph_db_contain_view(sylph_db *db, const uint64_t *sample_kmers, const uint32_t *sample_counts, uint64_t n, int mem,
+                          double min_number_kmers, const uint32_t **contain_count, const uint64_t **cov_off,
+                          const uint32_t **covs, uint64_t *out_n_covs);
 void sylph_db_destroy(sylph_db *db);
 
 #ifdef __cplusplus

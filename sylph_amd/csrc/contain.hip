@@ -134,6 +134,9 @@ struct sylph_db {
     DevBuf kmer, gid, bucket_start, glen;
     // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
     DevBuf q_kmers, q_counts, hits, hits_sorted, cov_off, ccount, covs, counter;
+    void* h_res = nullptr;         // pinned host results: [cov_off (G+1) u64 | contain_count G u32 | covs u32]
+    size_t h_res_cap = 0;
+    ~sylph_db() { if (h_res) (void)hipHostFree(h_res); }
     explicit sylph_db(sylph_ctx* cx)
         : ctx(cx), kmer(cx), gid(cx), bucket_start(cx), glen(cx), q_kmers(cx), q_counts(cx), hits(cx), hits_sorted(cx),
           cov_off(cx), ccount(cx), covs(cx), counter(cx) {}
@@ -217,70 +220,110 @@ int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genom
 uint64_t sylph_db_n_genomes(const sylph_db* db) { return db ? db->n_genomes : 0; }
 uint64_t sylph_db_n_kmers(const sylph_db* db) { return db ? db->n_kmers : 0; }
 
+// Runs the probe and leaves (cov_off, contain_count, covs) in db->h_res (pinned).  Returns the number of hits.
+static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
+                             double min_number_kmers) {
+    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+    SY_REQUIRE(n < (1ull << 32), "sample table larger than 2^32-1 entries");
+    sylph_ctx* ctx = db->ctx;
+    const uint64_t G = db->n_genomes;
+    uint32_t n_hits = 0;
+    if (n && db->n_kmers) {
+        SY_REQUIRE(sample_kmers && sample_counts, "null sample");
+        const uint64_t* d_k = sample_kmers;
+        const uint32_t* d_c = sample_counts;
+        if (mem == SYLPH_MEM_HOST) {
+            db->q_kmers.reserve(n * 8);
+            db->q_counts.reserve(n * 4);
+            ctx->h2d(db->q_kmers.p, sample_kmers, n * 8);
+            ctx->h2d(db->q_counts.p, sample_counts, n * 4);
+            d_k = db->q_kmers.as<uint64_t>();
+            d_c = db->q_counts.as<uint32_t>();
+        }
+        uint64_t cap = std::max<uint64_t>(n * 2, 1u << 20);
+        uint32_t* d_cnt = db->counter.as<uint32_t>();
+        for (int attempt = 0; attempt < 2; attempt++) {
+            SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one sample");
+            db->hits.reserve(cap * 8);
+            SY_HIP(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+            {
+                ScopedKernelTimer t(ctx, "probe");
+                hipLaunchKernelGGL(probe_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
+                                   (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
+                                   db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->glen.as<uint32_t>(),
+                                   min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
+                SY_HIP(hipGetLastError());
+            }
+            ctx->read_back(&n_hits, d_cnt, 4);
+            if (n_hits <= cap) break;
+            SY_REQUIRE(attempt == 0, "hit buffer overflow persisted");
+            cap = n_hits;
+        }
+    }
+    db->cov_off.reserve((G + 1) * 8);
+    db->ccount.reserve(std::max<uint64_t>(1, G) * 4);
+    const uint64_t* d_sorted = nullptr;
+    if (n_hits) {
+        db->hits_sorted.reserve((size_t)n_hits * 8);
+        db->covs.reserve((size_t)n_hits * 4);
+        sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
+        d_sorted = db->hits_sorted.as<uint64_t>();
+        hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
+                           db->covs.as<uint32_t>());
+    }
+    hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
+                       (uint32_t)G, db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
+    SY_HIP(hipGetLastError());
+    // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
+    const size_t need = (G + 1) * 8 + G * 4 + (size_t)n_hits * 4 + 64;
+    if (need > db->h_res_cap) {
+        if (db->h_res) SY_HIP(hipHostFree(db->h_res));
+        db->h_res = nullptr;
+        db->h_res_cap = 0;
+        SY_HIP(hipHostMalloc(&db->h_res, need + need / 2, hipHostMallocDefault));
+        db->h_res_cap = need + need / 2;
+    }
+    char* h = (char*)db->h_res;
+    SY_HIP(hipMemcpyAsync(h, db->cov_off.p, (G + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (G) SY_HIP(hipMemcpyAsync(h + (G + 1) * 8, db->ccount.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_hits)
+        SY_HIP(hipMemcpyAsync(h + (G + 1) * 8 + G * 4, db->covs.p, (size_t)n_hits * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->pending.empty()) profile_collect(ctx);
+    return n_hits;
+}
+
+int sylph_db_contain_view(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
+                          double min_number_kmers, const uint32_t** contain_count, const uint64_t** cov_off,
+                          const uint32_t** covs, uint64_t* out_n_covs) {
+    return guarded([&] {
+        SY_REQUIRE(db && contain_count && cov_off && covs, "null argument");
+        std::lock_guard<std::mutex> lock(db->ctx->mu);
+        DeviceGuard dg(db->ctx->device);
+        const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
+        const uint64_t G = db->n_genomes;
+        const char* h = (const char*)db->h_res;
+        *cov_off = (const uint64_t*)h;
+        *contain_count = (const uint32_t*)(h + (G + 1) * 8);
+        *covs = (const uint32_t*)(h + (G + 1) * 8 + G * 4);
+        if (out_n_covs) *out_n_covs = n_hits;
+    });
+}
+
 int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
                      double min_number_kmers, uint32_t* contain_count, uint64_t* cov_off, uint32_t** out_covs) {
     return guarded([&] {
         SY_REQUIRE(db && contain_count && cov_off && out_covs, "null argument");
-        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
-        SY_REQUIRE(n < (1ull << 32), "sample table larger than 2^32-1 entries");
-        sylph_ctx* ctx = db->ctx;
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        DeviceGuard dg(ctx->device);
+        std::lock_guard<std::mutex> lock(db->ctx->mu);
+        DeviceGuard dg(db->ctx->device);
+        const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
         const uint64_t G = db->n_genomes;
-        uint32_t n_hits = 0;
-        if (n && db->n_kmers) {
-            SY_REQUIRE(sample_kmers && sample_counts, "null sample");
-            const uint64_t* d_k = sample_kmers;
-            const uint32_t* d_c = sample_counts;
-            if (mem == SYLPH_MEM_HOST) {
-                db->q_kmers.reserve(n * 8);
-                db->q_counts.reserve(n * 4);
-                ctx->h2d(db->q_kmers.p, sample_kmers, n * 8);
-                ctx->h2d(db->q_counts.p, sample_counts, n * 4);
-                d_k = db->q_kmers.as<uint64_t>();
-                d_c = db->q_counts.as<uint32_t>();
-            }
-            uint64_t cap = std::max<uint64_t>(n * 2, 1u << 20);
-            uint32_t* d_cnt = db->counter.as<uint32_t>();
-            for (int attempt = 0; attempt < 2; attempt++) {
-                SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one sample");
-                db->hits.reserve(cap * 8);
-                SY_HIP(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
-                {
-                    ScopedKernelTimer t(ctx, "probe");
-                    hipLaunchKernelGGL(probe_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k,
-                                       d_c, (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
-                                       db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->glen.as<uint32_t>(),
-                                       min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
-                    SY_HIP(hipGetLastError());
-                }
-                ctx->read_back(&n_hits, d_cnt, 4);
-                if (n_hits <= cap) break;
-                SY_REQUIRE(attempt == 0, "hit buffer overflow persisted");
-                cap = n_hits;
-            }
-        }
-        db->cov_off.reserve((G + 1) * 8);
-        db->ccount.reserve(std::max<uint64_t>(1, G) * 4);
-        const uint64_t* d_sorted = nullptr;
-        if (n_hits) {
-            db->hits_sorted.reserve((size_t)n_hits * 8);
-            db->covs.reserve((size_t)n_hits * 4);
-            sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
-            d_sorted = db->hits_sorted.as<uint64_t>();
-            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
-                               db->covs.as<uint32_t>());
-        }
-        hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
-                           (uint32_t)G, db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
-        SY_HIP(hipGetLastError());
+        const char* h = (const char*)db->h_res;
         uint32_t* hcov = (uint32_t*)malloc(std::max<size_t>(1, n_hits) * 4);
         if (!hcov) throw std::bad_alloc();
-        try {
-            ctx->d2h(cov_off, db->cov_off.p, (G + 1) * 8);
-            ctx->d2h(contain_count, db->ccount.p, G * 4);
-            ctx->d2h(hcov, db->covs.p, (size_t)n_hits * 4);
-        } catch (...) { free(hcov); throw; }
+        memcpy(cov_off, h, (G + 1) * 8);
+        if (G) memcpy(contain_count, h + (G + 1) * 8, G * 4);
+        if (n_hits) memcpy(hcov, h + (G + 1) * 8 + G * 4, (size_t)n_hits * 4);
         *out_covs = hcov;
     });
 }

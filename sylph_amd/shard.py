@@ -66,6 +66,17 @@ def device_view(ptr, n, dtype, device):
     return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
 
 
+def to_host_numpy(t):
+    """Device tensor -> numpy through PINNED host memory (torch's caching host allocator).  A plain `.cpu()` lands in
+    pageable memory that the HIP runtime registers; when numpy frees it the driver evicts this process's GPU queues
+    (15-40 ms stalls) — see DESIGN.md §3."""
+    if not t.is_cuda:
+        return t.numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=False)
+    return h.numpy()
+
+
 def exchange_and_profile(contain_fn, group, sample_k, sample_c, owner, rank_genomes):
     """sample_k (int64 bit patterns of u64) / sample_c (int32 bit patterns of u32): this rank's sample table.
     owner[g]: rank that holds genome g.  rank_genomes[r]: global ids of rank r's genomes in shard order.
@@ -87,7 +98,7 @@ def exchange_and_profile(contain_fn, group, sample_k, sample_c, owner, rank_geno
         row = np.zeros(G_max, dtype=np.int64)
         row[:G_local] = cc
         parts.append(row)
-        cov_parts.append(np.asarray(covs, dtype=np.int64))
+        cov_parts.append(np.array(covs, dtype=np.int64))   # a copy: contain_fn may hand out views it will overwrite
     # 3. ONE all-gather of [counts of all samples | packed covs of all samples] per rank
     counts_block = np.concatenate(parts)
     payload = np.concatenate([counts_block] + cov_parts)
@@ -97,7 +108,7 @@ def exchange_and_profile(contain_fn, group, sample_k, sample_c, owner, rank_geno
     contain_count = np.zeros(n_total, dtype=np.uint32)
     cov_lists = [None] * world
     for r in range(world):
-        buf = got[r].cpu().numpy()
+        buf = to_host_numpy(got[r])
         counts = buf[: world * G_max].reshape(world, G_max)
         covs_r = buf[world * G_max:]
         g_r = len(rank_genomes[r])
@@ -127,12 +138,12 @@ def profile_step(db, group, dk_ptr, dc_ptr, n, mine, n_total, device, _cache={})
     """bench.py glue: db is a sylph_amd.Database holding this rank's shard; (dk_ptr, dc_ptr, n) the device-resident
     sample table of this rank."""
     if group.world == 1:
-        cc, off, covs = db.contain(dk_ptr, dc_ptr, device_ptrs=True, n=n)
+        cc, off, covs = db.contain_view(dk_ptr, dc_ptr, device_ptrs=True, n=n)   # borrowed pinned views
         return dict(contain_count=cc, cov_off=off, covs=covs, n_occurrences=None)
     key = (id(db), n_total)
     if key not in _cache:
         sizes = group.all_gather_var(torch.from_numpy(np.asarray(mine, dtype=np.int64)).to(device))
-        rank_genomes = [t.cpu().numpy() for t in sizes]
+        rank_genomes = [to_host_numpy(t).copy() for t in sizes]
         owner = np.zeros(n_total, dtype=np.int32)
         for r, g in enumerate(rank_genomes):
             owner[g] = r
@@ -141,8 +152,8 @@ def profile_step(db, group, dk_ptr, dc_ptr, n, mine, n_total, device, _cache={})
     sk = device_view(dk_ptr, n, torch.int64, device)
     sc = device_view(dc_ptr, n, torch.int32, device)
 
-    def contain_fn(k, c):
-        return db.contain(k.data_ptr(), c.data_ptr(), device_ptrs=True, n=k.numel())
+    def contain_fn(k, c):   # borrowed pinned views; exchange_and_profile copies what it keeps before the next call
+        return db.contain_view(k.data_ptr(), c.data_ptr(), device_ptrs=True, n=k.numel())
 
     res = exchange_and_profile(contain_fn, group, sk, sc, owner, rank_genomes)
     res["n_occurrences"] = None

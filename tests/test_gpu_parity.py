@@ -256,6 +256,8 @@ def test_read_sketch_empty(ctx):
 def check_contain(ctx, db_kmers, goff, sk, sc, min_kmers=50.0):
     db = S.Database(ctx, db_kmers, goff)
     cc, off, covs = db.contain(sk, sc, min_number_kmers=min_kmers)
+    vcc, voff, vcovs = db.contain_view(sk, sc, min_number_kmers=min_kmers)   # borrowed pinned views: same answer
+    assert np.array_equal(vcc, cc) and np.array_equal(voff, off) and np.array_equal(vcovs, covs)
     db.close()
     ecc, ecov, _ = O.contain(sk, sc, db_kmers, goff, min_number_kmers=min_kmers)
     assert np.array_equal(cc, ecc)
