@@ -518,7 +518,8 @@ static void seeds_positions_impl(sylph_ctx* ctx, const uint8_t* bases, const uin
     SY_REQUIRE(seed_mode == SYLPH_SEED_SCALAR || seed_mode == SYLPH_SEED_AVX2_COMPAT, "bad seed_mode %d", seed_mode);
     SY_REQUIRE(k == 21 || k == 31, "k must be 21 or 31 (avx2_seeding.rs:46-52)");
     if (n_contigs == 0) return;
-    SY_REQUIRE(bases && contig_off && contig_off[0] == 0, "bad contig offsets");
+    SY_REQUIRE(contig_off && contig_off[0] == 0, "bad contig offsets");
+    SY_REQUIRE(bases || contig_off[n_contigs] == 0, "null bases");
     SY_REQUIRE(n_contigs < (1ull << 32), "too many contigs");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);

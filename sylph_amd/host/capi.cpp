@@ -1,0 +1,88 @@
+// capi.cpp — flat C entry points over the host library for ctypes tests (statistics + on-disk formats).
+#include <cstring>
+
+#include "sylph_host.hpp"
+
+using namespace sylph_host;
+
+extern "C" {
+
+struct SylphHostStats {
+    double naive_ani, final_est_ani, final_est_cov, mean_cov, median_cov, lambda;
+    double ani_ci_lo, ani_ci_hi, lambda_ci_lo, lambda_ci_hi;
+    int32_t lambda_status;   // 0 Low, 1 High, 2 Lambda
+    int32_t passed, has_ci, pad;
+    uint64_t contain_count, n_kmers;
+};
+
+// statistics half of get_stats (contain.rs:657-813)
+int sylph_host_stats(const uint32_t* covs, uint64_t n, uint64_t n_genome_kmers, uint64_t k, double min_count_correct,
+                     double minimum_ani_or_neg, int pseudotax, int no_ci, int no_adj, int mean_coverage, SylphHostStats* out) {
+    memset(out, 0, sizeof(*out));
+    ContainArgs a;
+    a.min_count_correct = min_count_correct;
+    if (minimum_ani_or_neg >= 0) a.minimum_ani = minimum_ani_or_neg;
+    a.pseudotax = pseudotax; a.no_ci = no_ci; a.no_adj = no_adj; a.mean_coverage = mean_coverage;
+    auto r = stats_from_covs(a, std::vector<uint32_t>(covs, covs + n), n_genome_kmers, k, std::nullopt);
+    if (!r) return 0;
+    out->passed = 1;
+    out->naive_ani = r->naive_ani; out->final_est_ani = r->final_est_ani; out->final_est_cov = r->final_est_cov;
+    out->mean_cov = r->mean_cov; out->median_cov = r->median_cov; out->lambda = r->lambda;
+    out->lambda_status = r->lambda_status == AdjustStatus::Low ? 0 : (r->lambda_status == AdjustStatus::High ? 1 : 2);
+    if (r->ani_ci_lo) { out->has_ci = 1; out->ani_ci_lo = *r->ani_ci_lo; out->ani_ci_hi = *r->ani_ci_hi; out->lambda_ci_lo = *r->lambda_ci_lo; out->lambda_ci_hi = *r->lambda_ci_hi; }
+    out->contain_count = r->contain_count; out->n_kmers = r->n_kmers;
+    return 1;
+}
+
+double sylph_host_poisson_cdf(double lambda, uint64_t x) { return poisson_cdf(lambda, x); }
+
+// round trip helpers: write a .sylsp from arrays, read it back into caller buffers (sizes via the first call)
+int sylph_host_write_sylsp(const char* path, const uint64_t* kmers, const uint32_t* counts, uint64_t n, uint64_t c, uint64_t k,
+                           const char* file_name, const char* sample_name_or_null, int paired, double mean_read_length) {
+    try {
+        SequencesSketch s;
+        s.kmers.assign(kmers, kmers + n); s.counts.assign(counts, counts + n);
+        s.c = c; s.k = k; s.file_name = file_name; s.paired = paired; s.mean_read_length = mean_read_length;
+        if (sample_name_or_null) s.sample_name = sample_name_or_null;
+        write_sylsp(path, s);
+        return 0;
+    } catch (const Error&) { return -1; }
+}
+
+int sylph_host_read_sylsp(const char* path, uint64_t* kmers, uint32_t* counts, uint64_t cap, uint64_t* n, uint64_t* c, uint64_t* k,
+                          int* paired, double* mean_read_length, char* file_name, char* sample_name, uint64_t name_cap,
+                          int* has_sample_name) {
+    try {
+        SequencesSketch s = read_sylsp(path);
+        *n = s.kmers.size(); *c = s.c; *k = s.k; *paired = s.paired; *mean_read_length = s.mean_read_length;
+        *has_sample_name = s.sample_name ? 1 : 0;
+        snprintf(file_name, name_cap, "%s", s.file_name.c_str());
+        snprintf(sample_name, name_cap, "%s", s.sample_name ? s.sample_name->c_str() : "");
+        for (uint64_t i = 0; i < s.kmers.size() && i < cap; i++) { kmers[i] = s.kmers[i]; counts[i] = s.counts[i]; }
+        return 0;
+    } catch (const Error&) { return -1; }
+}
+
+// .syldb: number of genomes, then per-genome accessors
+void* sylph_host_read_syldb(const char* path) {
+    try { return new std::vector<GenomeSketch>(read_syldb(path)); } catch (const Error&) { return nullptr; }
+}
+uint64_t sylph_host_syldb_size(void* h) { return ((std::vector<GenomeSketch>*)h)->size(); }
+void sylph_host_syldb_genome(void* h, uint64_t i, uint64_t* n_kmers, uint64_t* n_tracked, int* has_tracked, uint64_t* c, uint64_t* k,
+                             uint64_t* gn_size, uint64_t* min_spacing, char* file_name, char* contig_name, uint64_t name_cap) {
+    const GenomeSketch& g = (*(std::vector<GenomeSketch>*)h)[i];
+    *n_kmers = g.genome_kmers.size();
+    *has_tracked = g.pseudotax_tracked_nonused_kmers ? 1 : 0;
+    *n_tracked = g.pseudotax_tracked_nonused_kmers ? g.pseudotax_tracked_nonused_kmers->size() : 0;
+    *c = g.c; *k = g.k; *gn_size = g.gn_size; *min_spacing = g.min_spacing;
+    snprintf(file_name, name_cap, "%s", g.file_name.c_str());
+    snprintf(contig_name, name_cap, "%s", g.first_contig_name.c_str());
+}
+void sylph_host_syldb_copy(void* h, uint64_t i, uint64_t* kmers, uint64_t* tracked) {
+    const GenomeSketch& g = (*(std::vector<GenomeSketch>*)h)[i];
+    memcpy(kmers, g.genome_kmers.data(), g.genome_kmers.size() * 8);
+    if (g.pseudotax_tracked_nonused_kmers && tracked) memcpy(tracked, g.pseudotax_tracked_nonused_kmers->data(), g.pseudotax_tracked_nonused_kmers->size() * 8);
+}
+void sylph_host_syldb_free(void* h) { delete (std::vector<GenomeSketch>*)h; }
+
+}  // extern "C"

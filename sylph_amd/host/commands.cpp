@@ -1,0 +1,522 @@
+// commands.cpp — minimal restatement of the sketch / contain command drivers (sketch.rs:276-479, contain.rs:115-351)
+// around the GPU engine: parse records on the host, push batches through the C ABI, keep the sequential f64
+// bookkeeping here, run the statistics on the containment results, print the reference's TSV rows.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <memory>
+
+#include "sylph_host.hpp"
+
+namespace sylph_host {
+
+namespace {
+
+void hip_check(int rc, const char* what) {
+    if (rc != SYLPH_OK) throw Error{1, std::string(what) + ": " + sylph_last_error()};
+}
+void warn(const std::string& m) { fprintf(stderr, "WARN  [sylph_hip] %s\n", m.c_str()); }
+void info(const std::string& m) { fprintf(stderr, "INFO  [sylph_hip] %s\n", m.c_str()); }
+
+template <class T>
+std::vector<T> take(T* p, uint64_t n) {
+    std::vector<T> v(p, p + n);
+    sylph_free(p);
+    return v;
+}
+
+std::string basename_of(const std::string& p) {
+    const size_t s = p.find_last_of('/');
+    return s == std::string::npos ? p : p.substr(s + 1);
+}
+std::string dirname_of(const std::string& p) {
+    const size_t s = p.find_last_of('/');
+    return s == std::string::npos ? std::string() : p.substr(0, s);
+}
+void create_dir_all(const std::string& dir) {
+    if (dir.empty()) return;
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); i++) {
+        if (i == dir.size() || dir[i] == '/') {
+            if (!cur.empty() && cur != "." && cur != "..") mkdir(cur.c_str(), 0777);
+        }
+        if (i < dir.size()) cur += dir[i];
+    }
+}
+std::string path_join(const std::string& a, const std::string& b) {
+    if (a.empty()) return b;
+    return a.back() == '/' ? a + b : a + "/" + b;
+}
+void parse_line_file(const std::string& file, std::vector<std::string>& out) {   // sketch.rs:252
+    std::ifstream f(file);
+    if (!f) throw Error{1, "could not open list file " + file};
+    std::string line;
+    while (std::getline(f, line)) out.push_back(line);
+}
+
+// Batches records into one flat buffer + offsets and pushes them to a GPU session.
+struct Batcher {
+    sylph_sketch* sk;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off{0};
+    static constexpr size_t BATCH = 512u << 20;
+    void add(const std::string& seq) {
+        bases.insert(bases.end(), seq.begin(), seq.end());
+        off.push_back(bases.size());
+    }
+    void flush(bool force) {
+        if (off.size() == 1 || (!force && bases.size() < BATCH)) return;
+        hip_check(sylph_sketch_push(sk, bases.data(), off.data(), off.size() - 1, SYLPH_MEM_HOST), "sylph_sketch_push");
+        bases.clear();
+        off.assign(1, 0);
+    }
+};
+
+struct Session {   // RAII
+    sylph_sketch* sk = nullptr;
+    Session(Engine& e, uint64_t c, uint64_t k, bool paired, bool no_dedup) {
+        hip_check(sylph_sketch_begin(e.ctx, (uint32_t)c, (uint32_t)k, paired ? SYLPH_READS_PAIRED : SYLPH_READS_SINGLE,
+                                     no_dedup ? 1 : 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
+    }
+    ~Session() { sylph_sketch_destroy(sk); }
+    void finish(SequencesSketch& out) {
+        uint64_t* k = nullptr; uint32_t* c = nullptr; uint64_t n = 0, dup = 0;
+        hip_check(sylph_sketch_finish(sk, &k, &c, &n, &dup), "sylph_sketch_finish");
+        out.kmers = take(k, n);
+        out.counts = take(c, n);
+    }
+};
+
+}  // namespace
+
+Engine::Engine(int device) { hip_check(sylph_ctx_create(device, nullptr, &ctx), "sylph_ctx_create"); }
+Engine::~Engine() { sylph_ctx_destroy(ctx); }
+
+// sketch.rs:897-959
+std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
+                                                       std::optional<std::string> sample_name, bool no_dedup) {
+    std::unique_ptr<FastxReader> reader;
+    try { reader.reset(new FastxReader(read_file)); }
+    catch (const Error&) { warn(read_file + " is not a valid fasta/fastq file; skipping."); return std::nullopt; }   // :911-914
+    Session s(e, c, k, false, no_dedup);
+    Batcher b{s.sk};
+    double mean_read_length = 0., counter = 0.;
+    FastxRecord rec;
+    for (;;) {
+        bool ok;
+        try { ok = reader->next(rec); }
+        catch (const Error&) { warn("File " + read_file + " is not a valid fasta/fastq file"); break; }   // :945
+        if (!ok) break;
+        b.add(rec.seq);
+        counter += 1.;                                                       // :941-943
+        mean_read_length = mean_read_length + ((double)rec.seq.size() - mean_read_length) / counter;
+        b.flush(false);
+    }
+    b.flush(true);
+    SequencesSketch out;
+    s.finish(out);
+    out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
+    out.sample_name = std::move(sample_name);
+    out.mean_read_length = mean_read_length;
+    return out;
+}
+
+// sketch.rs:771-895.  The exact marker set (--fpr 0, :829-838) is the only dedup structure on the GPU; the reference's
+// default for pairs is an approximate cuckoo filter (third-party crate) with the same intent.
+std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::string& read_file1, const std::string& read_file2,
+                                                     uint64_t c, uint64_t k, std::optional<std::string> sample_name,
+                                                     bool no_dedup, double /*dedup_fpr*/) {
+    std::unique_ptr<FastxReader> r1, r2;
+    try { r1.reset(new FastxReader(read_file1)); r2.reset(new FastxReader(read_file2)); }
+    catch (const Error&) {
+        throw Error{1, "Paired end reading failed for '" + read_file1 + "' and '" + read_file2 +
+                           "'. Make sure the files are present or the sequences are valid."};   // :781-784
+    }
+    Session s(e, c, k, true, no_dedup);
+    Batcher b{s.sk};
+    double mean_read_length = 0., counter = 0.;
+    FastxRecord rec1, rec2;
+    for (;;) {
+        bool ok1, ok2 = false, bad2 = false;
+        try { ok1 = r1->next(rec1); } catch (const Error&) { return std::nullopt; }   // :878-880
+        try { ok2 = r2->next(rec2); } catch (const Error&) { bad2 = true; }
+        if (!ok1) break;                                                     // :881-883
+        if (!ok2 || bad2) continue;                                          // mate 2 missing/invalid: pair skipped
+        b.add(rec1.seq);
+        b.add(rec2.seq);
+        counter += 1.;                                                       // :824-826 (mate-1 length only)
+        mean_read_length = mean_read_length + ((double)rec1.seq.size() - mean_read_length) / counter;
+        b.flush(false);
+    }
+    b.flush(true);
+    SequencesSketch out;
+    s.finish(out);
+    out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;
+    out.sample_name = std::move(sample_name);
+    out.mean_read_length = mean_read_length;
+    return out;
+}
+
+static GenomeSketch genome_from_contigs(Engine& e, const std::vector<uint8_t>& bases, const std::vector<uint64_t>& off, uint64_t c,
+                                        uint64_t k, uint64_t min_spacing, bool pseudotax) {
+    GenomeSketch g;
+    uint64_t *gk = nullptr, *tr = nullptr, n = 0, nt = 0;
+    hip_check(sylph_sketch_genome(e.ctx, bases.data(), off.data(), off.size() - 1, (uint32_t)c, (uint32_t)k,
+                                  SYLPH_SEED_AVX2_COMPAT, min_spacing, pseudotax ? 1 : 0, &gk, &n, &tr, &nt),
+              "sylph_sketch_genome");
+    g.genome_kmers = take(gk, n);
+    auto t = take(tr, nt);
+    if (pseudotax) g.pseudotax_tracked_nonused_kmers = std::move(t);
+    g.c = c; g.k = k; g.min_spacing = min_spacing;
+    return g;
+}
+
+// sketch.rs:550-622
+std::optional<GenomeSketch> sketch_genome(Engine& e, uint64_t c, uint64_t k, const std::string& ref_file, uint64_t min_spacing,
+                                          bool pseudotax) {
+    std::unique_ptr<FastxReader> reader;
+    try { reader.reset(new FastxReader(ref_file)); }
+    catch (const Error&) { warn(ref_file + " is not a valid fasta/fastq file; skipping."); return std::nullopt; }
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off{0};
+    std::string first_name;
+    bool first = true;
+    FastxRecord rec;
+    try {
+        while (reader->next(rec)) {
+            if (first) { first_name = rec.id; first = false; }
+            bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
+            off.push_back(bases.size());
+        }
+    } catch (const Error&) { warn("File " + ref_file + " is not a valid fasta/fastq file"); return std::nullopt; }   // :586-589
+    GenomeSketch g = genome_from_contigs(e, bases, off, c, k, min_spacing, pseudotax);
+    g.file_name = ref_file;
+    g.first_contig_name = first_name;
+    g.gn_size = bases.size();
+    return g;
+}
+
+// sketch.rs:481-548
+std::vector<GenomeSketch> sketch_genome_individual(Engine& e, uint64_t c, uint64_t k, const std::string& ref_file,
+                                                   uint64_t min_spacing, bool pseudotax) {
+    std::vector<GenomeSketch> out;
+    std::unique_ptr<FastxReader> reader;
+    try { reader.reset(new FastxReader(ref_file)); }
+    catch (const Error&) { warn(ref_file + " is not a valid fasta/fastq file; skipping."); return out; }
+    FastxRecord rec;
+    try {
+        while (reader->next(rec)) {
+            std::vector<uint8_t> bases(rec.seq.begin(), rec.seq.end());
+            std::vector<uint64_t> off{0, (uint64_t)bases.size()};
+            GenomeSketch g = genome_from_contigs(e, bases, off, c, k, min_spacing, pseudotax);
+            g.file_name = ref_file;
+            g.first_contig_name = rec.id;
+            g.gn_size = bases.size();
+            out.push_back(std::move(g));
+        }
+    } catch (const Error&) { warn("File " + ref_file + " is not a valid fasta/fastq file"); return {}; }
+    return out;
+}
+
+// sketch.rs:276-479
+int sketch(Engine& e, const SketchArgs& args) {
+    std::vector<std::string> read_inputs, genome_inputs, first_pairs, second_pairs;
+    const bool nothing = args.files.empty() && !args.list_sequence && args.first_pair.empty() && args.second_pair.empty() &&
+                         args.genomes.empty() && args.reads.empty() && !args.list_genomes && !args.list_reads &&
+                         !args.list_first_pair && !args.list_second_pair;
+    if (nothing) throw Error{1, "No input sequences found; see sylph sketch -h for help. Exiting."};   // :144-157
+    if (args.fpr < 0. || args.fpr >= 1.) throw Error{1, "Invalid FPR for sketching. Must be in [0,1)."};   // :158-161
+    std::vector<std::string> all_files;
+    if (args.list_sequence) parse_line_file(*args.list_sequence, all_files);
+    all_files.insert(all_files.end(), args.files.begin(), args.files.end());
+    for (const auto& f : all_files) {                                        // :164-189
+        if (is_fastq(f)) read_inputs.push_back(f);
+        else if (is_fasta(f)) genome_inputs.push_back(f);
+        else warn(f + " does not have a fasta/fastq/gzip type extension; skipping");
+    }
+    genome_inputs.insert(genome_inputs.end(), args.genomes.begin(), args.genomes.end());   // :191-216
+    read_inputs.insert(read_inputs.end(), args.reads.begin(), args.reads.end());
+    if (args.list_reads) parse_line_file(*args.list_reads, read_inputs);
+    if (args.list_genomes) parse_line_file(*args.list_genomes, genome_inputs);
+    if (args.first_pair.size() != args.second_pair.size()) throw Error{1, "Different number of paired sequences. Exiting."};
+    first_pairs = args.first_pair;
+    second_pairs = args.second_pair;
+    if (args.list_first_pair) parse_line_file(*args.list_first_pair, first_pairs);
+    if (args.list_second_pair) parse_line_file(*args.list_second_pair, second_pairs);
+    if (first_pairs.size() != second_pairs.size()) throw Error{1, "Different number of paired sequences. Exiting."};
+    std::optional<std::vector<std::string>> sample_names;                    // :260-274
+    if (args.list_sample_names) { sample_names.emplace(); parse_line_file(*args.list_sample_names, *sample_names); }
+    else if (args.sample_names) sample_names = args.sample_names;
+    if (sample_names && sample_names->size() != first_pairs.size() + read_inputs.size())
+        throw Error{1, "Sample name length is not equal to the number of reads. Exiting"};   // :288-292
+    if (args.fpr != 0. && !first_pairs.empty())
+        info("paired-end dedup uses the exact marker set (the reference's --fpr 0 path); --fpr is accepted for compatibility");
+
+    for (size_t i = 0; i < first_pairs.size(); i++) {                        // :311-367
+        std::optional<std::string> sample_name;
+        if (sample_names) sample_name = (*sample_names)[i];
+        auto sk = sketch_pair_sequences(e, first_pairs[i], second_pairs[i], args.c, args.k, sample_name, args.no_dedup, args.fpr);
+        if (!sk) continue;
+        create_dir_all(args.sample_output_dir);
+        const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
+        const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
+        write_sylsp(path, *sk);
+        info("Sketching " + path + " complete.");
+    }
+    for (size_t i = 0; i < read_inputs.size(); i++) {                        // :369-420
+        create_dir_all(args.sample_output_dir);
+        std::optional<std::string> sample_name;
+        if (sample_names) sample_name = (*sample_names)[i + first_pairs.size()];
+        auto sk = sketch_sequences_needle(e, read_inputs[i], args.c, args.k, sample_name, args.no_dedup);
+        if (!sk) continue;
+        const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
+        const std::string path = path_join(args.sample_output_dir, basename_of(name)) + SAMPLE_FILE_SUFFIX;
+        write_sylsp(path, *sk);
+        info("Sketching " + path + " complete.");
+    }
+    if (!genome_inputs.empty()) {                                            // :422-476
+        const std::string path = args.db_out_name + QUERY_FILE_SUFFIX;
+        create_dir_all(dirname_of(path));
+        std::vector<GenomeSketch> all;
+        for (const auto& gf : genome_inputs) {
+            if (args.individual) {
+                auto v = sketch_genome_individual(e, args.c, args.k, gf, args.min_spacing_kmer, !args.no_pseudotax);
+                for (auto& g : v) all.push_back(std::move(g));
+            } else {
+                auto g = sketch_genome(e, args.c, args.k, gf, args.min_spacing_kmer, !args.no_pseudotax);
+                if (g) all.push_back(std::move(*g));
+            }
+        }
+        if (all.empty()) warn("No valid genomes to sketch; " + path + " is not output");
+        else { write_syldb(path, all); info("Wrote all genome sketches to " + path); }
+    }
+    info("Finished.");
+    return 0;
+}
+
+// ---- contain ----------------------------------------------------------------------------------------------------
+
+namespace {
+
+// contain.rs:18-94
+void print_ani_result(const AniResult& r, const std::string& seq_name, const GenomeSketch& g, bool pseudotax, FILE* out) {
+    char final_ani[64];
+    snprintf(final_ani, sizeof(final_ani), "%.2f", std::min(r.final_est_ani * 100., 100.));
+    char lambda_print[64];
+    if (r.lambda_status == AdjustStatus::Lambda) snprintf(lambda_print, sizeof(lambda_print), "%.3f", r.lambda);
+    else snprintf(lambda_print, sizeof(lambda_print), "%s", r.lambda_status == AdjustStatus::High ? "HIGH" : "LOW");
+    char ci_ani[64] = "NA-NA", ci_lambda[64] = "NA-NA";
+    if (r.ani_ci_lo && r.ani_ci_hi) snprintf(ci_ani, sizeof(ci_ani), "%.2f-%.2f", *r.ani_ci_lo * 100., *r.ani_ci_hi * 100.);
+    if (r.lambda_ci_lo && r.lambda_ci_hi) snprintf(ci_lambda, sizeof(ci_lambda), "%.2f-%.2f", *r.lambda_ci_lo, *r.lambda_ci_hi);
+    if (!pseudotax) {
+        fprintf(out, "%s\t%s\t%s\t%.3f\t%s\t%s\t%s\t%.0f\t%.3f\t%zu/%zu\t%.2f\t%s\n", seq_name.c_str(), g.file_name.c_str(),
+                final_ani, r.final_est_cov, ci_ani, lambda_print, ci_lambda, r.median_cov, r.mean_cov, r.contain_count, r.n_kmers,
+                r.naive_ani * 100., g.first_contig_name.c_str());
+    } else {
+        fprintf(out, "%s\t%s\t%.4f\t%.4f\t%s\t%.3f\t%s\t%s\t%s\t%.0f\t%.3f\t%zu/%zu\t%.2f\t%zu\t%s\n", seq_name.c_str(),
+                g.file_name.c_str(), *r.rel_abund, *r.seq_abund, final_ani, r.final_est_cov, ci_ani, lambda_print, ci_lambda,
+                r.median_cov, r.mean_cov, r.contain_count, r.n_kmers, r.naive_ani * 100., *r.kmers_lost,
+                g.first_contig_name.c_str());
+    }
+}
+
+void print_header(bool pseudotax, FILE* out, bool estimate_unknown) {         // contain.rs:461-480
+    if (!pseudotax)
+        fprintf(out, "Sample_file\tGenome_file\tAdjusted_ANI\tEff_cov\tANI_5-95_percentile\tEff_lambda\tLambda_5-95_percentile\t"
+                     "Median_cov\tMean_cov_geq1\tContainment_ind\tNaive_ANI\tContig_name\n");
+    else
+        fprintf(out, "Sample_file\tGenome_file\tTaxonomic_abundance\tSequence_abundance\tAdjusted_ANI\t%s\tANI_5-95_percentile\t"
+                     "Eff_lambda\tLambda_5-95_percentile\tMedian_cov\tMean_cov_geq1\tContainment_ind\tNaive_ANI\tkmers_reassigned\t"
+                     "Contig_name\n", estimate_unknown ? "True_cov" : "Eff_cov");
+}
+
+// open-addressing map sample k-mer -> count for the winner pass (contain.rs:632-652 with winner_map)
+struct SampleMap {
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> vals;
+    uint64_t mask = 0;
+    explicit SampleMap(const SequencesSketch& s) {
+        uint64_t cap = 16;
+        while (cap < s.kmers.size() * 2 + 1) cap <<= 1;
+        keys.assign(cap, ~0ull);
+        vals.assign(cap, 0);
+        mask = cap - 1;
+        for (size_t i = 0; i < s.kmers.size(); i++) {
+            uint64_t h = (s.kmers[i] * 0x9E3779B97F4A7C15ull) >> 20 & mask;
+            while (keys[h] != ~0ull) h = (h + 1) & mask;
+            keys[h] = s.kmers[i];
+            vals[h] = s.counts[i];
+        }
+    }
+    uint32_t get(uint64_t k) const {
+        uint64_t h = (k * 0x9E3779B97F4A7C15ull) >> 20 & mask;
+        while (keys[h] != ~0ull) {
+            if (keys[h] == k) return vals[h];
+            h = (h + 1) & mask;
+        }
+        return 0;
+    }
+};
+
+}  // namespace
+
+// contain.rs:115-351
+int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
+    if (pseudotax_in) args.pseudotax = true;
+    if (args.estimate_unknown)
+        throw Error{1, "--estimate-unknown (-u) is not supported: it depends on hash-map iteration order in the reference"};
+    std::vector<std::string> genome_sketch_files, genome_files, read_sketch_files;
+    std::vector<std::vector<std::string>> read_files;
+    std::vector<std::string> all_files = args.files;
+    if (args.file_list) parse_line_file(*args.file_list, all_files);
+    auto ends = [](const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; };
+    for (const auto& f : all_files) {                                        // contain.rs:165-198
+        if (ends(f, ".syldb") || ends(f, ".sylqueries")) genome_sketch_files.push_back(f);
+        else if (ends(f, ".sylsp") || ends(f, ".sylsample")) read_sketch_files.push_back(f);
+        else if (is_fasta(f)) genome_files.push_back(f);
+        else if (is_fastq(f)) read_files.push_back({f});
+        else warn(f + " file extension is not a sketch or a fasta/fastq file.");
+    }
+    if (args.first_pair.size() != args.second_pair.size())
+        throw Error{1, "Different number of paired sequences (-1, -2) for sketching. Exiting."};
+    for (size_t i = 0; i < args.first_pair.size(); i++) read_files.push_back({args.first_pair[i], args.second_pair[i]});
+    for (const auto& r : args.reads) read_files.push_back({r});
+    if (genome_sketch_files.empty() && genome_files.empty())
+        throw Error{1, "No genome files found; see sylph query/profile -h for help. Exiting"};
+    if (read_sketch_files.empty() && read_files.empty())
+        throw Error{1, "No read files found; see sylph query/profile -h for help. Exiting"};
+
+    // get_genome_sketches, contain.rs:482-541
+    std::vector<GenomeSketch> genome_sketches;
+    std::optional<uint64_t> lowest_genome_c, current_k;
+    for (const auto& f : genome_sketch_files) {
+        auto v = read_syldb(f);
+        if (v.empty()) continue;
+        const uint64_t c = v.front().c, k = v.front().k;
+        if (!lowest_genome_c || *lowest_genome_c < c) lowest_genome_c = c;
+        if (!current_k) current_k = k;
+        else if (*current_k != k) throw Error{1, "Query sketches have inconsistent -k. Exiting."};
+        for (auto& g : v) genome_sketches.push_back(std::move(g));
+    }
+    for (const auto& gf : genome_files) {
+        if (lowest_genome_c && *lowest_genome_c < args.c) { fprintf(stderr, "ERROR [sylph_hip] Value of -c for contain is %llu -- greater than the smallest value of -c for a genome sketch %llu. Continuing without sketching.\n", (unsigned long long)args.c, (unsigned long long)*lowest_genome_c); continue; }
+        if (current_k && *current_k != args.k) { fprintf(stderr, "ERROR [sylph_hip] -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", (unsigned long long)args.k, (unsigned long long)*current_k); continue; }
+        if (args.individual) {
+            auto v = sketch_genome_individual(e, args.c, args.k, gf, args.min_spacing_kmer, args.pseudotax);
+            for (auto& g : v) genome_sketches.push_back(std::move(g));
+        } else {
+            auto g = sketch_genome(e, args.c, args.k, gf, args.min_spacing_kmer, args.pseudotax);
+            if (g) genome_sketches.push_back(std::move(*g));
+        }
+    }
+    info("Finished obtaining genome sketches.");
+    if (genome_sketches.empty()) throw Error{1, "No genome sketches found; see sylph query/profile -h for help. Exiting"};
+    if (!genome_sketches.front().pseudotax_tracked_nonused_kmers && args.pseudotax)
+        throw Error{1, "Attempting profiling, but *.syldb was sketched with the --disable-profiling option. Exiting"};   // :234-237
+
+    // database resident in HBM (replaces the per-genome probe loop of contain.rs:284-291)
+    std::vector<uint64_t> flat, goff{0};
+    for (const auto& g : genome_sketches) { flat.insert(flat.end(), g.genome_kmers.begin(), g.genome_kmers.end()); goff.push_back(flat.size()); }
+    sylph_db* db = nullptr;
+    hip_check(sylph_db_upload(e.ctx, flat.data(), goff.data(), genome_sketches.size(), SYLPH_MEM_HOST, &db), "sylph_db_upload");
+    struct DbGuard { sylph_db* d; ~DbGuard() { sylph_db_destroy(d); } } guard{db};
+    { std::vector<uint64_t>().swap(flat); }
+
+    print_header(args.pseudotax, out, args.estimate_unknown);
+    const uint64_t genome_c = genome_sketches[0].c, genome_k = genome_sketches[0].k;
+    std::vector<std::pair<std::vector<std::string>, bool>> samples;
+    for (auto& r : read_files) samples.push_back({r, false});
+    for (auto& s : read_sketch_files) samples.push_back({{s}, true});
+
+    for (const auto& [files, is_sketch] : samples) {
+        // get_seq_sketch, contain.rs:544-599
+        std::optional<SequencesSketch> seq;
+        if (is_sketch) {
+            SequencesSketch s = read_sylsp(files[0]);
+            if (s.c > genome_c) { fprintf(stderr, "ERROR [sylph_hip] %s value of -c is %llu; this is greater than the smallest value of -c = %llu for a genome sketch. Exiting.\n", files[0].c_str(), (unsigned long long)s.c, (unsigned long long)genome_c); }
+            else seq = std::move(s);
+        } else if (genome_c < args.c) {
+            fprintf(stderr, "ERROR [sylph_hip] %s error: value of -c for contain = %llu -- greater than the smallest value of -c for a genome sketch = %llu. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.c, (unsigned long long)genome_c);
+        } else if (genome_k != args.k) {
+            fprintf(stderr, "ERROR [sylph_hip] %s -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.k, (unsigned long long)genome_k);
+        } else if (files.size() == 1) {
+            seq = sketch_sequences_needle(e, files[0], args.c, args.k, std::nullopt, false);
+        } else {
+            seq = sketch_pair_sequences(e, files[0], files[1], args.c, args.k, std::nullopt, false, DEFAULT_FPR);
+        }
+        if (seq) {
+            const SequencesSketch& S = *seq;
+            if (genome_k != S.k) throw Error{1, "k parameter for reads != k parameter for genome"};   // contain.rs:608-615
+            const std::string seq_name = S.sample_name ? *S.sample_name : S.file_name;   // :775-781
+            // first pass: GPU probe of every genome, then host statistics
+            const uint32_t* cc = nullptr; const uint64_t* coff = nullptr; const uint32_t* covs = nullptr; uint64_t ncov = 0;
+            hip_check(sylph_db_contain_view(db, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST,
+                                            args.min_number_kmers, &cc, &coff, &covs, &ncov), "sylph_db_contain_view");
+            std::vector<AniResult> stats;
+            for (size_t g = 0; g < genome_sketches.size(); g++) {
+                if (genome_sketches[g].c < S.c) throw Error{1, "c parameter for reads > c parameter for genome"};   // :616-623
+                if (cc[g] == 0) continue;                                    // :654
+                std::vector<uint32_t> cv(covs + coff[g], covs + coff[g + 1]);
+                auto r = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, std::nullopt);
+                if (r) { r->genome_index = g; stats.push_back(*r); }
+            }
+            if (args.pseudotax) {
+                info(files[0] + " taxonomic profiling; reassigning k-mers for " + std::to_string(stats.size()) + " genomes...");
+                // winner_table, contain.rs:410-430: first inserted wins ties (strict >)
+                std::unordered_map<uint64_t, std::pair<double, size_t>> winner;
+                for (const auto& r : stats) {
+                    const GenomeSketch& g = genome_sketches[r.genome_index];
+                    auto feed = [&](const std::vector<uint64_t>& v) {
+                        for (uint64_t km : v) {
+                            auto it = winner.find(km);
+                            if (it == winner.end()) winner.emplace(km, std::make_pair(r.final_est_ani, r.genome_index));
+                            else if (r.final_est_ani > it->second.first) it->second = {r.final_est_ani, r.genome_index};
+                        }
+                    };
+                    feed(g.genome_kmers);
+                    if (g.pseudotax_tracked_nonused_kmers) feed(*g.pseudotax_tracked_nonused_kmers);
+                }
+                // second get_stats pass with the winner map, contain.rs:300-307 / :637-646
+                SampleMap smap(S);
+                std::vector<AniResult> stats2;
+                for (const auto& old : stats) {
+                    const GenomeSketch& g = genome_sketches[old.genome_index];
+                    if ((double)g.genome_kmers.size() < args.min_number_kmers) continue;
+                    std::vector<uint32_t> cv;
+                    size_t lost = 0;
+                    for (uint64_t km : g.genome_kmers) {
+                        const uint32_t cnt = smap.get(km);
+                        if (cnt == 0) continue;
+                        if (winner.at(km).second != old.genome_index) { lost++; continue; }
+                        cv.push_back(cnt);
+                    }
+                    auto r = stats_from_covs(args, std::move(cv), g.genome_kmers.size(), S.k, lost);
+                    if (!r) continue;
+                    r->genome_index = old.genome_index;
+                    // derep_if_reassign_threshold, contain.rs:353-375
+                    const double thr = std::pow(args.redundant_ani / 100., (double)S.k) * (double)r->n_kmers;
+                    if ((double)(old.contain_count - r->contain_count) < thr) stats2.push_back(*r);
+                }
+                stats.swap(stats2);
+                info(files[0] + " has " + std::to_string(stats.size()) + " genomes passing profiling threshold. ");
+                double total_cov = 0, total_seq_cov = 0;                     // contain.rs:319-326
+                for (const auto& r : stats) { total_cov += r.final_est_cov; total_seq_cov += r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size; }
+                for (auto& r : stats) r.rel_abund = r.final_est_cov / total_cov * 100.;
+                for (auto& r : stats) r.seq_abund = r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size / total_seq_cov * 100. * 1.;
+                std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return *y.rel_abund < *x.rel_abund; });   // :330
+            } else {
+                std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return y.final_est_ani < x.final_est_ani; });   // :333
+            }
+            for (const auto& r : stats) print_ani_result(r, seq_name, genome_sketches[r.genome_index], args.pseudotax, out);
+        }
+        info(std::string(files.size() > 1 ? "Finished paired sample " : "Finished sample ") + files[0] + ".");
+    }
+    fflush(out);
+    info("sylph finished.");
+    return 0;
+}
+
+}  // namespace sylph_host

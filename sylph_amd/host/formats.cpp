@@ -1,0 +1,222 @@
+// formats.cpp — .sylsp / .syldb (bincode 1.3.3 default layout) and FASTA/FASTQ(+gzip) records.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+
+#include "sylph_host.hpp"
+
+namespace sylph_host {
+
+namespace {
+
+struct Writer {
+    std::vector<char> b;
+    void u8(uint8_t v) { b.push_back((char)v); }
+    void u32(uint32_t v) { raw(&v, 4); }
+    void u64(uint64_t v) { raw(&v, 8); }
+    void f64(double v) { raw(&v, 8); }
+    void raw(const void* p, size_t n) { const char* c = (const char*)p; b.insert(b.end(), c, c + n); }
+    void str(const std::string& s) { u64(s.size()); raw(s.data(), s.size()); }
+    void flush(const std::string& path) {
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw Error{1, path + " path not valid; exiting."};
+        f.write(b.data(), (std::streamsize)b.size());
+    }
+};
+
+struct Reader {
+    std::vector<char> b;
+    size_t p = 0;
+    std::string path;
+    explicit Reader(const std::string& pth) : path(pth) {
+        std::ifstream f(pth, std::ios::binary | std::ios::ate);
+        if (!f) throw Error{1, "The sketch `" + pth + "` could not be opened"};
+        const std::streamsize n = f.tellg();
+        f.seekg(0);
+        b.resize((size_t)n);
+        if (n) f.read(b.data(), n);
+    }
+    void need(size_t n) {
+        if (p + n > b.size()) throw Error{1, "The sketch `" + path + "` is not a valid sketch. Perhaps it is an older incompatible version"};
+    }
+    uint8_t u8() { need(1); return (uint8_t)b[p++]; }
+    uint32_t u32() { need(4); uint32_t v; memcpy(&v, &b[p], 4); p += 4; return v; }
+    uint64_t u64() { need(8); uint64_t v; memcpy(&v, &b[p], 8); p += 8; return v; }
+    double f64() { need(8); double v; memcpy(&v, &b[p], 8); p += 8; return v; }
+    std::string str() { const uint64_t n = u64(); need(n); std::string s(&b[p], n); p += n; return s; }
+    std::vector<uint64_t> vec_u64() {
+        const uint64_t n = u64();
+        need(n * 8);
+        std::vector<uint64_t> v(n);
+        if (n) memcpy(v.data(), &b[p], n * 8);
+        p += n * 8;
+        return v;
+    }
+};
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+}  // namespace
+
+// types.rs:145-155: kmer_counts as a *sequence* of (u64, u32) (types.rs:132-138), c, k, file_name, sample_name, paired,
+// mean_read_length.  The reference writes the map in hashbrown iteration order; readers rebuild a map, so any order is
+// equivalent — we write ascending k-mer order.
+void write_sylsp(const std::string& path, const SequencesSketch& s) {
+    Writer w;
+    w.u64(s.kmers.size());
+    for (size_t i = 0; i < s.kmers.size(); i++) { w.u64(s.kmers[i]); w.u32(s.counts[i]); }
+    w.u64(s.c);
+    w.u64(s.k);
+    w.str(s.file_name);
+    if (s.sample_name) { w.u8(1); w.str(*s.sample_name); } else w.u8(0);
+    w.u8(s.paired ? 1 : 0);
+    w.f64(s.mean_read_length);
+    w.flush(path);
+}
+
+SequencesSketch read_sylsp(const std::string& path) {
+    Reader r(path);
+    SequencesSketch s;
+    const uint64_t n = r.u64();
+    r.need(n * 12);
+    std::vector<std::pair<uint64_t, uint32_t>> kv(n);
+    for (uint64_t i = 0; i < n; i++) { kv[i].first = r.u64(); kv[i].second = r.u32(); }
+    // the reference inserts into a map (types.rs:117-129): a repeated key keeps its last value
+    std::stable_sort(kv.begin(), kv.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    for (uint64_t i = 0; i < n; i++) {
+        if (i + 1 < n && kv[i + 1].first == kv[i].first) continue;
+        s.kmers.push_back(kv[i].first);
+        s.counts.push_back(kv[i].second);
+    }
+    s.c = r.u64();
+    s.k = r.u64();
+    s.file_name = r.str();
+    if (r.u8()) s.sample_name = r.str();
+    s.paired = r.u8() != 0;
+    s.mean_read_length = r.f64();
+    return s;
+}
+
+// types.rs:163-173 as Vec<GenomeSketch>
+void write_syldb(const std::string& path, const std::vector<GenomeSketch>& gs) {
+    Writer w;
+    w.u64(gs.size());
+    for (const GenomeSketch& g : gs) {
+        w.u64(g.genome_kmers.size());
+        w.raw(g.genome_kmers.data(), g.genome_kmers.size() * 8);
+        if (g.pseudotax_tracked_nonused_kmers) {
+            w.u8(1);
+            w.u64(g.pseudotax_tracked_nonused_kmers->size());
+            w.raw(g.pseudotax_tracked_nonused_kmers->data(), g.pseudotax_tracked_nonused_kmers->size() * 8);
+        } else {
+            w.u8(0);
+        }
+        w.str(g.file_name);
+        w.str(g.first_contig_name);
+        w.u64(g.c); w.u64(g.k); w.u64(g.gn_size); w.u64(g.min_spacing);
+    }
+    w.flush(path);
+}
+
+std::vector<GenomeSketch> read_syldb(const std::string& path) {
+    Reader r(path);
+    const uint64_t n = r.u64();
+    std::vector<GenomeSketch> gs;
+    gs.reserve(std::min<uint64_t>(n, 1u << 20));
+    for (uint64_t i = 0; i < n; i++) {
+        GenomeSketch g;
+        g.genome_kmers = r.vec_u64();
+        if (r.u8()) g.pseudotax_tracked_nonused_kmers = r.vec_u64();
+        g.file_name = r.str();
+        g.first_contig_name = r.str();
+        g.c = r.u64(); g.k = r.u64(); g.gn_size = r.u64(); g.min_spacing = r.u64();
+        gs.push_back(std::move(g));
+    }
+    return gs;
+}
+
+bool is_fastq(const std::string& f) {
+    for (const char* s : {".fq", ".fnq", ".fastq", ".fq.gz", ".fnq.gz", ".fastq.gz"}) if (ends_with(f, s)) return true;
+    return false;
+}
+bool is_fasta(const std::string& f) {
+    for (const char* s : {".fa", ".fna", ".fasta", ".fa.gz", ".fna.gz", ".fasta.gz"}) if (ends_with(f, s)) return true;
+    return false;
+}
+
+// ---- FASTX ---------------------------------------------------------------------------------------------------------
+FastxReader::FastxReader(const std::string& path) {
+    gz_ = gzopen(path.c_str(), "rb");   // transparently reads plain files too
+    if (!gz_) throw Error{1, path + " is not a valid fasta/fastq file; skipping."};
+    gzbuffer((gzFile)gz_, 1 << 20);
+    buf_.resize(1 << 20);
+    buf_.clear();
+}
+FastxReader::~FastxReader() { if (gz_) gzclose((gzFile)gz_); }
+
+bool FastxReader::getline(std::string& line) {
+    line.clear();
+    if (has_pending_) { line.swap(pending_); has_pending_ = false; return true; }
+    for (;;) {
+        if (pos_ < buf_.size()) {
+            const char* b = buf_.data() + pos_;
+            const char* nl = (const char*)memchr(b, '\n', buf_.size() - pos_);
+            if (nl) {
+                line.append(b, nl - b);
+                pos_ += (nl - b) + 1;
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                return true;
+            }
+            line.append(b, buf_.size() - pos_);
+            pos_ = buf_.size();
+        }
+        if (eof_) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            return !line.empty();
+        }
+        buf_.resize(1 << 20);
+        const int n = gzread((gzFile)gz_, &buf_[0], 1 << 20);
+        if (n < 0) throw Error{1, "read error"};
+        buf_.resize((size_t)n);
+        pos_ = 0;
+        if (n == 0) eof_ = true;
+    }
+}
+
+bool FastxReader::next(FastxRecord& rec) {
+    std::string line;
+    // skip blank lines between records
+    do {
+        if (!getline(line)) return false;
+    } while (line.empty());
+    if (!started_) {
+        started_ = true;
+        if (line[0] == '@') fastq_ = true;
+        else if (line[0] == '>') fastq_ = false;
+        else throw Error{1, "not a fasta/fastq file"};
+    }
+    rec.seq.clear();
+    if (fastq_) {
+        if (line[0] != '@') throw Error{1, "malformed fastq record"};
+        rec.id.assign(line, 1, std::string::npos);
+        if (!getline(rec.seq)) throw Error{1, "truncated fastq record"};
+        std::string plus, qual;
+        if (!getline(plus) || plus.empty() || plus[0] != '+') throw Error{1, "malformed fastq record"};
+        if (!getline(qual) && !rec.seq.empty()) throw Error{1, "truncated fastq record"};
+        return true;
+    }
+    if (line[0] != '>') throw Error{1, "malformed fasta record"};
+    rec.id.assign(line, 1, std::string::npos);
+    while (getline(line)) {
+        if (!line.empty() && line[0] == '>') { pending_.swap(line); has_pending_ = true; break; }
+        rec.seq += line;
+    }
+    return true;
+}
+
+}  // namespace sylph_host

@@ -1,0 +1,120 @@
+// main.cpp — `sylph-hip sketch|profile|query`: the reference's command surface for the hot path only (flag names and
+// defaults from cmdline.rs:28-160; `inspect`, hidden estimators and logging flags are not carried).
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#include "sylph_host.hpp"
+
+using namespace sylph_host;
+
+namespace {
+
+struct Argv {
+    int argc; char** argv; int i = 2;
+    bool more() const { return i < argc; }
+    std::string cur() const { return argv[i]; }
+    // values of a `multiple=true` option: everything up to the next token starting with '-'
+    std::vector<std::string> multi() {
+        std::vector<std::string> v;
+        i++;
+        while (i < argc && !(argv[i][0] == '-' && strlen(argv[i]) > 1)) v.push_back(argv[i++]);
+        return v;
+    }
+    std::string one() {
+        if (i + 1 >= argc) throw Error{2, std::string("option ") + argv[i] + " needs a value"};
+        i += 2;
+        return argv[i - 1];
+    }
+};
+
+void append(std::vector<std::string>& dst, const std::vector<std::string>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
+
+int run_sketch(Argv a) {
+    SketchArgs s;
+    while (a.more()) {
+        const std::string t = a.cur();
+        if (t == "-o" || t == "--out-name-db") s.db_out_name = a.one();
+        else if (t == "-d" || t == "--sample-output-directory") s.sample_output_dir = a.one();
+        else if (t == "-i" || t == "--individual-records") { s.individual = true; a.i++; }
+        else if (t == "-r" || t == "--reads") append(s.reads, a.multi());
+        else if (t == "-g" || t == "--genomes") append(s.genomes, a.multi());
+        else if (t == "-l" || t == "--list") s.list_sequence = a.one();
+        else if (t == "--rl") s.list_reads = a.one();
+        else if (t == "--gl") s.list_genomes = a.one();
+        else if (t == "--l1") s.list_first_pair = a.one();
+        else if (t == "--l2") s.list_second_pair = a.one();
+        else if (t == "--lS") s.list_sample_names = a.one();
+        else if (t == "-S" || t == "--sample-names") { if (!s.sample_names) s.sample_names.emplace(); append(*s.sample_names, a.multi()); }
+        else if (t == "-k") s.k = strtoull(a.one().c_str(), nullptr, 10);
+        else if (t == "-c") s.c = strtoull(a.one().c_str(), nullptr, 10);
+        else if (t == "-t") a.one();   // thread count: the GPU engine has no use for it
+        else if (t == "--no-dedup") { s.no_dedup = true; a.i++; }
+        else if (t == "--disable-profiling") { s.no_pseudotax = true; a.i++; }
+        else if (t == "--min-spacing") s.min_spacing_kmer = strtoull(a.one().c_str(), nullptr, 10);
+        else if (t == "--fpr") s.fpr = atof(a.one().c_str());
+        else if (t == "-1" || t == "--first-pairs") append(s.first_pair, a.multi());
+        else if (t == "-2" || t == "--second-pairs") append(s.second_pair, a.multi());
+        else if (t == "--debug" || t == "--trace") a.i++;
+        else if (t[0] == '-' && t.size() > 1) throw Error{2, "unknown option " + t};
+        else { s.files.push_back(t); a.i++; }
+    }
+    Engine e;
+    return sketch(e, s);
+}
+
+int run_contain(Argv a, bool profile) {
+    ContainCmdArgs c;
+    while (a.more()) {
+        const std::string t = a.cur();
+        if (t == "-l" || t == "--list") c.file_list = a.one();
+        else if (t == "--min-count-correct") c.min_count_correct = atof(a.one().c_str());
+        else if (t == "-M" || t == "--min-number-kmers") c.min_number_kmers = atof(a.one().c_str());
+        else if (t == "-m" || t == "--minimum-ani") c.minimum_ani = atof(a.one().c_str());
+        else if (t == "-t" || t == "-s" || t == "--sample-threads") a.one();
+        else if (t == "-u" || t == "--estimate-unknown") { c.estimate_unknown = true; a.i++; }
+        else if (t == "-I" || t == "--read-seq-id") a.one();
+        else if (t == "-R" || t == "--redundancy-threshold") c.redundant_ani = atof(a.one().c_str());
+        else if (t == "-r" || t == "--reads") append(c.reads, a.multi());
+        else if (t == "-1" || t == "--first-pairs") append(c.first_pair, a.multi());
+        else if (t == "-2" || t == "--second-pairs") append(c.second_pair, a.multi());
+        else if (t == "-c") c.c = strtoull(a.one().c_str(), nullptr, 10);
+        else if (t == "-k") c.k = strtoull(a.one().c_str(), nullptr, 10);
+        else if (t == "-i" || t == "--individual-records") { c.individual = true; a.i++; }
+        else if (t == "--min-spacing") c.min_spacing_kmer = strtoull(a.one().c_str(), nullptr, 10);
+        else if (t == "-o" || t == "--output-file") c.out_file_name = a.one();
+        else if (t == "--no-ci") { c.no_ci = true; a.i++; }
+        else if (t == "--no-adjust") { c.no_adj = true; a.i++; }
+        else if (t == "--mean-coverage") { c.mean_coverage = true; a.i++; }
+        else if (t == "--debug" || t == "--trace" || t == "--log-reassignments") a.i++;
+        else if (t[0] == '-' && t.size() > 1) throw Error{2, "unknown option " + t};
+        else { c.files.push_back(t); a.i++; }
+    }
+    FILE* out = stdout;
+    if (c.out_file_name) {
+        out = fopen(c.out_file_name->c_str(), "w");
+        if (!out) throw Error{1, "could not create " + *c.out_file_name};
+    }
+    Engine e;
+    const int rc = contain(e, c, profile, out);
+    if (out != stdout) fclose(out);
+    return rc;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: sylph-hip <sketch|profile|query> ...\n"); return 2; }
+    try {
+        const std::string cmd = argv[1];
+        Argv a{argc, argv};
+        if (cmd == "sketch") return run_sketch(a);
+        if (cmd == "profile") return run_contain(a, true);
+        if (cmd == "query") return run_contain(a, false);
+        fprintf(stderr, "unknown subcommand %s\n", argv[1]);
+        return 2;
+    } catch (const Error& e) {
+        fprintf(stderr, "ERROR [sylph_hip] %s\n", e.msg.c_str());   // log::error! + std::process::exit(1) in the reference
+        return e.code;
+    }
+}

@@ -1,0 +1,139 @@
+// sylph_host.hpp — host side above the C ABI (include/sylph_hip.h), mirroring the reference's operator interface
+// for the hot path: same names, argument meaning and error behaviour as the Rust functions it stands in for
+// (cited as file:line under /root/reference/src).  The reference is compiled Rust and no Rust toolchain exists in this
+// image, so the host is C++17.  Everything heavy is delegated to libsylph_hip.so; what stays here is what the
+// north_star leaves on the host: record parsing, sequential f64 bookkeeping, on-disk formats, coverage/ANI statistics
+// (contain.rs:657-813, inference.rs:207-242), profile reassignment and TSV formatting.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <optional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sylph_hip.h"
+
+namespace sylph_host {
+
+// constants.rs:1-17
+constexpr double CUTOFF_PVALUE = 0.9999999999;
+constexpr size_t SAMPLE_SIZE_CUTOFF = 25;
+constexpr double MEDIAN_ANI_THRESHOLD = 2.;
+constexpr double MIN_ANI_DEF = 0.9, MIN_ANI_P_DEF = 0.95;
+constexpr double MAX_MEDIAN_FOR_MEAN_FINAL_EST = 15.;
+constexpr double DEFAULT_FPR = 0.0001;
+constexpr const char* QUERY_FILE_SUFFIX = ".syldb";
+constexpr const char* SAMPLE_FILE_SUFFIX = ".sylsp";
+
+struct Error { int code; std::string msg; };   // thrown; the CLI maps it to log::error! + exit(code)
+
+// types.rs:145-155.  kmer_counts kept as two parallel arrays in ascending k-mer order (a keyed multiset is all any
+// consumer of the reference's FxHashMap can observe).
+struct SequencesSketch {
+    std::vector<uint64_t> kmers;
+    std::vector<uint32_t> counts;
+    uint64_t c = 0, k = 0;
+    std::string file_name;
+    std::optional<std::string> sample_name;
+    bool paired = false;
+    double mean_read_length = 0.;
+};
+
+// types.rs:163-173
+struct GenomeSketch {
+    std::vector<uint64_t> genome_kmers;
+    std::optional<std::vector<uint64_t>> pseudotax_tracked_nonused_kmers;
+    std::string file_name, first_contig_name;
+    uint64_t c = 0, k = 0, gn_size = 0, min_spacing = 0;
+};
+
+// ---- on-disk formats: bincode 1.3.3 default options (little-endian, fixed-width ints, u64 lengths) ----
+void write_sylsp(const std::string& path, const SequencesSketch& s);          // sketch.rs:360,411
+SequencesSketch read_sylsp(const std::string& path);                          // contain.rs:559
+void write_syldb(const std::string& path, const std::vector<GenomeSketch>& g); // sketch.rs:474
+std::vector<GenomeSketch> read_syldb(const std::string& path);                // contain.rs:495
+
+// ---- FASTA/FASTQ (+gzip) records with needletail 0.5.1 semantics: seq() without newlines, id() = whole header ----
+struct FastxRecord { std::string id; std::string seq; };
+class FastxReader {
+   public:
+    explicit FastxReader(const std::string& path);   // throws Error if the file cannot be opened / is not fasta/fastq
+    ~FastxReader();
+    bool next(FastxRecord& rec);                      // false at EOF; throws Error on a malformed record
+   private:
+    void* gz_ = nullptr;
+    std::string buf_;
+    size_t pos_ = 0;
+    bool eof_ = false, fastq_ = false, started_ = false;
+    bool getline(std::string& line);
+    std::string pending_;
+    bool has_pending_ = false;
+};
+bool is_fastq(const std::string& f);   // sketch.rs:95
+bool is_fasta(const std::string& f);   // sketch.rs:109
+
+// ---- sketching (GPU through the C ABI) ----
+struct Engine {   // one GPU context shared by the drivers
+    sylph_ctx* ctx = nullptr;
+    explicit Engine(int device = -1);
+    ~Engine();
+};
+// sketch.rs:897 / :771 / :550 / :481 — return nullopt where the reference returns None (warn + skip).
+std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
+                                                       std::optional<std::string> sample_name, bool no_dedup);
+std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::string& read_file1, const std::string& read_file2,
+                                                     uint64_t c, uint64_t k, std::optional<std::string> sample_name,
+                                                     bool no_dedup, double dedup_fpr);
+std::optional<GenomeSketch> sketch_genome(Engine& e, uint64_t c, uint64_t k, const std::string& ref_file, uint64_t min_spacing,
+                                          bool pseudotax);
+std::vector<GenomeSketch> sketch_genome_individual(Engine& e, uint64_t c, uint64_t k, const std::string& ref_file,
+                                                   uint64_t min_spacing, bool pseudotax);
+
+// ---- statistics (host, f64) ----
+enum class AdjustStatus { Low, High, Lambda };
+struct AniResult {   // types.rs:184-203
+    double naive_ani = 0, final_est_ani = 0, final_est_cov = 0, mean_cov = 0, median_cov = 0;
+    size_t contain_count = 0, n_kmers = 0;
+    AdjustStatus lambda_status = AdjustStatus::Low;
+    double lambda = 0;
+    std::optional<double> ani_ci_lo, ani_ci_hi, lambda_ci_lo, lambda_ci_hi;
+    size_t genome_index = 0;
+    std::optional<double> rel_abund, seq_abund;
+    std::optional<size_t> kmers_lost;
+};
+struct ContainArgs {   // the cmdline.rs:88-160 fields the statistics read
+    double min_count_correct = 3., min_number_kmers = 50.;
+    std::optional<double> minimum_ani;
+    bool pseudotax = false, no_ci = false, no_adj = false, mean_coverage = false, estimate_unknown = false;
+    double redundant_ani = 99.0;
+};
+std::optional<double> ratio_lambda(const std::vector<uint32_t>& full_covs, double min_count_correct);   // inference.rs:207
+std::optional<double> ani_from_lambda(std::optional<double> lambda, double k, const std::vector<uint32_t>& full_cov);  // contain.rs:817
+double poisson_cdf(double lambda, uint64_t x);   // statrs Poisson::cdf = Q(x+1, lambda) (third party; parity unpinned)
+// statistics half of get_stats (contain.rs:657-813): covs = the non-zero sample counts of the genome's k-mers found
+// in the sample (any order), n_genome_kmers = genome_kmers.len(), kmers_lost = Some(..) in the winner pass.
+std::optional<AniResult> stats_from_covs(const ContainArgs& args, std::vector<uint32_t> covs, size_t n_genome_kmers, uint64_t k,
+                                         std::optional<size_t> kmers_lost);
+
+// ---- commands ----
+struct SketchArgs {   // cmdline.rs:28-86
+    std::vector<std::string> files, reads, genomes, first_pair, second_pair;
+    std::optional<std::vector<std::string>> sample_names;
+    std::string db_out_name = "database", sample_output_dir = "./";
+    bool individual = false, no_dedup = false, no_pseudotax = false;
+    uint64_t k = 31, c = 200, min_spacing_kmer = 30;
+    double fpr = DEFAULT_FPR;
+    std::optional<std::string> list_sequence, list_reads, list_genomes, list_first_pair, list_second_pair, list_sample_names;
+};
+struct ContainCmdArgs : ContainArgs {   // cmdline.rs:88-160
+    std::vector<std::string> files, reads, first_pair, second_pair;
+    std::optional<std::string> file_list, out_file_name;
+    uint64_t k = 31, c = 200, min_spacing_kmer = 30;
+    bool individual = false;
+};
+int sketch(Engine& e, const SketchArgs& args);                              // sketch.rs:276; returns the exit code
+int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out);  // contain.rs:115 (query: false, profile: true)
+
+}  // namespace sylph_host

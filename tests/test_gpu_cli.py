@@ -1,0 +1,246 @@
+"""GPU tests of the C++ host + `sylph-hip` command: the reference's own integration assertions
+(tests/integration_test.rs: output files and names, line counts, raw-vs-presketched stdout equality, exit codes)
+re-expressed on committed fixtures, plus a row-by-row comparison of the TSV with the oracle's numbers."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+from .helpers import ACGT, random_seq, revcomp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "sylph_amd", "sylph-hip")
+
+
+def run(*args, check=True):
+    p = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    if check:
+        assert p.returncode == 0, p.stderr[-3000:]
+    return p
+
+
+def write_fasta(path, records, gz=True, width=70):
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for name, seq in records:
+            f.write(b">" + name + b"\n")
+            s = bytes(seq)
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + b"\n")
+
+
+def write_fastq(path, reads, gz=False, prefix=b"r"):
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b"@" + prefix + str(i).encode() + b" extra\n" + bytes(s) + b"\n+\n" + b"I" * len(s) + b"\n")
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory, golden_dir):
+    d = tmp_path_factory.mktemp("cli")
+    z = np.load(os.path.join(golden_dir, "ecoli_slices.npz"))
+    rng = np.random.default_rng(123)
+    genomes = {}
+    for gi, name in enumerate(("EC590", "K12", "O157")):
+        b, off = z[f"g{gi}_bases"], z[f"g{gi}_off"]
+        recs = [(f"{name}_contig{i} test genome".encode(), b[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+        p = str(d / f"{name}.fasta.gz")
+        write_fasta(p, recs)
+        genomes[name] = (p, recs)
+    unrelated = random_seq(rng, 120000)
+    genomes["rand"] = (str(d / "rand.fa"), [(b"random_genome", unrelated)])
+    write_fasta(genomes["rand"][0], genomes["rand"][1], gz=False)
+    # paired reads: 6x of the K12 slice + 1x of the random genome, 1 % errors, some exact duplicate pairs
+    def sim(g, n):
+        m1, m2 = [], []
+        for _ in range(n):
+            ins = int(rng.integers(200, 400))
+            s = int(rng.integers(0, len(g) - ins))
+            frag = g[s:s + ins] if rng.random() < 0.5 else revcomp(g[s:s + ins])
+            a, b = frag[:100].copy(), revcomp(frag)[:100].copy()
+            for m in (a, b):
+                e = rng.random(100) < 0.01
+                m[e] = rng.choice(ACGT, size=int(e.sum()))
+            m1.append(a); m2.append(b)
+        return m1, m2
+    k12 = genomes["K12"][1][0][1]
+    a1, a2 = sim(k12, 9000)
+    b1, b2 = sim(unrelated, 600)
+    c1, c2 = sim(genomes["EC590"][1][0][1], 6000)   # a second, closely related strain: shared k-mers get reassigned
+    m1, m2 = a1 + b1 + c1, a2 + b2 + c2
+    for i in range(300):
+        j = int(rng.integers(0, len(m1)))
+        m1.append(m1[j]); m2.append(m2[j])
+    write_fastq(str(d / "s_1.fq"), m1)
+    write_fastq(str(d / "s_2.fq"), m2)
+    write_fastq(str(d / "single.fastq.gz"), m1, gz=True)
+    return dict(dir=d, genomes=genomes, m1=m1, m2=m2)
+
+
+def expected_rows(data, sample, paired, pseudotax, genome_order):
+    """Recompute the TSV rows with the oracle (CI columns excluded: the bootstrap is parity-unpinned)."""
+    gs = []
+    for name in genome_order:
+        path, recs = data["genomes"][name]
+        b, off = O.concat([bytes(r[1]) for r in recs])
+        g = O.sketch_genome(b, off)
+        gs.append(dict(path=path, contig=recs[0][0].decode(), kmers=g["genome_kmers"], tracked=g["tracked"], gn_size=g["gn_size"]))
+    recs = [x for p in zip(data["m1"], data["m2"]) for x in p] if paired else data["m1"]
+    b, off = O.concat([bytes(r) for r in recs])
+    s = O.sketch_reads(b, off, paired=paired)
+    db = np.concatenate([g["kmers"] for g in gs])
+    goff = np.zeros(len(gs) + 1, dtype=np.uint64)
+    goff[1:] = np.cumsum([len(g["kmers"]) for g in gs])
+    cc, covs, _ = O.contain(s["kmers"], s["counts"], db, goff)
+    min_ani = 0.95 if pseudotax else 0.90
+    res = []
+    for i, g in enumerate(gs):
+        if cc[i] == 0:
+            continue
+        st = O.stats(covs[i], len(g["kmers"]), min_ani=min_ani)
+        if st.passed:
+            res.append(dict(i=i, st=st, cc=int(cc[i]), lost=None))
+    if pseudotax:
+        smap = dict(zip(s["kmers"].tolist(), s["counts"].tolist()))
+        winner = {}
+        for r in res:
+            g = gs[r["i"]]
+            for km in list(g["kmers"].tolist()) + list(g["tracked"].tolist()):
+                if km not in winner or r["st"].final_est_ani > winner[km][0]:
+                    winner[km] = (r["st"].final_est_ani, r["i"])
+        res2 = []
+        for r in res:
+            g = gs[r["i"]]
+            cv, lost = [], 0
+            for km in g["kmers"].tolist():
+                c = smap.get(km, 0)
+                if c == 0:
+                    continue
+                if winner[km][1] != r["i"]:
+                    lost += 1
+                    continue
+                cv.append(c)
+            if not cv:
+                continue
+            st = O.stats(np.array(cv, dtype=np.uint32), len(g["kmers"]), min_ani=min_ani)
+            if st.passed and (r["cc"] - len(cv)) < (0.99 ** 31) * len(g["kmers"]):
+                res2.append(dict(i=r["i"], st=st, cc=len(cv), lost=lost))
+        res = res2
+        tot = sum(r["st"].final_est_cov for r in res)
+        tots = sum(r["st"].final_est_cov * gs[r["i"]]["gn_size"] for r in res)
+        for r in res:
+            r["rel"] = r["st"].final_est_cov / tot * 100.0
+            r["seq"] = r["st"].final_est_cov * gs[r["i"]]["gn_size"] / tots * 100.0
+        res.sort(key=lambda r: -r["rel"])
+    else:
+        res.sort(key=lambda r: -r["st"].final_est_ani)
+    rows = []
+    for r in res:
+        st, g = r["st"], gs[r["i"]]
+        lam = "%.3f" % st.lambda_ if st.lambda_status == 2 else ("HIGH" if st.lambda_status == 1 else "LOW")
+        common = ["%.2f" % min(st.final_est_ani * 100, 100.0), "%.3f" % st.final_est_cov, None, lam, None, "%.0f" % st.median_cov,
+                  "%.3f" % st.mean_cov, "%d/%d" % (r["cc"], len(g["kmers"])), "%.2f" % (st.naive_ani * 100)]
+        if pseudotax:
+            rows.append([sample, g["path"], "%.4f" % r["rel"], "%.4f" % r["seq"]] + common + [str(r["lost"]), g["contig"]])
+        else:
+            rows.append([sample, g["path"]] + common + [g["contig"]])
+    return rows
+
+
+def compare(stdout, rows, pseudotax):
+    lines = stdout.strip().split("\n")
+    assert lines[0].startswith("Sample_file\tGenome_file")
+    assert len(lines) == 1 + len(rows), stdout
+    ci_cols = (6, 8) if pseudotax else (4, 6)
+    for line, exp in zip(lines[1:], rows):
+        got = line.split("\t")
+        assert len(got) == len(exp)
+        for j, (a, b) in enumerate(zip(got, exp)):
+            if j in ci_cols:
+                assert a == "NA-NA" or "-" in a
+            else:
+                assert a == b, (j, a, b, line)
+
+
+def test_sketch_outputs_and_names(data):
+    d = data["dir"]
+    g = data["genomes"]
+    out = d / "out1"
+    run("sketch", g["EC590"][0], g["K12"][0], g["O157"][0], g["rand"][0], "-o", out / "db", "-d", out / "samples", "-r", d / "single.fastq.gz",
+        "-1", d / "s_1.fq", "-2", d / "s_2.fq")
+    assert (out / "db.syldb").exists()
+    assert (out / "samples" / "single.fastq.gz.sylsp").exists()
+    assert (out / "samples" / "s_1.fq.paired.sylsp").exists()        # integration_test.rs:78,313
+    # sample names (-S): sketches are renamed (integration_test.rs:298-375)
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-r", d / "single.fastq.gz", "-S", "pairA", "singleB", "-d", out / "named")
+    assert (out / "named" / "pairA.paired.sylsp").exists() and (out / "named" / "singleB.sylsp").exists()
+    assert run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-S", "a", "b", "-d", out / "named2", check=False).returncode == 1
+
+
+def test_error_exit_codes(data):
+    d = data["dir"]
+    g = data["genomes"]
+    assert run("sketch", g["K12"][0], "--fpr", "2", "-o", d / "e" / "db", check=False).returncode == 1       # integration_test.rs:419
+    assert run("sketch", "-1", d / "s_1.fq", "-d", d / "e", check=False).returncode == 1                     # :445
+    assert run("sketch", check=False).returncode == 1
+    run("sketch", g["K12"][0], "--disable-profiling", "-o", d / "e" / "noprof")
+    run("sketch", "-r", d / "single.fastq.gz", "-d", d / "e")
+    assert run("profile", d / "e" / "noprof.syldb", d / "e" / "single.fastq.gz.sylsp", check=False).returncode == 1   # :234
+    assert run("query", d / "e" / "noprof.syldb", d / "e" / "single.fastq.gz.sylsp").returncode == 0
+    assert run("profile", d / "e" / "single.fastq.gz.sylsp", check=False).returncode == 1                    # no genomes
+    assert run("profile", d / "e" / "noprof.syldb", check=False).returncode == 1                             # no reads
+
+
+def test_query_and_profile_rows_match_oracle(data):
+    d = data["dir"]
+    g = data["genomes"]
+    order = ["EC590", "K12", "O157", "rand"]
+    out = d / "out2"
+    run("sketch", *[g[n][0] for n in order], "-o", out / "db", "-d", out, "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-r", d / "single.fastq.gz")
+    sample = str(d / "s_1.fq")
+    q = run("query", out / "db.syldb", out / "s_1.fq.paired.sylsp")
+    rows = expected_rows(data, sample, True, False, order)
+    assert len(rows) >= 2
+    compare(q.stdout, rows, False)
+    p = run("profile", out / "db.syldb", out / "s_1.fq.paired.sylsp")
+    prow = expected_rows(data, sample, True, True, order)
+    assert len(prow) >= 2 and any(int(r[13]) > 0 for r in prow)       # some k-mers really were reassigned
+    compare(p.stdout, prow, True)
+    # single-end sample, gz input, -o output file
+    run("query", out / "db.syldb", out / "single.fastq.gz.sylsp", "-o", out / "q.tsv")
+    compare(open(out / "q.tsv").read(), expected_rows(data, str(d / "single.fastq.gz"), False, False, order), False)
+
+
+def test_raw_inputs_equal_presketched(data):
+    """integration_test.rs:248-295 and :465-501: profiling raw fasta/fastq gives the same stdout as profiling sketches."""
+    d = data["dir"]
+    g = data["genomes"]
+    out = d / "out3"
+    order = ["EC590", "K12", "O157", "rand"]
+    run("sketch", *[g[n][0] for n in order], "-o", out / "db", "-d", out, "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-r", d / "single.fastq.gz")
+    a = run("profile", out / "db.syldb", out / "s_1.fq.paired.sylsp", out / "single.fastq.gz.sylsp")
+    b = run("profile", *[g[n][0] for n in order], "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-r", d / "single.fastq.gz")
+    # raw inputs are processed first, then sketches (contain.rs:257-258): compare as sets of rows
+    assert sorted(a.stdout.strip().split("\n")) == sorted(b.stdout.strip().split("\n"))
+    assert len(a.stdout.strip().split("\n")) >= 4
+    # mixing a raw genome with a database, -l list file
+    lst = out / "list.txt"
+    lst.write_text("\n".join([str(out / "db.syldb"), str(out / "s_1.fq.paired.sylsp")]) + "\n")
+    c = run("query", "-l", lst)
+    assert c.stdout == run("query", out / "db.syldb", out / "s_1.fq.paired.sylsp").stdout
+    # -i individual records: one sketch per contig
+    run("sketch", g["O157"][0], "-i", "-o", out / "indiv")
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "sylph_amd", "libsylph_host.so"))
+    L.sylph_host_read_syldb.restype = C.c_void_p
+    L.sylph_host_read_syldb.argtypes = [C.c_char_p]
+    L.sylph_host_syldb_size.restype = C.c_uint64
+    L.sylph_host_syldb_size.argtypes = [C.c_void_p]
+    h = L.sylph_host_read_syldb(str(out / "indiv.syldb").encode())
+    assert L.sylph_host_syldb_size(h) == len(g["O157"][1])

@@ -1,0 +1,157 @@
+"""CPU tests of the C++ host layer above the ABI: bincode layouts of .sylsp/.syldb against an independent struct.pack
+encoder, and the statistics half of get_stats against the oracle (float tolerance 1e-6, the north_star's bar)."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class HostStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("naive_ani", "final_est_ani", "final_est_cov", "mean_cov", "median_cov", "lambda_",
+                                          "ani_ci_lo", "ani_ci_hi", "lambda_ci_lo", "lambda_ci_hi")] + \
+               [("lambda_status", C.c_int32), ("passed", C.c_int32), ("has_ci", C.c_int32), ("pad", C.c_int32),
+                ("contain_count", C.c_uint64), ("n_kmers", C.c_uint64)]
+
+
+@pytest.fixture(scope="module")
+def host():
+    L = C.CDLL(os.path.join(ROOT, "sylph_amd", "libsylph_host.so"))
+    L.sylph_host_poisson_cdf.restype = C.c_double
+    L.sylph_host_poisson_cdf.argtypes = [C.c_double, C.c_uint64]
+    L.sylph_host_stats.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.POINTER(HostStats)]
+    L.sylph_host_write_sylsp.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p,
+                                         C.c_char_p, C.c_int, C.c_double]
+    L.sylph_host_read_sylsp.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 5 + \
+                                       [C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    L.sylph_host_read_syldb.restype = C.c_void_p
+    L.sylph_host_read_syldb.argtypes = [C.c_char_p]
+    L.sylph_host_syldb_size.restype = C.c_uint64
+    L.sylph_host_syldb_size.argtypes = [C.c_void_p]
+    L.sylph_host_syldb_genome.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 7 + [C.c_char_p, C.c_char_p, C.c_uint64]
+    L.sylph_host_syldb_copy.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.sylph_host_syldb_free.argtypes = [C.c_void_p]
+    return L
+
+
+def host_stats(L, covs, n_kmers, k=31, min_ani=-1.0, pseudotax=0, no_ci=1):
+    cv = np.ascontiguousarray(covs, dtype=np.uint32)
+    out = HostStats()
+    L.sylph_host_stats(cv.ctypes.data_as(C.c_void_p), len(cv), n_kmers, k, 3.0, min_ani, pseudotax, no_ci, 0, 0, C.byref(out))
+    return out
+
+
+def test_stats_match_oracle(host):
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        n_kmers = int(rng.integers(50, 30000))
+        lam = float(rng.choice([0.02, 0.1, 0.5, 1.0, 2.5, 8.0, 40.0]))
+        hit = rng.random(n_kmers) < rng.uniform(0.05, 1.0)
+        covs = rng.poisson(lam, size=n_kmers)[hit]
+        covs = covs[covs > 0].astype(np.uint32)
+        if trial % 7 == 0 and len(covs):
+            covs[rng.integers(0, len(covs), size=3)] = 100000          # outliers -> Poisson cap
+        e = O.stats(covs, n_kmers, min_ani=0.0)
+        h = host_stats(host, covs, n_kmers, min_ani=0.0)
+        if len(covs) == 0:
+            assert h.passed == 0
+            continue
+        assert h.passed == 1 and h.lambda_status == e.lambda_status
+        for f in ("naive_ani", "final_est_ani", "final_est_cov", "mean_cov", "median_cov"):
+            assert abs(getattr(h, f) - getattr(e, f)) <= 1e-6 * max(1.0, abs(getattr(e, f))), (trial, f)
+        if e.lambda_status == 2:
+            assert abs(h.lambda_ - e.lambda_) <= 1e-9
+        # default thresholds: query 0.90, profile 0.95 (contain.rs:746-748)
+        assert host_stats(host, covs, n_kmers).passed == int(e.final_est_ani >= 0.9)
+        assert host_stats(host, covs, n_kmers, pseudotax=1).passed == int(e.final_est_ani >= 0.95)
+        assert host_stats(host, covs, n_kmers, min_ani=99.0).passed == int(e.final_est_ani >= 0.99)
+    for lam in (1.0, 5.0, 29.0):
+        for x in (0, 3, 10, 50, 68):
+            assert abs(host.sylph_host_poisson_cdf(lam, x) - O.poisson_cdf(lam, x)) < 1e-12
+
+
+def test_bootstrap_ci_is_deterministic_and_ordered(host):
+    rng = np.random.default_rng(3)
+    covs = rng.poisson(0.8, size=5000)
+    covs = covs[covs > 0].astype(np.uint32)
+    a = host_stats(host, covs, 8000, min_ani=0.0, no_ci=0)
+    b = host_stats(host, covs, 8000, min_ani=0.0, no_ci=0)
+    assert a.lambda_status == 2 and a.has_ci == 1
+    assert (a.ani_ci_lo, a.ani_ci_hi, a.lambda_ci_lo, a.lambda_ci_hi) == (b.ani_ci_lo, b.ani_ci_hi, b.lambda_ci_lo, b.lambda_ci_hi)
+    assert a.ani_ci_lo <= a.final_est_ani <= a.ani_ci_hi + 1e-3 and a.lambda_ci_lo <= a.lambda_ci_hi
+
+
+def bincode_sylsp(kmers, counts, c, k, file_name, sample_name, paired, mean):
+    """Independent encoder of SequencesSketch (types.rs:145-155) in bincode 1.3.3 default options."""
+    b = struct.pack("<Q", len(kmers))
+    for a, x in zip(kmers, counts):
+        b += struct.pack("<QI", int(a), int(x))
+    b += struct.pack("<QQ", c, k)
+    b += struct.pack("<Q", len(file_name)) + file_name
+    b += (b"\x01" + struct.pack("<Q", len(sample_name)) + sample_name) if sample_name is not None else b"\x00"
+    b += struct.pack("<Bd", 1 if paired else 0, mean)
+    return b
+
+
+def test_sylsp_layout_and_roundtrip(host, tmp_path):
+    rng = np.random.default_rng(1)
+    kmers = np.sort(rng.integers(0, 2**63, size=1000, dtype=np.uint64))
+    counts = rng.integers(1, 2**32, size=1000, dtype=np.uint64).astype(np.uint32)
+    for sample_name, paired in ((None, False), (b"my sample", True)):
+        p = str(tmp_path / "x.sylsp").encode()
+        assert host.sylph_host_write_sylsp(p, kmers.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), len(kmers), 200, 31,
+                                           b"dir/reads.fq.gz", sample_name, int(paired), 149.25) == 0
+        assert open(p, "rb").read() == bincode_sylsp(kmers, counts, 200, 31, b"dir/reads.fq.gz", sample_name, paired, 149.25)
+        # a file written in a different element order (the reference writes hash-map order) reads back identically
+        perm = rng.permutation(len(kmers))
+        open(p, "wb").write(bincode_sylsp(kmers[perm], counts[perm], 100, 21, b"a", sample_name, paired, 70.0))
+        ok = np.zeros(1000, dtype=np.uint64); oc = np.zeros(1000, dtype=np.uint32)
+        n, c, k, mean = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
+        pr, hs = C.c_int(), C.c_int()
+        fn, sn = C.create_string_buffer(256), C.create_string_buffer(256)
+        assert host.sylph_host_read_sylsp(p, ok.ctypes.data_as(C.c_void_p), oc.ctypes.data_as(C.c_void_p), 1000, C.byref(n), C.byref(c),
+                                          C.byref(k), C.byref(pr), C.byref(mean), fn, sn, 256, C.byref(hs)) == 0
+        assert (n.value, c.value, k.value, pr.value, mean.value, fn.value) == (1000, 100, 21, int(paired), 70.0, b"a")
+        assert np.array_equal(ok, kmers) and np.array_equal(oc, counts)
+        assert (hs.value == 1 and sn.value == sample_name) or (hs.value == 0 and sample_name is None)
+    assert host.sylph_host_read_sylsp(b"/nonexistent.sylsp", None, None, 0, C.byref(n), C.byref(c), C.byref(k), C.byref(pr),
+                                      C.byref(mean), fn, sn, 256, C.byref(hs)) == -1
+
+
+def test_syldb_layout(host, tmp_path):
+    """Vec<GenomeSketch> (types.rs:163-173) written by an independent encoder is read back field by field."""
+    rng = np.random.default_rng(2)
+    genomes = []
+    b = struct.pack("<Q", 3)
+    for i in range(3):
+        gk = rng.integers(0, 2**63, size=int(rng.integers(0, 500)), dtype=np.uint64)
+        tr = None if i == 1 else rng.integers(0, 2**63, size=int(rng.integers(0, 80)), dtype=np.uint64)
+        fn, cn = f"genomes/g{i}.fa.gz".encode(), f"contig_{i} some description".encode()
+        b += struct.pack("<Q", len(gk)) + gk.tobytes()
+        b += b"\x00" if tr is None else (b"\x01" + struct.pack("<Q", len(tr)) + tr.tobytes())
+        b += struct.pack("<Q", len(fn)) + fn + struct.pack("<Q", len(cn)) + cn
+        b += struct.pack("<QQQQ", 200, 31, 5_000_000 + i, 30)
+        genomes.append((gk, tr, fn, cn))
+    p = str(tmp_path / "d.syldb").encode()
+    open(p, "wb").write(b)
+    h = host.sylph_host_read_syldb(p)
+    assert h and host.sylph_host_syldb_size(h) == 3
+    for i, (gk, tr, fn, cn) in enumerate(genomes):
+        nk, nt, c, k, gs, ms = (C.c_uint64() for _ in range(6))
+        ht = C.c_int()
+        f, cname = C.create_string_buffer(256), C.create_string_buffer(256)
+        host.sylph_host_syldb_genome(h, i, C.byref(nk), C.byref(nt), C.byref(ht), C.byref(c), C.byref(k), C.byref(gs), C.byref(ms), f, cname, 256)
+        assert (nk.value, c.value, k.value, gs.value, ms.value, f.value, cname.value) == (len(gk), 200, 31, 5_000_000 + i, 30, fn, cn)
+        assert ht.value == (0 if tr is None else 1) and nt.value == (0 if tr is None else len(tr))
+        ok = np.zeros(max(1, len(gk)), dtype=np.uint64); ot = np.zeros(max(1, nt.value), dtype=np.uint64)
+        host.sylph_host_syldb_copy(h, i, ok.ctypes.data_as(C.c_void_p), ot.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(ok[:len(gk)], gk) and (tr is None or np.array_equal(ot[:len(tr)], tr))
+    host.sylph_host_syldb_free(h)
+    open(p, "wb").write(b[:100])
+    assert not host.sylph_host_read_syldb(p)   # truncated file -> error, no crash
