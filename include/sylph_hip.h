@@ -104,8 +104,9 @@ int sylph_sketch_begin(sylph_ctx *ctx, uint32_t c, uint32_t k, int reads_mode, i
 
 /* Append a batch of records in file order: record i = bases[rec_off[i], rec_off[i+1]), rec_off[0] == 0.
  * SYLPH_READS_PAIRED: records are interleaved mate1, mate2, mate1, ... (n_records even).  A batch may hold up
- * to 2^32-1 bases.  With SYLPH_MEM_DEVICE `bases` must be 16-byte aligned and readable up to
- * rec_off[n_records] rounded up to 16 bytes. */
+ * to 2^32-17 bases.  With SYLPH_MEM_DEVICE the memory must be readable from `bases` rounded down to 16 bytes up to
+ * `bases + rec_off[n_records]` rounded up to 16 bytes (true for any pointer into a hipMalloc'ed buffer with 16 B of
+ * slack at its end), and complete: the library runs on its own stream unless the ctx was given the producer's. */
 int sylph_sketch_push(sylph_sketch *sk, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_records,
                       int mem);
 

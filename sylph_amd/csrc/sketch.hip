@@ -61,8 +61,8 @@ __device__ __forceinline__ void marker_halves(const uint8_t* __restrict__ p, uin
 // the full binary search for the first and last survivor, everyone else searches only inside that run.
 __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
-    const uint64_t* __restrict__ hash, uint32_t n, uint32_t k, int avx2_compat, int paired, int want_markers,
-    uint64_t rec_base, uint64_t* __restrict__ o_hash, uint64_t* __restrict__ o_rid, uint64_t* __restrict__ o_m0,
+    const uint64_t* __restrict__ hash, uint32_t n, uint32_t pos_bias, uint32_t k, int avx2_compat, int paired,
+    int want_markers, uint64_t rec_base, uint64_t* __restrict__ o_hash, uint64_t* __restrict__ o_rid, uint64_t* __restrict__ o_m0,
     uint64_t* __restrict__ o_m1) {
     constexpr uint32_t WIN = 1024;           // record offsets staged in LDS (8 KiB)
     __shared__ uint64_t s_lo, s_hi;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint64_t total = off[n_rec];
     if (threadIdx.x == 0 || threadIdx.x == 64) {
         const uint32_t j = threadIdx.x == 0 ? first : min(n, first + blockDim.x) - 1;
-        uint64_t p = pos[j];
+        uint64_t p = pos[j] >= pos_bias ? pos[j] - pos_bias : 0;   // positions are relative to the 16 B-aligned load base
         if (total && p >= total) p = total - 1;
         const uint64_t r = total ? find_record(off, n_rec, p) : 0;
         if (threadIdx.x == 0) s_lo = r; else s_hi = r + 1;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         for (uint32_t t = threadIdx.x; t < w_n; t += blockDim.x) s_off[t] = off[w_lo + t];
     __syncthreads();
     auto OFF = [&](uint64_t r) -> uint64_t { return in_lds ? s_off[r - w_lo] : off[r]; };
-    const bool live = i < n;
-    const uint64_t p = live ? pos[i] : ~0ull;
+    const bool live = i < n && pos[i] >= pos_bias;
+    const uint64_t p = live ? pos[i] - pos_bias : ~0ull;
     uint64_t h = live ? hash[i] : 0, rid = 0, m0 = 0, m1 = 0;
     bool valid = false;
     if (p < total) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
             }
         }
     }
-    if (live) {
+    if (i < n) {
         o_hash[i] = valid ? h : INVALID_HASH;
         o_rid[i] = rid;
         o_m0[i] = m0;
@@ -376,14 +376,16 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         d_bases = sk->batch_bases.as<uint8_t>();
         d_off = sk->batch_off.as<uint64_t>();
     } else {
-        SY_REQUIRE(((uintptr_t)bases & 15) == 0, "device bases pointer must be 16-byte aligned");
         ctx->read_back(&n_bases, rec_off + n_records, 8);
         SY_REQUIRE(bases || n_bases == 0, "null bases");
         d_bases = bases;
         d_off = rec_off;
     }
     uint32_t* d_count = sk->counters.as<uint32_t>();
-    const uint32_t n = seeds_sorted_by_pos(ctx, d_bases, n_bases, sk->c, sk->k, d_count);
+    // K1 loads 16 B per lane: start it at the aligned address below d_bases and subtract the bias afterwards (a device
+    // pointer into the middle of a larger buffer, e.g. the second batch of a sample, need not be aligned)
+    const uint32_t bias = (uint32_t)((uintptr_t)d_bases & 15);
+    const uint32_t n = seeds_sorted_by_pos(ctx, d_bases - bias, n_bases + bias, sk->c, sk->k, d_count);
     if (n) {
         HostPhase ph(ctx, "push: grow + annotate");
         const uint64_t need = sk->n_occ + n;
@@ -394,7 +396,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         sk->m1.grow_keep(need * 8, keep, ctx->stream);
         ScopedKernelTimer t(ctx, "annotate");
         hipLaunchKernelGGL(annotate_reads_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_bases, d_off, n_records,
-                           ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, sk->k, sk->avx2_compat,
+                           ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, bias, sk->k, sk->avx2_compat,
                            sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, sk->hash.as<uint64_t>() + sk->n_occ,
                            sk->rid.as<uint64_t>() + sk->n_occ, sk->m0.as<uint64_t>() + sk->n_occ,
                            sk->m1.as<uint64_t>() + sk->n_occ);

@@ -89,3 +89,52 @@ def decoy_sketches(n_genomes, c=200, device="cuda", seed=0, mean_len=3.3e6, sigm
     thr = (2**64 - 1) // c
     kmers = torch.randint(0, thr, (int(off[-1].item()),), generator=g, device=device, dtype=torch.int64)
     return kmers, off
+
+
+def long_reads(genomes, total_bases, n50=10_000, sigma=0.8, err=0.05, abundance_sigma=1.0, seed=0, chunk_bases=1 << 28,
+               min_len=500, max_len=200_000):
+    """ONT-like single-end reads: log-normal lengths with the given N50 (length-weighted median = exp(mu + sigma^2)),
+    substitution errors only (indels do not change the kernels' work).  -> (bases uint8 [+64 pad], rec_off int64 [n+1])."""
+    device = genomes.device
+    g = _gen(device, seed)
+    n_gen, glen = genomes.shape
+    mu = math.log(n50) - sigma * sigma
+    mean_len = math.exp(mu + sigma * sigma / 2)
+    n_guess = int(total_bases / mean_len * 1.2) + 16
+    lens = torch.exp(torch.randn(n_guess, generator=g, device=device) * sigma + mu).long().clamp(min_len, min(max_len, glen - 1))
+    csum = torch.cumsum(lens, 0)
+    n = int(torch.searchsorted(csum, torch.tensor([total_bases], device=device)).item()) + 1
+    lens = lens[:n]
+    off = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    off[1:] = torch.cumsum(lens, 0)
+    total = int(off[-1].item())
+    ab = torch.exp(torch.randn(n_gen, generator=g, device=device) * abundance_sigma)
+    gid = torch.multinomial(ab, n, replacement=True, generator=g)
+    start = (torch.rand(n, generator=g, device=device) * (glen - lens).float()).long().clamp(min=0)
+    src0 = gid * glen + start
+    flip = torch.rand(n, generator=g, device=device) < 0.5
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    lut = torch.tensor(_ACGT, dtype=torch.uint8, device=device)
+    out = torch.empty(total + 64, dtype=torch.uint8, device=device)
+    out[total:] = 0
+    flat = genomes.reshape(-1)
+    r0 = 0
+    while r0 < n:                                       # chunks of whole reads
+        r1 = int(torch.searchsorted(off, off[r0] + chunk_bases).item())
+        r1 = max(r0 + 1, min(r1, n))
+        b0, b1 = int(off[r0].item()), int(off[r1].item())
+        rel = torch.arange(b1 - b0, device=device)
+        rid = torch.repeat_interleave(torch.arange(r0, r1, device=device), lens[r0:r1])
+        within = rel - (off[rid] - b0)
+        fwd_idx = src0[rid] + within
+        rev_idx = src0[rid] + (lens[rid] - 1 - within)
+        f = flip[rid]
+        bases = flat[torch.where(f, rev_idx, fwd_idx)]
+        bases = torch.where(f, comp[bases.long()], bases)
+        e = torch.rand(b1 - b0, generator=g, device=device) < err
+        rnd = lut[torch.randint(0, 4, (b1 - b0,), generator=g, device=device)]
+        out[b0:b1] = torch.where(e, rnd, bases)
+        r0 = r1
+    return out, off

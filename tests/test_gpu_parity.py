@@ -346,6 +346,29 @@ def test_end_to_end_sketch_then_contain_device_resident(ctx):
     sk.close()
 
 
+def test_device_push_unaligned_batches(ctx):
+    """Device-resident batches that start at arbitrary byte offsets of one big buffer (second batch of a sample)."""
+    import torch
+    rng = np.random.default_rng(31)
+    genome = random_seq(rng, 50000)
+    recs = make_reads(rng, genome, 3000, 137, dup_frac=0.2, ragged=True)
+    b, off = concat(recs)
+    e = O.sketch_reads(b, off, c=20)
+    tb = torch.from_numpy(np.concatenate([np.zeros(3, dtype=np.uint8), b, np.zeros(80, dtype=np.uint8)])).cuda()   # +3: misaligned
+    sk = S.ReadSketcher(ctx, c=20)
+    n = len(off) - 1
+    cuts = [0, 1, 700, 701, 1999, n]
+    keep = []
+    for a, z in zip(cuts[:-1], cuts[1:]):
+        o = torch.from_numpy((off[a:z + 1] - off[a]).astype(np.int64)).cuda()
+        keep.append(o)
+        torch.cuda.synchronize()
+        sk.push_device(tb.data_ptr() + 3 + int(off[a]), o.data_ptr(), z - a)
+    g = sk.finish()
+    sk.close()
+    assert_same_sketch(g, e)
+
+
 # ---------------------------------------------------------------------------------------------- multi-process
 def test_sharded_containment_two_ranks_one_gpu():
     """Two ranks (gloo rendezvous, both on cuda:0) run the genome-sharded exchange with the real HIP probe and check
