@@ -1,0 +1,37 @@
+// hip_ffi.rs — extern "C" declarations for libsylph_hip.so (include/sylph_hip.h).  Shipped uncompiled: there is no Rust
+// toolchain in the build image.  See INTEGRATION.md for the call sites in sketch.rs / contain.rs.
+use std::os::raw::{c_char, c_int, c_void};
+#[repr(C)] pub struct SylphCtx { _p: [u8; 0] }
+#[repr(C)] pub struct SylphSketch { _p: [u8; 0] }
+#[repr(C)] pub struct SylphDb { _p: [u8; 0] }
+pub const SEED_AVX2_COMPAT: c_int = 1;   // what extract_markers does on every AVX2 host (sketch.rs:53-63)
+pub const READS_SINGLE: c_int = 0; pub const READS_PAIRED: c_int = 1;
+pub const MEM_HOST: c_int = 0;
+
+extern "C" {
+    pub fn sylph_last_error() -> *const c_char;
+    pub fn sylph_free(p: *mut c_void);
+    pub fn sylph_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut SylphCtx) -> c_int;
+    pub fn sylph_ctx_destroy(ctx: *mut SylphCtx);
+    // replaces extract_markers (sketch.rs:53) — test seam only, too small to offload per read
+    pub fn sylph_seeds(ctx: *mut SylphCtx, bases: *const u8, len: u64, c: u32, k: u32, seed_mode: c_int,
+                       out_hashes: *mut *mut u64, out_n: *mut u64) -> c_int;
+    // replaces the body of sketch_genome after parsing (sketch.rs:550-622)
+    pub fn sylph_sketch_genome(ctx: *mut SylphCtx, bases: *const u8, contig_off: *const u64, n_contigs: u64,
+                               c: u32, k: u32, seed_mode: c_int, min_spacing: u64, pseudotax: c_int,
+                               out_kmers: *mut *mut u64, out_n: *mut u64,
+                               out_tracked: *mut *mut u64, out_n_tracked: *mut u64) -> c_int;
+    // replace the record loops of sketch_sequences_needle (sketch.rs:897) / sketch_pair_sequences (sketch.rs:771)
+    pub fn sylph_sketch_begin(ctx: *mut SylphCtx, c: u32, k: u32, reads_mode: c_int, no_dedup: c_int,
+                              seed_mode: c_int, out: *mut *mut SylphSketch) -> c_int;
+    pub fn sylph_sketch_push(sk: *mut SylphSketch, bases: *const u8, rec_off: *const u64, n_records: u64, mem: c_int) -> c_int;
+    pub fn sylph_sketch_finish(sk: *mut SylphSketch, out_kmers: *mut *mut u64, out_counts: *mut *mut u32,
+                               out_n: *mut u64, out_dup_removed: *mut u64) -> c_int;
+    pub fn sylph_sketch_destroy(sk: *mut SylphSketch);
+    // replace the probe half of get_stats (contain.rs:601-656) for all genomes of a loaded database
+    pub fn sylph_db_upload(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,
+                           out: *mut *mut SylphDb) -> c_int;
+    pub fn sylph_db_contain(db: *mut SylphDb, sample_kmers: *const u64, sample_counts: *const u32, n: u64, mem: c_int,
+                            min_number_kmers: f64, contain_count: *mut u32, cov_off: *mut u64, out_covs: *mut *mut u32) -> c_int;
+    pub fn sylph_db_destroy(db: *mut SylphDb);
+}
