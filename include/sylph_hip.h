@@ -61,6 +61,11 @@ int sylph_ctx_create(int device, void *stream, sylph_ctx **out);
 void sylph_ctx_destroy(sylph_ctx *ctx);
 int sylph_ctx_synchronize(sylph_ctx *ctx);
 
+/* Tuning / test knobs (not needed for normal use).  "finish" = "auto" (default: bucket partition + in-LDS replay,
+ * falling back to the device-wide sort path when a bucket does not fit), "generic" (always the device-wide path) or
+ * "bucket" (error instead of falling back). */
+int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
+
 /* Per-kernel timing (hipEvent pairs on the ctx stream around every launch of the named kernel family) for
  * bench.py's roofline object.  enable=1 starts collecting and clears the totals. Families: "seeds", "annotate",
  * "sort", "replay", "probe", "db_index". */

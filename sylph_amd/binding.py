@@ -23,7 +23,7 @@ def lib_path():
 
 
 EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_ctx_create", "sylph_ctx_destroy",
-           "sylph_ctx_synchronize", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
+           "sylph_ctx_synchronize", "sylph_ctx_set_option", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
            "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_begin", "sylph_sketch_push",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
            "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_destroy"]
@@ -48,6 +48,7 @@ def load():
     L.sylph_ctx_destroy.argtypes = [vp]
     L.sylph_ctx_destroy.restype = None
     L.sylph_ctx_synchronize.argtypes = [vp]
+    L.sylph_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.sylph_ctx_profile.argtypes = [vp, i32]
     L.sylph_ctx_kernel_stats.argtypes = [vp, C.c_char_p, P(dbl), P(u64)]
     L.sylph_seeds.argtypes = [vp, vp, u64, u32, u32, i32, P(vp), P(u64)]
@@ -121,6 +122,9 @@ class Context:
 
     def synchronize(self):
         _check(load().sylph_ctx_synchronize(self._h))
+
+    def set_option(self, key, value):
+        _check(load().sylph_ctx_set_option(self._h, key.encode(), value.encode()))
 
     def profile(self, enable=True):
         _check(load().sylph_ctx_profile(self._h, int(enable)))

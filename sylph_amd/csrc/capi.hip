@@ -241,6 +241,21 @@ int sylph_ctx_synchronize(sylph_ctx* ctx) {
     });
 }
 
+int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && key && value, "null argument");
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (!strcmp(key, "finish")) {
+            if (!strcmp(value, "auto")) ctx->finish_mode = 0;
+            else if (!strcmp(value, "generic")) ctx->finish_mode = 1;
+            else if (!strcmp(value, "bucket")) ctx->finish_mode = 2;
+            else SY_REQUIRE(false, "finish must be auto|generic|bucket");
+        } else {
+            SY_REQUIRE(false, "unknown option %s", key);
+        }
+    });
+}
+
 int sylph_ctx_profile(sylph_ctx* ctx, int enable) {
     return guarded([&] {
         SY_REQUIRE(ctx, "null ctx");

@@ -124,6 +124,7 @@ struct sylph_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::mutex mu;                          // serialises calls on this ctx
+    int finish_mode = 0;                    // 0 auto, 1 generic, 2 bucket-only (sylph_ctx_set_option "finish")
     std::atomic<int> refs{1};               // the creator + every live session / db; freed when it drops to 0
     // profiling
     bool profile = false;
@@ -189,6 +190,8 @@ struct DeviceGuard {
 void sort_pairs_u64_u32(sylph_ctx* ctx, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout,
                         size_t n, int begin_bit, int end_bit);
 void sort_pairs_u32_u64(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uint64_t* vin, uint64_t* vout,
+                        size_t n, int begin_bit, int end_bit);
+void sort_pairs_u32_u32(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                         size_t n, int begin_bit, int end_bit);
 void sort_keys_u64(sylph_ctx* ctx, const uint64_t* kin, uint64_t* kout, size_t n, int begin_bit, int end_bit);
 void exclusive_sum_u32(sylph_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);   // out[i] = sum in[0..i)

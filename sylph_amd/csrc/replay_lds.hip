@@ -1,0 +1,376 @@
+// replay_lds.hip — finish() of a read-sketch session without device-wide sorts: bucket partition + in-LDS replay.
+//
+// FracMinHash survivors are uniformly distributed below the threshold (mm_hash64 is a bijection of canonical
+// k-mers), so the top bits of the hash split the sample's occurrences into B buckets of nearly equal size.  One
+// counting pass + one scatter pass puts every occurrence record (hash, rid, m0, m1: 32 B) into its bucket; one
+// workgroup then owns one bucket entirely in LDS: bitonic sort by (hash, record index) -> k-mer segments in file
+// order -> mate-2 skip, duplicate flags, cut-off and counts (the same data-parallel formulation of
+// dup_removal_lsh_full_exact as sketch.hip, see its header) -> distinct (k-mer, count) pairs.  Buckets are ordered
+// by hash, so concatenating their outputs gives the table in ascending k-mer order.
+// HBM traffic: 40 B (histogram) + 64 B (scatter) + 32 B (replay) per occurrence instead of ~16 radix passes.
+// A bucket that does not fit (a k-mer with thousands of occurrences) makes finish() fall back to the generic
+// device-wide path in sketch.hip.
+#include "common.h"
+#include "device_common.h"
+#include "sketch_session.h"
+
+namespace sylph {
+namespace {
+
+constexpr int RTPB = 128;
+constexpr int CAP = 512;             // occurrences per bucket that fit in LDS (23 KiB per workgroup -> 6 workgroups per CU)
+constexpr int PADN = 512;            // bitonic network size
+constexpr int ITEMS = CAP / RTPB;    // sorted positions per lane (contiguous)
+constexpr uint32_t TARGET = 160;     // mean bucket load aimed for (B in (n/2T, n/T] -> mean load in [T, 2T))
+
+// boff[b] = first position (in the array sorted by the bucket bits) whose bucket is >= b, for b in [0, B]
+__global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __restrict__ bk, uint32_t n, uint32_t B,
+                                                            uint32_t* __restrict__ boff) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const uint32_t lo = (i == 0) ? 0 : bk[i - 1] + 1;
+    const uint32_t hi = (i == n) ? B : bk[i];
+    for (uint32_t b = lo; b <= hi && b <= B; b++) boff[b] = i;
+}
+
+// bucket id of every occurrence (B = "invalid", sorts last) + identity permutation
+__global__ __launch_bounds__(256) void bucket_key_kernel(const uint64_t* __restrict__ hash, uint32_t n, int bshift, uint32_t B,
+                                                         uint32_t* __restrict__ bk, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = hash[i];
+    bk[i] = (h == INVALID_HASH) ? B : (uint32_t)(h >> bshift);
+    idx[i] = i;
+}
+
+// number of valid occurrences = first sorted position whose bucket id is B
+__global__ void count_valid_bk_kernel(const uint32_t* __restrict__ bk, uint32_t n, uint32_t B, uint32_t* __restrict__ out) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bk[mid] < B) lo = mid + 1; else hi = mid;
+    }
+    *out = lo;
+}
+
+// exclusive prefix sum of one value per lane across the workgroup (4 waves); total returned through *total
+__device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RTPB / 64; w++) {
+        const uint32_t t = s_wave[w];
+        if ((uint32_t)w < wave) base += t;
+        tot += t;
+    }
+    if (total) *total = tot;
+    return base + x - v;
+}
+
+// One workgroup = one bucket.  SINGLE_CUTOFF = 4 for single-end (sketch.rs:937), 0 for pairs.
+__global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const uint64_t* __restrict__ g_hash, const uint32_t* __restrict__ perm,
+                                                             const uint64_t* __restrict__ g_rid, const uint64_t* __restrict__ g_m0,
+                                                             const uint64_t* __restrict__ g_m1, const uint32_t* __restrict__ boff,
+                                                             uint32_t nv, int paired, int no_dedup,
+                                                             uint32_t cutoff, uint64_t* __restrict__ tmp_k,
+                                                             uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
+                                                             unsigned long long* __restrict__ removed_total,
+                                                             uint32_t* __restrict__ overflow, int dbg_stage) {
+    __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
+    __shared__ uint16_t s_idx[PADN];
+    __shared__ uint16_t s_seg[CAP];       // first sorted position of the k-mer each sorted position belongs to
+    __shared__ uint8_t s_fl[CAP];         // bit0 skip, bit1 would-be-dropped
+    __shared__ uint32_t s_a[CAP + 1], s_b[CAP + 1];
+    __shared__ uint32_t s_wave[RTPB / 64];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t first = boff[b], last = boff[b + 1];
+    const uint32_t n = last - first;
+    if (n == 0) { if (tid == 0) n_distinct[b] = 0; return; }
+    // too large for LDS (or, defensively, inconsistent bounds): report and let the generic path redo the sample
+    if (n > CAP || last > nv || first > last) { if (tid == 0) { n_distinct[b] = 0; atomicAdd(overflow, 1u); } return; }
+    for (uint32_t i = tid; i < n; i += RTPB) {   // the records are gathered through the partition permutation
+        const uint32_t p = perm[first + i];
+        s_hash[i] = g_hash[p]; s_rid[i] = g_rid[p]; s_m0[i] = g_m0[p]; s_m1[i] = g_m1[p];
+    }
+    uint32_t padn = 64;
+    while (padn < n) padn <<= 1;
+    for (uint32_t i = tid; i < padn; i += RTPB) s_idx[i] = (uint16_t)(i < n ? i : 0xFFFF);
+    __syncthreads();
+    if (dbg_stage == 1) { if (tid == 0) n_distinct[b] = 0; return; }
+    // ---- bitonic sort of s_idx by (hash, record index); 0xFFFF sorts last -----------------------------------
+    auto greater = [&](uint16_t x, uint16_t y) -> bool {   // key(x) > key(y)
+        if (x == 0xFFFF) return y != 0xFFFF;
+        if (y == 0xFFFF) return false;
+        const uint64_t hx = s_hash[x], hy = s_hash[y];
+        if (hx != hy) return hx > hy;
+        const uint64_t rx = s_rid[x] & RID_MASK, ry = s_rid[y] & RID_MASK;
+        if (rx != ry) return rx > ry;
+        return x > y;                                       // same k-mer twice in one record: symmetric, keep it total
+    };
+    for (uint32_t k2 = 2; k2 <= padn; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (padn >> 1); t += RTPB) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // comparator t: (lo, lo + j)
+                const uint32_t hi = lo + j;
+                const bool up = ((lo & k2) == 0);
+                const uint16_t x = s_idx[lo], y = s_idx[hi];
+                if (greater(x, y) == up) { s_idx[lo] = y; s_idx[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    if (dbg_stage == 2) { if (tid == 0) n_distinct[b] = 0; return; }
+    // ---- segments ---------------------------------------------------------------------------------------------
+    // lane owns ITEMS contiguous sorted positions; s_seg = running "last head seen" (segmented max-scan)
+    const uint32_t j0 = tid * ITEMS;
+    uint32_t heads = 0, last_head = 0;
+    bool has_head = false;
+    uint8_t headbits = 0;
+    for (int t = 0; t < ITEMS; t++) {
+        const uint32_t j = j0 + t;
+        if (j >= n) break;
+        const bool hd = (j == 0) || (s_hash[s_idx[j]] != s_hash[s_idx[j - 1]]);
+        if (hd) { heads++; last_head = j; has_head = true; headbits |= (uint8_t)(1u << t); }
+    }
+    // inclusive max-scan of last_head over lanes (a lane without a head inherits from the left)
+    uint32_t carry = has_head ? last_head + 1 : 0;   // +1 so that 0 means "none"
+    {
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        uint32_t x = carry;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x = max(x, y);
+        }
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        uint32_t left = 0;
+        for (uint32_t w = 0; w < wave; w++) left = max(left, s_wave[w]);
+        const uint32_t prev = max(left, __shfl_up(x, 1));   // inclusive result of the lane to the left
+        carry = (lane == 0) ? left : prev;
+    }
+    {
+        uint32_t cur = carry;   // last head (+1) before this lane's first position
+        for (int t = 0; t < ITEMS; t++) {
+            const uint32_t j = j0 + t;
+            if (j >= n) break;
+            if (headbits & (1u << t)) cur = j + 1;
+            s_seg[j] = (uint16_t)(cur - 1);
+        }
+    }
+    __syncthreads();
+    // ---- mate-2 skip (sketch.rs:852) and duplicate flags ----------------------------------------------------------
+    for (int t = 0; t < ITEMS; t++) {
+        const uint32_t j = j0 + t;
+        if (j >= n) break;
+        uint8_t fl = 0;
+        if (paired) {
+            const uint64_t rec = s_rid[s_idx[j]] & RID_MASK;
+            if (rec & 1) {
+                const uint32_t s0 = s_seg[j];
+                for (uint32_t q = j; q > s0;) {
+                    q--;
+                    const uint64_t rq = s_rid[s_idx[q]] & RID_MASK;
+                    if ((rq >> 1) != (rec >> 1)) break;
+                    if ((rq & 1) == 0) { fl = 1; break; }
+                }
+            }
+        }
+        s_fl[j] = fl;
+    }
+    __syncthreads();
+    uint32_t my_u = 0;
+    uint8_t ubits = 0;
+    for (int t = 0; t < ITEMS; t++) {
+        const uint32_t j = j0 + t;
+        if (j >= n) break;
+        uint8_t fl = s_fl[j];
+        const uint16_t me = s_idx[j];
+        if (!fl && !no_dedup && (s_rid[me] & RID_MARKER_BIT)) {
+            const uint64_t a = s_m0[me], bb = s_m1[me];
+            bool any_prev = false, hit = false;
+            for (uint32_t q = s_seg[j]; q < j; q++) {
+                if (s_fl[q] & 1) continue;
+                any_prev = true;
+                const uint16_t o = s_idx[q];
+                if (s_rid[o] & RID_MARKER_BIT) {
+                    const uint64_t x = s_m0[o], y = s_m1[o];
+                    if (x == a || y == a || x == bb || y == bb) { hit = true; break; }
+                }
+            }
+            if (any_prev && (hit || a == bb)) fl |= 2;
+        }
+        const bool u = !(fl & 1) && (no_dedup || !(fl & 2));
+        if (u) { my_u++; ubits |= (uint8_t)(1u << t); }
+        s_fl[j] = fl;   // NB: later lanes only read bit0 of earlier positions, which does not change here
+    }
+    if (dbg_stage == 3) { if (tid == 0) n_distinct[b] = 0; return; }
+    // ---- P_i = would-be-counted occurrences before i in its k-mer; counted_i (cut-off rule, sketch.rs:706) ------
+    uint32_t base_u = block_excl_sum(my_u, s_wave, nullptr);
+    {
+        uint32_t run = base_u;
+        for (int t = 0; t < ITEMS; t++) {
+            const uint32_t j = j0 + t;
+            if (j >= n) break;
+            s_a[j] = run;                       // Eu[j]
+            if (ubits & (1u << t)) run++;
+        }
+    }
+    __syncthreads();
+    uint32_t my_c = 0, my_removed = 0;
+    uint8_t cbits = 0;
+    for (int t = 0; t < ITEMS; t++) {
+        const uint32_t j = j0 + t;
+        if (j >= n) break;
+        const uint8_t fl = s_fl[j];
+        if (fl & 1) continue;
+        const uint32_t P = s_a[j] - s_a[s_seg[j]];
+        const bool u = (ubits >> t) & 1;
+        const bool c = (cutoff && P >= cutoff) ? true : u;
+        if (c) { my_c++; cbits |= (uint8_t)(1u << t); } else my_removed++;
+    }
+    uint32_t base_c = block_excl_sum(my_c, s_wave, nullptr);
+    uint32_t total_heads = 0;
+    uint32_t base_h = block_excl_sum(heads, s_wave, &total_heads);
+    uint32_t total_removed = 0;
+    (void)block_excl_sum(my_removed, s_wave, &total_removed);
+    {
+        uint32_t rc = base_c;
+        for (int t = 0; t < ITEMS; t++) {
+            const uint32_t j = j0 + t;
+            if (j >= n) break;
+            s_b[j] = rc;                        // Ec[j]
+            if (cbits & (1u << t)) rc++;
+        }
+        if (j0 < n && j0 + ITEMS >= n) s_b[n] = rc;   // Ec[n], written by the lane that owns the last position
+    }
+    __syncthreads();
+    // heads emit (k-mer, count); the distinct index of a head = number of heads before it
+    {
+        uint32_t rh = base_h;
+        const uint32_t out0 = first;
+        for (int t = 0; t < ITEMS; t++) {
+            const uint32_t j = j0 + t;
+            if (j >= n) break;
+            if (headbits & (1u << t)) {
+                // segment end = next head or n: walk (k-mers have few occurrences; bounded by the bucket size)
+                uint32_t e = j + 1;
+                while (e < n && s_seg[e] == j) e++;
+                tmp_k[out0 + rh] = s_hash[s_idx[j]];
+                tmp_c[out0 + rh] = s_b[e] - s_b[j];
+                rh++;
+            }
+        }
+    }
+    if (tid == 0) {
+        n_distinct[b] = total_heads;
+        if (total_removed) atomicAdd(removed_total, (unsigned long long)total_removed);
+    }
+}
+
+// out[d_off[b] + i] = tmp[boff[b] + i] for i < n_distinct[b]: one workgroup per bucket
+__global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t* __restrict__ tmp_k, const uint32_t* __restrict__ tmp_c,
+                                                             const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_off,
+                                                             const uint32_t* __restrict__ n_distinct, uint32_t n_buckets,
+                                                             uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c) {
+    for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        const uint32_t n = n_distinct[b], s = boff[b], d = d_off[b];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_k[d + i] = tmp_k[s + i]; out_c[d + i] = tmp_c[s + i]; }
+    }
+}
+
+uint32_t grid_of(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
+
+}  // namespace
+
+bool finish_bucketed(sylph_sketch* sk) {
+    sylph_ctx* ctx = sk->ctx;
+    const uint32_t n_all = (uint32_t)sk->n_occ;
+    sk->n_out = 0;
+    sk->dup_removed = 0;
+    if (n_all == 0) return true;
+    if (sk->c < 2) return false;   // c = 1: valid hashes reach the top bit that marks invalid occurrences
+    // bucket geometry: B = (thr >> bshift) + 1 buckets of TARGET..2*TARGET occurrences
+    const uint64_t thr = UINT64_MAX / (uint64_t)sk->c;
+    const int bits = bit_length(thr);
+    const int bbits = std::min(bit_length(n_all / TARGET), 24);
+    const int bshift = std::max(0, bits - bbits);
+    const uint32_t B = (uint32_t)(thr >> bshift) + 1;
+    DevBuf &b_idx = ctx->scratch[0], &b_keys = ctx->scratch[1], &b_perm = ctx->scratch[2], &b_tmpk = ctx->scratch[3],
+           &b_tmpc = ctx->scratch[4], &b_small = ctx->scratch[5], &b_bk = ctx->scratch[6];
+    b_idx.reserve((size_t)n_all * 4);
+    b_keys.reserve((size_t)n_all * 8);
+    b_perm.reserve((size_t)n_all * 4);
+    b_tmpk.reserve((size_t)n_all * 8);
+    b_tmpc.reserve((size_t)n_all * 4);
+    b_small.reserve(64);
+    b_bk.reserve((size_t)(B + 2) * 4 * 3);      // boff | n_distinct | d_off   (each B+2)
+    uint32_t* boff = b_bk.as<uint32_t>();
+    uint32_t* n_distinct = boff + (B + 2);
+    uint32_t* d_off = n_distinct + (B + 2);
+    unsigned long long* d_removed = b_small.as<unsigned long long>();
+    uint32_t* d_overflow = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 8);
+    uint32_t* d_nv = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 16);
+    SY_HIP(hipMemsetAsync(b_small.p, 0, 64, ctx->stream));
+    SY_HIP(hipMemsetAsync(n_distinct, 0, (size_t)(B + 2) * 4, ctx->stream));
+    // partition: stable radix sort on the bucket bits only (3 passes instead of 8); occurrences were appended in file
+    // order, so inside a bucket equal hashes keep file order and the in-LDS sort only has to order by (hash, record)
+    // partition: stable radix sort of (bucket id -> occurrence index) on bit_length(B) bits (2-3 passes of 4-byte keys
+    // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
+    uint32_t nv = 0;
+    uint32_t* bk_in = b_keys.as<uint32_t>();
+    uint32_t* bk_sorted = bk_in + n_all;
+    {
+        HostPhase ph(ctx, "finish(bucket): partition sort");
+        hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(n_all)), dim3(256), 0, ctx->stream, sk->hash.as<uint64_t>(), n_all, bshift,
+                           B, bk_in, b_idx.as<uint32_t>());
+        sort_pairs_u32_u32(ctx, bk_in, bk_sorted, b_idx.as<uint32_t>(), b_perm.as<uint32_t>(), n_all, 0, bit_length(B));
+        hipLaunchKernelGGL(count_valid_bk_kernel, dim3(1), dim3(1), 0, ctx->stream, bk_sorted, n_all, B, d_nv);
+        ctx->read_back(&nv, d_nv, 4);
+    }
+    if (nv == 0) return true;
+    {
+        HostPhase ph(ctx, "finish(bucket): bounds + LDS replay");
+        ScopedKernelTimer t(ctx, "replay");
+        hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)nv + 1)), dim3(256), 0, ctx->stream, bk_sorted, nv, B, boff);
+        hipLaunchKernelGGL(bucket_replay_kernel, dim3(B), dim3(RTPB), 0, ctx->stream, sk->hash.as<uint64_t>(), b_perm.as<uint32_t>(),
+                           sk->rid.as<uint64_t>(), sk->m0.as<uint64_t>(), sk->m1.as<uint64_t>(), boff, nv, sk->paired, sk->no_dedup,
+                           sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, b_tmpk.as<uint64_t>(),
+                           b_tmpc.as<uint32_t>(), n_distinct, d_removed, d_overflow,
+                           getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0);
+        SY_HIP(hipGetLastError());
+    }
+    exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
+    struct { unsigned long long removed; uint32_t overflow, n_seg; } host{};
+    SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 12, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 12, d_off + B, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(&host, ctx->pinned, 16);
+    if (!ctx->pending.empty()) profile_collect(ctx);
+    if (host.overflow) return false;             // some bucket did not fit in LDS: the generic path handles it
+    sk->out_k.reserve((size_t)host.n_seg * 8);
+    sk->out_c.reserve((size_t)host.n_seg * 4);
+    if (host.n_seg) {
+        HostPhase ph(ctx, "finish(bucket): compact");
+        ScopedKernelTimer t(ctx, "replay");
+        hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
+                           b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
+                           sk->out_c.as<uint32_t>());
+        SY_HIP(hipGetLastError());
+    }
+    sk->n_out = host.n_seg;
+    sk->dup_removed = host.removed;
+    return true;
+}
+
+}  // namespace sylph

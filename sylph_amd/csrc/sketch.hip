@@ -18,17 +18,17 @@
 
 #include "common.h"
 #include "device_common.h"
+#include "sketch_session.h"
 
 namespace sylph {
+
+bool finish_bucketed(sylph_sketch* sk);   // replay_lds.hip
 
 void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint64_t* d_out_hash,
                   uint32_t* d_out_pos, uint32_t out_cap, uint32_t* d_count);
 
 namespace {
 
-constexpr uint64_t RID_MARKER_BIT = 1ull << 63;   // rid: bit63 = has marker, low bits = global record index
-constexpr uint64_t RID_MASK = RID_MARKER_BIT - 1;
-constexpr uint64_t INVALID_HASH = ~0ull;
 
 // 32 consecutive bases starting at p (any alignment) -> (even-position 16-mer, odd-position 16-mer), each base a
 // 2-bit BYTE_TO_SEQ code, first base most significant (the order pair_kmer[_single] builds them in,
@@ -295,22 +295,6 @@ __global__ __launch_bounds__(256) void emit_table_kernel(const uint64_t* __restr
 
 using namespace sylph;
 
-struct sylph_sketch {
-    sylph_ctx* ctx;
-    uint32_t c, k;
-    int paired, no_dedup, avx2_compat;
-    bool finished = false;
-    uint64_t rec_base = 0;         // records pushed so far
-    uint64_t n_occ = 0;            // occurrences (valid + invalid) appended so far
-    DevBuf hash, rid, m0, m1;      // occurrence arrays, file order
-    DevBuf batch_bases, batch_off; // H2D staging for SYLPH_MEM_HOST pushes
-    DevBuf out_k, out_c;           // final table
-    uint64_t n_out = 0, dup_removed = 0;
-    DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
-    explicit sylph_sketch(sylph_ctx* cx)
-        : ctx(cx), hash(cx), rid(cx), m0(cx), m1(cx), batch_bases(cx), batch_off(cx), out_k(cx), out_c(cx), counters(cx) {}
-};
-
 namespace sylph {
 
 static uint32_t grid_for(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
@@ -415,6 +399,12 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     DeviceGuard dg(ctx->device);
     HostPhase ph_total(ctx, "finish: total incl. readback");
     SY_REQUIRE(sk->n_occ < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
+    // fast path: bucket partition + in-LDS replay (replay_lds.hip); falls through to the device-wide sort path
+    // below when a bucket does not fit in LDS (some k-mer with thousands of occurrences)
+    if (ctx->finish_mode != 1) {
+        if (finish_bucketed(sk)) { sk->finished = true; return; }
+        SY_REQUIRE(ctx->finish_mode != 2, "bucket finish overflowed and finish=bucket forbids the fallback");
+    }
     const uint32_t n_all = (uint32_t)sk->n_occ;
     uint32_t nv = 0;
     sk->n_out = 0;

@@ -1,0 +1,26 @@
+// sketch_session.h — state of one read-sketch session (shared by sketch.hip and replay_lds.hip).
+#pragma once
+#include "common.h"
+
+namespace sylph {
+constexpr uint64_t RID_MARKER_BIT = 1ull << 63;   // rid: bit63 = has marker, low bits = global record index
+constexpr uint64_t RID_MASK = RID_MARKER_BIT - 1;
+constexpr uint64_t INVALID_HASH = ~0ull;
+}  // namespace sylph
+
+struct sylph_sketch {
+    sylph_ctx* ctx;
+    uint32_t c, k;
+    int paired, no_dedup, avx2_compat;
+    bool finished = false;
+    uint64_t rec_base = 0;         // records pushed so far
+    uint64_t n_occ = 0;            // occurrences (valid + invalid) appended so far
+    sylph::DevBuf hash, rid, m0, m1;      // occurrence arrays, file order
+    sylph::DevBuf batch_bases, batch_off; // H2D staging for SYLPH_MEM_HOST pushes
+    sylph::DevBuf out_k, out_c;           // final table
+    uint64_t n_out = 0, dup_removed = 0;
+    sylph::DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
+    explicit sylph_sketch(sylph_ctx* cx)
+        : ctx(cx), hash(cx), rid(cx), m0(cx), m1(cx), batch_bases(cx), batch_off(cx), out_k(cx), out_c(cx), counters(cx) {}
+};
+

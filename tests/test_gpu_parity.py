@@ -96,7 +96,24 @@ def test_genome_sketch_synthetic_multicontig(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- read sketches
+FINISH_MODES = ("auto", "generic")   # bucket + in-LDS replay (with its fallback) and the device-wide sort path
+
+
 def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_AVX2_COMPAT, c=200, k=31, batches=1):
+    """Sketches with BOTH finish paths and insists that they agree before returning the result."""
+    res = []
+    for mode in FINISH_MODES:
+        ctx.set_option("finish", mode)
+        try:
+            res.append(_sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches))
+        finally:
+            ctx.set_option("finish", "auto")
+    assert np.array_equal(res[0]["kmers"], res[1]["kmers"]) and np.array_equal(res[0]["counts"], res[1]["counts"])
+    assert res[0]["dup_removed"] == res[1]["dup_removed"]
+    return res[0]
+
+
+def _sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches):
     sk = S.ReadSketcher(ctx, c=c, k=k, paired=paired, no_dedup=no_dedup, seed_mode=seed_mode)
     n = len(off) - 1
     step = max(2, ((n // batches + 1) // 2) * 2)
@@ -231,6 +248,25 @@ def test_read_sketch_long_reads_and_edge_lengths(ctx):
     b, off = concat(recs)
     e = O.sketch_reads(b, off, c=1, mode=O.MODE_SCALAR)
     assert_same_sketch(sketch_gpu(ctx, b, off, c=1, seed_mode=S.SEED_SCALAR), e)
+
+
+def test_bucket_path_is_really_used(ctx):
+    """finish=bucket forbids the fallback: an ordinary sample must go through the in-LDS replay; a sample with a k-mer of
+    thousands of occurrences must overflow it (and then works through the fallback under finish=auto)."""
+    rng = np.random.default_rng(17)
+    genome = random_seq(rng, 300000)
+    b, off = concat(make_reads(rng, genome, 20000, 150, dup_frac=0.1))
+    e = O.sketch_reads(b, off, c=20)
+    ctx.set_option("finish", "bucket")
+    try:
+        assert_same_sketch(_sketch_gpu_once(ctx, b, off, False, False, S.SEED_AVX2_COMPAT, 20, 31, 1), e)
+        deep = concat([genome[:200]] * 3000)
+        with pytest.raises(S.SylphHipError):
+            _sketch_gpu_once(ctx, deep[0], deep[1], False, False, S.SEED_AVX2_COMPAT, 3, 31, 1)
+    finally:
+        ctx.set_option("finish", "auto")
+    assert_same_sketch(_sketch_gpu_once(ctx, deep[0], deep[1], False, False, S.SEED_AVX2_COMPAT, 3, 31, 1),
+                       O.sketch_reads(deep[0], deep[1], c=3))
 
 
 def test_read_sketch_empty(ctx):
