@@ -17,6 +17,7 @@
 namespace sylph {
 namespace {
 
+// (one wavefront per bucket with CAP = 256 was measured 20 % slower than two wavefronts with CAP = 512)
 constexpr int RTPB = 128;
 constexpr int CAP = 512;             // occurrences per bucket that fit in LDS (23 KiB per workgroup -> 6 workgroups per CU)
 constexpr int PADN = 512;            // bitonic network size
@@ -77,9 +78,8 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave,
 }
 
 // One workgroup = one bucket.  SINGLE_CUTOFF = 4 for single-end (sketch.rs:937), 0 for pairs.
-__global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const uint64_t* __restrict__ g_hash, const uint32_t* __restrict__ perm,
-                                                             const uint64_t* __restrict__ g_rid, const uint64_t* __restrict__ g_m0,
-                                                             const uint64_t* __restrict__ g_m1, const uint32_t* __restrict__ boff,
+__global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
+                                                             const uint32_t* __restrict__ boff,
                                                              uint32_t nv, int paired, int no_dedup,
                                                              uint32_t cutoff, uint64_t* __restrict__ tmp_k,
                                                              uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const uint64_t* __r
     // too large for LDS (or, defensively, inconsistent bounds): report and let the generic path redo the sample
     if (n > CAP || last > nv || first > last) { if (tid == 0) { n_distinct[b] = 0; atomicAdd(overflow, 1u); } return; }
     for (uint32_t i = tid; i < n; i += RTPB) {   // the records are gathered through the partition permutation
-        const uint32_t p = perm[first + i];
-        s_hash[i] = g_hash[p]; s_rid[i] = g_rid[p]; s_m0[i] = g_m0[p]; s_m1[i] = g_m1[p];
+        const OccRec r = recs[perm[first + i]];   // one 32 B sector per occurrence
+        s_hash[i] = r.hash; s_rid[i] = r.rid; s_m0[i] = r.m0; s_m1[i] = r.m1;
     }
     uint32_t padn = 64;
     while (padn < n) padn <<= 1;
@@ -116,8 +116,12 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const uint64_t* __r
         if (rx != ry) return rx > ry;
         return x > y;                                       // same k-mer twice in one record: symmetric, keep it total
     };
+    // A wavefront's 64 comparators of a stage with partner distance j <= 64 touch only its own 128 consecutive
+    // elements, and a wavefront's LDS operations execute in program order, so those stages need no workgroup barrier:
+    // only the stages with j >= 128 (one per k2 >= 256) synchronise all waves.
     for (uint32_t k2 = 2; k2 <= padn; k2 <<= 1) {
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            if (j >= 128) __syncthreads();
             for (uint32_t t = tid; t < (padn >> 1); t += RTPB) {
                 const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // comparator t: (lo, lo + j)
                 const uint32_t hi = lo + j;
@@ -125,9 +129,11 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const uint64_t* __r
                 const uint16_t x = s_idx[lo], y = s_idx[hi];
                 if (greater(x, y) == up) { s_idx[lo] = y; s_idx[hi] = x; }
             }
-            __syncthreads();
+            if (j >= 128) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
+    __syncthreads();
     if (dbg_stage == 2) { if (tid == 0) n_distinct[b] = 0; return; }
     // ---- segments ---------------------------------------------------------------------------------------------
     // lane owns ITEMS contiguous sorted positions; s_seg = running "last head seen" (segmented max-scan)
@@ -216,7 +222,10 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const uint64_t* __r
     }
     if (dbg_stage == 3) { if (tid == 0) n_distinct[b] = 0; return; }
     // ---- P_i = would-be-counted occurrences before i in its k-mer; counted_i (cut-off rule, sketch.rs:706) ------
-    uint32_t base_u = block_excl_sum(my_u, s_wave, nullptr);
+    // two block scans in total: (would-count, heads) packed 16+16 bits here, (counted, removed) below; sums <= CAP
+    uint32_t tot_uh = 0;
+    const uint32_t base_uh = block_excl_sum(my_u | (heads << 16), s_wave, &tot_uh);
+    const uint32_t base_u = base_uh & 0xFFFFu, base_h = base_uh >> 16, total_heads = tot_uh >> 16;
     {
         uint32_t run = base_u;
         for (int t = 0; t < ITEMS; t++) {
@@ -239,11 +248,9 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const uint64_t* __r
         const bool c = (cutoff && P >= cutoff) ? true : u;
         if (c) { my_c++; cbits |= (uint8_t)(1u << t); } else my_removed++;
     }
-    uint32_t base_c = block_excl_sum(my_c, s_wave, nullptr);
-    uint32_t total_heads = 0;
-    uint32_t base_h = block_excl_sum(heads, s_wave, &total_heads);
-    uint32_t total_removed = 0;
-    (void)block_excl_sum(my_removed, s_wave, &total_removed);
+    uint32_t tot_cr = 0;
+    const uint32_t base_c = block_excl_sum(my_c | (my_removed << 16), s_wave, &tot_cr) & 0xFFFFu;
+    const uint32_t total_removed = tot_cr >> 16;
     {
         uint32_t rc = base_c;
         for (int t = 0; t < ITEMS; t++) {
@@ -343,8 +350,8 @@ bool finish_bucketed(sylph_sketch* sk) {
         HostPhase ph(ctx, "finish(bucket): bounds + LDS replay");
         ScopedKernelTimer t(ctx, "replay");
         hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)nv + 1)), dim3(256), 0, ctx->stream, bk_sorted, nv, B, boff);
-        hipLaunchKernelGGL(bucket_replay_kernel, dim3(B), dim3(RTPB), 0, ctx->stream, sk->hash.as<uint64_t>(), b_perm.as<uint32_t>(),
-                           sk->rid.as<uint64_t>(), sk->m0.as<uint64_t>(), sk->m1.as<uint64_t>(), boff, nv, sk->paired, sk->no_dedup,
+        hipLaunchKernelGGL(bucket_replay_kernel, dim3(B), dim3(RTPB), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(),
+                           boff, nv, sk->paired, sk->no_dedup,
                            sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, b_tmpk.as<uint64_t>(),
                            b_tmpc.as<uint32_t>(), n_distinct, d_removed, d_overflow,
                            getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0);

@@ -62,8 +62,7 @@ __device__ __forceinline__ void marker_halves(const uint8_t* __restrict__ p, uin
 __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
     const uint64_t* __restrict__ hash, uint32_t n, uint32_t pos_bias, uint32_t k, int avx2_compat, int paired,
-    int want_markers, uint64_t rec_base, uint64_t* __restrict__ o_hash, uint64_t* __restrict__ o_rid, uint64_t* __restrict__ o_m0,
-    uint64_t* __restrict__ o_m1) {
+    int want_markers, uint64_t rec_base, uint64_t* __restrict__ o_hash, OccRec* __restrict__ o_rec) {
     constexpr uint32_t WIN = 1024;           // record offsets staged in LDS (8 KiB)
     __shared__ uint64_t s_lo, s_hi;
     __shared__ uint64_t s_off[WIN + 2];
@@ -125,10 +124,9 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         }
     }
     if (i < n) {
-        o_hash[i] = valid ? h : INVALID_HASH;
-        o_rid[i] = rid;
-        o_m0[i] = m0;
-        o_m1[i] = m1;
+        const uint64_t hv = valid ? h : INVALID_HASH;
+        o_hash[i] = hv;
+        o_rec[i] = OccRec{hv, rid, m0, m1};
     }
     // (no counter of valid survivors here: one atomic per wavefront on a single word runs at ~88 atomics/us and was
     //  the whole 0.9 ms of this kernel; finish() finds the count by binary search in the hash-sorted array instead)
@@ -177,17 +175,17 @@ __global__ void iota_kernel(uint32_t* v, uint32_t n) {
 
 // gather payload into hash-sorted order and mark segment heads
 __global__ __launch_bounds__(256) void gather_heads_kernel(const uint64_t* __restrict__ hs, const uint32_t* __restrict__ perm,
-                                                           const uint64_t* __restrict__ rid, const uint64_t* __restrict__ m0,
-                                                           const uint64_t* __restrict__ m1, uint32_t n,
+                                                           const OccRec* __restrict__ recs, uint32_t n,
                                                            uint64_t* __restrict__ rid_s, uint64_t* __restrict__ m0_s,
                                                            uint64_t* __restrict__ m1_s, uint32_t* __restrict__ head,
                                                            uint32_t* __restrict__ headidx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t p = perm[i];
-    rid_s[i] = rid[p];
-    m0_s[i] = m0[p];
-    m1_s[i] = m1[p];
+    const OccRec r = recs[p];
+    rid_s[i] = r.rid;
+    m0_s[i] = r.m0;
+    m1_s[i] = r.m1;
     const bool hd = (i == 0) || (hs[i] != hs[i - 1]);
     head[i] = hd ? 1u : 0u;
     headidx[i] = hd ? i : 0u;
@@ -375,15 +373,12 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         const uint64_t need = sk->n_occ + n;
         const size_t keep = sk->n_occ * 8;
         sk->hash.grow_keep(need * 8, keep, ctx->stream);
-        sk->rid.grow_keep(need * 8, keep, ctx->stream);
-        sk->m0.grow_keep(need * 8, keep, ctx->stream);
-        sk->m1.grow_keep(need * 8, keep, ctx->stream);
+        sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
         ScopedKernelTimer t(ctx, "annotate");
         hipLaunchKernelGGL(annotate_reads_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_bases, d_off, n_records,
                            ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, bias, sk->k, sk->avx2_compat,
                            sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, sk->hash.as<uint64_t>() + sk->n_occ,
-                           sk->rid.as<uint64_t>() + sk->n_occ, sk->m0.as<uint64_t>() + sk->n_occ,
-                           sk->m1.as<uint64_t>() + sk->n_occ);
+                           sk->recs.as<OccRec>() + sk->n_occ);
         SY_HIP(hipGetLastError());
         sk->n_occ = need;
     }
@@ -445,7 +440,7 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(gather_heads_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, hs, b_perm.as<uint32_t>(),
-                               sk->rid.as<uint64_t>(), sk->m0.as<uint64_t>(), sk->m1.as<uint64_t>(), nv,
+                               sk->recs.as<OccRec>(), nv,
                                b_rid.as<uint64_t>(), b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), head, headidx);
         }
         inclusive_max_u32(ctx, headidx, seg_start, nv);
