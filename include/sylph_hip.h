@@ -148,6 +148,18 @@ int sylph_db_contain(sylph_db *db, const uint64_t *sample_kmers, const uint32_t 
 int sylph_db_contain_view(sylph_db *db, const uint64_t *sample_kmers, const uint32_t *sample_counts, uint64_t n, int mem,
                           double min_number_kmers, const uint32_t **contain_count, const uint64_t **cov_off,
                           const uint32_t **covs, uint64_t *out_n_covs);
+/* Profile reassignment (the `profile` subcommand only).
+ * sylph_db_attach_tracked: add the pseudotax_tracked_nonused_kmers of every genome of the shard (types.rs:166; genome g =
+ * tracked_kmers[tracked_off[g], tracked_off[g+1])), which take part in the winner table.
+ * sylph_db_reassign_view: winner_table (contain.rs:410-430) over the `n_passing` genomes that survived the first pass
+ * (passing_gids in the order of the reference's result vector, passing_ani = their first-pass final_est_ani; ties go to
+ * the earlier entry, :417) followed by the second probe pass with the winner map (contain.rs:300-307, :637-646).  Same
+ * borrowed result views as sylph_db_contain_view (non-passing genomes report 0), plus kmers_lost[g] (:641). */
+int sylph_db_attach_tracked(sylph_db *db, const uint64_t *tracked_kmers, const uint64_t *tracked_off, int mem);
+int sylph_db_reassign_view(sylph_db *db, const uint64_t *sample_kmers, const uint32_t *sample_counts, uint64_t n, int mem,
+                           const uint32_t *passing_gids, const double *passing_ani, uint32_t n_passing,
+                           const uint32_t **contain_count, const uint64_t **cov_off, const uint32_t **covs,
+                           uint64_t *out_n_covs, const uint32_t **kmers_lost);
 void sylph_db_destroy(sylph_db *db);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_ctx_create"
            "sylph_ctx_synchronize", "sylph_ctx_set_option", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
            "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_begin", "sylph_sketch_push",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
-           "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_destroy"]
+           "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy"]
 
 
 def load():
@@ -67,6 +67,8 @@ def load():
     L.sylph_db_n_kmers.restype = u64
     L.sylph_db_contain.argtypes = [vp, vp, vp, u64, i32, dbl, vp, vp, P(vp)]
     L.sylph_db_contain_view.argtypes = [vp, vp, vp, u64, i32, dbl, P(vp), P(vp), P(vp), P(u64)]
+    L.sylph_db_attach_tracked.argtypes = [vp, vp, vp, i32]
+    L.sylph_db_reassign_view.argtypes = [vp, vp, vp, u64, i32, vp, vp, u32, P(vp), P(vp), P(vp), P(u64), P(vp)]
     L.sylph_db_destroy.argtypes = [vp]
     L.sylph_db_destroy.restype = None
     _LIB = L
@@ -252,6 +254,27 @@ class Database:
         cc = view(pc, G, C.c_uint32, np.uint32)
         covs = view(pv, int(nh.value), C.c_uint32, np.uint32)
         return cc, off, covs
+
+    def attach_tracked(self, tracked_kmers, tracked_off):
+        k, off = _np(tracked_kmers, np.uint64), _np(tracked_off, np.uint64)
+        _check(load().sylph_db_attach_tracked(self._h, _ptr(k) if len(k) else None, _ptr(off), MEM_HOST))
+
+    def reassign_view(self, sample_kmers, sample_counts, passing_gids, passing_ani):
+        """winner_table + second probe pass on device -> (contain_count, cov_off, covs, kmers_lost), borrowed views."""
+        G = self.n_genomes
+        k, c = _np(sample_kmers, np.uint64), _np(sample_counts, np.uint32)
+        pg, pa = _np(passing_gids, np.uint32), _np(passing_ani, np.float64)
+        pc, po, pv, pl, nh = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        _check(load().sylph_db_reassign_view(self._h, _ptr(k) if len(k) else None, _ptr(c) if len(c) else None, len(k), MEM_HOST,
+                                             _ptr(pg) if len(pg) else None, _ptr(pa) if len(pa) else None, len(pg), C.byref(pc),
+                                             C.byref(po), C.byref(pv), C.byref(nh), C.byref(pl)))
+
+        def view(ptr, count, ctype, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).view(dtype)
+        return (view(pc, G, C.c_uint32, np.uint32), view(po, G + 1, C.c_uint64, np.uint64),
+                view(pv, int(nh.value), C.c_uint32, np.uint32), view(pl, G, C.c_uint32, np.uint32))
 
     def close(self):
         if self._h:

@@ -97,6 +97,87 @@ __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const uint64_t* __rest
     }
 }
 
+// equal range of `km` in a bucketed postings index: [lo, hi)
+__device__ __forceinline__ void posting_range(const uint64_t* __restrict__ kmer, const uint32_t* __restrict__ bucket_start, int shift,
+                                              uint32_t n_buckets, uint64_t km, uint32_t& lo_out, uint32_t& hi_out) {
+    lo_out = hi_out = 0;
+    const uint64_t b = km >> shift;
+    if (b >= n_buckets) return;
+    uint32_t lo = bucket_start[b];
+    const uint32_t end = bucket_start[b + 1];
+    uint32_t hi = end;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (kmer[mid] < km) lo = mid + 1; else hi = mid;
+    }
+    uint32_t e = lo;
+    while (e < end && kmer[e] == km) e++;
+    lo_out = lo;
+    hi_out = e;
+}
+
+// Profile reassignment on device: winner_table (contain.rs:410-430) + the second get_stats pass (contain.rs:300-307 with
+// the winner map, :637-646).  A k-mer belongs to the passing genome with the highest first-pass ANI among those that
+// hold it in genome_kmers or in pseudotax_tracked_nonused_kmers; ties go to the genome that comes first in the passing
+// list (the reference replaces only on strictly greater ANI, :417).  For every passing genome, sample k-mers of its
+// genome_kmers that it does not own count as kmers_lost, the others yield (genome, count) hits as in the first pass.
+__global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(
+    const uint64_t* __restrict__ s_kmers, const uint32_t* __restrict__ s_counts, uint32_t n_sample, const uint64_t* __restrict__ db_kmer,
+    const uint32_t* __restrict__ db_gid, const uint32_t* __restrict__ bucket_start, int shift, uint32_t n_buckets,
+    const uint64_t* __restrict__ t_kmer, const uint32_t* __restrict__ t_gid, const uint32_t* __restrict__ t_bucket_start, int t_shift,
+    uint32_t t_n_buckets, const uint32_t* __restrict__ rank, const double* __restrict__ ani, uint32_t* __restrict__ lost,
+    uint64_t* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
+    __shared__ uint64_t stage[PROBE_STAGE];
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * PROBE_TPB + threadIdx.x;
+    if (i < n_sample) {
+        const uint64_t km = s_kmers[i];
+        const uint32_t cnt = s_counts[i];
+        if (cnt != 0) {                                                      // contain.rs:634
+            uint32_t a0, a1, t0 = 0, t1 = 0;
+            posting_range(db_kmer, bucket_start, shift, n_buckets, km, a0, a1);
+            if (a1 > a0) {
+                if (t_n_buckets) posting_range(t_kmer, t_bucket_start, t_shift, t_n_buckets, km, t0, t1);
+                uint32_t best_rank = 0xFFFFFFFFu;
+                double best_ani = -1.0;
+                auto consider = [&](uint32_t g) {
+                    const uint32_t r = rank[g];
+                    if (r == 0xFFFFFFFFu) return;
+                    const double a = ani[r];
+                    if (a > best_ani || (a == best_ani && r < best_rank)) { best_ani = a; best_rank = r; }
+                };
+                for (uint32_t j = a0; j < a1; j++) consider(db_gid[j]);
+                for (uint32_t j = t0; j < t1; j++) consider(t_gid[j]);
+                for (uint32_t j = a0; j < a1; j++) {
+                    const uint32_t g = db_gid[j];
+                    const uint32_t r = rank[g];
+                    if (r == 0xFFFFFFFFu) continue;                          // not in remaining_genomes
+                    if (r != best_rank) { atomicAdd(&lost[g], 1u); continue; }   // contain.rs:639-642
+                    const uint64_t hit = ((uint64_t)g << 32) | cnt;
+                    const uint32_t slot = atomicAdd(&s_cnt, 1u);
+                    if (slot < PROBE_STAGE) stage[slot] = hit;
+                    else {
+                        const uint32_t o = atomicAdd(hit_count, 1u);
+                        if (o < hit_cap) hits[o] = hit;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = min(s_cnt, (uint32_t)PROBE_STAGE);
+    if (n) {
+        if (threadIdx.x == 0) s_base = atomicAdd(hit_count, n);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < n; t += PROBE_TPB) {
+            const uint32_t o = s_base + t;
+            if (o < hit_cap) hits[o] = stage[t];
+        }
+    }
+}
+
 // cov_off[g] = first sorted hit with genome id >= g; covs[i] = low 32 bits of hit i
 __global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __restrict__ hits, uint32_t n_hits,
                                                           uint32_t n_genomes, uint64_t* __restrict__ cov_off,
@@ -132,17 +213,77 @@ struct sylph_db {
     int shift = 0;
     uint32_t n_buckets = 0;
     DevBuf kmer, gid, bucket_start, glen;
+    // optional second postings index over pseudotax_tracked_nonused_kmers (types.rs:166), only used by the winner table
+    DevBuf t_kmer, t_gid, t_bucket_start;
+    int t_shift = 0;
+    uint32_t t_n_buckets = 0;
+    uint64_t t_n = 0;
+    DevBuf rank, ani, lost;        // reassign pass: rank[g] in the passing list (or ~0), ANI per rank, kmers_lost[g]
     // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
     DevBuf q_kmers, q_counts, hits, hits_sorted, cov_off, ccount, covs, counter;
     void* h_res = nullptr;         // pinned host results: [cov_off (G+1) u64 | contain_count G u32 | covs u32]
     size_t h_res_cap = 0;
     ~sylph_db() { if (h_res) (void)hipHostFree(h_res); }
     explicit sylph_db(sylph_ctx* cx)
-        : ctx(cx), kmer(cx), gid(cx), bucket_start(cx), glen(cx), q_kmers(cx), q_counts(cx), hits(cx), hits_sorted(cx),
+        : ctx(cx), kmer(cx), gid(cx), bucket_start(cx), glen(cx), t_kmer(cx), t_gid(cx), t_bucket_start(cx), rank(cx),
+          ani(cx), lost(cx), q_kmers(cx), q_counts(cx), hits(cx), hits_sorted(cx),
           cov_off(cx), ccount(cx), covs(cx), counter(cx) {}
 };
 
 static uint32_t grid_for64(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
+
+// Builds a postings index (k-mers sorted, genome id per posting, bucket table) from genome-major device arrays.
+static void build_postings(sylph_ctx* ctx, const uint64_t* d_kmers_in, const uint64_t* d_off, uint64_t n_genomes, uint64_t n,
+                           DevBuf& kmer, DevBuf& gid, DevBuf& bucket_start, int& shift, uint32_t& n_buckets) {
+    ScopedKernelTimer t(ctx, "db_index");
+    DevBuf gid_in(ctx);
+    gid_in.reserve(n * 4);
+    kmer.reserve(n * 8);
+    gid.reserve(n * 4);
+    hipLaunchKernelGGL(fill_gid_kernel, dim3((uint32_t)std::min<uint64_t>(n_genomes, 1u << 20)), dim3(256), 0, ctx->stream, d_off,
+                       n_genomes, gid_in.as<uint32_t>());
+    sort_pairs_u64_u32(ctx, d_kmers_in, kmer.as<uint64_t>(), gid_in.as<uint32_t>(), gid.as<uint32_t>(), n, 0, 64);
+    uint64_t max_key = 0;
+    ctx->read_back(&max_key, kmer.as<uint64_t>() + (n - 1), 8);
+    // ~8 postings per bucket on average (one or two 64 B sectors), index <= 2^28 entries
+    int b = bit_length(n / 8);
+    b = std::min(28, std::max(8, b));
+    const int bits = std::max(1, bit_length(max_key));
+    shift = std::max(0, bits - b);
+    n_buckets = (uint32_t)((max_key >> shift) + 1);
+    bucket_start.reserve(((size_t)n_buckets + 1) * 4);
+    hipLaunchKernelGGL(bucket_index_kernel, dim3(grid_for64(n + 1)), dim3(256), 0, ctx->stream, kmer.as<uint64_t>(), (uint32_t)n,
+                       shift, n_buckets, bucket_start.as<uint32_t>());
+    SY_HIP(hipGetLastError());
+    SY_HIP(hipStreamSynchronize(ctx->stream));   // the caller's staging buffers / gid_in are released on return
+}
+
+// Stages genome-major (k-mers, offsets) on the device if they are host arrays; returns the device pointers and the total.
+static uint64_t stage_genome_major(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* off, uint64_t n_genomes, int mem,
+                                   DevBuf& d_off_buf, DevBuf& d_in, const uint64_t*& d_off, const uint64_t*& d_kmers) {
+    uint64_t n = 0;
+    d_off = nullptr;
+    d_kmers = nullptr;
+    if (!n_genomes) return 0;
+    if (mem == SYLPH_MEM_HOST) {
+        SY_REQUIRE(off[0] == 0, "offsets[0] must be 0");
+        n = off[n_genomes];
+        d_off_buf.reserve((n_genomes + 1) * 8);
+        ctx->h2d(d_off_buf.p, off, (n_genomes + 1) * 8);
+        d_off = d_off_buf.as<uint64_t>();
+        if (n) {
+            SY_REQUIRE(kmers, "null kmers");
+            d_in.reserve(n * 8);
+            ctx->h2d(d_in.p, kmers, n * 8);
+            d_kmers = d_in.as<uint64_t>();
+        }
+    } else {
+        ctx->read_back(&n, off + n_genomes, 8);
+        d_off = off;
+        d_kmers = kmers;
+    }
+    return n;
+}
 
 extern "C" {
 
@@ -158,62 +299,37 @@ int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genom
         std::unique_ptr<sylph_db> db(new sylph_db(ctx));
         db->n_genomes = n_genomes;
         db->counter.reserve(64);
-        uint64_t n = 0;
         DevBuf d_off_buf(ctx), d_in(ctx);
         const uint64_t* d_off = nullptr;
         const uint64_t* d_kmers_in = nullptr;
-        if (n_genomes) {
-            if (mem == SYLPH_MEM_HOST) {
-                SY_REQUIRE(genome_off[0] == 0, "genome_off[0] must be 0");
-                n = genome_off[n_genomes];
-                d_off_buf.reserve((n_genomes + 1) * 8);
-                ctx->h2d(d_off_buf.p, genome_off, (n_genomes + 1) * 8);
-                d_off = d_off_buf.as<uint64_t>();
-                if (n) {
-                    SY_REQUIRE(kmers, "null kmers");
-                    d_in.reserve(n * 8);
-                    ctx->h2d(d_in.p, kmers, n * 8);
-                    d_kmers_in = d_in.as<uint64_t>();
-                }
-            } else {
-                ctx->read_back(&n, genome_off + n_genomes, 8);
-                d_off = genome_off;
-                d_kmers_in = kmers;
-            }
-        }
+        const uint64_t n = stage_genome_major(ctx, kmers, genome_off, n_genomes, mem, d_off_buf, d_in, d_off, d_kmers_in);
         SY_REQUIRE(n < (1ull << 32), "at most 2^32-1 k-mers per shard (got %llu): shard the database", (unsigned long long)n);
         db->n_kmers = n;
         db->glen.reserve(std::max<uint64_t>(1, n_genomes) * 4);
         if (n_genomes)
             hipLaunchKernelGGL(genome_len_kernel, dim3(grid_for64(n_genomes)), dim3(256), 0, ctx->stream, d_off, n_genomes,
                                db->glen.as<uint32_t>());
-        if (n) {
-            ScopedKernelTimer t(ctx, "db_index");
-            DevBuf gid_in(ctx);
-            gid_in.reserve(n * 4);
-            db->kmer.reserve(n * 8);
-            db->gid.reserve(n * 4);
-            hipLaunchKernelGGL(fill_gid_kernel, dim3((uint32_t)std::min<uint64_t>(n_genomes, 1u << 20)), dim3(256), 0,
-                               ctx->stream, d_off, n_genomes, gid_in.as<uint32_t>());
-            sort_pairs_u64_u32(ctx, d_kmers_in, db->kmer.as<uint64_t>(), gid_in.as<uint32_t>(), db->gid.as<uint32_t>(), n, 0,
-                               64);
-            uint64_t max_key = 0;
-            ctx->read_back(&max_key, db->kmer.as<uint64_t>() + (n - 1), 8);
-            // ~8 postings per bucket on average (one or two 64 B sectors), index <= 2^28 entries
-            int b = bit_length(n / 8);
-            b = std::min(28, std::max(8, b));
-            const int bits = std::max(1, bit_length(max_key));
-            db->shift = std::max(0, bits - b);
-            db->n_buckets = (uint32_t)((max_key >> db->shift) + 1);
-            db->bucket_start.reserve(((size_t)db->n_buckets + 1) * 4);
-            hipLaunchKernelGGL(bucket_index_kernel, dim3(grid_for64(n + 1)), dim3(256), 0, ctx->stream,
-                               db->kmer.as<uint64_t>(), (uint32_t)n, db->shift, db->n_buckets,
-                               db->bucket_start.as<uint32_t>());
-            SY_HIP(hipGetLastError());
-            SY_HIP(hipStreamSynchronize(ctx->stream));   // d_in / gid_in are released on return
-        }
+        if (n) build_postings(ctx, d_kmers_in, d_off, n_genomes, n, db->kmer, db->gid, db->bucket_start, db->shift, db->n_buckets);
         ctx->refs++;
         *out = db.release();
+    });
+}
+
+int sylph_db_attach_tracked(sylph_db* db, const uint64_t* tracked_kmers, const uint64_t* tracked_off, int mem) {
+    return guarded([&] {
+        SY_REQUIRE(db && tracked_off, "null argument");
+        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+        sylph_ctx* ctx = db->ctx;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        DevBuf d_off_buf(ctx), d_in(ctx);
+        const uint64_t* d_off = nullptr;
+        const uint64_t* d_k = nullptr;
+        const uint64_t n = stage_genome_major(ctx, tracked_kmers, tracked_off, db->n_genomes, mem, d_off_buf, d_in, d_off, d_k);
+        SY_REQUIRE(n < (1ull << 32), "at most 2^32-1 tracked k-mers per shard");
+        db->t_n = n;
+        db->t_n_buckets = 0;
+        if (n) build_postings(ctx, d_k, d_off, db->n_genomes, n, db->t_kmer, db->t_gid, db->t_bucket_start, db->t_shift, db->t_n_buckets);
     });
 }
 
@@ -221,14 +337,31 @@ uint64_t sylph_db_n_genomes(const sylph_db* db) { return db ? db->n_genomes : 0;
 uint64_t sylph_db_n_kmers(const sylph_db* db) { return db ? db->n_kmers : 0; }
 
 // Runs the probe and leaves (cov_off, contain_count, covs) in db->h_res (pinned).  Returns the number of hits.
+struct ReassignArgs { const uint32_t* passing_gids; const double* passing_ani; uint32_t n_passing; };
+
 static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
-                             double min_number_kmers) {
+                             double min_number_kmers, const ReassignArgs* re = nullptr) {
     SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
     SY_REQUIRE(n < (1ull << 32), "sample table larger than 2^32-1 entries");
     sylph_ctx* ctx = db->ctx;
     const uint64_t G = db->n_genomes;
     uint32_t n_hits = 0;
-    if (n && db->n_kmers) {
+    if (re) {   // rank[g] = position of genome g in the passing list (or ~0), ani[rank], lost[g] = 0
+        SY_REQUIRE(re->n_passing == 0 || (re->passing_gids && re->passing_ani), "null passing list");
+        std::vector<uint32_t> rank(std::max<uint64_t>(1, G), 0xFFFFFFFFu);
+        for (uint32_t r = 0; r < re->n_passing; r++) {
+            SY_REQUIRE(re->passing_gids[r] < G, "passing genome id %u out of range", re->passing_gids[r]);
+            SY_REQUIRE(rank[re->passing_gids[r]] == 0xFFFFFFFFu, "genome %u listed twice", re->passing_gids[r]);
+            rank[re->passing_gids[r]] = r;
+        }
+        db->rank.reserve(rank.size() * 4);
+        db->ani.reserve(std::max<size_t>(1, re->n_passing) * 8);
+        db->lost.reserve(rank.size() * 4);
+        ctx->h2d(db->rank.p, rank.data(), rank.size() * 4);
+        if (re->n_passing) ctx->h2d(db->ani.p, re->passing_ani, (size_t)re->n_passing * 8);
+        SY_HIP(hipMemsetAsync(db->lost.p, 0, rank.size() * 4, ctx->stream));
+    }
+    if (n && db->n_kmers && (!re || re->n_passing)) {
         SY_REQUIRE(sample_kmers && sample_counts, "null sample");
         const uint64_t* d_k = sample_kmers;
         const uint32_t* d_c = sample_counts;
@@ -248,10 +381,20 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             SY_HIP(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
             {
                 ScopedKernelTimer t(ctx, "probe");
-                hipLaunchKernelGGL(probe_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
-                                   (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
-                                   db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->glen.as<uint32_t>(),
-                                   min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
+                if (!re)
+                    hipLaunchKernelGGL(probe_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
+                                       (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
+                                       db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->glen.as<uint32_t>(),
+                                       min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
+                else {
+                    if (attempt) SY_HIP(hipMemsetAsync(db->lost.p, 0, std::max<uint64_t>(1, G) * 4, ctx->stream));
+                    hipLaunchKernelGGL(reassign_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
+                                       (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
+                                       db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->t_kmer.as<uint64_t>(),
+                                       db->t_gid.as<uint32_t>(), db->t_bucket_start.as<uint32_t>(), db->t_shift, db->t_n_buckets,
+                                       db->rank.as<uint32_t>(), db->ani.as<double>(), db->lost.as<uint32_t>(),
+                                       db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
+                }
                 SY_HIP(hipGetLastError());
             }
             ctx->read_back(&n_hits, d_cnt, 4);
@@ -275,7 +418,7 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
                        (uint32_t)G, db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
     SY_HIP(hipGetLastError());
     // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
-    const size_t need = (G + 1) * 8 + G * 4 + (size_t)n_hits * 4 + 64;
+    const size_t need = (G + 1) * 8 + G * 4 + (size_t)n_hits * 4 + (re ? G * 4 : 0) + 64;
     if (need > db->h_res_cap) {
         if (db->h_res) SY_HIP(hipHostFree(db->h_res));
         db->h_res = nullptr;
@@ -288,6 +431,8 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
     if (G) SY_HIP(hipMemcpyAsync(h + (G + 1) * 8, db->ccount.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (n_hits)
         SY_HIP(hipMemcpyAsync(h + (G + 1) * 8 + G * 4, db->covs.p, (size_t)n_hits * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (re && G)
+        SY_HIP(hipMemcpyAsync(h + (G + 1) * 8 + G * 4 + (size_t)n_hits * 4, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
     SY_HIP(hipStreamSynchronize(ctx->stream));
     if (!ctx->pending.empty()) profile_collect(ctx);
     return n_hits;
@@ -306,6 +451,26 @@ int sylph_db_contain_view(sylph_db* db, const uint64_t* sample_kmers, const uint
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + (G + 1) * 8);
         *covs = (const uint32_t*)(h + (G + 1) * 8 + G * 4);
+        if (out_n_covs) *out_n_covs = n_hits;
+    });
+}
+
+int sylph_db_reassign_view(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
+                           const uint32_t* passing_gids, const double* passing_ani, uint32_t n_passing,
+                           const uint32_t** contain_count, const uint64_t** cov_off, const uint32_t** covs, uint64_t* out_n_covs,
+                           const uint32_t** kmers_lost) {
+    return guarded([&] {
+        SY_REQUIRE(db && contain_count && cov_off && covs && kmers_lost, "null argument");
+        std::lock_guard<std::mutex> lock(db->ctx->mu);
+        DeviceGuard dg(db->ctx->device);
+        ReassignArgs re{passing_gids, passing_ani, n_passing};
+        const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, 0.0, &re);
+        const uint64_t G = db->n_genomes;
+        const char* h = (const char*)db->h_res;
+        *cov_off = (const uint64_t*)h;
+        *contain_count = (const uint32_t*)(h + (G + 1) * 8);
+        *covs = (const uint32_t*)(h + (G + 1) * 8 + G * 4);
+        *kmers_lost = (const uint32_t*)(h + (G + 1) * 8 + G * 4 + (size_t)n_hits * 4);
         if (out_n_covs) *out_n_covs = n_hits;
     });
 }

@@ -333,34 +333,6 @@ void print_header(bool pseudotax, FILE* out, bool estimate_unknown) {         //
                      "Contig_name\n", estimate_unknown ? "True_cov" : "Eff_cov");
 }
 
-// open-addressing map sample k-mer -> count for the winner pass (contain.rs:632-652 with winner_map)
-struct SampleMap {
-    std::vector<uint64_t> keys;
-    std::vector<uint32_t> vals;
-    uint64_t mask = 0;
-    explicit SampleMap(const SequencesSketch& s) {
-        uint64_t cap = 16;
-        while (cap < s.kmers.size() * 2 + 1) cap <<= 1;
-        keys.assign(cap, ~0ull);
-        vals.assign(cap, 0);
-        mask = cap - 1;
-        for (size_t i = 0; i < s.kmers.size(); i++) {
-            uint64_t h = (s.kmers[i] * 0x9E3779B97F4A7C15ull) >> 20 & mask;
-            while (keys[h] != ~0ull) h = (h + 1) & mask;
-            keys[h] = s.kmers[i];
-            vals[h] = s.counts[i];
-        }
-    }
-    uint32_t get(uint64_t k) const {
-        uint64_t h = (k * 0x9E3779B97F4A7C15ull) >> 20 & mask;
-        while (keys[h] != ~0ull) {
-            if (keys[h] == k) return vals[h];
-            h = (h + 1) & mask;
-        }
-        return 0;
-    }
-};
-
 }  // namespace
 
 // contain.rs:115-351
@@ -424,6 +396,15 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
     hip_check(sylph_db_upload(e.ctx, flat.data(), goff.data(), genome_sketches.size(), SYLPH_MEM_HOST, &db), "sylph_db_upload");
     struct DbGuard { sylph_db* d; ~DbGuard() { sylph_db_destroy(d); } } guard{db};
     { std::vector<uint64_t>().swap(flat); }
+    if (args.pseudotax) {   // the winner table also ranges over pseudotax_tracked_nonused_kmers (contain.rs:421-428)
+        std::vector<uint64_t> tflat, toff{0};
+        for (const auto& g : genome_sketches) {
+            if (g.pseudotax_tracked_nonused_kmers)
+                tflat.insert(tflat.end(), g.pseudotax_tracked_nonused_kmers->begin(), g.pseudotax_tracked_nonused_kmers->end());
+            toff.push_back(tflat.size());
+        }
+        hip_check(sylph_db_attach_tracked(db, tflat.data(), toff.data(), SYLPH_MEM_HOST), "sylph_db_attach_tracked");
+    }
 
     print_header(args.pseudotax, out, args.estimate_unknown);
     const uint64_t genome_c = genome_sketches[0].c, genome_k = genome_sketches[0].k;
@@ -465,37 +446,24 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             }
             if (args.pseudotax) {
                 info(files[0] + " taxonomic profiling; reassigning k-mers for " + std::to_string(stats.size()) + " genomes...");
-                // winner_table, contain.rs:410-430: first inserted wins ties (strict >)
-                std::unordered_map<uint64_t, std::pair<double, size_t>> winner;
-                for (const auto& r : stats) {
-                    const GenomeSketch& g = genome_sketches[r.genome_index];
-                    auto feed = [&](const std::vector<uint64_t>& v) {
-                        for (uint64_t km : v) {
-                            auto it = winner.find(km);
-                            if (it == winner.end()) winner.emplace(km, std::make_pair(r.final_est_ani, r.genome_index));
-                            else if (r.final_est_ani > it->second.first) it->second = {r.final_est_ani, r.genome_index};
-                        }
-                    };
-                    feed(g.genome_kmers);
-                    if (g.pseudotax_tracked_nonused_kmers) feed(*g.pseudotax_tracked_nonused_kmers);
-                }
-                // second get_stats pass with the winner map, contain.rs:300-307 / :637-646
-                SampleMap smap(S);
+                // winner_table (contain.rs:410-430) + second get_stats pass with the winner map (:300-307, :637-646) on the
+                // device: one more probe of the resident postings (genome_kmers + tracked k-mers), passing genomes only.
+                std::vector<uint32_t> pg(stats.size());
+                std::vector<double> pa(stats.size());
+                for (size_t i = 0; i < stats.size(); i++) { pg[i] = (uint32_t)stats[i].genome_index; pa[i] = stats[i].final_est_ani; }
+                const uint32_t *cc2 = nullptr, *covs2 = nullptr, *lost2 = nullptr;
+                const uint64_t* coff2 = nullptr;
+                uint64_t ncov2 = 0;
+                hip_check(sylph_db_reassign_view(db, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST, pg.data(),
+                                                 pa.data(), (uint32_t)pg.size(), &cc2, &coff2, &covs2, &ncov2, &lost2),
+                          "sylph_db_reassign_view");
                 std::vector<AniResult> stats2;
                 for (const auto& old : stats) {
-                    const GenomeSketch& g = genome_sketches[old.genome_index];
-                    if ((double)g.genome_kmers.size() < args.min_number_kmers) continue;
-                    std::vector<uint32_t> cv;
-                    size_t lost = 0;
-                    for (uint64_t km : g.genome_kmers) {
-                        const uint32_t cnt = smap.get(km);
-                        if (cnt == 0) continue;
-                        if (winner.at(km).second != old.genome_index) { lost++; continue; }
-                        cv.push_back(cnt);
-                    }
-                    auto r = stats_from_covs(args, std::move(cv), g.genome_kmers.size(), S.k, lost);
+                    const size_t g = old.genome_index;
+                    std::vector<uint32_t> cv(covs2 + coff2[g], covs2 + coff2[g + 1]);
+                    auto r = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, (size_t)lost2[g]);
                     if (!r) continue;
-                    r->genome_index = old.genome_index;
+                    r->genome_index = g;
                     // derep_if_reassign_threshold, contain.rs:353-375
                     const double thr = std::pow(args.redundant_ani / 100., (double)S.k) * (double)r->n_kmers;
                     if ((double)(old.contain_count - r->contain_count) < thr) stats2.push_back(*r);

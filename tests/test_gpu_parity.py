@@ -416,3 +416,61 @@ def test_sharded_containment_two_ranks_one_gpu():
            "--master-port", "29533", os.path.join(root, "tests", "dist_gpu_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_reassign_on_device_matches_reference_semantics(ctx):
+    """sylph_db_reassign_view vs a direct restatement of winner_table (contain.rs:410-430) + the winner pass of get_stats
+    (contain.rs:637-646): shared k-mers, tracked k-mers that steal ownership, ANI ties (first in the passing list wins),
+    non-passing genomes, duplicate postings."""
+    rng = np.random.default_rng(99)
+    thr = O.threshold(200)
+    pool = np.unique(rng.integers(0, thr, size=40000, dtype=np.uint64))
+    G = 14
+    genomes = [rng.choice(pool, size=int(n), replace=False) for n in rng.integers(300, 3000, size=G)]
+    tracked = [rng.choice(pool, size=int(n), replace=False) for n in rng.integers(0, 400, size=G)]
+    genomes[2][:500] = genomes[1][:500]                 # shared genome_kmers
+    genomes[5][:300] = genomes[1][200:500]
+    tracked[7][:100] = genomes[1][:100]                 # a tracked k-mer set that can steal from genome 1
+    tracked[3] = np.zeros(0, dtype=np.uint64)
+    genomes[9] = np.concatenate([genomes[9], genomes[9][:50]])   # duplicate postings inside one genome
+    db_k = np.concatenate(genomes)
+    goff = np.zeros(G + 1, dtype=np.uint64)
+    goff[1:] = np.cumsum([len(g) for g in genomes])
+    t_k = np.concatenate(tracked)
+    toff = np.zeros(G + 1, dtype=np.uint64)
+    toff[1:] = np.cumsum([len(t) for t in tracked])
+    sk = np.sort(rng.choice(pool, size=25000, replace=False))
+    sc = rng.integers(0, 6, size=len(sk)).astype(np.uint32)
+    db = S.Database(ctx, db_k, goff)
+    db.attach_tracked(t_k, toff)
+    smap = dict(zip(sk.tolist(), sc.tolist()))
+    for trial in range(4):
+        passing = rng.permutation(G)[: int(rng.integers(1, G + 1))]
+        ani = rng.choice([0.95, 0.96, 0.97, 0.97, 0.99], size=len(passing))          # plenty of ties
+        winner = {}
+        for r, g in enumerate(passing):
+            for km in list(genomes[g].tolist()) + list(tracked[g].tolist()):
+                if km not in winner or ani[r] > winner[km][0]:
+                    winner[km] = (ani[r], int(g))
+        cc, off, covs, lost = db.reassign_view(sk, sc, passing, ani)
+        for g in range(G):
+            got = covs[int(off[g]):int(off[g + 1])]
+            if g not in passing:
+                assert cc[g] == 0 and len(got) == 0 and lost[g] == 0
+                continue
+            exp, exp_lost = [], 0
+            for km in genomes[g].tolist():
+                c = smap.get(km, 0)
+                if c == 0:
+                    continue
+                if winner[km][1] != g:
+                    exp_lost += 1
+                else:
+                    exp.append(c)
+            assert cc[g] == len(exp) and lost[g] == exp_lost, (trial, g)
+            assert np.array_equal(got, np.sort(np.array(exp, dtype=np.uint32)))
+    cc, off, covs, lost = db.reassign_view(sk, sc, np.zeros(0, dtype=np.uint32), np.zeros(0))
+    assert cc.sum() == 0 and lost.sum() == 0 and len(covs) == 0
+    with pytest.raises(S.SylphHipError):
+        db.reassign_view(sk, sc, np.array([1, 1], dtype=np.uint32), np.array([0.9, 0.9]))
+    db.close()
