@@ -9,10 +9,13 @@ sample per GPU: sketch 1 Gbp of paired reads that are already resident in HBM (s
 profile the resulting table against the resident database (containment counts + coverage vectors back on the host).
 `value` = whole-job read Gbp/s through both stages; the per-stage rates are reported next to it.
 
-Multi-GPU (SURVEY §8e): samples are independent units (one per rank per step, no collective in the sketch stage);
-the database is sharded by genome across ranks; every rank probes every sample of the step against its shard after
-one all-gather of the (small) sample tables, and the per-shard containment counts are combined by ONE RCCL
-all-gather per step.  scaling = weak (per-GPU sketch work fixed).
+Multi-GPU: samples are independent units (one per rank per step, no collective in the sketch stage).
+Database placement (--db-mode): "replicate" (default when the postings index fits HBM comfortably — 22 GB of 288 GB at
+GTDB-R220 scale): every rank holds the whole index and profiles its own sample, and ONE RCCL all-gather per step
+collects the per-sample containment counts on every rank; "shard": the database is sharded by genome across ranks,
+sample tables are all-gathered, every rank probes every sample against its shard and ONE all-gather combines
+counts + coverage lists (what a database larger than one GPU needs; O(sample) probe work per rank per sample, so
+it scales worse).  scaling = weak (per-GPU sketch work fixed).
 
 The CPU baseline leg (rank 0, N=1 only) times the oracle — the C++ restatement of the reference's AVX2/rayon path —
 on a bounded sample of the same inputs; it is the only place bench.py touches oracle/.
@@ -47,7 +50,7 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def build_database(ctx, device, wl, c, k, seed, rank, world):
+def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode="shard"):
     """-> (Database for this rank's shard, shard genome ids, n_genomes_total, community genomes tensor, stats)"""
     n_pairs, n_comm, n_seq, n_total, glen = WORKLOADS[wl]
     t0 = time.time()
@@ -92,9 +95,9 @@ def build_database(ctx, device, wl, c, k, seed, rank, world):
     del dk
     lens = (goff[1:] - goff[:-1]).cpu().numpy()
     # shard by genome, balanced by k-mer count
-    owner = SH.partition_genomes(lens, world)
-    mine = np.nonzero(owner == rank)[0]
-    if world > 1:
+    owner = SH.partition_genomes(lens, world if db_mode == "shard" else 1)
+    mine = np.nonzero(owner == (rank if db_mode == "shard" else 0))[0]
+    if world > 1 and db_mode == "shard":
         idx = torch.from_numpy(mine).to(device)
         starts, ls = goff[:-1][idx], torch.from_numpy(lens[mine]).to(device)
         soff = torch.zeros(len(mine) + 1, dtype=torch.int64, device=device)
@@ -146,6 +149,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SYLPH_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--db-mode", default=os.environ.get("SYLPH_BENCH_DB_MODE", "auto"), choices=["auto", "replicate", "shard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline object)")
     ap.add_argument("--seed", type=int, default=20250711)
@@ -182,7 +186,13 @@ def main():
     ctx = S.Context(local, stream=stream)
 
     log(f"[bench] building workload {args.workload} on {world} GPU(s) ...")
-    db, mine, lens_mine, n_total, community, dbstats = build_database(ctx, device, args.workload, c, k, args.seed, rank, world)
+    # ~1.8e9 postings x 12.5 B = 22 GB at GTDB-R220 scale: replicate unless it would take more than a quarter of HBM
+    db_mode = args.db_mode
+    if db_mode == "auto":
+        hbm = torch.cuda.get_device_properties(device).total_memory
+        est = WORKLOADS[args.workload][3] * 16000 * 12.5
+        db_mode = "replicate" if est < hbm / 4 else "shard"
+    db, mine, lens_mine, n_total, community, dbstats = build_database(ctx, device, args.workload, c, k, args.seed, rank, world, db_mode)
     t0 = time.time()
     if long_mode:
         bases, rec_off = synth.long_reads(community, 5_000_000_000, seed=args.seed + 1_000_003 * (rank + 1))
@@ -198,7 +208,7 @@ def main():
             o = (rec_off[a:b + 1] - rec_off[a]).contiguous()
             start = int(rec_off[a].item())
             assert start % 16 == 0 or a == 0 or True
-            batches.append((start, o, b - a))
+            batches.append((start, o, b - a, int(o[-1].item())))
     else:
         bases, rec_off = synth.paired_reads(community, n_pairs, read_len=read_len, seed=args.seed + 1_000_003 * (rank + 1))
         n_bases = n_pairs * 2 * read_len
@@ -216,17 +226,21 @@ def main():
         sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode)
         t_a1 = time.perf_counter()
         if long_mode:
-            for start, o, nrec in batches:
-                sk.push_device(bases.data_ptr() + start, o.data_ptr(), nrec)
+            for start, o, nrec, nb in batches:
+                sk.push_device(bases.data_ptr() + start, o.data_ptr(), nrec, nb)
         else:
-            sk.push_device(bases.data_ptr(), rec_off.data_ptr(), n_records)
+            sk.push_device(bases.data_ptr(), rec_off.data_ptr(), n_records, n_bases)
         t_a2 = time.perf_counter()
         dk, dc, n, dup = sk.finish_device()
         t_b = time.perf_counter()
         if os.environ.get("SYLPH_BENCH_DEBUG"):
             log(f"[bench] begin {1e3 * (t_a1 - t_a):.3f} push {1e3 * (t_a2 - t_a1):.3f} finish {1e3 * (t_b - t_a2):.3f} ms")
         occ_holder[0] = (dc, n, dup)
-        res = SH.profile_step(db, group, dk, dc, n, mine, n_total, device)
+        if db_mode == "shard" or world == 1:
+            res = SH.profile_step(db, group, dk, dc, n, mine, n_total, device)
+        else:   # replicated index: profile the rank's own sample, then one all-gather of the containment counts
+            res = SH.profile_step(db, SH.LocalGroup(), dk, dc, n, mine, n_total, device)
+            res["all_counts"] = SH.gather_counts(group, res["contain_count"], device)
         t_c = time.perf_counter()
         if os.environ.get("SYLPH_BENCH_DEBUG"):
             log(f"[bench] contain {1e3 * (t_c - t_b):.3f} ms")
@@ -283,7 +297,7 @@ def main():
                                 "small": "functional smoke workload (NOT the BASELINE config)",
                                 "c5": "ONT-like long reads (N50 10 kb, 5 Gbp, 5 % substitutions) sketched at c=100 vs GTDB-R220-scale DB at c=200 (BASELINE configs[4])"}[args.workload],
                    "reads_per_gpu_per_step_gbp": round(n_bases / 1e9, 4), "genomes": n_total, "db_kmers_per_shard": dbstats["shard_kmers"],
-                   "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)", "seed_mode": "avx2_compat", "parallelism": f"samples x{world}, db sharded x{world}",
+                   "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)", "seed_mode": "avx2_compat", "parallelism": f"samples x{world}, db {db_mode}d x{world}" if world > 1 else "1 sample, 1 GPU",
                    "inputs": "reads + database resident in HBM before the timed region"},
         "sketch_gbp_per_s": round(world * n_bases / 1e9 / t_sketch, 3),
         "genome_comparisons_per_s": round(comparisons / t_profile, 1),

@@ -114,6 +114,10 @@ int sylph_sketch_begin(sylph_ctx *ctx, uint32_t c, uint32_t k, int reads_mode, i
  * slack at its end), and complete: the library runs on its own stream unless the ctx was given the producer's. */
 int sylph_sketch_push(sylph_sketch *sk, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_records,
                       int mem);
+/* Same with the batch's total number of bases (== rec_off[n_records]) supplied by the caller, which saves the library a
+ * device->host read of that word when rec_off lives in HBM. */
+int sylph_sketch_push_n(sylph_sketch *sk, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_records,
+                        uint64_t n_bases, int mem);
 
 /* Finish the sample: (k-mer, count) table in ascending k-mer order == SequencesSketch.kmer_counts
  * (types.rs:145-155) as a keyed multiset, and the number of occurrences removed as duplicates

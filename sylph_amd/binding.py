@@ -24,7 +24,7 @@ def lib_path():
 
 EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_ctx_create", "sylph_ctx_destroy",
            "sylph_ctx_synchronize", "sylph_ctx_set_option", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
-           "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_begin", "sylph_sketch_push",
+           "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_begin", "sylph_sketch_push", "sylph_sketch_push_n",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
            "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy"]
 
@@ -56,6 +56,7 @@ def load():
     L.sylph_sketch_genome.argtypes = [vp, vp, vp, u64, u32, u32, i32, u64, i32, P(vp), P(u64), P(vp), P(u64)]
     L.sylph_sketch_begin.argtypes = [vp, u32, u32, i32, i32, i32, P(vp)]
     L.sylph_sketch_push.argtypes = [vp, vp, vp, u64, i32]
+    L.sylph_sketch_push_n.argtypes = [vp, vp, vp, u64, u64, i32]
     L.sylph_sketch_finish.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
     L.sylph_sketch_finish_device.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
     L.sylph_sketch_destroy.argtypes = [vp]
@@ -174,9 +175,14 @@ class ReadSketcher:
         a, off = _bases(bases), _np(rec_off, np.uint64)
         _check(load().sylph_sketch_push(self._h, _ptr(a) if len(a) else None, _ptr(off), len(off) - 1, MEM_HOST))
 
-    def push_device(self, bases_ptr, rec_off_ptr, n_records):
-        """bases_ptr / rec_off_ptr: integer device addresses (e.g. torch tensor .data_ptr())."""
-        _check(load().sylph_sketch_push(self._h, C.c_void_p(bases_ptr), C.c_void_p(rec_off_ptr), n_records, MEM_DEVICE))
+    def push_device(self, bases_ptr, rec_off_ptr, n_records, n_bases=None):
+        """bases_ptr / rec_off_ptr: integer device addresses (e.g. torch tensor .data_ptr()); n_bases = rec_off[n_records]
+        if the caller knows it (saves a device->host read)."""
+        if n_bases is None:
+            _check(load().sylph_sketch_push(self._h, C.c_void_p(bases_ptr), C.c_void_p(rec_off_ptr), n_records, MEM_DEVICE))
+        else:
+            _check(load().sylph_sketch_push_n(self._h, C.c_void_p(bases_ptr), C.c_void_p(rec_off_ptr), n_records, n_bases,
+                                              MEM_DEVICE))
 
     def finish(self):
         ok, oc, n, d = C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint64(0)

@@ -25,9 +25,10 @@ constexpr int ITEMS = CAP / RTPB;    // sorted positions per lane (contiguous)
 constexpr uint32_t TARGET = 160;     // mean bucket load aimed for (B in (n/2T, n/T] -> mean load in [T, 2T))
 
 // boff[b] = first position (in the array sorted by the bucket bits) whose bucket is >= b, for b in [0, B]
-__global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __restrict__ bk, uint32_t n, uint32_t B,
-                                                            uint32_t* __restrict__ boff) {
+__global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __restrict__ bk, const uint32_t* __restrict__ p_n,
+                                                            uint32_t B, uint32_t* __restrict__ boff) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *p_n;   // number of valid occurrences, still on the device: no host round trip before the replay
     if (i > n) return;
     const uint32_t lo = (i == 0) ? 0 : bk[i - 1] + 1;
     const uint32_t hi = (i == n) ? B : bk[i];
@@ -80,7 +81,7 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave,
 // One workgroup = one bucket.  SINGLE_CUTOFF = 4 for single-end (sketch.rs:937), 0 for pairs.
 __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
                                                              const uint32_t* __restrict__ boff,
-                                                             uint32_t nv, int paired, int no_dedup,
+                                                             const uint32_t* __restrict__ p_nv, int paired, int no_dedup,
                                                              uint32_t cutoff, uint64_t* __restrict__ tmp_k,
                                                              uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
                                                              unsigned long long* __restrict__ removed_total,
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     __shared__ uint32_t s_a[CAP + 1], s_b[CAP + 1];
     __shared__ uint32_t s_wave[RTPB / 64];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nv = *p_nv;
     const uint32_t first = boff[b], last = boff[b + 1];
     const uint32_t n = last - first;
     if (n == 0) { if (tid == 0) n_distinct[b] = 0; return; }
@@ -330,51 +332,45 @@ bool finish_bucketed(sylph_sketch* sk) {
     uint32_t* d_nv = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 16);
     SY_HIP(hipMemsetAsync(b_small.p, 0, 64, ctx->stream));
     SY_HIP(hipMemsetAsync(n_distinct, 0, (size_t)(B + 2) * 4, ctx->stream));
-    // partition: stable radix sort on the bucket bits only (3 passes instead of 8); occurrences were appended in file
-    // order, so inside a bucket equal hashes keep file order and the in-LDS sort only has to order by (hash, record)
     // partition: stable radix sort of (bucket id -> occurrence index) on bit_length(B) bits (2-3 passes of 4-byte keys
     // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
-    uint32_t nv = 0;
     uint32_t* bk_in = b_keys.as<uint32_t>();
     uint32_t* bk_sorted = bk_in + n_all;
+    // every launch below takes its sizes from device memory; the host synchronises ONCE, at the end
+    sk->out_k.reserve((size_t)n_all * 8);          // upper bound: distinct k-mers <= occurrences
+    sk->out_c.reserve((size_t)n_all * 4);
     {
-        HostPhase ph(ctx, "finish(bucket): partition sort");
+        HostPhase ph(ctx, "finish(bucket): partition + LDS replay + compact");
         hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(n_all)), dim3(256), 0, ctx->stream, sk->hash.as<uint64_t>(), n_all, bshift,
                            B, bk_in, b_idx.as<uint32_t>());
         sort_pairs_u32_u32(ctx, bk_in, bk_sorted, b_idx.as<uint32_t>(), b_perm.as<uint32_t>(), n_all, 0, bit_length(B));
         hipLaunchKernelGGL(count_valid_bk_kernel, dim3(1), dim3(1), 0, ctx->stream, bk_sorted, n_all, B, d_nv);
-        ctx->read_back(&nv, d_nv, 4);
-    }
-    if (nv == 0) return true;
-    {
-        HostPhase ph(ctx, "finish(bucket): bounds + LDS replay");
-        ScopedKernelTimer t(ctx, "replay");
-        hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)nv + 1)), dim3(256), 0, ctx->stream, bk_sorted, nv, B, boff);
-        hipLaunchKernelGGL(bucket_replay_kernel, dim3(B), dim3(RTPB), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(),
-                           boff, nv, sk->paired, sk->no_dedup,
-                           sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, b_tmpk.as<uint64_t>(),
-                           b_tmpc.as<uint32_t>(), n_distinct, d_removed, d_overflow,
-                           getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0);
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)n_all + 1)), dim3(256), 0, ctx->stream, bk_sorted, d_nv, B,
+                               boff);
+            hipLaunchKernelGGL(bucket_replay_kernel, dim3(B), dim3(RTPB), 0, ctx->stream, sk->recs.as<OccRec>(),
+                               b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup,
+                               sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, b_tmpk.as<uint64_t>(),
+                               b_tmpc.as<uint32_t>(), n_distinct, d_removed, d_overflow,
+                               getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0);
+        }
+        exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
+                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
+                               sk->out_c.as<uint32_t>());
+        }
         SY_HIP(hipGetLastError());
     }
-    exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
     struct { unsigned long long removed; uint32_t overflow, n_seg; } host{};
     SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 12, hipMemcpyDeviceToHost, ctx->stream));
     SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 12, d_off + B, 4, hipMemcpyDeviceToHost, ctx->stream));
     SY_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(&host, ctx->pinned, 16);
     if (!ctx->pending.empty()) profile_collect(ctx);
-    if (host.overflow) return false;             // some bucket did not fit in LDS: the generic path handles it
-    sk->out_k.reserve((size_t)host.n_seg * 8);
-    sk->out_c.reserve((size_t)host.n_seg * 4);
-    if (host.n_seg) {
-        HostPhase ph(ctx, "finish(bucket): compact");
-        ScopedKernelTimer t(ctx, "replay");
-        hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
-                           b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                           sk->out_c.as<uint32_t>());
-        SY_HIP(hipGetLastError());
-    }
+    if (host.overflow) return false;             // some bucket did not fit in LDS: the generic path redoes the sample
     sk->n_out = host.n_seg;
     sk->dup_removed = host.removed;
     return true;

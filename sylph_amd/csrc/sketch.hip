@@ -330,7 +330,8 @@ static uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint
     return n;
 }
 
-static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, int mem) {
+static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, int mem,
+                             const uint64_t* n_bases_hint = nullptr) {
     sylph_ctx* ctx = sk->ctx;
     SY_REQUIRE(!sk->finished, "sylph_sketch_push after finish");
     SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
@@ -358,7 +359,8 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         d_bases = sk->batch_bases.as<uint8_t>();
         d_off = sk->batch_off.as<uint64_t>();
     } else {
-        ctx->read_back(&n_bases, rec_off + n_records, 8);
+        if (n_bases_hint) n_bases = *n_bases_hint;
+        else ctx->read_back(&n_bases, rec_off + n_records, 8);
         SY_REQUIRE(bases || n_bases == 0, "null bases");
         d_bases = bases;
         d_off = rec_off;
@@ -584,6 +586,16 @@ int sylph_sketch_push(sylph_sketch* sk, const uint8_t* bases, const uint64_t* re
     return guarded([&] {
         SY_REQUIRE(sk, "null session");
         sketch_push_impl(sk, bases, rec_off, n_records, mem);
+    });
+}
+
+int sylph_sketch_push_n(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, uint64_t n_bases,
+                        int mem) {
+    return guarded([&] {
+        SY_REQUIRE(sk, "null session");
+        SY_REQUIRE(mem != SYLPH_MEM_HOST || !rec_off || n_records == 0 || rec_off[n_records] == n_bases,
+                   "n_bases does not match rec_off[n_records]");
+        sketch_push_impl(sk, bases, rec_off, n_records, mem, &n_bases);
     });
 }
 

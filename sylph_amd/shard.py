@@ -134,6 +134,22 @@ def exchange_and_profile(contain_fn, group, sample_k, sample_c, owner, rank_geno
     return dict(contain_count=contain_count, cov_off=cov_off, covs=covs)
 
 
+_PIN = {}
+
+
+def gather_counts(group, contain_count, device):
+    """Replicated-database mode: every rank profiled its own sample against the whole index; ONE all-gather makes the
+    per-sample containment counts [world, n_genomes] available on every rank (fixed size, latency-bound)."""
+    n = len(contain_count)
+    key = (n, str(device))
+    if key not in _PIN:
+        _PIN[key] = (torch.empty(n, dtype=torch.int32, pin_memory=torch.cuda.is_available()), torch.empty(n, dtype=torch.int32, device=device))
+    host, dev = _PIN[key]
+    host.numpy()[:] = np.asarray(contain_count).view(np.int32)
+    dev.copy_(host, non_blocking=True)
+    return torch.stack(group.all_gather_fixed(dev))
+
+
 def profile_step(db, group, dk_ptr, dc_ptr, n, mine, n_total, device, _cache={}):
     """bench.py glue: db is a sylph_amd.Database holding this rank's shard; (dk_ptr, dc_ptr, n) the device-resident
     sample table of this rank."""

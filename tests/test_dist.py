@@ -71,6 +71,9 @@ def _worker(rank, world, port, ret):
         for g in range(len(genomes)):
             got = res["covs"][int(res["cov_off"][g]):int(res["cov_off"][g + 1])]
             ok = ok and np.array_equal(got, np.sort(ecov[g]))
+        # replicated mode: one all-gather of the per-sample counts
+        allc = SH.gather_counts(group, ecc, torch.device("cpu"))
+        ok = ok and allc.shape == (world, len(genomes)) and np.array_equal(allc[rank].numpy().view(np.uint32), ecc)
         ret[rank] = bool(ok) and int(ecc.sum()) > 0
     finally:
         dist.destroy_process_group()
