@@ -276,7 +276,7 @@ def main():
 
     # ---- per-kernel timing from HIP events recorded on the launch stream inside the library ----
     seeds_ms, seeds_launches = ctx.kernel_stats("seeds")
-    fam = {f: ctx.kernel_stats(f) for f in ("seeds", "annotate", "sort", "replay", "probe")}
+    fam = {f: ctx.kernel_stats(f) for f in ("seeds", "compact", "annotate", "sort", "replay", "probe")}
     ctx.profile(False)
     step("occ")   # untimed: count the seed occurrences for the roofline's algorithmic bytes
     t_sketch = float(np.mean([r[0] for r in rows]))

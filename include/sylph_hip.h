@@ -63,12 +63,13 @@ int sylph_ctx_synchronize(sylph_ctx *ctx);
 
 /* Tuning / test knobs (not needed for normal use).  "finish" = "auto" (default: bucket partition + in-LDS replay,
  * falling back to the device-wide sort path when a bucket does not fit), "generic" (always the device-wide path) or
- * "bucket" (error instead of falling back). */
+ * "bucket" (error instead of falling back).  "seeds" = "ordered" (default: per-tile slots in position order, falling back
+ * when a tile overflows) or "unordered" (LDS-staged atomics + radix sort by position). */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
 
 /* Per-kernel timing (hipEvent pairs on the ctx stream around every launch of the named kernel family) for
- * bench.py's roofline object.  enable=1 starts collecting and clears the totals. Families: "seeds", "annotate",
- * "sort", "replay", "probe", "db_index". */
+ * bench.py's roofline object.  enable=1 starts collecting and clears the totals. Families: "seeds", "compact",
+ * "annotate", "sort", "replay", "probe", "db_index". */
 int sylph_ctx_profile(sylph_ctx *ctx, int enable);
 int sylph_ctx_kernel_stats(sylph_ctx *ctx, const char *family, double *total_ms, uint64_t *launches);
 

@@ -250,6 +250,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             else if (!strcmp(value, "generic")) ctx->finish_mode = 1;
             else if (!strcmp(value, "bucket")) ctx->finish_mode = 2;
             else SY_REQUIRE(false, "finish must be auto|generic|bucket");
+        } else if (!strcmp(key, "seeds")) {
+            if (!strcmp(value, "ordered")) ctx->seeds_mode = 0;
+            else if (!strcmp(value, "unordered")) ctx->seeds_mode = 1;
+            else SY_REQUIRE(false, "seeds must be ordered|unordered");
         } else {
             SY_REQUIRE(false, "unknown option %s", key);
         }

@@ -177,6 +177,108 @@ __global__ __launch_bounds__(TPB) void seeds_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// K1, ordered flavour (the default).  Same load / pack / hash phases, but survivors are written in ascending position
+// order into a fixed-capacity slot region per tile: lanes count their hits (popcount of the four 16-bit masks), one
+// workgroup exclusive scan gives every lane its offset, and the rare hits are re-hashed and stored at
+// slot[tile * slot_cap + offset].  No atomics, deterministic output, and — because tiles are in position order too — a
+// scan + gather over the tile counts replaces the device-wide radix sort by position that the annotate kernel needs.
+// A tile that overflows its slots (pathological repeats) bumps `overflow`; the host then reruns the batch through the
+// unordered kernel + radix sort.
+template <int K, int HV>
+__global__ __launch_bounds__(TPB) void seeds_slots_kernel(const uint8_t* __restrict__ bases, uint32_t n_bases, uint64_t thr,
+                                                          uint32_t n_tiles, uint32_t slot_cap, uint64_t* __restrict__ slot_hash,
+                                                          uint32_t* __restrict__ slot_pos, uint32_t* __restrict__ tile_count,
+                                                          uint32_t* __restrict__ overflow) {
+    __shared__ __attribute__((aligned(16))) uint32_t sF[TILE_WORDS + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t sR[TILE_WORDS + 8];
+    __shared__ uint32_t s_wave[TPB / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t tile_base = (uint64_t)tile * TILE_BASES;
+#pragma unroll
+        for (int j = 0; j <= WPT; j++) {
+            const uint32_t ci = tid + j * TPB;
+            if (j == WPT && tid >= HALO_WORDS) break;
+            const uint64_t b0 = tile_base + (uint64_t)ci * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b0 < n_bases) v = *reinterpret_cast<const uint4*>(bases + b0);
+            uint32_t F, R;
+            pack16(v, F, R);
+            sF[ci] = F;
+            sR[ci] = R;
+        }
+        __syncthreads();
+        const uint32_t w0 = tid * WPT;
+        const uint4 fa = *reinterpret_cast<const uint4*>(&sF[w0]);
+        const uint2 fb = *reinterpret_cast<const uint2*>(&sF[w0 + 4]);
+        const uint4 ra = *reinterpret_cast<const uint4*>(&sR[w0]);
+        const uint2 rb = *reinterpret_cast<const uint2*>(&sR[w0 + 4]);
+        const uint32_t fw[6] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y};
+        const uint32_t rw[6] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y};
+        const uint32_t p0 = (uint32_t)tile_base + w0 * 16;
+        uint32_t masks[WPT];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < WPT; j++) {
+            masks[j] = 0;
+            if ((uint64_t)p0 + (uint64_t)j * 16 < n_bases)
+                Unroll16<K, 0, HV>::run(fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2], thr, masks[j]);
+            cnt += __popc(masks[j]);
+        }
+        // workgroup exclusive scan of cnt
+        uint32_t x = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();   // also: every lane has finished reading sF/sR of this tile
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; w++) {
+            const uint32_t t = s_wave[w];
+            if ((uint32_t)w < wave) base += t;
+            total += t;
+        }
+        uint32_t o = base + x - cnt;
+        if (cnt) {
+            const uint64_t out0 = (uint64_t)tile * slot_cap;
+#pragma unroll
+            for (int j = 0; j < WPT; j++) {
+                uint32_t m = masks[j];
+                while (m) {   // bit 15-O <-> in-dword offset O: highest bit first = ascending position
+                    const uint32_t b = 31u - (uint32_t)__clz((int)m);
+                    m &= ~(1u << b);
+                    const uint32_t off = 15u - b;
+                    if (o < slot_cap) {
+                        slot_hash[out0 + o] = hash_at_dyn<K>(off, fw[j], fw[j + 1], fw[j + 2], rw[j], rw[j + 1], rw[j + 2]);
+                        slot_pos[out0 + o] = p0 + j * 16 + off;
+                    }
+                    o++;
+                }
+            }
+        }
+        if (tid == 0) {
+            tile_count[tile] = min(total, slot_cap);
+            if (total > slot_cap) atomicAdd(overflow, total - slot_cap);
+        }
+        __syncthreads();   // s_wave is rewritten by the next tile
+    }
+}
+
+// out[tile_off[t] + i] = slot[t * slot_cap + i]: the survivors of the whole batch in ascending position order
+__global__ __launch_bounds__(64) void compact_slots_kernel(const uint64_t* __restrict__ slot_hash, const uint32_t* __restrict__ slot_pos,
+                                                           const uint32_t* __restrict__ tile_count,
+                                                           const uint32_t* __restrict__ tile_off, uint32_t n_tiles, uint32_t slot_cap,
+                                                           uint32_t* __restrict__ out_pos, uint64_t* __restrict__ out_hash) {
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t n = tile_count[t], d = tile_off[t];
+        const uint64_t s = (uint64_t)t * slot_cap;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_pos[d + i] = slot_pos[s + i]; out_hash[d + i] = slot_hash[s + i]; }
+    }
+}
+
 }  // namespace
 
 // Launch K1 on ctx->stream.  d_count must be zeroed by the caller.  Returns nothing; caller reads *d_count.
@@ -197,6 +299,41 @@ void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint
     else if (k == 21) { if (hv) SY_LAUNCH_SEEDS(21, 1); else SY_LAUNCH_SEEDS(21, 0); }
     else throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
 #undef SY_LAUNCH_SEEDS
+    SY_HIP(hipGetLastError());
+}
+
+
+// Ordered K1: fills scratch slots + tile counts; the caller scans tile_count and calls launch_compact_slots.
+uint32_t seeds_slot_capacity(uint32_t c) {
+    const uint64_t expect = (uint64_t)TILE_BASES / c;
+    return (uint32_t)std::min<uint64_t>(TILE_BASES, expect + expect * 3 / 4 + 48);
+}
+uint32_t seeds_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + TILE_BASES - 1) / TILE_BASES); }
+
+void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint32_t slot_cap,
+                        uint64_t* d_slot_hash, uint32_t* d_slot_pos, uint32_t* d_tile_count, uint32_t* d_overflow) {
+    const uint64_t thr = UINT64_MAX / (uint64_t)c;
+    const uint32_t n_tiles = seeds_n_tiles(n_bases);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);
+    static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
+    ScopedKernelTimer t(ctx, "seeds");
+#define SY_LAUNCH_SLOTS(KK, HH)                                                                                              \
+    hipLaunchKernelGGL((seeds_slots_kernel<KK, HH>), dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles, \
+                       slot_cap, d_slot_hash, d_slot_pos, d_tile_count, d_overflow)
+    if (k == 31) { if (hv) SY_LAUNCH_SLOTS(31, 1); else SY_LAUNCH_SLOTS(31, 0); }
+    else if (k == 21) { if (hv) SY_LAUNCH_SLOTS(21, 1); else SY_LAUNCH_SLOTS(21, 0); }
+    else throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
+#undef SY_LAUNCH_SLOTS
+    SY_HIP(hipGetLastError());
+}
+
+void launch_compact_slots(sylph_ctx* ctx, const uint64_t* d_slot_hash, const uint32_t* d_slot_pos, const uint32_t* d_tile_count,
+                          const uint32_t* d_tile_off, uint32_t n_tiles, uint32_t slot_cap, uint32_t* d_out_pos, uint64_t* d_out_hash) {
+    ScopedKernelTimer t(ctx, "compact");
+    hipLaunchKernelGGL(compact_slots_kernel, dim3(std::min<uint32_t>(n_tiles, 1u << 16)), dim3(64), 0, ctx->stream, d_slot_hash,
+                       d_slot_pos, d_tile_count, d_tile_off, n_tiles, slot_cap, d_out_pos, d_out_hash);
     SY_HIP(hipGetLastError());
 }
 

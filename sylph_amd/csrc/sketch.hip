@@ -26,6 +26,12 @@ bool finish_bucketed(sylph_sketch* sk);   // replay_lds.hip
 
 void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint64_t* d_out_hash,
                   uint32_t* d_out_pos, uint32_t out_cap, uint32_t* d_count);
+uint32_t seeds_slot_capacity(uint32_t c);
+uint32_t seeds_n_tiles(uint64_t n_bases);
+void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint32_t slot_cap,
+                        uint64_t* d_slot_hash, uint32_t* d_slot_pos, uint32_t* d_tile_count, uint32_t* d_overflow);
+void launch_compact_slots(sylph_ctx* ctx, const uint64_t* d_slot_hash, const uint32_t* d_slot_pos, const uint32_t* d_tile_count,
+                          const uint32_t* d_tile_off, uint32_t n_tiles, uint32_t slot_cap, uint32_t* d_out_pos, uint64_t* d_out_hash);
 
 namespace {
 
@@ -302,6 +308,38 @@ static uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint
                                     uint32_t* d_count) {
     SY_REQUIRE(n_bases < (1ull << 32), "a batch may hold at most 2^32-1 bases (got %llu)", (unsigned long long)n_bases);
     if (n_bases == 0) return 0;
+    if (ctx->seeds_mode != 1) {
+        // ordered K1: per-tile slots in position order, then scan + gather (no radix sort, no atomics)
+        HostPhase ph(ctx, "push: seeds (ordered slots)");
+        const uint32_t n_tiles = seeds_n_tiles(n_bases), slot_cap = seeds_slot_capacity(c);
+        DevBuf &b_sh = ctx->scratch[0], &b_sp = ctx->scratch[1], &b_tc = ctx->scratch[4];
+        b_sh.reserve((size_t)n_tiles * slot_cap * 8);
+        b_sp.reserve((size_t)n_tiles * slot_cap * 4);
+        b_tc.reserve(((size_t)n_tiles + 1) * 4 * 2 + 16);
+        uint32_t* tile_count = b_tc.as<uint32_t>();
+        uint32_t* tile_off = tile_count + (n_tiles + 1);
+        uint32_t* d_overflow = tile_off + (n_tiles + 1);
+        SY_HIP(hipMemsetAsync(tile_count + n_tiles, 0, 4, ctx->stream));   // scan sentinel
+        SY_HIP(hipMemsetAsync(d_overflow, 0, 4, ctx->stream));
+        launch_seeds_slots(ctx, d_bases, (uint32_t)n_bases, c, k, slot_cap, b_sh.as<uint64_t>(), b_sp.as<uint32_t>(), tile_count,
+                           d_overflow);
+        exclusive_sum_u32(ctx, tile_count, tile_off, (size_t)n_tiles + 1);
+        uint32_t res[2] = {0, 0};   // total survivors, overflowed survivors
+        SY_HIP(hipMemcpyAsync(ctx->pinned, tile_off + n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 4, d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(res, ctx->pinned, 8);
+        if (!ctx->pending.empty()) profile_collect(ctx);
+        if (res[1] == 0) {
+            if (res[0] == 0) return 0;
+            ctx->scratch[2].reserve((size_t)res[0] * 4);
+            ctx->scratch[3].reserve((size_t)res[0] * 8);
+            launch_compact_slots(ctx, b_sh.as<uint64_t>(), b_sp.as<uint32_t>(), tile_count, tile_off, n_tiles, slot_cap,
+                                 ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>());
+            return res[0];
+        }
+        // some tile held more survivors than its slots (extreme repeats): redo the batch with the unordered kernel
+    }
     uint64_t cap = n_bases / c + n_bases / (4ull * c) + 65536;
     if (cap > n_bases) cap = n_bases;
     uint32_t n = 0;

@@ -102,12 +102,14 @@ FINISH_MODES = ("auto", "generic")   # bucket + in-LDS replay (with its fallback
 def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_AVX2_COMPAT, c=200, k=31, batches=1):
     """Sketches with BOTH finish paths and insists that they agree before returning the result."""
     res = []
-    for mode in FINISH_MODES:
+    for mode, seeds in (("auto", "ordered"), ("generic", "unordered")):   # both finish paths x both K1 output flavours
         ctx.set_option("finish", mode)
+        ctx.set_option("seeds", seeds)
         try:
             res.append(_sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches))
         finally:
             ctx.set_option("finish", "auto")
+            ctx.set_option("seeds", "ordered")
     assert np.array_equal(res[0]["kmers"], res[1]["kmers"]) and np.array_equal(res[0]["counts"], res[1]["counts"])
     assert res[0]["dup_removed"] == res[1]["dup_removed"]
     return res[0]
@@ -267,6 +269,40 @@ def test_bucket_path_is_really_used(ctx):
         ctx.set_option("finish", "auto")
     assert_same_sketch(_sketch_gpu_once(ctx, deep[0], deep[1], False, False, S.SEED_AVX2_COMPAT, 3, 31, 1),
                        O.sketch_reads(deep[0], deep[1], c=3))
+
+
+def test_tandem_repeats_overflow_the_tile_slots(ctx):
+    """A short-period tandem repeat whose k-mer passes the threshold yields thousands of survivors per 16 KiB tile: the
+    ordered K1 must detect the slot overflow and fall back, the unordered K1 must spill past its LDS stage."""
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        unit = random_seq(rng, 13)
+        rep = np.tile(unit, 6000)[:70000]
+        if len(O.extract_markers(rep[:200], c=200)) > 0:
+            break
+    else:
+        pytest.skip("no passing repeat unit found")
+    recs = [rep, random_seq(rng, 5000), rep[:30000], rep[7:20000]]
+    b, off = concat(recs)
+    e = O.sketch_reads(b, off, c=200)
+    assert e["counts"].max() > 1000
+    assert_same_sketch(sketch_gpu(ctx, b, off, c=200), e)
+    g = ctx.sketch_genome(b, off, c=200)
+    eg = O.sketch_genome(b, off, c=200)
+    assert np.array_equal(g["genome_kmers"], eg["genome_kmers"]) and np.array_equal(g["tracked"], eg["tracked"])
+
+
+def test_read_sketch_k21(ctx):
+    rng = np.random.default_rng(21)
+    genome = random_seq(rng, 40000)
+    for paired in (False, True):
+        b, off = concat(make_reads(rng, genome, 2500, 120, paired=paired, dup_frac=0.2, insert=260))
+        for gm, om in MODES:
+            e = O.sketch_reads(b, off, c=30, k=21, mode=om, paired=paired)
+            assert_same_sketch(sketch_gpu(ctx, b, off, c=30, k=21, paired=paired, seed_mode=gm), e)
+    g = ctx.sketch_genome(genome, np.array([0, len(genome)], dtype=np.uint64), c=30, k=21)
+    e = O.sketch_genome(genome, np.array([0, len(genome)], dtype=np.uint64), c=30, k=21)
+    assert np.array_equal(g["genome_kmers"], e["genome_kmers"]) and np.array_equal(g["tracked"], e["tracked"])
 
 
 def test_read_sketch_empty(ctx):
