@@ -55,6 +55,7 @@ __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const uint64_t* __rest
                                                           uint32_t n_buckets, const uint32_t* __restrict__ glen,
                                                           double min_number_kmers, uint64_t* __restrict__ hits,
                                                           uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
+
     __shared__ uint64_t stage[PROBE_STAGE];
     __shared__ uint32_t s_cnt, s_base;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(
                     const uint32_t r = rank[g];
                     if (r == 0xFFFFFFFFu) continue;                          // not in remaining_genomes
                     if (r != best_rank) { atomicAdd(&lost[g], 1u); continue; }   // contain.rs:639-642
-                    const uint64_t hit = ((uint64_t)g << 32) | cnt;
+                        const uint64_t hit = ((uint64_t)g << 32) | cnt;
                     const uint32_t slot = atomicAdd(&s_cnt, 1u);
                     if (slot < PROBE_STAGE) stage[slot] = hit;
                     else {
@@ -197,6 +198,45 @@ __global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __rest
     if (g < n_genomes) contain_count[g] = lower(((uint64_t)g + 1) << 32) - a;
 }
 
+// largest count of the sample table (an upper bound of every hit's count): 256 workgroups, one atomic each
+__global__ __launch_bounds__(256) void max_count_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, counts[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    __shared__ uint32_t s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(s[0], s[1]), max(s[2], s[3])));
+}
+
+// Compact hit keys: (genome << 32 | count) -> 32-bit (genome << cb | count) with cb = bit_length(max count), whenever
+// bit_length(G) + cb <= 32 (always at GTDB scale unless a count exceeds 2^15): the radix sort of the hit list then moves
+// 4-byte keys through 3-4 passes instead of 8-byte keys through 8.  Otherwise the 64-bit keys are sorted as they are.
+__global__ __launch_bounds__(256) void pack_hits32_kernel(const uint64_t* __restrict__ hits, uint32_t n, int cb, uint32_t* __restrict__ k32) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint64_t h = hits[i]; k32[i] = ((uint32_t)(h >> 32) << cb) | (uint32_t)h; }
+}
+__global__ __launch_bounds__(256) void narrow32_kernel(const uint32_t* __restrict__ k32, uint32_t n, int cb, uint32_t* __restrict__ covs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) covs[i] = k32[i] & ((1u << cb) - 1u);
+}
+__global__ __launch_bounds__(256) void hit_offsets32_kernel(const uint32_t* __restrict__ k32, uint32_t n_hits, uint32_t n_genomes, int cb,
+                                                            uint64_t* __restrict__ cov_off, uint32_t* __restrict__ contain_count) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_genomes) return;
+    auto lower = [&](uint64_t key) {   // first hit whose (genome << cb | count) >= key
+        uint32_t lo = 0, hi = n_hits;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)k32[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t a = lower((uint64_t)g << cb);
+    cov_off[g] = a;
+    if (g < n_genomes) contain_count[g] = lower(((uint64_t)g + 1) << cb) - a;
+}
 __global__ __launch_bounds__(256) void narrow_kernel(const uint64_t* __restrict__ hits, uint32_t n, uint32_t* __restrict__ covs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) covs[i] = (uint32_t)hits[i];
@@ -345,7 +385,7 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
     SY_REQUIRE(n < (1ull << 32), "sample table larger than 2^32-1 entries");
     sylph_ctx* ctx = db->ctx;
     const uint64_t G = db->n_genomes;
-    uint32_t n_hits = 0;
+    uint32_t n_hits = 0, max_count = 0;
     if (re) {   // rank[g] = position of genome g in the passing list (or ~0), ani[rank], lost[g] = 0
         SY_REQUIRE(re->n_passing == 0 || (re->passing_gids && re->passing_ani), "null passing list");
         std::vector<uint32_t> rank(std::max<uint64_t>(1, G), 0xFFFFFFFFu);
@@ -374,7 +414,9 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             d_c = db->q_counts.as<uint32_t>();
         }
         uint64_t cap = std::max<uint64_t>(n * 2, 1u << 20);
-        uint32_t* d_cnt = db->counter.as<uint32_t>();
+        uint32_t* d_cnt = db->counter.as<uint32_t>();   // [0] = number of hits, [1] = largest sample count
+        SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(max_count_kernel, dim3(256), dim3(256), 0, ctx->stream, d_c, (uint32_t)n, d_cnt + 1);
         for (int attempt = 0; attempt < 2; attempt++) {
             SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one sample");
             db->hits.reserve(cap * 8);
@@ -397,7 +439,10 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
                 }
                 SY_HIP(hipGetLastError());
             }
-            ctx->read_back(&n_hits, d_cnt, 4);
+            uint32_t hc[2] = {0, 0};
+            ctx->read_back(hc, d_cnt, 8);
+            n_hits = hc[0];
+            max_count = hc[1];
             if (n_hits <= cap) break;
             SY_REQUIRE(attempt == 0, "hit buffer overflow persisted");
             cap = n_hits;
@@ -405,17 +450,31 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
     }
     db->cov_off.reserve((G + 1) * 8);
     db->ccount.reserve(std::max<uint64_t>(1, G) * 4);
-    const uint64_t* d_sorted = nullptr;
-    if (n_hits) {
-        db->hits_sorted.reserve((size_t)n_hits * 8);
-        db->covs.reserve((size_t)n_hits * 4);
-        sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
-        d_sorted = db->hits_sorted.as<uint64_t>();
-        hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
+    db->covs.reserve(std::max<size_t>(1, n_hits) * 4);
+    const int cb = std::max(1, bit_length(max_count)), gb = std::max(1, bit_length(G));
+    if (n_hits && cb + gb <= 32) {
+        db->hits_sorted.reserve((size_t)n_hits * 8);   // two u32 arrays: packed keys, sorted keys
+        uint32_t* k32 = db->hits_sorted.as<uint32_t>();
+        uint32_t* k32s = k32 + n_hits;
+        hipLaunchKernelGGL(pack_hits32_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, db->hits.as<uint64_t>(), n_hits, cb,
+                           k32);
+        sort_keys_u32(ctx, k32, k32s, n_hits, 0, cb + gb);
+        hipLaunchKernelGGL(narrow32_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb,
                            db->covs.as<uint32_t>());
+        hipLaunchKernelGGL(hit_offsets32_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, k32s, n_hits, (uint32_t)G, cb,
+                           db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
+    } else {
+        const uint64_t* d_sorted = nullptr;
+        if (n_hits) {
+            db->hits_sorted.reserve((size_t)n_hits * 8);
+            sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
+            d_sorted = db->hits_sorted.as<uint64_t>();
+            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
+                               db->covs.as<uint32_t>());
+        }
+        hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits, (uint32_t)G,
+                           db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
     }
-    hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
-                       (uint32_t)G, db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
     SY_HIP(hipGetLastError());
     // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
     const size_t need = (G + 1) * 8 + G * 4 + (size_t)n_hits * 4 + (re ? G * 4 : 0) + 64;

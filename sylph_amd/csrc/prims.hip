@@ -46,6 +46,14 @@ void sort_pairs_u32_u32(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, con
     });
 }
 
+void sort_keys_u32(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, size_t n, int begin_bit, int end_bit) {
+    if (n == 0) return;
+    ScopedKernelTimer t(ctx, "sort");
+    with_temp(ctx, [&](void* tmp, size_t& bytes) {
+        return rocprim::radix_sort_keys(tmp, bytes, kin, kout, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream);
+    });
+}
+
 void sort_keys_u64(sylph_ctx* ctx, const uint64_t* kin, uint64_t* kout, size_t n, int begin_bit, int end_bit) {
     if (n == 0) return;
     ScopedKernelTimer t(ctx, "sort");
