@@ -57,34 +57,42 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode="shard"):
     # sequence-backed genomes: community + unrelated + 10 % mutated copies (97 % identity) of the first ones
     n_mut = n_seq // 10
     community = synth.random_genomes(n_comm, glen, device, seed, mutated_frac=0.0)
-    sketches = []
-    off1 = np.array([0, glen], dtype=np.uint64)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed + 17)
-    # One pinned host buffer for every genome: a pageable .cpu() copy makes the HIP runtime register the destination
-    # pages; when numpy later unmaps them the driver evicts this process's GPU queues (15-40 ms stalls at random
-    # points of the timed region).
-    host_seq = torch.empty(glen, dtype=torch.uint8, pin_memory=True)
-    for g in range(n_seq):
-        if g < n_comm:
-            seq = community[g]
-        elif g >= n_seq - n_mut:
-            src = community[(g - (n_seq - n_mut)) % n_comm]
-            mask = torch.rand(glen, generator=gen, device=device) < 0.03
-            sub = torch.tensor([67, 71, 84, 65], dtype=torch.uint8, device=device)   # A->C, C->G, G->T, T->A
-            lut = torch.zeros(256, dtype=torch.uint8, device=device)
-            lut[torch.tensor([65, 67, 71, 84], device=device)] = sub
-            seq = torch.where(mask, lut[src.long()], src)
-        else:
-            seq = synth.random_genomes(1, glen, device, seed + 1000 + g, mutated_frac=0.0)[0]
-        host_seq.copy_(seq)
-        torch.cuda.current_stream().synchronize()
-        sk = ctx.sketch_genome(host_seq.numpy(), off1, c=c, k=k)
-        sketches.append(sk["genome_kmers"])
+    sub = torch.tensor([67, 71, 84, 65], dtype=torch.uint8, device=device)   # A->C, C->G, G->T, T->A
+    lut = torch.zeros(256, dtype=torch.uint8, device=device)
+    lut[torch.tensor([65, 67, 71, 84], device=device)] = sub
+    # Database build: genomes are generated on the device in batches of <= 1 Gbp and sketched by ONE
+    # sylph_sketch_genomes call per batch (seeding + genome-wide duplicate removal + spacing filter on the device; only the
+    # sketches come back to the host).  Timed separately from generation: db_build_gbp_per_s.
+    per_batch = max(1, min(n_seq, (1 << 30) // glen))
+    sk_parts, sk_lens, t_sketch = [], [], 0.0
+    for g0 in range(0, n_seq, per_batch):
+        g1 = min(n_seq, g0 + per_batch)
+        batch = torch.empty((g1 - g0, glen), dtype=torch.uint8, device=device)
+        for g in range(g0, g1):
+            if g < n_comm:
+                seq = community[g]
+            elif g >= n_seq - n_mut:
+                src = community[(g - (n_seq - n_mut)) % n_comm]
+                mask = torch.rand(glen, generator=gen, device=device) < 0.03
+                seq = torch.where(mask, lut[src.long()], src)
+            else:
+                seq = synth.random_genomes(1, glen, device, seed + 1000 + g, mutated_frac=0.0)[0]
+            batch[g - g0].copy_(seq)
+        torch.cuda.synchronize()
+        coff = np.arange(g1 - g0 + 1, dtype=np.uint64) * np.uint64(glen)     # one contig per genome
+        goff_b = np.arange(g1 - g0 + 1, dtype=np.uint64)
+        ts = time.perf_counter()
+        km, koff, _, _ = ctx.sketch_genomes(None, coff, goff_b, c=c, k=k, device_ptr=batch.data_ptr())
+        t_sketch += time.perf_counter() - ts
+        sk_parts.append(km)
+        sk_lens.append(np.diff(koff.astype(np.int64)))
+        del batch
     t1 = time.time()
-    seq_k = np.concatenate(sketches)
+    seq_k = np.concatenate(sk_parts) if sk_parts else np.zeros(0, dtype=np.uint64)
     seq_off = np.zeros(n_seq + 1, dtype=np.int64)
-    seq_off[1:] = np.cumsum([len(s) for s in sketches])
+    seq_off[1:] = np.cumsum(np.concatenate(sk_lens)) if sk_lens else 0
     n_decoy = n_total - n_seq
     if n_decoy > 0:
         dk, doff = synth.decoy_sketches(n_decoy, c=c, device=device, seed=seed + 7)
@@ -112,7 +120,9 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode="shard"):
     ctx.synchronize()
     t3 = time.time()
     stats = dict(n_genomes=int(n_total), shard_genomes=int(len(mine)), shard_kmers=int(db.n_kmers),
-                 seq_backed_sketch_s=round(t1 - t0, 2), generate_s=round(t2 - t1, 2), db_upload_index_s=round(t3 - t2, 2))
+                 seq_backed_generate_and_sketch_s=round(t1 - t0, 2), seq_backed_sketch_s=round(t_sketch, 4),
+                 db_build_gbp_per_s=round(n_seq * glen / 1e9 / max(t_sketch, 1e-9), 2), db_build_genomes=int(n_seq),
+                 generate_s=round(t2 - t1, 2), db_upload_index_s=round(t3 - t2, 2))
     lens_mine = lens[mine]
     # NB: no torch.cuda.empty_cache() here — returning tens of GB to the driver (hipFree) queues page-table work
     # that stalls this process's GPU queues for 15-40 ms at random moments over the next few hundred ms.

@@ -99,6 +99,19 @@ int sylph_sketch_genome(sylph_ctx *ctx, const uint8_t *bases, const uint64_t *co
                         uint64_t **out_genome_kmers, uint64_t *out_n, uint64_t **out_tracked,
                         uint64_t *out_n_tracked);
 
+/* The same for a BATCH of genomes in one call (a database build: sketch.rs:422-476 loops sketch_genome or
+ * sketch_genome_individual :481-548 over files; §8f-3).  The contigs of all genomes are concatenated; genome g owns
+ * contigs [genome_contig_off[g], genome_contig_off[g+1]) (for --individual-records: one contig per genome).  Duplicate
+ * removal and spacing are per genome, exactly as above, and run on the device.  `mem` says where `bases` lives; the
+ * offset arrays are host memory.  Outputs: genome g's genome_kmers = (*out_kmers)[kmer_off[g] .. kmer_off[g+1]) and
+ * its tracked k-mers likewise through out_tracked/tracked_off (both NULL, or both non-NULL; filled only when
+ * pseudotax != 0).  kmer_off/tracked_off are caller arrays of n_genomes + 1 entries; *out_kmers and *out_tracked are
+ * released with sylph_free().  One batch holds at most 2^32-1 bases. */
+int sylph_sketch_genomes(sylph_ctx *ctx, const uint8_t *bases, const uint64_t *contig_off, uint64_t n_contigs,
+                         const uint64_t *genome_contig_off, uint64_t n_genomes, uint32_t c, uint32_t k, int seed_mode,
+                         uint64_t min_spacing, int pseudotax, int mem, uint64_t **out_kmers, uint64_t *kmer_off,
+                         uint64_t **out_tracked, uint64_t *tracked_off);
+
 /* ---- read sketching (one session = one sample) --------------------------------------------------------- */
 
 /* Replaces sketch_sequences_needle (sketch.rs:897-959) / sketch_pair_sequences (sketch.rs:771-895) after record

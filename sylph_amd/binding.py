@@ -24,7 +24,7 @@ def lib_path():
 
 EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_ctx_create", "sylph_ctx_destroy",
            "sylph_ctx_synchronize", "sylph_ctx_set_option", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
-           "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_begin", "sylph_sketch_push", "sylph_sketch_push_n",
+           "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_genomes", "sylph_sketch_begin", "sylph_sketch_push", "sylph_sketch_push_n",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
            "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy"]
 
@@ -54,6 +54,7 @@ def load():
     L.sylph_seeds.argtypes = [vp, vp, u64, u32, u32, i32, P(vp), P(u64)]
     L.sylph_seeds_positions.argtypes = [vp, vp, vp, u64, u32, u32, i32, P(vp), P(vp), P(vp), P(u64)]
     L.sylph_sketch_genome.argtypes = [vp, vp, vp, u64, u32, u32, i32, u64, i32, P(vp), P(u64), P(vp), P(u64)]
+    L.sylph_sketch_genomes.argtypes = [vp, vp, vp, u64, vp, u64, u32, u32, i32, u64, i32, i32, P(vp), vp, P(vp), vp]
     L.sylph_sketch_begin.argtypes = [vp, u32, u32, i32, i32, i32, P(vp)]
     L.sylph_sketch_push.argtypes = [vp, vp, vp, u64, i32]
     L.sylph_sketch_push_n.argtypes = [vp, vp, vp, u64, u64, i32]
@@ -160,6 +161,24 @@ class Context:
                                           min_spacing, int(pseudotax), C.byref(ok), C.byref(n), C.byref(ot), C.byref(nt)))
         return dict(genome_kmers=_take(ok, n.value, np.uint64), tracked=_take(ot, nt.value, np.uint64),
                     gn_size=int(off[-1]) if len(off) else 0)
+
+
+    # a batch of genomes (database build, sketch.rs:422-476): dup removal + spacing on the device
+    def sketch_genomes(self, bases, contig_off, genome_contig_off, c=200, k=31, seed_mode=SEED_AVX2_COMPAT, min_spacing=30,
+                       pseudotax=True, device_ptr=None):
+        """-> (kmers, kmer_off, tracked, tracked_off).  `bases` is a host array, or pass device_ptr (int) with bases=None."""
+        off, goff = _np(contig_off, np.uint64), _np(genome_contig_off, np.uint64)
+        G = len(goff) - 1
+        koff, toff = np.zeros(G + 1, dtype=np.uint64), np.zeros(G + 1, dtype=np.uint64)
+        ok, ot = C.c_void_p(), C.c_void_p()
+        if device_ptr is None:
+            a = _bases(bases)
+            ptr, mem = (_ptr(a) if len(a) else None), MEM_HOST
+        else:
+            ptr, mem = C.c_void_p(int(device_ptr)), MEM_DEVICE
+        _check(load().sylph_sketch_genomes(self._h, ptr, _ptr(off), len(off) - 1, _ptr(goff), G, c, k, seed_mode, min_spacing,
+                                           int(pseudotax), mem, C.byref(ok), _ptr(koff), C.byref(ot), _ptr(toff)))
+        return _take(ok, int(koff[-1]), np.uint64), koff, _take(ot, int(toff[-1]), np.uint64), toff
 
 
 class ReadSketcher:

@@ -304,7 +304,7 @@ namespace sylph {
 static uint32_t grid_for(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
 
 // Runs K1 with capacity retry; returns survivors sorted by flat position in (ctx->scratch[2] = pos, [3] = hash).
-static uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uint32_t c, uint32_t k,
+uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uint32_t c, uint32_t k,
                                     uint32_t* d_count) {
     SY_REQUIRE(n_bases < (1ull << 32), "a batch may hold at most 2^32-1 bases (got %llu)", (unsigned long long)n_bases);
     if (n_bases == 0) return 0;
@@ -727,39 +727,6 @@ int sylph_seeds(sylph_ctx* ctx, const uint8_t* bases, uint64_t len, uint32_t c, 
         }
         *out_hashes = to_malloc(res);
         *out_n = res.size();
-    });
-}
-
-// sketch_genome, sketch.rs:550-622.  Seeds + validation + (contig,pos) ordering run on the GPU; the genome-wide
-// duplicate removal (:594-605) and the greedy spacing scan (:602-614) — a strictly sequential recurrence over
-// ~L/c seeds — run here on the host for single-genome calls.
-int sylph_sketch_genome(sylph_ctx* ctx, const uint8_t* bases, const uint64_t* contig_off, uint64_t n_contigs, uint32_t c,
-                        uint32_t k, int seed_mode, uint64_t min_spacing, int pseudotax, uint64_t** out_genome_kmers,
-                        uint64_t* out_n, uint64_t** out_tracked, uint64_t* out_n_tracked) {
-    return guarded([&] {
-        SY_REQUIRE(ctx && out_genome_kmers && out_n, "null argument");
-        ContigSeeds s;
-        seeds_positions_impl(ctx, bases, contig_off, n_contigs, c, k, seed_mode, s);
-        const size_t n = s.hash.size();
-        std::unordered_map<uint64_t, uint32_t> seen;
-        seen.reserve(n * 2);
-        for (size_t i = 0; i < n; i++) seen[s.hash[i]]++;
-        std::vector<uint64_t> kept, tracked;
-        uint64_t last_pos = 0, last_contig = 0;
-        for (size_t i = 0; i < n; i++) {
-            if (seen[s.hash[i]] > 1) continue;                                          // :605
-            if (last_pos == 0 || last_contig != s.contig[i] || s.pos[i] - last_pos > min_spacing) {   // :606
-                kept.push_back(s.hash[i]);
-                last_contig = s.contig[i];
-                last_pos = s.pos[i];
-            } else if (pseudotax) {
-                tracked.push_back(s.hash[i]);                                           // :610-611
-            }
-        }
-        *out_genome_kmers = to_malloc(kept);
-        *out_n = kept.size();
-        if (out_tracked) *out_tracked = to_malloc(tracked);
-        if (out_n_tracked) *out_n_tracked = tracked.size();
     });
 }
 

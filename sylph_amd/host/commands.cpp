@@ -160,64 +160,97 @@ std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::strin
     return out;
 }
 
-static GenomeSketch genome_from_contigs(Engine& e, const std::vector<uint8_t>& bases, const std::vector<uint64_t>& off, uint64_t c,
-                                        uint64_t k, uint64_t min_spacing, bool pseudotax) {
-    GenomeSketch g;
-    uint64_t *gk = nullptr, *tr = nullptr, n = 0, nt = 0;
-    hip_check(sylph_sketch_genome(e.ctx, bases.data(), off.data(), off.size() - 1, (uint32_t)c, (uint32_t)k,
-                                  SYLPH_SEED_AVX2_COMPAT, min_spacing, pseudotax ? 1 : 0, &gk, &n, &tr, &nt),
-              "sylph_sketch_genome");
-    g.genome_kmers = take(gk, n);
-    auto t = take(tr, nt);
-    if (pseudotax) g.pseudotax_tracked_nonused_kmers = std::move(t);
-    g.c = c; g.k = k; g.min_spacing = min_spacing;
-    return g;
-}
+// A batch of parsed genomes sketched by ONE sylph_sketch_genomes call (seeding, genome-wide duplicate removal and the spacing
+// filter all run on the device; sketch.rs:550-622 / :481-548 per genome).  Files are parsed on the host and appended until
+// the batch holds BATCH_BASES; results are split back into GenomeSketch records in input order.
+namespace {
+struct GenomeBatch {
+    static constexpr uint64_t BATCH_BASES = 1ull << 30;
+    Engine& e;
+    uint64_t c, k, min_spacing;
+    bool pseudotax;
+    std::vector<GenomeSketch>& out;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off{0}, goff{0};
+    std::vector<GenomeSketch> pending;   // names + gn_size of the genomes in the batch
+    GenomeBatch(Engine& en, uint64_t c_, uint64_t k_, uint64_t sp, bool pt, std::vector<GenomeSketch>& o)
+        : e(en), c(c_), k(k_), min_spacing(sp), pseudotax(pt), out(o) {}
+
+    // sketch_genome (individual = false) or sketch_genome_individual (true) up to the k-mer work; false = file skipped
+    bool add_file(const std::string& ref_file, bool individual) {
+        std::unique_ptr<FastxReader> reader;
+        try { reader.reset(new FastxReader(ref_file)); }
+        catch (const Error&) { warn(ref_file + " is not a valid fasta/fastq file; skipping."); return false; }
+        const size_t bases0 = bases.size(), off0 = off.size(), goff0 = goff.size(), pend0 = pending.size();
+        FastxRecord rec;
+        GenomeSketch whole;
+        bool first = true;
+        try {
+            while (reader->next(rec)) {
+                if (first) { whole.first_contig_name = rec.id; first = false; }
+                bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
+                off.push_back(bases.size());
+                if (individual) {
+                    GenomeSketch g;
+                    g.file_name = ref_file; g.first_contig_name = rec.id; g.gn_size = rec.seq.size();
+                    pending.push_back(std::move(g));
+                    goff.push_back(off.size() - 1);
+                }
+            }
+        } catch (const Error&) {                                             // :586-589: the whole file is dropped
+            warn("File " + ref_file + " is not a valid fasta/fastq file");
+            bases.resize(bases0); off.resize(off0); goff.resize(goff0); pending.resize(pend0);
+            return false;
+        }
+        if (!individual) {
+            whole.file_name = ref_file;
+            whole.gn_size = bases.size() - bases0;
+            pending.push_back(std::move(whole));
+            goff.push_back(off.size() - 1);
+        }
+        if (bases.size() >= BATCH_BASES) flush();
+        return true;
+    }
+
+    void flush() {
+        if (pending.empty()) return;
+        const uint64_t G = pending.size();
+        std::vector<uint64_t> koff(G + 1), toff(G + 1);
+        uint64_t *gk = nullptr, *tr = nullptr;
+        hip_check(sylph_sketch_genomes(e.ctx, bases.data(), off.data(), off.size() - 1, goff.data(), G, (uint32_t)c, (uint32_t)k,
+                                       SYLPH_SEED_AVX2_COMPAT, min_spacing, pseudotax ? 1 : 0, SYLPH_MEM_HOST, &gk, koff.data(), &tr,
+                                       toff.data()),
+                  "sylph_sketch_genomes");
+        struct Free { uint64_t* p; ~Free() { sylph_free(p); } } f1{gk}, f2{tr};
+        for (uint64_t g = 0; g < G; g++) {
+            GenomeSketch& s = pending[g];
+            s.genome_kmers.assign(gk + koff[g], gk + koff[g + 1]);
+            if (pseudotax) s.pseudotax_tracked_nonused_kmers = std::vector<uint64_t>(tr + toff[g], tr + toff[g + 1]);
+            s.c = c; s.k = k; s.min_spacing = min_spacing;
+            out.push_back(std::move(s));
+        }
+        pending.clear(); bases.clear(); off.assign(1, 0); goff.assign(1, 0);
+    }
+};
+}  // namespace
 
 // sketch.rs:550-622
 std::optional<GenomeSketch> sketch_genome(Engine& e, uint64_t c, uint64_t k, const std::string& ref_file, uint64_t min_spacing,
                                           bool pseudotax) {
-    std::unique_ptr<FastxReader> reader;
-    try { reader.reset(new FastxReader(ref_file)); }
-    catch (const Error&) { warn(ref_file + " is not a valid fasta/fastq file; skipping."); return std::nullopt; }
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> off{0};
-    std::string first_name;
-    bool first = true;
-    FastxRecord rec;
-    try {
-        while (reader->next(rec)) {
-            if (first) { first_name = rec.id; first = false; }
-            bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
-            off.push_back(bases.size());
-        }
-    } catch (const Error&) { warn("File " + ref_file + " is not a valid fasta/fastq file"); return std::nullopt; }   // :586-589
-    GenomeSketch g = genome_from_contigs(e, bases, off, c, k, min_spacing, pseudotax);
-    g.file_name = ref_file;
-    g.first_contig_name = first_name;
-    g.gn_size = bases.size();
-    return g;
+    std::vector<GenomeSketch> out;
+    GenomeBatch b(e, c, k, min_spacing, pseudotax, out);
+    if (!b.add_file(ref_file, false)) return std::nullopt;
+    b.flush();
+    return std::move(out.front());
 }
 
 // sketch.rs:481-548
 std::vector<GenomeSketch> sketch_genome_individual(Engine& e, uint64_t c, uint64_t k, const std::string& ref_file,
                                                    uint64_t min_spacing, bool pseudotax) {
     std::vector<GenomeSketch> out;
-    std::unique_ptr<FastxReader> reader;
-    try { reader.reset(new FastxReader(ref_file)); }
-    catch (const Error&) { warn(ref_file + " is not a valid fasta/fastq file; skipping."); return out; }
-    FastxRecord rec;
-    try {
-        while (reader->next(rec)) {
-            std::vector<uint8_t> bases(rec.seq.begin(), rec.seq.end());
-            std::vector<uint64_t> off{0, (uint64_t)bases.size()};
-            GenomeSketch g = genome_from_contigs(e, bases, off, c, k, min_spacing, pseudotax);
-            g.file_name = ref_file;
-            g.first_contig_name = rec.id;
-            g.gn_size = bases.size();
-            out.push_back(std::move(g));
-        }
-    } catch (const Error&) { warn("File " + ref_file + " is not a valid fasta/fastq file"); return {}; }
+    GenomeBatch b(e, c, k, min_spacing, pseudotax, out);
+    b.add_file(ref_file, true);
+    b.flush();
     return out;
 }
 
@@ -281,15 +314,9 @@ int sketch(Engine& e, const SketchArgs& args) {
         const std::string path = args.db_out_name + QUERY_FILE_SUFFIX;
         create_dir_all(dirname_of(path));
         std::vector<GenomeSketch> all;
-        for (const auto& gf : genome_inputs) {
-            if (args.individual) {
-                auto v = sketch_genome_individual(e, args.c, args.k, gf, args.min_spacing_kmer, !args.no_pseudotax);
-                for (auto& g : v) all.push_back(std::move(g));
-            } else {
-                auto g = sketch_genome(e, args.c, args.k, gf, args.min_spacing_kmer, !args.no_pseudotax);
-                if (g) all.push_back(std::move(*g));
-            }
-        }
+        GenomeBatch batch(e, args.c, args.k, args.min_spacing_kmer, !args.no_pseudotax, all);
+        for (const auto& gf : genome_inputs) batch.add_file(gf, args.individual);
+        batch.flush();
         if (all.empty()) warn("No valid genomes to sketch; " + path + " is not output");
         else { write_syldb(path, all); info("Wrote all genome sketches to " + path); }
     }
@@ -373,17 +400,13 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         else if (*current_k != k) throw Error{1, "Query sketches have inconsistent -k. Exiting."};
         for (auto& g : v) genome_sketches.push_back(std::move(g));
     }
+    GenomeBatch batch(e, args.c, args.k, args.min_spacing_kmer, args.pseudotax, genome_sketches);
     for (const auto& gf : genome_files) {
         if (lowest_genome_c && *lowest_genome_c < args.c) { fprintf(stderr, "ERROR [sylph_hip] Value of -c for contain is %llu -- greater than the smallest value of -c for a genome sketch %llu. Continuing without sketching.\n", (unsigned long long)args.c, (unsigned long long)*lowest_genome_c); continue; }
         if (current_k && *current_k != args.k) { fprintf(stderr, "ERROR [sylph_hip] -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", (unsigned long long)args.k, (unsigned long long)*current_k); continue; }
-        if (args.individual) {
-            auto v = sketch_genome_individual(e, args.c, args.k, gf, args.min_spacing_kmer, args.pseudotax);
-            for (auto& g : v) genome_sketches.push_back(std::move(g));
-        } else {
-            auto g = sketch_genome(e, args.c, args.k, gf, args.min_spacing_kmer, args.pseudotax);
-            if (g) genome_sketches.push_back(std::move(*g));
-        }
+        batch.add_file(gf, args.individual);
     }
+    batch.flush();
     info("Finished obtaining genome sketches.");
     if (genome_sketches.empty()) throw Error{1, "No genome sketches found; see sylph query/profile -h for help. Exiting"};
     if (!genome_sketches.front().pseudotax_tracked_nonused_kmers && args.pseudotax)

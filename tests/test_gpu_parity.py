@@ -95,6 +95,56 @@ def test_genome_sketch_synthetic_multicontig(ctx):
             assert list(zip(cc.tolist(), pp.tolist(), hh.tolist())) == exp
 
 
+def test_genome_batch_matches_per_genome_oracle(ctx):
+    """sylph_sketch_genomes (database build on the device): every genome of a batch must come out exactly as
+    sketch_genome (sketch.rs:550-622) gives it alone — duplicates are per genome even when other genomes of the batch share
+    the k-mer, spacing restarts per genome/contig, empty genomes and contigs are legal."""
+    import torch
+    rng = np.random.default_rng(41)
+    base = random_seq(rng, 120000)
+    genomes = []
+    genomes.append([base[:50000].copy(), base[60000:90000].copy()])
+    g1 = [base[:50000].copy(), random_seq(rng, 20000)]            # shares 50 kb with genome 0 (cross-genome equal hashes)
+    g1[1][2000:7000] = g1[0][10000:15000]                          # and repeats 5 kb inside itself (dup rule fires)
+    genomes.append(g1)
+    genomes.append([])                                             # a genome without contigs
+    genomes.append([random_seq(rng, n) for n in (0, 30, 61, 62, 63, 5000)])
+    g4 = [random_seq(rng, 40000)]
+    g4[0][20000:30000] = g4[0][5000:15000]                         # tandem-ish repeat: both copies dropped entirely
+    genomes.append(g4)
+    genomes.append([base.copy()])                                  # superset of genome 0
+    genomes.append([np.frombuffer(b"ACGTNNNNacgtuURYK" * 600, dtype=np.uint8).copy()])   # low complexity + non-ACGT
+    contigs = [c for g in genomes for c in g]
+    b, off = concat(contigs) if contigs else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    goff = np.zeros(len(genomes) + 1, dtype=np.uint64)
+    goff[1:] = np.cumsum([len(g) for g in genomes])
+    dev = torch.from_numpy(np.concatenate([np.zeros(5, np.uint8), b, np.zeros(64, np.uint8)])).cuda()
+    torch.cuda.synchronize()
+    for gm, om in MODES:
+        for c, spacing, pseudotax in ((200, 30, True), (50, 30, False), (7, 30, True), (7, 0, True), (20, 1000, True)):
+            runs = [ctx.sketch_genomes(b, off, goff, c=c, seed_mode=gm, min_spacing=spacing, pseudotax=pseudotax),
+                    ctx.sketch_genomes(None, off, goff, c=c, seed_mode=gm, min_spacing=spacing, pseudotax=pseudotax,
+                                       device_ptr=dev.data_ptr() + 5)]     # device-resident, deliberately misaligned
+            for km, koff, tr, toff in runs:
+                assert koff[0] == 0 and toff[0] == 0 and len(km) == koff[-1] and len(tr) == toff[-1]
+                any_dup = 0
+                for gi, g in enumerate(genomes):
+                    gb, go = concat(g) if g else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+                    e = O.sketch_genome(gb, go, c=c, mode=om, min_spacing=spacing, pseudotax=pseudotax)
+                    any_dup += e["n_dup_kmers"]
+                    assert np.array_equal(km[int(koff[gi]):int(koff[gi + 1])], e["genome_kmers"]), (gi, c, spacing)
+                    if pseudotax:
+                        assert np.array_equal(tr[int(toff[gi]):int(toff[gi + 1])], e["tracked"]), (gi, c, spacing)
+                    else:
+                        assert toff[gi + 1] == 0
+                assert any_dup > 0
+    # degenerate batches
+    km, koff, tr, toff = ctx.sketch_genomes(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(1, np.uint64))
+    assert len(km) == 0 and list(koff) == [0]
+    with pytest.raises(S.SylphHipError):
+        ctx.sketch_genomes(b, off, goff[:-1])                       # genome offsets do not cover all contigs
+
+
 # ---------------------------------------------------------------------------------------------- read sketches
 FINISH_MODES = ("auto", "generic")   # bucket + in-LDS replay (with its fallback) and the device-wide sort path
 
