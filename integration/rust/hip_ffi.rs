@@ -33,5 +33,26 @@ extern "C" {
                            out: *mut *mut SylphDb) -> c_int;
     pub fn sylph_db_contain(db: *mut SylphDb, sample_kmers: *const u64, sample_counts: *const u32, n: u64, mem: c_int,
                             min_number_kmers: f64, contain_count: *mut u32, cov_off: *mut u64, out_covs: *mut *mut u32) -> c_int;
+    // database build: sketch_genome / sketch_genome_individual for a batch of genomes (sketch.rs:422-476 loop)
+    pub fn sylph_sketch_genomes(ctx: *mut SylphCtx, bases: *const u8, contig_off: *const u64, n_contigs: u64,
+                                genome_contig_off: *const u64, n_genomes: u64, c: u32, k: u32, seed_mode: c_int,
+                                min_spacing: u64, pseudotax: c_int, mem: c_int, out_kmers: *mut *mut u64, kmer_off: *mut u64,
+                                out_tracked: *mut *mut u64, tracked_off: *mut u64) -> c_int;
+    pub fn sylph_sketch_push_n(sk: *mut SylphSketch, bases: *const u8, rec_off: *const u64, n_records: u64, n_bases: u64,
+                               mem: c_int) -> c_int;
+    pub fn sylph_sketch_finish_device(sk: *mut SylphSketch, dev_kmers: *mut *const u64, dev_counts: *mut *const u32,
+                                      out_n: *mut u64, out_dup_removed: *mut u64) -> c_int;
+    // borrowed-result variant of sylph_db_contain (no allocation per sample)
+    pub fn sylph_db_contain_view(db: *mut SylphDb, sample_kmers: *const u64, sample_counts: *const u32, n: u64, mem: c_int,
+                                 min_number_kmers: f64, contain_count: *mut *const u32, cov_off: *mut *const u64,
+                                 covs: *mut *const u32, out_n_covs: *mut u64) -> c_int;
+    // profile: winner_table + second get_stats pass (contain.rs:297-311, 410-430, 637-646)
+    pub fn sylph_db_attach_tracked(db: *mut SylphDb, tracked_kmers: *const u64, tracked_off: *const u64, mem: c_int) -> c_int;
+    pub fn sylph_db_reassign_view(db: *mut SylphDb, sample_kmers: *const u64, sample_counts: *const u32, n: u64, mem: c_int,
+                                  passing_gids: *const u32, passing_ani: *const f64, n_passing: u32,
+                                  contain_count: *mut *const u32, cov_off: *mut *const u64, covs: *mut *const u32,
+                                  out_n_covs: *mut u64, kmers_lost: *mut *const u32) -> c_int;
+    pub fn sylph_ctx_set_option(ctx: *mut SylphCtx, key: *const c_char, value: *const c_char) -> c_int;
+    pub fn sylph_ctx_synchronize(ctx: *mut SylphCtx) -> c_int;
     pub fn sylph_db_destroy(db: *mut SylphDb);
 }
