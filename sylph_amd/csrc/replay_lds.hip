@@ -3,7 +3,7 @@
 // FracMinHash survivors are uniformly distributed below the threshold (mm_hash64 is a bijection of canonical
 // k-mers), so the top bits of the hash split the sample's occurrences into B buckets of nearly equal size.  One
 // counting pass + one scatter pass puts every occurrence record (hash, rid, m0, m1: 32 B) into its bucket; one
-// workgroup then owns one bucket entirely in LDS: bitonic sort by (hash, record index) -> k-mer segments in file
+// workgroup then owns one bucket entirely in LDS: stable counting-rank sort by hash -> k-mer segments in file
 // order -> mate-2 skip, duplicate flags, cut-off and counts (the same data-parallel formulation of
 // dup_removal_lsh_full_exact as sketch.hip, see its header) -> distinct (k-mer, count) pairs.  Buckets are ordered
 // by hash, so concatenating their outputs gives the table in ascending k-mer order.
@@ -20,7 +20,6 @@ namespace {
 // (one wavefront per bucket with CAP = 256 was measured 20 % slower than two wavefronts with CAP = 512)
 constexpr int RTPB = 128;
 constexpr int CAP = 512;             // occurrences per bucket that fit in LDS (23 KiB per workgroup -> 6 workgroups per CU)
-constexpr int PADN = 512;            // bitonic network size
 constexpr int ITEMS = CAP / RTPB;    // sorted positions per lane (contiguous)
 constexpr uint32_t TARGET = 160;     // mean bucket load aimed for (B in (n/2T, n/T] -> mean load in [T, 2T))
 
@@ -79,15 +78,22 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave,
 }
 
 // One workgroup = one bucket.  SINGLE_CUTOFF = 4 for single-end (sketch.rs:937), 0 for pairs.
+//
+// Ordering inside the bucket: the partition sort is stable and occurrences were appended in file order, so a bucket's
+// occurrences arrive ordered by (record, position); what is left is a STABLE sort by hash.  Each lane keeps its (up to
+// ITEMS) records in registers, publishes one 64-bit key per record in LDS and finds the record's sorted position by
+// counting smaller keys — every lane reads the same LDS word per step (a broadcast, no bank conflicts), the loop has no
+// barriers and no dependent LDS round trips, and it is O(n^2 / lanes) with n ~ 200.  Keys are unique: the bucket's hashes
+// agree above bit `bshift`, so key = (hash mod 2^bshift) << 9 | arrival index whenever bshift <= 55 (else the two-part
+// comparison is spelled out).  Records are then written straight to their sorted slots.
 __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
                                                              const uint32_t* __restrict__ boff,
                                                              const uint32_t* __restrict__ p_nv, int paired, int no_dedup,
-                                                             uint32_t cutoff, uint64_t* __restrict__ tmp_k,
+                                                             uint32_t cutoff, int bshift, uint64_t* __restrict__ tmp_k,
                                                              uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
                                                              unsigned long long* __restrict__ removed_total,
                                                              uint32_t* __restrict__ overflow, int dbg_stage) {
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
-    __shared__ uint16_t s_idx[PADN];
     __shared__ uint16_t s_seg[CAP];       // first sorted position of the k-mer each sorted position belongs to
     __shared__ uint8_t s_fl[CAP];         // bit0 skip, bit1 would-be-dropped
     __shared__ uint32_t s_a[CAP + 1], s_b[CAP + 1];
@@ -99,54 +105,67 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     if (n == 0) { if (tid == 0) n_distinct[b] = 0; return; }
     // too large for LDS (or, defensively, inconsistent bounds): report and let the generic path redo the sample
     if (n > CAP || last > nv || first > last) { if (tid == 0) { n_distinct[b] = 0; atomicAdd(overflow, 1u); } return; }
-    for (uint32_t i = tid; i < n; i += RTPB) {   // the records are gathered through the partition permutation
-        const OccRec r = recs[perm[first + i]];   // one 32 B sector per occurrence
-        s_hash[i] = r.hash; s_rid[i] = r.rid; s_m0[i] = r.m0; s_m1[i] = r.m1;
+    // ---- gather (through the partition permutation, one 32 B sector per occurrence) + stable sort by hash ------------
+    uint64_t* s_key = s_m0;               // keys live in s_m0 until the sorted records are written
+    const bool composite = bshift <= 55;
+    const uint64_t lowmask = composite ? ((1ull << bshift) - 1ull) : ~0ull;
+    OccRec r[ITEMS];
+    uint64_t key[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RTPB;
+        key[q] = ~0ull;
+        if (i < n) {
+            r[q] = recs[perm[first + i]];
+            key[q] = composite ? (((r[q].hash & lowmask) << 9) | i) : r[q].hash;
+            s_key[i] = key[q];
+        }
     }
-    uint32_t padn = 64;
-    while (padn < n) padn <<= 1;
-    for (uint32_t i = tid; i < padn; i += RTPB) s_idx[i] = (uint16_t)(i < n ? i : 0xFFFF);
     __syncthreads();
     if (dbg_stage == 1) { if (tid == 0) n_distinct[b] = 0; return; }
-    // ---- bitonic sort of s_idx by (hash, record index); 0xFFFF sorts last -----------------------------------
-    auto greater = [&](uint16_t x, uint16_t y) -> bool {   // key(x) > key(y)
-        if (x == 0xFFFF) return y != 0xFFFF;
-        if (y == 0xFFFF) return false;
-        const uint64_t hx = s_hash[x], hy = s_hash[y];
-        if (hx != hy) return hx > hy;
-        const uint64_t rx = s_rid[x] & RID_MASK, ry = s_rid[y] & RID_MASK;
-        if (rx != ry) return rx > ry;
-        return x > y;                                       // same k-mer twice in one record: symmetric, keep it total
-    };
-    // A wavefront's 64 comparators of a stage with partner distance j <= 64 touch only its own 128 consecutive
-    // elements, and a wavefront's LDS operations execute in program order, so those stages need no workgroup barrier:
-    // only the stages with j >= 128 (one per k2 >= 256) synchronise all waves.
-    for (uint32_t k2 = 2; k2 <= padn; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            if (j >= 128) __syncthreads();
-            for (uint32_t t = tid; t < (padn >> 1); t += RTPB) {
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // comparator t: (lo, lo + j)
-                const uint32_t hi = lo + j;
-                const bool up = ((lo & k2) == 0);
-                const uint16_t x = s_idx[lo], y = s_idx[hi];
-                if (greater(x, y) == up) { s_idx[lo] = y; s_idx[hi] = x; }
-            }
-            if (j >= 128) __syncthreads();
-            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) rank[q] = 0;
+    const int levels = (int)((n + RTPB - 1) / RTPB);   // lanes of level q hold a record iff q < levels (wave-uniform)
+    if (composite) {
+#pragma unroll 8
+        for (uint32_t j = 0; j < n; j++) {
+            const uint64_t kj = s_key[j];
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++)
+                if (q < levels) rank[q] += (kj < key[q]) ? 1u : 0u;
+        }
+    } else {
+#pragma unroll 4
+        for (uint32_t j = 0; j < n; j++) {
+            const uint64_t kj = s_key[j];
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++)
+                if (q < levels) rank[q] += ((kj < key[q]) || (kj == key[q] && j < tid + q * RTPB)) ? 1u : 0u;
+        }
+    }
+    __syncthreads();                      // every lane is done with s_key (= s_m0)
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RTPB;
+        if (i < n) {
+            const uint32_t d = rank[q];
+            s_hash[d] = r[q].hash; s_rid[d] = r[q].rid; s_m0[d] = r[q].m0; s_m1[d] = r[q].m1;
         }
     }
     __syncthreads();
     if (dbg_stage == 2) { if (tid == 0) n_distinct[b] = 0; return; }
     // ---- segments ---------------------------------------------------------------------------------------------
-    // lane owns ITEMS contiguous sorted positions; s_seg = running "last head seen" (segmented max-scan)
-    const uint32_t j0 = tid * ITEMS;
+    // lane owns `items` contiguous sorted positions; s_seg = running "last head seen" (segmented max-scan)
+    const uint32_t items = (n + RTPB - 1) / RTPB;
+    const uint32_t j0 = tid * items;
     uint32_t heads = 0, last_head = 0;
     bool has_head = false;
     uint8_t headbits = 0;
-    for (int t = 0; t < ITEMS; t++) {
+    for (uint32_t t = 0; t < items; t++) {
         const uint32_t j = j0 + t;
         if (j >= n) break;
-        const bool hd = (j == 0) || (s_hash[s_idx[j]] != s_hash[s_idx[j - 1]]);
+        const bool hd = (j == 0) || (s_hash[j] != s_hash[j - 1]);
         if (hd) { heads++; last_head = j; has_head = true; headbits |= (uint8_t)(1u << t); }
     }
     // inclusive max-scan of last_head over lanes (a lane without a head inherits from the left)
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     }
     {
         uint32_t cur = carry;   // last head (+1) before this lane's first position
-        for (int t = 0; t < ITEMS; t++) {
+        for (uint32_t t = 0; t < items; t++) {
             const uint32_t j = j0 + t;
             if (j >= n) break;
             if (headbits & (1u << t)) cur = j + 1;
@@ -178,17 +197,17 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     }
     __syncthreads();
     // ---- mate-2 skip (sketch.rs:852) and duplicate flags ----------------------------------------------------------
-    for (int t = 0; t < ITEMS; t++) {
+    for (uint32_t t = 0; t < items; t++) {
         const uint32_t j = j0 + t;
         if (j >= n) break;
         uint8_t fl = 0;
         if (paired) {
-            const uint64_t rec = s_rid[s_idx[j]] & RID_MASK;
+            const uint64_t rec = s_rid[j] & RID_MASK;
             if (rec & 1) {
                 const uint32_t s0 = s_seg[j];
                 for (uint32_t q = j; q > s0;) {
                     q--;
-                    const uint64_t rq = s_rid[s_idx[q]] & RID_MASK;
+                    const uint64_t rq = s_rid[q] & RID_MASK;
                     if ((rq >> 1) != (rec >> 1)) break;
                     if ((rq & 1) == 0) { fl = 1; break; }
                 }
@@ -199,20 +218,18 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     __syncthreads();
     uint32_t my_u = 0;
     uint8_t ubits = 0;
-    for (int t = 0; t < ITEMS; t++) {
+    for (uint32_t t = 0; t < items; t++) {
         const uint32_t j = j0 + t;
         if (j >= n) break;
         uint8_t fl = s_fl[j];
-        const uint16_t me = s_idx[j];
-        if (!fl && !no_dedup && (s_rid[me] & RID_MARKER_BIT)) {
-            const uint64_t a = s_m0[me], bb = s_m1[me];
+        if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT)) {
+            const uint64_t a = s_m0[j], bb = s_m1[j];
             bool any_prev = false, hit = false;
             for (uint32_t q = s_seg[j]; q < j; q++) {
                 if (s_fl[q] & 1) continue;
                 any_prev = true;
-                const uint16_t o = s_idx[q];
-                if (s_rid[o] & RID_MARKER_BIT) {
-                    const uint64_t x = s_m0[o], y = s_m1[o];
+                if (s_rid[q] & RID_MARKER_BIT) {
+                    const uint64_t x = s_m0[q], y = s_m1[q];
                     if (x == a || y == a || x == bb || y == bb) { hit = true; break; }
                 }
             }
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     const uint32_t base_u = base_uh & 0xFFFFu, base_h = base_uh >> 16, total_heads = tot_uh >> 16;
     {
         uint32_t run = base_u;
-        for (int t = 0; t < ITEMS; t++) {
+        for (uint32_t t = 0; t < items; t++) {
             const uint32_t j = j0 + t;
             if (j >= n) break;
             s_a[j] = run;                       // Eu[j]
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     __syncthreads();
     uint32_t my_c = 0, my_removed = 0;
     uint8_t cbits = 0;
-    for (int t = 0; t < ITEMS; t++) {
+    for (uint32_t t = 0; t < items; t++) {
         const uint32_t j = j0 + t;
         if (j >= n) break;
         const uint8_t fl = s_fl[j];
@@ -255,27 +272,27 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     const uint32_t total_removed = tot_cr >> 16;
     {
         uint32_t rc = base_c;
-        for (int t = 0; t < ITEMS; t++) {
+        for (uint32_t t = 0; t < items; t++) {
             const uint32_t j = j0 + t;
             if (j >= n) break;
             s_b[j] = rc;                        // Ec[j]
             if (cbits & (1u << t)) rc++;
         }
-        if (j0 < n && j0 + ITEMS >= n) s_b[n] = rc;   // Ec[n], written by the lane that owns the last position
+        if (j0 < n && j0 + items >= n) s_b[n] = rc;   // Ec[n], written by the lane that owns the last position
     }
     __syncthreads();
     // heads emit (k-mer, count); the distinct index of a head = number of heads before it
     {
         uint32_t rh = base_h;
         const uint32_t out0 = first;
-        for (int t = 0; t < ITEMS; t++) {
+        for (uint32_t t = 0; t < items; t++) {
             const uint32_t j = j0 + t;
             if (j >= n) break;
             if (headbits & (1u << t)) {
                 // segment end = next head or n: walk (k-mers have few occurrences; bounded by the bucket size)
                 uint32_t e = j + 1;
                 while (e < n && s_seg[e] == j) e++;
-                tmp_k[out0 + rh] = s_hash[s_idx[j]];
+                tmp_k[out0 + rh] = s_hash[j];
                 tmp_c[out0 + rh] = s_b[e] - s_b[j];
                 rh++;
             }
@@ -351,7 +368,7 @@ bool finish_bucketed(sylph_sketch* sk) {
                                boff);
             hipLaunchKernelGGL(bucket_replay_kernel, dim3(B), dim3(RTPB), 0, ctx->stream, sk->recs.as<OccRec>(),
                                b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup,
-                               sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, b_tmpk.as<uint64_t>(),
+                               sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, bshift, b_tmpk.as<uint64_t>(),
                                b_tmpc.as<uint32_t>(), n_distinct, d_removed, d_overflow,
                                getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0);
         }
