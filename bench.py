@@ -194,6 +194,8 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     ctx = S.Context(local, stream=stream)
+    for kv in filter(None, os.environ.get("SYLPH_BENCH_CTX_OPTIONS", "").split(",")):   # tuning experiments only
+        ctx.set_option(*kv.split("=", 1))
 
     log(f"[bench] building workload {args.workload} on {world} GPU(s) ...")
     # ~1.8e9 postings x 12.5 B = 22 GB at GTDB-R220 scale: replicate unless it would take more than a quarter of HBM

@@ -254,6 +254,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             if (!strcmp(value, "ordered")) ctx->seeds_mode = 0;
             else if (!strcmp(value, "unordered")) ctx->seeds_mode = 1;
             else SY_REQUIRE(false, "seeds must be ordered|unordered");
+        } else if (!strcmp(key, "bucket_target")) {
+            const long v = strtol(value, nullptr, 10);
+            SY_REQUIRE(v >= 16 && v <= 256, "bucket_target must be in [16, 256]");
+            ctx->bucket_target = (uint32_t)v;
         } else {
             SY_REQUIRE(false, "unknown option %s", key);
         }

@@ -17,11 +17,14 @@
 namespace sylph {
 namespace {
 
-// (one wavefront per bucket with CAP = 256 was measured 20 % slower than two wavefronts with CAP = 512)
-constexpr int RTPB = 128;
-constexpr int CAP = 512;             // occurrences per bucket that fit in LDS (23 KiB per workgroup -> 6 workgroups per CU)
-constexpr int ITEMS = CAP / RTPB;    // sorted positions per lane (contiguous)
-constexpr uint32_t TARGET = 160;     // mean bucket load aimed for (B in (n/2T, n/T] -> mean load in [T, 2T))
+// Two launches of the same kernel template: buckets of up to CAP_SMALL occurrences (all of them, for ordinary samples) run
+// with 10 KiB of LDS per workgroup -> 16 workgroups = 32 wavefronts per CU, which is what hides the latency of this
+// barrier- and gather-heavy kernel (with a single 512-slot configuration occupancy was 14 wavefronts and the kernel 1.4x
+// slower); the rare larger buckets (high-abundance k-mers) are redone by the CAP_LARGE configuration; only beyond that
+// does finish() fall back to the device-wide path.
+constexpr int CAP_SMALL = 256, RTPB_SMALL = 128;
+constexpr int CAP_LARGE = 1024, RTPB_LARGE = 256;
+constexpr int IDX_BITS = 10;         // arrival index inside a bucket (< CAP_LARGE)
 
 // boff[b] = first position (in the array sorted by the bucket bits) whose bucket is >= b, for b in [0, B]
 __global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __restrict__ bk, const uint32_t* __restrict__ p_n,
@@ -35,12 +38,20 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __re
 }
 
 // bucket id of every occurrence (B = "invalid", sorts last) + identity permutation
-__global__ __launch_bounds__(256) void bucket_key_kernel(const uint64_t* __restrict__ hash, uint32_t n, int bshift, uint32_t B,
+// Bucket of a hash: hs = hash >> sh (its 32 most significant bits below the threshold), b = (hs * mult) >> 32 — B
+// equal ranges for ANY B (not only powers of two), monotone in the hash.  Inverse used by the replay kernel: the
+// smallest hs of bucket b is ceil(b * 2^32 / mult).
+struct BucketMap { int sh; uint32_t mult; uint32_t B; int composite; };
+__device__ __forceinline__ uint32_t bucket_of(uint64_t h, const BucketMap m) {
+    return min(__umulhi((uint32_t)(h >> m.sh), m.mult), m.B - 1u);
+}
+
+__global__ __launch_bounds__(256) void bucket_key_kernel(const uint64_t* __restrict__ hash, uint32_t n, BucketMap bm, uint32_t B,
                                                          uint32_t* __restrict__ bk, uint32_t* __restrict__ idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t h = hash[i];
-    bk[i] = (h == INVALID_HASH) ? B : (uint32_t)(h >> bshift);
+    bk[i] = (h == INVALID_HASH) ? B : bucket_of(h, bm);
     idx[i] = i;
 }
 
@@ -55,6 +66,7 @@ __global__ void count_valid_bk_kernel(const uint32_t* __restrict__ bk, uint32_t 
 }
 
 // exclusive prefix sum of one value per lane across the workgroup (4 waves); total returned through *total
+template <int RTPB>
 __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave, uint32_t* total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t x = v;
@@ -84,31 +96,37 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave,
 // ITEMS) records in registers, publishes one 64-bit key per record in LDS and finds the record's sorted position by
 // counting smaller keys — every lane reads the same LDS word per step (a broadcast, no bank conflicts), the loop has no
 // barriers and no dependent LDS round trips, and it is O(n^2 / lanes) with n ~ 200.  Keys are unique: the bucket's hashes
-// agree above bit `bshift`, so key = (hash mod 2^bshift) << 9 | arrival index whenever bshift <= 55 (else the two-part
-// comparison is spelled out).  Records are then written straight to their sorted slots.
+// lie in one narrow range, so key = (hash - lowest hash of the bucket) << 10 | arrival index whenever that difference fits
+// in 54 bits (bm.composite, decided by the host; else — tiny samples — the two-part comparison is spelled out).  Records are then written straight to their sorted slots.
+// Handles buckets with min_n < n <= CAP; larger ones bump `overflow` (when count_overflow) and are left to the caller.
+template <int CAP, int RTPB>
 __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
                                                              const uint32_t* __restrict__ boff,
                                                              const uint32_t* __restrict__ p_nv, int paired, int no_dedup,
-                                                             uint32_t cutoff, int bshift, uint64_t* __restrict__ tmp_k,
+                                                             uint32_t cutoff, BucketMap bm, uint64_t* __restrict__ tmp_k,
                                                              uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
-                                                             unsigned long long* __restrict__ removed_total,
-                                                             uint32_t* __restrict__ overflow, int dbg_stage) {
+                                                             uint32_t* __restrict__ removed_b,
+                                                             uint32_t* __restrict__ overflow, uint32_t min_n, int count_overflow,
+                                                             int dbg_stage) {
+    constexpr int ITEMS = CAP / RTPB;     // records per lane
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
     __shared__ uint16_t s_seg[CAP];       // first sorted position of the k-mer each sorted position belongs to
     __shared__ uint8_t s_fl[CAP];         // bit0 skip, bit1 would-be-dropped
-    __shared__ uint32_t s_a[CAP + 1], s_b[CAP + 1];
+    __shared__ uint16_t s_a[CAP + 2], s_b[CAP + 2];   // exclusive counts <= CAP
     __shared__ uint32_t s_wave[RTPB / 64];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t nv = *p_nv;
     const uint32_t first = boff[b], last = boff[b + 1];
     const uint32_t n = last - first;
-    if (n == 0) { if (tid == 0) n_distinct[b] = 0; return; }
-    // too large for LDS (or, defensively, inconsistent bounds): report and let the generic path redo the sample
-    if (n > CAP || last > nv || first > last) { if (tid == 0) { n_distinct[b] = 0; atomicAdd(overflow, 1u); } return; }
+    if (last > nv || first > last) { if (tid == 0 && count_overflow) atomicAdd(overflow, 1u); return; }   // defensive
+    if (n <= min_n) return;               // empty (n_distinct was zeroed by the host) or done by the previous launch
+    // too large for this configuration: the next launch, or (count_overflow) the generic path, redoes it
+    if (n > CAP) { if (tid == 0 && count_overflow) atomicAdd(overflow, 1u); return; }
     // ---- gather (through the partition permutation, one 32 B sector per occurrence) + stable sort by hash ------------
     uint64_t* s_key = s_m0;               // keys live in s_m0 until the sorted records are written
-    const bool composite = bshift <= 55;
-    const uint64_t lowmask = composite ? ((1ull << bshift) - 1ull) : ~0ull;
+    const bool composite = bm.composite != 0;
+    // lowest hash that maps to this bucket: hs >= ceil(b * 2^32 / mult)  (exact inverse of bucket_of)
+    const uint64_t lo_hash = composite ? (((((uint64_t)b << 32) + bm.mult - 1u) / bm.mult) << bm.sh) : 0ull;
     OccRec r[ITEMS];
     uint64_t key[ITEMS];
 #pragma unroll
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
         key[q] = ~0ull;
         if (i < n) {
             r[q] = recs[perm[first + i]];
-            key[q] = composite ? (((r[q].hash & lowmask) << 9) | i) : r[q].hash;
+            key[q] = composite ? (((r[q].hash - lo_hash) << IDX_BITS) | i) : r[q].hash;
             s_key[i] = key[q];
         }
     }
@@ -243,14 +261,14 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     // ---- P_i = would-be-counted occurrences before i in its k-mer; counted_i (cut-off rule, sketch.rs:706) ------
     // two block scans in total: (would-count, heads) packed 16+16 bits here, (counted, removed) below; sums <= CAP
     uint32_t tot_uh = 0;
-    const uint32_t base_uh = block_excl_sum(my_u | (heads << 16), s_wave, &tot_uh);
+    const uint32_t base_uh = block_excl_sum<RTPB>(my_u | (heads << 16), s_wave, &tot_uh);
     const uint32_t base_u = base_uh & 0xFFFFu, base_h = base_uh >> 16, total_heads = tot_uh >> 16;
     {
         uint32_t run = base_u;
         for (uint32_t t = 0; t < items; t++) {
             const uint32_t j = j0 + t;
             if (j >= n) break;
-            s_a[j] = run;                       // Eu[j]
+            s_a[j] = (uint16_t)run;             // Eu[j]
             if (ubits & (1u << t)) run++;
         }
     }
@@ -262,23 +280,23 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
         if (j >= n) break;
         const uint8_t fl = s_fl[j];
         if (fl & 1) continue;
-        const uint32_t P = s_a[j] - s_a[s_seg[j]];
+        const uint32_t P = (uint32_t)s_a[j] - (uint32_t)s_a[s_seg[j]];
         const bool u = (ubits >> t) & 1;
         const bool c = (cutoff && P >= cutoff) ? true : u;
         if (c) { my_c++; cbits |= (uint8_t)(1u << t); } else my_removed++;
     }
     uint32_t tot_cr = 0;
-    const uint32_t base_c = block_excl_sum(my_c | (my_removed << 16), s_wave, &tot_cr) & 0xFFFFu;
+    const uint32_t base_c = block_excl_sum<RTPB>(my_c | (my_removed << 16), s_wave, &tot_cr) & 0xFFFFu;
     const uint32_t total_removed = tot_cr >> 16;
     {
         uint32_t rc = base_c;
         for (uint32_t t = 0; t < items; t++) {
             const uint32_t j = j0 + t;
             if (j >= n) break;
-            s_b[j] = rc;                        // Ec[j]
+            s_b[j] = (uint16_t)rc;              // Ec[j]
             if (cbits & (1u << t)) rc++;
         }
-        if (j0 < n && j0 + items >= n) s_b[n] = rc;   // Ec[n], written by the lane that owns the last position
+        if (j0 < n && j0 + items >= n) s_b[n] = (uint16_t)rc;   // Ec[n], written by the lane that owns the last position
     }
     __syncthreads();
     // heads emit (k-mer, count); the distinct index of a head = number of heads before it
@@ -293,14 +311,29 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
                 uint32_t e = j + 1;
                 while (e < n && s_seg[e] == j) e++;
                 tmp_k[out0 + rh] = s_hash[j];
-                tmp_c[out0 + rh] = s_b[e] - s_b[j];
+                tmp_c[out0 + rh] = (uint32_t)s_b[e] - (uint32_t)s_b[j];
                 rh++;
             }
         }
     }
-    if (tid == 0) {
-        n_distinct[b] = total_heads;
-        if (total_removed) atomicAdd(removed_total, (unsigned long long)total_removed);
+    // (per-bucket removed counts are summed by a separate kernel: one atomic per workgroup on a single word runs at ~88
+    //  atomics/us on this chip and was bounding the whole kernel at ~0.2 ms for 2e4 buckets)
+    if (tid == 0) { n_distinct[b] = total_heads; removed_b[b] = total_removed; }
+}
+
+__global__ __launch_bounds__(1024) void sum_removed_kernel(const uint32_t* __restrict__ removed_b, uint32_t B,
+                                                           unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s[16];
+    unsigned long long v = 0;
+    for (uint32_t i = threadIdx.x; i < B; i += 1024) v += removed_b[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; w++) t += s[w];
+        *out = t;
     }
 }
 
@@ -326,12 +359,18 @@ bool finish_bucketed(sylph_sketch* sk) {
     sk->dup_removed = 0;
     if (n_all == 0) return true;
     if (sk->c < 2) return false;   // c = 1: valid hashes reach the top bit that marks invalid occurrences
-    // bucket geometry: B = (thr >> bshift) + 1 buckets of TARGET..2*TARGET occurrences
+    // bucket geometry: B = n / TARGET equal hash ranges (see BucketMap)
     const uint64_t thr = UINT64_MAX / (uint64_t)sk->c;
-    const int bits = bit_length(thr);
-    const int bbits = std::min(bit_length(n_all / TARGET), 24);
-    const int bshift = std::max(0, bits - bbits);
-    const uint32_t B = (uint32_t)(thr >> bshift) + 1;
+    const uint32_t TARGET = ctx->bucket_target;
+    const uint32_t B = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, n_all / TARGET), 1u << 24);
+    BucketMap bm;
+    bm.sh = std::max(0, bit_length(thr) - 32);
+    const uint64_t hs_max = thr >> bm.sh;                              // hashes are < thr
+    bm.mult = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)B << 32) / (hs_max + 1));
+    bm.B = B;
+    // widest bucket in hs units is ceil(2^32 / mult) + 1; the key needs (range << sh) to fit in 64 - IDX_BITS bits
+    const uint64_t range_hs = (0x100000000ull + bm.mult - 1) / std::max<uint32_t>(1, bm.mult) + 1;
+    bm.composite = bm.mult >= 1 && bit_length(range_hs) + bm.sh <= 64 - IDX_BITS;
     DevBuf &b_idx = ctx->scratch[0], &b_keys = ctx->scratch[1], &b_perm = ctx->scratch[2], &b_tmpk = ctx->scratch[3],
            &b_tmpc = ctx->scratch[4], &b_small = ctx->scratch[5], &b_bk = ctx->scratch[6];
     b_idx.reserve((size_t)n_all * 4);
@@ -340,15 +379,16 @@ bool finish_bucketed(sylph_sketch* sk) {
     b_tmpk.reserve((size_t)n_all * 8);
     b_tmpc.reserve((size_t)n_all * 4);
     b_small.reserve(64);
-    b_bk.reserve((size_t)(B + 2) * 4 * 3);      // boff | n_distinct | d_off   (each B+2)
+    b_bk.reserve((size_t)(B + 2) * 4 * 4);      // boff | n_distinct | removed | d_off   (each B+2)
     uint32_t* boff = b_bk.as<uint32_t>();
     uint32_t* n_distinct = boff + (B + 2);
-    uint32_t* d_off = n_distinct + (B + 2);
+    uint32_t* removed_b = n_distinct + (B + 2);
+    uint32_t* d_off = removed_b + (B + 2);
     unsigned long long* d_removed = b_small.as<unsigned long long>();
     uint32_t* d_overflow = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 8);
     uint32_t* d_nv = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 16);
     SY_HIP(hipMemsetAsync(b_small.p, 0, 64, ctx->stream));
-    SY_HIP(hipMemsetAsync(n_distinct, 0, (size_t)(B + 2) * 4, ctx->stream));
+    SY_HIP(hipMemsetAsync(n_distinct, 0, (size_t)(B + 2) * 4 * 2, ctx->stream));   // n_distinct and removed
     // partition: stable radix sort of (bucket id -> occurrence index) on bit_length(B) bits (2-3 passes of 4-byte keys
     // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
     uint32_t* bk_in = b_keys.as<uint32_t>();
@@ -358,7 +398,7 @@ bool finish_bucketed(sylph_sketch* sk) {
     sk->out_c.reserve((size_t)n_all * 4);
     {
         HostPhase ph(ctx, "finish(bucket): partition + LDS replay + compact");
-        hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(n_all)), dim3(256), 0, ctx->stream, sk->hash.as<uint64_t>(), n_all, bshift,
+        hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(n_all)), dim3(256), 0, ctx->stream, sk->hash.as<uint64_t>(), n_all, bm,
                            B, bk_in, b_idx.as<uint32_t>());
         sort_pairs_u32_u32(ctx, bk_in, bk_sorted, b_idx.as<uint32_t>(), b_perm.as<uint32_t>(), n_all, 0, bit_length(B));
         hipLaunchKernelGGL(count_valid_bk_kernel, dim3(1), dim3(1), 0, ctx->stream, bk_sorted, n_all, B, d_nv);
@@ -366,11 +406,16 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)n_all + 1)), dim3(256), 0, ctx->stream, bk_sorted, d_nv, B,
                                boff);
-            hipLaunchKernelGGL(bucket_replay_kernel, dim3(B), dim3(RTPB), 0, ctx->stream, sk->recs.as<OccRec>(),
-                               b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup,
-                               sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, bshift, b_tmpk.as<uint64_t>(),
-                               b_tmpc.as<uint32_t>(), n_distinct, d_removed, d_overflow,
-                               getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0);
+            const int dbg = getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0;
+            const uint32_t cutoff = sk->paired ? 0u : 4u;   // MAX_DEDUP_COUNT, constants.rs:14
+            hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
+                               sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
+                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, 0u, 0, dbg);
+            hipLaunchKernelGGL((bucket_replay_kernel<CAP_LARGE, RTPB_LARGE>), dim3(B), dim3(RTPB_LARGE), 0, ctx->stream,
+                               sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
+                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow,
+                               (uint32_t)CAP_SMALL, 1, dbg);
+            hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
         }
         exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
         {

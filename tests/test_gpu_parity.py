@@ -321,6 +321,30 @@ def test_bucket_path_is_really_used(ctx):
                        O.sketch_reads(deep[0], deep[1], c=3))
 
 
+def test_bucket_path_large_buckets(ctx):
+    """k-mers with a few hundred occurrences each: their buckets exceed the 256-slot configuration of the in-LDS replay and
+    must be picked up by its 1024-slot second launch — still without the device-wide fallback (finish=bucket)."""
+    rng = np.random.default_rng(23)
+    genome = random_seq(rng, 350)
+    filler = random_seq(rng, 60000)
+    ctx.set_option("finish", "bucket")
+    try:
+        recs = make_reads(rng, genome, 1000, 100, err=0.0, dup_frac=0.3, ragged=False) + make_reads(rng, filler, 6000, 100, dup_frac=0.1)
+        order = rng.permutation(len(recs))
+        b, off = concat([recs[i] for i in order])
+        e = O.sketch_reads(b, off, c=10)
+        assert 256 < e["counts"].max() < 600
+        assert_same_sketch(_sketch_gpu_once(ctx, b, off, False, False, S.SEED_AVX2_COMPAT, 10, 31, 1), e)
+        recs = make_reads(rng, genome, 600, 100, err=0.0, dup_frac=0.3, paired=True, insert=200, ragged=False) + \
+            make_reads(rng, filler, 3000, 100, dup_frac=0.1, paired=True, insert=300, ragged=False)
+        b, off = concat(recs)
+        e = O.sketch_reads(b, off, c=10, paired=True)
+        assert e["counts"].max() > 256
+        assert_same_sketch(_sketch_gpu_once(ctx, b, off, True, False, S.SEED_AVX2_COMPAT, 10, 31, 1), e)
+    finally:
+        ctx.set_option("finish", "auto")
+
+
 def test_tandem_repeats_overflow_the_tile_slots(ctx):
     """A short-period tandem repeat whose k-mer passes the threshold yields thousands of survivors per 16 KiB tile: the
     ordered K1 must detect the slot overflow and fall back, the unordered K1 must spill past its LDS stage."""
