@@ -60,15 +60,33 @@ __device__ __forceinline__ void marker_halves(const uint8_t* __restrict__ p, uin
     odd = o;
 }
 
+// Coarse record index of a batch: coarse[t] = record containing flat base t * 2^COARSE_SHIFT (the last record for
+// positions at or beyond the end).  One thread per entry, all binary searches in flight at once — so the annotate
+// kernel's workgroups need ONE dependent load to bound their record window instead of a 23-step search each
+// (that chain of L2/HBM round trips was half of the kernel's time).
+constexpr int COARSE_SHIFT = 14;
+__global__ __launch_bounds__(256) void coarse_index_kernel(const uint64_t* __restrict__ off, uint64_t n_rec, uint32_t n_entries,
+                                                           uint32_t* __restrict__ coarse) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_entries) return;
+    const uint64_t total = off[n_rec];
+    uint64_t p = (uint64_t)t << COARSE_SHIFT;
+    if (total == 0) { coarse[t] = 0; return; }
+    if (p >= total) p = total - 1;
+    coarse[t] = (uint32_t)find_record(off, n_rec, p);
+}
+
 // ---- K2: annotate survivors of one batch (already sorted by flat position) ---------------------------------
 // Validates that the k-mer lies inside one record and among the k-mers the reference hashes, finds the record,
 // and computes the dedup markers.  Invalid survivors get hash = ~0 (sorts last, dropped in finish()).
-// Survivors arrive sorted by position, so a workgroup's 256 survivors span a short run of records: two lanes do
-// the full binary search for the first and last survivor, everyone else searches only inside that run.
+// Survivors arrive sorted by position, so a workgroup's 256 survivors span a short run of records: two lanes bound
+// it through the coarse index (first and last survivor), the run's offsets are staged in LDS and every lane searches
+// only inside that run.
 __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
     const uint64_t* __restrict__ hash, uint32_t n, uint32_t pos_bias, uint32_t k, int avx2_compat, int paired,
-    int want_markers, uint64_t rec_base, uint64_t* __restrict__ o_hash, OccRec* __restrict__ o_rec) {
+    int want_markers, uint64_t rec_base, const uint32_t* __restrict__ coarse, uint64_t* __restrict__ o_hash,
+    OccRec* __restrict__ o_rec) {
     constexpr uint32_t WIN = 1024;           // record offsets staged in LDS (8 KiB)
     __shared__ uint64_t s_lo, s_hi;
     __shared__ uint64_t s_off[WIN + 2];
@@ -79,8 +97,9 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         const uint32_t j = threadIdx.x == 0 ? first : min(n, first + blockDim.x) - 1;
         uint64_t p = pos[j] >= pos_bias ? pos[j] - pos_bias : 0;   // positions are relative to the 16 B-aligned load base
         if (total && p >= total) p = total - 1;
-        const uint64_t r = total ? find_record(off, n_rec, p) : 0;
-        if (threadIdx.x == 0) s_lo = r; else s_hi = r + 1;
+        // the record of p lies in [coarse[t], coarse[t + 1]]: bound the window with those instead of searching for it
+        const uint64_t t = p >> COARSE_SHIFT;
+        if (threadIdx.x == 0) s_lo = total ? coarse[t] : 0; else s_hi = (total ? coarse[t + 1] : 0) + 1;
     }
     __syncthreads();
     // stage off[s_lo .. s_hi + 1] (the run of records this workgroup's survivors fall into, +1 for the mate lookup)
@@ -414,10 +433,15 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         const size_t keep = sk->n_occ * 8;
         sk->hash.grow_keep(need * 8, keep, ctx->stream);
         sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
+        const uint32_t n_coarse = (uint32_t)(n_bases >> COARSE_SHIFT) + 2;
+        ctx->scratch[5].reserve((size_t)n_coarse * 4);
         ScopedKernelTimer t(ctx, "annotate");
+        hipLaunchKernelGGL(coarse_index_kernel, dim3(grid_for(n_coarse)), dim3(256), 0, ctx->stream, d_off, n_records, n_coarse,
+                           ctx->scratch[5].as<uint32_t>());
         hipLaunchKernelGGL(annotate_reads_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_bases, d_off, n_records,
                            ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, bias, sk->k, sk->avx2_compat,
-                           sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, sk->hash.as<uint64_t>() + sk->n_occ,
+                           sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, ctx->scratch[5].as<uint32_t>(),
+                           sk->hash.as<uint64_t>() + sk->n_occ,
                            sk->recs.as<OccRec>() + sk->n_occ);
         SY_HIP(hipGetLastError());
         sk->n_occ = need;
