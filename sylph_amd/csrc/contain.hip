@@ -42,10 +42,49 @@ __global__ __launch_bounds__(256) void bucket_index_kernel(const uint64_t* __res
     for (uint64_t b = lo; b <= hi && b <= n_buckets; b++) bucket_start[b] = i;
 }
 
-// Probe: one lane per sample k-mer.  Hits are (gid << 32 | count), staged per workgroup in LDS and flushed with
-// one global atomic per workgroup.
+// Probe: one lane per sample k-mer, persistent workgroups striding over 256-k-mer chunks.  Hits are (gid << 32 | count),
+// staged per workgroup in LDS and flushed with one global atomic per ~PROBE_FLUSH hits: with one workgroup per chunk and
+// one atomic each (7.7e3 on a single word for a 2 M-entry sample) the atomic unit (~88 single-address atomics/us on this
+// chip) was 40 % of the kernel.
 constexpr int PROBE_TPB = 256;
-constexpr int PROBE_STAGE = 2048;
+constexpr int PROBE_STAGE = 4096;
+constexpr int PROBE_FLUSH = 2048;
+constexpr int PROBE_GRID = 512;    // measured optimum on MI355X: 256 -> 0.22 ms, 512 -> 0.177, 1024 -> 0.199, one workgroup per chunk -> 0.22
+
+struct HitStage {
+    uint64_t stage[PROBE_STAGE];
+    uint32_t cnt, base;
+};
+__device__ __forceinline__ void hit_stage_init(HitStage& st) {
+    if (threadIdx.x == 0) st.cnt = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void hit_stage_push(HitStage& st, uint64_t hit, uint64_t* __restrict__ hits, uint32_t hit_cap,
+                                               uint32_t* __restrict__ hit_count) {
+    const uint32_t slot = atomicAdd(&st.cnt, 1u);
+    if (slot < PROBE_STAGE) st.stage[slot] = hit;
+    else {                                       // a k-mer shared by thousands of genomes: straight to HBM
+        const uint32_t o = atomicAdd(hit_count, 1u);
+        if (o < hit_cap) hits[o] = hit;
+    }
+}
+// called by all threads after a chunk; flushes when the stage is filling up or `force`
+__device__ __forceinline__ void hit_stage_flush(HitStage& st, bool force, uint64_t* __restrict__ hits, uint32_t hit_cap,
+                                                uint32_t* __restrict__ hit_count) {
+    __syncthreads();
+    const uint32_t n = min(st.cnt, (uint32_t)PROBE_STAGE);
+    __syncthreads();                                     // everyone has read cnt before anyone pushes again
+    if (n == 0 || (!force && n < PROBE_FLUSH)) return;   // uniform: all lanes saw the same cnt
+    if (threadIdx.x == 0) st.base = atomicAdd(hit_count, n);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n; t += PROBE_TPB) {
+        const uint32_t o = st.base + t;
+        if (o < hit_cap) hits[o] = st.stage[t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st.cnt = 0;
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const uint64_t* __restrict__ s_kmers,
                                                           const uint32_t* __restrict__ s_counts, uint32_t n_sample,
@@ -55,46 +94,31 @@ __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const uint64_t* __rest
                                                           uint32_t n_buckets, const uint32_t* __restrict__ glen,
                                                           double min_number_kmers, uint64_t* __restrict__ hits,
                                                           uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
-
-    __shared__ uint64_t stage[PROBE_STAGE];
-    __shared__ uint32_t s_cnt, s_base;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * PROBE_TPB + threadIdx.x;
-    if (i < n_sample) {
-        const uint64_t km = s_kmers[i];
-        const uint32_t cnt = s_counts[i];
-        const uint64_t b = km >> shift;
-        if (cnt != 0 && b < n_buckets) {                                     // contain.rs:634
-            uint32_t lo = bucket_start[b];
-            const uint32_t end = bucket_start[b + 1];
-            uint32_t hi = end;
-            while (lo < hi) {                                                // lower_bound inside the bucket
-                const uint32_t mid = (lo + hi) >> 1;
-                if (db_kmer[mid] < km) lo = mid + 1; else hi = mid;
-            }
-            for (uint32_t j = lo; j < end && db_kmer[j] == km; j++) {
-                const uint32_t g = db_gid[j];
-                if ((double)glen[g] < min_number_kmers) continue;            // contain.rs:627
-                const uint64_t hit = ((uint64_t)g << 32) | cnt;
-                const uint32_t slot = atomicAdd(&s_cnt, 1u);
-                if (slot < PROBE_STAGE) stage[slot] = hit;
-                else {
-                    const uint32_t o = atomicAdd(hit_count, 1u);
-                    if (o < hit_cap) hits[o] = hit;
+    __shared__ HitStage st;
+    hit_stage_init(st);
+    const uint32_t n_chunks = (n_sample + PROBE_TPB - 1) / PROBE_TPB;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t i = chunk * PROBE_TPB + threadIdx.x;
+        if (i < n_sample) {
+            const uint64_t km = s_kmers[i];
+            const uint32_t cnt = s_counts[i];
+            const uint64_t b = km >> shift;
+            if (cnt != 0 && b < n_buckets) {                                     // contain.rs:634
+                uint32_t lo = bucket_start[b];
+                const uint32_t end = bucket_start[b + 1];
+                uint32_t hi = end;
+                while (lo < hi) {                                                // lower_bound inside the bucket
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (db_kmer[mid] < km) lo = mid + 1; else hi = mid;
+                }
+                for (uint32_t j = lo; j < end && db_kmer[j] == km; j++) {
+                    const uint32_t g = db_gid[j];
+                    if ((double)glen[g] < min_number_kmers) continue;            // contain.rs:627
+                    hit_stage_push(st, ((uint64_t)g << 32) | cnt, hits, hit_cap, hit_count);
                 }
             }
         }
-    }
-    __syncthreads();
-    const uint32_t n = min(s_cnt, (uint32_t)PROBE_STAGE);
-    if (n) {
-        if (threadIdx.x == 0) s_base = atomicAdd(hit_count, n);
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < n; t += PROBE_TPB) {
-            const uint32_t o = s_base + t;
-            if (o < hit_cap) hits[o] = stage[t];
-        }
+        hit_stage_flush(st, chunk + gridDim.x >= n_chunks, hits, hit_cap, hit_count);
     }
 }
 
@@ -128,15 +152,14 @@ __global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(
     const uint64_t* __restrict__ t_kmer, const uint32_t* __restrict__ t_gid, const uint32_t* __restrict__ t_bucket_start, int t_shift,
     uint32_t t_n_buckets, const uint32_t* __restrict__ rank, const double* __restrict__ ani, uint32_t* __restrict__ lost,
     uint64_t* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
-    __shared__ uint64_t stage[PROBE_STAGE];
-    __shared__ uint32_t s_cnt, s_base;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * PROBE_TPB + threadIdx.x;
-    if (i < n_sample) {
-        const uint64_t km = s_kmers[i];
-        const uint32_t cnt = s_counts[i];
-        if (cnt != 0) {                                                      // contain.rs:634
+    __shared__ HitStage st;
+    hit_stage_init(st);
+    const uint32_t n_chunks = (n_sample + PROBE_TPB - 1) / PROBE_TPB;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t i = chunk * PROBE_TPB + threadIdx.x;
+        const uint32_t cnt = i < n_sample ? s_counts[i] : 0;
+        if (cnt != 0) {                                                          // contain.rs:634
+            const uint64_t km = s_kmers[i];
             uint32_t a0, a1, t0 = 0, t1 = 0;
             posting_range(db_kmer, bucket_start, shift, n_buckets, km, a0, a1);
             if (a1 > a0) {
@@ -154,28 +177,13 @@ __global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(
                 for (uint32_t j = a0; j < a1; j++) {
                     const uint32_t g = db_gid[j];
                     const uint32_t r = rank[g];
-                    if (r == 0xFFFFFFFFu) continue;                          // not in remaining_genomes
+                    if (r == 0xFFFFFFFFu) continue;                              // not in remaining_genomes
                     if (r != best_rank) { atomicAdd(&lost[g], 1u); continue; }   // contain.rs:639-642
-                        const uint64_t hit = ((uint64_t)g << 32) | cnt;
-                    const uint32_t slot = atomicAdd(&s_cnt, 1u);
-                    if (slot < PROBE_STAGE) stage[slot] = hit;
-                    else {
-                        const uint32_t o = atomicAdd(hit_count, 1u);
-                        if (o < hit_cap) hits[o] = hit;
-                    }
+                    hit_stage_push(st, ((uint64_t)g << 32) | cnt, hits, hit_cap, hit_count);
                 }
             }
         }
-    }
-    __syncthreads();
-    const uint32_t n = min(s_cnt, (uint32_t)PROBE_STAGE);
-    if (n) {
-        if (threadIdx.x == 0) s_base = atomicAdd(hit_count, n);
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < n; t += PROBE_TPB) {
-            const uint32_t o = s_base + t;
-            if (o < hit_cap) hits[o] = stage[t];
-        }
+        hit_stage_flush(st, chunk + gridDim.x >= n_chunks, hits, hit_cap, hit_count);
     }
 }
 
@@ -377,6 +385,11 @@ uint64_t sylph_db_n_genomes(const sylph_db* db) { return db ? db->n_genomes : 0;
 uint64_t sylph_db_n_kmers(const sylph_db* db) { return db ? db->n_kmers : 0; }
 
 // Runs the probe and leaves (cov_off, contain_count, covs) in db->h_res (pinned).  Returns the number of hits.
+static uint32_t probe_grid() {
+    static const uint32_t g = getenv("SYLPH_HIP_PROBE_GRID") ? (uint32_t)atoi(getenv("SYLPH_HIP_PROBE_GRID")) : PROBE_GRID;
+    return std::max<uint32_t>(1, g);
+}
+
 struct ReassignArgs { const uint32_t* passing_gids; const double* passing_ani; uint32_t n_passing; };
 
 static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
@@ -424,13 +437,13 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             {
                 ScopedKernelTimer t(ctx, "probe");
                 if (!re)
-                    hipLaunchKernelGGL(probe_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
+                    hipLaunchKernelGGL(probe_kernel, dim3(std::min<uint32_t>(grid_for64(n, PROBE_TPB), probe_grid())), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
                                        (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
                                        db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->glen.as<uint32_t>(),
                                        min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
                 else {
                     if (attempt) SY_HIP(hipMemsetAsync(db->lost.p, 0, std::max<uint64_t>(1, G) * 4, ctx->stream));
-                    hipLaunchKernelGGL(reassign_kernel, dim3(grid_for64(n, PROBE_TPB)), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
+                    hipLaunchKernelGGL(reassign_kernel, dim3(std::min<uint32_t>(grid_for64(n, PROBE_TPB), probe_grid())), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
                                        (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
                                        db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->t_kmer.as<uint64_t>(),
                                        db->t_gid.as<uint32_t>(), db->t_bucket_start.as<uint32_t>(), db->t_shift, db->t_n_buckets,

@@ -109,19 +109,27 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
     if (in_lds)
         for (uint32_t t = threadIdx.x; t < w_n; t += blockDim.x) s_off[t] = off[w_lo + t];
     __syncthreads();
-    auto OFF = [&](uint64_t r) -> uint64_t { return in_lds ? s_off[r - w_lo] : off[r]; };
     const bool live = i < n && pos[i] >= pos_bias;
     const uint64_t p = live ? pos[i] - pos_bias : ~0ull;
     uint64_t h = live ? hash[i] : 0, rid = 0, m0 = 0, m1 = 0;
     bool valid = false;
     if (p < total) {
-        uint64_t lo = s_lo, hi = s_hi;   // off[lo] <= p < off[hi]
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (OFF(mid) <= p) lo = mid; else hi = mid;
-        }
-        const uint64_t r = lo;
-        const uint64_t start = OFF(r), L = OFF(r + 1) - start;
+        // record search + the (up to five) offsets needed, from LDS when the run fits (the usual case) — kept as two
+        // separate code paths so that the LDS one compiles to ds_read, not to flat loads through a selected pointer
+        uint64_t r, start, L, s1 = 0, s2 = 0, e2 = 0;
+        auto locate = [&](auto OFF) {
+            uint64_t lo = s_lo, hi = s_hi;   // off[lo] <= p < off[hi]
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (OFF(mid) <= p) lo = mid; else hi = mid;
+            }
+            r = lo;
+            start = OFF(r);
+            L = OFF(r + 1) - start;
+            if (paired) { const uint64_t r1 = r & ~1ull; s1 = OFF(r1); s2 = OFF(r1 + 1); e2 = OFF(r1 + 2); }
+        };
+        if (in_lds) locate([&](uint64_t q) -> uint64_t { return s_off[q - w_lo]; });
+        else locate([&](uint64_t q) -> uint64_t { return off[q]; });
         valid = (p - start) < n_hashed_kmers(L, k, avx2_compat, 0);
         if (valid) {
             rid = rec_base + r;
@@ -133,8 +141,6 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
                     if (L >= 66 && L <= 400) { a = bases + start; b = a + L / 2; }
                 } else {
                     // pair_kmer, sketch.rs:659-688: both mates >= 33 bp
-                    const uint64_t r1 = r & ~1ull;
-                    const uint64_t s1 = OFF(r1), s2 = OFF(r1 + 1), e2 = OFF(r1 + 2);
                     if (s2 - s1 >= 33 && e2 - s2 >= 33) { a = bases + s1; b = bases + s2; }
                 }
                 if (a) {
