@@ -15,8 +15,10 @@
  *  - a sylph_ctx may be used from several host threads (rayon workers call concurrently, sketch.rs:313,371;
  *    contain.rs:267,284): calls on one ctx are serialised internally, use one ctx per worker for overlap;
  *  - results never depend on thread interleaving: tables are returned in ascending k-mer order.
- *  - `mem` says where the caller's input arrays live: SYLPH_MEM_HOST (pageable/pinned host memory, copied
- *    H2D by the library) or SYLPH_MEM_DEVICE (already resident in this GPU's HBM; zero-copy).
+ *  - `mem` says where the caller's input arrays live: SYLPH_MEM_HOST (ordinary host memory, copied H2D by the
+ *    library through its own pinned staging buffers), SYLPH_MEM_HOST_PINNED (page-locked memory obtained from
+ *    sylph_pinned_alloc(), copied H2D directly — the host feed of a parser that fills batches in place; accepted
+ *    by sylph_sketch_push[_n]) or SYLPH_MEM_DEVICE (already resident in this GPU's HBM; zero-copy).
  */
 #ifndef SYLPH_HIP_H
 #define SYLPH_HIP_H
@@ -46,6 +48,7 @@ extern "C" {
 
 #define SYLPH_MEM_HOST 0
 #define SYLPH_MEM_DEVICE 1
+#define SYLPH_MEM_HOST_PINNED 2   /* host memory from sylph_pinned_alloc(): copied H2D without the staging memcpy */
 
 typedef struct sylph_ctx sylph_ctx;        /* one GPU + one HIP stream + scratch memory */
 typedef struct sylph_sketch sylph_sketch;  /* a read-sketch session (one sample) */
@@ -54,6 +57,9 @@ typedef struct sylph_db sylph_db;          /* a genome database (shard) resident
 int sylph_version(void);
 const char *sylph_last_error(void);
 void sylph_free(void *p);
+/* Page-locked host memory for SYLPH_MEM_HOST_PINNED inputs (host feed); release with sylph_pinned_free(). */
+int sylph_pinned_alloc(uint64_t bytes, void **out);
+void sylph_pinned_free(void *p);
 
 /* device < 0: current device.  stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a
  * private stream. */

@@ -7,7 +7,7 @@ import numpy as np
 
 SEED_SCALAR, SEED_AVX2_COMPAT = 0, 1
 READS_SINGLE, READS_PAIRED = 0, 1
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 
 _LIB = None
 
@@ -22,7 +22,7 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsylph_hip.so")
 
 
-EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_ctx_create", "sylph_ctx_destroy",
+EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_alloc", "sylph_pinned_free", "sylph_ctx_create", "sylph_ctx_destroy",
            "sylph_ctx_synchronize", "sylph_ctx_set_option", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
            "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_genomes", "sylph_sketch_begin", "sylph_sketch_push", "sylph_sketch_push_n",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
@@ -44,6 +44,9 @@ def load():
     L.sylph_last_error.restype = C.c_char_p
     L.sylph_free.argtypes = [vp]
     L.sylph_free.restype = None
+    L.sylph_pinned_alloc.argtypes = [u64, P(vp)]
+    L.sylph_pinned_free.argtypes = [vp]
+    L.sylph_pinned_free.restype = None
     L.sylph_ctx_create.argtypes = [i32, vp, P(vp)]
     L.sylph_ctx_destroy.argtypes = [vp]
     L.sylph_ctx_destroy.restype = None
@@ -181,6 +184,28 @@ class Context:
         return _take(ok, int(koff[-1]), np.uint64), koff, _take(ot, int(toff[-1]), np.uint64), toff
 
 
+class PinnedBuffer:
+    """Page-locked host memory (sylph_pinned_alloc) exposed as a numpy array, for SYLPH_MEM_HOST_PINNED pushes."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(load().sylph_pinned_alloc(nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self.ptr))
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            load().sylph_pinned_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ReadSketcher:
     """Session for one sample: sketch_sequences_needle (sketch.rs:897) / sketch_pair_sequences --fpr 0 (sketch.rs:771)."""
 
@@ -193,6 +218,12 @@ class ReadSketcher:
     def push(self, bases, rec_off):
         a, off = _bases(bases), _np(rec_off, np.uint64)
         _check(load().sylph_sketch_push(self._h, _ptr(a) if len(a) else None, _ptr(off), len(off) - 1, MEM_HOST))
+
+    def push_pinned(self, buf, bases_len, rec_off_view):
+        """Batch living in page-locked memory from pinned_alloc(): buf (PinnedBuffer) holds the bases in [0, bases_len),
+        rec_off_view is a uint64 numpy view of another PinnedBuffer (n_records + 1 entries)."""
+        off = rec_off_view
+        _check(load().sylph_sketch_push(self._h, C.c_void_p(buf.ptr), C.c_void_p(off.ctypes.data), len(off) - 1, MEM_HOST_PINNED))
 
     def push_device(self, bases_ptr, rec_off_ptr, n_records, n_bases=None):
         """bases_ptr / rec_off_ptr: integer device addresses (e.g. torch tensor .data_ptr()); n_bases = rec_off[n_records]

@@ -241,6 +241,18 @@ int sylph_ctx_synchronize(sylph_ctx* ctx) {
     });
 }
 
+int sylph_pinned_alloc(uint64_t bytes, void** out) {
+    return guarded([&] {
+        SY_REQUIRE(out, "null argument");
+        *out = nullptr;
+        SY_HIP(hipHostMalloc(out, std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+    });
+}
+
+void sylph_pinned_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
     return guarded([&] {
         SY_REQUIRE(ctx && key && value, "null argument");

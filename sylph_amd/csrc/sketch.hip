@@ -397,7 +397,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
                              const uint64_t* n_bases_hint = nullptr) {
     sylph_ctx* ctx = sk->ctx;
     SY_REQUIRE(!sk->finished, "sylph_sketch_push after finish");
-    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE || mem == SYLPH_MEM_HOST_PINNED, "bad mem kind %d", mem);
     SY_REQUIRE(!sk->paired || (n_records % 2 == 0), "paired batches must hold an even number of records");
     if (n_records == 0) return;
     SY_REQUIRE(rec_off, "null rec_off");
@@ -411,14 +411,19 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     const uint8_t* d_bases;
     const uint64_t* d_off;
     uint64_t n_bases;
-    if (mem == SYLPH_MEM_HOST) {
+    if (mem != SYLPH_MEM_DEVICE) {
         SY_REQUIRE(rec_off[0] == 0, "rec_off[0] must be 0");
         n_bases = rec_off[n_records];
         SY_REQUIRE(bases || n_bases == 0, "null bases");
         sk->batch_bases.reserve(n_bases + 64);
         sk->batch_off.reserve((n_records + 1) * 8);
-        ctx->h2d(sk->batch_bases.p, bases, n_bases);
-        ctx->h2d(sk->batch_off.p, rec_off, (n_records + 1) * 8);
+        if (mem == SYLPH_MEM_HOST_PINNED) {   // page-locked by sylph_pinned_alloc: straight DMA, no staging memcpy
+            if (n_bases) SY_HIP(hipMemcpyAsync(sk->batch_bases.p, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
+            SY_HIP(hipMemcpyAsync(sk->batch_off.p, rec_off, (n_records + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            ctx->h2d(sk->batch_bases.p, bases, n_bases);
+            ctx->h2d(sk->batch_off.p, rec_off, (n_records + 1) * 8);
+        }
         d_bases = sk->batch_bases.as<uint8_t>();
         d_off = sk->batch_off.as<uint64_t>();
     } else {
@@ -453,8 +458,8 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         sk->n_occ = need;
     }
     sk->rec_base += n_records;
-    // device staging buffers are reused by the next push: make sure this batch is consumed
-    if (mem == SYLPH_MEM_HOST) SY_HIP(hipStreamSynchronize(ctx->stream));
+    // device staging buffers (and a pinned caller buffer) are reused by the next push: make sure this batch is consumed
+    if (mem != SYLPH_MEM_DEVICE) SY_HIP(hipStreamSynchronize(ctx->stream));
 }
 
 static void sketch_finish_impl(sylph_sketch* sk) {
@@ -661,7 +666,7 @@ int sylph_sketch_push_n(sylph_sketch* sk, const uint8_t* bases, const uint64_t* 
                         int mem) {
     return guarded([&] {
         SY_REQUIRE(sk, "null session");
-        SY_REQUIRE(mem != SYLPH_MEM_HOST || !rec_off || n_records == 0 || rec_off[n_records] == n_bases,
+        SY_REQUIRE(mem == SYLPH_MEM_DEVICE || !rec_off || n_records == 0 || rec_off[n_records] == n_bases,
                    "n_bases does not match rec_off[n_records]");
         sketch_push_impl(sk, bases, rec_off, n_records, mem, &n_bases);
     });

@@ -57,24 +57,6 @@ void parse_line_file(const std::string& file, std::vector<std::string>& out) {  
     while (std::getline(f, line)) out.push_back(line);
 }
 
-// Batches records into one flat buffer + offsets and pushes them to a GPU session.
-struct Batcher {
-    sylph_sketch* sk;
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> off{0};
-    static constexpr size_t BATCH = 512u << 20;
-    void add(const std::string& seq) {
-        bases.insert(bases.end(), seq.begin(), seq.end());
-        off.push_back(bases.size());
-    }
-    void flush(bool force) {
-        if (off.size() == 1 || (!force && bases.size() < BATCH)) return;
-        hip_check(sylph_sketch_push(sk, bases.data(), off.data(), off.size() - 1, SYLPH_MEM_HOST), "sylph_sketch_push");
-        bases.clear();
-        off.assign(1, 0);
-    }
-};
-
 struct Session {   // RAII
     sylph_sketch* sk = nullptr;
     Session(Engine& e, uint64_t c, uint64_t k, bool paired, bool no_dedup) {
@@ -98,24 +80,22 @@ Engine::~Engine() { sylph_ctx_destroy(ctx); }
 // sketch.rs:897-959
 std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
                                                        std::optional<std::string> sample_name, bool no_dedup) {
-    std::unique_ptr<FastxReader> reader;
-    try { reader.reset(new FastxReader(read_file)); }
+    std::unique_ptr<ChunkStream> reader;
+    try { reader.reset(new ChunkStream(read_file)); }
     catch (const Error&) { warn(read_file + " is not a valid fasta/fastq file; skipping."); return std::nullopt; }   // :911-914
     Session s(e, c, k, false, no_dedup);
-    Batcher b{s.sk};
     double mean_read_length = 0., counter = 0.;
-    FastxRecord rec;
+    const uint8_t* seq = nullptr;
+    uint32_t len = 0;
     for (;;) {
-        bool ok;
-        try { ok = reader->next(rec); }
-        catch (const Error&) { warn("File " + read_file + " is not a valid fasta/fastq file"); break; }   // :945
-        if (!ok) break;
-        b.add(rec.seq);
+        const ChunkStream::Kind kind = reader->next(seq, len);
+        if (kind == ChunkStream::ERR) { warn("File " + read_file + " is not a valid fasta/fastq file"); break; }   // :945
+        if (kind == ChunkStream::END) break;
+        e.batch.add(s.sk, seq, len, nullptr, 0, false);
         counter += 1.;                                                       // :941-943
-        mean_read_length = mean_read_length + ((double)rec.seq.size() - mean_read_length) / counter;
-        b.flush(false);
+        mean_read_length = mean_read_length + ((double)len - mean_read_length) / counter;
     }
-    b.flush(true);
+    e.batch.flush(s.sk);
     SequencesSketch out;
     s.finish(out);
     out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
@@ -129,29 +109,27 @@ std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::str
 std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                      uint64_t c, uint64_t k, std::optional<std::string> sample_name,
                                                      bool no_dedup, double /*dedup_fpr*/) {
-    std::unique_ptr<FastxReader> r1, r2;
-    try { r1.reset(new FastxReader(read_file1)); r2.reset(new FastxReader(read_file2)); }
+    std::unique_ptr<ChunkStream> r1, r2;   // the two mate files are parsed/inflated concurrently by their reader threads
+    try { r1.reset(new ChunkStream(read_file1)); r2.reset(new ChunkStream(read_file2)); }
     catch (const Error&) {
         throw Error{1, "Paired end reading failed for '" + read_file1 + "' and '" + read_file2 +
                            "'. Make sure the files are present or the sequences are valid."};   // :781-784
     }
     Session s(e, c, k, true, no_dedup);
-    Batcher b{s.sk};
     double mean_read_length = 0., counter = 0.;
-    FastxRecord rec1, rec2;
+    const uint8_t *s1 = nullptr, *s2 = nullptr;
+    uint32_t l1 = 0, l2 = 0;
     for (;;) {
-        bool ok1, ok2 = false, bad2 = false;
-        try { ok1 = r1->next(rec1); } catch (const Error&) { return std::nullopt; }   // :878-880
-        try { ok2 = r2->next(rec2); } catch (const Error&) { bad2 = true; }
-        if (!ok1) break;                                                     // :881-883
-        if (!ok2 || bad2) continue;                                          // mate 2 missing/invalid: pair skipped
-        b.add(rec1.seq);
-        b.add(rec2.seq);
+        const ChunkStream::Kind k1 = r1->next(s1, l1);
+        if (k1 == ChunkStream::ERR) { e.batch.flush(s.sk); return std::nullopt; }   // :878-880
+        const ChunkStream::Kind k2 = r2->next(s2, l2);
+        if (k1 == ChunkStream::END) break;                                   // :881-883
+        if (k2 != ChunkStream::REC) continue;                                // mate 2 missing/invalid: pair skipped
+        e.batch.add(s.sk, s1, l1, s2, l2, true);
         counter += 1.;                                                       // :824-826 (mate-1 length only)
-        mean_read_length = mean_read_length + ((double)rec1.seq.size() - mean_read_length) / counter;
-        b.flush(false);
+        mean_read_length = mean_read_length + ((double)l1 - mean_read_length) / counter;
     }
-    b.flush(true);
+    e.batch.flush(s.sk);
     SequencesSketch out;
     s.finish(out);
     out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;

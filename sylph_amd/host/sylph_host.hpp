@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <optional>
 #include <string>
 #include <unordered_map>
@@ -71,12 +72,44 @@ class FastxReader {
     std::string pending_;
     bool has_pending_ = false;
 };
+// ---- host feed (feed.cpp): one reader thread per file -> chunks of records; page-locked batches for the GPU ----
+struct RecordChunk {
+    static constexpr uint32_t ERR = 0xFFFFFFFFu;   // len entry of a record that failed to parse
+    std::vector<uint8_t> bases;                    // sequences of the chunk's records, concatenated
+    std::vector<uint32_t> len;
+    std::string first_id;
+};
+class ChunkStream {
+   public:
+    explicit ChunkStream(const std::string& path);   // throws Error like FastxReader; starts the reader thread
+    ~ChunkStream();
+    enum Kind { REC, ERR, END };
+    Kind next(const uint8_t*& seq, uint32_t& len);    // records in file order; seq stays valid until the next call
+   private:
+    struct Impl;
+    std::unique_ptr<Impl> p_;
+};
+class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinned_alloc), pushed with SYLPH_MEM_HOST_PINNED
+   public:
+    static constexpr size_t BATCH_BASES = 256u << 20, BATCH_RECS = 4u << 20;
+    PinnedBatch();
+    ~PinnedBatch();
+    // appends one record (pair = false) or the two mates of a pair, flushing to the session first when the batch is full
+    void add(sylph_sketch* sk, const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb, bool pair);
+    void flush(sylph_sketch* sk);
+   private:
+    void reserve(size_t bases_cap, size_t recs_cap);
+    uint8_t* bases_ = nullptr;
+    uint64_t* off_ = nullptr;
+    size_t cap_bases_ = 0, cap_recs_ = 0, n_bases_ = 0, n_recs_ = 0;
+};
 bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109
 
 // ---- sketching (GPU through the C ABI) ----
 struct Engine {   // one GPU context shared by the drivers
     sylph_ctx* ctx = nullptr;
+    PinnedBatch batch;   // reused by every sample sketched through this engine
     explicit Engine(int device = -1);
     ~Engine();
 };

@@ -515,6 +515,30 @@ def test_device_push_unaligned_batches(ctx):
     assert_same_sketch(g, e)
 
 
+def test_push_from_pinned_host_memory(ctx):
+    """SYLPH_MEM_HOST_PINNED (host feed): batches parsed in place into page-locked buffers, reused between
+    pushes, give the same table as ordinary host memory."""
+    rng = np.random.default_rng(37)
+    genome = random_seq(rng, 80000)
+    recs = make_reads(rng, genome, 4000, 150, dup_frac=0.2, paired=True, ragged=True)
+    b, off = concat(recs)
+    e = O.sketch_reads(b, off, c=20, paired=True)
+    pb, po = S.PinnedBuffer(1 << 20), S.PinnedBuffer(8 * 4001)
+    sk = S.ReadSketcher(ctx, c=20, paired=True)
+    n = len(off) - 1
+    for s0 in range(0, n, 2000):                     # 4 batches through the same two pinned buffers
+        s1 = min(n, s0 + 2000)
+        lo, hi = int(off[s0]), int(off[s1])
+        pb.array[:hi - lo] = b[lo:hi]
+        ov = po.array[:8 * (s1 - s0 + 1)].view(np.uint64)
+        ov[:] = off[s0:s1 + 1] - off[s0]
+        sk.push_pinned(pb, hi - lo, ov)
+    g = sk.finish()
+    sk.close()
+    pb.close(); po.close()
+    assert_same_sketch(g, e)
+
+
 # ---------------------------------------------------------------------------------------------- multi-process
 def test_sharded_containment_two_ranks_one_gpu():
     """Two ranks (gloo rendezvous, both on cuda:0) run the genome-sharded exchange with the real HIP probe and check

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""End-to-end host-feed measurement: synthetic paired FASTQ files on local disk -> `sylph-hip sketch` -> .sylsp,
+plain and gzip, wall clock of the whole command (process start, parsing, H2D, GPU, sketch file written)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "sylph_amd", "sylph-hip")
+
+
+def write_fastq(path, seqs, L):
+    n = len(seqs) // L
+    rec = np.empty((n, 12 + L + 3 + L + 1), dtype=np.uint8)
+    ids = np.arange(n)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("r")
+    for d in range(9):
+        rec[:, 10 - d] = 48 + (ids // 10 ** d) % 10
+    rec[:, 11] = 10
+    rec[:, 12:12 + L] = seqs.reshape(n, L)
+    rec[:, 12 + L:12 + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 12 + L + 3:12 + 2 * L + 3] = ord("I")
+    rec[:, -1] = 10
+    rec.tofile(path)
+    return rec.nbytes
+
+
+def main():
+    n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    L = 150
+    d = "/tmp/feed_bench"
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(1)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=20_000_000)
+    starts = rng.integers(0, len(genome) - 400, size=n_pairs)
+    idx = starts[:, None] + np.arange(L)[None, :]
+    m1 = genome[idx].reshape(-1)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    m2 = comp[genome[(starts[:, None] + 399 - np.arange(L)[None, :])]].reshape(-1)
+    b1 = write_fastq(f"{d}/s_1.fq", m1, L)
+    write_fastq(f"{d}/s_2.fq", m2, L)
+    gbp = 2 * n_pairs * L / 1e9
+    subprocess.run(["gzip", "-1", "-k", "-f", f"{d}/s_1.fq", f"{d}/s_2.fq"], check=True)
+    res = {"gbp": gbp, "fastq_bytes_per_file": b1}
+    for name, a in (("paired_plain", ["-1", f"{d}/s_1.fq", "-2", f"{d}/s_2.fq"]), ("paired_gz", ["-1", f"{d}/s_1.fq.gz", "-2", f"{d}/s_2.fq.gz"]),
+                    ("single_plain", ["-r", f"{d}/s_1.fq"]), ("single_gz", ["-r", f"{d}/s_1.fq.gz"])):
+        best = 1e9
+        for _ in range(2):
+            t = time.perf_counter()
+            p = subprocess.run([BIN, "sketch", *a, "-d", f"{d}/out"], capture_output=True, text=True)
+            dt = time.perf_counter() - t
+            assert p.returncode == 0, p.stderr[-2000:]
+            best = min(best, dt)
+        g = gbp if name.startswith("paired") else gbp / 2
+        res[name] = {"seconds": round(best, 3), "gbp_per_s": round(g / best, 3)}
+    print(res)
+
+
+if __name__ == "__main__":
+    main()
