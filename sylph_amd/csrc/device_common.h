@@ -64,20 +64,29 @@ __device__ __forceinline__ uint32_t codes4_exact(uint32_t w) {
            (byte_to_seq(w >> 24) << 24);
 }
 
-// 4 byte-lane codes -> 8 packed bits.  Multiplying by a constant with four set bits moves the four 2-bit fields
-// into the top byte without overlaps (all partial products land on distinct bit pairs).
-__device__ __forceinline__ uint32_t fwd8(uint32_t c) { return (c * 0x40100401u) >> 24; }                   // c0<<6|c1<<4|c2<<2|c3
-__device__ __forceinline__ uint32_t rev8(uint32_t c) { return ((c ^ 0x03030303u) * 0x01041040u) >> 24; }   // ~c0|~c1<<2|~c2<<4|~c3<<6
-
 // 16 ASCII bases (memory order x,y,z,w) -> F: base j at bits 30-2j (big-endian), R: (3-base j) at bits 2j.
+// The four code dwords hold base 4q+j in byte j of dword q.  A 4x4 byte transpose (8 v_perm_b32) gives D_j = byte q holds
+// base 4q+j; then three shift-ors put the four bases of every byte side by side: that is R's layout directly (after the
+// complement) and F's layout after reversing the bytes.  16 full-rate instructions; the previous formulation used eight
+// v_mul_lo_u32, which issue at quarter rate on gfx950.
 __device__ __forceinline__ void pack16(uint4 v, uint32_t& F, uint32_t& R) {
     uint32_t bad = 0;
     uint32_t c0 = codes4_fast(v.x, bad), c1 = codes4_fast(v.y, bad), c2 = codes4_fast(v.z, bad), c3 = codes4_fast(v.w, bad);
     if (bad) {   // rare: N / lower-case U / raw 1,2,3 / anything else
         c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w);
     }
-    F = (fwd8(c0) << 24) | (fwd8(c1) << 16) | (fwd8(c2) << 8) | fwd8(c3);
-    R = rev8(c0) | (rev8(c1) << 8) | (rev8(c2) << 16) | (rev8(c3) << 24);
+    // __builtin_amdgcn_perm(hi, lo, sel): selector bytes 0-3 pick from lo, 4-7 from hi
+    const uint32_t t0 = __builtin_amdgcn_perm(c1, c0, 0x05010400u);   // c0.0 c1.0 c0.1 c1.1
+    const uint32_t t1 = __builtin_amdgcn_perm(c1, c0, 0x07030602u);   // c0.2 c1.2 c0.3 c1.3
+    const uint32_t t2 = __builtin_amdgcn_perm(c3, c2, 0x05010400u);   // c2.0 c3.0 c2.1 c3.1
+    const uint32_t t3 = __builtin_amdgcn_perm(c3, c2, 0x07030602u);
+    const uint32_t d0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);   // byte q = base 4q+0
+    const uint32_t d1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);   // byte q = base 4q+1
+    const uint32_t d2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    const uint32_t d3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+    R = ~(d0 | (d1 << 2) | (d2 << 4) | (d3 << 6));                     // complement of base 4q+j at bits 8q+2j
+    const uint32_t g = (d0 << 6) | (d1 << 4) | (d2 << 2) | d3;        // base 4q+j at bits 8q+6-2j
+    F = __builtin_amdgcn_perm(0u, g, 0x00010203u);                     // bytes reversed: base b at bits 30-2b
 }
 
 // Number of k-mer start positions of a length-L sequence that the reference hashes.
