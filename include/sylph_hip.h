@@ -173,6 +173,13 @@ int sylph_db_contain(sylph_db *db, const uint64_t *sample_kmers, const uint32_t 
 int sylph_db_contain_view(sylph_db *db, const uint64_t *sample_kmers, const uint32_t *sample_counts, uint64_t n, int mem,
                           double min_number_kmers, const uint32_t **contain_count, const uint64_t **cov_off,
                           const uint32_t **covs, uint64_t *out_n_covs);
+/* The same again with the coverage values stored as the narrowest of 1, 2 or 4 bytes per value that holds the sample's
+ * largest count (*cov_width receives the element size): at GTDB scale the result block shrinks from 7.4 MB to 1.9 MB per
+ * sample, and its PCIe transfer is a visible part of the profile stage.  `get_stats` only ever widens these values. */
+int sylph_db_contain_view_packed(sylph_db *db, const uint64_t *sample_kmers, const uint32_t *sample_counts, uint64_t n,
+                                 int mem, double min_number_kmers, const uint32_t **contain_count,
+                                 const uint64_t **cov_off, const void **covs, uint32_t *cov_width,
+                                 uint64_t *out_n_covs);
 /* Profile reassignment (the `profile` subcommand only).
  * sylph_db_attach_tracked: add the pseudotax_tracked_nonused_kmers of every genome of the shard (types.rs:166; genome g =
  * tracked_kmers[tracked_off[g], tracked_off[g+1])), which take part in the winner table.

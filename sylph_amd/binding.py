@@ -26,7 +26,7 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_ctx_synchronize", "sylph_ctx_set_option", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
            "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_genomes", "sylph_sketch_begin", "sylph_sketch_push", "sylph_sketch_push_n",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
-           "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy"]
+           "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_contain_view_packed", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy"]
 
 
 def load():
@@ -72,6 +72,7 @@ def load():
     L.sylph_db_n_kmers.restype = u64
     L.sylph_db_contain.argtypes = [vp, vp, vp, u64, i32, dbl, vp, vp, P(vp)]
     L.sylph_db_contain_view.argtypes = [vp, vp, vp, u64, i32, dbl, P(vp), P(vp), P(vp), P(u64)]
+    L.sylph_db_contain_view_packed.argtypes = [vp, vp, vp, u64, i32, dbl, P(vp), P(vp), P(vp), P(u32), P(u64)]
     L.sylph_db_attach_tracked.argtypes = [vp, vp, vp, i32]
     L.sylph_db_reassign_view.argtypes = [vp, vp, vp, u64, i32, vp, vp, u32, P(vp), P(vp), P(vp), P(u64), P(vp)]
     L.sylph_db_destroy.argtypes = [vp]
@@ -289,18 +290,20 @@ class Database:
         covs = _take(out, int(off[G]), np.uint32)
         return cc[:G], off, covs
 
-    def contain_view(self, sample_kmers, sample_counts, min_number_kmers=50.0, device_ptrs=False, n=None):
-        """Zero-copy variant: numpy views of the db-owned pinned result buffers, valid until the next contain* call."""
+    def contain_view(self, sample_kmers, sample_counts, min_number_kmers=50.0, device_ptrs=False, n=None, packed=False):
+        """Zero-copy variant: numpy views of the db-owned pinned result buffers, valid until the next contain* call.
+        packed=True: coverage values come back as uint8/uint16/uint32, whichever holds the sample's largest count."""
         G = self.n_genomes
-        pc, po, pv, nh = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        pc, po, pv, nh, cw = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint32(4)
         if device_ptrs:
-            _check(load().sylph_db_contain_view(self._h, C.c_void_p(sample_kmers), C.c_void_p(sample_counts), n, MEM_DEVICE,
-                                                float(min_number_kmers), C.byref(pc), C.byref(po), C.byref(pv), C.byref(nh)))
+            args = (self._h, C.c_void_p(sample_kmers), C.c_void_p(sample_counts), n, MEM_DEVICE, float(min_number_kmers))
         else:
             k, c = _np(sample_kmers, np.uint64), _np(sample_counts, np.uint32)
-            _check(load().sylph_db_contain_view(self._h, _ptr(k) if len(k) else None, _ptr(c) if len(c) else None, len(k),
-                                                MEM_HOST, float(min_number_kmers), C.byref(pc), C.byref(po), C.byref(pv),
-                                                C.byref(nh)))
+            args = (self._h, _ptr(k) if len(k) else None, _ptr(c) if len(c) else None, len(k), MEM_HOST, float(min_number_kmers))
+        if packed:
+            _check(load().sylph_db_contain_view_packed(*args, C.byref(pc), C.byref(po), C.byref(pv), C.byref(cw), C.byref(nh)))
+        else:
+            _check(load().sylph_db_contain_view(*args, C.byref(pc), C.byref(po), C.byref(pv), C.byref(nh)))
 
         def view(ptr, count, ctype, dtype):
             if count == 0:
@@ -308,7 +311,8 @@ class Database:
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).view(dtype)
         off = view(po, G + 1, C.c_uint64, np.uint64)
         cc = view(pc, G, C.c_uint32, np.uint32)
-        covs = view(pv, int(nh.value), C.c_uint32, np.uint32)
+        ct, dt = {1: (C.c_uint8, np.uint8), 2: (C.c_uint16, np.uint16), 4: (C.c_uint32, np.uint32)}[int(cw.value)]
+        covs = view(pv, int(nh.value), ct, dt)
         return cc, off, covs
 
     def attach_tracked(self, tracked_kmers, tracked_off):

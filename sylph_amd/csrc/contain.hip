@@ -225,9 +225,10 @@ __global__ __launch_bounds__(256) void pack_hits32_kernel(const uint64_t* __rest
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const uint64_t h = hits[i]; k32[i] = ((uint32_t)(h >> 32) << cb) | (uint32_t)h; }
 }
-__global__ __launch_bounds__(256) void narrow32_kernel(const uint32_t* __restrict__ k32, uint32_t n, int cb, uint32_t* __restrict__ covs) {
+template <class T>
+__global__ __launch_bounds__(256) void narrow32_kernel(const uint32_t* __restrict__ k32, uint32_t n, int cb, T* __restrict__ covs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) covs[i] = k32[i] & ((1u << cb) - 1u);
+    if (i < n) covs[i] = (T)(k32[i] & ((1u << cb) - 1u));
 }
 __global__ __launch_bounds__(256) void hit_offsets32_kernel(const uint32_t* __restrict__ k32, uint32_t n_hits, uint32_t n_genomes, int cb,
                                                             uint64_t* __restrict__ cov_off, uint32_t* __restrict__ contain_count) {
@@ -392,8 +393,16 @@ static uint32_t probe_grid() {
 
 struct ReassignArgs { const uint32_t* passing_gids; const double* passing_ani; uint32_t n_passing; };
 
+// Layout of the pinned result block: [cov_off (G+1) u64 | contain_count G u32 | kmers_lost G u32 (reassign only) | covs].
+struct ResultLayout {
+    size_t ccount, lost, covs;
+    ResultLayout(uint64_t G, bool reassign) : ccount((G + 1) * 8), lost(ccount + G * 4), covs(lost + (reassign ? G * 4 : 0)) {}
+};
+
+// cov_width: nullptr = coverage values as u32; else in/out — the values are stored with the narrowest of 1, 2 or 4 bytes
+// that holds the sample's largest count (7.4 MB -> 1.9 MB over PCIe per sample at GTDB scale) and the width is returned.
 static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
-                             double min_number_kmers, const ReassignArgs* re = nullptr) {
+                             double min_number_kmers, const ReassignArgs* re = nullptr, uint32_t* cov_width = nullptr) {
     SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
     SY_REQUIRE(n < (1ull << 32), "sample table larger than 2^32-1 entries");
     sylph_ctx* ctx = db->ctx;
@@ -465,6 +474,7 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
     db->ccount.reserve(std::max<uint64_t>(1, G) * 4);
     db->covs.reserve(std::max<size_t>(1, n_hits) * 4);
     const int cb = std::max(1, bit_length(max_count)), gb = std::max(1, bit_length(G));
+    uint32_t width = 4;
     if (n_hits && cb + gb <= 32) {
         db->hits_sorted.reserve((size_t)n_hits * 8);   // two u32 arrays: packed keys, sorted keys
         uint32_t* k32 = db->hits_sorted.as<uint32_t>();
@@ -472,8 +482,9 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
         hipLaunchKernelGGL(pack_hits32_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, db->hits.as<uint64_t>(), n_hits, cb,
                            k32);
         sort_keys_u32(ctx, k32, k32s, n_hits, 0, cb + gb);
-        hipLaunchKernelGGL(narrow32_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb,
-                           db->covs.as<uint32_t>());
+        if (cov_width && cb <= 8) { width = 1; hipLaunchKernelGGL(narrow32_kernel<uint8_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, db->covs.as<uint8_t>()); }
+        else if (cov_width && cb <= 16) { width = 2; hipLaunchKernelGGL(narrow32_kernel<uint16_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, db->covs.as<uint16_t>()); }
+        else hipLaunchKernelGGL(narrow32_kernel<uint32_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, db->covs.as<uint32_t>());
         hipLaunchKernelGGL(hit_offsets32_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, k32s, n_hits, (uint32_t)G, cb,
                            db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
     } else {
@@ -490,7 +501,8 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
     }
     SY_HIP(hipGetLastError());
     // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
-    const size_t need = (G + 1) * 8 + G * 4 + (size_t)n_hits * 4 + (re ? G * 4 : 0) + 64;
+    const ResultLayout lay(G, re != nullptr);
+    const size_t need = lay.covs + (size_t)n_hits * width + 64;
     if (need > db->h_res_cap) {
         if (db->h_res) SY_HIP(hipHostFree(db->h_res));
         db->h_res = nullptr;
@@ -500,11 +512,10 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
     }
     char* h = (char*)db->h_res;
     SY_HIP(hipMemcpyAsync(h, db->cov_off.p, (G + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (G) SY_HIP(hipMemcpyAsync(h + (G + 1) * 8, db->ccount.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_hits)
-        SY_HIP(hipMemcpyAsync(h + (G + 1) * 8 + G * 4, db->covs.p, (size_t)n_hits * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (re && G)
-        SY_HIP(hipMemcpyAsync(h + (G + 1) * 8 + G * 4 + (size_t)n_hits * 4, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (G) SY_HIP(hipMemcpyAsync(h + lay.ccount, db->ccount.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (re && G) SY_HIP(hipMemcpyAsync(h + lay.lost, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_hits) SY_HIP(hipMemcpyAsync(h + lay.covs, db->covs.p, (size_t)n_hits * width, hipMemcpyDeviceToHost, ctx->stream));
+    if (cov_width) *cov_width = width;
     SY_HIP(hipStreamSynchronize(ctx->stream));
     if (!ctx->pending.empty()) profile_collect(ctx);
     return n_hits;
@@ -518,11 +529,28 @@ int sylph_db_contain_view(sylph_db* db, const uint64_t* sample_kmers, const uint
         std::lock_guard<std::mutex> lock(db->ctx->mu);
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
-        const uint64_t G = db->n_genomes;
+        const ResultLayout lay(db->n_genomes, false);
         const char* h = (const char*)db->h_res;
         *cov_off = (const uint64_t*)h;
-        *contain_count = (const uint32_t*)(h + (G + 1) * 8);
-        *covs = (const uint32_t*)(h + (G + 1) * 8 + G * 4);
+        *contain_count = (const uint32_t*)(h + lay.ccount);
+        *covs = (const uint32_t*)(h + lay.covs);
+        if (out_n_covs) *out_n_covs = n_hits;
+    });
+}
+
+int sylph_db_contain_view_packed(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
+                                 double min_number_kmers, const uint32_t** contain_count, const uint64_t** cov_off,
+                                 const void** covs, uint32_t* cov_width, uint64_t* out_n_covs) {
+    return guarded([&] {
+        SY_REQUIRE(db && contain_count && cov_off && covs && cov_width, "null argument");
+        std::lock_guard<std::mutex> lock(db->ctx->mu);
+        DeviceGuard dg(db->ctx->device);
+        const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers, nullptr, cov_width);
+        const ResultLayout lay(db->n_genomes, false);
+        const char* h = (const char*)db->h_res;
+        *cov_off = (const uint64_t*)h;
+        *contain_count = (const uint32_t*)(h + lay.ccount);
+        *covs = h + lay.covs;
         if (out_n_covs) *out_n_covs = n_hits;
     });
 }
@@ -537,12 +565,12 @@ int sylph_db_reassign_view(sylph_db* db, const uint64_t* sample_kmers, const uin
         DeviceGuard dg(db->ctx->device);
         ReassignArgs re{passing_gids, passing_ani, n_passing};
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, 0.0, &re);
-        const uint64_t G = db->n_genomes;
+        const ResultLayout lay(db->n_genomes, true);
         const char* h = (const char*)db->h_res;
         *cov_off = (const uint64_t*)h;
-        *contain_count = (const uint32_t*)(h + (G + 1) * 8);
-        *covs = (const uint32_t*)(h + (G + 1) * 8 + G * 4);
-        *kmers_lost = (const uint32_t*)(h + (G + 1) * 8 + G * 4 + (size_t)n_hits * 4);
+        *contain_count = (const uint32_t*)(h + lay.ccount);
+        *covs = (const uint32_t*)(h + lay.covs);
+        *kmers_lost = (const uint32_t*)(h + lay.lost);
         if (out_n_covs) *out_n_covs = n_hits;
     });
 }
@@ -555,12 +583,13 @@ int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t*
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
         const uint64_t G = db->n_genomes;
+        const ResultLayout lay(G, false);
         const char* h = (const char*)db->h_res;
         uint32_t* hcov = (uint32_t*)malloc(std::max<size_t>(1, n_hits) * 4);
         if (!hcov) throw std::bad_alloc();
         memcpy(cov_off, h, (G + 1) * 8);
-        if (G) memcpy(contain_count, h + (G + 1) * 8, G * 4);
-        if (n_hits) memcpy(hcov, h + (G + 1) * 8 + G * 4, (size_t)n_hits * 4);
+        if (G) memcpy(contain_count, h + lay.ccount, G * 4);
+        if (n_hits) memcpy(hcov, h + lay.covs, (size_t)n_hits * 4);
         *out_covs = hcov;
     });
 }

@@ -154,7 +154,7 @@ def profile_step(db, group, dk_ptr, dc_ptr, n, mine, n_total, device, _cache={})
     """bench.py glue: db is a sylph_amd.Database holding this rank's shard; (dk_ptr, dc_ptr, n) the device-resident
     sample table of this rank."""
     if group.world == 1:
-        cc, off, covs = db.contain_view(dk_ptr, dc_ptr, device_ptrs=True, n=n)   # borrowed pinned views
+        cc, off, covs = db.contain_view(dk_ptr, dc_ptr, device_ptrs=True, n=n, packed=True)   # borrowed pinned views
         return dict(contain_count=cc, cov_off=off, covs=covs, n_occurrences=None)
     key = (id(db), n_total)
     if key not in _cache:

@@ -404,6 +404,11 @@ def check_contain(ctx, db_kmers, goff, sk, sc, min_kmers=50.0):
     cc, off, covs = db.contain(sk, sc, min_number_kmers=min_kmers)
     vcc, voff, vcovs = db.contain_view(sk, sc, min_number_kmers=min_kmers)   # borrowed pinned views: same answer
     assert np.array_equal(vcc, cc) and np.array_equal(voff, off) and np.array_equal(vcovs, covs)
+    pcc, poff, pcovs = db.contain_view(sk, sc, min_number_kmers=min_kmers, packed=True)   # narrowest width that fits
+    big = int(sc.max()) if len(sc) else 0
+    assert pcovs.dtype == (np.uint8 if big < 256 else np.uint16 if big < 65536 else np.uint32) or len(pcovs) == 0 or \
+        pcovs.dtype == np.uint32                                  # (64-bit hit keys always report u32)
+    assert np.array_equal(pcc, cc) and np.array_equal(poff, off) and np.array_equal(pcovs.astype(np.uint32), covs)
     db.close()
     ecc, ecov, _ = O.contain(sk, sc, db_kmers, goff, min_number_kmers=min_kmers)
     assert np.array_equal(cc, ecc)
@@ -442,6 +447,8 @@ def test_contain_synthetic(ctx):
     sc[rng.random(len(sk)) < 0.01] = 3_000_000_000              # large counts survive the 32-bit packing
     for mk in (50.0, 0.0, 1000.5):
         check_contain(ctx, db, goff, sk, sc, min_kmers=mk)
+    check_contain(ctx, db, goff, sk, np.minimum(sc, 200).astype(np.uint32))      # counts fit one byte
+    check_contain(ctx, db, goff, sk, np.minimum(sc, 40000).astype(np.uint32))    # counts fit two bytes
     check_contain(ctx, db, goff, sk[:0], sc[:0])                # empty sample
     check_contain(ctx, db[:0], np.zeros(4, dtype=np.uint64), sk, sc)   # three empty genomes
     check_contain(ctx, db, goff, np.array([5, thr - 1, 2**64 - 1], dtype=np.uint64), np.array([1, 2, 3], dtype=np.uint32))
