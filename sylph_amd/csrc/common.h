@@ -195,6 +195,11 @@ void sort_pairs_u32_u64(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, con
                         size_t n, int begin_bit, int end_bit);
 void sort_pairs_u32_u32(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                         size_t n, int begin_bit, int end_bit);
+// Ordered K1: tiles whose survivors did not fit their slots (low-complexity reads, tandem repeats).  Up to SPILL_MAX_TILES
+// of them are redone into full-size spill regions; more than that sends the batch to the unordered kernel + radix sort.
+constexpr uint32_t SPILL_MAX_TILES = 256;
+struct SpillState { uint32_t n_tiles; uint32_t tiles[SPILL_MAX_TILES]; };
+
 void sort_keys_u32(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, size_t n, int begin_bit, int end_bit);
 void sort_keys_u64(sylph_ctx* ctx, const uint64_t* kin, uint64_t* kout, size_t n, int begin_bit, int end_bit);
 void exclusive_sum_u32(sylph_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);   // out[i] = sum in[0..i)

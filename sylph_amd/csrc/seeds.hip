@@ -188,12 +188,16 @@ template <int K, int HV>
 __global__ __launch_bounds__(TPB) void seeds_slots_kernel(const uint8_t* __restrict__ bases, uint32_t n_bases, uint64_t thr,
                                                           uint32_t n_tiles, uint32_t slot_cap, uint64_t* __restrict__ slot_hash,
                                                           uint32_t* __restrict__ slot_pos, uint32_t* __restrict__ tile_count,
-                                                          uint32_t* __restrict__ overflow) {
+                                                          SpillState* __restrict__ spill, const uint32_t* __restrict__ tile_list,
+                                                          uint32_t* __restrict__ spill_slot_of_tile) {
     __shared__ __attribute__((aligned(16))) uint32_t sF[TILE_WORDS + 8];
     __shared__ __attribute__((aligned(16))) uint32_t sR[TILE_WORDS + 8];
     __shared__ uint32_t s_wave[TPB / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // first pass: it = tile; redo pass (tile_list != nullptr): it = index into the list of tiles that overflowed their slots,
+    // which now get a slot region of TILE_BASES entries each (n_tiles = length of the list)
+    for (uint32_t it = blockIdx.x; it < n_tiles; it += gridDim.x) {
+        const uint32_t tile = tile_list ? tile_list[it] : it;
         const uint64_t tile_base = (uint64_t)tile * TILE_BASES;
 #pragma unroll
         for (int j = 0; j <= WPT; j++) {
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(TPB) void seeds_slots_kernel(const uint8_t* __restr
         }
         uint32_t o = base + x - cnt;
         if (cnt) {
-            const uint64_t out0 = (uint64_t)tile * slot_cap;
+            const uint64_t out0 = (uint64_t)it * slot_cap;
 #pragma unroll
             for (int j = 0; j < WPT; j++) {
                 uint32_t m = masks[j];
@@ -260,22 +264,38 @@ __global__ __launch_bounds__(TPB) void seeds_slots_kernel(const uint8_t* __restr
             }
         }
         if (tid == 0) {
-            tile_count[tile] = min(total, slot_cap);
-            if (total > slot_cap) atomicAdd(overflow, total - slot_cap);
+            if (tile_list) {
+                spill_slot_of_tile[tile] = it;
+            } else {
+                tile_count[tile] = total;          // the true count: a tile above slot_cap is redone into a spill region
+                if (total > slot_cap) {
+                    const uint32_t s = atomicAdd(&spill->n_tiles, 1u);
+                    if (s < SPILL_MAX_TILES) spill->tiles[s] = tile;
+                }
+            }
         }
         __syncthreads();   // s_wave is rewritten by the next tile
     }
 }
 
-// out[tile_off[t] + i] = slot[t * slot_cap + i]: the survivors of the whole batch in ascending position order
+// out[tile_off[t] + i] = slot[t * slot_cap + i]: the survivors of the whole batch in ascending position order; tiles that
+// overflowed their slots are taken from their spill region instead
 __global__ __launch_bounds__(64) void compact_slots_kernel(const uint64_t* __restrict__ slot_hash, const uint32_t* __restrict__ slot_pos,
                                                            const uint32_t* __restrict__ tile_count,
                                                            const uint32_t* __restrict__ tile_off, uint32_t n_tiles, uint32_t slot_cap,
+                                                           const uint64_t* __restrict__ spill_hash, const uint32_t* __restrict__ spill_pos,
+                                                           const uint32_t* __restrict__ spill_slot_of_tile,
                                                            uint32_t* __restrict__ out_pos, uint64_t* __restrict__ out_hash) {
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint32_t n = tile_count[t], d = tile_off[t];
-        const uint64_t s = (uint64_t)t * slot_cap;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_pos[d + i] = slot_pos[s + i]; out_hash[d + i] = slot_hash[s + i]; }
+        const uint64_t* sh = slot_hash + (uint64_t)t * slot_cap;
+        const uint32_t* sp = slot_pos + (uint64_t)t * slot_cap;
+        if (n > slot_cap) {
+            const uint64_t s = (uint64_t)spill_slot_of_tile[t] * TILE_BASES;
+            sh = spill_hash + s;
+            sp = spill_pos + s;
+        }
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_pos[d + i] = sp[i]; out_hash[d + i] = sh[i]; }
     }
 }
 
@@ -310,10 +330,14 @@ uint32_t seeds_slot_capacity(uint32_t c) {
 }
 uint32_t seeds_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + TILE_BASES - 1) / TILE_BASES); }
 
+// tile_list == nullptr: first pass over all tiles of the batch.  Otherwise: redo pass over `n_list` overflowed tiles with
+// TILE_BASES slots each (d_slot_* = the spill regions), recording each tile's spill slot in d_spill_slot_of_tile.
 void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint32_t slot_cap,
-                        uint64_t* d_slot_hash, uint32_t* d_slot_pos, uint32_t* d_tile_count, uint32_t* d_overflow) {
+                        uint64_t* d_slot_hash, uint32_t* d_slot_pos, uint32_t* d_tile_count, SpillState* d_spill,
+                        const uint32_t* d_tile_list, uint32_t n_list, uint32_t* d_spill_slot_of_tile) {
     const uint64_t thr = UINT64_MAX / (uint64_t)c;
-    const uint32_t n_tiles = seeds_n_tiles(n_bases);
+    const uint32_t n_tiles = d_tile_list ? n_list : seeds_n_tiles(n_bases);
+    if (d_tile_list) slot_cap = TILE_BASES;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);
@@ -321,19 +345,23 @@ void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases
     ScopedKernelTimer t(ctx, "seeds");
 #define SY_LAUNCH_SLOTS(KK, HH)                                                                                              \
     hipLaunchKernelGGL((seeds_slots_kernel<KK, HH>), dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles, \
-                       slot_cap, d_slot_hash, d_slot_pos, d_tile_count, d_overflow)
+                       slot_cap, d_slot_hash, d_slot_pos, d_tile_count, d_spill, d_tile_list, d_spill_slot_of_tile)
     if (k == 31) { if (hv) SY_LAUNCH_SLOTS(31, 1); else SY_LAUNCH_SLOTS(31, 0); }
     else if (k == 21) { if (hv) SY_LAUNCH_SLOTS(21, 1); else SY_LAUNCH_SLOTS(21, 0); }
     else throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
 #undef SY_LAUNCH_SLOTS
     SY_HIP(hipGetLastError());
 }
+uint32_t seeds_tile_bases() { return TILE_BASES; }
 
 void launch_compact_slots(sylph_ctx* ctx, const uint64_t* d_slot_hash, const uint32_t* d_slot_pos, const uint32_t* d_tile_count,
-                          const uint32_t* d_tile_off, uint32_t n_tiles, uint32_t slot_cap, uint32_t* d_out_pos, uint64_t* d_out_hash) {
+                          const uint32_t* d_tile_off, uint32_t n_tiles, uint32_t slot_cap, const uint64_t* d_spill_hash,
+                          const uint32_t* d_spill_pos, const uint32_t* d_spill_slot_of_tile, uint32_t* d_out_pos,
+                          uint64_t* d_out_hash) {
     ScopedKernelTimer t(ctx, "compact");
     hipLaunchKernelGGL(compact_slots_kernel, dim3(std::min<uint32_t>(n_tiles, 1u << 16)), dim3(64), 0, ctx->stream, d_slot_hash,
-                       d_slot_pos, d_tile_count, d_tile_off, n_tiles, slot_cap, d_out_pos, d_out_hash);
+                       d_slot_pos, d_tile_count, d_tile_off, n_tiles, slot_cap, d_spill_hash, d_spill_pos, d_spill_slot_of_tile,
+                       d_out_pos, d_out_hash);
     SY_HIP(hipGetLastError());
 }
 

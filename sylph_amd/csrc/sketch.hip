@@ -29,9 +29,13 @@ void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint
 uint32_t seeds_slot_capacity(uint32_t c);
 uint32_t seeds_n_tiles(uint64_t n_bases);
 void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint32_t slot_cap,
-                        uint64_t* d_slot_hash, uint32_t* d_slot_pos, uint32_t* d_tile_count, uint32_t* d_overflow);
+                        uint64_t* d_slot_hash, uint32_t* d_slot_pos, uint32_t* d_tile_count, SpillState* d_spill,
+                        const uint32_t* d_tile_list, uint32_t n_list, uint32_t* d_spill_slot_of_tile);
+uint32_t seeds_tile_bases();
 void launch_compact_slots(sylph_ctx* ctx, const uint64_t* d_slot_hash, const uint32_t* d_slot_pos, const uint32_t* d_tile_count,
-                          const uint32_t* d_tile_off, uint32_t n_tiles, uint32_t slot_cap, uint32_t* d_out_pos, uint64_t* d_out_hash);
+                          const uint32_t* d_tile_off, uint32_t n_tiles, uint32_t slot_cap, const uint64_t* d_spill_hash,
+                          const uint32_t* d_spill_pos, const uint32_t* d_spill_slot_of_tile, uint32_t* d_out_pos,
+                          uint64_t* d_out_hash);
 
 namespace {
 
@@ -340,30 +344,46 @@ uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint64_t n_
         DevBuf &b_sh = ctx->scratch[0], &b_sp = ctx->scratch[1], &b_tc = ctx->scratch[4];
         b_sh.reserve((size_t)n_tiles * slot_cap * 8);
         b_sp.reserve((size_t)n_tiles * slot_cap * 4);
-        b_tc.reserve(((size_t)n_tiles + 1) * 4 * 2 + 16);
+        // [tile_count (n_tiles+1) | tile_off (n_tiles+1) | spill_slot_of_tile (n_tiles) | SpillState]
+        b_tc.reserve(((size_t)n_tiles + 1) * 4 * 3 + sizeof(SpillState) + 16);
         uint32_t* tile_count = b_tc.as<uint32_t>();
         uint32_t* tile_off = tile_count + (n_tiles + 1);
-        uint32_t* d_overflow = tile_off + (n_tiles + 1);
+        uint32_t* spill_slot = tile_off + (n_tiles + 1);
+        SpillState* d_spill = reinterpret_cast<SpillState*>(spill_slot + n_tiles + 1);
         SY_HIP(hipMemsetAsync(tile_count + n_tiles, 0, 4, ctx->stream));   // scan sentinel
-        SY_HIP(hipMemsetAsync(d_overflow, 0, 4, ctx->stream));
+        SY_HIP(hipMemsetAsync(d_spill, 0, 4, ctx->stream));                // n_tiles of the spill list
         launch_seeds_slots(ctx, d_bases, (uint32_t)n_bases, c, k, slot_cap, b_sh.as<uint64_t>(), b_sp.as<uint32_t>(), tile_count,
-                           d_overflow);
+                           d_spill, nullptr, 0, nullptr);
         exclusive_sum_u32(ctx, tile_count, tile_off, (size_t)n_tiles + 1);
-        uint32_t res[2] = {0, 0};   // total survivors, overflowed survivors
+        uint32_t res[2] = {0, 0};   // total survivors, tiles that overflowed their slots
         SY_HIP(hipMemcpyAsync(ctx->pinned, tile_off + n_tiles, 4, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 4, d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 4, d_spill, 4, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
         memcpy(res, ctx->pinned, 8);
         if (!ctx->pending.empty()) profile_collect(ctx);
-        if (res[1] == 0) {
+        if (res[1] <= SPILL_MAX_TILES) {
             if (res[0] == 0) return 0;
+            const uint64_t* sp_h = nullptr;
+            const uint32_t* sp_p = nullptr;
+            if (res[1]) {   // a few tiles (low-complexity reads, repeats) are redone with room for every position
+                DevBuf& b_x = ctx->scratch[7];   // [spill hashes | spill positions]
+                const size_t tb = seeds_tile_bases();
+                b_x.reserve((size_t)res[1] * tb * 12);
+                uint64_t* xh = b_x.as<uint64_t>();
+                uint32_t* xp = reinterpret_cast<uint32_t*>(xh + (size_t)res[1] * tb);
+                ScopedKernelTimer ts(ctx, "seeds_spill");   // (family of its own so that tests can see this path was taken)
+                launch_seeds_slots(ctx, d_bases, (uint32_t)n_bases, c, k, slot_cap, xh, xp, tile_count, d_spill, d_spill->tiles, res[1],
+                                   spill_slot);
+                sp_h = xh;
+                sp_p = xp;
+            }
             ctx->scratch[2].reserve((size_t)res[0] * 4);
             ctx->scratch[3].reserve((size_t)res[0] * 8);
-            launch_compact_slots(ctx, b_sh.as<uint64_t>(), b_sp.as<uint32_t>(), tile_count, tile_off, n_tiles, slot_cap,
-                                 ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>());
+            launch_compact_slots(ctx, b_sh.as<uint64_t>(), b_sp.as<uint32_t>(), tile_count, tile_off, n_tiles, slot_cap, sp_h, sp_p,
+                                 spill_slot, ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>());
             return res[0];
         }
-        // some tile held more survivors than its slots (extreme repeats): redo the batch with the unordered kernel
+        // more overflowing tiles than spill regions (a batch dominated by repeats): redo it with the unordered kernel
     }
     uint64_t cap = n_bases / c + n_bases / (4ull * c) + 65536;
     if (cap > n_bases) cap = n_bases;

@@ -366,6 +366,35 @@ def test_tandem_repeats_overflow_the_tile_slots(ctx):
     assert np.array_equal(g["genome_kmers"], eg["genome_kmers"]) and np.array_equal(g["tracked"], eg["tracked"])
 
 
+def test_low_complexity_reads_spill_locally(ctx):
+    """Runs of low-complexity reads whose k-mer passes the threshold (thousands of survivors in one 16 KiB tile) inside an
+    ordinary sample: the ordered K1 redoes only those tiles into spill regions (no whole-batch fallback); results equal the
+    oracle's.  (ACC)n yields 40 survivors per 150 bp read at c = 20."""
+    rng = np.random.default_rng(29)
+    lowc = np.tile(np.frombuffer(b"ACC", dtype=np.uint8), 50)
+    assert len(O.extract_markers(lowc, c=20)) == 40
+    genome = random_seq(rng, 400000)
+    recs = make_reads(rng, genome, 3000, 150, dup_frac=0.05, ragged=False)
+    for pos in (200, 1700, 1701 + 60):
+        for j in range(60):
+            recs.insert(pos, np.roll(lowc, j % 3).copy())
+    b, off = concat(recs)
+    e = O.sketch_reads(b, off, c=20)
+    assert e["dup_removed"] > 5000                     # 180 reads x 40 identical survivors, nearly all removed as duplicates
+    ctx.profile(True)
+    try:
+        assert_same_sketch(_sketch_gpu_once(ctx, b, off, False, False, S.SEED_AVX2_COMPAT, 20, 31, 1), e)
+        assert ctx.kernel_stats("seeds_spill")[1] == 1   # the overflowing tiles were redone locally ...
+        assert ctx.kernel_stats("seeds")[1] == 2         # ... by the same kernel: no unordered fallback, no radix sort
+    finally:
+        ctx.profile(False)
+    assert_same_sketch(sketch_gpu(ctx, b, off, c=20), e)
+    recs2 = [r for r in recs for _ in (0, 1)]          # as mate pairs (mate 2 = copy of mate 1: the :852 skip rule fires)
+    b, off = concat(recs2)
+    e = O.sketch_reads(b, off, c=20, paired=True)
+    assert_same_sketch(sketch_gpu(ctx, b, off, c=20, paired=True), e)
+
+
 def test_read_sketch_k21(ctx):
     rng = np.random.default_rng(21)
     genome = random_seq(rng, 40000)
