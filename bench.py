@@ -334,7 +334,7 @@ def main():
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "seeds_slots_kernel<31,1>", "achieved": round(achieved, 1), "peak": 8000.0,
+        out["roofline"] = {"bound": "hbm", "kernel": "seeds_slots_kernel<31,1>" if long_mode else "reads_kernel<31,1>", "achieved": round(achieved, 1), "peak": 8000.0,
                            "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
                            "note": "integer-VALU issue bound (38 VALU wave-instructions per k-mer-lane, 91 % VALU busy; profiles/r01_seeds_pmc.md)",

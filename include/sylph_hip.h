@@ -69,8 +69,9 @@ int sylph_ctx_synchronize(sylph_ctx *ctx);
 
 /* Tuning / test knobs (not needed for normal use).  "finish" = "auto" (default: bucket partition + in-LDS replay,
  * falling back to the device-wide sort path when a bucket does not fit), "generic" (always the device-wide path) or
- * "bucket" (error instead of falling back).  "seeds" = "ordered" (default: per-tile slots in position order, falling back
- * when a tile overflows) or "unordered" (LDS-staged atomics + radix sort by position).  "bucket_target" = mean number of
+ * "bucket" (error instead of falling back).  "seeds" = "auto" (default: the read-per-lane kernel for short-read batches, the
+ * position kernel with per-tile ordered slots otherwise), "slots" (always the position kernel with ordered slots) or
+ * "unordered" (position kernel with LDS-staged atomics + radix sort by position).  "bucket_target" = mean number of
  * occurrences per replay bucket aimed for, "16".."256". */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
 

@@ -263,9 +263,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             else if (!strcmp(value, "bucket")) ctx->finish_mode = 2;
             else SY_REQUIRE(false, "finish must be auto|generic|bucket");
         } else if (!strcmp(key, "seeds")) {
-            if (!strcmp(value, "ordered")) ctx->seeds_mode = 0;
+            if (!strcmp(value, "auto") || !strcmp(value, "ordered")) ctx->seeds_mode = 0;
             else if (!strcmp(value, "unordered")) ctx->seeds_mode = 1;
-            else SY_REQUIRE(false, "seeds must be ordered|unordered");
+            else if (!strcmp(value, "slots")) ctx->seeds_mode = 2;
+            else SY_REQUIRE(false, "seeds must be auto|slots|unordered");
         } else if (!strcmp(key, "bucket_target")) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 16 && v <= 256, "bucket_target must be in [16, 256]");

@@ -126,7 +126,7 @@ struct sylph_ctx {
     std::mutex mu;                          // serialises calls on this ctx
     int finish_mode = 0;                    // 0 auto, 1 generic, 2 bucket-only (sylph_ctx_set_option "finish")
     uint32_t bucket_target = 160;           // mean occurrences per replay bucket aimed for ("bucket_target")
-    int seeds_mode = 0;                     // 0 ordered slots (+ fallback), 1 unordered kernel + radix sort ("seeds")
+    int seeds_mode = 0;                     // 0 auto: read-per-lane kernel for short reads, else ordered slots; 1 unordered kernel + radix sort; 2 ordered slots only ("seeds")
     std::atomic<int> refs{1};               // the creator + every live session / db; freed when it drops to 0
     // profiling
     bool profile = false;
@@ -199,6 +199,7 @@ void sort_pairs_u32_u32(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, con
 // of them are redone into full-size spill regions; more than that sends the batch to the unordered kernel + radix sort.
 constexpr uint32_t SPILL_MAX_TILES = 256;
 struct SpillState { uint32_t n_tiles; uint32_t tiles[SPILL_MAX_TILES]; };
+struct ReadsState { uint32_t long_record; SpillState spill; };   // reads.hip: a record too long for the short-read kernel was seen
 
 void sort_keys_u32(sylph_ctx* ctx, const uint32_t* kin, uint32_t* kout, size_t n, int begin_bit, int end_bit);
 void sort_keys_u64(sylph_ctx* ctx, const uint64_t* kin, uint64_t* kout, size_t n, int begin_bit, int end_bit);

@@ -1,0 +1,374 @@
+// reads.hip — seeding + per-read bookkeeping fused for SHORT-READ batches (every record <= READ_HALO = 400 bases): one lane
+// per RECORD instead of one lane per 64 flat positions (seeds.hip), so that
+//   * only the k-mers the reference hashes are hashed — the position kernel also hashes the k-1 positions per read whose
+//     k-mer crosses a record boundary (20 % of a 150 bp read) and throws them away later;
+//   * the record, the validity rule (avx2_seeding.rs:37-44) and the dedup markers (pair_kmer / pair_kmer_single,
+//     sketch.rs:625-688) are known right here, from the packed bases already in LDS: the separate annotate kernel with its
+//     scattered marker loads disappears, and the occurrences leave this kernel as finished 32 B records in file order.
+// Replaces extract_markers + the marker half of the record loops (sketch.rs:897-959, :771-895) for Illumina-like input;
+// long reads and genomes keep the position kernel (boundary waste there is k/L < 1 %).
+//
+// A workgroup owns the records whose start falls into a block of `rt` (16 B-aligned) base coordinates — rt is chosen by the
+// host so that a block holds about 256 records — and loads that block plus a halo of READ_HALO bases on both sides (the end of its last record; mate 1 of a mate 2 that starts the block)
+// as a 2-bit big-endian stream F.  Each lane then walks ITS record: the forward k-mer f and the reverse complement r are
+// rolling registers (f = (f << 2 | b), r = (r >> 2 | (3-b) << 2(k-1))), the next base comes from a 64-bit shift register
+// refilled from LDS every 16 steps, and the canonical hash / threshold test are the same instruction sequences as in the
+// position kernel.  Hits are accumulated as bit masks (one bit per k-mer, 32 k-mers per LDS word), counted, scanned across
+// the workgroup — lanes are in record order, so the scan gives file order — and only then re-hashed and written.
+#include "common.h"
+#include "device_common.h"
+#include "sketch_session.h"
+
+namespace sylph {
+
+namespace {
+
+constexpr int RTPB = 256;
+// A workgroup's block of aligned base coordinates is sized by the host so that it holds about RTPB records (rt = 256 x mean
+// record length, a multiple of 16): with a fixed 16 KiB block only 109 of the 256 lanes had a 150 bp read to work on.
+constexpr int RT_MIN = 4096, RT_MAX = 65536;
+constexpr int RH = 400;                            // halo = longest record taken (pair_kmer_single's upper limit, sketch.rs:923)
+constexpr int RPAD = 32;                           // lanes that idle behind the longest read of their wave read past the data
+constexpr int MASKW = 12;                          // 12 * 32 = 384 >= RH - 20 k-mers per record
+constexpr int OFFS = 600;                          // record offsets staged in LDS
+
+template <int K>
+struct KC {
+    static constexpr uint64_t MASK = (1ull << (2 * K)) - 1;
+};
+
+// 64-bit window of 32 bases starting at stream base `b`: base b in bits 63:62
+__device__ __forceinline__ uint64_t win64(const uint32_t* sF, uint32_t b) {
+    const uint32_t j = b >> 4, ph = (b & 15u) * 2u;
+    const uint64_t x = ((uint64_t)sF[j] << 32) | sF[j + 1];
+    return (x << ph) | ((uint64_t)sF[j + 2] >> (32u - ph));   // ph = 0: second term shifts a 32-bit value by 32 -> 0
+}
+
+// reverse complement of the k-mer in the top 2K bits of x (anything below is ignored): field order reversed by a 64-bit
+// bit reversal, the two bits of every field swapped back, complement = bitwise NOT of a 2-bit code
+template <int K>
+__device__ __forceinline__ uint64_t revcomp_top(uint64_t x) {
+    const uint64_t rev = __brevll(x);
+    const uint64_t y = ((rev & 0x5555555555555555ull) << 1) | ((rev >> 1) & 0x5555555555555555ull);
+    return (~y) & KC<K>::MASK;
+}
+
+// every other base of a 32-base window, first base most significant (the order pair_kmer builds its 16-mers in)
+__device__ __forceinline__ uint32_t even16(uint64_t x) {
+    x &= 0xCCCCCCCCCCCCCCCCull;
+    x = (x | (x << 2)) & 0xF0F0F0F0F0F0F0F0ull;
+    x = (x | (x << 4)) & 0xFF00FF00FF00FF00ull;
+    x = (x | (x << 8)) & 0xFFFF0000FFFF0000ull;
+    x = (x | (x << 16)) & 0xFFFFFFFF00000000ull;
+    return (uint32_t)(x >> 32);
+}
+
+// 16 ASCII bases -> forward stream word (base j at bits 30-2j); the F half of pack16
+__device__ __forceinline__ uint32_t pack16_fwd(uint4 v) {
+    uint32_t bad = 0;
+    uint32_t c0 = codes4_fast(v.x, bad), c1 = codes4_fast(v.y, bad), c2 = codes4_fast(v.z, bad), c3 = codes4_fast(v.w, bad);
+    if (bad) { c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w); }
+    const uint32_t t0 = __builtin_amdgcn_perm(c1, c0, 0x05010400u), t1 = __builtin_amdgcn_perm(c1, c0, 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(c3, c2, 0x05010400u), t3 = __builtin_amdgcn_perm(c3, c2, 0x07030602u);
+    const uint32_t d0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u), d1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    const uint32_t d2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u), d3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+    const uint32_t g = (d0 << 6) | (d1 << 4) | (d2 << 2) | d3;
+    return __builtin_amdgcn_perm(0u, g, 0x00010203u);
+}
+
+// blk_rec[b] = first record whose aligned start coordinate (off + bias) is >= b * rt, for b in [0, n_blk]
+__global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __restrict__ off, uint64_t n_rec, uint32_t bias,
+                                                            uint32_t rt, uint32_t n_entries, uint32_t* __restrict__ blk_rec) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_entries) return;
+    const uint64_t target = (uint64_t)b * rt;
+    uint64_t lo = 0, hi = n_rec;   // first r in [0, n_rec] with off[r] + bias >= target (off is non-decreasing)
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (off[mid] + bias < target) lo = mid + 1; else hi = mid;
+    }
+    blk_rec[b] = (uint32_t)lo;
+}
+
+template <int K, int HV>
+__global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
+                                                     const uint64_t* __restrict__ off, uint64_t n_rec,
+                                                     const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
+                                                     int avx2_compat, int paired, int want_markers, uint64_t rec_base,
+                                                     uint32_t slot_cap, uint64_t* __restrict__ slot_hash,
+                                                     OccRec* __restrict__ slot_rec, uint32_t* __restrict__ blk_count,
+                                                     ReadsState* __restrict__ state, const uint32_t* __restrict__ blk_list,
+                                                     uint32_t* __restrict__ spill_slot_of_blk) {
+    extern __shared__ uint32_t sF[];                                 // (rt + 2 RH) / 16 + 3 stream words + RPAD
+    __shared__ uint64_t s_off[OFFS + 4];
+    const uint32_t n_words = (rt + 2 * RH) / 16 + 3;
+    __shared__ uint32_t s_mask[MASKW][RTPB];
+    __shared__ uint32_t s_wave[RTPB / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t it = blockIdx.x; it < n_blk; it += gridDim.x) {
+        const uint32_t blk = blk_list ? blk_list[it] : it;
+        const int64_t a0 = (int64_t)blk * rt - RH;                 // aligned coordinate of stream base 0 (multiple of 16)
+        for (uint32_t ci = tid; ci < n_words; ci += RTPB) {
+            const int64_t a = a0 + (int64_t)ci * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && (uint64_t)a < n_al) v = *reinterpret_cast<const uint4*>(bases_al + a);
+            sF[ci] = pack16_fwd(v);
+        }
+        const uint64_t R0 = blk_rec[blk], R1 = blk_rec[blk + 1];
+        // offsets of the block's records (+ the mate-1 offset in front of a block that starts with a mate 2, + two behind)
+        const uint64_t w_lo = paired ? (R0 & ~1ull) : R0;
+        const uint64_t w_hi = min(R1 + 2, n_rec);                   // last offset index needed
+        const bool in_lds = (w_hi - w_lo + 1) <= (uint64_t)(OFFS + 4);
+        if (in_lds)
+            for (uint64_t t = tid; t <= w_hi - w_lo; t += RTPB) s_off[t] = off[w_lo + t];
+        __syncthreads();
+        uint32_t base_prev = 0;                                      // survivors of the earlier passes of this block
+        const uint64_t out0 = (uint64_t)it * slot_cap;
+        for (uint64_t pass = R0; pass < R1; pass += RTPB) {         // more than 256 records in a block: only tiny reads
+            const uint64_t r = pass + tid;
+            const bool active = r < R1;
+            uint64_t start = 0, L = 0, s1 = 0, s2 = 0, e2 = 0;
+            if (active) {
+                if (in_lds) {
+                    start = s_off[r - w_lo];
+                    L = s_off[r + 1 - w_lo] - start;
+                    if (paired) { const uint64_t r1 = (r & ~1ull) - w_lo; s1 = s_off[r1]; s2 = s_off[r1 + 1]; e2 = s_off[r1 + 2]; }
+                } else {
+                    start = off[r];
+                    L = off[r + 1] - start;
+                    if (paired) { const uint64_t r1 = r & ~1ull; s1 = off[r1]; s2 = off[r1 + 1]; e2 = off[r1 + 2]; }
+                }
+            }
+            const bool too_long = active && (L > (uint64_t)RH || (paired && (s2 - s1 > (uint64_t)RH || e2 - s2 > (uint64_t)RH)));
+            if (too_long) state->long_record = 1u;                  // the host reruns the batch through the position kernel
+            const uint32_t nh = (active && !too_long) ? (uint32_t)n_hashed_kmers(L, K, avx2_compat, 0) : 0u;
+            const uint32_t rel = active ? (uint32_t)((int64_t)(start + bias) - a0) : 0u;   // stream base of the record
+            uint32_t nh_max = nh;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d));
+            if (nh_max) {
+                // k-mer 0 and the stream behind it
+                uint64_t f = win64(sF, rel) >> (64 - 2 * K);
+                uint64_t rc = revcomp_top<K>(f << (64 - 2 * K));
+                uint64_t cur = win64(sF, rel + K);                   // bases K .. K+31
+                uint32_t jn = (rel + K + 32) >> 4;
+                const uint32_t sh = 32u - ((rel + K + 32) & 15u) * 2u;   // in [2, 32]
+                uint32_t wa = sF[jn], wb = sF[jn + 1];
+                uint32_t mask = 0;
+                for (uint32_t g = 0; g * 16 < nh_max; g++) {
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const uint64_t canon = f < rc ? f : rc;                             // seeding.rs:134-139
+                        const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
+                        asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(h), "s"(thr) : "vcc");
+                        const uint64_t nb = cur >> 62;
+                        cur <<= 2;
+                        f = ((f << 2) | nb) & KC<K>::MASK;
+                        rc = (rc >> 2) | ((3ull - nb) << (2 * K - 2));
+                    }
+                    cur |= (uint32_t)((((uint64_t)wa << 32) | wb) >> sh);   // the next 16 bases behind the 16 left in `cur`
+                    jn++;
+                    wa = wb;
+                    wb = sF[jn + 1];
+                    if (g & 1) { s_mask[g >> 1][tid] = mask; mask = 0; }
+                    else if ((g + 1) * 16 >= nh_max) s_mask[g >> 1][tid] = mask << 16;   // last, half-filled word
+                }
+            }
+            // count this lane's real hits (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)
+            uint32_t cnt = 0;
+            const uint32_t nw = (nh + 31) >> 5;
+            for (uint32_t w = 0; w < nw; w++) {
+                uint32_t m = s_mask[w][tid];
+                const uint32_t left = nh - w * 32;
+                if (left < 32) m &= ~(0xFFFFFFFFu >> left);
+                s_mask[w][tid] = m;
+                cnt += __popc(m);
+            }
+            uint32_t x = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (lane >= (uint32_t)d) x += y;
+            }
+            __syncthreads();
+            if (lane == 63) s_wave[wave] = x;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < RTPB / 64; w++) {
+                const uint32_t t = s_wave[w];
+                if ((uint32_t)w < wave) before += t;
+                total += t;
+            }
+            uint32_t o = base_prev + before + x - cnt;
+            if (cnt) {
+                uint64_t rid = rec_base + r, m0 = 0, m1 = 0;
+                if (want_markers) {
+                    bool has = false;
+                    uint32_t ba = 0, bb = 0;
+                    if (!paired) {
+                        if (L >= 66 && L <= 400) { has = true; ba = rel; bb = rel + (uint32_t)(L / 2); }   // sketch.rs:625-656, :923
+                    } else if (s2 - s1 >= 33 && e2 - s2 >= 33) {                                             // sketch.rs:659-688
+                        has = true;
+                        ba = (uint32_t)((int64_t)(s1 + bias) - a0);
+                        bb = (uint32_t)((int64_t)(s2 + bias) - a0);
+                    }
+                    if (has) {
+                        const uint64_t wa64 = win64(sF, ba), wb64 = win64(sF, bb);
+                        m0 = (uint64_t)even16(wa64) | ((uint64_t)even16(wb64) << 32);
+                        m1 = (uint64_t)even16(wa64 << 2) | ((uint64_t)even16(wb64 << 2) << 32);
+                        rid |= RID_MARKER_BIT;
+                    }
+                }
+                for (uint32_t w = 0; w < nw; w++) {
+                    uint32_t m = s_mask[w][tid];
+                    while (m) {   // highest bit first = ascending k-mer index
+                        const uint32_t b = 31u - (uint32_t)__clz((int)m);
+                        m &= ~(1u << b);
+                        const uint32_t i = w * 32 + (31u - b);
+                        if (o < slot_cap) {
+                            const uint64_t ft = win64(sF, rel + i);
+                            const uint64_t fk = ft >> (64 - 2 * K), rk = revcomp_top<K>(ft);
+                            const uint64_t h = mm_hash64(fk < rk ? fk : rk);
+                            slot_hash[out0 + o] = h;
+                            slot_rec[out0 + o] = OccRec{h, rid, m0, m1};
+                        }
+                        o++;
+                    }
+                }
+            }
+            base_prev += total;
+            __syncthreads();   // s_wave and s_mask are reused by the next pass
+        }
+        if (tid == 0) {
+            if (blk_list) {
+                spill_slot_of_blk[blk] = it;
+            } else {
+                blk_count[blk] = base_prev;      // the true count: a block above slot_cap is redone into a spill region
+                if (base_prev > slot_cap) {
+                    const uint32_t s = atomicAdd(&state->spill.n_tiles, 1u);
+                    if (s < SPILL_MAX_TILES) state->spill.tiles[s] = blk;
+                }
+            }
+        }
+        __syncthreads();   // sF / s_off are rewritten by the next block
+    }
+}
+
+// out[blk_off[b] + i] = slot[b * slot_cap + i] (or its spill region): the occurrences of the batch in file order
+__global__ __launch_bounds__(64) void compact_occ_kernel(const uint64_t* __restrict__ slot_hash, const OccRec* __restrict__ slot_rec,
+                                                         const uint32_t* __restrict__ blk_count, const uint32_t* __restrict__ blk_off,
+                                                         uint32_t n_blk, uint32_t slot_cap, uint32_t spill_cap,
+                                                         const uint64_t* __restrict__ spill_hash, const OccRec* __restrict__ spill_rec,
+                                                         const uint32_t* __restrict__ spill_slot_of_blk,
+                                                         uint64_t* __restrict__ out_hash, OccRec* __restrict__ out_rec) {
+    for (uint32_t b = blockIdx.x; b < n_blk; b += gridDim.x) {
+        const uint32_t n = blk_count[b], d = blk_off[b];
+        const uint64_t* sh = slot_hash + (uint64_t)b * slot_cap;
+        const OccRec* sr = slot_rec + (uint64_t)b * slot_cap;
+        if (n > slot_cap) {
+            const uint64_t s = (uint64_t)spill_slot_of_blk[b] * spill_cap;
+            sh = spill_hash + s;
+            sr = spill_rec + s;
+        }
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_hash[d + i] = sh[i]; out_rec[d + i] = sr[i]; }
+    }
+}
+
+uint32_t grid_for(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
+
+}  // namespace
+
+// Short-read path of sylph_sketch_push: appends the batch's occurrences (hash + OccRec, file order) to the session and
+// returns true; returns false — having appended nothing — when the batch is not for this kernel (a record longer than
+// READ_HALO, or more overflowing blocks than spill regions), and the caller runs the position kernel + annotate instead.
+bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases) {
+    sylph_ctx* ctx = sk->ctx;
+    const uint32_t bias = (uint32_t)((uintptr_t)d_bases & 15);
+    const uint8_t* bases_al = d_bases - bias;
+    const uint64_t n_al = n_bases + bias;
+    // block size: about RTPB records per workgroup
+    uint32_t rt = (uint32_t)std::min<uint64_t>(RT_MAX, std::max<uint64_t>(RT_MIN, (uint64_t)RTPB * n_bases / n_records));
+    rt = (rt + 15u) & ~15u;
+    const uint32_t n_blk = (uint32_t)(n_al / rt) + 1;
+    const uint64_t expect = (uint64_t)rt / sk->c;
+    const uint32_t spill_cap = rt + RH;
+    const uint32_t slot_cap = (uint32_t)std::min<uint64_t>(spill_cap, expect + expect * 3 / 4 + 48);
+    const size_t lds_bytes = ((size_t)(rt + 2 * RH) / 16 + 3 + RPAD) * 4;
+    const uint64_t thr = UINT64_MAX / (uint64_t)sk->c;
+    DevBuf &b_sh = ctx->scratch[0], &b_sr = ctx->scratch[1], &b_meta = ctx->scratch[4];
+    b_sh.reserve((size_t)n_blk * slot_cap * 8);
+    b_sr.reserve((size_t)n_blk * slot_cap * sizeof(OccRec));
+    // [blk_rec (n_blk+1) | blk_count (n_blk+1) | blk_off (n_blk+1) | spill_slot_of_blk (n_blk+1) | ReadsState]
+    b_meta.reserve(((size_t)n_blk + 1) * 4 * 4 + sizeof(ReadsState) + 16);
+    uint32_t* blk_rec = b_meta.as<uint32_t>();
+    uint32_t* blk_count = blk_rec + (n_blk + 1);
+    uint32_t* blk_off = blk_count + (n_blk + 1);
+    uint32_t* spill_slot = blk_off + (n_blk + 1);
+    ReadsState* d_state = reinterpret_cast<ReadsState*>(spill_slot + (n_blk + 1));
+    SY_HIP(hipMemsetAsync(blk_count + n_blk, 0, 4, ctx->stream));   // scan sentinel
+    SY_HIP(hipMemsetAsync(d_state, 0, 8, ctx->stream));             // long_record, spill.n_tiles
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
+    auto launch = [&](uint32_t n_it, uint32_t cap, uint64_t* sh, OccRec* sr, const uint32_t* list) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * 8);
+#define SY_LAUNCH_READS(KK, HH)                                                                                               \
+    hipLaunchKernelGGL((reads_kernel<KK, HH>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
+                       blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sh, sr,      \
+                       blk_count, d_state, list, spill_slot)
+        if (sk->k == 31) { if (hv) SY_LAUNCH_READS(31, 1); else SY_LAUNCH_READS(31, 0); }
+        else { if (hv) SY_LAUNCH_READS(21, 1); else SY_LAUNCH_READS(21, 0); }
+#undef SY_LAUNCH_READS
+        SY_HIP(hipGetLastError());
+    };
+    {
+        HostPhase ph(ctx, "push: reads kernel");
+        {
+            ScopedKernelTimer t(ctx, "annotate");   // the record lookup this kernel replaces
+            hipLaunchKernelGGL(block_records_kernel, dim3(grid_for(n_blk + 1)), dim3(256), 0, ctx->stream, d_off, n_records, bias, rt,
+                               n_blk + 1, blk_rec);
+        }
+        {
+            ScopedKernelTimer t(ctx, "seeds");
+            launch(n_blk, slot_cap, b_sh.as<uint64_t>(), b_sr.as<OccRec>(), nullptr);
+        }
+        exclusive_sum_u32(ctx, blk_count, blk_off, (size_t)n_blk + 1);
+    }
+    uint32_t res[3] = {0, 0, 0};   // total occurrences, long_record flag, overflowing blocks
+    SY_HIP(hipMemcpyAsync(ctx->pinned, blk_off + n_blk, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 4, d_state, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(res, ctx->pinned, 12);
+    if (!ctx->pending.empty()) profile_collect(ctx);
+    if (res[1] || res[2] > SPILL_MAX_TILES) return false;
+    const uint32_t n = res[0];
+    if (n == 0) return true;
+    const uint64_t* sp_h = nullptr;
+    const OccRec* sp_r = nullptr;
+    if (res[2]) {   // a few blocks (low-complexity reads) are redone with room for every position
+        DevBuf& b_x = ctx->scratch[7];   // [spill records | spill hashes]
+        b_x.reserve((size_t)res[2] * spill_cap * (sizeof(OccRec) + 8));
+        OccRec* xr = b_x.as<OccRec>();
+        uint64_t* xh = reinterpret_cast<uint64_t*>(xr + (size_t)res[2] * spill_cap);
+        ScopedKernelTimer ts(ctx, "seeds_spill");
+        ScopedKernelTimer t(ctx, "seeds");
+        launch(res[2], spill_cap, xh, xr, d_state->spill.tiles);
+        sp_h = xh;
+        sp_r = xr;
+    }
+    const uint64_t need = sk->n_occ + n;
+    sk->hash.grow_keep(need * 8, sk->n_occ * 8, ctx->stream);
+    sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
+    {
+        ScopedKernelTimer t(ctx, "compact");
+        hipLaunchKernelGGL(compact_occ_kernel, dim3(std::min<uint32_t>(n_blk, 1u << 16)), dim3(64), 0, ctx->stream, b_sh.as<uint64_t>(),
+                           b_sr.as<OccRec>(), blk_count, blk_off, n_blk, slot_cap, spill_cap, sp_h, sp_r, spill_slot,
+                           sk->hash.as<uint64_t>() + sk->n_occ, sk->recs.as<OccRec>() + sk->n_occ);
+        SY_HIP(hipGetLastError());
+    }
+    sk->n_occ = need;
+    return true;
+}
+
+}  // namespace sylph

@@ -23,6 +23,7 @@
 namespace sylph {
 
 bool finish_bucketed(sylph_sketch* sk);   // replay_lds.hip
+bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases);   // reads.hip
 
 void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint64_t* d_out_hash,
                   uint32_t* d_out_pos, uint32_t out_cap, uint32_t* d_count);
@@ -453,11 +454,16 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         d_bases = bases;
         d_off = rec_off;
     }
+    // short-read batches (mean record length <= 300): one lane per record, seeding + markers fused (reads.hip); it declines
+    // (returns false) when some record is longer than its halo, and the position kernel + annotate below take over
+    bool done = false;
+    if (ctx->seeds_mode == 0 && n_bases < (1ull << 32) - 32 && n_bases <= 300ull * n_records)
+        done = push_short_reads(sk, d_bases, d_off, n_records, n_bases);
     uint32_t* d_count = sk->counters.as<uint32_t>();
     // K1 loads 16 B per lane: start it at the aligned address below d_bases and subtract the bias afterwards (a device
     // pointer into the middle of a larger buffer, e.g. the second batch of a sample, need not be aligned)
     const uint32_t bias = (uint32_t)((uintptr_t)d_bases & 15);
-    const uint32_t n = seeds_sorted_by_pos(ctx, d_bases - bias, n_bases + bias, sk->c, sk->k, d_count);
+    const uint32_t n = done ? 0 : seeds_sorted_by_pos(ctx, d_bases - bias, n_bases + bias, sk->c, sk->k, d_count);
     if (n) {
         HostPhase ph(ctx, "push: grow + annotate");
         const uint64_t need = sk->n_occ + n;

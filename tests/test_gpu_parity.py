@@ -152,16 +152,18 @@ FINISH_MODES = ("auto", "generic")   # bucket + in-LDS replay (with its fallback
 def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_AVX2_COMPAT, c=200, k=31, batches=1):
     """Sketches with BOTH finish paths and insists that they agree before returning the result."""
     res = []
-    for mode, seeds in (("auto", "ordered"), ("generic", "unordered")):   # both finish paths x both K1 output flavours
+    # both finish paths x the three seeding flavours (read-per-lane kernel, position kernel with ordered slots / unordered)
+    for mode, seeds in (("auto", "auto"), ("generic", "unordered"), ("auto", "slots")):
         ctx.set_option("finish", mode)
         ctx.set_option("seeds", seeds)
         try:
             res.append(_sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches))
         finally:
             ctx.set_option("finish", "auto")
-            ctx.set_option("seeds", "ordered")
-    assert np.array_equal(res[0]["kmers"], res[1]["kmers"]) and np.array_equal(res[0]["counts"], res[1]["counts"])
-    assert res[0]["dup_removed"] == res[1]["dup_removed"]
+            ctx.set_option("seeds", "auto")
+    for other in res[1:]:
+        assert np.array_equal(res[0]["kmers"], other["kmers"]) and np.array_equal(res[0]["counts"], other["counts"])
+        assert res[0]["dup_removed"] == other["dup_removed"]
     return res[0]
 
 
