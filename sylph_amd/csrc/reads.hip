@@ -147,31 +147,43 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d));
             if (nh_max) {
-                // k-mer 0 and the stream behind it
-                uint64_t f = win64(sF, rel) >> (64 - 2 * K);
-                uint64_t rc = revcomp_top<K>(f << (64 - 2 * K));
-                uint64_t cur = win64(sF, rel + K);                   // bases K .. K+31
+                // k-mer 0 and the stream behind it.  f and rc live as 32-bit halves so that the rolling update is three
+                // instructions each (shift-or on one half, funnel shift on the other) instead of 64-bit shift + or + masks
+                const uint64_t f0 = win64(sF, rel) >> (64 - 2 * K);
+                const uint64_t r0 = revcomp_top<K>(f0 << (64 - 2 * K));
+                uint32_t flo = (uint32_t)f0, fhi = (uint32_t)(f0 >> 32), rlo = (uint32_t)r0, rhi = (uint32_t)(r0 >> 32);
+                const uint64_t cur0 = win64(sF, rel + K);            // bases K .. K+31
+                uint32_t chi = (uint32_t)(cur0 >> 32), clo = (uint32_t)cur0;   // chi: the next 16 bases, clo: the 16 after them
                 uint32_t jn = (rel + K + 32) >> 4;
                 const uint32_t sh = 32u - ((rel + K + 32) & 15u) * 2u;   // in [2, 32]
                 uint32_t wa = sF[jn], wb = sF[jn + 1];
                 uint32_t mask = 0;
-                for (uint32_t g = 0; g * 16 < nh_max; g++) {
+                constexpr uint32_t HI_MASK = (uint32_t)(KC<K>::MASK >> 32);
+                constexpr int TOP = 2 * K - 2 - 32;                  // bit of the top base inside the high half (K > 16)
+                for (uint32_t g = 0; g * 8 < nh_max; g++) {          // 8 k-mers per group: 150 bp reads (120 k-mers) waste none
+                    const uint32_t cw = chi, cwn = ~chi;
 #pragma unroll
-                    for (int t = 0; t < 16; t++) {
+                    for (int t = 0; t < 8; t++) {
+                        const uint64_t f = ((uint64_t)fhi << 32) | flo, rc = ((uint64_t)rhi << 32) | rlo;
                         const uint64_t canon = f < rc ? f : rc;                             // seeding.rs:134-139
                         const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
                         asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(h), "s"(thr) : "vcc");
-                        const uint64_t nb = cur >> 62;
-                        cur <<= 2;
-                        f = ((f << 2) | nb) & KC<K>::MASK;
-                        rc = (rc >> 2) | ((3ull - nb) << (2 * K - 2));
+                        const uint32_t nb = (cw >> (30 - 2 * t)) & 3u, nbc = (cwn >> (30 - 2 * t)) & 3u;   // v_bfe_u32 each
+                        fhi = __builtin_amdgcn_alignbit(fhi, flo, 30) & HI_MASK;            // (f << 2 | nb) & mask
+                        flo = (flo << 2) | nb;                                              // v_lshl_or_b32
+                        rlo = __builtin_amdgcn_alignbit(rhi, rlo, 2);                       // rc >> 2 | (3 - nb) << 2(K-1)
+                        rhi = (rhi >> 2) | (nbc << TOP);
                     }
-                    cur |= (uint32_t)((((uint64_t)wa << 32) | wb) >> sh);   // the next 16 bases behind the 16 left in `cur`
-                    jn++;
-                    wa = wb;
-                    wb = sF[jn + 1];
-                    if (g & 1) { s_mask[g >> 1][tid] = mask; mask = 0; }
-                    else if ((g + 1) * 16 >= nh_max) s_mask[g >> 1][tid] = mask << 16;   // last, half-filled word
+                    chi <<= 16;                                      // 8 bases consumed
+                    if (g & 1) {                                     // 16 consumed: the stream moves up one word
+                        chi = clo;
+                        clo = (uint32_t)((((uint64_t)wa << 32) | wb) >> sh);   // the 16 bases behind
+                        jn++;
+                        wa = wb;
+                        wb = sF[jn + 1];
+                    }
+                    if ((g & 3) == 3) { s_mask[g >> 2][tid] = mask; mask = 0; }
+                    else if ((g + 1) * 8 >= nh_max) s_mask[g >> 2][tid] = mask << (8 * (3 - (g & 3)));   // last, partly filled word
                 }
             }
             // count this lane's real hits (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)

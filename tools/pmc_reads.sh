@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+out=gpurun_out/pmc_reads; mkdir -p $out
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex 'reads_kernel' --output-format csv -d $out/sq -o s -- python tools/trace_run.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-include-regex 'reads_kernel' --output-format csv -d $out/sq2 -o s -- python tools/trace_run.py > /dev/null 2>&1
+python - <<'PY'
+import csv,glob,collections
+for d in ('sq','sq2'):
+    for f in glob.glob(f'gpurun_out/pmc_reads/{d}/*counter_collection.csv'):
+        agg=collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[r['Counter_Name']].append(float(r['Counter_Value']))
+        for k,v in agg.items(): print(k, ['%.4g'%x for x in v])
+PY
