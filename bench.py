@@ -334,14 +334,17 @@ def main():
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # hashed k-mers per launch: every position (position kernel) or only the in-read k-mers (read-per-lane kernel)
+        ipk = 38 if long_mode else 44
+        hashed = (n_bases if long_mode else max(0, n_bases - n_rec * (k - 1))) // launches_per_step
         out["roofline"] = {"bound": "hbm", "kernel": "seeds_slots_kernel<31,1>" if long_mode else "reads_kernel<31,1>", "achieved": round(achieved, 1), "peak": 8000.0,
                            "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
-                           "note": "integer-VALU issue bound (38 VALU wave-instructions per k-mer-lane, 91 % VALU busy; profiles/r01_seeds_pmc.md)",
+                           "note": "integer-VALU issue bound: 44 (read-per-lane kernel) / 38 (position kernel) VALU wave-instructions per hashed k-mer, 91-94 % VALU busy (profiles/r01_kernel_stats.md SQ section)",
                            # secondary ceiling: VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s
-                           "valu_ceiling": {"instr_per_kmer": 38, "kmers_per_launch": int(n_bases // launches_per_step),
-                                            "min_ms": round(38 * (n_bases // launches_per_step) / (256 * 4 * 16 * 2.4e9) * 1e3, 4),
-                                            "frac": round(38 * (n_bases // launches_per_step) / (256 * 4 * 16 * 2.4e9) * 1e3 / avg_ms, 3)}}
+                           "valu_ceiling": {"instr_per_kmer": ipk, "kmers_per_launch": int(hashed),
+                                            "min_ms": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3, 4),
+                                            "frac": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3 / avg_ms, 3)}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not long_mode:
         try:
             from oracle import oracle as O  # noqa: F401  (cpu_baseline leg only)

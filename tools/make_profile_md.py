@@ -32,20 +32,37 @@ out = [
     "coverage lists, 7.4 MB over PCIe), `fillBufferAligned` are hipMemsetAsync.  The second table aggregates the last 5 steps.", "",
     timeline, "",
     "## PMC passes for the dominant kernel (separate runs, counters only, no trace domains)", "",
-    "    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex seeds_slots_kernel --output-format csv -d gpurun_out/final/pmc_fetch -o s -- python tools/trace_run.py",
-    "    rocprofv3 --pmc WRITE_SIZE --kernel-include-regex seeds_slots_kernel --output-format csv -d gpurun_out/final/pmc_write -o s -- python tools/trace_run.py",
+    "    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex reads_kernel --output-format csv -d gpurun_out/final/pmc_fetch -o s -- python tools/trace_run.py",
+    "    rocprofv3 --pmc WRITE_SIZE --kernel-include-regex reads_kernel --output-format csv -d gpurun_out/final/pmc_write -o s -- python tools/trace_run.py",
     "", "| dispatch | FETCH_SIZE (KB, raw) | WRITE_SIZE (KB, raw) | duration (us) |", "|---|---|---|---|"]
 for i, (a, b) in enumerate(zip(f, w)):
     out.append(f"| {i + 1} | {float(a['Counter_Value']):.1f} | {float(b['Counter_Value']):.1f} | {(int(a['End_Timestamp']) - int(a['Start_Timestamp'])) / 1e3:.1f} |")
 out += ["",
         f"Read bytes = FETCH_SIZE x 1024 x 2 (gfx950 correction for wide coalesced streaming reads, MI355X_MICROARCH.md HBM section) = {fe:.4e} B",
-        f"(1.0000e9 bases + 32 B halo per 16 KiB tile); written = WRITE_SIZE x 1024 = {wr:.3e} B (5.0 M survivors x 12 B into per-tile slots + one",
-        f"count per tile).  HBM bytes per launch = **{fe + wr:.4e} B** vs {rf['algorithmic_bytes_per_launch']:.4e} algorithmic: no wasted re-reads.",
+        f"(1.0000e9 bases + the 2 x 400-base halo per 38,400-base block + record offsets); written = WRITE_SIZE x 1024 = {wr:.3e} B (4.0 M",
+        f"occurrences x 40 B into per-block slots).  HBM bytes per launch = **{fe + wr:.4e} B** vs {rf['algorithmic_bytes_per_launch']:.4e} algorithmic",
+        "(the finished 32 B occurrence record is written here instead of 8 B hash + 4 B position; the annotate kernel's traffic is gone).",
         f"Achieved = algorithmic bytes / {rf['avg_launch_ms']} ms = {rf['achieved']} GB/s = {100 * rf['frac']:.1f} % of the 8 TB/s HBM peak; the kernel is integer-VALU bound",
-        "(r01_seeds_pmc.md): 38 VALU wave-instructions per k-mer-lane x 1.0e9 k-mers / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz) = 0.97 ms at one",
-        "instruction per SIMD per 4 cycles, i.e. the launch runs at ~90 % of the VALU issue ceiling."]
+        "(SQ counters below): every VALU wave-instruction occupies its SIMD for 4 cycles."]
+sq = os.path.join(src, "pmc_sq", "s_counter_collection.csv")
+if os.path.exists(sq):
+    import collections
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(sq)):
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    v = {k: sum(x) / len(x) for k, x in agg.items()}
+    cyc = v.get("GRBM_GUI_ACTIVE", 0) / 8
+    out += ["", "## SQ counters of the dominant kernel (one more separate pass)", "",
+            "    rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex reads_kernel ...",
+            "", "| counter | per launch (mean of 3) |", "|---|---|"]
+    for k2 in sorted(v):
+        out.append(f"| {k2} | {v[k2]:.4g} |")
+    if cyc and v.get("SQ_INSTS_VALU"):
+        out += ["", f"GRBM_GUI_ACTIVE / 8 XCDs = {cyc:.3g} cycles per launch; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles) = "
+                f"**{100 * v['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * cyc):.0f} %**; SQ_INSTS_VALU / (8.0e8 hashed k-mers / 64 lanes) = "
+                f"**{v['SQ_INSTS_VALU'] / 1.25e7:.1f} VALU instructions per hashed k-mer**."]
 open(os.path.join(dst, "r01_kernel_stats.md"), "w").write("\n".join(out) + "\n")
-json.dump({"hbm_bytes_per_launch": int(fe + wr), "kernel": "seeds_slots_kernel<31,1>",
+json.dump({"hbm_bytes_per_launch": int(fe + wr), "kernel": "reads_kernel<31,1>",
            "source": "profiles/r01_kernel_stats.md PMC section (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"},
           open(os.path.join(dst, "seeds_traffic.json"), "w"))
 print("ok", fe + wr)
