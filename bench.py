@@ -329,7 +329,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "seeds_traffic.json")
-        if os.path.exists(tf) and args.workload in ("c2", "c3"):   # measured on this read set (profiles/r01_seeds_traffic.md)
+        if os.path.exists(tf) and args.workload in ("c2", "c3"):   # measured on this read set (profiles/r01_kernel_stats.md, PMC section)
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
