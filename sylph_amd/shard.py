@@ -42,6 +42,15 @@ class TorchGroup:
         self.dist.all_gather(out, t)
         return out
 
+    def all_gather_flat(self, t, out):
+        """One collective into a preallocated [world * n] tensor (no per-step allocations, no stacking)."""
+        try:
+            self.dist.all_gather_into_tensor(out, t)
+        except (RuntimeError, AttributeError, NotImplementedError):   # backend without the flat variant
+            parts = self.all_gather_fixed(t)
+            out.copy_(torch.cat(parts))
+        return out
+
     def all_gather_var(self, t):
         """all-gather of 1-D tensors of different lengths: sizes first, then one padded payload."""
         n = torch.tensor([t.numel()], dtype=torch.int64, device=self.device)
@@ -143,10 +152,13 @@ def gather_counts(group, contain_count, device):
     n = len(contain_count)
     key = (n, str(device))
     if key not in _PIN:
-        _PIN[key] = (torch.empty(n, dtype=torch.int32, pin_memory=torch.cuda.is_available()), torch.empty(n, dtype=torch.int32, device=device))
-    host, dev = _PIN[key]
+        _PIN[key] = (torch.empty(n, dtype=torch.int32, pin_memory=torch.cuda.is_available()), torch.empty(n, dtype=torch.int32, device=device),
+                     torch.empty(group.world * n, dtype=torch.int32, device=device))
+    host, dev, out = _PIN[key]
     host.numpy()[:] = np.asarray(contain_count).view(np.int32)
     dev.copy_(host, non_blocking=True)
+    if hasattr(group, "all_gather_flat"):
+        return group.all_gather_flat(dev, out).view(group.world, n)
     return torch.stack(group.all_gather_fixed(dev))
 
 
