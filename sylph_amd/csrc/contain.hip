@@ -256,6 +256,15 @@ __global__ __launch_bounds__(256) void narrow_kernel(const uint64_t* __restrict_
 
 using namespace sylph;
 
+// Layout of the result block, identical on the device (one buffer, ONE device->host copy) and in pinned host memory:
+// [cov_off (G+1) u64 | contain_count G u32 | covs n_hits x width | pad to 8 | kmers_lost G u32 (reassign only, second copy)].
+struct ResultLayout {
+    size_t ccount = 0, covs = 0, lost = 0, end = 0;
+    ResultLayout() = default;
+    ResultLayout(uint64_t G, uint64_t n_hits, uint32_t width, bool reassign)
+        : ccount((G + 1) * 8), covs(ccount + G * 4), lost((covs + n_hits * width + 7) & ~(size_t)7), end(lost + (reassign ? G * 4 : 0)) {}
+};
+
 struct sylph_db {
     sylph_ctx* ctx;
     uint64_t n_genomes = 0, n_kmers = 0;
@@ -269,14 +278,15 @@ struct sylph_db {
     uint64_t t_n = 0;
     DevBuf rank, ani, lost;        // reassign pass: rank[g] in the passing list (or ~0), ANI per rank, kmers_lost[g]
     // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
-    DevBuf q_kmers, q_counts, hits, hits_sorted, cov_off, ccount, covs, counter;
+    DevBuf q_kmers, q_counts, hits, hits_sorted, res, counter;   // res: device copy of the result block
+    ResultLayout lay;              // layout of the last result
     void* h_res = nullptr;         // pinned host results: [cov_off (G+1) u64 | contain_count G u32 | covs u32]
     size_t h_res_cap = 0;
     ~sylph_db() { if (h_res) (void)hipHostFree(h_res); }
     explicit sylph_db(sylph_ctx* cx)
         : ctx(cx), kmer(cx), gid(cx), bucket_start(cx), glen(cx), t_kmer(cx), t_gid(cx), t_bucket_start(cx), rank(cx),
           ani(cx), lost(cx), q_kmers(cx), q_counts(cx), hits(cx), hits_sorted(cx),
-          cov_off(cx), ccount(cx), covs(cx), counter(cx) {}
+          res(cx), counter(cx) {}
 };
 
 static uint32_t grid_for64(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
@@ -393,12 +403,6 @@ static uint32_t probe_grid() {
 
 struct ReassignArgs { const uint32_t* passing_gids; const double* passing_ani; uint32_t n_passing; };
 
-// Layout of the pinned result block: [cov_off (G+1) u64 | contain_count G u32 | kmers_lost G u32 (reassign only) | covs].
-struct ResultLayout {
-    size_t ccount, lost, covs;
-    ResultLayout(uint64_t G, bool reassign) : ccount((G + 1) * 8), lost(ccount + G * 4), covs(lost + (reassign ? G * 4 : 0)) {}
-};
-
 // cov_width: nullptr = coverage values as u32; else in/out — the values are stored with the narrowest of 1, 2 or 4 bytes
 // that holds the sample's largest count (7.4 MB -> 1.9 MB over PCIe per sample at GTDB scale) and the width is returned.
 static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
@@ -470,11 +474,16 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             cap = n_hits;
         }
     }
-    db->cov_off.reserve((G + 1) * 8);
-    db->ccount.reserve(std::max<uint64_t>(1, G) * 4);
-    db->covs.reserve(std::max<size_t>(1, n_hits) * 4);
     const int cb = std::max(1, bit_length(max_count)), gb = std::max(1, bit_length(G));
     uint32_t width = 4;
+    if (cov_width && n_hits && cb + gb <= 32) width = cb <= 8 ? 1 : cb <= 16 ? 2 : 4;
+    const ResultLayout lay(G, n_hits, width, re != nullptr);
+    db->lay = lay;
+    db->res.reserve(lay.lost + 64);
+    char* d_res = db->res.as<char>();
+    uint64_t* d_cov_off = reinterpret_cast<uint64_t*>(d_res);
+    uint32_t* d_ccount = reinterpret_cast<uint32_t*>(d_res + lay.ccount);
+    void* d_covs = d_res + lay.covs;
     if (n_hits && cb + gb <= 32) {
         db->hits_sorted.reserve((size_t)n_hits * 8);   // two u32 arrays: packed keys, sorted keys
         uint32_t* k32 = db->hits_sorted.as<uint32_t>();
@@ -482,11 +491,11 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
         hipLaunchKernelGGL(pack_hits32_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, db->hits.as<uint64_t>(), n_hits, cb,
                            k32);
         sort_keys_u32(ctx, k32, k32s, n_hits, 0, cb + gb);
-        if (cov_width && cb <= 8) { width = 1; hipLaunchKernelGGL(narrow32_kernel<uint8_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, db->covs.as<uint8_t>()); }
-        else if (cov_width && cb <= 16) { width = 2; hipLaunchKernelGGL(narrow32_kernel<uint16_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, db->covs.as<uint16_t>()); }
-        else hipLaunchKernelGGL(narrow32_kernel<uint32_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, db->covs.as<uint32_t>());
+        if (width == 1) hipLaunchKernelGGL(narrow32_kernel<uint8_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint8_t*)d_covs);
+        else if (width == 2) hipLaunchKernelGGL(narrow32_kernel<uint16_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint16_t*)d_covs);
+        else hipLaunchKernelGGL(narrow32_kernel<uint32_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint32_t*)d_covs);
         hipLaunchKernelGGL(hit_offsets32_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, k32s, n_hits, (uint32_t)G, cb,
-                           db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
+                           d_cov_off, d_ccount);
     } else {
         const uint64_t* d_sorted = nullptr;
         if (n_hits) {
@@ -494,15 +503,14 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
             d_sorted = db->hits_sorted.as<uint64_t>();
             hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
-                               db->covs.as<uint32_t>());
+                               (uint32_t*)d_covs);
         }
         hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits, (uint32_t)G,
-                           db->cov_off.as<uint64_t>(), db->ccount.as<uint32_t>());
+                           d_cov_off, d_ccount);
     }
     SY_HIP(hipGetLastError());
     // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
-    const ResultLayout lay(G, re != nullptr);
-    const size_t need = lay.covs + (size_t)n_hits * width + 64;
+    const size_t need = lay.end + 64;
     if (need > db->h_res_cap) {
         if (db->h_res) SY_HIP(hipHostFree(db->h_res));
         db->h_res = nullptr;
@@ -511,10 +519,8 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
         db->h_res_cap = need + need / 2;
     }
     char* h = (char*)db->h_res;
-    SY_HIP(hipMemcpyAsync(h, db->cov_off.p, (G + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (G) SY_HIP(hipMemcpyAsync(h + lay.ccount, db->ccount.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipMemcpyAsync(h, d_res, lay.covs + (size_t)n_hits * width, hipMemcpyDeviceToHost, ctx->stream));   // one copy
     if (re && G) SY_HIP(hipMemcpyAsync(h + lay.lost, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_hits) SY_HIP(hipMemcpyAsync(h + lay.covs, db->covs.p, (size_t)n_hits * width, hipMemcpyDeviceToHost, ctx->stream));
     if (cov_width) *cov_width = width;
     SY_HIP(hipStreamSynchronize(ctx->stream));
     if (!ctx->pending.empty()) profile_collect(ctx);
@@ -529,7 +535,7 @@ int sylph_db_contain_view(sylph_db* db, const uint64_t* sample_kmers, const uint
         std::lock_guard<std::mutex> lock(db->ctx->mu);
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
-        const ResultLayout lay(db->n_genomes, false);
+        const ResultLayout& lay = db->lay;
         const char* h = (const char*)db->h_res;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
@@ -546,7 +552,7 @@ int sylph_db_contain_view_packed(sylph_db* db, const uint64_t* sample_kmers, con
         std::lock_guard<std::mutex> lock(db->ctx->mu);
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers, nullptr, cov_width);
-        const ResultLayout lay(db->n_genomes, false);
+        const ResultLayout& lay = db->lay;
         const char* h = (const char*)db->h_res;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
@@ -565,7 +571,7 @@ int sylph_db_reassign_view(sylph_db* db, const uint64_t* sample_kmers, const uin
         DeviceGuard dg(db->ctx->device);
         ReassignArgs re{passing_gids, passing_ani, n_passing};
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, 0.0, &re);
-        const ResultLayout lay(db->n_genomes, true);
+        const ResultLayout& lay = db->lay;
         const char* h = (const char*)db->h_res;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
@@ -583,7 +589,7 @@ int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t*
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
         const uint64_t G = db->n_genomes;
-        const ResultLayout lay(G, false);
+        const ResultLayout& lay = db->lay;
         const char* h = (const char*)db->h_res;
         uint32_t* hcov = (uint32_t*)malloc(std::max<size_t>(1, n_hits) * 4);
         if (!hcov) throw std::bad_alloc();

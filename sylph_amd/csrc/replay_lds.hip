@@ -26,18 +26,18 @@ constexpr int CAP_SMALL = 256, RTPB_SMALL = 128;
 constexpr int CAP_LARGE = 1024, RTPB_LARGE = 256;
 constexpr int IDX_BITS = 10;         // arrival index inside a bucket (< CAP_LARGE)
 
-// boff[b] = first position (in the array sorted by the bucket bits) whose bucket is >= b, for b in [0, B]
-__global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __restrict__ bk, const uint32_t* __restrict__ p_n,
-                                                            uint32_t B, uint32_t* __restrict__ boff) {
+// boff[b] = first position (in the array sorted by bucket id) whose bucket is >= b, for b in [0, B].  Invalid occurrences
+// carry bucket id B and sort last, so boff[B] is also the number of valid occurrences (read by the replay kernels from
+// device memory: no host round trip before the replay).
+__global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __restrict__ bk, uint32_t n_all, uint32_t B,
+                                                            uint32_t* __restrict__ boff) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = *p_n;   // number of valid occurrences, still on the device: no host round trip before the replay
-    if (i > n) return;
+    if (i > n_all) return;
     const uint32_t lo = (i == 0) ? 0 : bk[i - 1] + 1;
-    const uint32_t hi = (i == n) ? B : bk[i];
-    for (uint32_t b = lo; b <= hi && b <= B; b++) boff[b] = i;
+    const uint32_t hi = (i == n_all) ? B : min(bk[i], B);
+    for (uint32_t b = lo; b <= hi; b++) boff[b] = i;
 }
 
-// bucket id of every occurrence (B = "invalid", sorts last) + identity permutation
 // Bucket of a hash: hs = hash >> sh (its 32 most significant bits below the threshold), b = (hs * mult) >> 32 — B
 // equal ranges for ANY B (not only powers of two), monotone in the hash.  Inverse used by the replay kernel: the
 // smallest hs of bucket b is ceil(b * 2^32 / mult).
@@ -53,16 +53,6 @@ __global__ __launch_bounds__(256) void bucket_key_kernel(const uint64_t* __restr
     const uint64_t h = hash[i];
     bk[i] = (h == INVALID_HASH) ? B : bucket_of(h, bm);
     idx[i] = i;
-}
-
-// number of valid occurrences = first sorted position whose bucket id is B
-__global__ void count_valid_bk_kernel(const uint32_t* __restrict__ bk, uint32_t n, uint32_t B, uint32_t* __restrict__ out) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (bk[mid] < B) lo = mid + 1; else hi = mid;
-    }
-    *out = lo;
 }
 
 // exclusive prefix sum of one value per lane across the workgroup (4 waves); total returned through *total
@@ -100,13 +90,13 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave,
 // in 54 bits (bm.composite, decided by the host; else — tiny samples — the two-part comparison is spelled out).  Records are then written straight to their sorted slots.
 // Handles buckets with min_n < n <= CAP; larger ones bump `overflow` (when count_overflow) and are left to the caller.
 template <int CAP, int RTPB>
-__global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
+__device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
                                                              const uint32_t* __restrict__ boff,
                                                              const uint32_t* __restrict__ p_nv, int paired, int no_dedup,
                                                              uint32_t cutoff, BucketMap bm, uint64_t* __restrict__ tmp_k,
                                                              uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
                                                              uint32_t* __restrict__ removed_b,
-                                                             uint32_t* __restrict__ overflow, uint32_t min_n, int count_overflow,
+                                                             uint32_t* __restrict__ overflow, uint32_t* __restrict__ large_list,
                                                              int dbg_stage) {
     constexpr int ITEMS = CAP / RTPB;     // records per lane
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
@@ -114,14 +104,21 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     __shared__ uint8_t s_fl[CAP];         // bit0 skip, bit1 would-be-dropped
     __shared__ uint16_t s_a[CAP + 2], s_b[CAP + 2];   // exclusive counts <= CAP
     __shared__ uint32_t s_wave[RTPB / 64];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t nv = *p_nv;
     const uint32_t first = boff[b], last = boff[b + 1];
     const uint32_t n = last - first;
-    if (last > nv || first > last) { if (tid == 0 && count_overflow) atomicAdd(overflow, 1u); return; }   // defensive
-    if (n <= min_n) return;               // empty (n_distinct was zeroed by the host) or done by the previous launch
-    // too large for this configuration: the next launch, or (count_overflow) the generic path, redoes it
-    if (n > CAP) { if (tid == 0 && count_overflow) atomicAdd(overflow, 1u); return; }
+    if (last > nv || first > last) { if (tid == 0) atomicAdd(overflow, 1u); return; }   // defensive: inconsistent bounds
+    if (n == 0) return;                   // (n_distinct was zeroed by the host)
+    // too large for this configuration: queue it for the large one (large_list != nullptr: [0] = count, [1..] = buckets),
+    // or tell the host that the generic path has to redo the sample
+    if (n > CAP) {
+        if (tid == 0) {
+            if (large_list) large_list[1 + atomicAdd(&large_list[0], 1u)] = b;
+            else atomicAdd(overflow, 1u);
+        }
+        return;
+    }
     // ---- gather (through the partition permutation, one 32 B sector per occurrence) + stable sort by hash ------------
     uint64_t* s_key = s_m0;               // keys live in s_m0 until the sorted records are written
     const bool composite = bm.composite != 0;
@@ -321,6 +318,35 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
     if (tid == 0) { n_distinct[b] = total_heads; removed_b[b] = total_removed; }
 }
 
+template <int CAP, int RTPB>
+__global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
+                                                             const uint32_t* __restrict__ boff, const uint32_t* __restrict__ p_nv,
+                                                             int paired, int no_dedup, uint32_t cutoff, BucketMap bm,
+                                                             uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
+                                                             uint32_t* __restrict__ n_distinct, uint32_t* __restrict__ removed_b,
+                                                             uint32_t* __restrict__ overflow, uint32_t* __restrict__ large_list,
+                                                             int dbg_stage) {
+    replay_bucket<CAP, RTPB>(blockIdx.x, recs, perm, boff, p_nv, paired, no_dedup, cutoff, bm, tmp_k, tmp_c, n_distinct, removed_b,
+                             overflow, large_list, dbg_stage);
+}
+
+// second configuration: a fixed, small grid walks the (usually empty) list of buckets the first one queued
+template <int CAP, int RTPB>
+__global__ __launch_bounds__(RTPB) void bucket_replay_list_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
+                                                                  const uint32_t* __restrict__ boff, const uint32_t* __restrict__ p_nv,
+                                                                  int paired, int no_dedup, uint32_t cutoff, BucketMap bm,
+                                                                  uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
+                                                                  uint32_t* __restrict__ n_distinct, uint32_t* __restrict__ removed_b,
+                                                                  uint32_t* __restrict__ overflow, const uint32_t* __restrict__ large_list,
+                                                                  int dbg_stage) {
+    const uint32_t n_large = large_list[0];
+    for (uint32_t i = blockIdx.x; i < n_large; i += gridDim.x) {
+        replay_bucket<CAP, RTPB>(large_list[1 + i], recs, perm, boff, p_nv, paired, no_dedup, cutoff, bm, tmp_k, tmp_c, n_distinct,
+                                 removed_b, overflow, nullptr, dbg_stage);
+        __syncthreads();   // the LDS arrays are reused by the next bucket
+    }
+}
+
 __global__ __launch_bounds__(1024) void sum_removed_kernel(const uint32_t* __restrict__ removed_b, uint32_t B,
                                                            unsigned long long* __restrict__ out) {
     __shared__ unsigned long long s[16];
@@ -379,15 +405,17 @@ bool finish_bucketed(sylph_sketch* sk) {
     b_tmpk.reserve((size_t)n_all * 8);
     b_tmpc.reserve((size_t)n_all * 4);
     b_small.reserve(64);
-    b_bk.reserve((size_t)(B + 2) * 4 * 4);      // boff | n_distinct | removed | d_off   (each B+2)
+    b_bk.reserve((size_t)(B + 2) * 4 * 5);      // boff | large_list | n_distinct | removed | d_off   (each B+2)
     uint32_t* boff = b_bk.as<uint32_t>();
-    uint32_t* n_distinct = boff + (B + 2);
+    uint32_t* large_list = boff + (B + 2);      // [0] = number of buckets queued for the large configuration, [1..] = ids
+    uint32_t* n_distinct = large_list + (B + 2);
     uint32_t* removed_b = n_distinct + (B + 2);
     uint32_t* d_off = removed_b + (B + 2);
     unsigned long long* d_removed = b_small.as<unsigned long long>();
     uint32_t* d_overflow = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 8);
-    uint32_t* d_nv = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 16);
+    const uint32_t* d_nv = boff + B;            // boff[B] = number of valid occurrences
     SY_HIP(hipMemsetAsync(b_small.p, 0, 64, ctx->stream));
+    SY_HIP(hipMemsetAsync(large_list, 0, 4, ctx->stream));
     SY_HIP(hipMemsetAsync(n_distinct, 0, (size_t)(B + 2) * 4 * 2, ctx->stream));   // n_distinct and removed
     // partition: stable radix sort of (bucket id -> occurrence index) on bit_length(B) bits (2-3 passes of 4-byte keys
     // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
@@ -401,20 +429,19 @@ bool finish_bucketed(sylph_sketch* sk) {
         hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(n_all)), dim3(256), 0, ctx->stream, sk->hash.as<uint64_t>(), n_all, bm,
                            B, bk_in, b_idx.as<uint32_t>());
         sort_pairs_u32_u32(ctx, bk_in, bk_sorted, b_idx.as<uint32_t>(), b_perm.as<uint32_t>(), n_all, 0, bit_length(B));
-        hipLaunchKernelGGL(count_valid_bk_kernel, dim3(1), dim3(1), 0, ctx->stream, bk_sorted, n_all, B, d_nv);
         {
             ScopedKernelTimer t(ctx, "replay");
-            hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)n_all + 1)), dim3(256), 0, ctx->stream, bk_sorted, d_nv, B,
+            hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)n_all + 1)), dim3(256), 0, ctx->stream, bk_sorted, n_all, B,
                                boff);
             const int dbg = getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0;
             const uint32_t cutoff = sk->paired ? 0u : 4u;   // MAX_DEDUP_COUNT, constants.rs:14
             hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
                                sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
-                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, 0u, 0, dbg);
-            hipLaunchKernelGGL((bucket_replay_kernel<CAP_LARGE, RTPB_LARGE>), dim3(B), dim3(RTPB_LARGE), 0, ctx->stream,
-                               sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
-                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow,
-                               (uint32_t)CAP_SMALL, 1, dbg);
+                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, large_list, dbg);
+            hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(B, 256u)),
+                               dim3(RTPB_LARGE), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
+                               sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
+                               d_overflow, large_list, dbg);
             hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
         }
         exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
