@@ -97,7 +97,7 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
                                                              uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
                                                              uint32_t* __restrict__ removed_b,
                                                              uint32_t* __restrict__ overflow, uint32_t* __restrict__ large_list,
-                                                             int dbg_stage) {
+                                                             uint32_t* __restrict__ ovf_list, int dbg_stage) {
     constexpr int ITEMS = CAP / RTPB;     // records per lane
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
     __shared__ uint16_t s_seg[CAP];       // first sorted position of the k-mer each sorted position belongs to
@@ -110,12 +110,12 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
     const uint32_t n = last - first;
     if (last > nv || first > last) { if (tid == 0) atomicAdd(overflow, 1u); return; }   // defensive: inconsistent bounds
     if (n == 0) return;                   // (n_distinct was zeroed by the host)
-    // too large for this configuration: queue it for the large one (large_list != nullptr: [0] = count, [1..] = buckets),
-    // or tell the host that the generic path has to redo the sample
+    // too large for this configuration: queue it for the large one (large_list: [0] = count, [1..] = buckets), or for the
+    // host, which sends the occurrences of such buckets through the device-wide path (ovf_list, same layout)
     if (n > CAP) {
         if (tid == 0) {
             if (large_list) large_list[1 + atomicAdd(&large_list[0], 1u)] = b;
-            else atomicAdd(overflow, 1u);
+            else ovf_list[1 + atomicAdd(&ovf_list[0], 1u)] = b;
         }
         return;
     }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
                                                              uint32_t* __restrict__ overflow, uint32_t* __restrict__ large_list,
                                                              int dbg_stage) {
     replay_bucket<CAP, RTPB>(blockIdx.x, recs, perm, boff, p_nv, paired, no_dedup, cutoff, bm, tmp_k, tmp_c, n_distinct, removed_b,
-                             overflow, large_list, dbg_stage);
+                             overflow, large_list, nullptr, dbg_stage);
 }
 
 // second configuration: a fixed, small grid walks the (usually empty) list of buckets the first one queued
@@ -338,11 +338,11 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_list_kernel(const OccRec* 
                                                                   uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
                                                                   uint32_t* __restrict__ n_distinct, uint32_t* __restrict__ removed_b,
                                                                   uint32_t* __restrict__ overflow, const uint32_t* __restrict__ large_list,
-                                                                  int dbg_stage) {
+                                                                  uint32_t* __restrict__ ovf_list, int dbg_stage) {
     const uint32_t n_large = large_list[0];
     for (uint32_t i = blockIdx.x; i < n_large; i += gridDim.x) {
         replay_bucket<CAP, RTPB>(large_list[1 + i], recs, perm, boff, p_nv, paired, no_dedup, cutoff, bm, tmp_k, tmp_c, n_distinct,
-                                 removed_b, overflow, nullptr, dbg_stage);
+                                 removed_b, overflow, nullptr, ovf_list, dbg_stage);
         __syncthreads();   // the LDS arrays are reused by the next bucket
     }
 }
@@ -372,6 +372,72 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t* __r
         const uint32_t n = n_distinct[b], s = boff[b], d = d_off[b];
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_k[d + i] = tmp_k[s + i]; out_c[d + i] = tmp_c[s + i]; }
     }
+}
+
+// ---- buckets beyond the large configuration: their occurrences go through the device-wide path as one small sample --------
+// sub_off[i] = occurrences of the listed buckets before bucket i (single workgroup; the list is short); sub_off[m] = total
+__global__ __launch_bounds__(1024) void ovf_offsets_kernel(const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ boff,
+                                                           uint32_t* __restrict__ sub_off) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t m = ovf_list[0], tid = threadIdx.x;
+    const uint32_t per = (m + 1023) / 1024;
+    uint32_t sum = 0;
+    for (uint32_t i = tid * per; i < min(m, (tid + 1) * per); i++) { const uint32_t b = ovf_list[1 + i]; sum += boff[b + 1] - boff[b]; }
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 1024; t++) { const uint32_t v = s_part[t]; s_part[t] = run; run += v; }
+        sub_off[m] = run;
+    }
+    __syncthreads();
+    uint32_t run = s_part[tid];
+    for (uint32_t i = tid * per; i < min(m, (tid + 1) * per); i++) {
+        const uint32_t b = ovf_list[1 + i];
+        sub_off[i] = run;
+        run += boff[b + 1] - boff[b];
+    }
+}
+
+// copies the occurrences of listed bucket i (file order inside the bucket) to sub_*[sub_off[i] ..)
+__global__ __launch_bounds__(256) void ovf_gather_kernel(const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ sub_off,
+                                                         const uint32_t* __restrict__ boff, const uint32_t* __restrict__ perm,
+                                                         const OccRec* __restrict__ recs, uint64_t* __restrict__ sub_hash,
+                                                         OccRec* __restrict__ sub_recs) {
+    const uint32_t b = ovf_list[1 + blockIdx.x], first = boff[b], n = boff[b + 1] - first, o = sub_off[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        const OccRec r = recs[perm[first + j]];
+        sub_hash[o + j] = r.hash;
+        sub_recs[o + j] = r;
+    }
+}
+
+// the (k-mer, count) rows the device-wide path produced for listed bucket i go to the bucket's slots of the temporary table
+__global__ __launch_bounds__(256) void ovf_patch_kernel(const uint32_t* __restrict__ ovf_list, BucketMap bm,
+                                                        const uint64_t* __restrict__ sub_k, const uint32_t* __restrict__ sub_c,
+                                                        uint32_t n_sub_out, const uint32_t* __restrict__ boff,
+                                                        uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
+                                                        uint32_t* __restrict__ n_distinct) {
+    const uint32_t b = ovf_list[1 + blockIdx.x];
+    auto lower = [&](uint64_t key) {   // first row with k-mer >= key
+        uint32_t lo = 0, hi = n_sub_out;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sub_k[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    // rows of bucket b = rows with k-mer in [smallest hash of bucket b, smallest hash of bucket b + 1) (inverse of bucket_of)
+    __shared__ uint32_t s_lo, s_hi;
+    if (threadIdx.x == 0) {
+        auto lo_hash = [&](uint32_t bb) { return ((((uint64_t)bb << 32) + bm.mult - 1u) / bm.mult) << bm.sh; };
+        s_lo = lower(lo_hash(b));
+        s_hi = (b + 1 < bm.B) ? lower(lo_hash(b + 1)) : n_sub_out;
+    }
+    __syncthreads();
+    const uint32_t lo = s_lo, n = s_hi - s_lo, d = boff[b];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { tmp_k[d + i] = sub_k[lo + i]; tmp_c[d + i] = sub_c[lo + i]; }
+    if (threadIdx.x == 0) n_distinct[b] = n;
 }
 
 uint32_t grid_of(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
@@ -405,10 +471,11 @@ bool finish_bucketed(sylph_sketch* sk) {
     b_tmpk.reserve((size_t)n_all * 8);
     b_tmpc.reserve((size_t)n_all * 4);
     b_small.reserve(64);
-    b_bk.reserve((size_t)(B + 2) * 4 * 5);      // boff | large_list | n_distinct | removed | d_off   (each B+2)
+    b_bk.reserve((size_t)(B + 2) * 4 * 6);      // boff | large_list | ovf_list | n_distinct | removed | d_off   (each B+2)
     uint32_t* boff = b_bk.as<uint32_t>();
     uint32_t* large_list = boff + (B + 2);      // [0] = number of buckets queued for the large configuration, [1..] = ids
-    uint32_t* n_distinct = large_list + (B + 2);
+    uint32_t* ovf_list = large_list + (B + 2);  // [0] = number of buckets beyond the large configuration, [1..] = ids
+    uint32_t* n_distinct = ovf_list + (B + 2);
     uint32_t* removed_b = n_distinct + (B + 2);
     uint32_t* d_off = removed_b + (B + 2);
     unsigned long long* d_removed = b_small.as<unsigned long long>();
@@ -416,6 +483,7 @@ bool finish_bucketed(sylph_sketch* sk) {
     const uint32_t* d_nv = boff + B;            // boff[B] = number of valid occurrences
     SY_HIP(hipMemsetAsync(b_small.p, 0, 64, ctx->stream));
     SY_HIP(hipMemsetAsync(large_list, 0, 4, ctx->stream));
+    SY_HIP(hipMemsetAsync(ovf_list, 0, 4, ctx->stream));
     SY_HIP(hipMemsetAsync(n_distinct, 0, (size_t)(B + 2) * 4 * 2, ctx->stream));   // n_distinct and removed
     // partition: stable radix sort of (bucket id -> occurrence index) on bit_length(B) bits (2-3 passes of 4-byte keys
     // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
@@ -441,7 +509,7 @@ bool finish_bucketed(sylph_sketch* sk) {
             hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(B, 256u)),
                                dim3(RTPB_LARGE), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
                                sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
-                               d_overflow, large_list, dbg);
+                               d_overflow, large_list, ovf_list, dbg);
             hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
         }
         exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
@@ -453,15 +521,57 @@ bool finish_bucketed(sylph_sketch* sk) {
         }
         SY_HIP(hipGetLastError());
     }
-    struct { unsigned long long removed; uint32_t overflow, n_seg; } host{};
-    SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 12, hipMemcpyDeviceToHost, ctx->stream));
-    SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 12, d_off + B, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SY_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(&host, ctx->pinned, 16);
-    if (!ctx->pending.empty()) profile_collect(ctx);
-    if (host.overflow) return false;             // some bucket did not fit in LDS: the generic path redoes the sample
+    struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf; } host{};
+    auto read_tail = [&] {
+        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 12, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 12, d_off + B, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 16, ovf_list, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(&host, ctx->pinned, 20);
+        if (!ctx->pending.empty()) profile_collect(ctx);
+    };
+    read_tail();
+    if (host.overflow) return false;             // inconsistent bounds (defensive): the generic path redoes the sample
+    unsigned long long removed_extra = 0;
+    if (host.n_ovf) {
+        // Some buckets exceed even the large configuration (k-mers with thousands of occurrences: low-complexity reads,
+        // very abundant genomes).  Only THEIR occurrences go through the device-wide path, as one small sample; its rows
+        // are patched into the buckets' slots and the table is compacted again.
+        if (ctx->finish_mode == 2 || host.n_ovf > 4096) return false;
+        HostPhase ph(ctx, "finish(bucket): overflowing buckets through the device-wide path");
+        const uint32_t m = host.n_ovf;
+        DevBuf b_so(ctx), b_sh(ctx), b_sr(ctx), sub_k(ctx), sub_c(ctx);
+        b_so.reserve(((size_t)m + 1) * 4);
+        hipLaunchKernelGGL(ovf_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, ovf_list, boff, b_so.as<uint32_t>());
+        uint32_t n_sub = 0;
+        ctx->read_back(&n_sub, b_so.as<uint32_t>() + m, 4);
+        b_sh.reserve((size_t)n_sub * 8);
+        b_sr.reserve((size_t)n_sub * sizeof(OccRec));
+        {
+            ScopedKernelTimer t(ctx, "replay_overflow");   // (family of its own so that tests can see this path was taken)
+            hipLaunchKernelGGL(ovf_gather_kernel, dim3(m), dim3(256), 0, ctx->stream, ovf_list, b_so.as<uint32_t>(), boff,
+                               b_perm.as<uint32_t>(), sk->recs.as<OccRec>(), b_sh.as<uint64_t>(), b_sr.as<OccRec>());
+        }
+        uint64_t n_sub_out = 0, removed_sub = 0;
+        generic_replay(ctx, b_sh.as<uint64_t>(), b_sr.as<OccRec>(), n_sub, sk->paired, sk->no_dedup, sub_k, sub_c, n_sub_out, removed_sub);
+        removed_extra = removed_sub;
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            hipLaunchKernelGGL(ovf_patch_kernel, dim3(m), dim3(256), 0, ctx->stream, ovf_list, bm, sub_k.as<uint64_t>(),
+                               sub_c.as<uint32_t>(), (uint32_t)n_sub_out, boff, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct);
+        }
+        exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
+                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
+                               sk->out_c.as<uint32_t>());
+        }
+        SY_HIP(hipGetLastError());
+        read_tail();
+    }
     sk->n_out = host.n_seg;
-    sk->dup_removed = host.removed;
+    sk->dup_removed = host.removed + removed_extra;
     return true;
 }
 

@@ -488,24 +488,19 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     if (mem != SYLPH_MEM_DEVICE) SY_HIP(hipStreamSynchronize(ctx->stream));
 }
 
-static void sketch_finish_impl(sylph_sketch* sk) {
-    if (sk->finished) return;
-    sylph_ctx* ctx = sk->ctx;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    DeviceGuard dg(ctx->device);
-    HostPhase ph_total(ctx, "finish: total incl. readback");
-    SY_REQUIRE(sk->n_occ < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
-    // fast path: bucket partition + in-LDS replay (replay_lds.hip); falls through to the device-wide sort path
-    // below when a bucket does not fit in LDS (some k-mer with thousands of occurrences)
-    if (ctx->finish_mode != 1) {
-        if (finish_bucketed(sk)) { sk->finished = true; return; }
-        SY_REQUIRE(ctx->finish_mode != 2, "bucket finish overflowed and finish=bucket forbids the fallback");
-    }
-    const uint32_t n_all = (uint32_t)sk->n_occ;
+// Device-wide replay of dup_removal_lsh_full_exact over `n_all` occurrences (hash = sort key, INVALID_HASH entries ignored;
+// recs in file order): stable radix sort by hash, then per-occurrence kernels and scans (see the file header).  Writes the
+// (k-mer, count) table in ascending k-mer order.  Used for whole samples (finish = generic, c < 2) and, by the bucket path,
+// for the occurrences of buckets that do not fit in LDS.
+void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, bool no_dedup,
+                    DevBuf& out_k, DevBuf& out_c, uint64_t& n_out, uint64_t& removed_out) {
     uint32_t nv = 0;
-    sk->n_out = 0;
-    sk->dup_removed = 0;
-    DevBuf &b_idx = ctx->scratch[0], &b_hs = ctx->scratch[1], &b_perm = ctx->scratch[2];
+    n_out = 0;
+    removed_out = 0;
+    // (buffers come from the ctx pool, not from ctx->scratch: the bucket path calls this for the occurrences of its
+    //  overflowing buckets while its own scratch arrays are still live)
+    DevBuf b_idx(ctx), b_hs(ctx), b_perm(ctx), b_cnt(ctx);
+    b_cnt.reserve(64);
     if (n_all) {
         // stable sort by hash; invalid occurrences carry ~0 and end up behind the nv valid ones
         HostPhase ph(ctx, "finish: sort by hash");
@@ -513,16 +508,15 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         b_hs.reserve((size_t)n_all * 8);
         b_perm.reserve((size_t)n_all * 4);
         hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n_all)), dim3(256), 0, ctx->stream, b_idx.as<uint32_t>(), n_all);
-        sort_pairs_u64_u32(ctx, sk->hash.as<uint64_t>(), b_hs.as<uint64_t>(), b_idx.as<uint32_t>(), b_perm.as<uint32_t>(),
+        sort_pairs_u64_u32(ctx, d_hash, b_hs.as<uint64_t>(), b_idx.as<uint32_t>(), b_perm.as<uint32_t>(),
                            n_all, 0, 64);
-        uint32_t* d_nv = reinterpret_cast<uint32_t*>(sk->counters.as<uint8_t>() + 8);
+        uint32_t* d_nv = b_cnt.as<uint32_t>();
         hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1), 0, ctx->stream, b_hs.as<uint64_t>(), n_all, d_nv);
         ctx->read_back(&nv, d_nv, 4);
     }
     if (nv) {
         HostPhase ph_replay(ctx, "finish: replay");
-        DevBuf &b_rid = ctx->scratch[3], &b_m0 = ctx->scratch[4], &b_m1 = ctx->scratch[5], &b_u32 = ctx->scratch[6],
-               &b_fl = ctx->scratch[7];
+        DevBuf b_rid(ctx), b_m0(ctx), b_m1(ctx), b_u32(ctx), b_fl(ctx);
         const size_t nv1 = (size_t)nv + 1;
         b_rid.reserve((size_t)nv * 8);
         b_m0.reserve((size_t)nv * 8);
@@ -541,34 +535,34 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(gather_heads_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, hs, b_perm.as<uint32_t>(),
-                               sk->recs.as<OccRec>(), nv,
+                               d_recs, nv,
                                b_rid.as<uint64_t>(), b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), head, headidx);
         }
         inclusive_max_u32(ctx, headidx, seg_start, nv);
         exclusive_sum_u32(ctx, head, seg_id, nv);
-        unsigned int* d_skipped = reinterpret_cast<unsigned int*>(sk->counters.as<uint8_t>() + 16);
+        unsigned int* d_skipped = b_cnt.as<unsigned int>() + 4;
         SY_HIP(hipMemsetAsync(d_skipped, 0, 4, ctx->stream));
         uint32_t* Eu = headidx;
         {
             ScopedKernelTimer t(ctx, "replay");
             const uint8_t* skip_arg = nullptr;
-            if (sk->paired) {
+            if (paired) {
                 hipLaunchKernelGGL(skip_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
                                    seg_start, nv, skip, d_skipped);
                 skip_arg = skip;
             }
-            if (!sk->no_dedup || sk->paired)
+            if (!no_dedup || paired)
                 hipLaunchKernelGGL(dup_flags_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
                                    b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), seg_start, skip_arg, nv, flags);
             else
                 SY_HIP(hipMemsetAsync(flags, 0, nv, ctx->stream));
-            hipLaunchKernelGGL(would_count_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, nv, sk->no_dedup, uc);
+            hipLaunchKernelGGL(would_count_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, nv, no_dedup ? 1 : 0, uc);
         }
         exclusive_sum_u32(ctx, uc, Eu, nv1);
         {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(counted_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, Eu, seg_start, nv,
-                               sk->no_dedup, sk->paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, uc);
+                               no_dedup ? 1 : 0, paired ? 0u : 4u /* MAX_DEDUP_COUNT, constants.rs:14 */, uc);
         }
         exclusive_sum_u32(ctx, uc, Ec, nv1);
         uint32_t tail[4] = {0, 0, 0, 0};   // seg_id, head of the last occurrence; total counted; skipped
@@ -580,19 +574,39 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         memcpy(tail, ctx->pinned, 16);
         const uint32_t n_seg = tail[0] + tail[1];
         const unsigned long long removed = (unsigned long long)nv - tail[3] - tail[2];   // processed - counted
-        sk->out_k.reserve((size_t)n_seg * 8);
-        sk->out_c.reserve((size_t)n_seg * 4);
+        out_k.reserve((size_t)n_seg * 8);
+        out_c.reserve((size_t)n_seg * 4);
         {
             ScopedKernelTimer t(ctx, "replay");
             uint32_t* start = seg_start;   // seg_start is dead now: reuse as start[n_seg+1]
             hipLaunchKernelGGL(seg_starts_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, head, seg_id, nv, n_seg, start);
             hipLaunchKernelGGL(emit_table_kernel, dim3(grid_for(n_seg)), dim3(256), 0, ctx->stream, hs, start, Ec, n_seg,
-                               sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>());
+                               out_k.as<uint64_t>(), out_c.as<uint32_t>());
             SY_HIP(hipGetLastError());
         }
-        sk->n_out = n_seg;
-        sk->dup_removed = removed;
+        n_out = n_seg;
+        removed_out = removed;
     }
+}
+
+
+static void sketch_finish_impl(sylph_sketch* sk) {
+    if (sk->finished) return;
+    sylph_ctx* ctx = sk->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    HostPhase ph_total(ctx, "finish: total incl. readback");
+    SY_REQUIRE(sk->n_occ < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
+    // fast path: bucket partition + in-LDS replay (replay_lds.hip); falls through to the device-wide sort path
+    // below when a bucket does not fit in LDS (some k-mer with thousands of occurrences)
+    if (ctx->finish_mode != 1) {
+        if (finish_bucketed(sk)) { sk->finished = true; return; }
+        SY_REQUIRE(ctx->finish_mode != 2, "bucket finish overflowed and finish=bucket forbids the fallback");
+    }
+    sk->n_out = 0;
+    sk->dup_removed = 0;
+    generic_replay(ctx, sk->hash.as<uint64_t>(), sk->recs.as<OccRec>(), (uint32_t)sk->n_occ, sk->paired, sk->no_dedup, sk->out_k,
+                   sk->out_c, sk->n_out, sk->dup_removed);
     sk->finished = true;
 }
 

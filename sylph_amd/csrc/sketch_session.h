@@ -11,6 +11,11 @@ constexpr uint64_t INVALID_HASH = ~0ull;
 struct alignas(32) OccRec { uint64_t hash, rid, m0, m1; };
 }  // namespace sylph
 
+namespace sylph {
+void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, bool no_dedup,
+                    DevBuf& out_k, DevBuf& out_c, uint64_t& n_out, uint64_t& removed_out);   // sketch.hip
+}
+
 struct sylph_sketch {
     sylph_ctx* ctx;
     uint32_t c, k;

@@ -321,6 +321,20 @@ def test_bucket_path_is_really_used(ctx):
         ctx.set_option("finish", "auto")
     assert_same_sketch(_sketch_gpu_once(ctx, deep[0], deep[1], False, False, S.SEED_AVX2_COMPAT, 3, 31, 1),
                        O.sketch_reads(deep[0], deep[1], c=3))
+    # an ordinary sample with a few k-mers at thousands of occurrences: only the buckets that hold them leave the in-LDS
+    # replay (their occurrences go through the device-wide path as a small sample of their own), single-end and paired
+    recs = make_reads(rng, genome, 20000, 150, dup_frac=0.1) + [genome[1000:1200].copy() for _ in range(2500)]
+    order = rng.permutation(len(recs))
+    mixed = concat([recs[i] for i in order])
+    ctx.profile(True)
+    try:
+        for paired in (False, True):
+            e = O.sketch_reads(mixed[0], mixed[1], c=20, paired=paired)
+            assert e["counts"].max() > 500
+            assert_same_sketch(_sketch_gpu_once(ctx, mixed[0], mixed[1], paired, False, S.SEED_AVX2_COMPAT, 20, 31, 1), e)
+        assert ctx.kernel_stats("replay_overflow")[1] >= 1
+    finally:
+        ctx.profile(False)
 
 
 def test_bucket_path_large_buckets(ctx):
