@@ -23,6 +23,12 @@ def golden_dir():
 def ctx():
     """A device context on cuda:0.  Fails loudly when libsylph_hip.so or the GPU is missing."""
     import sylph_amd
+    try:   # tests that also use torch on the GPU: let torch bring its HIP runtime up first, as bench.py does
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     c = sylph_amd.Context(0)
     yield c
     c.close()

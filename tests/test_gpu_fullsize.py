@@ -1,0 +1,80 @@
+"""Full-size parity (BASELINE configs[1], C2): 1 Gbp of synthetic 2x150 bp reads (3,333,334 pairs, duplicates, errors) sketched
+on the GPU through every seeding / finishing flavour and compared — bit for bit — with the CPU oracle on the same bytes (the
+oracle needs a few seconds for 1 Gbp), then profiled against sequence-backed genomes + decoy sketches, again against the
+oracle.  Plus the size-independent properties: ascending distinct k-mers below the threshold, occurrences conserved,
+batch-split invariance."""
+import numpy as np
+import pytest
+
+import sylph_amd as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_gbp_sample_against_the_oracle(ctx):
+    import torch
+    from sylph_amd import synth
+    dev = torch.device("cuda", 0)
+    c, k, n_pairs, read_len = 200, 31, 3_333_334, 150
+    genomes = synth.random_genomes(24, 2_000_000, dev, 3, mutated_frac=0.0)
+    bases, off = synth.paired_reads(genomes, n_pairs, seed=11)
+    torch.cuda.synchronize()
+    n_rec = 2 * n_pairs
+    n_bases = n_rec * read_len                      # (the generator leaves a few bytes of slack behind the last read)
+    assert int(off[-1].item()) == n_bases and int(bases.numel()) >= n_bases
+
+    def sketch(finish, seeds, batches=1):
+        ctx.set_option("finish", finish)
+        ctx.set_option("seeds", seeds)
+        try:
+            sk = S.ReadSketcher(ctx, c=c, k=k, paired=True)
+            step = ((n_rec // batches + 1) // 2) * 2
+            keep = []
+            for a in range(0, n_rec, step):
+                z = min(n_rec, a + step)
+                o = (off[a:z + 1] - off[a]).contiguous()
+                keep.append(o)
+                torch.cuda.synchronize()
+                sk.push_device(bases.data_ptr() + a * read_len, o.data_ptr(), z - a, (z - a) * read_len)
+            r = sk.finish()
+            sk.close()
+            return r
+        finally:
+            ctx.set_option("finish", "auto")
+            ctx.set_option("seeds", "auto")
+
+    g = sketch("auto", "auto")
+    # size-independent properties
+    thr = np.uint64((2**64 - 1) // c)
+    assert np.all(np.diff(g["kmers"].astype(np.uint64)) > 0) and g["kmers"][-1] < thr and g["counts"].min() >= 1
+    # the other flavours and a three-batch split of the same sample
+    for finish, seeds, batches in (("generic", "slots", 1), ("auto", "unordered", 1), ("auto", "auto", 3)):
+        o = sketch(finish, seeds, batches)
+        assert np.array_equal(o["kmers"], g["kmers"]) and np.array_equal(o["counts"], g["counts"]), (finish, seeds, batches)
+        assert o["dup_removed"] == g["dup_removed"]
+    # the oracle on the same bytes
+    hb = bases[:n_bases].cpu().numpy()
+    ho = off.cpu().numpy().astype(np.uint64)
+    e = O.sketch_reads(hb, ho, c=c, k=k, paired=True)
+    assert np.array_equal(g["kmers"], e["kmers"]) and np.array_equal(g["counts"], e["counts"])
+    assert g["dup_removed"] == e["dup_removed"] and e["dup_removed"] > 10000
+    # containment: the 24 source genomes (sketched on the GPU in one batch) + 3,000 decoy sketches
+    gb = genomes.reshape(-1).cpu().numpy()
+    coff = np.arange(25, dtype=np.uint64) * np.uint64(2_000_000)
+    km, koff, _, _ = ctx.sketch_genomes(gb, coff, np.arange(25, dtype=np.uint64), c=c, k=k)
+    for i in (0, 23):
+        eg = O.sketch_genome(gb[i * 2_000_000:(i + 1) * 2_000_000], np.array([0, 2_000_000], dtype=np.uint64), c=c, k=k)
+        assert np.array_equal(km[int(koff[i]):int(koff[i + 1])], eg["genome_kmers"])
+    dk, doff = synth.decoy_sketches(3000, c=c, device=dev, seed=5)
+    dk, doff = dk.cpu().numpy().view(np.uint64), doff.cpu().numpy().astype(np.uint64)
+    db_k = np.concatenate([km, dk])
+    db_off = np.concatenate([koff, doff[1:] + koff[-1]])
+    db = S.Database(ctx, db_k, db_off)
+    cc, coff2, covs = db.contain_view(g["kmers"], g["counts"], packed=True)
+    cc, coff2, covs = cc.copy(), coff2.copy(), covs.astype(np.uint32)
+    db.close()
+    ecc, ecov, _ = O.contain(g["kmers"], g["counts"], db_k, db_off, n_threads=8)
+    assert np.array_equal(cc, ecc) and cc[:24].min() > 1000
+    for gi in list(range(24)) + list(np.nonzero(ecc[24:])[0][:50] + 24):
+        assert np.array_equal(covs[int(coff2[gi]):int(coff2[gi + 1])], np.sort(ecov[gi]))
