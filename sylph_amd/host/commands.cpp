@@ -7,7 +7,10 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <atomic>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "sylph_host.hpp"
 
@@ -74,7 +77,7 @@ struct Session {   // RAII
 
 }  // namespace
 
-Engine::Engine(int device) { hip_check(sylph_ctx_create(device, nullptr, &ctx), "sylph_ctx_create"); }
+Engine::Engine(int dev) : device(dev) { hip_check(sylph_ctx_create(dev, nullptr, &ctx), "sylph_ctx_create"); }
 Engine::~Engine() { sylph_ctx_destroy(ctx); }
 
 // sketch.rs:897-959
@@ -266,27 +269,56 @@ int sketch(Engine& e, const SketchArgs& args) {
     if (args.fpr != 0. && !first_pairs.empty())
         info("paired-end dedup uses the exact marker set (the reference's --fpr 0 path); --fpr is accepted for compatibility");
 
-    for (size_t i = 0; i < first_pairs.size(); i++) {                        // :311-367
-        std::optional<std::string> sample_name;
-        if (sample_names) sample_name = (*sample_names)[i];
-        auto sk = sketch_pair_sequences(e, first_pairs[i], second_pairs[i], args.c, args.k, sample_name, args.no_dedup, args.fpr);
-        if (!sk) continue;
-        create_dir_all(args.sample_output_dir);
-        const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
-        const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
-        write_sylsp(path, *sk);
-        info("Sketching " + path + " complete.");
-    }
-    for (size_t i = 0; i < read_inputs.size(); i++) {                        // :369-420
-        create_dir_all(args.sample_output_dir);
-        std::optional<std::string> sample_name;
-        if (sample_names) sample_name = (*sample_names)[i + first_pairs.size()];
-        auto sk = sketch_sequences_needle(e, read_inputs[i], args.c, args.k, sample_name, args.no_dedup);
-        if (!sk) continue;
-        const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
-        const std::string path = path_join(args.sample_output_dir, basename_of(name)) + SAMPLE_FILE_SUFFIX;
-        write_sylsp(path, *sk);
-        info("Sketching " + path + " complete.");
+    // Samples are independent (sketch.rs:313,371 runs them on the rayon pool, `-t`): a pool of `-t` worker threads, each with
+    // its own GPU context (calls on one context are serialised) and its own page-locked batch, takes them in input order.
+    // The parsing / inflating of different samples overlaps; the GPU work of one sample is ~2 ms per Gbp.
+    create_dir_all(args.sample_output_dir);
+    const size_t n_jobs = first_pairs.size() + read_inputs.size();
+    auto run_job = [&](Engine& eng, size_t j) {
+        if (j < first_pairs.size()) {                                        // :311-367
+            std::optional<std::string> sample_name;
+            if (sample_names) sample_name = (*sample_names)[j];
+            auto sk = sketch_pair_sequences(eng, first_pairs[j], second_pairs[j], args.c, args.k, sample_name, args.no_dedup, args.fpr);
+            if (!sk) return;
+            const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
+            const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
+            write_sylsp(path, *sk);
+            info("Sketching " + path + " complete.");
+        } else {                                                             // :369-420
+            const size_t i = j - first_pairs.size();
+            std::optional<std::string> sample_name;
+            if (sample_names) sample_name = (*sample_names)[j];
+            auto sk = sketch_sequences_needle(eng, read_inputs[i], args.c, args.k, sample_name, args.no_dedup);
+            if (!sk) return;
+            const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
+            const std::string path = path_join(args.sample_output_dir, basename_of(name)) + SAMPLE_FILE_SUFFIX;
+            write_sylsp(path, *sk);
+            info("Sketching " + path + " complete.");
+        }
+    };
+    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(args.threads, n_jobs));
+    if (n_workers <= 1) {
+        for (size_t j = 0; j < n_jobs; j++) run_job(e, j);
+    } else {
+        std::atomic<size_t> next{0};
+        std::mutex err_mu;
+        std::optional<Error> first_error;
+        auto worker = [&](Engine* eng) {
+            try {
+                std::unique_ptr<Engine> own;
+                if (!eng) { own.reset(new Engine(e.device)); eng = own.get(); }
+                for (size_t j = next++; j < n_jobs; j = next++) run_job(*eng, j);
+            } catch (const Error& er) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (!first_error) first_error = er;
+                next = n_jobs;   // stop handing out work
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < n_workers; w++) pool.emplace_back(worker, nullptr);
+        worker(&e);
+        for (auto& t : pool) t.join();
+        if (first_error) throw *first_error;
     }
     if (!genome_inputs.empty()) {                                            // :422-476
         const std::string path = args.db_out_name + QUERY_FILE_SUFFIX;

@@ -48,7 +48,7 @@ int run_sketch(Argv a) {
         else if (t == "-S" || t == "--sample-names") { if (!s.sample_names) s.sample_names.emplace(); append(*s.sample_names, a.multi()); }
         else if (t == "-k") s.k = strtoull(a.one().c_str(), nullptr, 10);
         else if (t == "-c") s.c = strtoull(a.one().c_str(), nullptr, 10);
-        else if (t == "-t") a.one();   // thread count: the GPU engine has no use for it
+        else if (t == "-t") s.threads = std::max<uint64_t>(1, strtoull(a.one().c_str(), nullptr, 10));   // samples in flight
         else if (t == "--no-dedup") { s.no_dedup = true; a.i++; }
         else if (t == "--disable-profiling") { s.no_pseudotax = true; a.i++; }
         else if (t == "--min-spacing") s.min_spacing_kmer = strtoull(a.one().c_str(), nullptr, 10);

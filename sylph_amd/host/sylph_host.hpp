@@ -109,6 +109,7 @@ bool is_fasta(const std::string& f);   // sketch.rs:109
 // ---- sketching (GPU through the C ABI) ----
 struct Engine {   // one GPU context shared by the drivers
     sylph_ctx* ctx = nullptr;
+    int device = -1;
     PinnedBatch batch;   // reused by every sample sketched through this engine
     explicit Engine(int device = -1);
     ~Engine();
@@ -156,7 +157,7 @@ struct SketchArgs {   // cmdline.rs:28-86
     std::optional<std::vector<std::string>> sample_names;
     std::string db_out_name = "database", sample_output_dir = "./";
     bool individual = false, no_dedup = false, no_pseudotax = false;
-    uint64_t k = 31, c = 200, min_spacing_kmer = 30;
+    uint64_t k = 31, c = 200, min_spacing_kmer = 30, threads = 3;   // -t: samples in flight (cmdline.rs: default 3)
     double fpr = DEFAULT_FPR;
     std::optional<std::string> list_sequence, list_reads, list_genomes, list_first_pair, list_second_pair, list_sample_names;
 };

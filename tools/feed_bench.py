@@ -58,6 +58,21 @@ def main():
             best = min(best, dt)
         g = gbp if name.startswith("paired") else gbp / 2
         res[name] = {"seconds": round(best, 3), "gbp_per_s": round(g / best, 3)}
+    # several samples in one command: -t worker threads, one GPU context each
+    for i in range(4):
+        for m in (1, 2):
+            dst = f"{d}/m{i}_{m}.fq.gz"
+            if os.path.lexists(dst):
+                os.remove(dst)
+            os.symlink(f"{d}/s_{m}.fq.gz", dst)
+    firsts = [f"{d}/m{i}_1.fq.gz" for i in range(4)]
+    seconds = [f"{d}/m{i}_2.fq.gz" for i in range(4)]
+    for t in (1, 4):
+        tm = time.perf_counter()
+        p = subprocess.run([BIN, "sketch", "-1", *firsts, "-2", *seconds, "-d", f"{d}/out", "-t", str(t)], capture_output=True, text=True)
+        dt = time.perf_counter() - tm
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[f"four_paired_gz_samples_t{t}"] = {"seconds": round(dt, 3), "gbp_per_s": round(4 * gbp / dt, 3)}
     print(res)
 
 
