@@ -85,4 +85,38 @@ void sylph_host_syldb_copy(void* h, uint64_t i, uint64_t* kmers, uint64_t* track
 }
 void sylph_host_syldb_free(void* h) { delete (std::vector<GenomeSketch>*)h; }
 
+// FASTA/FASTQ(+gzip) record stream digest, through the plain reader (threaded = 0) or through the reader thread + chunk
+// queue of the host feed (threaded = 1): number of records, parse errors, total bases, FNV-1a over every sequence byte and
+// every record length, length of the first header.  Returns -1 if the file cannot be opened.
+int sylph_host_fastx_digest(const char* path, int threaded, uint64_t* n_records, uint64_t* n_errors, uint64_t* n_bases,
+                            uint64_t* digest) {
+    uint64_t h = 1469598103934665603ull, nr = 0, ne = 0, nb = 0;
+    auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
+    auto mix_len = [&](uint64_t l) { mix((const uint8_t*)&l, 8); };
+    try {
+        if (threaded) {
+            ChunkStream cs(path);
+            const uint8_t* seq = nullptr;
+            uint32_t len = 0;
+            for (;;) {
+                const ChunkStream::Kind k = cs.next(seq, len);
+                if (k == ChunkStream::END) break;
+                if (k == ChunkStream::ERR) { ne++; if (ne > 1000) break; continue; }
+                mix(seq, len); mix_len(len); nr++; nb += len;
+            }
+        } else {
+            FastxReader r(path);
+            FastxRecord rec;
+            for (;;) {
+                bool ok = false;
+                try { ok = r.next(rec); } catch (const Error&) { ne++; if (ne > 1000) break; continue; }
+                if (!ok) break;
+                mix((const uint8_t*)rec.seq.data(), rec.seq.size()); mix_len(rec.seq.size()); nr++; nb += rec.seq.size();
+            }
+        }
+    } catch (const Error&) { return -1; }
+    *n_records = nr; *n_errors = ne; *n_bases = nb; *digest = h;
+    return 0;
+}
+
 }  // extern "C"

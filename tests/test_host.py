@@ -155,3 +155,80 @@ def test_syldb_layout(host, tmp_path):
     host.sylph_host_syldb_free(h)
     open(p, "wb").write(b[:100])
     assert not host.sylph_host_read_syldb(p)   # truncated file -> error, no crash
+
+
+# ---------------------------------------------------------------------------------------------- FASTX records (host feed)
+def _py_records(text):
+    """Independent reading of needletail's record semantics: 4-line FASTQ, multi-line FASTA, CR stripped, blank lines
+    between records ignored."""
+    lines = [l.rstrip(b"\r") for l in text.split(b"\n")]
+    if lines and lines[-1] == b"":
+        lines.pop()
+    recs, i = [], 0
+    while i < len(lines) and lines[i] == b"":
+        i += 1
+    if i == len(lines):
+        return recs
+    if lines[i][:1] == b"@":
+        while i < len(lines):
+            if lines[i] == b"":
+                i += 1
+                continue
+            recs.append(lines[i + 1])
+            i += 4
+    else:
+        cur = None
+        for l in lines[i:]:
+            if l[:1] == b">":
+                if cur is not None:
+                    recs.append(cur)
+                cur = b""
+            elif cur is not None:
+                cur += l
+        if cur is not None:
+            recs.append(cur)
+    return recs
+
+
+def _fnv(recs):
+    h = 1469598103934665603
+    for r in recs:
+        for b in r + struct.pack("<Q", len(r)):
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_fastx_reader_and_threaded_feed_agree(host, tmp_path):
+    import gzip
+    host.sylph_host_fastx_digest.argtypes = [C.c_char_p, C.c_int] + [C.POINTER(C.c_uint64)] * 4
+    rng = np.random.default_rng(3)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), size=int(n))) for n in
+            list(rng.integers(0, 400, size=3000)) + [0, 1, 70000]]
+    fq = b"".join(b"@r%d some text\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs))
+    fa = b"".join(b">c%d\n" % i + b"".join(s[j:j + 60] + b"\n" for j in range(0, len(s), 60)) for i, s in enumerate(seqs))
+    cases = {"a.fq": fq, "b.fastq": fq.replace(b"\n", b"\r\n"), "c.fa": fa, "d.fasta": b"\n\n" + fa.replace(b"\n>", b"\n\n>"),
+             "e.fq": b"", "f.fa": b">only header\n"}
+    for name, text in cases.items():
+        for gz in (False, True):
+            path = tmp_path / (name + (".gz" if gz else ""))
+            path.write_bytes(gzip.compress(text, 1) if gz else text)
+            exp = _py_records(text)
+            got = []
+            for threaded in (0, 1):
+                v = [C.c_uint64(0) for _ in range(4)]
+                assert host.sylph_host_fastx_digest(str(path).encode(), threaded, *[C.byref(x) for x in v]) == 0
+                got.append(tuple(int(x.value) for x in v))
+            assert got[0] == got[1], (name, gz)
+            assert got[0][0] == len(exp) and got[0][1] == 0 and got[0][2] == sum(map(len, exp)), (name, gz, got[0][:3])
+            assert got[0][3] == _fnv(exp), (name, gz)
+    # malformed input: both paths must report the same number of records and errors, and terminate
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(fq[:5000] + b"@broken\nACGT\nnot a plus line\nIIII\n" + fq[5000:9000])
+    got = []
+    for threaded in (0, 1):
+        v = [C.c_uint64(0) for _ in range(4)]
+        assert host.sylph_host_fastx_digest(str(bad).encode(), threaded, *[C.byref(x) for x in v]) == 0
+        got.append(tuple(int(x.value) for x in v))
+    assert got[0] == got[1] and got[0][1] >= 1
+    v = [C.c_uint64(0) for _ in range(4)]
+    assert host.sylph_host_fastx_digest(str(tmp_path / "missing.fq").encode(), 0, *[C.byref(x) for x in v]) == -1
