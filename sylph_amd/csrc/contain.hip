@@ -304,9 +304,12 @@ static void build_postings(sylph_ctx* ctx, const uint64_t* d_kmers_in, const uin
     sort_pairs_u64_u32(ctx, d_kmers_in, kmer.as<uint64_t>(), gid_in.as<uint32_t>(), gid.as<uint32_t>(), n, 0, 64);
     uint64_t max_key = 0;
     ctx->read_back(&max_key, kmer.as<uint64_t>() + (n - 1), 8);
-    // ~8 postings per bucket on average (one or two 64 B sectors), index <= 2^28 entries
-    int b = bit_length(n / 8);
-    b = std::min(28, std::max(8, b));
+    // ~2-3 postings per bucket on average, index <= 2^30 entries (measured on MI355X at 1.8e9 postings: 8 per bucket 0.177 ms
+    // per probe of a 2 M-entry sample, 2 per bucket 0.166 ms, 32 per bucket 0.20 ms: the dependent loads inside the bucket
+    // cost more than the larger table)
+    static const uint64_t ppb = getenv("SYLPH_HIP_POSTINGS_PER_BUCKET") ? std::max(1, atoi(getenv("SYLPH_HIP_POSTINGS_PER_BUCKET"))) : 2;
+    int b = bit_length(n / ppb);
+    b = std::min(getenv("SYLPH_HIP_BUCKET_BITS_MAX") ? atoi(getenv("SYLPH_HIP_BUCKET_BITS_MAX")) : 30, std::max(8, b));
     const int bits = std::max(1, bit_length(max_key));
     shift = std::max(0, bits - b);
     n_buckets = (uint32_t)((max_key >> shift) + 1);
