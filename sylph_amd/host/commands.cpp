@@ -60,6 +60,19 @@ void parse_line_file(const std::string& file, std::vector<std::string>& out) {  
     while (std::getline(f, line)) out.push_back(line);
 }
 
+// f(i) for i in [0, n) on up to `threads` threads (f must not throw)
+template <class F>
+void parallel_for(size_t n, uint64_t threads, F&& f) {
+    const size_t t = std::max<size_t>(1, std::min<size_t>(threads, (n + 15) / 16));
+    if (t <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&] { for (size_t i = next++; i < n; i = next++) f(i); };
+    std::vector<std::thread> pool;
+    for (size_t w = 1; w < t; w++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+}
+
 struct Session {   // RAII
     sylph_sketch* sk = nullptr;
     Session(Engine& e, uint64_t c, uint64_t k, bool paired, bool no_dedup) {
@@ -470,12 +483,21 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             hip_check(sylph_db_contain_view(db, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST,
                                             args.min_number_kmers, &cc, &coff, &covs, &ncov), "sylph_db_contain_view");
             std::vector<AniResult> stats;
-            for (size_t g = 0; g < genome_sketches.size(); g++) {
-                if (genome_sketches[g].c < S.c) throw Error{1, "c parameter for reads > c parameter for genome"};   // :616-623
-                if (cc[g] == 0) continue;                                    // :654
-                std::vector<uint32_t> cv(covs + coff[g], covs + coff[g + 1]);
-                auto r = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, std::nullopt);
-                if (r) { r->genome_index = g; stats.push_back(*r); }
+            {   // the statistics of different genomes are independent (contain.rs:284 runs them on the rayon pool): -t threads,
+                // results gathered in genome order so that the output does not depend on the interleaving
+                std::vector<size_t> with_hits;
+                for (size_t g = 0; g < genome_sketches.size(); g++) {
+                    if (genome_sketches[g].c < S.c) throw Error{1, "c parameter for reads > c parameter for genome"};   // :616-623
+                    if (cc[g] != 0) with_hits.push_back(g);                  // :654
+                }
+                std::vector<std::optional<AniResult>> res(with_hits.size());
+                parallel_for(with_hits.size(), args.threads, [&](size_t i) {
+                    const size_t g = with_hits[i];
+                    std::vector<uint32_t> cv(covs + coff[g], covs + coff[g + 1]);
+                    res[i] = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, std::nullopt);
+                    if (res[i]) res[i]->genome_index = g;
+                });
+                for (auto& r : res) if (r) stats.push_back(*r);
             }
             if (args.pseudotax) {
                 info(files[0] + " taxonomic profiling; reassigning k-mers for " + std::to_string(stats.size()) + " genomes...");
@@ -491,15 +513,19 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                                                  pa.data(), (uint32_t)pg.size(), &cc2, &coff2, &covs2, &ncov2, &lost2),
                           "sylph_db_reassign_view");
                 std::vector<AniResult> stats2;
-                for (const auto& old : stats) {
-                    const size_t g = old.genome_index;
+                std::vector<std::optional<AniResult>> res2(stats.size());
+                parallel_for(stats.size(), args.threads, [&](size_t i) {
+                    const size_t g = stats[i].genome_index;
                     std::vector<uint32_t> cv(covs2 + coff2[g], covs2 + coff2[g + 1]);
-                    auto r = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, (size_t)lost2[g]);
+                    res2[i] = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, (size_t)lost2[g]);
+                    if (res2[i]) res2[i]->genome_index = g;
+                });
+                for (size_t i = 0; i < stats.size(); i++) {
+                    const auto& r = res2[i];
                     if (!r) continue;
-                    r->genome_index = g;
                     // derep_if_reassign_threshold, contain.rs:353-375
                     const double thr = std::pow(args.redundant_ani / 100., (double)S.k) * (double)r->n_kmers;
-                    if ((double)(old.contain_count - r->contain_count) < thr) stats2.push_back(*r);
+                    if ((double)(stats[i].contain_count - r->contain_count) < thr) stats2.push_back(*r);
                 }
                 stats.swap(stats2);
                 info(files[0] + " has " + std::to_string(stats.size()) + " genomes passing profiling threshold. ");

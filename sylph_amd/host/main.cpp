@@ -71,7 +71,8 @@ int run_contain(Argv a, bool profile) {
         else if (t == "--min-count-correct") c.min_count_correct = atof(a.one().c_str());
         else if (t == "-M" || t == "--min-number-kmers") c.min_number_kmers = atof(a.one().c_str());
         else if (t == "-m" || t == "--minimum-ani") c.minimum_ani = atof(a.one().c_str());
-        else if (t == "-t" || t == "-s" || t == "--sample-threads") a.one();
+        else if (t == "-t") c.threads = std::max<uint64_t>(1, strtoull(a.one().c_str(), nullptr, 10));
+        else if (t == "-s" || t == "--sample-threads") a.one();
         else if (t == "-u" || t == "--estimate-unknown") { c.estimate_unknown = true; a.i++; }
         else if (t == "-I" || t == "--read-seq-id") a.one();
         else if (t == "-R" || t == "--redundancy-threshold") c.redundant_ani = atof(a.one().c_str());

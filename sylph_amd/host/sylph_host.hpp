@@ -142,6 +142,7 @@ struct ContainArgs {   // the cmdline.rs:88-160 fields the statistics read
     std::optional<double> minimum_ani;
     bool pseudotax = false, no_ci = false, no_adj = false, mean_coverage = false, estimate_unknown = false;
     double redundant_ani = 99.0;
+    uint64_t threads = 3;   // -t: genomes whose statistics run concurrently (cmdline.rs default 3)
 };
 std::optional<double> ratio_lambda(const std::vector<uint32_t>& full_covs, double min_count_correct);   // inference.rs:207
 std::optional<double> ani_from_lambda(std::optional<double> lambda, double k, const std::vector<uint32_t>& full_cov);  // contain.rs:817
