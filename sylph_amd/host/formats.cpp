@@ -1,4 +1,8 @@
 // formats.cpp — .sylsp / .syldb (bincode 1.3.3 default layout) and FASTA/FASTQ(+gzip) records.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -26,20 +30,38 @@ struct Writer {
     }
 };
 
+// The file is mapped, not read into a buffer: a GTDB-scale .syldb is 13 GB and its k-mer vectors are copied out exactly once.
+struct Mapped {
+    const char* base = nullptr;
+    size_t len = 0;
+    size_t size() const { return len; }
+    const char& operator[](size_t i) const { return base[i]; }
+};
 struct Reader {
-    std::vector<char> b;
+    Mapped b;
     size_t p = 0;
     std::string path;
     explicit Reader(const std::string& pth) : path(pth) {
-        std::ifstream f(pth, std::ios::binary | std::ios::ate);
-        if (!f) throw Error{1, "The sketch `" + pth + "` could not be opened"};
-        const std::streamsize n = f.tellg();
-        f.seekg(0);
-        b.resize((size_t)n);
-        if (n) f.read(b.data(), n);
+        const int fd = open(pth.c_str(), O_RDONLY);
+        if (fd < 0) throw Error{1, "The sketch `" + pth + "` could not be opened"};
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); throw Error{1, "The sketch `" + pth + "` could not be opened"}; }
+        b.len = (size_t)st.st_size;
+        if (b.len) {
+            void* m = mmap(nullptr, b.len, PROT_READ, MAP_PRIVATE, fd, 0);
+            close(fd);
+            if (m == MAP_FAILED) throw Error{1, "The sketch `" + pth + "` could not be mapped"};
+            (void)madvise(m, b.len, MADV_SEQUENTIAL);
+            b.base = (const char*)m;
+        } else {
+            close(fd);
+        }
     }
+    ~Reader() { if (b.base) munmap((void*)b.base, b.len); }
+    Reader(const Reader&) = delete;
+    Reader& operator=(const Reader&) = delete;
     void need(size_t n) {
-        if (p + n > b.size()) throw Error{1, "The sketch `" + path + "` is not a valid sketch. Perhaps it is an older incompatible version"};
+        if (n > b.size() || p > b.size() - n) throw Error{1, "The sketch `" + path + "` is not a valid sketch. Perhaps it is an older incompatible version"};
     }
     uint8_t u8() { need(1); return (uint8_t)b[p++]; }
     uint32_t u32() { need(4); uint32_t v; memcpy(&v, &b[p], 4); p += 4; return v; }
@@ -48,6 +70,7 @@ struct Reader {
     std::string str() { const uint64_t n = u64(); need(n); std::string s(&b[p], n); p += n; return s; }
     std::vector<uint64_t> vec_u64() {
         const uint64_t n = u64();
+        if (n > b.size() / 8) need(b.size() + 1);   // (n * 8 must not wrap)
         need(n * 8);
         std::vector<uint64_t> v(n);
         if (n) memcpy(v.data(), &b[p], n * 8);
@@ -83,6 +106,7 @@ SequencesSketch read_sylsp(const std::string& path) {
     Reader r(path);
     SequencesSketch s;
     const uint64_t n = r.u64();
+    if (n > r.b.size() / 12) r.need(r.b.size() + 1);
     r.need(n * 12);
     std::vector<std::pair<uint64_t, uint32_t>> kv(n);
     for (uint64_t i = 0; i < n; i++) { kv[i].first = r.u64(); kv[i].second = r.u32(); }
