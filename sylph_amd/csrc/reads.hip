@@ -95,8 +95,8 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                                                      const uint64_t* __restrict__ off, uint64_t n_rec,
                                                      const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
                                                      int avx2_compat, int paired, int want_markers, uint64_t rec_base,
-                                                     uint32_t slot_cap, uint64_t* __restrict__ slot_hash,
-                                                     OccRec* __restrict__ slot_rec, uint32_t* __restrict__ blk_count,
+                                                     uint32_t slot_cap, OccRec* __restrict__ slot_rec,
+                                                     uint32_t* __restrict__ blk_count,
                                                      ReadsState* __restrict__ state, const uint32_t* __restrict__ blk_list,
                                                      uint32_t* __restrict__ spill_slot_of_blk) {
     extern __shared__ uint32_t sF[];                                 // (rt + 2 RH) / 16 + 3 stream words + RPAD
@@ -242,7 +242,6 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                             const uint64_t ft = win64(sF, rel + i);
                             const uint64_t fk = ft >> (64 - 2 * K), rk = revcomp_top<K>(ft);
                             const uint64_t h = mm_hash64(fk < rk ? fk : rk);
-                            slot_hash[out0 + o] = h;
                             slot_rec[out0 + o] = OccRec{h, rid, m0, m1};
                         }
                         o++;
@@ -268,22 +267,20 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
 }
 
 // out[blk_off[b] + i] = slot[b * slot_cap + i] (or its spill region): the occurrences of the batch in file order
-__global__ __launch_bounds__(64) void compact_occ_kernel(const uint64_t* __restrict__ slot_hash, const OccRec* __restrict__ slot_rec,
-                                                         const uint32_t* __restrict__ blk_count, const uint32_t* __restrict__ blk_off,
-                                                         uint32_t n_blk, uint32_t slot_cap, uint32_t spill_cap,
-                                                         const uint64_t* __restrict__ spill_hash, const OccRec* __restrict__ spill_rec,
+__global__ __launch_bounds__(64) void compact_occ_kernel(const OccRec* __restrict__ slot_rec, const uint32_t* __restrict__ blk_count,
+                                                         const uint32_t* __restrict__ blk_off, uint32_t n_blk, uint32_t slot_cap,
+                                                         uint32_t spill_cap, const OccRec* __restrict__ spill_rec,
                                                          const uint32_t* __restrict__ spill_slot_of_blk,
                                                          uint64_t* __restrict__ out_hash, OccRec* __restrict__ out_rec) {
     for (uint32_t b = blockIdx.x; b < n_blk; b += gridDim.x) {
         const uint32_t n = blk_count[b], d = blk_off[b];
-        const uint64_t* sh = slot_hash + (uint64_t)b * slot_cap;
         const OccRec* sr = slot_rec + (uint64_t)b * slot_cap;
-        if (n > slot_cap) {
-            const uint64_t s = (uint64_t)spill_slot_of_blk[b] * spill_cap;
-            sh = spill_hash + s;
-            sr = spill_rec + s;
+        if (n > slot_cap) sr = spill_rec + (uint64_t)spill_slot_of_blk[b] * spill_cap;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const OccRec r = sr[i];
+            out_hash[d + i] = r.hash;   // the sort key array of the session
+            out_rec[d + i] = r;
         }
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_hash[d + i] = sh[i]; out_rec[d + i] = sr[i]; }
     }
 }
 
@@ -308,8 +305,7 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* 
     const uint32_t slot_cap = (uint32_t)std::min<uint64_t>(spill_cap, expect + expect * 3 / 4 + 48);
     const size_t lds_bytes = ((size_t)(rt + 2 * RH) / 16 + 3 + RPAD) * 4;
     const uint64_t thr = UINT64_MAX / (uint64_t)sk->c;
-    DevBuf &b_sh = ctx->scratch[0], &b_sr = ctx->scratch[1], &b_meta = ctx->scratch[4];
-    b_sh.reserve((size_t)n_blk * slot_cap * 8);
+    DevBuf &b_sr = ctx->scratch[1], &b_meta = ctx->scratch[4];
     b_sr.reserve((size_t)n_blk * slot_cap * sizeof(OccRec));
     // [blk_rec (n_blk+1) | blk_count (n_blk+1) | blk_off (n_blk+1) | spill_slot_of_blk (n_blk+1) | ReadsState]
     b_meta.reserve(((size_t)n_blk + 1) * 4 * 4 + sizeof(ReadsState) + 16);
@@ -323,11 +319,11 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* 
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
-    auto launch = [&](uint32_t n_it, uint32_t cap, uint64_t* sh, OccRec* sr, const uint32_t* list) {
+    auto launch = [&](uint32_t n_it, uint32_t cap, OccRec* sr, const uint32_t* list) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * 8);
 #define SY_LAUNCH_READS(KK, HH)                                                                                               \
     hipLaunchKernelGGL((reads_kernel<KK, HH>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
-                       blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sh, sr,      \
+                       blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr,          \
                        blk_count, d_state, list, spill_slot)
         if (sk->k == 31) { if (hv) SY_LAUNCH_READS(31, 1); else SY_LAUNCH_READS(31, 0); }
         else { if (hv) SY_LAUNCH_READS(21, 1); else SY_LAUNCH_READS(21, 0); }
@@ -343,7 +339,7 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* 
         }
         {
             ScopedKernelTimer t(ctx, "seeds");
-            launch(n_blk, slot_cap, b_sh.as<uint64_t>(), b_sr.as<OccRec>(), nullptr);
+            launch(n_blk, slot_cap, b_sr.as<OccRec>(), nullptr);
         }
         exclusive_sum_u32(ctx, blk_count, blk_off, (size_t)n_blk + 1);
     }
@@ -356,17 +352,14 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* 
     if (res[1] || res[2] > SPILL_MAX_TILES) return false;
     const uint32_t n = res[0];
     if (n == 0) return true;
-    const uint64_t* sp_h = nullptr;
     const OccRec* sp_r = nullptr;
     if (res[2]) {   // a few blocks (low-complexity reads) are redone with room for every position
-        DevBuf& b_x = ctx->scratch[7];   // [spill records | spill hashes]
-        b_x.reserve((size_t)res[2] * spill_cap * (sizeof(OccRec) + 8));
+        DevBuf& b_x = ctx->scratch[7];   // spill records
+        b_x.reserve((size_t)res[2] * spill_cap * sizeof(OccRec));
         OccRec* xr = b_x.as<OccRec>();
-        uint64_t* xh = reinterpret_cast<uint64_t*>(xr + (size_t)res[2] * spill_cap);
         ScopedKernelTimer ts(ctx, "seeds_spill");
         ScopedKernelTimer t(ctx, "seeds");
-        launch(res[2], spill_cap, xh, xr, d_state->spill.tiles);
-        sp_h = xh;
+        launch(res[2], spill_cap, xr, d_state->spill.tiles);
         sp_r = xr;
     }
     const uint64_t need = sk->n_occ + n;
@@ -374,8 +367,8 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* 
     sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
     {
         ScopedKernelTimer t(ctx, "compact");
-        hipLaunchKernelGGL(compact_occ_kernel, dim3(std::min<uint32_t>(n_blk, 1u << 16)), dim3(64), 0, ctx->stream, b_sh.as<uint64_t>(),
-                           b_sr.as<OccRec>(), blk_count, blk_off, n_blk, slot_cap, spill_cap, sp_h, sp_r, spill_slot,
+        hipLaunchKernelGGL(compact_occ_kernel, dim3(std::min<uint32_t>(n_blk, 1u << 16)), dim3(64), 0, ctx->stream,
+                           b_sr.as<OccRec>(), blk_count, blk_off, n_blk, slot_cap, spill_cap, sp_r, spill_slot,
                            sk->hash.as<uint64_t>() + sk->n_occ, sk->recs.as<OccRec>() + sk->n_occ);
         SY_HIP(hipGetLastError());
     }
