@@ -660,3 +660,63 @@ def test_reassign_on_device_matches_reference_semantics(ctx):
     with pytest.raises(S.SylphHipError):
         db.reassign_view(sk, sc, np.array([1, 1], dtype=np.uint32), np.array([0.9, 0.9]))
     db.close()
+
+
+# ---------------------------------------------------------------------------------------------- fuzz over read shapes
+@pytest.mark.parametrize("seed", range(6))
+def test_read_shapes_fuzz(ctx, seed):
+    """Random mixtures of record lengths around every threshold of the seeding kernels (k, k+1, 33, 66, 400, 401, tiny reads
+    that put more than 256 records into one block of the read-per-lane kernel, long reads that make it decline), random
+    alphabets, pairs and singles, 1-3 batches, through all seeding/finishing flavours against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    genome = random_seq(rng, 30000)
+    shapes = [
+        lambda: int(rng.integers(0, 40)),                      # tiny: hundreds of records per block, most without k-mers
+        lambda: int(rng.choice([30, 31, 32, 33, 34, 35, 65, 66, 67])),
+        lambda: int(rng.integers(100, 160)),
+        lambda: int(rng.choice([398, 399, 400])),
+        lambda: int(rng.integers(240, 310)),
+    ]
+    if seed % 3 == 2:
+        shapes.append(lambda: int(rng.choice([401, 402, 1500])))    # beyond the read-per-lane kernel: whole batch falls back
+    n_pairs = int(rng.integers(300, 1500))
+    pick = rng.integers(0, len(shapes), size=2)
+    recs = []
+    for _ in range(n_pairs):
+        for m in range(2):
+            L = shapes[pick[m] if rng.random() < 0.8 else int(rng.integers(0, len(shapes)))]()
+            s = int(rng.integers(0, len(genome) - L)) if L else 0
+            r = genome[s:s + L].copy()
+            if rng.random() < 0.5:
+                r = revcomp(r)
+            if L and rng.random() < 0.05:
+                r[rng.integers(0, L, size=max(1, L // 20))] = rng.choice(np.frombuffer(b"NnRYacgtu", dtype=np.uint8))
+            recs.append(r)
+    for _ in range(n_pairs // 5):                                 # exact duplicate pairs
+        j = 2 * int(rng.integers(0, len(recs) // 2))
+        recs += [recs[j].copy(), recs[j + 1].copy()]
+    b, off = concat(recs)
+    c = int(rng.choice([1, 3, 20, 200]))
+    for paired in (False, True):
+        for gm, om in MODES:
+            e = O.sketch_reads(b, off, c=c, mode=om, paired=paired)
+            g = sketch_gpu(ctx, b, off, paired=paired, seed_mode=gm, c=c, batches=int(rng.integers(1, 4)))
+            assert_same_sketch(g, e)
+
+
+def test_tiny_reads_many_records_per_block(ctx):
+    """Reads of 0-45 bases: a block of the read-per-lane kernel holds more records than lanes (several passes per block), most
+    records have no k-mer at all, mates shorter than 33 bases carry no marker (sketch.rs:661)."""
+    rng = np.random.default_rng(77)
+    genome = random_seq(rng, 5000)
+    recs = []
+    for _ in range(6000):
+        L = int(rng.integers(0, 46))
+        s = int(rng.integers(0, len(genome) - 46))
+        recs.append(genome[s:s + L].copy())
+    b, off = concat(recs)
+    for paired in (False, True):
+        for c in (1, 5):
+            e = O.sketch_reads(b, off, c=c, paired=paired)
+            assert len(e["kmers"]) > 50
+            assert_same_sketch(sketch_gpu(ctx, b, off, paired=paired, c=c), e)
