@@ -714,6 +714,7 @@ def test_tiny_reads_many_records_per_block(ctx):
         L = int(rng.integers(0, 46))
         s = int(rng.integers(0, len(genome) - 46))
         recs.append(genome[s:s + L].copy())
+    recs[3000:3000] = [genome[:0].copy() for _ in range(3000)]   # thousands of empty records inside one block
     b, off = concat(recs)
     for paired in (False, True):
         for c in (1, 5):
