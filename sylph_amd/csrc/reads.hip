@@ -105,7 +105,13 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
     __shared__ uint32_t s_mask[MASKW][RTPB];
     __shared__ uint32_t s_wave[RTPB / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t it = blockIdx.x; it < n_blk; it += gridDim.x) {
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the
+    // blocks, so that the halo a block shares with its neighbour is found in the same L2.  (Outputs are indexed by block,
+    // so the order of the results does not depend on this mapping.)
+    const uint32_t per_xcd = (n_blk + 7) / 8, n_round = blk_list ? n_blk : per_xcd * 8;
+    for (uint32_t it0 = blockIdx.x; it0 < n_round; it0 += gridDim.x) {
+        const uint32_t it = blk_list ? it0 : (it0 & 7u) * per_xcd + (it0 >> 3);
+        if (it >= n_blk) continue;                                   // padding of the last XCD's range (uniform per workgroup)
         const uint32_t blk = blk_list ? blk_list[it] : it;
         const int64_t a0 = (int64_t)blk * rt - RH;                 // aligned coordinate of stream base 0 (multiple of 16)
         for (uint32_t ci = tid; ci < n_words; ci += RTPB) {
