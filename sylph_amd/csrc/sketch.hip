@@ -457,7 +457,7 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
     // short-read batches (mean record length <= 300): one lane per record, seeding + markers fused (reads.hip); it declines
     // (returns false) when some record is longer than its halo, and the position kernel + annotate below take over
     bool done = false;
-    if (ctx->seeds_mode == 0 && n_bases < (1ull << 32) - 32 && n_bases <= 300ull * n_records)
+    if (ctx->seeds_mode == 0 && n_bases < (1ull << 32) - 32 && n_records < (1ull << 31) && n_bases <= 300ull * n_records)
         done = push_short_reads(sk, d_bases, d_off, n_records, n_bases);
     uint32_t* d_count = sk->counters.as<uint32_t>();
     // K1 loads 16 B per lane: start it at the aligned address below d_bases and subtract the bias afterwards (a device
