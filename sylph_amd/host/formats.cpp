@@ -212,7 +212,35 @@ bool FastxReader::getline(std::string& line) {
     }
 }
 
+// Fast path for 4-line FASTQ records that lie completely inside the current buffer (all but one record per MiB): four memchr
+// calls and two assigns instead of four line copies.  Returns false (nothing consumed) when the slow path has to take over.
+bool FastxReader::next_fastq_in_buffer(FastxRecord& rec) {
+    if (!started_ || !fastq_ || has_pending_) return false;
+    const char* b = buf_.data();
+    const size_t n = buf_.size();
+    size_t p = pos_;
+    const char* e[4];
+    size_t start[4];
+    for (int l = 0; l < 4; l++) {
+        if (p >= n) return false;
+        start[l] = p;
+        const char* nl = (const char*)memchr(b + p, '\n', n - p);
+        if (!nl) return false;
+        e[l] = nl;
+        p = (size_t)(nl - b) + 1;
+    }
+    if (b[start[0]] != '@' || e[0] == b + start[0] || b[start[2]] != '+') return false;   // blank lines, malformed: slow path
+    auto trim = [&](int l) { const char* z = e[l]; if (z > b + start[l] && z[-1] == '\r') z--; return z; };
+    const char* h_end = trim(0);
+    const char* s_end = trim(1);
+    rec.id.assign(b + start[0] + 1, h_end);
+    rec.seq.assign(b + start[1], s_end);
+    pos_ = p;
+    return true;
+}
+
 bool FastxReader::next(FastxRecord& rec) {
+    if (next_fastq_in_buffer(rec)) return true;
     std::string line;
     // skip blank lines between records
     do {

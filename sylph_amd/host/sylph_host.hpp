@@ -69,6 +69,7 @@ class FastxReader {
     size_t pos_ = 0;
     bool eof_ = false, fastq_ = false, started_ = false;
     bool getline(std::string& line);
+    bool next_fastq_in_buffer(FastxRecord& rec);
     std::string pending_;
     bool has_pending_ = false;
 };
