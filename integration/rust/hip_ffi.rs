@@ -61,5 +61,15 @@ extern "C" {
     // host feed: page-locked batch buffers for sylph_sketch_push(.., MEM_HOST_PINNED)
     pub fn sylph_pinned_alloc(bytes: u64, out: *mut *mut c_void) -> c_int;
     pub fn sylph_pinned_free(p: *mut c_void);
+    // small helpers: library version, sizes of an uploaded database, (contig, end position, hash) triples of a genome
+    // (extract_markers_positions, sketch.rs:71-93), per-kernel timing for profiling builds
+    pub fn sylph_version() -> c_int;
+    pub fn sylph_db_n_genomes(db: *const SylphDb) -> u64;
+    pub fn sylph_db_n_kmers(db: *const SylphDb) -> u64;
+    pub fn sylph_seeds_positions(ctx: *mut SylphCtx, bases: *const u8, contig_off: *const u64, n_contigs: u64, c: u32, k: u32,
+                                 seed_mode: c_int, out_contig: *mut *mut u32, out_pos: *mut *mut u64, out_hash: *mut *mut u64,
+                                 out_n: *mut u64) -> c_int;
+    pub fn sylph_ctx_profile(ctx: *mut SylphCtx, enable: c_int) -> c_int;
+    pub fn sylph_ctx_kernel_stats(ctx: *mut SylphCtx, family: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn sylph_db_destroy(db: *mut SylphDb);
 }
