@@ -52,3 +52,17 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(sylph_amd.SylphHipError):
         sylph_amd.Context(0)
+
+
+def test_reference_side_binding_covers_every_entry_point():
+    """INTEGRATION.md and integration/rust/hip_ffi.rs (the binding a sylph maintainer would add) declare every function of
+    include/sylph_hip.h."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "sylph_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(sylph_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 30
+    for doc in ("INTEGRATION.md", os.path.join("integration", "rust", "hip_ffi.rs")):
+        text = open(os.path.join(root, doc)).read()
+        missing = [n for n in names if n not in text]
+        assert not missing, (doc, missing)
