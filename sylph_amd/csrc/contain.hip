@@ -53,15 +53,16 @@ constexpr int PROBE_GRID = 512;    // measured optimum on MI355X: 256 -> 0.22 ms
 
 struct HitStage {
     uint64_t stage[PROBE_STAGE];
-    uint32_t cnt, base;
+    uint32_t cnt, base, max_count;   // max_count: largest count among this workgroup's hits since the last flush
 };
 __device__ __forceinline__ void hit_stage_init(HitStage& st) {
-    if (threadIdx.x == 0) st.cnt = 0;
+    if (threadIdx.x == 0) { st.cnt = 0; st.max_count = 0; }
     __syncthreads();
 }
 __device__ __forceinline__ void hit_stage_push(HitStage& st, uint64_t hit, uint64_t* __restrict__ hits, uint32_t hit_cap,
                                                uint32_t* __restrict__ hit_count) {
     const uint32_t slot = atomicAdd(&st.cnt, 1u);
+    if ((uint32_t)hit > st.max_count) atomicMax(&st.max_count, (uint32_t)hit);   // (plain read first: almost never true)
     if (slot < PROBE_STAGE) st.stage[slot] = hit;
     else {                                       // a k-mer shared by thousands of genomes: straight to HBM
         const uint32_t o = atomicAdd(hit_count, 1u);
@@ -75,7 +76,10 @@ __device__ __forceinline__ void hit_stage_flush(HitStage& st, bool force, uint64
     const uint32_t n = min(st.cnt, (uint32_t)PROBE_STAGE);
     __syncthreads();                                     // everyone has read cnt before anyone pushes again
     if (n == 0 || (!force && n < PROBE_FLUSH)) return;   // uniform: all lanes saw the same cnt
-    if (threadIdx.x == 0) st.base = atomicAdd(hit_count, n);
+    if (threadIdx.x == 0) {
+        st.base = atomicAdd(hit_count, n);
+        atomicMax(hit_count + 1, st.max_count);          // [1] = largest count of any hit (sizes the sort keys)
+    }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n; t += PROBE_TPB) {
         const uint32_t o = st.base + t;
@@ -204,18 +208,6 @@ __global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __rest
     const uint32_t a = lower((uint64_t)g << 32);
     cov_off[g] = a;
     if (g < n_genomes) contain_count[g] = lower(((uint64_t)g + 1) << 32) - a;
-}
-
-// largest count of the sample table (an upper bound of every hit's count): 256 workgroups, one atomic each
-__global__ __launch_bounds__(256) void max_count_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ out) {
-    uint32_t m = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, counts[i]);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-    __shared__ uint32_t s[4];
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, max(max(s[0], s[1]), max(s[2], s[3])));
 }
 
 // Compact hit keys: (genome << 32 | count) -> 32-bit (genome << cb | count) with cb = bit_length(max count), whenever
@@ -443,13 +435,11 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             d_c = db->q_counts.as<uint32_t>();
         }
         uint64_t cap = std::max<uint64_t>(n * 2, 1u << 20);
-        uint32_t* d_cnt = db->counter.as<uint32_t>();   // [0] = number of hits, [1] = largest sample count
-        SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(max_count_kernel, dim3(256), dim3(256), 0, ctx->stream, d_c, (uint32_t)n, d_cnt + 1);
+        uint32_t* d_cnt = db->counter.as<uint32_t>();   // [0] = number of hits, [1] = largest count among the hits
         for (int attempt = 0; attempt < 2; attempt++) {
             SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one sample");
             db->hits.reserve(cap * 8);
-            SY_HIP(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+            SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
             {
                 ScopedKernelTimer t(ctx, "probe");
                 if (!re)

@@ -450,9 +450,9 @@ def check_contain(ctx, db_kmers, goff, sk, sc, min_kmers=50.0):
     vcc, voff, vcovs = db.contain_view(sk, sc, min_number_kmers=min_kmers)   # borrowed pinned views: same answer
     assert np.array_equal(vcc, cc) and np.array_equal(voff, off) and np.array_equal(vcovs, covs)
     pcc, poff, pcovs = db.contain_view(sk, sc, min_number_kmers=min_kmers, packed=True)   # narrowest width that fits
-    big = int(sc.max()) if len(sc) else 0
-    assert pcovs.dtype == (np.uint8 if big < 256 else np.uint16 if big < 65536 else np.uint32) or len(pcovs) == 0 or \
-        pcovs.dtype == np.uint32                                  # (64-bit hit keys always report u32)
+    big = int(covs.max()) if len(covs) else 0                    # the width follows the largest count among the HITS
+    assert len(pcovs) == 0 or pcovs.dtype == np.uint32 or \
+        pcovs.dtype == (np.uint8 if big < 256 else np.uint16 if big < 65536 else np.uint32)   # (64-bit hit keys report u32)
     assert np.array_equal(pcc, cc) and np.array_equal(poff, off) and np.array_equal(pcovs.astype(np.uint32), covs)
     db.close()
     ecc, ecov, _ = O.contain(sk, sc, db_kmers, goff, min_number_kmers=min_kmers)
