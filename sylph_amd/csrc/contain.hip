@@ -112,7 +112,7 @@ __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const uint64_t* __rest
                 const uint32_t end = bucket_start[b + 1];
                 uint32_t hi = end;
                 while (lo < hi) {                                                // lower_bound inside the bucket
-                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
                     if (db_kmer[mid] < km) lo = mid + 1; else hi = mid;
                 }
                 for (uint32_t j = lo; j < end && db_kmer[j] == km; j++) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ void posting_range(const uint64_t* __restrict__ kmer,
     const uint32_t end = bucket_start[b + 1];
     uint32_t hi = end;
     while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t mid = lo + ((hi - lo) >> 1);
         if (kmer[mid] < km) lo = mid + 1; else hi = mid;
     }
     uint32_t e = lo;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __rest
     auto lower = [&](uint64_t key) {
         uint32_t lo = 0, hi = n_hits;
         while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t mid = lo + ((hi - lo) >> 1);
             if (hits[mid] < key) lo = mid + 1; else hi = mid;
         }
         return lo;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void hit_offsets32_kernel(const uint32_t* __re
     auto lower = [&](uint64_t key) {   // first hit whose (genome << cb | count) >= key
         uint32_t lo = 0, hi = n_hits;
         while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t mid = lo + ((hi - lo) >> 1);
             if ((uint64_t)k32[mid] < key) lo = mid + 1; else hi = mid;
         }
         return lo;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void genome_offsets_kernel(const uint32_t* __r
     const uint32_t n_live = *n_live_p;
     uint32_t lo = 0, hi = n_live;
     while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t mid = lo + ((hi - lo) >> 1);
         if ((uint64_t)l_gid[mid] < g) lo = mid + 1; else hi = mid;
     }
     const uint32_t k = kpos[lo];   // kpos has n_live + 1 valid entries (sentinel)

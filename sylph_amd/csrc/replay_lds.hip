@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void ovf_patch_kernel(const uint32_t* __restri
     auto lower = [&](uint64_t key) {   // first row with k-mer >= key
         uint32_t lo = 0, hi = n_sub_out;
         while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t mid = lo + ((hi - lo) >> 1);
             if (sub_k[mid] < key) lo = mid + 1; else hi = mid;
         }
         return lo;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void annotate_contigs_kernel(const uint64_t* _
 __global__ void count_valid_kernel(const uint64_t* __restrict__ hs, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t mid = lo + ((hi - lo) >> 1);
         if (hs[mid] < INVALID_HASH) lo = mid + 1; else hi = mid;
     }
     *out = lo;
@@ -249,29 +249,64 @@ __global__ __launch_bounds__(256) void skip_kernel(const uint64_t* __restrict__ 
     wave_count_add(n_skipped, s != 0);
 }
 
-// K3b: dropped_i as defined in the file header.  flags[i]: bit0 = skip, bit1 = would-be-dropped.
+// K3b: dropped_i as defined in the file header, computed by SORTING instead of scanning: an occurrence is dropped iff it is
+// not the first processed occurrence of its k-mer and (m0 == m1, or one of its two markers was already inserted by an earlier
+// processed occurrence of the same k-mer).  "Already inserted" = the (k-mer segment, marker value) pair has an entry with a
+// smaller occurrence index.  Every processed occurrence with a marker contributes two entries e = 2 i + w (w: m0 / m1);
+// entries are ordered by (segment, value, e) with two stable radix sorts (by value, then by segment) and every entry whose
+// predecessor carries the same (segment, value) marks its occurrence as a hit.  O(n log n) whatever the coverage: the earlier
+// formulation scanned all previous occurrences of the k-mer (quadratic for a k-mer with thousands of distinct reads).
+__global__ __launch_bounds__(256) void marker_entries_kernel(const uint64_t* __restrict__ rid_s, const uint64_t* __restrict__ m0_s,
+                                                             const uint64_t* __restrict__ m1_s, const uint8_t* __restrict__ skip,
+                                                             uint32_t n, uint64_t* __restrict__ key, uint32_t* __restrict__ ent) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * n) return;
+    const uint32_t i = e >> 1;
+    key[e] = (e & 1) ? m1_s[i] : m0_s[i];
+    ent[e] = e;
+}
+// segment key of an entry: the index of the first occurrence of its k-mer, or n (behind every real segment) for entries of
+// occurrences that insert no marker (skipped mate 2, sketch.rs:852; records without marker, :627,:661)
+__global__ __launch_bounds__(256) void marker_segkey_kernel(const uint32_t* __restrict__ ent, const uint64_t* __restrict__ rid_s,
+                                                            const uint32_t* __restrict__ seg_start, const uint8_t* __restrict__ skip,
+                                                            uint32_t n, uint32_t* __restrict__ segkey) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= 2 * n) return;
+    const uint32_t i = ent[p] >> 1;
+    const bool inserts = (rid_s[i] & RID_MARKER_BIT) && !(skip && skip[i]);
+    segkey[p] = inserts ? seg_start[i] : n;
+}
+__global__ __launch_bounds__(256) void marker_hits_kernel(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ segkey,
+                                                          const uint64_t* __restrict__ m0_s, const uint64_t* __restrict__ m1_s,
+                                                          uint32_t n, uint8_t* __restrict__ hit) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0 || p >= 2 * n) return;
+    const uint32_t sk = segkey[p];
+    if (sk == n || segkey[p - 1] != sk) return;
+    const uint32_t e = ent[p], f = ent[p - 1];
+    const uint64_t v = (e & 1) ? m1_s[e >> 1] : m0_s[e >> 1], w = (f & 1) ? m1_s[f >> 1] : m0_s[f >> 1];
+    if (v == w) hit[e >> 1] = 1;   // (f >> 1 == e >> 1 only when m0 == m1, which drops the occurrence anyway)
+}
+// flags[i]: bit0 = skip, bit1 = would-be-dropped.  Eproc = exclusive count of processed (non-skipped) occurrences.
 __global__ __launch_bounds__(256) void dup_flags_kernel(const uint64_t* __restrict__ rid_s, const uint64_t* __restrict__ m0_s,
                                                         const uint64_t* __restrict__ m1_s,
                                                         const uint32_t* __restrict__ seg_start,
-                                                        const uint8_t* __restrict__ skip, uint32_t n,
+                                                        const uint8_t* __restrict__ skip, const uint32_t* __restrict__ Eproc,
+                                                        const uint8_t* __restrict__ hit, uint32_t n,
                                                         uint8_t* __restrict__ flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint8_t fl = skip ? skip[i] : 0;
     if (!fl && (rid_s[i] & RID_MARKER_BIT)) {
-        const uint64_t a = m0_s[i], b = m1_s[i];
-        bool any_prev = false, hit = false;
-        for (uint32_t j = seg_start[i]; j < i; j++) {
-            if (skip && skip[j]) continue;
-            any_prev = true;
-            if (rid_s[j] & RID_MARKER_BIT) {
-                const uint64_t x = m0_s[j], y = m1_s[j];
-                if (x == a || y == a || x == b || y == b) { hit = true; break; }
-            }
-        }
-        if (any_prev && (hit || a == b)) fl |= 2;
+        const uint32_t s0 = seg_start[i];
+        const bool any_prev = skip ? (Eproc[i] != Eproc[s0]) : (i != s0);
+        if (any_prev && (hit[i] || m0_s[i] == m1_s[i])) fl |= 2;
     }
     flags[i] = fl;
+}
+__global__ __launch_bounds__(256) void processed_kernel(const uint8_t* __restrict__ skip, uint32_t n, uint32_t* __restrict__ u) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) u[i] = (i < n && !skip[i]) ? 1u : 0u;
 }
 
 // K3c.  With u_i = 1 if occurrence i would be counted were there no cut-off (processed and not dropped) and
@@ -551,10 +586,38 @@ void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs
                                    seg_start, nv, skip, d_skipped);
                 skip_arg = skip;
             }
-            if (!no_dedup || paired)
+            if (!no_dedup || paired) {
+                // (with --no-dedup only the skip flags matter, :852 applies regardless; the marker flags are ignored by
+                //  would_count_kernel, but computing them keeps one code path)
+                DevBuf b_key(ctx), b_key2(ctx), b_ent(ctx), b_hit(ctx);
+                const size_t ne = (size_t)nv * 2;
+                b_key.reserve(ne * 8);
+                b_key2.reserve(ne * 8);
+                b_ent.reserve(ne * 4 * 4);       // ent_in | ent_mid -> ent_out | segkey_in | segkey_out
+                b_hit.reserve((size_t)nv + 4);
+                uint32_t* ent_in = b_ent.as<uint32_t>();
+                uint32_t* ent_mid = ent_in + ne;
+                uint32_t* sk_in = ent_mid + ne;
+                uint32_t* sk_out = sk_in + ne;
+                uint32_t* ent_out = ent_in;      // ent_in is dead after the first sort
+                SY_HIP(hipMemsetAsync(b_hit.p, 0, nv, ctx->stream));
+                hipLaunchKernelGGL(marker_entries_kernel, dim3(grid_for(ne)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
+                                   b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), skip_arg, nv, b_key.as<uint64_t>(), ent_in);
+                sort_pairs_u64_u32(ctx, b_key.as<uint64_t>(), b_key2.as<uint64_t>(), ent_in, ent_mid, ne, 0, 64);
+                hipLaunchKernelGGL(marker_segkey_kernel, dim3(grid_for(ne)), dim3(256), 0, ctx->stream, ent_mid, b_rid.as<uint64_t>(),
+                                   seg_start, skip_arg, nv, sk_in);
+                sort_pairs_u32_u32(ctx, sk_in, sk_out, ent_mid, ent_out, ne, 0, std::max(1, bit_length(nv)));
+                hipLaunchKernelGGL(marker_hits_kernel, dim3(grid_for(ne)), dim3(256), 0, ctx->stream, ent_out, sk_out,
+                                   b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), nv, b_hit.as<uint8_t>());
+                const uint32_t* Eproc = nullptr;
+                if (skip_arg) {   // exclusive count of processed occurrences (uc / Ec are free until would_count_kernel)
+                    hipLaunchKernelGGL(processed_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, skip_arg, nv, uc);
+                    exclusive_sum_u32(ctx, uc, Ec, nv1);
+                    Eproc = Ec;
+                }
                 hipLaunchKernelGGL(dup_flags_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
-                                   b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), seg_start, skip_arg, nv, flags);
-            else
+                                   b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), seg_start, skip_arg, Eproc, b_hit.as<uint8_t>(), nv, flags);
+            } else
                 SY_HIP(hipMemsetAsync(flags, 0, nv, ctx->stream));
             hipLaunchKernelGGL(would_count_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, nv, no_dedup ? 1 : 0, uc);
         }

@@ -361,6 +361,38 @@ def test_bucket_path_large_buckets(ctx):
         ctx.set_option("finish", "auto")
 
 
+def test_deep_kmers_of_distinct_reads_are_not_quadratic(ctx):
+    """100 k-mers with 6,000 occurrences each, every occurrence in a DIFFERENT read (random flanks => distinct markers): the
+    buckets overflow the in-LDS replay and go through the device-wide path, whose marker test used to scan all earlier
+    occurrences of the k-mer (quadratic: ~2e9 dependent loads here).  The sort-based formulation must agree with the oracle,
+    single-end (cut-off at 4) and paired (no cut-off), within a time bound."""
+    import time
+    rng = np.random.default_rng(77)
+    probe = random_seq(rng, 60000)
+    pos, _ = O.extract_markers_positions(probe, c=200)
+    cores = np.stack([probe[int(p) - 30:int(p) + 1] for p in pos[:100]])       # k-mers whose hash passes the c=200 threshold
+    assert cores.shape == (100, 31)
+    n = 100 * 6000
+    reads = rng.choice(ACGT, size=(n, 150)).astype(np.uint8)
+    reads[:, 60:91] = cores[rng.integers(0, 100, size=n)]
+    reads[rng.integers(0, n, size=n // 50)] = reads[rng.integers(0, n, size=n // 50)]   # some exact duplicates too
+    b = reads.reshape(-1)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
+    for paired in (False, True):
+        e = O.sketch_reads(b, off, c=200, paired=paired)
+        assert e["counts"].max() > 2500 and e["dup_removed"] > 0
+        for finish in ("auto", "generic"):
+            ctx.set_option("finish", finish)
+            try:
+                t0 = time.perf_counter()
+                g = _sketch_gpu_once(ctx, b, off, paired, False, S.SEED_AVX2_COMPAT, 200, 31, 1)
+                dt = time.perf_counter() - t0
+            finally:
+                ctx.set_option("finish", "auto")
+            assert_same_sketch(g, e)
+            assert dt < 5.0, (paired, finish, dt)   # ~0.1 s including the host->device copy of 90 MB
+
+
 def test_tandem_repeats_overflow_the_tile_slots(ctx):
     """A short-period tandem repeat whose k-mer passes the threshold yields thousands of survivors per 16 KiB tile: the
     ordered K1 must detect the slot overflow and fall back, the unordered K1 must spill past its LDS stage."""
