@@ -279,8 +279,10 @@ int sketch(Engine& e, const SketchArgs& args) {
     else if (args.sample_names) sample_names = args.sample_names;
     if (sample_names && sample_names->size() != first_pairs.size() + read_inputs.size())
         throw Error{1, "Sample name length is not equal to the number of reads. Exiting"};   // :288-292
-    if (args.fpr != 0. && !first_pairs.empty())
-        info("paired-end dedup uses the exact marker set (the reference's --fpr 0 path); --fpr is accepted for compatibility");
+    if (args.fpr != 0. && !first_pairs.empty())   // a10 (sketch.rs:733-769, default cmdline.rs:77) is not built: say so, once
+        warn("paired-end deduplication uses the EXACT marker set (sylph's `--fpr 0` path, sketch.rs:690-731), not the reference's "
+             "default approximate cuckoo filter (--fpr " + std::to_string(args.fpr) + "): counts can differ from `sylph sketch -1 -2` "
+             "by the filter's false positives; pass --fpr 0 to both tools for identical sketches");
 
     // Samples are independent (sketch.rs:313,371 runs them on the rayon pool, `-t`): a pool of `-t` worker threads, each with
     // its own GPU context (calls on one context are serialised) and its own page-locked batch, takes them in input order.
@@ -352,7 +354,21 @@ int sketch(Engine& e, const SketchArgs& args) {
 namespace {
 
 // contain.rs:18-94
-void print_ani_result(const AniResult& r, const std::string& seq_name, const GenomeSketch& g, bool pseudotax, FILE* out) {
+void print_ani_result(const AniResult& r, const std::string& seq_name, const GenomeSketch& g, bool pseudotax, FILE* out,
+                      bool debug_f64 = false) {
+    if (debug_f64) {   // --debug-f64 (not in the reference): every float column as %.17g, unclamped, for 1e-6 parity checks
+        auto opt = [](const std::optional<double>& v) { char b[40]; if (v) snprintf(b, sizeof(b), "%.17g", *v); else snprintf(b, sizeof(b), "NA"); return std::string(b); };
+        fprintf(out, "%s\t%s\t", seq_name.c_str(), g.file_name.c_str());
+        if (pseudotax) fprintf(out, "%.17g\t%.17g\t", *r.rel_abund, *r.seq_abund);
+        fprintf(out, "%.17g\t%.17g\t%s-%s\t", r.final_est_ani * 100., r.final_est_cov, opt(r.ani_ci_lo).c_str(), opt(r.ani_ci_hi).c_str());
+        if (r.lambda_status == AdjustStatus::Lambda) fprintf(out, "%.17g\t", r.lambda);
+        else fprintf(out, "%s\t", r.lambda_status == AdjustStatus::High ? "HIGH" : "LOW");
+        fprintf(out, "%s-%s\t%.17g\t%.17g\t%zu/%zu\t%.17g\t", opt(r.lambda_ci_lo).c_str(), opt(r.lambda_ci_hi).c_str(), r.median_cov,
+                r.mean_cov, r.contain_count, r.n_kmers, r.naive_ani * 100.);
+        if (pseudotax) fprintf(out, "%zu\t", *r.kmers_lost);
+        fprintf(out, "%s\n", g.first_contig_name.c_str());
+        return;
+    }
     char final_ani[64];
     snprintf(final_ani, sizeof(final_ani), "%.2f", std::min(r.final_est_ani * 100., 100.));
     char lambda_print[64];
@@ -472,6 +488,13 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         } else if (files.size() == 1) {
             seq = sketch_sequences_needle(e, files[0], args.c, args.k, std::nullopt, false);
         } else {
+            // contain.rs:591 forces the cuckoo default (fpr 1e-4) for raw pairs; here: the exact set (see the warning below)
+            static bool warned = false;
+            if (!warned) {
+                warned = true;
+                warn("raw paired reads are deduplicated with the EXACT marker set (`--fpr 0` semantics), not the approximate cuckoo "
+                     "filter `sylph profile -1 -2` uses (contain.rs:591): results match `sylph sketch --fpr 0` followed by profile");
+            }
             seq = sketch_pair_sequences(e, files[0], files[1], args.c, args.k, std::nullopt, false, DEFAULT_FPR);
         }
         if (seq) {
@@ -537,7 +560,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             } else {
                 std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return y.final_est_ani < x.final_est_ani; });   // :333
             }
-            for (const auto& r : stats) print_ani_result(r, seq_name, genome_sketches[r.genome_index], args.pseudotax, out);
+            for (const auto& r : stats) print_ani_result(r, seq_name, genome_sketches[r.genome_index], args.pseudotax, out, args.debug_f64);
         }
         info(std::string(files.size() > 1 ? "Finished paired sample " : "Finished sample ") + files[0] + ".");
     }

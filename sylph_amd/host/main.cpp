@@ -87,6 +87,7 @@ int run_contain(Argv a, bool profile) {
         else if (t == "--no-ci") { c.no_ci = true; a.i++; }
         else if (t == "--no-adjust") { c.no_adj = true; a.i++; }
         else if (t == "--mean-coverage") { c.mean_coverage = true; a.i++; }
+        else if (t == "--debug-f64") { c.debug_f64 = true; a.i++; }
         else if (t == "--debug" || t == "--trace" || t == "--log-reassignments") a.i++;
         else if (t[0] == '-' && t.size() > 1) throw Error{2, "unknown option " + t};
         else { c.files.push_back(t); a.i++; }

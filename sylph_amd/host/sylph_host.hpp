@@ -142,6 +142,7 @@ struct ContainArgs {   // the cmdline.rs:88-160 fields the statistics read
     double min_count_correct = 3., min_number_kmers = 50.;
     std::optional<double> minimum_ani;
     bool pseudotax = false, no_ci = false, no_adj = false, mean_coverage = false, estimate_unknown = false;
+    bool debug_f64 = false;   // --debug-f64: float columns as %.17g (test aid, not in the reference)
     double redundant_ani = 99.0;
     uint64_t threads = 3;   // -t: genomes whose statistics run concurrently (cmdline.rs default 3)
 };

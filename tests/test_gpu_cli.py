@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+from oracle import pyref as P
 
 from .helpers import ACGT, random_seq, revcomp
 
@@ -244,3 +245,106 @@ def test_raw_inputs_equal_presketched(data):
     L.sylph_host_syldb_size.argtypes = [C.c_void_p]
     h = L.sylph_host_read_syldb(str(out / "indiv.syldb").encode())
     assert L.sylph_host_syldb_size(h) == len(g["O157"][1])
+
+
+def expected_floats(data, sample, paired, pseudotax, genome_order):
+    """The float columns recomputed by the INDEPENDENT restatement (oracle/pyref.py: Python ints/dicts, scipy Poisson tail —
+    no code shared with sylph_amd/host/inference.cpp or with the C++ oracle): statistics, winner table, reassignment
+    threshold, abundances, sort order."""
+    cache = data.setdefault("_pyref", {})          # pure-Python sketching takes seconds: once per fixture
+    gs = []
+    for name in genome_order:
+        path, recs = data["genomes"][name]
+        if ("g", name) not in cache:
+            cache[("g", name)] = P.sketch_genome([bytes(r[1]) for r in recs], 200, 31)
+        g = cache[("g", name)]
+        gs.append(dict(path=path, kmers=g["genome_kmers"], tracked=g["tracked"], gn_size=g["gn_size"]))
+    if ("s", paired) not in cache:
+        if paired:
+            cache[("s", paired)] = P.sketch_pair_sequences([bytes(r) for r in data["m1"]], [bytes(r) for r in data["m2"]], 200, 31)
+        else:
+            cache[("s", paired)] = P.sketch_sequences_needle([bytes(r) for r in data["m1"]], 200, 31)
+    counts = cache[("s", paired)]["kmer_counts"]
+    min_ani = 0.95 if pseudotax else 0.90
+    res = []
+    for i, g in enumerate(gs):
+        pr = P.probe(g["kmers"], counts)
+        if pr is None or not pr[1]:
+            continue
+        st = P.stats(pr[0], pr[1], len(g["kmers"]), min_ani=min_ani)
+        if st["passed"]:
+            res.append(dict(i=i, st=st, lost=None))
+    if pseudotax:
+        winner = P.winner_table([(r["i"], r["st"]["final_est_ani"], gs[r["i"]]["kmers"], gs[r["i"]]["tracked"]) for r in res])
+        res2 = []
+        for r in res:
+            g = gs[r["i"]]
+            cc, covs, lost = P.probe(g["kmers"], counts, winner=winner, me=r["i"])
+            if not covs:
+                continue
+            st = P.stats(cc, covs, len(g["kmers"]), min_ani=min_ani)
+            if st["passed"] and P.derep_if_reassign_threshold(r["st"]["contain_count"], cc, len(g["kmers"])):
+                res2.append(dict(i=r["i"], st=st, lost=lost))
+        res = res2
+        tot = sum(r["st"]["final_est_cov"] for r in res)
+        tots = sum(r["st"]["final_est_cov"] * gs[r["i"]]["gn_size"] for r in res)
+        for r in res:
+            r["rel"] = r["st"]["final_est_cov"] / tot * 100.0
+            r["seq"] = r["st"]["final_est_cov"] * gs[r["i"]]["gn_size"] / tots * 100.0
+        res.sort(key=lambda r: -r["rel"])
+    else:
+        res.sort(key=lambda r: -r["st"]["final_est_ani"])
+    return res, gs
+
+
+def compare_f64(stdout, res, gs, pseudotax, rel=1e-6):
+    """--debug-f64 rows against the independent restatement: every float column at `rel` (the north_star's 1e-6)."""
+    lines = stdout.strip().split("\n")
+    assert len(lines) == 1 + len(res), stdout
+    o = 2 if pseudotax else 0
+    for line, r in zip(lines[1:], res):
+        got = line.split("\t")
+        st = r["st"]
+        assert got[1] == gs[r["i"]]["path"]
+        close = lambda a, b: abs(float(a) - b) <= rel * abs(b)
+        if pseudotax:
+            assert close(got[2], r["rel"]) and close(got[3], r["seq"]), line
+            assert int(got[o + 11]) == r["lost"]
+        assert close(got[o + 2], st["final_est_ani"] * 100.0), (line, st)
+        assert close(got[o + 3], st["final_est_cov"]), (line, st)
+        if st["lambda_status"] == "LAMBDA":
+            assert close(got[o + 5], st["lambda_"])
+            lo, hi = got[o + 4].split("-")      # bootstrap CI (fastrand: parity unpinned) — present, ordered, brackets sanely
+            if lo != "NA":
+                assert float(lo) <= float(hi)
+        else:
+            assert got[o + 5] == st["lambda_status"]
+        assert close(got[o + 7], st["median_cov"]) and close(got[o + 8], st["mean_cov"])
+        assert got[o + 9] == "%d/%d" % (st["contain_count"], st["n_kmers"])
+        assert close(got[o + 10], st["naive_ani"] * 100.0)
+
+
+def test_float_columns_1e6_vs_independent_restatement(data):
+    """north_star: 'derived ANI/abundance floats within 1e-6'.  The printed TSV has 2-4 decimals, so the CLI's --debug-f64
+    mode prints %.17g and the comparison is against oracle/pyref.py, which shares no code with the host statistics."""
+    d = data["dir"]
+    g = data["genomes"]
+    order = ["EC590", "K12", "O157", "rand"]
+    out = d / "out5"
+    run("sketch", *[g[n][0] for n in order], "-o", out / "db", "-d", out, "-1", d / "s_1.fq", "-2", d / "s_2.fq", "--fpr", "0",
+        "-r", d / "single.fastq.gz")
+    for sample, paired in ((out / "s_1.fq.paired.sylsp", True), (out / "single.fastq.gz.sylsp", False)):
+        for cmd, pseudotax in (("query", False), ("profile", True)):
+            p = run(cmd, out / "db.syldb", sample, "--debug-f64")
+            res, gs = expected_floats(data, None, paired, pseudotax, order)
+            assert len(res) >= 1
+            compare_f64(p.stdout, res, gs, pseudotax)
+
+
+def test_paired_default_fpr_warns_about_exact_semantics(data):
+    """a10 (cuckoo-filter dedup, sketch.rs:733-769, default for pairs cmdline.rs:77) is not built: the command must say so."""
+    d = data["dir"]
+    p = run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w1")
+    assert "EXACT marker set" in p.stderr and "--fpr 0" in p.stderr
+    q = run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w2", "--fpr", "0")
+    assert "EXACT marker set" not in q.stderr

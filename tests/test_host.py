@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+from oracle import pyref as P
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -74,6 +75,66 @@ def test_stats_match_oracle(host):
     for lam in (1.0, 5.0, 29.0):
         for x in (0, 3, 10, 50, 68):
             assert abs(host.sylph_host_poisson_cdf(lam, x) - O.poisson_cdf(lam, x)) < 1e-12
+
+
+def test_poisson_cdf_against_mpmath_table(host, golden_dir):
+    """The Poisson tail behind the coverage cap (contain.rs:664-675; statrs Poisson::cdf = Q(x+1, lambda)) against a table
+    computed with mpmath at 50 digits (tests/golden/make_poisson_table.py) — NOT against the oracle, whose incomplete-gamma
+    routine is the host's twin.  The quantity that matters is the decision `cdf < 0.9999999999` for medians 1..29."""
+    import json
+    with open(os.path.join(golden_dir, "poisson_q_table.json")) as f:
+        t = json.load(f)
+    closest = 1.0
+    for r in t["rows"]:
+        lam, x = float(r["lambda"]), int(r["x"])
+        exact, tail = float(r["q"]), float(r["one_minus_q"])
+        for name, got in (("host", host.sylph_host_poisson_cdf(lam, x)), ("oracle", O.poisson_cdf(lam, x)), ("pyref", P.poisson_cdf(lam, float(x)))):
+            assert abs(got - exact) <= (4e-15 if exact > 0.999 else 1e-13), (name, lam, x, got, exact)
+            assert (got < 0.9999999999) == r["below_cutoff"], (name, lam, x)
+        closest = min(closest, abs(tail - 1e-10) / 1e-10)
+    # no (median, coverage) pair sits within f64 noise of the cut-off: the nearest tail (median 7, coverage 29:
+    # 1 - Q = 0.9983e-10) differs from 1e-10 by 0.17 % = 1.7e-13 absolute, ~40x the 4e-15 agreement demanded near the cut-off
+    assert closest > 1.5e-3
+    for lam, cap in t["largest_admitted_cov"].items():
+        covs = np.array([int(lam)] * 60 + [cap, cap + 1], dtype=np.uint32)      # median = lam; cap admitted, cap+1 cut
+        h = host_stats(host, covs, 100, min_ani=0.0)
+        assert h.mean_cov == pytest.approx((60 * int(lam) + cap) / 62.0, rel=1e-12)     # Σfull / |covs| (contain.rs:690)
+
+
+def test_stats_match_independent_restatement(host):
+    """Host statistics (C++, f64) against oracle/pyref.py (pure Python, scipy's incomplete gamma, dict histograms): every
+    branch of contain.rs:657-764 and inference.rs:207-242 at 1e-9 relative — tighter than the north_star's 1e-6."""
+    rng = np.random.default_rng(20250711)
+    n_lambda = 0
+    for trial in range(400):
+        kind = trial % 6
+        n_hits = int(rng.choice([1, 5, 24, 25, 26, 60, 300, 2000]))
+        if kind == 0:
+            covs = rng.choice([1, 2], size=n_hits, p=[0.85, 0.15])
+        elif kind == 1:
+            covs = rng.choice([1, 2, 3, 4], size=n_hits)                                  # ties for the mode
+        elif kind == 2:
+            covs = rng.poisson(float(rng.choice([0.3, 1.0, 2.5, 8.0, 14.0, 16.0, 29.0, 31.0, 80.0])), size=n_hits) + 1
+        elif kind == 3:
+            covs = np.full(n_hits, int(rng.integers(1, 5)))                                 # a single distinct value
+        elif kind == 4:
+            covs = np.concatenate([rng.choice([1, 3], size=n_hits), [2] * int(rng.integers(0, 4))])
+        else:
+            covs = np.concatenate([rng.poisson(1.0, size=n_hits) + 1, rng.integers(50, 100000, size=3)])   # beyond the cap
+        covs = covs.astype(np.uint32)
+        L = len(covs) + int(rng.integers(0, 40000))
+        e = P.stats(len(covs), covs.tolist(), L)
+        h = host_stats(host, covs, L, min_ani=0.0)
+        assert h.passed == 1 and {0: "LOW", 1: "HIGH", 2: "LAMBDA"}[h.lambda_status] == e["lambda_status"], trial
+        for f in ("naive_ani", "final_est_ani", "final_est_cov", "mean_cov", "median_cov"):
+            assert getattr(h, f) == pytest.approx(e[f], rel=1e-9, abs=0), (trial, f)
+        if e["lambda_"] is not None:
+            n_lambda += 1
+            assert h.lambda_ == pytest.approx(e["lambda_"], rel=1e-12)
+        assert (h.contain_count, h.n_kmers) == (len(covs), L)
+        for thr, kw in ((0.90, {}), (0.95, dict(pseudotax=1)), (0.99, dict(min_ani=99.0))):
+            assert host_stats(host, covs, L, **kw).passed == int(e["final_est_ani"] >= thr)
+    assert n_lambda > 40
 
 
 def test_bootstrap_ci_is_deterministic_and_ordered(host):
