@@ -72,7 +72,9 @@ int sylph_ctx_synchronize(sylph_ctx *ctx);
  * "bucket" (error instead of falling back).  "seeds" = "auto" (default: the read-per-lane kernel for short-read batches, the
  * position kernel with per-tile ordered slots otherwise), "slots" (always the position kernel with ordered slots) or
  * "unordered" (position kernel with LDS-staged atomics + radix sort by position).  "bucket_target" = mean number of
- * occurrences per replay bucket aimed for, "16".."256". */
+ * occurrences per replay bucket aimed for, "16".."256".  "index_lambda" = postings per 64-byte bucket line of a database
+ * index aimed for ("1".."8", default 3; applies to databases uploaded afterwards), "index_pass_max" = postings sorted per pass
+ * of the index build (tests lower it to force several passes). */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
 
 /* Per-kernel timing (hipEvent pairs on the ctx stream around every launch of the named kernel family) for
@@ -154,8 +156,9 @@ void sylph_sketch_destroy(sylph_sketch *sk);
 /* ---- containment (sample vs every genome of a resident DB shard) ----------------------------------------- */
 
 /* Load the genome_kmers of a set of GenomeSketch (types.rs:163-173; contain.rs:495 deserialises them) into HBM:
- * genome g = kmers[genome_off[g], genome_off[g+1]).  Builds the k-mer -> genome postings index once.
- * At most 2^32-1 k-mers and 2^32-1 genomes per shard. */
+ * genome g = kmers[genome_off[g], genome_off[g+1]).  Builds the k-mer -> genome postings index once (one 64-byte line of
+ * 8 {k-mer remainder, genome} slots per bucket of the k-mer space).  At most 2^30-1 genomes; the number of k-mers is bounded
+ * by HBM only (the index is built in passes). */
 int sylph_db_upload(sylph_ctx *ctx, const uint64_t *kmers, const uint64_t *genome_off, uint64_t n_genomes, int mem,
                     sylph_db **out);
 uint64_t sylph_db_n_genomes(const sylph_db *db);
@@ -194,6 +197,70 @@ int sylph_db_reassign_view(sylph_db *db, const uint64_t *sample_kmers, const uin
                            const uint32_t **contain_count, const uint64_t **cov_off, const uint32_t **covs,
                            uint64_t *out_n_covs, const uint32_t **kmers_lost);
 void sylph_db_destroy(sylph_db *db);
+uint64_t sylph_db_index_bytes(const sylph_db *db);   /* HBM taken by the postings index (lines + overflow runs) */
+
+/* ---- batched containment: S samples per call --------------------------------------------------------------------- */
+
+/* One sample table: n (k-mer, count) entries, k-mers ascending and distinct (what sylph_sketch_finish[_device] returns). */
+typedef struct sylph_sample_ref {
+    const uint64_t *kmers;
+    const uint32_t *counts;
+    uint64_t n;
+} sylph_sample_ref;
+
+/* The sample-chunk x genome loop of contain.rs:267-289 for a batch of n_samples tables at once: ONE probe launch over the
+ * concatenated tables, one sort of (sample, genome, count) hit keys, one device->host copy.  All tables live in `mem`
+ * (SYLPH_MEM_HOST or SYLPH_MEM_DEVICE).  Results are borrowed views into pinned memory owned by the db (valid until the next
+ * contain call): row r = s * n_genomes + g;  contain_count[r];  coverage values of (s, g) = covs[cov_off[r] .. cov_off[r+1]),
+ * ascending, stored as *cov_width (1, 2 or 4) bytes each.  n_samples * n_genomes must stay below 2^32. */
+int sylph_db_contain_batch(sylph_db *db, const sylph_sample_ref *samples, uint32_t n_samples, int mem, double min_number_kmers,
+                           const uint32_t **contain_count, const uint64_t **cov_off, const void **covs, uint32_t *cov_width,
+                           uint64_t *out_n_covs);
+
+/* ---- one database over several GPUs: k-mer-range shards + RCCL ----------------------------------------------------- */
+
+/* SURVEY 8e / north_star: "genome DB resident in HBM and sharded across the 8 GPUs of one node, per-shard containments combined
+ * by a single RCCL all-gather".  One process per GPU.  The database is sharded by k-mer RANGE: rank r holds the postings
+ * whose k-mer lies in [bounds[r], bounds[r+1]) for ALL genomes, so that — sample tables being sorted — the part of any sample a
+ * rank has to probe is a contiguous slice holding 1/world of it, and per-rank work per sample does not grow with `world`.
+ * sylph_shard_bounds: equal-width ranges over [0, max_kmer] (hashes are uniform below u64::MAX / c); bounds has world + 1
+ * entries.  sylph_db_upload_shard: every rank passes the same genome-major arrays (or at least all k-mers of its range, with
+ * the genomes' full offsets) and keeps its range; genome lengths stay those of the whole genomes (contain.rs:627). */
+int sylph_shard_bounds(uint64_t max_kmer, uint32_t world, uint64_t *bounds);
+int sylph_db_upload_shard(sylph_ctx *ctx, const uint64_t *kmers, const uint64_t *genome_off, uint64_t n_genomes, int mem,
+                          const uint64_t *bounds, uint32_t world, uint32_t rank, sylph_db **out);
+
+/* Communicator = the collectives the exchange needs, on device buffers, enqueued on `stream` (a hipStream_t).
+ * sylph_comm_create_rccl: RCCL (librccl.so resolved at run time: the copy already mapped into the process — e.g. PyTorch's
+ * — or the ROCm one); `id` is the 128-byte ncclUniqueId made by sylph_comm_rccl_unique_id on rank 0 and handed to every rank
+ * by the host program (MPI, torch.distributed, a file ...).
+ * sylph_comm_create: collectives supplied by the caller (tests run the exchange over gloo this way).  Both callbacks return
+ * 0 on success.  all_gather: `bytes` from every rank, rank-major, into recv.  all_to_all: send_off / recv_off hold
+ * world + 1 byte offsets; [send_off[r], send_off[r+1]) of `send` goes to rank r and lands at recv_off[me] of ITS recv
+ * layout, i.e. this rank receives rank r's block into [recv_off[r], recv_off[r+1]). */
+typedef struct sylph_comm sylph_comm;
+typedef struct sylph_comm_ops {
+    int (*all_gather)(void *user, const void *send, void *recv, uint64_t bytes, void *stream);
+    int (*all_to_all)(void *user, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off, void *stream);
+} sylph_comm_ops;
+int sylph_comm_rccl_unique_id(uint8_t id[128]);
+int sylph_comm_create_rccl(sylph_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t id[128], sylph_comm **out);
+int sylph_comm_create(uint32_t rank, uint32_t world, const sylph_comm_ops *ops, void *user, sylph_comm **out);
+void sylph_comm_destroy(sylph_comm *comm);
+
+/* sylph_db_contain_batch for a sharded database: every rank calls it with ITS OWN n_local samples (the ones it sketched;
+ * all ranks must call together, n_local may differ per rank, 0 allowed) and gets the complete results of those samples
+ * against the WHOLE database, laid out exactly as sylph_db_contain_batch returns them.  Inside, per batch:
+ *   1. all-gather of the slice boundaries (a few hundred bytes),
+ *   2. all-to-all of the table slices (each rank receives 1/world of every sample of the step),
+ *   3. one probe launch over all received slices against the resident shard,
+ *   4. ONE all-gather of the per-shard hit lists (fixed-layout buffer: [count | overflow flag | hits]),
+ *   5. each rank sorts the hits of its own samples and assembles counts + coverage vectors (partial counts of a genome from
+ *      different shards add up because a k-mer lives on exactly one shard).
+ * Everything stays on the device between the steps; nothing is translated from the reference (which has no such path). */
+int sylph_db_contain_batch_sharded(sylph_db *db, sylph_comm *comm, const sylph_sample_ref *samples, uint32_t n_local, int mem,
+                                   double min_number_kmers, const uint32_t **contain_count, const uint64_t **cov_off,
+                                   const void **covs, uint32_t *cov_width, uint64_t *out_n_covs);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,9 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_ctx_synchronize", "sylph_ctx_set_option", "sylph_ctx_profile", "sylph_ctx_kernel_stats", "sylph_seeds",
            "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_genomes", "sylph_sketch_begin", "sylph_sketch_push", "sylph_sketch_push_n",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
-           "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_contain_view_packed", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy"]
+           "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_contain_view_packed", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy",
+           "sylph_db_index_bytes", "sylph_db_contain_batch", "sylph_shard_bounds", "sylph_db_upload_shard", "sylph_comm_rccl_unique_id",
+           "sylph_comm_create_rccl", "sylph_comm_create", "sylph_comm_destroy", "sylph_db_contain_batch_sharded"]
 
 
 def load():
@@ -77,6 +79,17 @@ def load():
     L.sylph_db_reassign_view.argtypes = [vp, vp, vp, u64, i32, vp, vp, u32, P(vp), P(vp), P(vp), P(u64), P(vp)]
     L.sylph_db_destroy.argtypes = [vp]
     L.sylph_db_destroy.restype = None
+    L.sylph_db_index_bytes.argtypes = [vp]
+    L.sylph_db_index_bytes.restype = u64
+    L.sylph_db_contain_batch.argtypes = [vp, vp, u32, i32, dbl, P(vp), P(vp), P(vp), P(u32), P(u64)]
+    L.sylph_shard_bounds.argtypes = [u64, u32, vp]
+    L.sylph_db_upload_shard.argtypes = [vp, vp, vp, u64, i32, vp, u32, u32, P(vp)]
+    L.sylph_comm_rccl_unique_id.argtypes = [vp]
+    L.sylph_comm_create_rccl.argtypes = [vp, u32, u32, vp, P(vp)]
+    L.sylph_comm_create.argtypes = [u32, u32, vp, vp, P(vp)]
+    L.sylph_comm_destroy.argtypes = [vp]
+    L.sylph_comm_destroy.restype = None
+    L.sylph_db_contain_batch_sharded.argtypes = [vp, vp, vp, u32, i32, dbl, P(vp), P(vp), P(vp), P(u32), P(u64)]
     _LIB = L
     return L
 
@@ -258,19 +271,89 @@ class ReadSketcher:
             pass
 
 
+class SampleRef(C.Structure):
+    _fields_ = [("kmers", C.c_void_p), ("counts", C.c_void_p), ("n", C.c_uint64)]
+
+
+def shard_bounds(max_kmer, world):
+    b = np.zeros(world + 1, dtype=np.uint64)
+    _check(load().sylph_shard_bounds(int(max_kmer), world, _ptr(b)))
+    return b
+
+
+class CommOps(C.Structure):
+    _fields_ = [("all_gather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)),
+                ("all_to_all", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p))]
+
+
+class Comm:
+    """sylph_comm: RCCL (rccl_id = the 128-byte id from Comm.rccl_unique_id(), the same on every rank) or caller-supplied
+    collectives: all_gather(send_ptr, recv_ptr, nbytes, stream) / all_to_all(send_ptr, send_off, recv_ptr, recv_off, stream)
+    working on device addresses."""
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(load().sylph_comm_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, rank, world, ctx=None, rccl_id=None, all_gather=None, all_to_all=None):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        if rccl_id is not None:
+            buf = (C.c_uint8 * 128).from_buffer_copy(rccl_id)
+            _check(load().sylph_comm_create_rccl(ctx._h, rank, world, buf, C.byref(self._h)))
+        else:
+            def ag(user, send, recv, nbytes, stream):
+                try:
+                    all_gather(send, recv, nbytes, stream)
+                    return 0
+                except Exception as e:   # never unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            def a2a(user, send, send_off, recv, recv_off, stream):
+                try:
+                    all_to_all(send, [send_off[i] for i in range(world + 1)], recv, [recv_off[i] for i in range(world + 1)], stream)
+                    return 0
+                except Exception as e:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._ops = CommOps(CommOps._fields_[0][1](ag), CommOps._fields_[1][1](a2a))   # keep the thunks alive
+            _check(load().sylph_comm_create(rank, world, C.byref(self._ops), None, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().sylph_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Database:
     """genome_kmers of many GenomeSketch resident in HBM + postings index; probe half of get_stats (contain.rs:601-656)."""
 
-    def __init__(self, ctx, kmers, genome_off, device_ptrs=False, n_genomes=None):
+    def __init__(self, ctx, kmers, genome_off, device_ptrs=False, n_genomes=None, shard=None):
+        """shard = (bounds[world + 1], world, rank): keep only the k-mers of this rank's range (sylph_db_upload_shard)."""
         self.ctx = ctx
         self._h = C.c_void_p()
         if device_ptrs:
-            _check(load().sylph_db_upload(ctx._h, C.c_void_p(kmers), C.c_void_p(genome_off), n_genomes, MEM_DEVICE,
-                                          C.byref(self._h)))
+            kp, op, G, mem = C.c_void_p(kmers), C.c_void_p(genome_off), n_genomes, MEM_DEVICE
         else:
             k, off = _np(kmers, np.uint64), _np(genome_off, np.uint64)
-            _check(load().sylph_db_upload(ctx._h, _ptr(k) if len(k) else None, _ptr(off), len(off) - 1, MEM_HOST,
-                                          C.byref(self._h)))
+            kp, op, G, mem = (_ptr(k) if len(k) else None), _ptr(off), len(off) - 1, MEM_HOST
+        if shard is None:
+            _check(load().sylph_db_upload(ctx._h, kp, op, G, mem, C.byref(self._h)))
+        else:
+            b = _np(shard[0], np.uint64)
+            assert len(b) == shard[1] + 1
+            _check(load().sylph_db_upload_shard(ctx._h, kp, op, G, mem, _ptr(b), shard[1], shard[2], C.byref(self._h)))
         self.n_genomes = int(load().sylph_db_n_genomes(self._h))
         self.n_kmers = int(load().sylph_db_n_kmers(self._h))
 
@@ -314,6 +397,49 @@ class Database:
         ct, dt = {1: (C.c_uint8, np.uint8), 2: (C.c_uint16, np.uint16), 4: (C.c_uint32, np.uint32)}[int(cw.value)]
         covs = view(pv, int(nh.value), ct, dt)
         return cc, off, covs
+
+    @property
+    def index_bytes(self):
+        return int(load().sylph_db_index_bytes(self._h))
+
+    def _batch_args(self, samples, device_ptrs):
+        """samples: list of (kmers, counts) numpy arrays, or of (kmers_ptr, counts_ptr, n) device addresses."""
+        arr = (SampleRef * max(1, len(samples)))()
+        keep = []
+        for i, smp in enumerate(samples):
+            if device_ptrs:
+                arr[i].kmers, arr[i].counts, arr[i].n = smp[0], smp[1], smp[2]
+            else:
+                k, c = _np(smp[0], np.uint64), _np(smp[1], np.uint32)
+                keep.append((k, c))
+                arr[i].kmers, arr[i].counts, arr[i].n = (k.ctypes.data if len(k) else None), (c.ctypes.data if len(c) else None), len(k)
+        return arr, keep
+
+    def _batch_views(self, S, pc, po, pv, nh, cw):
+        R = S * self.n_genomes
+
+        def view(ptr, count, ctype, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).view(dtype)
+        ct, dt = {1: (C.c_uint8, np.uint8), 2: (C.c_uint16, np.uint16), 4: (C.c_uint32, np.uint32)}[int(cw.value)]
+        return view(pc, R, C.c_uint32, np.uint32), view(po, R + 1, C.c_uint64, np.uint64), view(pv, int(nh.value), ct, dt)
+
+    def contain_batch(self, samples, min_number_kmers=50.0, device_ptrs=False):
+        """sylph_db_contain_batch -> (contain_count[S*G], cov_off[S*G+1], covs): borrowed views, row = s * G + g."""
+        arr, keep = self._batch_args(samples, device_ptrs)
+        pc, po, pv, nh, cw = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint32(4)
+        _check(load().sylph_db_contain_batch(self._h, arr, len(samples), MEM_DEVICE if device_ptrs else MEM_HOST, float(min_number_kmers),
+                                             C.byref(pc), C.byref(po), C.byref(pv), C.byref(cw), C.byref(nh)))
+        return self._batch_views(len(samples), pc, po, pv, nh, cw)
+
+    def contain_batch_sharded(self, comm, samples, min_number_kmers=50.0, device_ptrs=False):
+        """sylph_db_contain_batch_sharded: collective — every rank calls it with its own samples."""
+        arr, keep = self._batch_args(samples, device_ptrs)
+        pc, po, pv, nh, cw = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint32(4)
+        _check(load().sylph_db_contain_batch_sharded(self._h, comm._h, arr, len(samples), MEM_DEVICE if device_ptrs else MEM_HOST,
+                                                     float(min_number_kmers), C.byref(pc), C.byref(po), C.byref(pv), C.byref(cw), C.byref(nh)))
+        return self._batch_views(len(samples), pc, po, pv, nh, cw)
 
     def attach_tracked(self, tracked_kmers, tracked_off):
         k, off = _np(tracked_kmers, np.uint64), _np(tracked_off, np.uint64)

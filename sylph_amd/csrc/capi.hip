@@ -271,6 +271,14 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 16 && v <= 256, "bucket_target must be in [16, 256]");
             ctx->bucket_target = (uint32_t)v;
+        } else if (!strcmp(key, "index_lambda")) {
+            const long v = strtol(value, nullptr, 10);
+            SY_REQUIRE(v >= 1 && v <= 8, "index_lambda must be in [1, 8]");
+            ctx->index_lambda = (uint32_t)v;
+        } else if (!strcmp(key, "index_pass_max")) {
+            const long long v = strtoll(value, nullptr, 10);
+            SY_REQUIRE(v >= 1 && v <= (1ll << 31), "index_pass_max must be in [1, 2^31]");
+            ctx->index_pass_max = (uint64_t)v;
         } else {
             SY_REQUIRE(false, "unknown option %s", key);
         }

@@ -126,6 +126,8 @@ struct sylph_ctx {
     std::mutex mu;                          // serialises calls on this ctx
     int finish_mode = 0;                    // 0 auto, 1 generic, 2 bucket-only (sylph_ctx_set_option "finish")
     uint32_t bucket_target = 128;           // mean occurrences per replay bucket aimed for ("bucket_target")
+    uint32_t index_lambda = 3;              // postings per 64-byte bucket line of a database index aimed for ("index_lambda")
+    uint64_t index_pass_max = 1ull << 30;   // postings sorted per pass of the index build ("index_pass_max"; tests lower it)
     int seeds_mode = 0;                     // 0 auto: read-per-lane kernel for short reads, else ordered slots; 1 unordered kernel + radix sort; 2 ordered slots only ("seeds")
     std::atomic<int> refs{1};               // the creator + every live session / db; freed when it drops to 0
     // profiling

@@ -1,17 +1,31 @@
 // contain.hip — sample-vs-database containment on gfx950 (probe half of get_stats, contain.rs:601-656).
 //
 // The reference walks every genome's k-mers and probes the sample's FxHashMap (contain.rs:632-652): ~1.4e9 random
-// probes per sample at GTDB-R220 scale.  Here the database lives in HBM as ONE postings array sorted by k-mer,
-//     db_kmer[N] ascending,  db_gid[N] (genome of each posting),  bucket_start[] (radix index on the top bits),
-// built once at upload, and the (much smaller, already sorted) sample table is streamed against it: each sample
-// k-mer finds its bucket (one 8 B index read), scans the few postings in it, and emits one (genome, count) hit per
-// matching posting.  Hits are radix-sorted by (genome, count): that yields contain_count[g] and the per-genome
-// coverage vectors already in the ascending order the reference sorts them into (contain.rs:661).
-// Same outputs, O(sample) instead of O(database) work per sample.  Pure integer work, HBM/L2-latency bound.
+// probes per sample at GTDB-R220 scale.  Here the database lives in HBM as an inverted index, k-mer -> genomes, and the
+// (much smaller, already sorted) sample tables are streamed against it: O(sample) work per sample instead of O(database).
+//
+// Index layout ("line index", contain_index.h): the k-mer space [base, max_kmer] is cut into n_buckets equal ranges of `div`
+// consecutive values, about 3 postings per bucket, and every bucket owns ONE 64-byte line of 8 slots — the HBM access
+// granule — so a probe is exactly one line read:
+//     slot = ((kmer - base) % div) << (gb + 1)  |  flag << gb  |  genome id        (gb = bit length of the genome count)
+// The bucket number fixes the high part of the k-mer, the slot keeps only the remainder (the 8 + 4 bytes of a
+// {k-mer, genome} posting in two arrays become 8 bytes in one), and the genome id rides with the key.  Unused slots are
+// all-ones.  A bucket with more than 8 postings (a k-mer shared by many genomes) keeps its first 7 in the line and puts a
+// descriptor (flag = 1, remainder field = start) in slot 7 that points at the rest in an overflow array: a run sorted by
+// (remainder, genome), closed by an all-ones slot.  Round 1 kept db_kmer[] u64 + db_gid[] u32 + bucket_start[] u32 and
+// touched three to four lines per probe (180 B fetched per probe, measured); this is 64 B.
+//
+// Hits are (row = sample * G + genome, count) keys, radix-sorted: that yields contain_count[sample][genome] and every
+// coverage vector already in the ascending order the reference sorts it into (contain.rs:661).  A batch of S samples is ONE
+// probe launch over the concatenated tables, one sort, one device->host copy (sylph_db_contain_batch; contain.rs:267-289 is
+// the reference's sample-chunk x genome loop).  Pure integer work, HBM-latency bound.
+//
+// Multi-GPU: a database shard holds the postings of one k-mer RANGE (sylph_db_upload_shard); sample tables are sorted, so
+// the part of a sample a rank must probe is a contiguous slice; shard.hip does the exchange.
 #include <algorithm>
 #include <memory>
 
-#include "common.h"
+#include "contain_index.h"
 #include "device_common.h"
 
 namespace sylph {
@@ -26,30 +40,140 @@ __global__ __launch_bounds__(256) void fill_gid_kernel(const uint64_t* __restric
     }
 }
 
+// glen[g] = number of k-mers of genome g (the WHOLE genome, also on a k-mer-range shard: contain.rs:627 tests
+// genome_kmers.len()); *min_len = smallest of them
 __global__ __launch_bounds__(256) void genome_len_kernel(const uint64_t* __restrict__ genome_off, uint64_t n_genomes,
-                                                         uint32_t* __restrict__ glen) {
+                                                         uint32_t* __restrict__ glen, uint32_t* __restrict__ min_len) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_genomes) glen[g] = (uint32_t)(genome_off[g + 1] - genome_off[g]);
+    if (g >= n_genomes) return;
+    const uint32_t l = (uint32_t)(genome_off[g + 1] - genome_off[g]);
+    glen[g] = l;
+    atomicMin(min_len, l);
 }
 
-// bucket_start[b] = first posting whose (kmer >> shift) >= b, for b in [0, n_buckets]
-__global__ __launch_bounds__(256) void bucket_index_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
-                                                           uint32_t n_buckets, uint32_t* __restrict__ bucket_start) {
+// stat[0] = largest k-mer inside [lo, hi), stat[1] = number of k-mers inside [lo, hi)      (hi == 0: no upper bound)
+__device__ __forceinline__ bool in_range(uint64_t k, uint64_t lo, uint64_t hi) { return k >= lo && (hi == 0 || k < hi); }
+__global__ __launch_bounds__(256) void range_stats_kernel(const uint64_t* __restrict__ kmers, uint64_t n, uint64_t lo, uint64_t hi,
+                                                          unsigned long long* __restrict__ stat) {
+    unsigned long long mx = 0, cnt = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = kmers[i];
+        if (in_range(k, lo, hi)) { mx = max(mx, (unsigned long long)k); cnt++; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mx = max(mx, (unsigned long long)__shfl_xor(mx, d));
+        cnt += (unsigned long long)__shfl_xor(cnt, d);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) { atomicMax(&stat[0], mx); atomicAdd(&stat[1], cnt); }
+}
+
+// ---- stable compaction of the postings whose k-mer falls into [lo, hi): counts per workgroup, scan, scatter -------------
+constexpr int FILT_TPB = 256, FILT_ITEMS = 8, FILT_TILE = FILT_TPB * FILT_ITEMS;
+
+__global__ __launch_bounds__(FILT_TPB) void filter_count_kernel(const uint64_t* __restrict__ kmers, uint64_t n, uint64_t lo, uint64_t hi,
+                                                                uint32_t* __restrict__ wg_count) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * FILT_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < FILT_ITEMS; j++) {
+        const uint64_t i = base + (uint64_t)j * FILT_TPB + threadIdx.x;
+        if (i < n) c += in_range(kmers[i], lo, hi) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = s_cnt;
+}
+
+__global__ __launch_bounds__(FILT_TPB) void filter_scatter_kernel(const uint64_t* __restrict__ kmers, const uint32_t* __restrict__ gid,
+                                                                  uint64_t n, uint64_t lo, uint64_t hi, const uint32_t* __restrict__ wg_off,
+                                                                  uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_g) {
+    __shared__ uint32_t s_wave[FILT_TPB / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * FILT_TILE;
+    uint32_t run = wg_off[blockIdx.x];
+    for (int j = 0; j < FILT_ITEMS; j++) {              // rows of 256 consecutive postings: the order of i is preserved
+        const uint64_t i = base + (uint64_t)j * FILT_TPB + threadIdx.x;
+        uint64_t k = 0;
+        bool in = false;
+        if (i < n) { k = kmers[i]; in = in_range(k, lo, hi); }
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < FILT_TPB / 64; w++) { const uint32_t t = s_wave[w]; if ((uint32_t)w < wave) before += t; total += t; }
+        if (in) {
+            const uint32_t o = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            out_k[o] = k;
+            out_g[o] = gid[i];
+        }
+        run += total;
+        __syncthreads();
+    }
+}
+
+// bfirst[b - b0] = first sorted posting whose bucket ((k - base) / div) is >= b, for b in [b0, b1]
+__global__ __launch_bounds__(256) void bucket_first_kernel(const uint64_t* __restrict__ keys, uint32_t m, uint64_t base, uint64_t div,
+                                                           uint32_t b0, uint32_t b1, uint32_t* __restrict__ bfirst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    const uint64_t lo = (i == 0) ? 0 : (keys[i - 1] >> shift) + 1;          // first bucket not yet started
-    const uint64_t hi = (i == n) ? (uint64_t)n_buckets : (keys[i] >> shift);   // last bucket that starts at i
-    for (uint64_t b = lo; b <= hi && b <= n_buckets; b++) bucket_start[b] = i;
+    if (i > m) return;
+    const uint64_t lo = (i == 0) ? (uint64_t)b0 : (keys[i - 1] - base) / div + 1;   // first bucket not yet started
+    const uint64_t hi = (i == m) ? (uint64_t)b1 : (keys[i] - base) / div;          // last bucket that starts at i
+    for (uint64_t b = lo; b <= hi && b <= b1; b++) bfirst[b - b0] = i;
 }
 
-// Probe: one lane per sample k-mer, persistent workgroups striding over 256-k-mer chunks.  Hits are (gid << 32 | count),
-// staged per workgroup in LDS and flushed with one global atomic per ~PROBE_FLUSH hits: with one workgroup per chunk and
-// one atomic each (7.7e3 on a single word for a 2 M-entry sample) the atomic unit (~88 single-address atomics/us on this
-// chip) was 40 % of the kernel.
+// overflow slots a bucket needs: its postings from the 8th on, the 8th itself (slot 7 becomes the descriptor) and the
+// closing sentinel
+__global__ __launch_bounds__(256) void ovf_need_kernel(const uint32_t* __restrict__ bfirst, uint32_t nb, uint32_t* __restrict__ need) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    if (b == nb) { need[b] = 0; return; }
+    const uint32_t c = bfirst[b + 1] - bfirst[b];
+    need[b] = c > LINE_SLOTS ? (c - (LINE_SLOTS - 1)) + 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void write_lines_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ gids,
+                                                          const uint32_t* __restrict__ bfirst, const uint32_t* __restrict__ ovf_off,
+                                                          uint32_t b0, uint32_t nb, uint64_t base, uint64_t div, int gshift,
+                                                          uint64_t ovf_base, uint64_t* __restrict__ lines, uint64_t* __restrict__ ovf) {
+    const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= nb) return;
+    const uint64_t b = (uint64_t)b0 + bi;
+    const uint32_t first = bfirst[bi], c = bfirst[bi + 1] - first;
+    const uint64_t kbase = base + b * div;
+    auto slot_of = [&](uint32_t j) { return ((keys[first + j] - kbase) << gshift) | (uint64_t)gids[first + j]; };
+    uint64_t s[LINE_SLOTS];
+    const uint32_t inl = c > LINE_SLOTS ? LINE_SLOTS - 1 : c;
+#pragma unroll
+    for (int j = 0; j < LINE_SLOTS; j++) s[j] = (uint32_t)j < inl ? slot_of(j) : SLOT_EMPTY;
+    if (c > LINE_SLOTS) {
+        const uint64_t start = ovf_base + ovf_off[bi];
+        s[LINE_SLOTS - 1] = (start << gshift) | (1ull << (gshift - 1));          // descriptor: flag set, genome field 0
+        uint64_t* o = ovf + start;
+        for (uint32_t j = LINE_SLOTS - 1; j < c; j++) *o++ = slot_of(j);
+        *o = SLOT_EMPTY;
+    }
+    uint4* lp = reinterpret_cast<uint4*>(lines + b * LINE_SLOTS);
+    lp[0] = make_uint4((uint32_t)s[0], (uint32_t)(s[0] >> 32), (uint32_t)s[1], (uint32_t)(s[1] >> 32));
+    lp[1] = make_uint4((uint32_t)s[2], (uint32_t)(s[2] >> 32), (uint32_t)s[3], (uint32_t)(s[3] >> 32));
+    lp[2] = make_uint4((uint32_t)s[4], (uint32_t)(s[4] >> 32), (uint32_t)s[5], (uint32_t)(s[5] >> 32));
+    lp[3] = make_uint4((uint32_t)s[6], (uint32_t)(s[6] >> 32), (uint32_t)s[7], (uint32_t)(s[7] >> 32));
+}
+
+// ---- probe -----------------------------------------------------------------------------------------------------------
+// One lane per sample k-mer, persistent workgroups striding over 256-k-mer chunks of the concatenated batch.  Hits are
+// (row << 32 | count), staged per workgroup in LDS and flushed with one global atomic per ~PROBE_FLUSH hits (one atomic per
+// chunk on a single word made the atomic unit 40 % of the kernel: ~88 single-address atomics/us on this chip).
 constexpr int PROBE_TPB = 256;
 constexpr int PROBE_STAGE = 4096;
 constexpr int PROBE_FLUSH = 2048;
-constexpr int PROBE_GRID = 512;    // measured optimum on MI355X: 256 -> 0.22 ms, 512 -> 0.177, 1024 -> 0.199, one workgroup per chunk -> 0.22
+constexpr int PROBE_GRID = 1024;
 
 struct HitStage {
     uint64_t stage[PROBE_STAGE];
@@ -90,59 +214,33 @@ __device__ __forceinline__ void hit_stage_flush(HitStage& st, bool force, uint64
     __syncthreads();
 }
 
-__global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const uint64_t* __restrict__ s_kmers,
-                                                          const uint32_t* __restrict__ s_counts, uint32_t n_sample,
-                                                          const uint64_t* __restrict__ db_kmer,
-                                                          const uint32_t* __restrict__ db_gid,
-                                                          const uint32_t* __restrict__ bucket_start, int shift,
-                                                          uint32_t n_buckets, const uint32_t* __restrict__ glen,
-                                                          double min_number_kmers, uint64_t* __restrict__ hits,
+__global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const SampleRef* __restrict__ refs, uint32_t n_samples, uint32_t n_chunks,
+                                                          LineView v, uint32_t n_genomes, const uint32_t* __restrict__ glen,
+                                                          double min_number_kmers, int check_len, uint64_t* __restrict__ hits,
                                                           uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
     __shared__ HitStage st;
     hit_stage_init(st);
-    const uint32_t n_chunks = (n_sample + PROBE_TPB - 1) / PROBE_TPB;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const uint32_t i = chunk * PROBE_TPB + threadIdx.x;
-        if (i < n_sample) {
-            const uint64_t km = s_kmers[i];
-            const uint32_t cnt = s_counts[i];
-            const uint64_t b = km >> shift;
-            if (cnt != 0 && b < n_buckets) {                                     // contain.rs:634
-                uint32_t lo = bucket_start[b];
-                const uint32_t end = bucket_start[b + 1];
-                uint32_t hi = end;
-                while (lo < hi) {                                                // lower_bound inside the bucket
-                    const uint32_t mid = lo + ((hi - lo) >> 1);
-                    if (db_kmer[mid] < km) lo = mid + 1; else hi = mid;
-                }
-                for (uint32_t j = lo; j < end && db_kmer[j] == km; j++) {
-                    const uint32_t g = db_gid[j];
-                    if ((double)glen[g] < min_number_kmers) continue;            // contain.rs:627
-                    hit_stage_push(st, ((uint64_t)g << 32) | cnt, hits, hit_cap, hit_count);
-                }
+        uint32_t s = 0, hi = n_samples;                  // sample of this chunk: largest s with chunk0[s] <= chunk (uniform)
+        while (hi - s > 1) {
+            const uint32_t mid = s + ((hi - s) >> 1);
+            if (refs[mid].chunk0 <= chunk) s = mid; else hi = mid;
+        }
+        const uint64_t* __restrict__ sk = refs[s].k;
+        const uint32_t* __restrict__ sc = refs[s].c;
+        const uint64_t i = (uint64_t)(chunk - refs[s].chunk0) * PROBE_TPB + threadIdx.x;
+        if (i < refs[s].n) {
+            const uint32_t cnt = sc[i];
+            if (cnt != 0) {                                                          // contain.rs:634
+                const uint64_t row0 = (uint64_t)s * n_genomes;
+                for_each_posting(v, sk[i], [&](uint32_t g) {
+                    if (check_len && (double)glen[g] < min_number_kmers) return;     // contain.rs:627
+                    hit_stage_push(st, ((row0 + g) << 32) | cnt, hits, hit_cap, hit_count);
+                });
             }
         }
         hit_stage_flush(st, chunk + gridDim.x >= n_chunks, hits, hit_cap, hit_count);
     }
-}
-
-// equal range of `km` in a bucketed postings index: [lo, hi)
-__device__ __forceinline__ void posting_range(const uint64_t* __restrict__ kmer, const uint32_t* __restrict__ bucket_start, int shift,
-                                              uint32_t n_buckets, uint64_t km, uint32_t& lo_out, uint32_t& hi_out) {
-    lo_out = hi_out = 0;
-    const uint64_t b = km >> shift;
-    if (b >= n_buckets) return;
-    uint32_t lo = bucket_start[b];
-    const uint32_t end = bucket_start[b + 1];
-    uint32_t hi = end;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (kmer[mid] < km) lo = mid + 1; else hi = mid;
-    }
-    uint32_t e = lo;
-    while (e < end && kmer[e] == km) e++;
-    lo_out = lo;
-    hi_out = e;
 }
 
 // Profile reassignment on device: winner_table (contain.rs:410-430) + the second get_stats pass (contain.rs:300-307 with
@@ -150,12 +248,11 @@ __device__ __forceinline__ void posting_range(const uint64_t* __restrict__ kmer,
 // hold it in genome_kmers or in pseudotax_tracked_nonused_kmers; ties go to the genome that comes first in the passing
 // list (the reference replaces only on strictly greater ANI, :417).  For every passing genome, sample k-mers of its
 // genome_kmers that it does not own count as kmers_lost, the others yield (genome, count) hits as in the first pass.
-__global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(
-    const uint64_t* __restrict__ s_kmers, const uint32_t* __restrict__ s_counts, uint32_t n_sample, const uint64_t* __restrict__ db_kmer,
-    const uint32_t* __restrict__ db_gid, const uint32_t* __restrict__ bucket_start, int shift, uint32_t n_buckets,
-    const uint64_t* __restrict__ t_kmer, const uint32_t* __restrict__ t_gid, const uint32_t* __restrict__ t_bucket_start, int t_shift,
-    uint32_t t_n_buckets, const uint32_t* __restrict__ rank, const double* __restrict__ ani, uint32_t* __restrict__ lost,
-    uint64_t* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
+__global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(const uint64_t* __restrict__ s_kmers, const uint32_t* __restrict__ s_counts,
+                                                             uint32_t n_sample, LineView kept, LineView tracked, int have_tracked,
+                                                             const uint32_t* __restrict__ rank, const double* __restrict__ ani,
+                                                             uint32_t* __restrict__ lost, uint64_t* __restrict__ hits, uint32_t hit_cap,
+                                                             uint32_t* __restrict__ hit_count) {
     __shared__ HitStage st;
     hit_stage_init(st);
     const uint32_t n_chunks = (n_sample + PROBE_TPB - 1) / PROBE_TPB;
@@ -164,39 +261,34 @@ __global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(
         const uint32_t cnt = i < n_sample ? s_counts[i] : 0;
         if (cnt != 0) {                                                          // contain.rs:634
             const uint64_t km = s_kmers[i];
-            uint32_t a0, a1, t0 = 0, t1 = 0;
-            posting_range(db_kmer, bucket_start, shift, n_buckets, km, a0, a1);
-            if (a1 > a0) {
-                if (t_n_buckets) posting_range(t_kmer, t_bucket_start, t_shift, t_n_buckets, km, t0, t1);
-                uint32_t best_rank = 0xFFFFFFFFu;
-                double best_ani = -1.0;
-                auto consider = [&](uint32_t g) {
+            uint32_t best_rank = 0xFFFFFFFFu, n_kept = 0;
+            double best_ani = -1.0;
+            auto consider = [&](uint32_t g) {
+                const uint32_t r = rank[g];
+                if (r == 0xFFFFFFFFu) return;
+                const double a = ani[r];
+                if (a > best_ani || (a == best_ani && r < best_rank)) { best_ani = a; best_rank = r; }
+            };
+            for_each_posting(kept, km, [&](uint32_t g) { n_kept++; consider(g); });
+            if (n_kept) {
+                if (have_tracked) for_each_posting(tracked, km, consider);
+                for_each_posting(kept, km, [&](uint32_t g) {
                     const uint32_t r = rank[g];
-                    if (r == 0xFFFFFFFFu) return;
-                    const double a = ani[r];
-                    if (a > best_ani || (a == best_ani && r < best_rank)) { best_ani = a; best_rank = r; }
-                };
-                for (uint32_t j = a0; j < a1; j++) consider(db_gid[j]);
-                for (uint32_t j = t0; j < t1; j++) consider(t_gid[j]);
-                for (uint32_t j = a0; j < a1; j++) {
-                    const uint32_t g = db_gid[j];
-                    const uint32_t r = rank[g];
-                    if (r == 0xFFFFFFFFu) continue;                              // not in remaining_genomes
-                    if (r != best_rank) { atomicAdd(&lost[g], 1u); continue; }   // contain.rs:639-642
+                    if (r == 0xFFFFFFFFu) return;                                // not in remaining_genomes
+                    if (r != best_rank) { atomicAdd(&lost[g], 1u); return; }     // contain.rs:639-642
                     hit_stage_push(st, ((uint64_t)g << 32) | cnt, hits, hit_cap, hit_count);
-                }
+                });
             }
         }
         hit_stage_flush(st, chunk + gridDim.x >= n_chunks, hits, hit_cap, hit_count);
     }
 }
 
-// cov_off[g] = first sorted hit with genome id >= g; covs[i] = low 32 bits of hit i
-__global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __restrict__ hits, uint32_t n_hits,
-                                                          uint32_t n_genomes, uint64_t* __restrict__ cov_off,
-                                                          uint32_t* __restrict__ contain_count) {
+// cov_off[r] = first sorted hit with row >= r; covs[i] = low 32 bits of hit i
+__global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __restrict__ hits, uint32_t n_hits, uint32_t n_rows,
+                                                          uint64_t* __restrict__ cov_off, uint32_t* __restrict__ contain_count) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > n_genomes) return;
+    if (g > n_rows) return;
     auto lower = [&](uint64_t key) {
         uint32_t lo = 0, hi = n_hits;
         while (lo < hi) {
@@ -207,12 +299,12 @@ __global__ __launch_bounds__(256) void hit_offsets_kernel(const uint64_t* __rest
     };
     const uint32_t a = lower((uint64_t)g << 32);
     cov_off[g] = a;
-    if (g < n_genomes) contain_count[g] = lower(((uint64_t)g + 1) << 32) - a;
+    if (g < n_rows) contain_count[g] = lower(((uint64_t)g + 1) << 32) - a;
 }
 
-// Compact hit keys: (genome << 32 | count) -> 32-bit (genome << cb | count) with cb = bit_length(max count), whenever
-// bit_length(G) + cb <= 32 (always at GTDB scale unless a count exceeds 2^15): the radix sort of the hit list then moves
-// 4-byte keys through 3-4 passes instead of 8-byte keys through 8.  Otherwise the 64-bit keys are sorted as they are.
+// Compact hit keys: (row << 32 | count) -> 32-bit (row << cb | count) with cb = bit_length(max count), whenever
+// bit_length(rows) + cb <= 32: the radix sort of the hit list then moves 4-byte keys through 3-4 passes instead of 8-byte
+// keys through 8.  Otherwise the 64-bit keys are sorted as they are.
 __global__ __launch_bounds__(256) void pack_hits32_kernel(const uint64_t* __restrict__ hits, uint32_t n, int cb, uint32_t* __restrict__ k32) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const uint64_t h = hits[i]; k32[i] = ((uint32_t)(h >> 32) << cb) | (uint32_t)h; }
@@ -222,11 +314,11 @@ __global__ __launch_bounds__(256) void narrow32_kernel(const uint32_t* __restric
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) covs[i] = (T)(k32[i] & ((1u << cb) - 1u));
 }
-__global__ __launch_bounds__(256) void hit_offsets32_kernel(const uint32_t* __restrict__ k32, uint32_t n_hits, uint32_t n_genomes, int cb,
+__global__ __launch_bounds__(256) void hit_offsets32_kernel(const uint32_t* __restrict__ k32, uint32_t n_hits, uint32_t n_rows, int cb,
                                                             uint64_t* __restrict__ cov_off, uint32_t* __restrict__ contain_count) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > n_genomes) return;
-    auto lower = [&](uint64_t key) {   // first hit whose (genome << cb | count) >= key
+    if (g > n_rows) return;
+    auto lower = [&](uint64_t key) {   // first hit whose (row << cb | count) >= key
         uint32_t lo = 0, hi = n_hits;
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -236,81 +328,228 @@ __global__ __launch_bounds__(256) void hit_offsets32_kernel(const uint32_t* __re
     };
     const uint32_t a = lower((uint64_t)g << cb);
     cov_off[g] = a;
-    if (g < n_genomes) contain_count[g] = lower(((uint64_t)g + 1) << cb) - a;
+    if (g < n_rows) contain_count[g] = lower(((uint64_t)g + 1) << cb) - a;
 }
 __global__ __launch_bounds__(256) void narrow_kernel(const uint64_t* __restrict__ hits, uint32_t n, uint32_t* __restrict__ covs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) covs[i] = (uint32_t)hits[i];
 }
 
+uint32_t grid_for64(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
+
 }  // namespace
+
+// ---- index build -------------------------------------------------------------------------------------------------------
+// Builds the line index over the postings of genome-major device arrays whose k-mer lies in [kmer_lo, kmer_hi) (kmer_hi == 0:
+// no upper bound).  The bucket range is processed in passes of about ctx->index_pass_max postings (filter -> stable radix
+// sort by k-mer -> lines), so neither the number of postings of a shard nor the temporary memory is tied to a 32-bit index.
+void build_line_index(sylph_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d_gid, uint64_t n, uint64_t n_genomes, uint64_t kmer_lo,
+                      uint64_t kmer_hi, LineIndex& ix) {
+    ScopedKernelTimer t(ctx, "db_index");
+    ix.lines.release();
+    ix.ovf.release();
+    ix.base = kmer_lo; ix.div = 1; ix.magic = 0; ix.n_postings = 0; ix.n_ovf = 0; ix.n_buckets = 0; ix.gshift = 2;
+    if (!n) return;
+    DevBuf b_stat(ctx);
+    b_stat.reserve(64);
+    auto range_stats = [&](uint64_t lo, uint64_t hi, uint64_t out[2]) {
+        SY_HIP(hipMemsetAsync(b_stat.p, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(range_stats_kernel, dim3((uint32_t)std::min<uint64_t>(grid_for64(n), 4096)), dim3(256), 0, ctx->stream, d_kmers, n,
+                           lo, hi, b_stat.as<unsigned long long>());
+        ctx->read_back(out, b_stat.p, 16);
+    };
+    uint64_t st[2] = {0, 0};
+    range_stats(kmer_lo, kmer_hi, st);
+    const uint64_t max_key = st[0], m_total = st[1];
+    ix.n_postings = m_total;
+    if (!m_total) return;
+    // slot = remainder << gshift | flag << gb | genome: gb bits of genome id, 63 - gb bits of remainder
+    const int gb = std::max(1, bit_length(n_genomes ? n_genomes - 1 : 0));
+    SY_REQUIRE(gb <= 30, "at most 2^30 genomes per shard");
+    ix.gshift = gb + 1;
+    const uint64_t div_cap = (1ull << (63 - gb)) - 1;                       // remainder < div keeps the all-ones pattern free
+    const uint64_t span = max_key - kmer_lo + 1;                            // bucket 0 starts at kmer_lo     (span >= 1)
+    const uint64_t want_buckets = std::max<uint64_t>(1, m_total / std::max<uint32_t>(1, ctx->index_lambda));
+    uint64_t div = span / want_buckets + (span % want_buckets ? 1 : 0);
+    if (span == 0) div = div_cap;                                           // (max_key - kmer_lo + 1 wrapped: the full 2^64 range)
+    div = std::min(std::max<uint64_t>(div, 1), div_cap);
+    const uint64_t nb64 = (max_key - kmer_lo) / div + 1;
+    SY_REQUIRE(nb64 < (1ull << 32) - 1, "index would need %llu buckets", (unsigned long long)nb64);
+    ix.div = div;
+    ix.magic = div > 1 ? (uint64_t)((((unsigned __int128)1) << 64) / div) : 0;
+    ix.n_buckets = (uint32_t)nb64;
+    ix.lines.reserve((size_t)nb64 * LINE_SLOTS * 8);
+    const uint64_t pass_max = std::max<uint64_t>(1, ctx->index_pass_max);
+    const uint32_t n_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb64, (m_total + pass_max - 1) / pass_max));
+    const bool whole = n_pass == 1 && m_total == n;                         // nothing to filter: sort the input directly
+    DevBuf b_fk(ctx), b_fg(ctx), b_sk(ctx), b_sg(ctx), b_wg(ctx), b_bf(ctx), b_need(ctx);
+    uint64_t ovf_total = 0;
+    for (uint32_t p = 0; p < n_pass; p++) {
+        const uint32_t b0 = (uint32_t)(nb64 * p / n_pass), b1 = (uint32_t)(nb64 * (p + 1) / n_pass);
+        const uint32_t nbp = b1 - b0;
+        const uint64_t klo = kmer_lo + (uint64_t)b0 * div;
+        uint64_t khi = kmer_hi;                                             // last pass: up to the shard's own bound
+        if (p + 1 < n_pass) khi = kmer_lo + (uint64_t)b1 * div;             // (b1 * div <= max_key - kmer_lo: no overflow)
+        const uint64_t* fk = d_kmers;
+        const uint32_t* fg = d_gid;
+        uint64_t m = n;
+        if (!whole) {
+            uint64_t cnt[2] = {0, 0};
+            range_stats(klo, khi, cnt);
+            m = cnt[1];
+            SY_REQUIRE(m < (1ull << 32) - 1, "index pass holds %llu postings: lower index_pass_max", (unsigned long long)m);
+            if (m) {
+                const uint32_t n_wg = grid_for64(n, FILT_TILE);
+                b_wg.reserve(((size_t)n_wg + 1) * 8);
+                uint32_t* wg_count = b_wg.as<uint32_t>();
+                uint32_t* wg_off = wg_count + (n_wg + 1);
+                SY_HIP(hipMemsetAsync(wg_count + n_wg, 0, 4, ctx->stream));
+                hipLaunchKernelGGL(filter_count_kernel, dim3(n_wg), dim3(FILT_TPB), 0, ctx->stream, d_kmers, n, klo, khi, wg_count);
+                exclusive_sum_u32(ctx, wg_count, wg_off, (size_t)n_wg + 1);
+                b_fk.reserve(m * 8);
+                b_fg.reserve(m * 4);
+                hipLaunchKernelGGL(filter_scatter_kernel, dim3(n_wg), dim3(FILT_TPB), 0, ctx->stream, d_kmers, d_gid, n, klo, khi, wg_off,
+                                   b_fk.as<uint64_t>(), b_fg.as<uint32_t>());
+            }
+            fk = b_fk.as<uint64_t>();
+            fg = b_fg.as<uint32_t>();
+        } else {
+            SY_REQUIRE(m < (1ull << 32) - 1, "internal: single pass with %llu postings", (unsigned long long)m);
+        }
+        b_sk.reserve(std::max<uint64_t>(m, 1) * 8);
+        b_sg.reserve(std::max<uint64_t>(m, 1) * 4);
+        if (m) sort_pairs_u64_u32(ctx, fk, b_sk.as<uint64_t>(), fg, b_sg.as<uint32_t>(), m, 0, 64);   // stable: genome ids stay ascending
+        b_bf.reserve(((size_t)nbp + 2) * 4);
+        b_need.reserve(((size_t)nbp + 2) * 8);
+        uint32_t* bfirst = b_bf.as<uint32_t>();
+        uint32_t* need = b_need.as<uint32_t>();
+        uint32_t* ovf_off = need + (nbp + 1);
+        hipLaunchKernelGGL(bucket_first_kernel, dim3(grid_for64((uint64_t)m + 1)), dim3(256), 0, ctx->stream, b_sk.as<uint64_t>(),
+                           (uint32_t)m, kmer_lo, div, b0, b1, bfirst);
+        hipLaunchKernelGGL(ovf_need_kernel, dim3(grid_for64((uint64_t)nbp + 1)), dim3(256), 0, ctx->stream, bfirst, nbp, need);
+        exclusive_sum_u32(ctx, need, ovf_off, (size_t)nbp + 1);
+        uint32_t ovf_pass = 0;
+        ctx->read_back(&ovf_pass, ovf_off + nbp, 4);
+        ix.ovf.grow_keep((ovf_total + ovf_pass + 1) * 8, ovf_total * 8, ctx->stream);
+        hipLaunchKernelGGL(write_lines_kernel, dim3(grid_for64(nbp)), dim3(256), 0, ctx->stream, b_sk.as<uint64_t>(), b_sg.as<uint32_t>(),
+                           bfirst, ovf_off, b0, nbp, kmer_lo, div, ix.gshift, ovf_total, ix.lines.as<uint64_t>(), ix.ovf.as<uint64_t>());
+        SY_HIP(hipGetLastError());
+        ovf_total += ovf_pass;
+        SY_REQUIRE(ovf_total < (1ull << (62 - gb)), "overflow area too large for the slot format");
+    }
+    ix.n_ovf = ovf_total;
+    SY_HIP(hipStreamSynchronize(ctx->stream));   // the temporaries and the caller's staging buffers are released on return
+}
+
+static uint32_t probe_grid() {
+    static const uint32_t g = getenv("SYLPH_HIP_PROBE_GRID") ? (uint32_t)atoi(getenv("SYLPH_HIP_PROBE_GRID")) : PROBE_GRID;
+    return std::max<uint32_t>(1, g);
+}
+
+uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint32_t* max_count) {
+    sylph_ctx* ctx = db->ctx;
+    const uint64_t G = db->n_genomes;
+    uint64_t total = 0, chunks = 0;
+    for (auto& r : refs) {
+        SY_REQUIRE(r.n < (1ull << 32), "sample table larger than 2^32-1 entries");
+        SY_REQUIRE(chunks < (1ull << 32), "batch too large");
+        r.chunk0 = (uint32_t)chunks;
+        r.pad = 0;
+        chunks += (r.n + PROBE_TPB - 1) / PROBE_TPB;
+        total += r.n;
+    }
+    SY_REQUIRE(chunks < (1ull << 32) && total < (1ull << 32), "batch holds more than 2^32-1 k-mers: split it");
+    SY_REQUIRE((uint64_t)refs.size() * std::max<uint64_t>(G, 1) < (1ull << 32) - 1, "samples x genomes must stay below 2^32: split the batch");
+    *max_count = 0;
+    if (!total || !db->kept.n_postings) return 0;
+    db->q_refs.reserve(refs.size() * sizeof(SampleRef));
+    ctx->h2d(db->q_refs.p, refs.data(), refs.size() * sizeof(SampleRef));
+    uint64_t cap = std::max<uint64_t>(total * 2, 1u << 20);
+    uint32_t* d_cnt = db->counter.as<uint32_t>();   // [0] = number of hits, [1] = largest count among the hits
+    const int check_len = (double)db->min_glen < min_number_kmers;
+    uint32_t n_hits = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one batch: split it");
+        db->hits.reserve(cap * 8);
+        SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        {
+            ScopedKernelTimer t(ctx, "probe");
+            hipLaunchKernelGGL(probe_kernel, dim3(std::min<uint32_t>((uint32_t)chunks, probe_grid())), dim3(PROBE_TPB), 0, ctx->stream,
+                               db->q_refs.as<SampleRef>(), (uint32_t)refs.size(), (uint32_t)chunks, db->kept.view(), (uint32_t)G,
+                               db->glen.as<uint32_t>(), min_number_kmers, check_len, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
+            SY_HIP(hipGetLastError());
+        }
+        uint32_t hc[2] = {0, 0};
+        ctx->read_back(hc, d_cnt, 8);
+        n_hits = hc[0];
+        *max_count = hc[1];
+        if (n_hits <= cap) break;
+        SY_REQUIRE(attempt == 0, "hit buffer overflow persisted");
+        cap = n_hits;
+    }
+    return n_hits;
+}
+
+// cov_width: nullptr = coverage values as u32; else in/out — the values are stored with the narrowest of 1, 2 or 4 bytes
+// that holds the batch's largest count (7.4 MB -> 1.9 MB over PCIe per sample at GTDB scale) and the width is returned.
+void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost) {
+    sylph_ctx* ctx = db->ctx;
+    const uint64_t G = db->n_genomes;
+    SY_REQUIRE(n_rows < (1ull << 32) - 1, "too many result rows");
+    const int cb = std::max(1, bit_length(max_count)), rb = std::max(1, bit_length(n_rows));
+    uint32_t width = 4;
+    if (cov_width && n_hits && cb + rb <= 32) width = cb <= 8 ? 1 : cb <= 16 ? 2 : 4;
+    const ResultLayout lay(n_rows, n_hits, width, with_lost ? G : 0);
+    db->lay = lay;
+    db->last_rows = n_rows;
+    db->res.reserve(lay.lost + 64);
+    char* d_res = db->res.as<char>();
+    uint64_t* d_cov_off = reinterpret_cast<uint64_t*>(d_res);
+    uint32_t* d_ccount = reinterpret_cast<uint32_t*>(d_res + lay.ccount);
+    void* d_covs = d_res + lay.covs;
+    if (n_hits && cb + rb <= 32) {
+        db->hits_sorted.reserve((size_t)n_hits * 8);   // two u32 arrays: packed keys, sorted keys
+        uint32_t* k32 = db->hits_sorted.as<uint32_t>();
+        uint32_t* k32s = k32 + n_hits;
+        hipLaunchKernelGGL(pack_hits32_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, db->hits.as<uint64_t>(), n_hits, cb, k32);
+        sort_keys_u32(ctx, k32, k32s, n_hits, 0, cb + rb);
+        if (width == 1) hipLaunchKernelGGL(narrow32_kernel<uint8_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint8_t*)d_covs);
+        else if (width == 2) hipLaunchKernelGGL(narrow32_kernel<uint16_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint16_t*)d_covs);
+        else hipLaunchKernelGGL(narrow32_kernel<uint32_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint32_t*)d_covs);
+        hipLaunchKernelGGL(hit_offsets32_kernel, dim3(grid_for64(n_rows + 1)), dim3(256), 0, ctx->stream, k32s, n_hits, (uint32_t)n_rows, cb,
+                           d_cov_off, d_ccount);
+    } else {
+        const uint64_t* d_sorted = nullptr;
+        if (n_hits) {
+            db->hits_sorted.reserve((size_t)n_hits * 8);
+            sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
+            d_sorted = db->hits_sorted.as<uint64_t>();
+            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits, (uint32_t*)d_covs);
+        }
+        hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(n_rows + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits, (uint32_t)n_rows,
+                           d_cov_off, d_ccount);
+    }
+    SY_HIP(hipGetLastError());
+    // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
+    const size_t need = lay.end + 64;
+    if (need > db->h_res_cap) {
+        if (db->h_res) SY_HIP(hipHostFree(db->h_res));
+        db->h_res = nullptr;
+        db->h_res_cap = 0;
+        SY_HIP(hipHostMalloc(&db->h_res, need + need / 2, hipHostMallocDefault));
+        db->h_res_cap = need + need / 2;
+    }
+    char* h = (char*)db->h_res;
+    SY_HIP(hipMemcpyAsync(h, d_res, lay.covs + (size_t)n_hits * width, hipMemcpyDeviceToHost, ctx->stream));   // one copy
+    if (with_lost && G) SY_HIP(hipMemcpyAsync(h + lay.lost, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (cov_width) *cov_width = width;
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->pending.empty()) profile_collect(ctx);
+}
+
 }  // namespace sylph
 
 using namespace sylph;
-
-// Layout of the result block, identical on the device (one buffer, ONE device->host copy) and in pinned host memory:
-// [cov_off (G+1) u64 | contain_count G u32 | covs n_hits x width | pad to 8 | kmers_lost G u32 (reassign only, second copy)].
-struct ResultLayout {
-    size_t ccount = 0, covs = 0, lost = 0, end = 0;
-    ResultLayout() = default;
-    ResultLayout(uint64_t G, uint64_t n_hits, uint32_t width, bool reassign)
-        : ccount((G + 1) * 8), covs(ccount + G * 4), lost((covs + n_hits * width + 7) & ~(size_t)7), end(lost + (reassign ? G * 4 : 0)) {}
-};
-
-struct sylph_db {
-    sylph_ctx* ctx;
-    uint64_t n_genomes = 0, n_kmers = 0;
-    int shift = 0;
-    uint32_t n_buckets = 0;
-    DevBuf kmer, gid, bucket_start, glen;
-    // optional second postings index over pseudotax_tracked_nonused_kmers (types.rs:166), only used by the winner table
-    DevBuf t_kmer, t_gid, t_bucket_start;
-    int t_shift = 0;
-    uint32_t t_n_buckets = 0;
-    uint64_t t_n = 0;
-    DevBuf rank, ani, lost;        // reassign pass: rank[g] in the passing list (or ~0), ANI per rank, kmers_lost[g]
-    // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
-    DevBuf q_kmers, q_counts, hits, hits_sorted, res, counter;   // res: device copy of the result block
-    ResultLayout lay;              // layout of the last result
-    void* h_res = nullptr;         // pinned host results: [cov_off (G+1) u64 | contain_count G u32 | covs u32]
-    size_t h_res_cap = 0;
-    ~sylph_db() { if (h_res) (void)hipHostFree(h_res); }
-    explicit sylph_db(sylph_ctx* cx)
-        : ctx(cx), kmer(cx), gid(cx), bucket_start(cx), glen(cx), t_kmer(cx), t_gid(cx), t_bucket_start(cx), rank(cx),
-          ani(cx), lost(cx), q_kmers(cx), q_counts(cx), hits(cx), hits_sorted(cx),
-          res(cx), counter(cx) {}
-};
-
-static uint32_t grid_for64(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
-
-// Builds a postings index (k-mers sorted, genome id per posting, bucket table) from genome-major device arrays.
-static void build_postings(sylph_ctx* ctx, const uint64_t* d_kmers_in, const uint64_t* d_off, uint64_t n_genomes, uint64_t n,
-                           DevBuf& kmer, DevBuf& gid, DevBuf& bucket_start, int& shift, uint32_t& n_buckets) {
-    ScopedKernelTimer t(ctx, "db_index");
-    DevBuf gid_in(ctx);
-    gid_in.reserve(n * 4);
-    kmer.reserve(n * 8);
-    gid.reserve(n * 4);
-    hipLaunchKernelGGL(fill_gid_kernel, dim3((uint32_t)std::min<uint64_t>(n_genomes, 1u << 20)), dim3(256), 0, ctx->stream, d_off,
-                       n_genomes, gid_in.as<uint32_t>());
-    sort_pairs_u64_u32(ctx, d_kmers_in, kmer.as<uint64_t>(), gid_in.as<uint32_t>(), gid.as<uint32_t>(), n, 0, 64);
-    uint64_t max_key = 0;
-    ctx->read_back(&max_key, kmer.as<uint64_t>() + (n - 1), 8);
-    // ~2-3 postings per bucket on average, index <= 2^30 entries (measured on MI355X at 1.8e9 postings: 8 per bucket 0.177 ms
-    // per probe of a 2 M-entry sample, 2 per bucket 0.166 ms, 32 per bucket 0.20 ms: the dependent loads inside the bucket
-    // cost more than the larger table)
-    static const uint64_t ppb = getenv("SYLPH_HIP_POSTINGS_PER_BUCKET") ? std::max(1, atoi(getenv("SYLPH_HIP_POSTINGS_PER_BUCKET"))) : 2;
-    int b = bit_length(n / ppb);
-    b = std::min(getenv("SYLPH_HIP_BUCKET_BITS_MAX") ? atoi(getenv("SYLPH_HIP_BUCKET_BITS_MAX")) : 30, std::max(8, b));
-    const int bits = std::max(1, bit_length(max_key));
-    shift = std::max(0, bits - b);
-    n_buckets = (uint32_t)((max_key >> shift) + 1);
-    bucket_start.reserve(((size_t)n_buckets + 1) * 4);
-    hipLaunchKernelGGL(bucket_index_kernel, dim3(grid_for64(n + 1)), dim3(256), 0, ctx->stream, kmer.as<uint64_t>(), (uint32_t)n,
-                       shift, n_buckets, bucket_start.as<uint32_t>());
-    SY_HIP(hipGetLastError());
-    SY_HIP(hipStreamSynchronize(ctx->stream));   // the caller's staging buffers / gid_in are released on return
-}
 
 // Stages genome-major (k-mers, offsets) on the device if they are host arrays; returns the device pointers and the total.
 static uint64_t stage_genome_major(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* off, uint64_t n_genomes, int mem,
@@ -339,123 +578,119 @@ static uint64_t stage_genome_major(sylph_ctx* ctx, const uint64_t* kmers, const 
     return n;
 }
 
-extern "C" {
-
-int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
-                    sylph_db** out) {
-    return guarded([&] {
-        SY_REQUIRE(ctx && out, "null argument");
-        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
-        SY_REQUIRE(n_genomes < (1ull << 32), "at most 2^32-1 genomes per shard");
-        SY_REQUIRE(n_genomes == 0 || genome_off, "null genome_off");
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        DeviceGuard dg(ctx->device);
-        std::unique_ptr<sylph_db> db(new sylph_db(ctx));
-        db->n_genomes = n_genomes;
-        db->counter.reserve(64);
-        DevBuf d_off_buf(ctx), d_in(ctx);
-        const uint64_t* d_off = nullptr;
-        const uint64_t* d_kmers_in = nullptr;
-        const uint64_t n = stage_genome_major(ctx, kmers, genome_off, n_genomes, mem, d_off_buf, d_in, d_off, d_kmers_in);
-        SY_REQUIRE(n < (1ull << 32), "at most 2^32-1 k-mers per shard (got %llu): shard the database", (unsigned long long)n);
-        db->n_kmers = n;
-        db->glen.reserve(std::max<uint64_t>(1, n_genomes) * 4);
-        if (n_genomes)
-            hipLaunchKernelGGL(genome_len_kernel, dim3(grid_for64(n_genomes)), dim3(256), 0, ctx->stream, d_off, n_genomes,
-                               db->glen.as<uint32_t>());
-        if (n) build_postings(ctx, d_kmers_in, d_off, n_genomes, n, db->kmer, db->gid, db->bucket_start, db->shift, db->n_buckets);
-        ctx->refs++;
-        *out = db.release();
-    });
+// genome-major device arrays -> line index over the k-mers in [lo, hi)
+static void index_genome_major(sylph_ctx* ctx, const uint64_t* d_kmers, const uint64_t* d_off, uint64_t n_genomes, uint64_t n, uint64_t lo,
+                               uint64_t hi, LineIndex& ix) {
+    DevBuf gid(ctx);
+    gid.reserve(std::max<uint64_t>(n, 1) * 4);
+    if (n)
+        hipLaunchKernelGGL(fill_gid_kernel, dim3((uint32_t)std::min<uint64_t>(n_genomes, 1u << 20)), dim3(256), 0, ctx->stream, d_off, n_genomes,
+                           gid.as<uint32_t>());
+    build_line_index(ctx, d_kmers, gid.as<uint32_t>(), n, n_genomes, lo, hi, ix);
+    SY_HIP(hipStreamSynchronize(ctx->stream));
 }
 
-int sylph_db_attach_tracked(sylph_db* db, const uint64_t* tracked_kmers, const uint64_t* tracked_off, int mem) {
-    return guarded([&] {
-        SY_REQUIRE(db && tracked_off, "null argument");
-        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
-        sylph_ctx* ctx = db->ctx;
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        DeviceGuard dg(ctx->device);
-        DevBuf d_off_buf(ctx), d_in(ctx);
-        const uint64_t* d_off = nullptr;
-        const uint64_t* d_k = nullptr;
-        const uint64_t n = stage_genome_major(ctx, tracked_kmers, tracked_off, db->n_genomes, mem, d_off_buf, d_in, d_off, d_k);
-        SY_REQUIRE(n < (1ull << 32), "at most 2^32-1 tracked k-mers per shard");
-        db->t_n = n;
-        db->t_n_buckets = 0;
-        if (n) build_postings(ctx, d_k, d_off, db->n_genomes, n, db->t_kmer, db->t_gid, db->t_bucket_start, db->t_shift, db->t_n_buckets);
-    });
-}
-
-uint64_t sylph_db_n_genomes(const sylph_db* db) { return db ? db->n_genomes : 0; }
-uint64_t sylph_db_n_kmers(const sylph_db* db) { return db ? db->n_kmers : 0; }
-
-// Runs the probe and leaves (cov_off, contain_count, covs) in db->h_res (pinned).  Returns the number of hits.
-static uint32_t probe_grid() {
-    static const uint32_t g = getenv("SYLPH_HIP_PROBE_GRID") ? (uint32_t)atoi(getenv("SYLPH_HIP_PROBE_GRID")) : PROBE_GRID;
-    return std::max<uint32_t>(1, g);
+static void db_upload_impl(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
+                           const uint64_t* bounds, uint32_t world, uint32_t rank, sylph_db** out) {
+    SY_REQUIRE(ctx && out, "null argument");
+    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+    SY_REQUIRE(n_genomes < (1ull << 30), "at most 2^30-1 genomes per shard");
+    SY_REQUIRE(n_genomes == 0 || genome_off, "null genome_off");
+    SY_REQUIRE(world >= 1 && rank < world, "bad rank %u of %u", rank, world);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    std::unique_ptr<sylph_db> db(new sylph_db(ctx));
+    db->n_genomes = n_genomes;
+    db->world = world;
+    db->rank = rank;
+    if (bounds) {
+        db->bounds.assign(bounds, bounds + world + 1);
+        for (uint32_t r = 0; r < world; r++) SY_REQUIRE(db->bounds[r] <= db->bounds[r + 1], "shard bounds must be non-decreasing");
+        SY_REQUIRE(db->bounds[0] == 0, "bounds[0] must be 0");
+    }
+    db->counter.reserve(64);
+    DevBuf d_off_buf(ctx), d_in(ctx);
+    const uint64_t* d_off = nullptr;
+    const uint64_t* d_kmers_in = nullptr;
+    const uint64_t n = stage_genome_major(ctx, kmers, genome_off, n_genomes, mem, d_off_buf, d_in, d_off, d_kmers_in);
+    db->glen.reserve(std::max<uint64_t>(1, n_genomes) * 4);
+    uint32_t min_len = 0;
+    if (n_genomes) {
+        uint32_t* d_min = db->counter.as<uint32_t>() + 4;
+        SY_HIP(hipMemsetAsync(d_min, 0xFF, 4, ctx->stream));
+        hipLaunchKernelGGL(genome_len_kernel, dim3(grid_for64(n_genomes)), dim3(256), 0, ctx->stream, d_off, n_genomes, db->glen.as<uint32_t>(),
+                           d_min);
+        ctx->read_back(&min_len, d_min, 4);
+    }
+    db->min_glen = min_len;
+    const uint64_t lo = bounds ? db->bounds[rank] : 0, hi = bounds ? db->bounds[rank + 1] : 0;
+    const bool last = !bounds || rank + 1 == world;   // the last shard is open-ended (hi == 0 means "no upper bound" in the build)
+    if (last || hi > lo) index_genome_major(ctx, d_kmers_in, d_off, n_genomes, n, lo, last ? 0 : hi, db->kept);
+    else db->kept.base = lo;                         // an empty range (more ranks than k-mer values)
+    db->n_kmers = db->kept.n_postings;
+    ctx->refs++;
+    *out = db.release();
 }
 
 struct ReassignArgs { const uint32_t* passing_gids; const double* passing_ani; uint32_t n_passing; };
 
-// cov_width: nullptr = coverage values as u32; else in/out — the values are stored with the narrowest of 1, 2 or 4 bytes
-// that holds the sample's largest count (7.4 MB -> 1.9 MB over PCIe per sample at GTDB scale) and the width is returned.
+// single-sample entry points (and the reassignment pass): results in db->h_res, returns the number of hits
 static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
                              double min_number_kmers, const ReassignArgs* re = nullptr, uint32_t* cov_width = nullptr) {
     SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
     SY_REQUIRE(n < (1ull << 32), "sample table larger than 2^32-1 entries");
+    SY_REQUIRE(db->world == 1, "this database is one shard of %u: use sylph_db_contain_batch_sharded", db->world);
     sylph_ctx* ctx = db->ctx;
     const uint64_t G = db->n_genomes;
     uint32_t n_hits = 0, max_count = 0;
-    if (re) {   // rank[g] = position of genome g in the passing list (or ~0), ani[rank], lost[g] = 0
-        SY_REQUIRE(re->n_passing == 0 || (re->passing_gids && re->passing_ani), "null passing list");
-        std::vector<uint32_t> rank(std::max<uint64_t>(1, G), 0xFFFFFFFFu);
-        for (uint32_t r = 0; r < re->n_passing; r++) {
-            SY_REQUIRE(re->passing_gids[r] < G, "passing genome id %u out of range", re->passing_gids[r]);
-            SY_REQUIRE(rank[re->passing_gids[r]] == 0xFFFFFFFFu, "genome %u listed twice", re->passing_gids[r]);
-            rank[re->passing_gids[r]] = r;
-        }
-        db->rank.reserve(rank.size() * 4);
-        db->ani.reserve(std::max<size_t>(1, re->n_passing) * 8);
-        db->lost.reserve(rank.size() * 4);
-        ctx->h2d(db->rank.p, rank.data(), rank.size() * 4);
-        if (re->n_passing) ctx->h2d(db->ani.p, re->passing_ani, (size_t)re->n_passing * 8);
-        SY_HIP(hipMemsetAsync(db->lost.p, 0, rank.size() * 4, ctx->stream));
-    }
-    if (n && db->n_kmers && (!re || re->n_passing)) {
+    const uint64_t* d_k = sample_kmers;
+    const uint32_t* d_c = sample_counts;
+    if (n && mem == SYLPH_MEM_HOST) {
         SY_REQUIRE(sample_kmers && sample_counts, "null sample");
-        const uint64_t* d_k = sample_kmers;
-        const uint32_t* d_c = sample_counts;
-        if (mem == SYLPH_MEM_HOST) {
-            db->q_kmers.reserve(n * 8);
-            db->q_counts.reserve(n * 4);
-            ctx->h2d(db->q_kmers.p, sample_kmers, n * 8);
-            ctx->h2d(db->q_counts.p, sample_counts, n * 4);
-            d_k = db->q_kmers.as<uint64_t>();
-            d_c = db->q_counts.as<uint32_t>();
-        }
+        db->q_kmers.reserve(n * 8);
+        db->q_counts.reserve(n * 4);
+        ctx->h2d(db->q_kmers.p, sample_kmers, n * 8);
+        ctx->h2d(db->q_counts.p, sample_counts, n * 4);
+        d_k = db->q_kmers.as<uint64_t>();
+        d_c = db->q_counts.as<uint32_t>();
+    }
+    if (!re) {
+        if (n) SY_REQUIRE(d_k && d_c, "null sample");
+        std::vector<SampleRef> refs(1);
+        refs[0].k = d_k; refs[0].c = d_c; refs[0].n = n;
+        n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
+        finish_hits(db, n_hits, max_count, G, cov_width, false);
+        return n_hits;
+    }
+    // rank[g] = position of genome g in the passing list (or ~0), ani[rank], lost[g] = 0
+    SY_REQUIRE(re->n_passing == 0 || (re->passing_gids && re->passing_ani), "null passing list");
+    std::vector<uint32_t> rank(std::max<uint64_t>(1, G), 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < re->n_passing; r++) {
+        SY_REQUIRE(re->passing_gids[r] < G, "passing genome id %u out of range", re->passing_gids[r]);
+        SY_REQUIRE(rank[re->passing_gids[r]] == 0xFFFFFFFFu, "genome %u listed twice", re->passing_gids[r]);
+        rank[re->passing_gids[r]] = r;
+    }
+    db->rank_of.reserve(rank.size() * 4);
+    db->ani.reserve(std::max<size_t>(1, re->n_passing) * 8);
+    db->lost.reserve(rank.size() * 4);
+    ctx->h2d(db->rank_of.p, rank.data(), rank.size() * 4);
+    if (re->n_passing) ctx->h2d(db->ani.p, re->passing_ani, (size_t)re->n_passing * 8);
+    SY_HIP(hipMemsetAsync(db->lost.p, 0, rank.size() * 4, ctx->stream));
+    if (n && db->kept.n_postings && re->n_passing) {
+        SY_REQUIRE(d_k && d_c, "null sample");
         uint64_t cap = std::max<uint64_t>(n * 2, 1u << 20);
-        uint32_t* d_cnt = db->counter.as<uint32_t>();   // [0] = number of hits, [1] = largest count among the hits
+        uint32_t* d_cnt = db->counter.as<uint32_t>();
         for (int attempt = 0; attempt < 2; attempt++) {
             SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one sample");
             db->hits.reserve(cap * 8);
             SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+            if (attempt) SY_HIP(hipMemsetAsync(db->lost.p, 0, std::max<uint64_t>(1, G) * 4, ctx->stream));
             {
                 ScopedKernelTimer t(ctx, "probe");
-                if (!re)
-                    hipLaunchKernelGGL(probe_kernel, dim3(std::min<uint32_t>(grid_for64(n, PROBE_TPB), probe_grid())), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
-                                       (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
-                                       db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->glen.as<uint32_t>(),
-                                       min_number_kmers, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
-                else {
-                    if (attempt) SY_HIP(hipMemsetAsync(db->lost.p, 0, std::max<uint64_t>(1, G) * 4, ctx->stream));
-                    hipLaunchKernelGGL(reassign_kernel, dim3(std::min<uint32_t>(grid_for64(n, PROBE_TPB), probe_grid())), dim3(PROBE_TPB), 0, ctx->stream, d_k, d_c,
-                                       (uint32_t)n, db->kmer.as<uint64_t>(), db->gid.as<uint32_t>(),
-                                       db->bucket_start.as<uint32_t>(), db->shift, db->n_buckets, db->t_kmer.as<uint64_t>(),
-                                       db->t_gid.as<uint32_t>(), db->t_bucket_start.as<uint32_t>(), db->t_shift, db->t_n_buckets,
-                                       db->rank.as<uint32_t>(), db->ani.as<double>(), db->lost.as<uint32_t>(),
-                                       db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
-                }
+                hipLaunchKernelGGL(reassign_kernel, dim3(std::min<uint32_t>(grid_for64(n, PROBE_TPB), probe_grid())), dim3(PROBE_TPB), 0, ctx->stream,
+                                   d_k, d_c, (uint32_t)n, db->kept.view(), db->tracked.view(), db->tracked.n_postings ? 1 : 0,
+                                   db->rank_of.as<uint32_t>(), db->ani.as<double>(), db->lost.as<uint32_t>(), db->hits.as<uint64_t>(),
+                                   (uint32_t)cap, d_cnt);
                 SY_HIP(hipGetLastError());
             }
             uint32_t hc[2] = {0, 0};
@@ -467,57 +702,55 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             cap = n_hits;
         }
     }
-    const int cb = std::max(1, bit_length(max_count)), gb = std::max(1, bit_length(G));
-    uint32_t width = 4;
-    if (cov_width && n_hits && cb + gb <= 32) width = cb <= 8 ? 1 : cb <= 16 ? 2 : 4;
-    const ResultLayout lay(G, n_hits, width, re != nullptr);
-    db->lay = lay;
-    db->res.reserve(lay.lost + 64);
-    char* d_res = db->res.as<char>();
-    uint64_t* d_cov_off = reinterpret_cast<uint64_t*>(d_res);
-    uint32_t* d_ccount = reinterpret_cast<uint32_t*>(d_res + lay.ccount);
-    void* d_covs = d_res + lay.covs;
-    if (n_hits && cb + gb <= 32) {
-        db->hits_sorted.reserve((size_t)n_hits * 8);   // two u32 arrays: packed keys, sorted keys
-        uint32_t* k32 = db->hits_sorted.as<uint32_t>();
-        uint32_t* k32s = k32 + n_hits;
-        hipLaunchKernelGGL(pack_hits32_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, db->hits.as<uint64_t>(), n_hits, cb,
-                           k32);
-        sort_keys_u32(ctx, k32, k32s, n_hits, 0, cb + gb);
-        if (width == 1) hipLaunchKernelGGL(narrow32_kernel<uint8_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint8_t*)d_covs);
-        else if (width == 2) hipLaunchKernelGGL(narrow32_kernel<uint16_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint16_t*)d_covs);
-        else hipLaunchKernelGGL(narrow32_kernel<uint32_t>, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, k32s, n_hits, cb, (uint32_t*)d_covs);
-        hipLaunchKernelGGL(hit_offsets32_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, k32s, n_hits, (uint32_t)G, cb,
-                           d_cov_off, d_ccount);
-    } else {
-        const uint64_t* d_sorted = nullptr;
-        if (n_hits) {
-            db->hits_sorted.reserve((size_t)n_hits * 8);
-            sort_keys_u64(ctx, db->hits.as<uint64_t>(), db->hits_sorted.as<uint64_t>(), n_hits, 0, 64);
-            d_sorted = db->hits_sorted.as<uint64_t>();
-            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for64(n_hits)), dim3(256), 0, ctx->stream, d_sorted, n_hits,
-                               (uint32_t*)d_covs);
-        }
-        hipLaunchKernelGGL(hit_offsets_kernel, dim3(grid_for64(G + 1)), dim3(256), 0, ctx->stream, d_sorted, n_hits, (uint32_t)G,
-                           d_cov_off, d_ccount);
-    }
-    SY_HIP(hipGetLastError());
-    // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
-    const size_t need = lay.end + 64;
-    if (need > db->h_res_cap) {
-        if (db->h_res) SY_HIP(hipHostFree(db->h_res));
-        db->h_res = nullptr;
-        db->h_res_cap = 0;
-        SY_HIP(hipHostMalloc(&db->h_res, need + need / 2, hipHostMallocDefault));
-        db->h_res_cap = need + need / 2;
-    }
-    char* h = (char*)db->h_res;
-    SY_HIP(hipMemcpyAsync(h, d_res, lay.covs + (size_t)n_hits * width, hipMemcpyDeviceToHost, ctx->stream));   // one copy
-    if (re && G) SY_HIP(hipMemcpyAsync(h + lay.lost, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (cov_width) *cov_width = width;
-    SY_HIP(hipStreamSynchronize(ctx->stream));
-    if (!ctx->pending.empty()) profile_collect(ctx);
+    finish_hits(db, n_hits, max_count, G, cov_width, true);
     return n_hits;
+}
+
+extern "C" {
+
+int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
+                    sylph_db** out) {
+    return guarded([&] { db_upload_impl(ctx, kmers, genome_off, n_genomes, mem, nullptr, 1, 0, out); });
+}
+
+int sylph_shard_bounds(uint64_t max_kmer, uint32_t world, uint64_t* bounds) {
+    return guarded([&] {
+        SY_REQUIRE(bounds && world >= 1, "bad argument");
+        const unsigned __int128 span = (unsigned __int128)max_kmer + 1;
+        for (uint32_t r = 0; r < world; r++) bounds[r] = (uint64_t)(span * r / world);
+        bounds[world] = max_kmer == UINT64_MAX ? UINT64_MAX : max_kmer + 1;
+    });
+}
+
+int sylph_db_upload_shard(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
+                          const uint64_t* bounds, uint32_t world, uint32_t rank, sylph_db** out) {
+    return guarded([&] {
+        SY_REQUIRE(bounds, "null bounds");
+        db_upload_impl(ctx, kmers, genome_off, n_genomes, mem, bounds, world, rank, out);
+    });
+}
+
+int sylph_db_attach_tracked(sylph_db* db, const uint64_t* tracked_kmers, const uint64_t* tracked_off, int mem) {
+    return guarded([&] {
+        SY_REQUIRE(db && tracked_off, "null argument");
+        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+        SY_REQUIRE(db->world == 1, "reassignment runs on an unsharded database");
+        sylph_ctx* ctx = db->ctx;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        DevBuf d_off_buf(ctx), d_in(ctx);
+        const uint64_t* d_off = nullptr;
+        const uint64_t* d_k = nullptr;
+        const uint64_t n = stage_genome_major(ctx, tracked_kmers, tracked_off, db->n_genomes, mem, d_off_buf, d_in, d_off, d_k);
+        index_genome_major(ctx, d_k, d_off, db->n_genomes, n, 0, 0, db->tracked);
+    });
+}
+
+uint64_t sylph_db_n_genomes(const sylph_db* db) { return db ? db->n_genomes : 0; }
+uint64_t sylph_db_n_kmers(const sylph_db* db) { return db ? db->n_kmers : 0; }
+uint64_t sylph_db_index_bytes(const sylph_db* db) {
+    if (!db) return 0;
+    return ((uint64_t)db->kept.n_buckets + db->tracked.n_buckets) * LINE_SLOTS * 8 + (db->kept.n_ovf + db->tracked.n_ovf) * 8;
 }
 
 int sylph_db_contain_view(sylph_db* db, const uint64_t* sample_kmers, const uint32_t* sample_counts, uint64_t n, int mem,
@@ -545,6 +778,53 @@ int sylph_db_contain_view_packed(sylph_db* db, const uint64_t* sample_kmers, con
         std::lock_guard<std::mutex> lock(db->ctx->mu);
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers, nullptr, cov_width);
+        const ResultLayout& lay = db->lay;
+        const char* h = (const char*)db->h_res;
+        *cov_off = (const uint64_t*)h;
+        *contain_count = (const uint32_t*)(h + lay.ccount);
+        *covs = h + lay.covs;
+        if (out_n_covs) *out_n_covs = n_hits;
+    });
+}
+
+int sylph_db_contain_batch(sylph_db* db, const sylph_sample_ref* samples, uint32_t n_samples, int mem, double min_number_kmers,
+                           const uint32_t** contain_count, const uint64_t** cov_off, const void** covs, uint32_t* cov_width,
+                           uint64_t* out_n_covs) {
+    return guarded([&] {
+        SY_REQUIRE(db && contain_count && cov_off && covs && cov_width, "null argument");
+        SY_REQUIRE(n_samples == 0 || samples, "null samples");
+        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+        SY_REQUIRE(db->world == 1, "this database is one shard of %u: use sylph_db_contain_batch_sharded", db->world);
+        sylph_ctx* ctx = db->ctx;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        std::vector<SampleRef> refs(n_samples);
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < n_samples; s++) {
+            SY_REQUIRE(samples[s].n == 0 || (samples[s].kmers && samples[s].counts), "null sample %u", s);
+            total += samples[s].n;
+        }
+        if (mem == SYLPH_MEM_HOST && total) {   // stage the tables back to back
+            db->q_kmers.reserve(total * 8);
+            db->q_counts.reserve(total * 4);
+            uint64_t o = 0;
+            for (uint32_t s = 0; s < n_samples; s++) {
+                const uint64_t n = samples[s].n;
+                if (n) {
+                    ctx->h2d(db->q_kmers.as<uint64_t>() + o, samples[s].kmers, n * 8);
+                    ctx->h2d(db->q_counts.as<uint32_t>() + o, samples[s].counts, n * 4);
+                }
+                refs[s].k = db->q_kmers.as<uint64_t>() + o;
+                refs[s].c = db->q_counts.as<uint32_t>() + o;
+                refs[s].n = n;
+                o += n;
+            }
+        } else {
+            for (uint32_t s = 0; s < n_samples; s++) { refs[s].k = samples[s].kmers; refs[s].c = samples[s].counts; refs[s].n = samples[s].n; }
+        }
+        uint32_t max_count = 0, n_hits = 0;
+        if (n_samples) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
+        finish_hits(db, n_hits, max_count, (uint64_t)n_samples * db->n_genomes, cov_width, false);
         const ResultLayout& lay = db->lay;
         const char* h = (const char*)db->h_res;
         *cov_off = (const uint64_t*)h;

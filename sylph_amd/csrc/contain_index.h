@@ -1,0 +1,122 @@
+// contain_index.h — the k-mer -> genomes "line index" of a database (shard) and the database object, shared by contain.hip
+// (build, probe, result assembly) and shard.hip (multi-GPU exchange).  Internal, not part of the ABI.
+#pragma once
+#include "common.h"
+
+namespace sylph {
+
+constexpr int LINE_SLOTS = 8;                 // 8 x 8 B = one 64-byte line per bucket
+constexpr uint64_t SLOT_EMPTY = ~0ull;
+
+// What the kernels need to probe an index (POD, passed by value).
+//   bucket(km) = (km - base) / div;   slot = ((km - base) % div) << gshift | flag << (gshift - 1) | genome id
+struct LineView {
+    const uint64_t* lines;   // n_buckets x LINE_SLOTS
+    const uint64_t* ovf;     // overflow runs, each closed by SLOT_EMPTY
+    uint64_t base, div, magic;   // magic = floor(2^64 / div) for div >= 2
+    uint32_t n_buckets;
+    int gshift;
+};
+
+struct LineIndex {
+    DevBuf lines, ovf;
+    uint64_t base = 0, div = 1, magic = 0, n_postings = 0, n_ovf = 0;
+    uint32_t n_buckets = 0;
+    int gshift = 2;
+    LineIndex() = default;
+    explicit LineIndex(sylph_ctx* c) : lines(c), ovf(c) {}
+    LineView view() const { return LineView{lines.as<uint64_t>(), ovf.as<uint64_t>(), base, div, magic, n_buckets, gshift}; }
+};
+
+// One sample table of a batch: n (k-mer, count) entries; chunk0 = index of its first 256-entry chunk in the batch.
+struct SampleRef {
+    const uint64_t* k;
+    const uint32_t* c;
+    uint64_t n;
+    uint32_t chunk0, pad;
+};
+
+#ifdef __HIPCC__
+// Calls f(genome id) for every posting of k-mer `km`.  One 64 B line read (4 x global_load_dwordx4); the overflow run of
+// a crowded bucket is walked only when the 7 postings kept in the line do not already exceed the remainder looked for.
+template <class F>
+__device__ __forceinline__ void for_each_posting(const LineView& v, uint64_t km, F&& f) {
+    if (km < v.base) return;
+    const uint64_t x = km - v.base;
+    uint64_t q, rem;
+    if (v.div == 1) { q = x; rem = 0; }
+    else {
+        q = __umul64hi(x, v.magic);                       // floor(x * floor(2^64/div) / 2^64) is q or q - 1
+        rem = x - q * v.div;
+        if (rem >= v.div) { rem -= v.div; q++; }
+    }
+    if (q >= v.n_buckets) return;
+    const uint4* lp = reinterpret_cast<const uint4*>(v.lines + q * LINE_SLOTS);
+    const uint4 a = lp[0], b = lp[1], c = lp[2], d = lp[3];
+    const uint64_t s[LINE_SLOTS] = {((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, ((uint64_t)b.y << 32) | b.x,
+                                    ((uint64_t)b.w << 32) | b.z, ((uint64_t)c.y << 32) | c.x, ((uint64_t)c.w << 32) | c.z,
+                                    ((uint64_t)d.y << 32) | d.x, ((uint64_t)d.w << 32) | d.z};
+    const uint64_t flag = 1ull << (v.gshift - 1), gmask = flag - 1;
+#pragma unroll
+    for (int j = 0; j < LINE_SLOTS; j++)
+        if ((s[j] >> v.gshift) == rem && !(s[j] & flag)) f((uint32_t)(s[j] & gmask));
+    const uint64_t last = s[LINE_SLOTS - 1];
+    if ((last & flag) && last != SLOT_EMPTY && (s[LINE_SLOTS - 2] >> v.gshift) <= rem) {   // descriptor: rest of the bucket
+        for (uint64_t i = last >> v.gshift;; i++) {
+            const uint64_t y = v.ovf[i];
+            if (y == SLOT_EMPTY) break;
+            const uint64_t r = y >> v.gshift;
+            if (r > rem) break;                            // the run is sorted by (remainder, genome)
+            if (r == rem) f((uint32_t)(y & gmask));
+        }
+    }
+}
+#endif
+
+// Layout of the result block, identical on the device (one buffer, ONE device->host copy) and in pinned host memory:
+// [cov_off (R+1) u64 | contain_count R u32 | covs n_hits x width | pad to 8 | kmers_lost G u32 (reassign only, second copy)]
+// with R = n_samples x n_genomes rows (row = sample * n_genomes + genome).
+struct ResultLayout {
+    size_t ccount = 0, covs = 0, lost = 0, end = 0;
+    ResultLayout() = default;
+    ResultLayout(uint64_t R, uint64_t n_hits, uint32_t width, uint64_t lost_entries)
+        : ccount((R + 1) * 8), covs(ccount + R * 4), lost((covs + n_hits * width + 7) & ~(size_t)7), end(lost + lost_entries * 4) {}
+};
+
+void build_line_index(sylph_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d_gid, uint64_t n, uint64_t n_genomes, uint64_t kmer_lo,
+                      uint64_t kmer_hi, LineIndex& ix);
+
+}  // namespace sylph
+
+struct sylph_db {
+    sylph_ctx* ctx;
+    uint64_t n_genomes = 0, n_kmers = 0;     // n_kmers: postings resident on this shard
+    uint32_t min_glen = 0;                   // smallest genome (k-mers): the contain.rs:627 test is skipped when nothing can fail it
+    sylph::LineIndex kept, tracked;          // genome_kmers; pseudotax_tracked_nonused_kmers (winner table only, types.rs:166)
+    sylph::DevBuf glen;
+    // k-mer-range sharding (sylph_db_upload_shard): this shard holds k-mers in [bounds[rank], bounds[rank + 1])
+    std::vector<uint64_t> bounds;
+    uint32_t world = 1, rank = 0;
+    uint64_t shard_hit_cap = 1ull << 20;     // hits per rank in the all-gathered block; doubles identically on every rank
+    sylph::DevBuf rank_of, ani, lost;        // reassign pass: rank[g] in the passing list (or ~0), ANI per rank, kmers_lost[g]
+    // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
+    sylph::DevBuf q_kmers, q_counts, q_refs, hits, hits_sorted, res, counter;   // res: device copy of the result block
+    sylph::DevBuf x_send, x_recv, x_meta;    // shard exchange buffers (shard.hip)
+    sylph::ResultLayout lay;                 // layout of the last result
+    uint64_t last_rows = 0;
+    void* h_res = nullptr;                   // pinned host results
+    size_t h_res_cap = 0;
+    ~sylph_db() { if (h_res) (void)hipHostFree(h_res); }
+    explicit sylph_db(sylph_ctx* cx)
+        : ctx(cx), kept(cx), tracked(cx), glen(cx), rank_of(cx), ani(cx), lost(cx), q_kmers(cx), q_counts(cx), q_refs(cx), hits(cx),
+          hits_sorted(cx), res(cx), counter(cx), x_send(cx), x_recv(cx), x_meta(cx) {}
+};
+
+namespace sylph {
+// Probes a batch of device-resident sample tables (refs: host array of n_samples entries with k, c, n filled in) against the
+// kept index and leaves unsorted hits ((row << 32) | count, row = sample * n_genomes + genome) in db->hits.
+// Returns the number of hits; *max_count = largest count among them.
+uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint32_t* max_count);
+// Sorts n_hits hits of db->hits (rows < n_rows) and assembles + copies out the result block (db->h_res, db->lay).
+void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost);
+}  // namespace sylph

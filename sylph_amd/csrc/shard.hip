@@ -1,0 +1,420 @@
+// shard.hip — one database over several GPUs (north_star: "genome DB ... sharded across the 8 GPUs of one node,
+// per-shard containment counts reduced by a single RCCL all-gather over xGMI").  One process per GPU.
+//
+// The reference has no distributed path (contain.rs:239-291 is a rayon loop over sample chunks x genomes inside one
+// process), so nothing here translates one.  The database is sharded by k-mer RANGE (contain.hip, sylph_db_upload_shard):
+// sample tables are sorted by k-mer, so what a rank has to probe of any sample is a contiguous slice holding 1/world of it —
+// per-rank probe work per sample is constant in `world` (with genome-sharding every rank would probe every sample in full).
+// Per batch of samples (every rank contributes the samples it sketched):
+//   1. all-gather of the slice boundaries                                  (a few KB, fixed-size block per rank)
+//   2. all-to-all of the table slices                                      (each rank receives 1/world of every table)
+//   3. one probe launch over all received slices against the resident shard
+//   4. ONE all-gather of the per-shard hit lists                           (fixed layout: [n_hits | max count | hits x cap])
+//   5. every rank keeps the hits of its own samples, sorts them and assembles counts + coverage vectors (contain.hip).
+// xGMI is point-to-point: the all-to-all moves 1/world of the bytes an all-gather of whole tables would move over each
+// link, and the payloads of steps 1 and 4 are small enough to be latency-bound.  All buffers stay on the device; the host
+// only reads the sizes.
+//
+// The collectives come from a sylph_comm: RCCL (resolved with dlopen at run time, so that the library neither links against a
+// second copy of librccl next to the one PyTorch may already have mapped, nor needs RCCL at all on a single GPU), or callbacks
+// supplied by the caller (tests run the same code over gloo).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <memory>
+
+#include "contain_index.h"
+
+namespace sylph {
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already mapped into the process first (PyTorch ships its own librccl.so), then the ROCm installation
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        void* h = nullptr;
+        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        api.lib = h;
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+        api.Send = (decltype(api.Send))dlsym(h, "ncclSend");
+        api.Recv = (decltype(api.Recv))dlsym(h, "ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    });
+    return api;
+}
+
+void rccl_require() {
+    RcclApi& a = rccl();
+    SY_REQUIRE(a.lib && a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Send && a.Recv && a.GroupStart && a.GroupEnd,
+               "librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+}
+
+#define SY_NCCL(expr)                                                                                              \
+    do {                                                                                                           \
+        ncclResult_t _r = (expr);                                                                                  \
+        if (_r != ncclSuccess) {                                                                                   \
+            char _b[384];                                                                                          \
+            snprintf(_b, sizeof(_b), "RCCL error %d (%s) in %s", (int)_r,                                          \
+                     rccl().GetErrorString ? rccl().GetErrorString(_r) : "?", #expr);                              \
+            throw ::sylph::ArgError{_b};                                                                           \
+        }                                                                                                          \
+    } while (0)
+
+}  // namespace
+}  // namespace sylph
+
+using namespace sylph;
+
+struct sylph_comm {
+    uint32_t rank = 0, world = 1;
+    sylph_comm_ops ops{nullptr, nullptr};
+    void* user = nullptr;
+    ncclComm_t nccl = nullptr;       // RCCL flavour
+    int device = -1;
+
+    void all_gather(const void* send, void* recv, uint64_t bytes, hipStream_t s) {
+        if (nccl) { SY_NCCL(rccl().AllGather(send, recv, bytes, ncclUint8, nccl, s)); return; }
+        SY_REQUIRE(ops.all_gather(user, send, recv, bytes, (void*)s) == 0, "all_gather callback failed");
+    }
+    void all_to_all(const void* send, const uint64_t* send_off, void* recv, const uint64_t* recv_off, hipStream_t s) {
+        if (!nccl) { SY_REQUIRE(ops.all_to_all(user, send, send_off, recv, recv_off, (void*)s) == 0, "all_to_all callback failed"); return; }
+        // own block: a device copy; the others: one grouped send/recv pair per peer (xGMI is point-to-point: all links at once)
+        const uint64_t mine = send_off[rank + 1] - send_off[rank];
+        SY_REQUIRE(mine == recv_off[rank + 1] - recv_off[rank], "internal: self block size mismatch");
+        if (mine) SY_HIP(hipMemcpyAsync((char*)recv + recv_off[rank], (const char*)send + send_off[rank], mine, hipMemcpyDeviceToDevice, s));
+        SY_NCCL(rccl().GroupStart());
+        for (uint32_t r = 0; r < world; r++) {
+            if (r == rank) continue;
+            const uint64_t ns = send_off[r + 1] - send_off[r], nr = recv_off[r + 1] - recv_off[r];
+            if (ns) SY_NCCL(rccl().Send((const char*)send + send_off[r], ns, ncclUint8, (int)r, nccl, s));
+            if (nr) SY_NCCL(rccl().Recv((char*)recv + recv_off[r], nr, ncclUint8, (int)r, nccl, s));
+        }
+        SY_NCCL(rccl().GroupEnd());
+    }
+};
+
+namespace sylph {
+namespace {
+
+constexpr uint32_t MAX_LOCAL = 64;           // samples a rank may contribute to one batch (fixes the size of the meta block)
+
+// split[s * (W + 1) + j] = first entry of sample s whose k-mer is >= bounds[j]   (j = 0..W; the tables are ascending)
+__global__ __launch_bounds__(256) void split_kernel(const SampleRef* __restrict__ refs, uint32_t n_samples, const uint64_t* __restrict__ bounds,
+                                                    uint32_t W, uint64_t* __restrict__ split) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_samples * (W + 1)) return;
+    const uint32_t s = t / (W + 1), j = t % (W + 1);
+    const uint64_t* __restrict__ k = refs[s].k;
+    const uint64_t key = bounds[j];
+    uint64_t lo = 0, hi = refs[s].n;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (k[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    split[t] = lo;
+}
+
+// segmented copy in 4-byte words: workgroup (x = segment, y strides)
+struct Seg { const uint32_t* src; uint32_t* dst; uint64_t words; };
+__global__ __launch_bounds__(256) void copy_segments_kernel(const Seg* __restrict__ segs) {
+    const Seg sg = segs[blockIdx.x];
+    for (uint64_t i = (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < sg.words; i += (uint64_t)gridDim.y * blockDim.x) sg.dst[i] = sg.src[i];
+}
+
+// keeps the hits whose row belongs to samples [s0, s0 + ns) of this rank, re-based to local rows; the gathered buffer holds
+// `world` blocks of [n_hits u64 | max u64 | hits x cap]
+__global__ __launch_bounds__(256) void take_hits_kernel(const uint64_t* __restrict__ gathered, uint32_t world, uint64_t block_words, uint64_t cap,
+                                                        uint64_t n_genomes, uint64_t s0, uint64_t ns, uint64_t* __restrict__ out,
+                                                        uint32_t* __restrict__ counter) {
+    __shared__ uint32_t s_cnt, s_base, s_max;
+    const uint64_t row_lo = s0 * n_genomes, row_hi = (s0 + ns) * n_genomes;
+    for (uint32_t r = 0; r < world; r++) {
+        const uint64_t* blk = gathered + (uint64_t)r * block_words;
+        const uint64_t n = min(blk[0], cap);
+        const uint64_t* h = blk + 2;
+        for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
+            if (threadIdx.x == 0) { s_cnt = 0; s_max = 0; }
+            __syncthreads();
+            const uint64_t i = base + threadIdx.x;
+            uint64_t hit = 0;
+            bool mine = false;
+            uint32_t slot = 0;
+            if (i < n) {
+                hit = h[i];
+                const uint64_t row = hit >> 32;
+                mine = row >= row_lo && row < row_hi;
+                if (mine) { slot = atomicAdd(&s_cnt, 1u); atomicMax(&s_max, (uint32_t)hit); hit = ((row - row_lo) << 32) | (uint32_t)hit; }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0 && s_cnt) { s_base = atomicAdd(counter, s_cnt); atomicMax(counter + 1, s_max); }
+            __syncthreads();
+            if (mine) out[s_base + slot] = hit;
+            __syncthreads();
+        }
+    }
+}
+
+uint32_t grid_for64(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
+
+}  // namespace
+}  // namespace sylph
+
+extern "C" {
+
+int sylph_comm_rccl_unique_id(uint8_t id[128]) {
+    return guarded([&] {
+        SY_REQUIRE(id, "null argument");
+        rccl_require();
+        ncclUniqueId u;
+        static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+        SY_NCCL(rccl().GetUniqueId(&u));
+        memcpy(id, &u, 128);
+    });
+}
+
+int sylph_comm_create_rccl(sylph_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t id[128], sylph_comm** out) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && id && out && world >= 1 && rank < world, "bad argument");
+        rccl_require();
+        DeviceGuard dg(ctx->device);
+        std::unique_ptr<sylph_comm> c(new sylph_comm());
+        c->rank = rank; c->world = world; c->device = ctx->device;
+        ncclUniqueId u;
+        memcpy(&u, id, 128);
+        SY_NCCL(rccl().CommInitRank(&c->nccl, (int)world, u, (int)rank));
+        *out = c.release();
+    });
+}
+
+int sylph_comm_create(uint32_t rank, uint32_t world, const sylph_comm_ops* ops, void* user, sylph_comm** out) {
+    return guarded([&] {
+        SY_REQUIRE(ops && ops->all_gather && ops->all_to_all && out && world >= 1 && rank < world, "bad argument");
+        sylph_comm* c = new sylph_comm();
+        c->rank = rank; c->world = world; c->ops = *ops; c->user = user;
+        *out = c;
+    });
+}
+
+void sylph_comm_destroy(sylph_comm* comm) {
+    if (!comm) return;
+    if (comm->nccl) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (comm->device >= 0) (void)hipSetDevice(comm->device);
+        (void)rccl().CommDestroy(comm->nccl);
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    delete comm;
+}
+
+int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
+                                   double min_number_kmers, const uint32_t** contain_count, const uint64_t** cov_off,
+                                   const void** covs, uint32_t* cov_width, uint64_t* out_n_covs) {
+    return guarded([&] {
+        SY_REQUIRE(db && comm && contain_count && cov_off && covs && cov_width, "null argument");
+        SY_REQUIRE(n_local == 0 || samples, "null samples");
+        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+        SY_REQUIRE(n_local <= MAX_LOCAL, "at most %u samples per rank and batch", MAX_LOCAL);
+        SY_REQUIRE(db->world == comm->world && db->rank == comm->rank, "database shard %u/%u does not match communicator rank %u/%u", db->rank,
+                   db->world, comm->rank, comm->world);
+        SY_REQUIRE(db->bounds.size() == (size_t)db->world + 1, "database was not uploaded with sylph_db_upload_shard");
+        sylph_ctx* ctx = db->ctx;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        const uint32_t W = comm->world, me = comm->rank;
+        const uint64_t G = db->n_genomes;
+        hipStream_t st = ctx->stream;
+
+        // ---- local tables on the device
+        std::vector<SampleRef> mine(n_local);
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < n_local; s++) {
+            SY_REQUIRE(samples[s].n == 0 || (samples[s].kmers && samples[s].counts), "null sample %u", s);
+            SY_REQUIRE(samples[s].n < (1ull << 32), "sample table larger than 2^32-1 entries");
+            total += samples[s].n;
+        }
+        if (mem == SYLPH_MEM_HOST && total) {
+            db->q_kmers.reserve(total * 8);
+            db->q_counts.reserve(total * 4);
+            uint64_t o = 0;
+            for (uint32_t s = 0; s < n_local; s++) {
+                const uint64_t n = samples[s].n;
+                if (n) {
+                    ctx->h2d(db->q_kmers.as<uint64_t>() + o, samples[s].kmers, n * 8);
+                    ctx->h2d(db->q_counts.as<uint32_t>() + o, samples[s].counts, n * 4);
+                }
+                mine[s].k = db->q_kmers.as<uint64_t>() + o; mine[s].c = db->q_counts.as<uint32_t>() + o; mine[s].n = n;
+                o += n;
+            }
+        } else {
+            for (uint32_t s = 0; s < n_local; s++) { mine[s].k = samples[s].kmers; mine[s].c = samples[s].counts; mine[s].n = samples[s].n; }
+        }
+        for (auto& r : mine) { r.chunk0 = 0; r.pad = 0; }
+
+        // ---- 1. slice boundaries of every local table, all-gathered: block = [n_local | split[MAX_LOCAL][W + 1]] u64
+        const uint64_t meta_words = 1 + (uint64_t)MAX_LOCAL * (W + 1);
+        // x_meta: [my block | gathered blocks (W) | bounds (W + 1) | refs | segs]
+        const size_t off_gather = meta_words * 8, off_bounds = off_gather + (size_t)W * meta_words * 8, off_refs = off_bounds + (size_t)(W + 1) * 8;
+        const size_t off_segs = off_refs + (size_t)MAX_LOCAL * sizeof(SampleRef);
+        db->x_meta.reserve(off_segs + (size_t)MAX_LOCAL * W * 2 * sizeof(Seg) + 64);
+        char* xm = db->x_meta.as<char>();
+        uint64_t* d_myblock = reinterpret_cast<uint64_t*>(xm);
+        uint64_t* d_gather = reinterpret_cast<uint64_t*>(xm + off_gather);
+        uint64_t* d_bounds = reinterpret_cast<uint64_t*>(xm + off_bounds);
+        SampleRef* d_refs = reinterpret_cast<SampleRef*>(xm + off_refs);
+        Seg* d_segs = reinterpret_cast<Seg*>(xm + off_segs);
+        SY_HIP(hipMemsetAsync(d_myblock, 0, meta_words * 8, st));
+        const uint64_t nl64 = n_local;
+        ctx->h2d(d_myblock, &nl64, 8);
+        ctx->h2d(d_bounds, db->bounds.data(), (size_t)(W + 1) * 8);
+        if (n_local) {
+            ctx->h2d(d_refs, mine.data(), (size_t)n_local * sizeof(SampleRef));
+            hipLaunchKernelGGL(split_kernel, dim3(grid_for64((uint64_t)n_local * (W + 1))), dim3(256), 0, st, d_refs, n_local, d_bounds, W,
+                               d_myblock + 1);
+            SY_HIP(hipGetLastError());
+        }
+        comm->all_gather(d_myblock, d_gather, meta_words * 8, st);
+        std::vector<uint64_t> meta((size_t)W * meta_words);
+        ctx->d2h(meta.data(), d_gather, meta.size() * 8);
+        auto n_loc = [&](uint32_t r) { return (uint32_t)meta[(size_t)r * meta_words]; };
+        auto split = [&](uint32_t r, uint32_t s, uint32_t j) { return meta[(size_t)r * meta_words + 1 + (size_t)s * (W + 1) + j]; };
+        std::vector<uint64_t> prefix(W + 1, 0);
+        for (uint32_t r = 0; r < W; r++) {
+            SY_REQUIRE(n_loc(r) <= MAX_LOCAL, "rank %u announced %u samples", r, n_loc(r));
+            prefix[r + 1] = prefix[r] + n_loc(r);
+        }
+        const uint64_t S_total = prefix[W];
+        SY_REQUIRE(S_total * std::max<uint64_t>(G, 1) < (1ull << 32) - 1, "samples x genomes of one step must stay below 2^32");
+
+        // ---- 2. all-to-all of the slices.  Block for rank d: [k-mers of slice (s, d), s = 0.. | counts of slice (s, d) | pad to 8]
+        std::vector<uint64_t> send_off(W + 1, 0), recv_off(W + 1, 0);
+        auto block_bytes = [&](uint32_t src, uint32_t dst) {
+            uint64_t e = 0;
+            for (uint32_t s = 0; s < n_loc(src); s++) e += split(src, s, dst + 1) - split(src, s, dst);
+            return (e * 12 + 7) & ~7ull;
+        };
+        for (uint32_t r = 0; r < W; r++) { send_off[r + 1] = send_off[r] + block_bytes(me, r); recv_off[r + 1] = recv_off[r] + block_bytes(r, me); }
+        db->x_send.reserve(send_off[W] + 64);
+        db->x_recv.reserve(recv_off[W] + 64);
+        if (n_local) {
+            std::vector<Seg> segs;
+            uint64_t max_words = 1;
+            for (uint32_t d = 0; d < W; d++) {
+                uint64_t e = 0;
+                for (uint32_t s = 0; s < n_local; s++) e += split(me, s, d + 1) - split(me, s, d);
+                char* blk = db->x_send.as<char>() + send_off[d];
+                uint64_t ok = 0, oc = e * 8;
+                for (uint32_t s = 0; s < n_local; s++) {
+                    const uint64_t a = split(me, s, d), len = split(me, s, d + 1) - a;
+                    if (!len) continue;
+                    segs.push_back(Seg{reinterpret_cast<const uint32_t*>(mine[s].k + a), reinterpret_cast<uint32_t*>(blk + ok), len * 2});
+                    segs.push_back(Seg{mine[s].c + a, reinterpret_cast<uint32_t*>(blk + oc), len});
+                    ok += len * 8; oc += len * 4;
+                    max_words = std::max(max_words, len * 2);
+                }
+            }
+            if (!segs.empty()) {
+                ctx->h2d(d_segs, segs.data(), segs.size() * sizeof(Seg));
+                const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (max_words + 256 * 16 - 1) / (256 * 16));
+                hipLaunchKernelGGL(copy_segments_kernel, dim3((uint32_t)segs.size(), std::max(1u, gy)), dim3(256), 0, st, d_segs);
+                SY_HIP(hipGetLastError());
+            }
+        }
+        comm->all_to_all(db->x_send.p, send_off.data(), db->x_recv.p, recv_off.data(), st);
+
+        // ---- 3. probe every received slice against the resident shard; row = global sample index * G + genome
+        std::vector<SampleRef> refs(S_total);
+        for (uint32_t r = 0; r < W; r++) {
+            uint64_t e = 0;
+            for (uint32_t s = 0; s < n_loc(r); s++) e += split(r, s, me + 1) - split(r, s, me);
+            const char* blk = db->x_recv.as<char>() + recv_off[r];
+            uint64_t ok = 0, oc = e * 8;
+            for (uint32_t s = 0; s < n_loc(r); s++) {
+                const uint64_t len = split(r, s, me + 1) - split(r, s, me);
+                SampleRef& f = refs[prefix[r] + s];
+                f.k = reinterpret_cast<const uint64_t*>(blk + ok); f.c = reinterpret_cast<const uint32_t*>(blk + oc); f.n = len;
+                ok += len * 8; oc += len * 4;
+            }
+        }
+        uint32_t max_count = 0, n_hits = 0;
+        if (S_total) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
+
+        // ---- 4. ONE all-gather of the hit lists: block = [n_hits | max count | hits x cap]; cap is the same on every rank and
+        //         doubles (on every rank, from the same gathered headers) until no shard overflows
+        uint32_t n_mine = 0, max_mine = 0;
+        for (;;) {
+            const uint64_t cap = db->shard_hit_cap, block_words = 2 + cap;
+            db->x_send.reserve(block_words * 8);
+            db->x_recv.reserve((size_t)W * block_words * 8);
+            const uint64_t hdr[2] = {n_hits, max_count};
+            ctx->h2d(db->x_send.p, hdr, 16);
+            const uint64_t n_copy = std::min<uint64_t>(n_hits, cap);
+            if (n_copy) SY_HIP(hipMemcpyAsync(db->x_send.as<char>() + 16, db->hits.p, n_copy * 8, hipMemcpyDeviceToDevice, st));
+            {
+                ScopedKernelTimer t(ctx, "exchange");
+                comm->all_gather(db->x_send.p, db->x_recv.p, block_words * 8, st);
+            }
+            std::vector<uint64_t> hdrs((size_t)W * 2);
+            for (uint32_t r = 0; r < W; r++)
+                SY_HIP(hipMemcpyAsync((char*)ctx->pinned + r * 16, db->x_recv.as<char>() + (size_t)r * block_words * 8, 16, hipMemcpyDeviceToHost, st));
+            SY_HIP(hipStreamSynchronize(st));
+            memcpy(hdrs.data(), ctx->pinned, (size_t)W * 16);
+            uint64_t worst = 0, sum = 0;
+            for (uint32_t r = 0; r < W; r++) { worst = std::max(worst, hdrs[2 * r]); sum += std::min(hdrs[2 * r], cap); }
+            if (worst > cap) {                       // some shard's list was cut: every rank sees it and grows alike
+                uint64_t c2 = cap;
+                while (c2 < worst) c2 *= 2;
+                db->shard_hit_cap = c2;
+                continue;
+            }
+            // ---- 5. keep the hits of this rank's samples
+            SY_REQUIRE(sum < (1ull << 32), "more than 2^32-1 hits in one step: use smaller batches");
+            uint32_t* d_cnt = db->counter.as<uint32_t>();
+            SY_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
+            if (sum && n_local) {
+                db->hits.reserve(sum * 8);
+                hipLaunchKernelGGL(take_hits_kernel, dim3((uint32_t)std::min<uint64_t>(1024, grid_for64(std::max<uint64_t>(worst, 1)))), dim3(256), 0, st,
+                                   db->x_recv.as<uint64_t>(), W, block_words, cap, G, prefix[me], (uint64_t)n_local, db->hits.as<uint64_t>(), d_cnt);
+                SY_HIP(hipGetLastError());
+            }
+            uint32_t hc[2] = {0, 0};
+            ctx->read_back(hc, d_cnt, 8);
+            n_mine = hc[0];
+            max_mine = hc[1];
+            break;
+        }
+        finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false);
+        const ResultLayout& lay = db->lay;
+        const char* h = (const char*)db->h_res;
+        *cov_off = (const uint64_t*)h;
+        *contain_count = (const uint32_t*)(h + lay.ccount);
+        *covs = h + lay.covs;
+        if (out_n_covs) *out_n_covs = n_mine;
+    });
+}
+
+}  // extern "C"

@@ -76,6 +76,28 @@ def paired_reads(genomes, n_pairs, read_len=150, insert_mean=350.0, insert_sd=30
     return bases, rec_off
 
 
+def ragged_paired_reads(genomes, n_pairs, min_len=35, max_len=151, n_frac=0.001, seed=0, **kw):
+    """Pairs as paired_reads() makes them, every mate then trimmed to its own length in [min_len, max_len] (adapter/quality
+    trimming) and with a fraction n_frac of the bases called N: the 'honest input' variant of the short-read workload (no two
+    lanes of a wavefront walk the same number of k-mers; the exact ASCII->2-bit path is taken).  -> (bases, rec_off) as above."""
+    device = genomes.device
+    bases, _ = paired_reads(genomes, n_pairs, read_len=max_len, seed=seed, **kw)
+    g = _gen(device, seed + 911)
+    full = bases[:n_pairs * 2 * max_len].reshape(2 * n_pairs, max_len)
+    lens = torch.randint(min_len, max_len + 1, (2 * n_pairs,), generator=g, device=device)
+    keep = torch.arange(max_len, device=device)[None, :] < lens[:, None]
+    out = []
+    step = 1 << 20
+    for s in range(0, 2 * n_pairs, step):                                   # boolean compaction in slabs (bounded temporaries)
+        blk = full[s:s + step][keep[s:s + step]]
+        nmask = torch.rand(blk.shape, generator=g, device=device) < n_frac
+        out.append(torch.where(nmask, torch.full_like(blk, 78), blk))
+    out.append(torch.zeros(64, dtype=torch.uint8, device=device))
+    rec_off = torch.zeros(2 * n_pairs + 1, dtype=torch.int64, device=device)
+    rec_off[1:] = torch.cumsum(lens, 0)
+    return torch.cat(out), rec_off
+
+
 def decoy_sketches(n_genomes, c=200, device="cuda", seed=0, mean_len=3.3e6, sigma=0.45, kept_frac=0.87,
                    lo=0.5e6, hi=15e6):
     """Sketch-only genomes: n_kept = round(kept_frac * len / c) uniform u64 below the FracMinHash threshold (valid

@@ -1,6 +1,8 @@
 """Worker for tests/test_gpu_parity.py::test_sharded_containment_two_ranks_one_gpu — run under torch.distributed.run.
-Each rank owns a genome shard resident on the GPU (real HIP probe), samples are exchanged with gloo, and every rank
-checks its own sample against the oracle over the whole database."""
+Each rank holds one k-mer-range shard of the database on the GPU and calls sylph_db_contain_batch_sharded (the library's own
+exchange: slice boundaries all-gathered, slices all-to-all, one probe launch, one all-gather of hit lists) with its own
+samples; the collectives go through torch.distributed (gloo) callbacks because RCCL cannot put two ranks on one device.
+Every rank checks its samples against the oracle over the WHOLE database."""
 import os
 import sys
 
@@ -19,6 +21,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
     rng = np.random.default_rng(5)
     thr = O.threshold(200)
     pool = np.unique(rng.integers(0, thr, size=60000, dtype=np.uint64))
@@ -26,38 +29,41 @@ def main():
     lens[5] = 0
     lens[9] = 49
     genomes = [rng.choice(pool, size=int(n), replace=False) for n in lens]
-    owner = SH.partition_genomes(lens, world)
-    rank_genomes = [np.nonzero(owner == r)[0] for r in range(world)]
-    mine = rank_genomes[rank]
-    shard_k = np.concatenate([genomes[g] for g in mine]) if len(mine) else np.zeros(0, dtype=np.uint64)
-    shard_off = np.zeros(len(mine) + 1, dtype=np.uint64)
-    shard_off[1:] = np.cumsum([len(genomes[g]) for g in mine])
-    ctx = S.Context(0)
-    db = S.Database(ctx, shard_k, shard_off)
-    r2 = np.random.default_rng(100 + rank)
-    sk = np.sort(r2.choice(pool, size=9000 + 1000 * rank, replace=False))
-    sc = r2.integers(0, 9, size=len(sk)).astype(np.uint32)
-    tk = torch.from_numpy(sk.view(np.int64)).to(dev)
-    tc = torch.from_numpy(sc.view(np.int32)).to(dev)
-    torch.cuda.synchronize()
-
-    def contain_fn(k, c):
-        k, c = k.to(dev).contiguous(), c.to(dev).contiguous()
-        torch.cuda.synchronize()
-        return db.contain(k.data_ptr(), c.data_ptr(), device_ptrs=True, n=k.numel())
-
-    group = SH.TorchGroup(dist, dev)
-    res = SH.exchange_and_profile(contain_fn, group, tk, tc, owner, rank_genomes)
+    genomes[20] = np.concatenate([genomes[20], pool[:300]])
+    genomes[21] = np.concatenate([genomes[21], pool[:300], genomes[21][:10]])     # shared and repeated k-mers
     full = np.concatenate(genomes)
     goff = np.zeros(len(genomes) + 1, dtype=np.uint64)
-    goff[1:] = np.cumsum(lens)
-    ecc, ecov, _ = O.contain(sk, sc, full, goff)
-    assert np.array_equal(res["contain_count"], ecc), (rank, res["contain_count"][:10], ecc[:10])
-    for g in range(len(genomes)):
-        got = res["covs"][int(res["cov_off"][g]):int(res["cov_off"][g + 1])]
-        assert np.array_equal(got, np.sort(ecov[g])), (rank, g)
-    assert int(ecc.sum()) > 0
+    goff[1:] = np.cumsum([len(g) for g in genomes])
+    G = len(genomes)
+    ctx = S.Context(0)
+    bounds = S.shard_bounds(int(full.max()), world)
+    db = S.Database(ctx, full, goff, shard=(bounds, world, rank))
+    assert 0 < db.n_kmers < len(full)
+    comm = SH.torch_callback_comm(dist, dev)
+    r2 = np.random.default_rng(100 + rank)
+    for step in range(3):
+        n_local = [2, 3][rank] if step < 2 else [0, 1][rank]         # different batch sizes per rank; one rank may bring none
+        samples = []
+        for i in range(n_local):
+            k = np.sort(r2.choice(pool, size=9000 + 1000 * rank + 10 * i, replace=False)) if (step, i) != (0, 1) else np.zeros(0, np.uint64)
+            samples.append((k, r2.integers(0, 9, size=len(k)).astype(np.uint32)))
+        if step == 1:                                                # device-resident tables
+            tk = [torch.from_numpy(k.view(np.int64)).to(dev) for k, _ in samples]
+            tc = [torch.from_numpy(c.view(np.int32)).to(dev) for _, c in samples]
+            torch.cuda.synchronize()
+            cc, off, covs = db.contain_batch_sharded(comm, [(a.data_ptr() if a.numel() else 0, b.data_ptr() if b.numel() else 0, a.numel())
+                                                            for a, b in zip(tk, tc)], device_ptrs=True)
+        else:
+            cc, off, covs = db.contain_batch_sharded(comm, samples)
+        assert len(cc) == n_local * G
+        for s, (k, c) in enumerate(samples):
+            ecc, ecov, _ = O.contain(k, c, full, goff)
+            assert np.array_equal(cc[s * G:(s + 1) * G], ecc), (rank, step, s)
+            for g in range(G):
+                assert np.array_equal(covs[int(off[s * G + g]):int(off[s * G + g + 1])].astype(np.uint32), np.sort(ecov[g])), (rank, step, s, g)
+            assert len(k) == 0 or int(ecc.sum()) > 0
     db.close()
+    comm.close()
     ctx.close()
     dist.barrier()
     if rank == 0:

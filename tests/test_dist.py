@@ -1,15 +1,17 @@
-"""N>1 path on CPU: world_size-2 (and 3) gloo run of the genome-sharded containment exchange (sylph_amd/shard.py),
-with the oracle standing in for the HIP probe.  Each rank must recover, for its own sample, exactly the
-single-process answer over the whole database."""
+"""N>1 path on CPU: world_size-2 and -3 gloo runs of the k-mer-range sharded containment exchange.  The product's exchange runs
+in the HIP library (csrc/shard.hip) and needs a GPU; what runs here is its executable specification,
+sylph_amd.shard.model_contain_batch_sharded — the same five steps on host arrays — with the oracle standing in for the HIP probe.
+Every rank must recover, for its OWN samples, exactly the single-process answer over the WHOLE database.  (tests/test_gpu_parity.py
+runs the library's exchange itself over gloo with two ranks on one GPU, and over RCCL with one rank.)"""
 import os
 import socket
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import sylph_amd as S
 from oracle import oracle as O
 from sylph_amd import shard as SH
 
@@ -22,7 +24,7 @@ def _free_port():
     return p
 
 
-def _make_db(seed=5, G=37):
+def make_db(seed=5, G=37):
     rng = np.random.default_rng(seed)
     thr = O.threshold(200)
     pool = np.unique(rng.integers(0, thr, size=30000, dtype=np.uint64))
@@ -30,7 +32,31 @@ def _make_db(seed=5, G=37):
     lens[3] = 0
     lens[7] = 49
     genomes = [rng.choice(pool, size=int(n), replace=False) for n in lens]
+    genomes[11] = np.concatenate([genomes[11], genomes[11][:5]])       # a k-mer twice in one genome: counted twice (contain.rs:632)
     return pool, genomes
+
+
+def make_samples(pool, rank, n):
+    rng = np.random.default_rng(100 + rank)
+    out = []
+    for i in range(n):
+        k = np.sort(rng.choice(pool, size=3000 + 500 * rank + 100 * i, replace=False)) if (rank, i) != (1, 1) else np.zeros(0, np.uint64)
+        out.append((k, rng.integers(0, 9, size=len(k)).astype(np.uint32)))
+    return out
+
+
+def shard_probe(genomes, lo, hi, min_number_kmers=50.0):
+    """CPU stand-in for the resident shard: genomes cut to the k-mer range, full genome lengths kept for the :627 test."""
+    cut = [g[(g >= lo) & ((g < hi) if hi else True)] for g in genomes]
+    off = np.zeros(len(cut) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(g) for g in cut])
+    flat = np.concatenate(cut) if len(cut) else np.zeros(0, np.uint64)
+    full_len = [len(g) for g in genomes]
+
+    def probe(k, c):
+        cc, covs, _ = O.contain(k, c, flat, off, min_number_kmers=0.0)
+        return [(g, int(x)) for g in range(len(cut)) if full_len[g] >= min_number_kmers for x in covs[g]]
+    return probe
 
 
 def _worker(rank, world, port, ret):
@@ -38,43 +64,21 @@ def _worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        pool, genomes = _make_db()
-        lens = np.array([len(g) for g in genomes])
-        owner = SH.partition_genomes(lens, world)
-        rank_genomes = [np.nonzero(owner == r)[0] for r in range(world)]
-        mine = rank_genomes[rank]
-        shard_k = np.concatenate([genomes[g] for g in mine]) if len(mine) else np.zeros(0, dtype=np.uint64)
-        shard_off = np.zeros(len(mine) + 1, dtype=np.uint64)
-        shard_off[1:] = np.cumsum([len(genomes[g]) for g in mine])
-        rng = np.random.default_rng(100 + rank)
-        sk = np.sort(rng.choice(pool, size=4000 + 500 * rank, replace=False))
-        sc = rng.integers(0, 9, size=len(sk)).astype(np.uint32)
-
-        def contain_fn(k, c):   # CPU stand-in for Database.contain: sorted covs per genome
-            kk = k.numpy().view(np.uint64)
-            cc_ = c.numpy().view(np.uint32)
-            cc, covs, _ = O.contain(kk, cc_, shard_k, shard_off)
-            off = np.zeros(len(mine) + 1, dtype=np.uint64)
-            off[1:] = np.cumsum(cc.astype(np.uint64))
-            flat = np.concatenate([np.sort(x) for x in covs]) if len(covs) and off[-1] else np.zeros(0, dtype=np.uint32)
-            return cc, off, flat
-
-        group = SH.TorchGroup(dist, torch.device("cpu"))
-        res = SH.exchange_and_profile(contain_fn, group, torch.from_numpy(sk.view(np.int64)), torch.from_numpy(sc.view(np.int32)),
-                                      owner, rank_genomes)
-        # single-process answer over the whole database
+        pool, genomes = make_db()
+        G = len(genomes)
+        bounds = SH.shard_bounds(int(max(g.max() for g in genomes if len(g))), world)
+        hi = int(bounds[rank + 1]) if rank + 1 < world else 0
+        samples = make_samples(pool, rank, [2, 3, 0][rank])      # different batch sizes per rank, one rank may bring none
+        cc, covs = SH.model_contain_batch_sharded(dist, bounds, G, samples, shard_probe(genomes, int(bounds[rank]), hi))
         db = np.concatenate(genomes)
-        goff = np.zeros(len(genomes) + 1, dtype=np.uint64)
-        goff[1:] = np.cumsum(lens)
-        ecc, ecov, _ = O.contain(sk, sc, db, goff)
-        ok = np.array_equal(res["contain_count"], ecc)
-        for g in range(len(genomes)):
-            got = res["covs"][int(res["cov_off"][g]):int(res["cov_off"][g + 1])]
-            ok = ok and np.array_equal(got, np.sort(ecov[g]))
-        # replicated mode: one all-gather of the per-sample counts
-        allc = SH.gather_counts(group, ecc, torch.device("cpu"))
-        ok = ok and allc.shape == (world, len(genomes)) and np.array_equal(allc[rank].numpy().view(np.uint32), ecc)
-        ret[rank] = bool(ok) and int(ecc.sum()) > 0
+        goff = np.zeros(G + 1, dtype=np.uint64)
+        goff[1:] = np.cumsum([len(g) for g in genomes])
+        ok = cc.shape == (len(samples), G)
+        for s, (k, c) in enumerate(samples):
+            ecc, ecov, _ = O.contain(k, c, db, goff)
+            ok = ok and np.array_equal(cc[s], ecc) and all(np.array_equal(covs[s][g], np.sort(ecov[g])) for g in range(G))
+            ok = ok and (len(k) == 0 or int(ecc.sum()) > 0)
+        ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
 
@@ -88,12 +92,12 @@ def test_sharded_containment_gloo(world):
     assert [ret.get(r) for r in range(world)] == [True] * world
 
 
-def test_partition_balances():
-    rng = np.random.default_rng(0)
-    lens = rng.integers(500, 70000, size=113104)
-    for w in (2, 4, 8):
-        owner = SH.partition_genomes(lens, w)
-        loads = np.bincount(owner, weights=lens, minlength=w)
-        counts = np.bincount(owner, minlength=w)
-        assert loads.max() / loads.mean() < 1.001 and counts.max() - counts.min() <= 1
-    assert SH.partition_genomes(lens[:5], 1).tolist() == [0] * 5
+def test_shard_bounds_match_library_and_cover_the_range():
+    for mx in (0, 1, 6, 2**64 // 200, 2**64 - 2, 2**64 - 1):
+        for w in (1, 2, 3, 8):
+            b = SH.shard_bounds(mx, w)
+            assert np.array_equal(b, S.shard_bounds(mx, w)), (mx, w)          # host function of the C ABI: runs without a GPU
+            assert b[0] == 0 and all(b[i] <= b[i + 1] for i in range(w)) and int(b[w]) >= min(mx, 2**64 - 2)
+    b = [int(x) for x in SH.shard_bounds(2**64 // 200, 8)]
+    w = [b[i + 1] - b[i] for i in range(8)]
+    assert max(w) - min(w) <= 2          # equal widths: uniform hashes => equal postings and equal slices per rank

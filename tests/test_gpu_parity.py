@@ -531,6 +531,115 @@ def test_contain_synthetic(ctx):
     check_contain(ctx, db, goff, np.array([5, thr - 1, 2**64 - 1], dtype=np.uint64), np.array([1, 2, 3], dtype=np.uint32))
 
 
+def crowded_db(rng, n_genomes=300):
+    """A database with crowded index buckets: k-mers shared by 2 .. all genomes (overflow runs behind the 64-byte line), k-mers
+    repeated inside a genome, neighbours that differ only in the low bits (same bucket, different remainder), the extreme
+    values 0 and 2^64 - 1."""
+    thr = O.threshold(200)
+    pool = np.unique(rng.integers(0, thr, size=60000, dtype=np.uint64))
+    shared = pool[:400]
+    cluster = (pool[1000] + np.arange(64, dtype=np.uint64))           # 64 consecutive values: one or two buckets
+    genomes = []
+    for g in range(n_genomes):
+        n = int(rng.integers(60, 400))
+        own = rng.choice(pool[2000:], size=n, replace=False)
+        sh = shared[:int(rng.integers(0, 400))] if g % 3 else shared[:8]
+        parts = [own, sh, cluster[rng.random(64) < 0.5]]
+        if g == 7:
+            parts.append(np.array([0, 2**64 - 1, 2**64 - 1, thr - 1], dtype=np.uint64))
+        if g == 9:
+            parts.append(own[:30])                                    # repeated inside the genome: counted twice (contain.rs:632)
+        genomes.append(np.concatenate(parts))
+    return pool, shared, cluster, genomes
+
+
+def flat_db(genomes):
+    goff = np.zeros(len(genomes) + 1, dtype=np.uint64)
+    goff[1:] = np.cumsum([len(g) for g in genomes])
+    return np.concatenate(genomes), goff
+
+
+def test_contain_crowded_buckets_and_index_shapes(ctx):
+    """The line index under every shape the build can take: 1..8 postings per bucket aimed for, one pass and several
+    (index_pass_max lowered so that the filter -> sort -> lines passes really split the bucket range), overflow runs."""
+    rng = np.random.default_rng(31)
+    pool, shared, cluster, genomes = crowded_db(rng)
+    db, goff = flat_db(genomes)
+    sk = np.unique(np.concatenate([rng.choice(pool, size=20000, replace=False), shared[:300], cluster[::2],
+                                   np.array([0, 2**64 - 1, 1], dtype=np.uint64)]))
+    sc = rng.integers(0, 300, size=len(sk)).astype(np.uint32)
+    try:
+        for lam, pass_max in ((3, 1 << 30), (1, 1 << 30), (8, 1 << 30), (3, 5000), (2, 777)):
+            ctx.set_option("index_lambda", str(lam))
+            ctx.set_option("index_pass_max", str(pass_max))
+            cc = check_contain(ctx, db, goff, sk, sc, min_kmers=0.0)
+            assert cc.max() > 300            # the shared k-mers hit
+            check_contain(ctx, db, goff, sk, sc, min_kmers=100.0)
+    finally:
+        ctx.set_option("index_lambda", "3")
+        ctx.set_option("index_pass_max", str(1 << 30))
+
+
+def test_contain_batch_matches_single_samples(ctx):
+    """sylph_db_contain_batch: S tables in one probe launch / sort / copy — row s * G + g must equal what the single-sample
+    call gives for sample s (and the oracle), with empty tables, zero counts and wide counts in the batch."""
+    import torch
+    rng = np.random.default_rng(32)
+    pool, shared, cluster, genomes = crowded_db(rng, n_genomes=120)
+    db, goff = flat_db(genomes)
+    G = len(genomes)
+    samples = []
+    for s in range(7):
+        n = [5000, 0, 12000, 1, 3000, 0, 800][s]
+        k = np.unique(np.concatenate([rng.choice(pool, size=n, replace=False), shared[:50 * s]])) if n else np.zeros(0, np.uint64)
+        c = rng.integers(0, 50, size=len(k)).astype(np.uint32)
+        if s == 4:
+            c[::7] = 70000                                             # forces 4-byte coverage values for the whole batch
+        samples.append((k, c))
+    d = S.Database(ctx, db, goff)
+    for subset in (samples, samples[:1], samples[1:2], samples[:4], []):
+        for mk in (50.0, 0.0):
+            cc, off, covs = d.contain_batch(subset, min_number_kmers=mk)
+            cc, off, covs = cc.copy(), off.copy(), covs.astype(np.uint32)
+            assert len(cc) == len(subset) * G and len(off) == len(subset) * G + 1
+            for s, (k, c) in enumerate(subset):
+                ecc, ecov, _ = O.contain(k, c, db, goff, min_number_kmers=mk)
+                assert np.array_equal(cc[s * G:(s + 1) * G], ecc), s
+                for g in range(G):
+                    assert np.array_equal(covs[int(off[s * G + g]):int(off[s * G + g + 1])], np.sort(ecov[g])), (s, g)
+    # device-resident tables (what sylph_sketch_finish_device hands over)
+    tk = [torch.from_numpy(k.view(np.int64)).cuda() for k, _ in samples]
+    tc = [torch.from_numpy(c.view(np.int32)).cuda() for _, c in samples]
+    torch.cuda.synchronize()
+    cc2, off2, covs2 = d.contain_batch([(a.data_ptr() if a.numel() else 0, b.data_ptr() if b.numel() else 0, a.numel()) for a, b in zip(tk, tc)],
+                                       device_ptrs=True)
+    cc, off, covs = d.contain_batch(samples)
+    assert np.array_equal(cc2, cc) and np.array_equal(off2, off) and np.array_equal(covs2, covs)
+    d.close()
+
+
+def test_sharded_database_one_rank_over_rccl(ctx):
+    """sylph_db_contain_batch_sharded with a real RCCL communicator (world size 1: the only one a 1-GPU box can form — RCCL
+    refuses two ranks on one device): librccl is resolved with dlopen, ncclCommInitRank / ncclAllGather / the grouped
+    send-recv path execute on the GPU, and the sharded entry point must return exactly what the unsharded batch call returns."""
+    rng = np.random.default_rng(33)
+    pool, shared, cluster, genomes = crowded_db(rng, n_genomes=90)
+    db, goff = flat_db(genomes)
+    samples = [(np.sort(rng.choice(pool, size=n, replace=False)), rng.integers(0, 9, size=n).astype(np.uint32)) for n in (4000, 0, 9000)]
+    comm = S.Comm(0, 1, ctx=ctx, rccl_id=S.Comm.rccl_unique_id())
+    bounds = S.shard_bounds(int(db.max()), 1)
+    d1 = S.Database(ctx, db, goff, shard=(bounds, 1, 0))
+    d0 = S.Database(ctx, db, goff)
+    for subset in (samples, samples[:1], []):
+        a = d1.contain_batch_sharded(comm, subset)
+        a = [x.copy() for x in a]
+        b = d0.contain_batch(subset)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(S.SylphHipError):
+        d0.contain_batch_sharded(comm, samples)            # not a shard
+    d1.close(); d0.close(); comm.close()
+
+
 # ---------------------------------------------------------------------------------------------- end to end
 def test_end_to_end_sketch_then_contain_device_resident(ctx):
     """Reads -> device-resident table -> containment without a host round trip; checked against the oracle end to end,
@@ -625,8 +734,9 @@ def test_push_from_pinned_host_memory(ctx):
 
 # ---------------------------------------------------------------------------------------------- multi-process
 def test_sharded_containment_two_ranks_one_gpu():
-    """Two ranks (gloo rendezvous, both on cuda:0) run the genome-sharded exchange with the real HIP probe and check
-    their own sample against the oracle over the whole database."""
+    """Two ranks (gloo rendezvous, both on cuda:0) run the library's k-mer-range sharded exchange (csrc/shard.hip) with the
+    collectives routed through torch.distributed callbacks, each with its own shard resident on the GPU, and check their own
+    samples against the oracle over the whole database."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
