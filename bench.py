@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--samples-per-step", type=int, default=0, help="samples per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
     ap.add_argument("--seed", type=int, default=20250711)
     args = ap.parse_args()
@@ -432,6 +433,55 @@ def main():
             out["verify"] = {"genomes_checked": 0, "mismatches": None, "error": str(e)}
     for sk in last.get("sessions", []):
         sk.close()
+    # ---- host-fed leg (untimed w.r.t. `value`): the same step with the reads starting in PAGE-LOCKED HOST memory, as ASCII and
+    # as the packed 2-bit stream a feed would hand over (sylph_sketch_push_enc cuts the batch into chunks that travel on a copy
+    # stream while the previous chunk is sketched): pinned host -> HBM -> sketch -> profile -> results on the host.
+    if rank == 0 and world == 1 and not args.no_h2d and not long_mode:
+        try:
+            from sylph_amd.binding import ENC_2BIT, ENC_ASCII, MEM_HOST_PINNED
+            rs = read_sets[0]
+            nb, nrec = rs["n_bases"], rs["n_records"]
+            host_ascii = rs["bases"][:nb].cpu().numpy()
+            off_h = rs["rec_off"].cpu().numpy().astype(np.uint64)
+            packed = S.pack_2bit(host_ascii)
+            pin_a, pin_p, pin_o = S.PinnedBuffer(nb + 64), S.PinnedBuffer(len(packed) + 64), S.PinnedBuffer(len(off_h) * 8)
+            pin_a.array[:nb] = host_ascii
+            pin_p.array[:len(packed)] = packed
+            pin_o.array.view(np.uint64)[:len(off_h)] = off_h
+            del host_ascii, packed
+            # the link itself: one page-locked 1 GiB host -> device copy
+            probe_t = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+            src_t = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+            bw = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                probe_t.copy_(src_t, non_blocking=True)
+                torch.cuda.synchronize()
+                bw.append((1 << 30) / (time.perf_counter() - tq) / 1e9)
+            del probe_t, src_t
+            link = max(bw)
+            h2d = {"pinned_h2d_gb_per_s": round(link, 1)}
+            for name, enc, pin, nbytes in (("ascii", ENC_ASCII, pin_a, nb), ("2bit", ENC_2BIT, pin_p, (nb + 3) // 4)):
+                ts = []
+                for rep in range(4):
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=True)
+                    sk.push_enc(pin.ptr, pin_o.ptr, nb, MEM_HOST_PINNED, enc, n_records=nrec)
+                    dk, dc, n, dup = sk.finish_device()
+                    res = db.contain_batch([(dk, dc, n)], device_ptrs=True)
+                    ts.append(time.perf_counter() - tq)
+                    sk.close()
+                t_best = float(np.median(ts[1:]))
+                moved = nbytes + 8 * (nrec + 1)
+                h2d[name] = {"gbp_per_s": round(nb / 1e9 / t_best, 2), "ms_per_step": round(t_best * 1e3, 3), "bytes_over_pcie": int(moved),
+                             "pcie_frac": round(moved / t_best / 1e9 / link, 3)}
+            out["value_h2d_inclusive"] = h2d
+            for p_ in (pin_a, pin_p, pin_o):
+                p_.close()
+        except Exception as e:
+            out["value_h2d_inclusive"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not long_mode and wl != "c3r":
         try:
             from oracle import oracle as O  # noqa: F401  (cpu_baseline leg only)

@@ -74,7 +74,8 @@ int sylph_ctx_synchronize(sylph_ctx *ctx);
  * "unordered" (position kernel with LDS-staged atomics + radix sort by position).  "bucket_target" = mean number of
  * occurrences per replay bucket aimed for, "16".."256".  "index_lambda" = postings per 64-byte bucket line of a database
  * index aimed for ("1".."8", default 3; applies to databases uploaded afterwards), "index_pass_max" = postings sorted per pass
- * of the index build (tests lower it to force several passes). */
+ * of the index build (tests lower it to force several passes), "push_chunk_bytes" = bytes of bases per chunk of a host batch
+ * (default 64 MiB). */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
 
 /* Per-kernel timing (hipEvent pairs on the ctx stream around every launch of the named kernel family) for
@@ -142,6 +143,19 @@ int sylph_sketch_push(sylph_sketch *sk, const uint8_t *bases, const uint64_t *re
  * device->host read of that word when rec_off lives in HBM. */
 int sylph_sketch_push_n(sylph_sketch *sk, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_records,
                         uint64_t n_bases, int mem);
+
+/* The same with the encoding of `bases` stated.  SYLPH_ENC_ASCII: one byte per base, any byte value (BYTE_TO_SEQ semantics,
+ * types.rs:50-59).  SYLPH_ENC_2BIT: the flat stream packed 4 bases per byte, base i in bits 7-2(i%4)..6-2(i%4) of byte i/4, codes
+ * A=0 C=1 G=2 T/U=3 and everything else 0 — exactly what BYTE_TO_SEQ would make of the ASCII, so results are identical; a
+ * quarter of the PCIe bytes (the transfer is the long pole of a host-fed sample).  rec_off stays in BASES.  sylph_pack_2bit
+ * packs on the host (the feed does it while parsing).  A packed SYLPH_MEM_DEVICE stream must be 4-byte aligned.
+ * Host batches (SYLPH_MEM_HOST[_PINNED]) of any size are cut into chunks of whole records inside the call and copied on a
+ * second stream while the previous chunk is being sketched. */
+#define SYLPH_ENC_ASCII 0
+#define SYLPH_ENC_2BIT 1
+int sylph_sketch_push_enc(sylph_sketch *sk, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_records, uint64_t n_bases,
+                          int mem, int enc);
+int sylph_pack_2bit(const uint8_t *ascii, uint64_t n, uint8_t *out);
 
 /* Finish the sample: (k-mer, count) table in ascending k-mer order == SequencesSketch.kmer_counts
  * (types.rs:145-155) as a keyed multiset, and the number of occurrences removed as duplicates

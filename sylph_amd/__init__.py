@@ -5,7 +5,7 @@ package is the thin Python binding used by tests/ and bench.py; it fails loudly 
 is no CPU fallback.
 """
 from .binding import (Comm, Context, Database, PinnedBuffer, ReadSketcher, SylphHipError, SEED_AVX2_COMPAT, SEED_SCALAR, READS_PAIRED,
-                      READS_SINGLE, lib_path, load, shard_bounds)
+                      READS_SINGLE, lib_path, load, pack_2bit, shard_bounds)
 
-__all__ = ["Comm", "shard_bounds", "Context", "Database", "PinnedBuffer", "ReadSketcher", "SylphHipError", "SEED_AVX2_COMPAT", "SEED_SCALAR", "READS_PAIRED",
+__all__ = ["pack_2bit", "Comm", "shard_bounds", "Context", "Database", "PinnedBuffer", "ReadSketcher", "SylphHipError", "SEED_AVX2_COMPAT", "SEED_SCALAR", "READS_PAIRED",
            "READS_SINGLE", "lib_path", "load"]

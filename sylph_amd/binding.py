@@ -8,6 +8,7 @@ import numpy as np
 SEED_SCALAR, SEED_AVX2_COMPAT = 0, 1
 READS_SINGLE, READS_PAIRED = 0, 1
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
+ENC_ASCII, ENC_2BIT = 0, 1
 
 _LIB = None
 
@@ -27,7 +28,7 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_seeds_positions", "sylph_sketch_genome", "sylph_sketch_genomes", "sylph_sketch_begin", "sylph_sketch_push", "sylph_sketch_push_n",
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
            "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_contain_view_packed", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy",
-           "sylph_db_index_bytes", "sylph_db_contain_batch", "sylph_shard_bounds", "sylph_db_upload_shard", "sylph_comm_rccl_unique_id",
+           "sylph_sketch_push_enc", "sylph_pack_2bit", "sylph_db_index_bytes", "sylph_db_contain_batch", "sylph_shard_bounds", "sylph_db_upload_shard", "sylph_comm_rccl_unique_id",
            "sylph_comm_create_rccl", "sylph_comm_create", "sylph_comm_destroy", "sylph_db_contain_batch_sharded"]
 
 
@@ -63,6 +64,8 @@ def load():
     L.sylph_sketch_begin.argtypes = [vp, u32, u32, i32, i32, i32, P(vp)]
     L.sylph_sketch_push.argtypes = [vp, vp, vp, u64, i32]
     L.sylph_sketch_push_n.argtypes = [vp, vp, vp, u64, u64, i32]
+    L.sylph_sketch_push_enc.argtypes = [vp, vp, vp, u64, u64, i32, i32]
+    L.sylph_pack_2bit.argtypes = [vp, u64, vp]
     L.sylph_sketch_finish.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
     L.sylph_sketch_finish_device.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
     L.sylph_sketch_destroy.argtypes = [vp]
@@ -198,6 +201,14 @@ class Context:
         return _take(ok, int(koff[-1]), np.uint64), koff, _take(ot, int(toff[-1]), np.uint64), toff
 
 
+def pack_2bit(ascii_bases):
+    """sylph_pack_2bit: BYTE_TO_SEQ codes, 4 bases per byte, first base in the top bits (host function, no GPU needed)."""
+    a = _bases(ascii_bases)
+    out = np.zeros((len(a) + 3) // 4 + 16, dtype=np.uint8)
+    _check(load().sylph_pack_2bit(_ptr(a) if len(a) else None, len(a), _ptr(out)))
+    return out
+
+
 class PinnedBuffer:
     """Page-locked host memory (sylph_pinned_alloc) exposed as a numpy array, for SYLPH_MEM_HOST_PINNED pushes."""
 
@@ -247,6 +258,15 @@ class ReadSketcher:
         else:
             _check(load().sylph_sketch_push_n(self._h, C.c_void_p(bases_ptr), C.c_void_p(rec_off_ptr), n_records, n_bases,
                                               MEM_DEVICE))
+
+    def push_enc(self, bases, rec_off, n_bases, mem=MEM_HOST, enc=ENC_ASCII, n_records=None):
+        """sylph_sketch_push_enc.  bases / rec_off: numpy arrays (MEM_HOST), integer addresses of page-locked memory
+        (MEM_HOST_PINNED) or of device memory (MEM_DEVICE; then n_records must be given)."""
+        if mem == MEM_HOST:
+            a, off = _np(bases, np.uint8), _np(rec_off, np.uint64)
+            _check(load().sylph_sketch_push_enc(self._h, _ptr(a) if len(a) else None, _ptr(off), len(off) - 1, int(n_bases), mem, enc))
+        else:
+            _check(load().sylph_sketch_push_enc(self._h, C.c_void_p(int(bases)), C.c_void_p(int(rec_off)), int(n_records), int(n_bases), mem, enc))
 
     def finish(self):
         ok, oc, n, d = C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint64(0)

@@ -227,6 +227,8 @@ void sylph::ctx_unref(sylph_ctx* ctx) {
         if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (int i = 0; i < 2; i++) if (ctx->copy_ev[i]) (void)hipEventDestroy(ctx->copy_ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -271,6 +273,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 16 && v <= 256, "bucket_target must be in [16, 256]");
             ctx->bucket_target = (uint32_t)v;
+        } else if (!strcmp(key, "push_chunk_bytes")) {
+            const long long v = strtoll(value, nullptr, 10);
+            SY_REQUIRE(v >= 64 && v <= (1ll << 31), "push_chunk_bytes must be in [64, 2^31]");
+            ctx->push_chunk_bytes = (uint64_t)v;
         } else if (!strcmp(key, "index_lambda")) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 1 && v <= 8, "index_lambda must be in [1, 8]");

@@ -128,6 +128,7 @@ struct sylph_ctx {
     uint32_t bucket_target = 128;           // mean occurrences per replay bucket aimed for ("bucket_target")
     uint32_t index_lambda = 3;              // postings per 64-byte bucket line of a database index aimed for ("index_lambda")
     uint64_t index_pass_max = 1ull << 30;   // postings sorted per pass of the index build ("index_pass_max"; tests lower it)
+    uint64_t push_chunk_bytes = 64ull << 20;  // bytes of bases per chunk of a host batch ("push_chunk_bytes"; tests lower it)
     int seeds_mode = 0;                     // 0 auto: read-per-lane kernel for short reads, else ordered slots; 1 unordered kernel + radix sort; 2 ordered slots only ("seeds")
     std::atomic<int> refs{1};               // the creator + every live session / db; freed when it drops to 0
     // profiling
@@ -152,6 +153,8 @@ struct sylph_ctx {
     static constexpr size_t STAGE_BYTES = 32u << 20;
     void* stage[2] = {nullptr, nullptr};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;       // host batches travel on this stream while ctx->stream computes (sketch.hip)
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
     void d2h(void* dst, const void* dev_src, size_t bytes);     // synchronous on return
     void h2d(void* dev_dst, const void* src, size_t bytes);     // queued on `stream`; src may be reused on return
 };

@@ -10,11 +10,15 @@
 //
 // A workgroup owns the records whose start falls into a block of `rt` (16 B-aligned) base coordinates — rt is chosen by the
 // host so that a block holds about 256 records — and loads that block plus a halo of READ_HALO bases on both sides (the end of its last record; mate 1 of a mate 2 that starts the block)
-// as a 2-bit big-endian stream F.  Each lane then walks ITS record: the forward k-mer f and the reverse complement r are
-// rolling registers (f = (f << 2 | b), r = (r >> 2 | (3-b) << 2(k-1))), the next base comes from a 64-bit shift register
-// refilled from LDS every 16 steps, and the canonical hash / threshold test are the same instruction sequences as in the
-// position kernel.  Hits are accumulated as bit masks (one bit per k-mer, 32 k-mers per LDS word), counted, scanned across
-// the workgroup — lanes are in record order, so the scan gives file order — and only then re-hashed and written.
+// as a 2-bit big-endian stream F (input may already BE 2-bit: SYLPH_ENC_2BIT, a quarter of the PCIe bytes).  Each lane then
+// walks ITS record with no rolling state at all: it keeps three lane-aligned stream words A(g..g+2) (16 bases each, refilled
+// from LDS once per 16 k-mers) and their reverse-complement images B = ~pairswap(bitreverse(A)); the forward k-mer t of the
+// group and its reverse complement are funnel-shift extracts (v_alignbit_b32) of those registers at COMPILE-TIME shifts,
+// both left-aligned in 64 bits with a few garbage bits below (the next base / the complement of the previous one), which
+// cannot change which of the two is smaller; one shift drops the garbage from the winner.  4 instructions per k-mer
+// instead of the 8 of a rolling update (r01), then the same hash / threshold sequences as the position kernel.
+// Hits are accumulated as bit masks (one bit per k-mer, 32 k-mers per LDS word), counted, scanned across the workgroup —
+// lanes are in record order, so the scan gives file order — and only then re-hashed and written.
 #include "common.h"
 #include "device_common.h"
 #include "sketch_session.h"
@@ -63,6 +67,45 @@ __device__ __forceinline__ uint32_t even16(uint64_t x) {
     return (uint32_t)(x >> 32);
 }
 
+// reverse-complement image of a stream word: base i of `a` (bits 31-2i, 30-2i) -> its complement at bits 2i+1, 2i
+__device__ __forceinline__ uint32_t rcword(uint32_t a) {
+    const uint32_t r = __brev(a);
+    return ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+}
+
+// One k-mer of a group of 16: T = index inside the group.  A0..A2: the lane-aligned forward words of the group and the two
+// behind it; Bm, B0..B2: reverse-complement images of the word before the group and of A0..A2.  Forward window = bases
+// [T, T + 32) of A0:A1:A2; reverse-complement window = bits [2T - D, 2T - D + 64) of the little-endian multiword Bm:B0:B1:B2
+// counted from B0's bit 0, D = 64 - 2K: both hold their k-mer in the top 2K bits.
+template <int K, int T, int HV>
+__device__ __forceinline__ void kmer_step(uint32_t A0, uint32_t A1, uint32_t A2, uint32_t Bm, uint32_t B0, uint32_t B1, uint32_t B2,
+                                          uint64_t thr, uint32_t& mask) {
+    constexpr int D = 64 - 2 * K;
+    uint32_t fhi, flo, rhi, rlo;
+    if constexpr (T == 0) { fhi = A0; flo = A1; }
+    else { fhi = __builtin_amdgcn_alignbit(A0, A1, 32 - 2 * T); flo = __builtin_amdgcn_alignbit(A1, A2, 32 - 2 * T); }
+    constexpr int OFF = 2 * T - D;
+    if constexpr (OFF < 0) { rlo = __builtin_amdgcn_alignbit(B0, Bm, OFF + 32); rhi = __builtin_amdgcn_alignbit(B1, B0, OFF + 32); }
+    else if constexpr (OFF == 0) { rlo = B0; rhi = B1; }
+    else { rlo = __builtin_amdgcn_alignbit(B1, B0, OFF); rhi = __builtin_amdgcn_alignbit(B2, B1, OFF); }
+    const uint64_t f = ((uint64_t)fhi << 32) | flo, rc = ((uint64_t)rhi << 32) | rlo;
+    const uint64_t canon = (f < rc ? f : rc) >> D;                                      // seeding.rs:134-139
+    const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
+    asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(h), "s"(thr) : "vcc");
+}
+template <int K, int T0, int HV>
+__device__ __forceinline__ void kmer_steps8(uint32_t A0, uint32_t A1, uint32_t A2, uint32_t Bm, uint32_t B0, uint32_t B1, uint32_t B2,
+                                            uint64_t thr, uint32_t& mask) {
+    kmer_step<K, T0 + 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+    kmer_step<K, T0 + 1, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+    kmer_step<K, T0 + 2, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+    kmer_step<K, T0 + 3, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+    kmer_step<K, T0 + 4, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+    kmer_step<K, T0 + 5, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+    kmer_step<K, T0 + 6, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+    kmer_step<K, T0 + 7, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+}
+
 // 16 ASCII bases -> forward stream word (base j at bits 30-2j); the F half of pack16
 __device__ __forceinline__ uint32_t pack16_fwd(uint4 v) {
     uint32_t bad = 0;
@@ -90,7 +133,7 @@ __global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __re
     blk_rec[b] = (uint32_t)lo;
 }
 
-template <int K, int HV>
+template <int K, int HV, int ENC>
 __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
                                                      const uint64_t* __restrict__ off, uint64_t n_rec,
                                                      const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
@@ -115,10 +158,16 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
         const uint32_t blk = blk_list ? blk_list[it] : it;
         const int64_t a0 = (int64_t)blk * rt - RH;                 // aligned coordinate of stream base 0 (multiple of 16)
         for (uint32_t ci = tid; ci < n_words; ci += RTPB) {
-            const int64_t a = a0 + (int64_t)ci * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a >= 0 && (uint64_t)a < n_al) v = *reinterpret_cast<const uint4*>(bases_al + a);
-            sF[ci] = pack16_fwd(v);
+            const int64_t a = a0 + (int64_t)ci * 16;                  // aligned base coordinate of this word's first base
+            if constexpr (ENC == 0) {                                  // ASCII: 16 bytes -> one word
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (a >= 0 && (uint64_t)a < n_al) v = *reinterpret_cast<const uint4*>(bases_al + a);
+                sF[ci] = pack16_fwd(v);
+            } else {                                                   // packed input: 4 bytes, first base in bits 7:6 of byte 0
+                uint32_t w = 0;
+                if (a >= 0 && (uint64_t)a < n_al) w = *reinterpret_cast<const uint32_t*>(bases_al + (a >> 2));
+                sF[ci] = __builtin_amdgcn_perm(0u, w, 0x00010203u);
+            }
         }
         const uint64_t R0 = blk_rec[blk], R1 = blk_rec[blk + 1];
         // offsets of the block's records (+ the mate-1 offset in front of a block that starts with a mate 2, + two behind)
@@ -153,43 +202,30 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d));
             if (nh_max) {
-                // k-mer 0 and the stream behind it.  f and rc live as 32-bit halves so that the rolling update is three
-                // instructions each (shift-or on one half, funnel shift on the other) instead of 64-bit shift + or + masks
-                const uint64_t f0 = win64(sF, rel) >> (64 - 2 * K);
-                const uint64_t r0 = revcomp_top<K>(f0 << (64 - 2 * K));
-                uint32_t flo = (uint32_t)f0, fhi = (uint32_t)(f0 >> 32), rlo = (uint32_t)r0, rhi = (uint32_t)(r0 >> 32);
-                const uint64_t cur0 = win64(sF, rel + K);            // bases K .. K+31
-                uint32_t chi = (uint32_t)(cur0 >> 32), clo = (uint32_t)cur0;   // chi: the next 16 bases, clo: the 16 after them
-                uint32_t jn = (rel + K + 32) >> 4;
-                const uint32_t sh = 32u - ((rel + K + 32) & 15u) * 2u;   // in [2, 32]
-                uint32_t wa = sF[jn], wb = sF[jn + 1];
+                // lane-aligned stream words A(j) = bases [rel + 16 j, rel + 16 j + 16): one LDS read and one 64-bit shift each
+                const uint32_t w0 = rel >> 4, sh = 32u - (rel & 15u) * 2u;          // sh in [2, 32]
+                uint32_t raw = sF[w0], nxt = sF[w0 + 1];
+                auto next_word = [&](uint32_t j) {                                   // A(j), advancing the raw pair to j + 1
+                    const uint32_t a = (uint32_t)((((uint64_t)raw << 32) | nxt) >> sh);
+                    raw = nxt;
+                    nxt = sF[w0 + j + 2];
+                    return a;
+                };
+                uint32_t A0 = next_word(0), A1 = next_word(1), A2 = next_word(2);
+                uint32_t Bm = 0, B0 = rcword(A0), B1 = rcword(A1), B2 = rcword(A2);  // (Bm only feeds garbage bits of group 0)
                 uint32_t mask = 0;
-                constexpr uint32_t HI_MASK = (uint32_t)(KC<K>::MASK >> 32);
-                constexpr int TOP = 2 * K - 2 - 32;                  // bit of the top base inside the high half (K > 16)
-                for (uint32_t g = 0; g * 8 < nh_max; g++) {          // 8 k-mers per group: 150 bp reads (120 k-mers) waste none
-                    const uint32_t cw = chi, cwn = ~chi;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const uint64_t f = ((uint64_t)fhi << 32) | flo, rc = ((uint64_t)rhi << 32) | rlo;
-                        const uint64_t canon = f < rc ? f : rc;                             // seeding.rs:134-139
-                        const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
-                        asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(h), "s"(thr) : "vcc");
-                        const uint32_t nb = (cw >> (30 - 2 * t)) & 3u, nbc = (cwn >> (30 - 2 * t)) & 3u;   // v_bfe_u32 each
-                        fhi = __builtin_amdgcn_alignbit(fhi, flo, 30) & HI_MASK;            // (f << 2 | nb) & mask
-                        flo = (flo << 2) | nb;                                              // v_lshl_or_b32
-                        rlo = __builtin_amdgcn_alignbit(rhi, rlo, 2);                       // rc >> 2 | (3 - nb) << 2(K-1)
-                        rhi = (rhi >> 2) | (nbc << TOP);
+                const uint32_t n_half = (nh_max + 7) >> 3;                           // half-groups of 8 k-mers (uniform per wave)
+                for (uint32_t hg = 0; hg < n_half; hg += 2) {
+                    kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+                    if (hg + 1 < n_half) {
+                        kmer_steps8<K, 8, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+                        A0 = A1; A1 = A2; A2 = next_word((hg >> 1) + 3);
+                        Bm = B0; B0 = B1; B1 = B2; B2 = rcword(A2);
                     }
-                    chi <<= 16;                                      // 8 bases consumed
-                    if (g & 1) {                                     // 16 consumed: the stream moves up one word
-                        chi = clo;
-                        clo = (uint32_t)((((uint64_t)wa << 32) | wb) >> sh);   // the 16 bases behind
-                        jn++;
-                        wa = wb;
-                        wb = sF[jn + 1];
-                    }
-                    if ((g & 3) == 3) { s_mask[g >> 2][tid] = mask; mask = 0; }
-                    else if ((g + 1) * 8 >= nh_max) s_mask[g >> 2][tid] = mask << (8 * (3 - (g & 3)));   // last, partly filled word
+                    // 32 k-mers per mask word: k-mer i <-> bit 31 - (i & 31) of word i >> 5
+                    const uint32_t done = min(hg + 2, n_half);                       // half-groups finished so far
+                    if ((done & 3u) == 0) { s_mask[(done >> 2) - 1][tid] = mask; mask = 0; }
+                    else if (done == n_half) s_mask[done >> 2][tid] = mask << (8 * (4 - (done & 3u)));   // last, partly filled word
                 }
             }
             // count this lane's real hits (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)
@@ -297,10 +333,13 @@ uint32_t grid_for(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb -
 // Short-read path of sylph_sketch_push: appends the batch's occurrences (hash + OccRec, file order) to the session and
 // returns true; returns false — having appended nothing — when the batch is not for this kernel (a record longer than
 // READ_HALO, or more overflowing blocks than spill regions), and the caller runs the position kernel + annotate instead.
-bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases) {
+bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases,
+                      int enc) {
     sylph_ctx* ctx = sk->ctx;
-    const uint32_t bias = (uint32_t)((uintptr_t)d_bases & 15);
-    const uint8_t* bases_al = d_bases - bias;
+    // the kernel works in 16 B-aligned coordinates: bias = bases between the aligned address below d_bases and d_bases
+    // (a packed stream holds 4 bases per byte and may begin `phase` bases into its first byte)
+    const uint32_t bias = enc == SYLPH_ENC_2BIT ? (uint32_t)((uintptr_t)d_bases & 15) * 4u + phase : (uint32_t)((uintptr_t)d_bases & 15);
+    const uint8_t* bases_al = d_bases - ((uintptr_t)d_bases & 15);
     const uint64_t n_al = n_bases + bias;
     // block size: about RTPB records per workgroup
     uint32_t rt = (uint32_t)std::min<uint64_t>(RT_MAX, std::max<uint64_t>(RT_MIN, (uint64_t)RTPB * n_bases / n_records));
@@ -327,12 +366,14 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* 
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
     auto launch = [&](uint32_t n_it, uint32_t cap, OccRec* sr, const uint32_t* list) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * 8);
-#define SY_LAUNCH_READS(KK, HH)                                                                                               \
-    hipLaunchKernelGGL((reads_kernel<KK, HH>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
+#define SY_LAUNCH_READS(KK, HH, EE)                                                                                                   \
+    hipLaunchKernelGGL((reads_kernel<KK, HH, EE>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
                        blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr,          \
                        blk_count, d_state, list, spill_slot)
-        if (sk->k == 31) { if (hv) SY_LAUNCH_READS(31, 1); else SY_LAUNCH_READS(31, 0); }
-        else { if (hv) SY_LAUNCH_READS(21, 1); else SY_LAUNCH_READS(21, 0); }
+        if (enc == SYLPH_ENC_2BIT) {
+            if (sk->k == 31) SY_LAUNCH_READS(31, 1, 1); else SY_LAUNCH_READS(21, 1, 1);
+        } else if (sk->k == 31) { if (hv) SY_LAUNCH_READS(31, 1, 0); else SY_LAUNCH_READS(31, 0, 0); }
+        else { if (hv) SY_LAUNCH_READS(21, 1, 0); else SY_LAUNCH_READS(21, 0, 0); }
 #undef SY_LAUNCH_READS
         SY_HIP(hipGetLastError());
     };

@@ -23,7 +23,7 @@
 namespace sylph {
 
 bool finish_bucketed(sylph_sketch* sk);   // replay_lds.hip
-bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases);   // reads.hip
+bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases, int enc);   // reads.hip
 
 void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint32_t c, uint32_t k, uint64_t* d_out_hash,
                   uint32_t* d_out_pos, uint32_t out_cap, uint32_t* d_count);
@@ -449,51 +449,39 @@ uint32_t seeds_sorted_by_pos(sylph_ctx* ctx, const uint8_t* d_bases, uint64_t n_
     return n;
 }
 
-static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, int mem,
-                             const uint64_t* n_bases_hint = nullptr) {
-    sylph_ctx* ctx = sk->ctx;
-    SY_REQUIRE(!sk->finished, "sylph_sketch_push after finish");
-    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE || mem == SYLPH_MEM_HOST_PINNED, "bad mem kind %d", mem);
-    SY_REQUIRE(!sk->paired || (n_records % 2 == 0), "paired batches must hold an even number of records");
-    if (n_records == 0) return;
-    SY_REQUIRE(rec_off, "null rec_off");
-    static const bool slowlog = getenv("SYLPH_HIP_SLOWLOG") != nullptr;
-    const double t_enter = slowlog ? HostPhase::now() : 0;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    DeviceGuard dg(ctx->device);
-    if (slowlog && HostPhase::now() - t_enter > 3.0)
-        fprintf(stderr, "[sylph_hip] slow push entry (lock/device): %.3f ms\n", HostPhase::now() - t_enter);
-    HostPhase ph_total(ctx, "push: total");
-    const uint8_t* d_bases;
-    const uint64_t* d_off;
-    uint64_t n_bases;
-    if (mem != SYLPH_MEM_DEVICE) {
-        SY_REQUIRE(rec_off[0] == 0, "rec_off[0] must be 0");
-        n_bases = rec_off[n_records];
-        SY_REQUIRE(bases || n_bases == 0, "null bases");
-        sk->batch_bases.reserve(n_bases + 64);
-        sk->batch_off.reserve((n_records + 1) * 8);
-        if (mem == SYLPH_MEM_HOST_PINNED) {   // page-locked by sylph_pinned_alloc: straight DMA, no staging memcpy
-            if (n_bases) SY_HIP(hipMemcpyAsync(sk->batch_bases.p, bases, n_bases, hipMemcpyHostToDevice, ctx->stream));
-            SY_HIP(hipMemcpyAsync(sk->batch_off.p, rec_off, (n_records + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        } else {
-            ctx->h2d(sk->batch_bases.p, bases, n_bases);
-            ctx->h2d(sk->batch_off.p, rec_off, (n_records + 1) * 8);
-        }
-        d_bases = sk->batch_bases.as<uint8_t>();
-        d_off = sk->batch_off.as<uint64_t>();
-    } else {
-        if (n_bases_hint) n_bases = *n_bases_hint;
-        else ctx->read_back(&n_bases, rec_off + n_records, 8);
-        SY_REQUIRE(bases || n_bases == 0, "null bases");
-        d_bases = bases;
-        d_off = rec_off;
+// packed (SYLPH_ENC_2BIT) stream -> ASCII, for the batches the short-read kernel declines (long records, repeats everywhere)
+__global__ __launch_bounds__(256) void unpack_2bit_kernel(const uint8_t* __restrict__ packed, uint32_t phase, uint64_t n_bases,
+                                                          uint8_t* __restrict__ ascii) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bases; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = i + phase;
+        const uint32_t code = (packed[b >> 2] >> (6u - 2u * (uint32_t)(b & 3))) & 3u;
+        ascii[i] = (uint8_t)((0x54474341u >> (8u * code)) & 0xFFu);   // 'A','C','G','T'
     }
+}
+// off_out[i] = off_in[i] - off_in[0]: a chunk of a larger batch becomes a batch of its own
+__global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] - in[0];
+}
+
+// One device-resident batch: records d_off[0..n_records] over the stream at d_bases (ASCII, or packed 2-bit starting
+// `phase` bases into the first byte).  Appends the batch's occurrences to the session.
+static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases,
+                          int enc) {
+    sylph_ctx* ctx = sk->ctx;
     // short-read batches (mean record length <= 300): one lane per record, seeding + markers fused (reads.hip); it declines
     // (returns false) when some record is longer than its halo, and the position kernel + annotate below take over
     bool done = false;
-    if (ctx->seeds_mode == 0 && n_bases < (1ull << 32) - 32 && n_records < (1ull << 31) && n_bases <= 300ull * n_records)
-        done = push_short_reads(sk, d_bases, d_off, n_records, n_bases);
+    if (ctx->seeds_mode == 0 && n_bases < (1ull << 32) - 64 && n_records < (1ull << 31) && n_bases <= 300ull * n_records)
+        done = push_short_reads(sk, d_bases, phase, d_off, n_records, n_bases, enc);
+    if (!done && enc == SYLPH_ENC_2BIT) {   // the position kernel and the marker loads of annotate read ASCII
+        sk->batch_ascii.reserve(n_bases + 64);
+        if (n_bases)
+            hipLaunchKernelGGL(unpack_2bit_kernel, dim3((uint32_t)std::min<uint64_t>((n_bases + 255) / 256, 65536)), dim3(256), 0, ctx->stream,
+                               d_bases, phase, n_bases, sk->batch_ascii.as<uint8_t>());
+        SY_HIP(hipMemsetAsync(sk->batch_ascii.as<uint8_t>() + n_bases, 0, 64, ctx->stream));
+        d_bases = sk->batch_ascii.as<uint8_t>();
+    }
     uint32_t* d_count = sk->counters.as<uint32_t>();
     // K1 loads 16 B per lane: start it at the aligned address below d_bases and subtract the bias afterwards (a device
     // pointer into the middle of a larger buffer, e.g. the second batch of a sample, need not be aligned)
@@ -519,8 +507,115 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
         sk->n_occ = need;
     }
     sk->rec_base += n_records;
-    // device staging buffers (and a pinned caller buffer) are reused by the next push: make sure this batch is consumed
-    if (mem != SYLPH_MEM_DEVICE) SY_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+// Host batches (SYLPH_MEM_HOST / SYLPH_MEM_HOST_PINNED) are cut into chunks of whole records (whole pairs) that travel on a
+// COPY stream into two device slots while the compute stream works on the previous chunk: the PCIe transfer (1 B per base,
+// or 1/4 B packed) is the long pole of a host-fed sample — 18 ms per Gbp against ~1 ms of kernels — and everything else
+// hides under it.  Page-locked caller memory is DMA'd in place; pageable memory goes through the ctx's pinned staging pair.
+static void push_host_batch(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, int mem, int enc) {
+    sylph_ctx* ctx = sk->ctx;
+    const bool pinned = mem == SYLPH_MEM_HOST_PINNED;
+    const uint64_t bpb = enc == SYLPH_ENC_2BIT ? 4 : 1;                         // bases per byte
+    if (!ctx->copy_stream) {
+        SY_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) SY_HIP(hipEventCreateWithFlags(&ctx->copy_ev[i], hipEventDisableTiming));
+    }
+    if (!pinned) {   // make sure the staging pair exists (ctx->h2d creates it lazily)
+        uint8_t dummy = 0;
+        ctx->counters.reserve(64);
+        ctx->h2d(ctx->counters.as<uint8_t>() + 32, &dummy, 1);
+    }
+    // chunk limits: page-locked input is only bounded by the device slots; pageable input must fit a 32 MiB staging buffer
+    // (bases + offsets)
+    const uint64_t max_bytes = std::min<uint64_t>(ctx->push_chunk_bytes, pinned ? (1ull << 31) : (24ull << 20));
+    const uint64_t max_recs = pinned ? (4ull << 20) : ((sylph_ctx::STAGE_BYTES - (24ull << 20)) / 8 - 2);
+    struct Chunk { uint64_t r0, r1, b0, b1; };
+    auto next_chunk = [&](uint64_t r0) {
+        const uint64_t b0 = rec_off[r0];
+        uint64_t hi = std::min(n_records, r0 + max_recs);
+        const uint64_t limit = b0 + std::min<uint64_t>(max_bytes * bpb, 1ull << 31) - 8;
+        if (rec_off[hi] > limit) hi = (uint64_t)(std::upper_bound(rec_off + r0, rec_off + hi + 1, limit) - rec_off) - 1;
+        if (sk->paired) hi -= (hi - r0) & 1;
+        if (hi <= r0) hi = std::min(n_records, r0 + (sk->paired ? 2 : 1));     // a single record longer than a chunk
+        return Chunk{r0, hi, b0, rec_off[hi]};
+    };
+    auto enqueue_copy = [&](const Chunk& c, int slot) {
+        // device slot: [bases (from the byte that holds base b0) | pad] and [raw offsets r0..r1]
+        const uint64_t byte0 = c.b0 / bpb, byte1 = (c.b1 + bpb - 1) / bpb, nb = byte1 - byte0, no = (c.r1 - c.r0 + 1) * 8;
+        sk->slot_bases[slot].reserve(nb + 64);
+        sk->slot_off[slot].reserve(no * 2);
+        const uint8_t* src_b = bases + byte0;
+        const uint64_t* src_o = rec_off + c.r0;
+        if (!pinned && nb + no + 8 > sylph_ctx::STAGE_BYTES) {   // one record longer than a staging buffer: the plain staged copy
+            SY_HIP(hipStreamSynchronize(ctx->copy_stream));       // (it reuses the staging pair: nothing of ours may still be in flight)
+            ctx->h2d(sk->slot_bases[slot].p, src_b, nb);
+            SY_HIP(hipMemsetAsync(sk->slot_bases[slot].as<uint8_t>() + nb, 0, 64, ctx->stream));
+            ctx->h2d(sk->slot_off[slot].p, src_o, no);
+            SY_HIP(hipEventRecord(ctx->copy_ev[slot], ctx->stream));
+            return;
+        }
+        if (!pinned) {
+            SY_HIP(hipEventSynchronize(ctx->stage_ev[slot]));                   // the previous copy out of this staging buffer finished
+            uint8_t* stg = (uint8_t*)ctx->stage[slot];
+            if (nb) memcpy(stg, src_b, nb);
+            memcpy(stg + ((nb + 7) & ~7ull), src_o, no);
+            src_b = stg;
+            src_o = reinterpret_cast<const uint64_t*>(stg + ((nb + 7) & ~7ull));
+        }
+        if (nb) SY_HIP(hipMemcpyAsync(sk->slot_bases[slot].p, src_b, nb, hipMemcpyHostToDevice, ctx->copy_stream));
+        SY_HIP(hipMemsetAsync(sk->slot_bases[slot].as<uint8_t>() + nb, 0, 64, ctx->copy_stream));
+        SY_HIP(hipMemcpyAsync(sk->slot_off[slot].p, src_o, no, hipMemcpyHostToDevice, ctx->copy_stream));
+        SY_HIP(hipEventRecord(ctx->copy_ev[slot], ctx->copy_stream));
+        if (!pinned) SY_HIP(hipEventRecord(ctx->stage_ev[slot], ctx->copy_stream));
+    };
+    // the device slots may still be read by kernels of the previous push (spill redo, annotate): order the copy stream behind them
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    Chunk cur = next_chunk(0);
+    enqueue_copy(cur, 0);
+    for (int j = 0;; j++) {
+        const int slot = j & 1;
+        Chunk nxt{0, 0, 0, 0};
+        const bool more = cur.r1 < n_records;
+        if (more) { nxt = next_chunk(cur.r1); enqueue_copy(nxt, slot ^ 1); }    // travels while this chunk is processed
+        SY_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[slot], 0));
+        const uint64_t n_rec = cur.r1 - cur.r0;
+        uint64_t* d_raw = sk->slot_off[slot].as<uint64_t>();
+        uint64_t* d_off = d_raw + (n_rec + 1);
+        hipLaunchKernelGGL(rebase_offsets_kernel, dim3(grid_for(n_rec + 1)), dim3(256), 0, ctx->stream, d_raw, n_rec + 1, d_off);
+        process_batch(sk, sk->slot_bases[slot].as<uint8_t>(), (uint32_t)(cur.b0 % bpb), d_off, n_rec, cur.b1 - cur.b0, enc);
+        // every kernel that reads this slot must be done before the copy after next overwrites it
+        SY_HIP(hipStreamSynchronize(ctx->stream));
+        if (!more) break;
+        cur = nxt;
+    }
+}
+
+static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, int mem,
+                             const uint64_t* n_bases_hint = nullptr, int enc = SYLPH_ENC_ASCII) {
+    sylph_ctx* ctx = sk->ctx;
+    SY_REQUIRE(!sk->finished, "sylph_sketch_push after finish");
+    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE || mem == SYLPH_MEM_HOST_PINNED, "bad mem kind %d", mem);
+    SY_REQUIRE(enc == SYLPH_ENC_ASCII || enc == SYLPH_ENC_2BIT, "bad encoding %d", enc);
+    SY_REQUIRE(!sk->paired || (n_records % 2 == 0), "paired batches must hold an even number of records");
+    if (n_records == 0) return;
+    SY_REQUIRE(rec_off, "null rec_off");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    HostPhase ph_total(ctx, "push: total");
+    if (mem != SYLPH_MEM_DEVICE) {
+        SY_REQUIRE(rec_off[0] == 0, "rec_off[0] must be 0");
+        SY_REQUIRE(bases || rec_off[n_records] == 0, "null bases");
+        SY_REQUIRE(!n_bases_hint || *n_bases_hint == rec_off[n_records], "n_bases does not match rec_off[n_records]");
+        push_host_batch(sk, bases, rec_off, n_records, mem, enc);
+        return;
+    }
+    uint64_t n_bases;
+    if (n_bases_hint) n_bases = *n_bases_hint;
+    else ctx->read_back(&n_bases, rec_off + n_records, 8);
+    SY_REQUIRE(bases || n_bases == 0, "null bases");
+    SY_REQUIRE(enc == SYLPH_ENC_ASCII || ((uintptr_t)bases & 3) == 0, "a packed device stream must be 4-byte aligned");
+    process_batch(sk, bases, 0, rec_off, n_records, n_bases, enc);
 }
 
 // Device-wide replay of dup_removal_lsh_full_exact over `n_all` occurrences (hash = sort key, INVALID_HASH entries ignored;
@@ -769,9 +864,40 @@ int sylph_sketch_push_n(sylph_sketch* sk, const uint8_t* bases, const uint64_t* 
                         int mem) {
     return guarded([&] {
         SY_REQUIRE(sk, "null session");
-        SY_REQUIRE(mem == SYLPH_MEM_DEVICE || !rec_off || n_records == 0 || rec_off[n_records] == n_bases,
-                   "n_bases does not match rec_off[n_records]");
         sketch_push_impl(sk, bases, rec_off, n_records, mem, &n_bases);
+    });
+}
+
+int sylph_sketch_push_enc(sylph_sketch* sk, const uint8_t* bases, const uint64_t* rec_off, uint64_t n_records, uint64_t n_bases, int mem,
+                          int enc) {
+    return guarded([&] {
+        SY_REQUIRE(sk, "null session");
+        sketch_push_impl(sk, bases, rec_off, n_records, mem, &n_bases, enc);
+    });
+}
+
+// BYTE_TO_SEQ (types.rs:50-59) + packing, on the host: what a feed does before a SYLPH_ENC_2BIT push.  out holds (n + 3) / 4
+// bytes; base i lands in bits 7-2(i%4) .. 6-2(i%4) of byte i/4.
+int sylph_pack_2bit(const uint8_t* ascii, uint64_t n, uint8_t* out) {
+    return guarded([&] {
+        SY_REQUIRE((ascii && out) || n == 0, "null argument");
+        static uint8_t lut[256];
+        static std::once_flag once;
+        std::call_once(once, [] {
+            memset(lut, 0, sizeof(lut));
+            lut[1] = 1; lut[2] = 2; lut[3] = 3;
+            const char* s4 = "AaCcGgTtUu";
+            const uint8_t v[10] = {0, 0, 1, 1, 2, 2, 3, 3, 3, 3};
+            for (int i = 0; i < 10; i++) lut[(uint8_t)s4[i]] = v[i];
+        });
+        uint64_t i = 0;
+        for (; i + 4 <= n; i += 4)
+            out[i >> 2] = (uint8_t)((lut[ascii[i]] << 6) | (lut[ascii[i + 1]] << 4) | (lut[ascii[i + 2]] << 2) | lut[ascii[i + 3]]);
+        if (i < n) {
+            uint8_t b = 0;
+            for (uint64_t j = i; j < n; j++) b |= (uint8_t)(lut[ascii[j]] << (6 - 2 * (j - i)));
+            out[i >> 2] = b;
+        }
     });
 }
 

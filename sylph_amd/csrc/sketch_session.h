@@ -25,11 +25,13 @@ struct sylph_sketch {
     uint64_t n_occ = 0;            // occurrences (valid + invalid) appended so far
     sylph::DevBuf hash;                   // hash of every occurrence, file order (sort key)
     sylph::DevBuf recs;                   // OccRec of every occurrence, file order
-    sylph::DevBuf batch_bases, batch_off; // H2D staging for SYLPH_MEM_HOST pushes
+    sylph::DevBuf slot_bases[2], slot_off[2];   // device slots of the host-batch pipeline (copy stream fills one, kernels read the other)
+    sylph::DevBuf batch_ascii;            // a packed batch expanded to ASCII for the position-kernel path
     sylph::DevBuf out_k, out_c;           // final table
     uint64_t n_out = 0, dup_removed = 0;
     sylph::DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
     explicit sylph_sketch(sylph_ctx* cx)
-        : ctx(cx), hash(cx), recs(cx), batch_bases(cx), batch_off(cx), out_k(cx), out_c(cx), counters(cx) {}
+        : ctx(cx), hash(cx), recs(cx), slot_bases{sylph::DevBuf(cx), sylph::DevBuf(cx)}, slot_off{sylph::DevBuf(cx), sylph::DevBuf(cx)},
+          batch_ascii(cx), out_k(cx), out_c(cx), counters(cx) {}
 };
 

@@ -202,6 +202,24 @@ struct GenomeBatch {
             pending.push_back(std::move(whole));
             goff.push_back(off.size() - 1);
         }
+        // one sylph_sketch_genomes call holds < 2^32 bases: a file that would push the batch over the limit starts a new batch,
+        // and a single genome beyond it is skipped with a warning instead of aborting the whole run
+        constexpr uint64_t LIMIT = (1ull << 32) - 4096;
+        if (bases.size() >= LIMIT) {
+            const std::vector<uint8_t> nb(bases.begin() + bases0, bases.end());
+            std::vector<uint64_t> noff(off.begin() + off0, off.end()), ngoff(goff.begin() + goff0, goff.end());
+            std::vector<GenomeSketch> npend(std::make_move_iterator(pending.begin() + pend0), std::make_move_iterator(pending.end()));
+            bases.resize(bases0); off.resize(off0); goff.resize(goff0); pending.resize(pend0);
+            flush();
+            if (nb.size() >= LIMIT) {
+                warn(ref_file + " holds " + std::to_string(nb.size()) + " bases, more than one device batch (2^32): skipping it");
+                return false;
+            }
+            for (uint64_t o : noff) off.push_back(o - bases0);
+            for (uint64_t g : ngoff) goff.push_back(g - (off0 - 1));
+            bases = nb;
+            pending = std::move(npend);
+        }
         if (bases.size() >= BATCH_BASES) flush();
         return true;
     }

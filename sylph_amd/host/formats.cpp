@@ -15,18 +15,46 @@ namespace sylph_host {
 
 namespace {
 
+// Streams to `path + ".tmp"` through a 4 MiB buffer, checks every write and the close, and renames into place: a full disk
+// or an I/O error can never leave a truncated database behind a success message (a GTDB-scale .syldb is 13 GB).
 struct Writer {
+    std::string path, tmp;
+    FILE* f = nullptr;
     std::vector<char> b;
-    void u8(uint8_t v) { b.push_back((char)v); }
+    explicit Writer(const std::string& p) : path(p), tmp(p + ".tmp") {
+        f = fopen(tmp.c_str(), "wb");
+        if (!f) throw Error{1, path + " path not valid; exiting."};
+        b.reserve(4u << 20);
+    }
+    ~Writer() { if (f) { fclose(f); (void)remove(tmp.c_str()); } }
+    Writer(const Writer&) = delete;
+    Writer& operator=(const Writer&) = delete;
+    void spill() {
+        if (!b.empty() && fwrite(b.data(), 1, b.size(), f) != b.size()) throw Error{1, "write error on " + path + " (disk full?)"};
+        b.clear();
+    }
+    void raw(const void* p, size_t n) {
+        if (n >= (1u << 20)) {                       // large arrays go straight out
+            spill();
+            if (fwrite(p, 1, n, f) != n) throw Error{1, "write error on " + path + " (disk full?)"};
+            return;
+        }
+        const char* c = (const char*)p;
+        b.insert(b.end(), c, c + n);
+        if (b.size() >= (4u << 20)) spill();
+    }
+    void u8(uint8_t v) { raw(&v, 1); }
     void u32(uint32_t v) { raw(&v, 4); }
     void u64(uint64_t v) { raw(&v, 8); }
     void f64(double v) { raw(&v, 8); }
-    void raw(const void* p, size_t n) { const char* c = (const char*)p; b.insert(b.end(), c, c + n); }
     void str(const std::string& s) { u64(s.size()); raw(s.data(), s.size()); }
-    void flush(const std::string& path) {
-        std::ofstream f(path, std::ios::binary);
-        if (!f) throw Error{1, path + " path not valid; exiting."};
-        f.write(b.data(), (std::streamsize)b.size());
+    void finish() {
+        spill();
+        const bool bad = fflush(f) != 0 || ferror(f);
+        const bool bad_close = fclose(f) != 0;
+        f = nullptr;
+        if (bad || bad_close) { (void)remove(tmp.c_str()); throw Error{1, "write error on " + path + " (disk full?)"}; }
+        if (rename(tmp.c_str(), path.c_str()) != 0) { (void)remove(tmp.c_str()); throw Error{1, "could not move " + tmp + " to " + path}; }
     }
 };
 
@@ -90,7 +118,7 @@ bool ends_with(const std::string& s, const char* suf) {
 // mean_read_length.  The reference writes the map in hashbrown iteration order; readers rebuild a map, so any order is
 // equivalent — we write ascending k-mer order.
 void write_sylsp(const std::string& path, const SequencesSketch& s) {
-    Writer w;
+    Writer w(path);
     w.u64(s.kmers.size());
     for (size_t i = 0; i < s.kmers.size(); i++) { w.u64(s.kmers[i]); w.u32(s.counts[i]); }
     w.u64(s.c);
@@ -99,7 +127,7 @@ void write_sylsp(const std::string& path, const SequencesSketch& s) {
     if (s.sample_name) { w.u8(1); w.str(*s.sample_name); } else w.u8(0);
     w.u8(s.paired ? 1 : 0);
     w.f64(s.mean_read_length);
-    w.flush(path);
+    w.finish();
 }
 
 SequencesSketch read_sylsp(const std::string& path) {
@@ -128,7 +156,7 @@ SequencesSketch read_sylsp(const std::string& path) {
 
 // types.rs:163-173 as Vec<GenomeSketch>
 void write_syldb(const std::string& path, const std::vector<GenomeSketch>& gs) {
-    Writer w;
+    Writer w(path);
     w.u64(gs.size());
     for (const GenomeSketch& g : gs) {
         w.u64(g.genome_kmers.size());
@@ -144,7 +172,7 @@ void write_syldb(const std::string& path, const std::vector<GenomeSketch>& gs) {
         w.str(g.first_contig_name);
         w.u64(g.c); w.u64(g.k); w.u64(g.gn_size); w.u64(g.min_spacing);
     }
-    w.flush(path);
+    w.finish();
 }
 
 std::vector<GenomeSketch> read_syldb(const std::string& path) {
@@ -180,6 +208,21 @@ FastxReader::FastxReader(const std::string& path) {
     gzbuffer((gzFile)gz_, 1 << 20);
     buf_.resize(1 << 20);
     buf_.clear();
+    // parse_fastx_file (needletail 0.5.1; call sites sketch.rs:488,557,780-781,906) fails up front on an empty file or on a
+    // first byte that is neither '>' nor '@': peek, so that callers take their "not a valid fasta/fastq file; skipping" branch
+    // instead of writing an empty sketch
+    buf_.resize(1 << 20);
+    const int n = gzread((gzFile)gz_, &buf_[0], 1 << 20);
+    if (n < 0) { gzclose((gzFile)gz_); gz_ = nullptr; throw Error{1, path + " is not a valid fasta/fastq file; skipping."}; }
+    buf_.resize((size_t)n);
+    if (n == 0) eof_ = true;
+    size_t q = 0;
+    while (q < buf_.size() && (buf_[q] == '\n' || buf_[q] == '\r')) q++;
+    if (q >= buf_.size() || (buf_[q] != '>' && buf_[q] != '@')) {
+        gzclose((gzFile)gz_);
+        gz_ = nullptr;
+        throw Error{1, path + " is not a valid fasta/fastq file; skipping."};
+    }
 }
 FastxReader::~FastxReader() { if (gz_) gzclose((gzFile)gz_); }
 
@@ -233,6 +276,7 @@ bool FastxReader::next_fastq_in_buffer(FastxRecord& rec) {
     auto trim = [&](int l) { const char* z = e[l]; if (z > b + start[l] && z[-1] == '\r') z--; return z; };
     const char* h_end = trim(0);
     const char* s_end = trim(1);
+    if (trim(3) - (b + start[3]) != s_end - (b + start[1])) return false;   // quality length != sequence length: slow path reports it
     rec.id.assign(b + start[0] + 1, h_end);
     rec.seq.assign(b + start[1], s_end);
     pos_ = p;
@@ -260,6 +304,7 @@ bool FastxReader::next(FastxRecord& rec) {
         std::string plus, qual;
         if (!getline(plus) || plus.empty() || plus[0] != '+') throw Error{1, "malformed fastq record"};
         if (!getline(qual) && !rec.seq.empty()) throw Error{1, "truncated fastq record"};
+        if (qual.size() != rec.seq.size()) throw Error{1, "fastq record with quality and sequence of different lengths"};   // needletail rejects it
         return true;
     }
     if (line[0] != '>') throw Error{1, "malformed fasta record"};

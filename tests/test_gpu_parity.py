@@ -733,6 +733,60 @@ def test_push_from_pinned_host_memory(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- multi-process
+def test_packed_input_and_chunked_host_pipeline(ctx):
+    """sylph_sketch_push_enc: SYLPH_ENC_2BIT input (host-packed with sylph_pack_2bit) must give the same sketch as the ASCII
+    bytes it was packed from, from pageable, page-locked and device memory; host batches are cut into chunks that travel on the
+    copy stream (push_chunk_bytes lowered so that a small batch has dozens of chunks, chunk starts at every phase inside a
+    packed byte, pairs never split); long records send a packed batch through the unpack + position-kernel path."""
+    import torch
+    from sylph_amd.binding import ENC_2BIT, ENC_ASCII, MEM_DEVICE, MEM_HOST, MEM_HOST_PINNED
+    rng = np.random.default_rng(55)
+    genome = random_seq(rng, 80000)
+    short_single = make_reads(rng, genome, 3000, 151, dup_frac=0.2, ragged=True)
+    for r in short_single[::17]:
+        if len(r) > 5:
+            r[int(rng.integers(0, len(r)))] = ord("N")
+    short_paired = make_reads(rng, genome, 2500, 150, paired=True, dup_frac=0.2, ragged=True)
+    with_long = short_single[:500] + [genome[1000:9000].copy(), genome[20000:20401].copy()] + short_single[500:900]
+    cases = [(short_single, False, 20), (short_paired, True, 20), (with_long, False, 50), ([], False, 20),
+             ([genome[:50].copy(), np.zeros(0, np.uint8), genome[100:131].copy()], False, 3)]
+    try:
+        for recs, paired, c in cases:
+            b, off = concat(recs)
+            e = O.sketch_reads(b, off, c=c, paired=paired)
+            packed = S.pack_2bit(b)
+            n_bases, n_rec = int(off[-1]), len(off) - 1
+            pin_a, pin_p, pin_o = S.PinnedBuffer(len(b) + 64), S.PinnedBuffer(len(packed) + 64), S.PinnedBuffer(len(off) * 8)
+            pin_a.array[:len(b)] = b
+            pin_p.array[:len(packed)] = packed
+            pin_o.array.view(np.uint64)[:len(off)] = off
+            dev_a = torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).cuda()
+            dev_p = torch.from_numpy(packed).cuda()
+            dev_o = torch.from_numpy(off.astype(np.int64)).cuda()
+            torch.cuda.synchronize()
+            for chunk in (str(64 << 20), "4099", "1000"):
+                ctx.set_option("push_chunk_bytes", chunk)
+                for enc, host, pin, dev in ((ENC_ASCII, b, pin_a, dev_a), (ENC_2BIT, packed, pin_p, dev_p)):
+                    for mem in (MEM_HOST, MEM_HOST_PINNED, MEM_DEVICE):
+                        if mem == MEM_DEVICE and chunk != "1000":
+                            continue
+                        sk = S.ReadSketcher(ctx, c=c, paired=paired)
+                        if n_rec:
+                            if mem == MEM_HOST:
+                                sk.push_enc(host, off, n_bases, mem, enc)
+                            elif mem == MEM_HOST_PINNED:
+                                sk.push_enc(pin.ptr, pin_o.ptr, n_bases, mem, enc, n_records=n_rec)
+                            else:
+                                sk.push_enc(dev.data_ptr(), dev_o.data_ptr(), n_bases, mem, enc, n_records=n_rec)
+                        g = sk.finish()
+                        sk.close()
+                        assert_same_sketch(g, e)
+            for p_ in (pin_a, pin_p, pin_o):
+                p_.close()
+    finally:
+        ctx.set_option("push_chunk_bytes", str(64 << 20))
+
+
 def test_sharded_containment_two_ranks_one_gpu():
     """Two ranks (gloo rendezvous, both on cuda:0) run the library's k-mer-range sharded exchange (csrc/shard.hip) with the
     collectives routed through torch.distributed callbacks, each with its own shard resident on the GPU, and check their own
