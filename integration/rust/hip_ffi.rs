@@ -4,6 +4,14 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct SylphCtx { _p: [u8; 0] }
 #[repr(C)] pub struct SylphSketch { _p: [u8; 0] }
 #[repr(C)] pub struct SylphDb { _p: [u8; 0] }
+#[repr(C)] pub struct SylphComm { _p: [u8; 0] }
+#[repr(C)] pub struct SylphSampleRef { pub kmers: *const u64, pub counts: *const u32, pub n: u64 }   // one sorted (k-mer, count) table
+#[repr(C)] pub struct SylphCommOps {   // caller-supplied collectives on device buffers (stream = hipStream_t); 0 = success
+    pub all_gather: extern "C" fn(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes: u64, stream: *mut c_void) -> c_int,
+    pub all_to_all: extern "C" fn(user: *mut c_void, send: *const c_void, send_off: *const u64, recv: *mut c_void,
+                                  recv_off: *const u64, stream: *mut c_void) -> c_int,
+}
+pub const ENC_ASCII: c_int = 0; pub const ENC_2BIT: c_int = 1;
 pub const SEED_AVX2_COMPAT: c_int = 1;   // what extract_markers does on every AVX2 host (sketch.rs:53-63)
 pub const READS_SINGLE: c_int = 0; pub const READS_PAIRED: c_int = 1;
 pub const MEM_HOST: c_int = 0;
@@ -71,5 +79,28 @@ extern "C" {
                                  out_n: *mut u64) -> c_int;
     pub fn sylph_ctx_profile(ctx: *mut SylphCtx, enable: c_int) -> c_int;
     pub fn sylph_ctx_kernel_stats(ctx: *mut SylphCtx, family: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    // ---- round 2: batched containment, packed input, one database over several GPUs ----
+    pub fn sylph_db_index_bytes(db: *const SylphDb) -> u64;
+    // the sample-chunk x genome loop of contain.rs:267-289 for S samples in one call (row = s * n_genomes + g)
+    pub fn sylph_db_contain_batch(db: *mut SylphDb, samples: *const SylphSampleRef, n_samples: u32, mem: c_int,
+                                  min_number_kmers: f64, contain_count: *mut *const u32, cov_off: *mut *const u64,
+                                  covs: *mut *const c_void, cov_width: *mut u32, out_n_covs: *mut u64) -> c_int;
+    // sketch_sequences_needle / sketch_pair_sequences batches with the encoding stated (ENC_2BIT: 4 bases per byte, a quarter
+    // of the PCIe bytes); sylph_pack_2bit = BYTE_TO_SEQ (types.rs:50-59) + packing on the host
+    pub fn sylph_sketch_push_enc(sk: *mut SylphSketch, bases: *const u8, rec_off: *const u64, n_records: u64, n_bases: u64,
+                                 mem: c_int, enc: c_int) -> c_int;
+    pub fn sylph_pack_2bit(ascii: *const u8, n: u64, out: *mut u8) -> c_int;
+    // k-mer-range shards: bounds for `world` GPUs, upload of this rank's range, communicator, the collective batch call
+    pub fn sylph_shard_bounds(max_kmer: u64, world: u32, bounds: *mut u64) -> c_int;
+    pub fn sylph_db_upload_shard(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,
+                                 bounds: *const u64, world: u32, rank: u32, out: *mut *mut SylphDb) -> c_int;
+    pub fn sylph_comm_rccl_unique_id(id: *mut u8) -> c_int;                       // 128 bytes, made on rank 0
+    pub fn sylph_comm_create_rccl(ctx: *mut SylphCtx, rank: u32, world: u32, id: *const u8, out: *mut *mut SylphComm) -> c_int;
+    pub fn sylph_comm_create(rank: u32, world: u32, ops: *const SylphCommOps, user: *mut c_void, out: *mut *mut SylphComm) -> c_int;
+    pub fn sylph_comm_destroy(comm: *mut SylphComm);
+    pub fn sylph_db_contain_batch_sharded(db: *mut SylphDb, comm: *mut SylphComm, samples: *const SylphSampleRef, n_local: u32,
+                                          mem: c_int, min_number_kmers: f64, contain_count: *mut *const u32,
+                                          cov_off: *mut *const u64, covs: *mut *const c_void, cov_width: *mut u32,
+                                          out_n_covs: *mut u64) -> c_int;
     pub fn sylph_db_destroy(db: *mut SylphDb);
 }

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -93,9 +94,61 @@ struct Session {   // RAII
 Engine::Engine(int dev) : device(dev) { hip_check(sylph_ctx_create(dev, nullptr, &ctx), "sylph_ctx_create"); }
 Engine::~Engine() { sylph_ctx_destroy(ctx); }
 
+namespace {
+// prefix sums of the sequence lengths of an indexed file: cum[i] = bases of records [0, i)
+std::vector<uint64_t> cumulative(const FastqIndex& ix) {
+    std::vector<uint64_t> c(ix.n_records() + 1, 0);
+    for (size_t i = 0; i < ix.n_records(); i++) c[i + 1] = c[i] + ix.seq_len[i];
+    return c;
+}
+// Uncompressed 4-line FASTQ (the common case): the files are indexed by parse_threads() workers, whole batches are gathered
+// into page-locked memory in parallel and pushed; the record loop of the reference shrinks to its one sequential piece, the
+// running mean of the read lengths (f64, file order: sketch.rs:941-943, :825-826).  Returns false — nothing pushed — when
+// a file is not that simple, and the caller runs the sequential reader with needletail's exact record/error semantics.
+bool sketch_indexed(Engine& e, sylph_sketch* sk, const std::string& f1, const std::string* f2, double& mean_read_length) {
+    if (getenv("SYLPH_HIP_SEQUENTIAL_FEED")) return false;
+    const unsigned T = parse_threads();
+    FastqIndex a(f1, T);
+    if (!a.ok) return false;
+    std::unique_ptr<FastqIndex> b;
+    if (f2) { b.reset(new FastqIndex(*f2, T)); if (!b->ok) return false; }
+    const size_t n = b ? std::min(a.n_records(), b->n_records()) : a.n_records();   // lock-step readers: sketch.rs:813-815
+    const std::vector<uint64_t> ca = cumulative(a), cb = b ? cumulative(*b) : std::vector<uint64_t>();
+    e.batch.flush(sk);
+    size_t i0 = 0;
+    while (i0 < n) {
+        // largest i1 with at most BATCH_BASES bases and BATCH_RECS records in [i0, i1)
+        size_t lo = i0 + 1, hi = std::min(n, i0 + PinnedBatch::BATCH_RECS / (b ? 2 : 1));
+        auto bases_upto = [&](size_t i) { return ca[i] - ca[i0] + (b ? cb[i] - cb[i0] : 0); };
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo + 1) / 2;
+            if (bases_upto(mid) <= PinnedBatch::BATCH_BASES) lo = mid; else hi = mid - 1;
+        }
+        e.batch.push_indexed(sk, a, b.get(), ca, b ? &cb : nullptr, i0, lo, T);
+        i0 = lo;
+    }
+    double mean = 0., counter = 0.;
+    for (size_t i = 0; i < n; i++) { counter += 1.; mean = mean + ((double)a.seq_len[i] - mean) / counter; }
+    mean_read_length = mean;
+    return true;
+}
+}  // namespace
+
 // sketch.rs:897-959
 std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
                                                        std::optional<std::string> sample_name, bool no_dedup) {
+    {
+        Session s(e, c, k, false, no_dedup);
+        double mean = 0.;
+        if (sketch_indexed(e, s.sk, read_file, nullptr, mean)) {
+            SequencesSketch out;
+            s.finish(out);
+            out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
+            out.sample_name = std::move(sample_name);
+            out.mean_read_length = mean;
+            return out;
+        }
+    }
     std::unique_ptr<ChunkStream> reader;
     try { reader.reset(new ChunkStream(read_file)); }
     catch (const Error&) { warn(read_file + " is not a valid fasta/fastq file; skipping."); return std::nullopt; }   // :911-914
@@ -125,6 +178,18 @@ std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::str
 std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                      uint64_t c, uint64_t k, std::optional<std::string> sample_name,
                                                      bool no_dedup, double /*dedup_fpr*/) {
+    {
+        Session s(e, c, k, true, no_dedup);
+        double mean = 0.;
+        if (sketch_indexed(e, s.sk, read_file1, &read_file2, mean)) {
+            SequencesSketch out;
+            s.finish(out);
+            out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;
+            out.sample_name = std::move(sample_name);
+            out.mean_read_length = mean;
+            return out;
+        }
+    }
     std::unique_ptr<ChunkStream> r1, r2;   // the two mate files are parsed/inflated concurrently by their reader threads
     try { r1.reset(new ChunkStream(read_file1)); r2.reset(new ChunkStream(read_file2)); }
     catch (const Error&) {
@@ -308,6 +373,16 @@ int sketch(Engine& e, const SketchArgs& args) {
     create_dir_all(args.sample_output_dir);
     const size_t n_jobs = first_pairs.size() + read_inputs.size();
     auto run_job = [&](Engine& eng, size_t j) {
+        const auto t_job = std::chrono::steady_clock::now();
+        auto timing = [&](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_job).count();
+            uint64_t occ = 0;
+            for (uint32_t c : sk.counts) occ += c;
+            char b[256];
+            snprintf(b, sizeof(b), "timing: %s sketched + written in %.3f s (%zu distinct k-mers, %llu counted occurrences)", what.c_str(), sec,
+                     sk.kmers.size(), (unsigned long long)occ);
+            info(b);
+        };
         if (j < first_pairs.size()) {                                        // :311-367
             std::optional<std::string> sample_name;
             if (sample_names) sample_name = (*sample_names)[j];
@@ -317,6 +392,7 @@ int sketch(Engine& e, const SketchArgs& args) {
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
             write_sylsp(path, *sk);
             info("Sketching " + path + " complete.");
+            timing(*sk, first_pairs[j]);
         } else {                                                             // :369-420
             const size_t i = j - first_pairs.size();
             std::optional<std::string> sample_name;
@@ -327,6 +403,7 @@ int sketch(Engine& e, const SketchArgs& args) {
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + SAMPLE_FILE_SUFFIX;
             write_sylsp(path, *sk);
             info("Sketching " + path + " complete.");
+            timing(*sk, read_inputs[i]);
         }
     };
     const size_t n_workers = std::max<size_t>(1, std::min<size_t>(args.threads, n_jobs));

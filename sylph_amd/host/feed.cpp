@@ -3,6 +3,11 @@
 // (interleaving the mates of a pair) and pushes it with SYLPH_MEM_HOST_PINNED.  Parsing therefore overlaps with the H2D copy
 // and the GPU work of the previous batch, the two mate files are read concurrently, and the library needs no staging memcpy.
 // Record semantics are those of FastxReader (needletail 0.5.1: seq() without newlines, errors per record).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -148,6 +153,140 @@ void PinnedBatch::add(sylph_sketch* sk, const uint8_t* a, uint32_t la, const uin
         n_bases_ += lb;
         off_[++n_recs_] = n_bases_;
     }
+}
+
+// ---- block-parallel FASTQ indexing -------------------------------------------------------------------
+unsigned parse_threads() {
+    static const unsigned n = [] {
+        if (const char* e = getenv("SYLPH_HIP_PARSE_THREADS")) return (unsigned)std::max(1, atoi(e));
+        return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }();
+    return n;
+}
+
+namespace {
+template <class F>
+void run_workers(unsigned n, F&& f) {
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < n; w++) th.emplace_back([&f, w] { f(w); });
+    f(0u);
+    for (auto& t : th) t.join();
+}
+inline size_t next_line(const uint8_t* d, size_t n, size_t p) {   // start of the line after the one containing p (n if none)
+    const void* nl = p < n ? memchr(d + p, '\n', n - p) : nullptr;
+    return nl ? (size_t)((const uint8_t*)nl - d) + 1 : n;
+}
+}  // namespace
+
+FastqIndex::~FastqIndex() { if (data) munmap((void*)data, size); }
+
+FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 4 || !S_ISREG(st.st_mode)) { close(fd); return; }
+    size = (size_t)st.st_size;
+    void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { data = nullptr; return; }
+    data = (const uint8_t*)m;
+    (void)madvise(m, size, MADV_WILLNEED);
+    const uint8_t* d = data;
+    const size_t n = size;
+    if (d[0] != '@' || (d[0] == 0x1f && d[1] == 0x8b)) return;   // not plain FASTQ: sequential reader
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / (1u << 20)));
+    // a record starts at a line that begins with '@' and whose line after next begins with '+' (a QUALITY line may begin
+    // with '@' too, but then the line after next is a sequence line)
+    std::vector<size_t> starts(T + 1, n);
+    starts[0] = 0;
+    run_workers(T, [&](unsigned w) {
+        if (w == 0) return;
+        size_t p = next_line(d, n, n / T * w);
+        while (p < n) {
+            if (d[p] == '@') {
+                const size_t l2 = next_line(d, n, next_line(d, n, p));
+                if (l2 < n && d[l2] == '+') break;
+            }
+            p = next_line(d, n, p);
+        }
+        starts[w] = p;
+    });
+    for (unsigned w = 0; w < T; w++) if (starts[w] > starts[w + 1]) return;   // (cannot happen for a regular file)
+    std::vector<std::vector<uint64_t>> offs(T);
+    std::vector<std::vector<uint32_t>> lens(T);
+    std::vector<char> good(T, 1);
+    run_workers(T, [&](unsigned w) {
+        size_t p = starts[w];
+        const size_t end = starts[w + 1];
+        auto& o = offs[w];
+        auto& l = lens[w];
+        o.reserve((end - p) / 300 + 16);
+        l.reserve((end - p) / 300 + 16);
+        while (p < end) {
+            if (d[p] != '@') {                                     // only blank space may follow the last record
+                for (size_t q = p; q < n; q++) if (d[q] != '\n' && d[q] != '\r') { good[w] = 0; return; }
+                if (end != n) { good[w] = 0; return; }
+                p = end;
+                break;
+            }
+            const size_t s = next_line(d, n, p);
+            if (s >= n) { good[w] = 0; return; }
+            const size_t pl = next_line(d, n, s);
+            if (pl >= n || d[pl] != '+') { good[w] = 0; return; }
+            if (d[pl - 1] != '\n') { good[w] = 0; return; }        // (pl < n: the sequence line was terminated)
+            const size_t q = next_line(d, n, pl);                  // quality line [q, nx): may be the unterminated last line
+            if (q == n && d[n - 1] != '\n') { good[w] = 0; return; }   // the '+' line is the last, unterminated line: no quality
+            const size_t nx = next_line(d, n, q);
+            size_t sl = pl - 1 - s, ql = nx > q ? ((d[nx - 1] == '\n') ? nx - 1 - q : nx - q) : 0;
+            if (sl && d[s + sl - 1] == '\r') sl--;
+            if (ql && d[q + ql - 1] == '\r') ql--;
+            if (sl != ql || sl > 0xFFFFFFFEu) { good[w] = 0; return; }
+            o.push_back(s);
+            l.push_back((uint32_t)sl);
+            p = nx;
+        }
+        if (p != end && !(end == n && p >= n)) good[w] = 0;        // the next range must begin exactly where this one ended
+    });
+    for (unsigned w = 0; w < T; w++) if (!good[w]) return;
+    std::vector<size_t> pre(T + 1, 0);
+    for (unsigned w = 0; w < T; w++) pre[w + 1] = pre[w] + lens[w].size();
+    seq_off.resize(pre[T]);
+    seq_len.resize(pre[T]);
+    run_workers(T, [&](unsigned w) {
+        if (!lens[w].empty()) {
+            memcpy(seq_off.data() + pre[w], offs[w].data(), offs[w].size() * 8);
+            memcpy(seq_len.data() + pre[w], lens[w].data(), lens[w].size() * 4);
+        }
+    });
+    ok = true;
+}
+
+void PinnedBatch::push_indexed(sylph_sketch* sk, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
+                               const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads) {
+    if (i1 <= i0) return;
+    const size_t n_items = i1 - i0, nrec = b ? 2 * n_items : n_items;
+    const uint64_t base0 = cum_a[i0] + (b ? (*cum_b)[i0] : 0);
+    const uint64_t total = cum_a[i1] + (b ? (*cum_b)[i1] : 0) - base0;
+    reserve(std::max<size_t>(total + 64, cap_bases_), std::max<size_t>(nrec, cap_recs_));
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n_items / 4096 + 1));
+    off_[0] = 0;
+    run_workers(T, [&](unsigned w) {
+        const size_t j0 = i0 + n_items * w / T, j1 = i0 + n_items * (w + 1) / T;
+        for (size_t i = j0; i < j1; i++) {
+            uint64_t o = cum_a[i] + (b ? (*cum_b)[i] : 0) - base0;
+            memcpy(bases_ + o, a.data + a.seq_off[i], a.seq_len[i]);
+            o += a.seq_len[i];
+            const size_t r = (b ? 2 * (i - i0) : (i - i0)) + 1;
+            off_[r] = o;
+            if (b) {
+                memcpy(bases_ + o, b->data + b->seq_off[i], b->seq_len[i]);
+                off_[r + 1] = o + b->seq_len[i];
+            }
+        }
+    });
+    n_recs_ = nrec;
+    n_bases_ = total;
+    flush(sk);
 }
 
 }  // namespace sylph_host

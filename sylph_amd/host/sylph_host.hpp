@@ -90,6 +90,25 @@ class ChunkStream {
     struct Impl;
     std::unique_ptr<Impl> p_;
 };
+// Block-parallel index of an UNCOMPRESSED, strictly 4-line FASTQ file (feed.cpp): the file is mapped, cut into byte ranges, and
+// one thread per range finds its first record boundary and records where every sequence lies.  `ok` is false when the file is
+// anything else (gzip, FASTA, blank lines, multi-line records, a quality line of the wrong length, ...): the caller then falls
+// back to the sequential reader, which reproduces needletail's record/error semantics exactly.
+struct FastqIndex {
+    bool ok = false;
+    const uint8_t* data = nullptr;   // the mapping (owned)
+    size_t size = 0;
+    std::vector<uint64_t> seq_off;   // byte offset of every record's sequence line
+    std::vector<uint32_t> seq_len;
+    FastqIndex() = default;
+    FastqIndex(const std::string& path, unsigned threads);
+    ~FastqIndex();
+    FastqIndex(const FastqIndex&) = delete;
+    FastqIndex& operator=(const FastqIndex&) = delete;
+    size_t n_records() const { return seq_len.size(); }
+};
+unsigned parse_threads();   // worker threads of the parallel feed: SYLPH_HIP_PARSE_THREADS, else min(16, hardware threads)
+
 class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinned_alloc), pushed with SYLPH_MEM_HOST_PINNED
    public:
     static constexpr size_t BATCH_BASES = 256u << 20, BATCH_RECS = 4u << 20;
@@ -98,6 +117,10 @@ class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinne
     // appends one record (pair = false) or the two mates of a pair, flushing to the session first when the batch is full
     void add(sylph_sketch* sk, const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb, bool pair);
     void flush(sylph_sketch* sk);
+    // records [i0, i1) of an indexed file (single-end), or pairs [i0, i1) of two indexed files interleaved mate 1, mate 2,
+    // copied into the batch by `threads` workers and pushed; the batch must be empty (flush() first)
+    void push_indexed(sylph_sketch* sk, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
+                      const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads);
    private:
     void reserve(size_t bases_cap, size_t recs_cap);
     uint8_t* bases_ = nullptr;

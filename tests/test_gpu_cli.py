@@ -348,3 +348,19 @@ def test_paired_default_fpr_warns_about_exact_semantics(data):
     assert "EXACT marker set" in p.stderr and "--fpr 0" in p.stderr
     q = run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w2", "--fpr", "0")
     assert "EXACT marker set" not in q.stderr
+
+
+def test_parallel_feed_equals_sequential_feed(data):
+    """Uncompressed FASTQ goes through the block-parallel index (feed.cpp FastqIndex: files cut into byte ranges, batches gathered
+    into page-locked memory by worker threads); SYLPH_HIP_SEQUENTIAL_FEED=1 forces the reader-thread path.  The sketches must be
+    byte-identical, for single-end and paired input and for every thread count."""
+    d = data["dir"]
+    outs = []
+    for env in ({"SYLPH_HIP_SEQUENTIAL_FEED": "1"}, {"SYLPH_HIP_PARSE_THREADS": "1"}, {"SYLPH_HIP_PARSE_THREADS": "7"}):
+        o = d / ("feed_" + "_".join(env.values()))
+        p = subprocess.run([BIN, "sketch", "-1", str(d / "s_1.fq"), "-2", str(d / "s_2.fq"), "-r", str(d / "s_1.fq"), "--fpr", "0", "-d", str(o)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(((o / "s_1.fq.paired.sylsp").read_bytes(), (o / "s_1.fq.sylsp").read_bytes()))
+    assert outs[0] == outs[1] == outs[2]
+    assert len(outs[0][0]) > 1000

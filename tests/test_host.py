@@ -268,7 +268,7 @@ def test_fastx_reader_and_threaded_feed_agree(host, tmp_path):
     fq = b"".join(b"@r%d some text\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs))
     fa = b"".join(b">c%d\n" % i + b"".join(s[j:j + 60] + b"\n" for j in range(0, len(s), 60)) for i, s in enumerate(seqs))
     cases = {"a.fq": fq, "b.fastq": fq.replace(b"\n", b"\r\n"), "c.fa": fa, "d.fasta": b"\n\n" + fa.replace(b"\n>", b"\n\n>"),
-             "e.fq": b"", "f.fa": b">only header\n"}
+             "f.fa": b">only header\n"}
     for name, text in cases.items():
         for gz in (False, True):
             path = tmp_path / (name + (".gz" if gz else ""))
@@ -293,3 +293,64 @@ def test_fastx_reader_and_threaded_feed_agree(host, tmp_path):
     assert got[0] == got[1] and got[0][1] >= 1
     v = [C.c_uint64(0) for _ in range(4)]
     assert host.sylph_host_fastx_digest(str(tmp_path / "missing.fq").encode(), 0, *[C.byref(x) for x in v]) == -1
+    # parse_fastx_file fails up front on an empty file and on a first byte that is neither '>' nor '@' (callers then warn and
+    # skip, sketch.rs:911-914, instead of writing an empty sketch); a quality line of the wrong length is a malformed record
+    for name, text in (("empty.fq", b""), ("blank.fq", b"\n\n"), ("text.fq", b"hello\n@r\nACGT\n+\nIIII\n")):
+        for gz in (False, True):
+            path = tmp_path / (name + (".gz" if gz else ""))
+            path.write_bytes(gzip.compress(text, 1) if gz else text)
+            for threaded in (0, 1):
+                assert host.sylph_host_fastx_digest(str(path).encode(), threaded, *[C.byref(x) for x in v]) == -1, (name, gz, threaded)
+    short_q = tmp_path / "shortq.fq"
+    short_q.write_bytes(b"@a\nACGTACGT\n+\nIIIIIIII\n@b\nACGTACGT\n+\nIIII\n@c\nACGT\n+\nIIII\n")
+    for threaded in (0, 1):
+        assert host.sylph_host_fastx_digest(str(short_q).encode(), threaded, *[C.byref(x) for x in v]) == 0
+        assert v[0].value >= 1 and v[1].value >= 1          # record a parsed, record b reported as an error
+
+
+def test_block_parallel_fastq_index_matches_the_sequential_reader(host, tmp_path):
+    """feed.cpp FastqIndex: an uncompressed 4-line FASTQ cut into byte ranges and indexed by several threads must yield exactly
+    the records of the sequential reader (same FNV digest over sequences and lengths) — with quality lines that start with
+    '@' (the classic boundary trap), CRLF, a missing final newline, trailing blank lines, empty sequences — and must DECLINE
+    (ok = 0, so that the drivers fall back to the sequential reader's needletail semantics) on anything irregular."""
+    host.sylph_host_fastx_digest.argtypes = [C.c_char_p, C.c_int] + [C.POINTER(C.c_uint64)] * 4
+    host.sylph_host_fastq_index_digest.argtypes = [C.c_char_p, C.c_uint, C.POINTER(C.c_int)] + [C.POINTER(C.c_uint64)] * 3
+    rng = np.random.default_rng(8)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=int(n))) for n in rng.integers(0, 300, size=40000)]
+
+    def qual(s, i):
+        q = bytearray(rng.integers(33, 74, size=len(s), dtype=np.uint8).tobytes())
+        if q and i % 3 == 0:
+            q[0] = ord("@")                     # quality lines beginning with '@'
+        if len(q) > 1 and i % 5 == 0:
+            q[0] = ord("+")
+        return bytes(q)
+    fq = b"".join(b"@r%d/1 x\n%s\n+\n%s\n" % (i, s, qual(s, i)) for i, s in enumerate(seqs))
+    assert len(fq) > 6 << 20                    # several 1 MiB ranges per thread
+    good = {"lf.fq": fq, "crlf.fq": fq.replace(b"\n", b"\r\n"), "noeol.fq": fq[:-1], "blank_tail.fq": fq + b"\n\r\n\n",
+            "plus_comment.fq": fq.replace(b"\n+\n", b"\n+comment\n"), "tiny.fq": b"@a\nACGT\n+\nIIII\n", "one_empty.fq": b"@a\n\n+\n\n"}
+    for name, text in good.items():
+        path = tmp_path / name
+        path.write_bytes(text)
+        v = [C.c_uint64(0) for _ in range(4)]
+        assert host.sylph_host_fastx_digest(str(path).encode(), 0, *[C.byref(x) for x in v]) == 0
+        assert v[1].value == 0
+        for threads in (1, 3, 16):
+            ok = C.c_int(0)
+            w = [C.c_uint64(0) for _ in range(3)]
+            assert host.sylph_host_fastq_index_digest(str(path).encode(), threads, C.byref(ok), *[C.byref(x) for x in w]) == 0
+            assert ok.value == 1, (name, threads)
+            assert (w[0].value, w[1].value, w[2].value) == (v[0].value, v[2].value, v[3].value), (name, threads)
+    import gzip
+    cut = fq.index(b"\n@r20000/1")
+    bad = {"blank_inside.fq": fq[:cut] + b"\n" + fq[cut:], "short_qual.fq": fq[:cut - 1] + fq[cut:], "fasta.fa": b">a\nACGT\n" * 10,
+           "gz.fq.gz": gzip.compress(fq[:100000], 1), "multiline.fq": b"@a\nACGT\nACGT\n+\nIIII\nIIII\n" * 5, "trunc.fq": fq[:cut + 30],
+           "empty.fq": b"", "noplus.fq": b"@a\nACGT\n-\nIIII\n"}
+    for name, text in bad.items():
+        path = tmp_path / name
+        path.write_bytes(text)
+        for threads in (1, 4):
+            ok = C.c_int(1)
+            w = [C.c_uint64(0) for _ in range(3)]
+            assert host.sylph_host_fastq_index_digest(str(path).encode(), threads, C.byref(ok), *[C.byref(x) for x in w]) == 0
+            assert ok.value == 0, (name, threads)
