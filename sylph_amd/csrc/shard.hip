@@ -9,11 +9,16 @@
 //   1. all-gather of the slice boundaries                                  (a few KB, fixed-size block per rank)
 //   2. all-to-all of the table slices                                      (each rank receives 1/world of every table)
 //   3. one probe launch over all received slices against the resident shard
-//   4. ONE all-gather of the per-shard hit lists                           (fixed layout: [n_hits | max count | hits x cap])
-//   5. every rank keeps the hits of its own samples, sorts them and assembles counts + coverage vectors (contain.hip).
-// xGMI is point-to-point: the all-to-all moves 1/world of the bytes an all-gather of whole tables would move over each
-// link, and the payloads of steps 1 and 4 are small enough to be latency-bound.  All buffers stay on the device; the host
-// only reads the sizes.
+//   4. the hits are grouped by the rank that owns their sample; all-gather of the group sizes (W + 1 words per rank)
+//   5. all-to-all of the hit groups: every rank receives exactly the hits of ITS samples, from every shard
+//   6. every rank sorts its hits and assembles counts + coverage vectors (contain.hip, as for an unsharded batch): partial
+//      counts of a genome from different shards simply add up, because a k-mer lives on exactly one shard.
+// xGMI is point-to-point (7 links per GPU): an all-to-all puts 1/world of the payload on each link at the same time, whereas
+// an all-gather of whole tables / whole hit lists would deliver world x the bytes anybody needs (at GTDB scale a step of
+// 64 samples produces ~0.9 GB of hits; each rank needs its 1/8).  The two all-gathers carry a few KB: latency-bound.
+// north_star words the reduction as "a single RCCL all-gather" of containment counts; that fits per-genome count vectors of a
+// genome-sharded database, whose probe work grows with the number of GPUs — the reason for sharding by k-mer range instead.
+// All buffers stay on the device; the host only reads the sizes.
 //
 // The collectives come from a sylph_comm: RCCL (resolved with dlopen at run time, so that the library neither links against a
 // second copy of librccl next to the one PyTorch may already have mapped, nor needs RCCL at all on a single GPU), or callbacks
@@ -145,36 +150,45 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const Seg* __restric
     for (uint64_t i = (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < sg.words; i += (uint64_t)gridDim.y * blockDim.x) sg.dst[i] = sg.src[i];
 }
 
-// keeps the hits whose row belongs to samples [s0, s0 + ns) of this rank, re-based to local rows; the gathered buffer holds
-// `world` blocks of [n_hits u64 | max u64 | hits x cap]
-__global__ __launch_bounds__(256) void take_hits_kernel(const uint64_t* __restrict__ gathered, uint32_t world, uint64_t block_words, uint64_t cap,
-                                                        uint64_t n_genomes, uint64_t s0, uint64_t ns, uint64_t* __restrict__ out,
-                                                        uint32_t* __restrict__ counter) {
-    __shared__ uint32_t s_cnt, s_base, s_max;
-    const uint64_t row_lo = s0 * n_genomes, row_hi = (s0 + ns) * n_genomes;
-    for (uint32_t r = 0; r < world; r++) {
-        const uint64_t* blk = gathered + (uint64_t)r * block_words;
-        const uint64_t n = min(blk[0], cap);
-        const uint64_t* h = blk + 2;
-        for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
-            if (threadIdx.x == 0) { s_cnt = 0; s_max = 0; }
-            __syncthreads();
-            const uint64_t i = base + threadIdx.x;
-            uint64_t hit = 0;
-            bool mine = false;
-            uint32_t slot = 0;
-            if (i < n) {
-                hit = h[i];
-                const uint64_t row = hit >> 32;
-                mine = row >= row_lo && row < row_hi;
-                if (mine) { slot = atomicAdd(&s_cnt, 1u); atomicMax(&s_max, (uint32_t)hit); hit = ((row - row_lo) << 32) | (uint32_t)hit; }
-            }
-            __syncthreads();
-            if (threadIdx.x == 0 && s_cnt) { s_base = atomicAdd(counter, s_cnt); atomicMax(counter + 1, s_max); }
-            __syncthreads();
-            if (mine) out[s_base + slot] = hit;
-            __syncthreads();
-        }
+// owner of a hit = the rank whose samples include row / n_genomes (prefix[r] <= sample < prefix[r + 1])
+__device__ __forceinline__ uint32_t owner_of(uint64_t hit, uint64_t n_genomes, const uint64_t* __restrict__ prefix, uint32_t world) {
+    const uint64_t s = (hit >> 32) / n_genomes;
+    uint32_t lo = 0, hi = world;                         // largest r with prefix[r] <= s
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (prefix[mid] <= s) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+constexpr uint32_t MAX_WORLD = 64;
+// counts[r] = hits owned by rank r (LDS histogram per workgroup, one global atomic per bin and workgroup)
+__global__ __launch_bounds__(256) void owner_count_kernel(const uint64_t* __restrict__ hits, uint32_t n, uint64_t n_genomes,
+                                                          const uint64_t* __restrict__ prefix, uint32_t world, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t bins[MAX_WORLD];
+    if (threadIdx.x < MAX_WORLD) bins[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        atomicAdd(&bins[owner_of(hits[i], n_genomes, prefix, world)], 1u);
+    __syncthreads();
+    if (threadIdx.x < world && bins[threadIdx.x]) atomicAdd(&counts[threadIdx.x], bins[threadIdx.x]);
+}
+// out[start[r] + k] = k-th hit of owner r (any order inside a group: the owner sorts), rows re-based to the owner's samples
+__global__ __launch_bounds__(256) void owner_scatter_kernel(const uint64_t* __restrict__ hits, uint32_t n, uint64_t n_genomes,
+                                                            const uint64_t* __restrict__ prefix, uint32_t world, const uint32_t* __restrict__ start,
+                                                            uint32_t* __restrict__ cursor, uint64_t* __restrict__ out) {
+    __shared__ uint32_t bins[MAX_WORLD], base[MAX_WORLD];
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        if (threadIdx.x < MAX_WORLD) bins[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t r = 0, slot = 0;
+        uint64_t h = 0;
+        if (i < n) { h = hits[i]; r = owner_of(h, n_genomes, prefix, world); slot = atomicAdd(&bins[r], 1u); }
+        __syncthreads();
+        if (threadIdx.x < world && bins[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], bins[threadIdx.x]);
+        __syncthreads();
+        if (i < n) out[start[r] + base[r] + slot] = h - ((prefix[r] * n_genomes) << 32);
+        __syncthreads();
     }
 }
 
@@ -363,50 +377,52 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         uint32_t max_count = 0, n_hits = 0;
         if (S_total) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
 
-        // ---- 4. ONE all-gather of the hit lists: block = [n_hits | max count | hits x cap]; cap is the same on every rank and
-        //         doubles (on every rank, from the same gathered headers) until no shard overflows
-        uint32_t n_mine = 0, max_mine = 0;
-        for (;;) {
-            const uint64_t cap = db->shard_hit_cap, block_words = 2 + cap;
-            db->x_send.reserve(block_words * 8);
-            db->x_recv.reserve((size_t)W * block_words * 8);
-            const uint64_t hdr[2] = {n_hits, max_count};
-            ctx->h2d(db->x_send.p, hdr, 16);
-            const uint64_t n_copy = std::min<uint64_t>(n_hits, cap);
-            if (n_copy) SY_HIP(hipMemcpyAsync(db->x_send.as<char>() + 16, db->hits.p, n_copy * 8, hipMemcpyDeviceToDevice, st));
-            {
-                ScopedKernelTimer t(ctx, "exchange");
-                comm->all_gather(db->x_send.p, db->x_recv.p, block_words * 8, st);
-            }
-            std::vector<uint64_t> hdrs((size_t)W * 2);
-            for (uint32_t r = 0; r < W; r++)
-                SY_HIP(hipMemcpyAsync((char*)ctx->pinned + r * 16, db->x_recv.as<char>() + (size_t)r * block_words * 8, 16, hipMemcpyDeviceToHost, st));
-            SY_HIP(hipStreamSynchronize(st));
-            memcpy(hdrs.data(), ctx->pinned, (size_t)W * 16);
-            uint64_t worst = 0, sum = 0;
-            for (uint32_t r = 0; r < W; r++) { worst = std::max(worst, hdrs[2 * r]); sum += std::min(hdrs[2 * r], cap); }
-            if (worst > cap) {                       // some shard's list was cut: every rank sees it and grows alike
-                uint64_t c2 = cap;
-                while (c2 < worst) c2 *= 2;
-                db->shard_hit_cap = c2;
-                continue;
-            }
-            // ---- 5. keep the hits of this rank's samples
-            SY_REQUIRE(sum < (1ull << 32), "more than 2^32-1 hits in one step: use smaller batches");
-            uint32_t* d_cnt = db->counter.as<uint32_t>();
-            SY_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
-            if (sum && n_local) {
-                db->hits.reserve(sum * 8);
-                hipLaunchKernelGGL(take_hits_kernel, dim3((uint32_t)std::min<uint64_t>(1024, grid_for64(std::max<uint64_t>(worst, 1)))), dim3(256), 0, st,
-                                   db->x_recv.as<uint64_t>(), W, block_words, cap, G, prefix[me], (uint64_t)n_local, db->hits.as<uint64_t>(), d_cnt);
-                SY_HIP(hipGetLastError());
-            }
-            uint32_t hc[2] = {0, 0};
-            ctx->read_back(hc, d_cnt, 8);
-            n_mine = hc[0];
-            max_mine = hc[1];
-            break;
+        // ---- 4. group the hits by owner rank; all-gather the group sizes: block = [count for rank 0..W-1 | largest count value]
+        SY_REQUIRE(W <= MAX_WORLD, "at most %u ranks", MAX_WORLD);
+        // x_meta (reused): [prefix (W + 1) u64 | my sizes (W + 1) u32 | cursors (W) u32 | starts (W) u32 | gathered sizes W x (W + 1) u32]
+        uint64_t* d_prefix = reinterpret_cast<uint64_t*>(xm);
+        uint32_t* d_sizes = reinterpret_cast<uint32_t*>(xm + (size_t)(W + 1) * 8);
+        uint32_t* d_cursor = d_sizes + (W + 1);
+        uint32_t* d_start = d_cursor + W;
+        uint32_t* d_allsizes = d_start + W + ((W & 1) ? 1 : 0);
+        ctx->h2d(d_prefix, prefix.data(), (size_t)(W + 1) * 8);
+        SY_HIP(hipMemsetAsync(d_sizes, 0, (size_t)(3 * W + 2) * 4, st));
+        if (n_hits) {
+            hipLaunchKernelGGL(owner_count_kernel, dim3((uint32_t)std::min<uint64_t>(1024, grid_for64(n_hits))), dim3(256), 0, st, db->hits.as<uint64_t>(),
+                               n_hits, G, d_prefix, W, d_sizes);
+            SY_HIP(hipGetLastError());
         }
+        ctx->h2d(d_sizes + W, &max_count, 4);
+        comm->all_gather(d_sizes, d_allsizes, (uint64_t)(W + 1) * 4, st);
+        std::vector<uint32_t> sizes((size_t)W * (W + 1));
+        ctx->d2h(sizes.data(), d_allsizes, sizes.size() * 4);
+        auto n_from_to = [&](uint32_t src, uint32_t dst) { return (uint64_t)sizes[(size_t)src * (W + 1) + dst]; };
+        // ---- 5. all-to-all of the hit groups
+        std::vector<uint64_t> hs_off(W + 1, 0), hr_off(W + 1, 0);
+        std::vector<uint32_t> start(W, 0);
+        uint32_t max_mine = 0;
+        for (uint32_t r = 0; r < W; r++) {
+            start[r] = (uint32_t)(hs_off[r] / 8);
+            hs_off[r + 1] = hs_off[r] + n_from_to(me, r) * 8;
+            hr_off[r + 1] = hr_off[r] + n_from_to(r, me) * 8;
+            if (n_from_to(r, me)) max_mine = std::max(max_mine, sizes[(size_t)r * (W + 1) + W]);
+        }
+        SY_REQUIRE(hs_off[W] / 8 == n_hits, "internal: owner counts do not add up");
+        SY_REQUIRE(hr_off[W] / 8 < (1ull << 32), "more than 2^32-1 hits for this rank's samples in one step: use smaller batches");
+        db->x_send.reserve(hs_off[W] + 64);
+        if (n_hits) {
+            ctx->h2d(d_start, start.data(), (size_t)W * 4);
+            hipLaunchKernelGGL(owner_scatter_kernel, dim3((uint32_t)std::min<uint64_t>(1024, grid_for64(n_hits))), dim3(256), 0, st,
+                               db->hits.as<uint64_t>(), n_hits, G, d_prefix, W, d_start, d_cursor, db->x_send.as<uint64_t>());
+            SY_HIP(hipGetLastError());
+        }
+        const uint32_t n_mine = (uint32_t)(hr_off[W] / 8);
+        db->hits.reserve((size_t)std::max<uint32_t>(n_mine, 1) * 8);      // (the scatter above has been queued: stream order keeps it safe)
+        {
+            ScopedKernelTimer t(ctx, "exchange");
+            comm->all_to_all(db->x_send.p, hs_off.data(), db->hits.p, hr_off.data(), st);
+        }
+        // ---- 6. sort + assemble this rank's samples
         finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false);
         const ResultLayout& lay = db->lay;
         const char* h = (const char*)db->h_res;

@@ -137,4 +137,11 @@ int sylph_host_fastq_index_digest(const char* path, unsigned threads, int* ok, u
     return 0;
 }
 
+// index only (tools/feed_bench.py times the parser alone with it)
+int sylph_host_fastq_index_count(const char* path, unsigned threads, uint64_t* n_records) {
+    FastqIndex ix(path, threads);
+    *n_records = ix.ok ? ix.n_records() : 0;
+    return ix.ok ? 1 : 0;
+}
+
 }  // extern "C"

@@ -77,7 +77,7 @@ void parallel_for(size_t n, uint64_t threads, F&& f) {
 struct Session {   // RAII
     sylph_sketch* sk = nullptr;
     Session(Engine& e, uint64_t c, uint64_t k, bool paired, bool no_dedup) {
-        hip_check(sylph_sketch_begin(e.ctx, (uint32_t)c, (uint32_t)k, paired ? SYLPH_READS_PAIRED : SYLPH_READS_SINGLE,
+        hip_check(sylph_sketch_begin(e.context(), (uint32_t)c, (uint32_t)k, paired ? SYLPH_READS_PAIRED : SYLPH_READS_SINGLE,
                                      no_dedup ? 1 : 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
     }
     ~Session() { sylph_sketch_destroy(sk); }
@@ -91,8 +91,37 @@ struct Session {   // RAII
 
 }  // namespace
 
-Engine::Engine(int dev) : device(dev) { hip_check(sylph_ctx_create(dev, nullptr, &ctx), "sylph_ctx_create"); }
-Engine::~Engine() { sylph_ctx_destroy(ctx); }
+Engine::Engine(int dev) : device(dev) {
+    init_ = std::thread([this] {
+        try {
+            hip_check(sylph_ctx_create(device, nullptr, &ctx_), "sylph_ctx_create");
+            if (getenv("SYLPH_HIP_NO_WARMUP")) return;
+            batch.prealloc();
+            // first use of a kernel loads its code object (~25 ms for the sketch kernels): do it here, with a few dummy pairs
+            sylph_sketch* sk = nullptr;
+            hip_check(sylph_sketch_begin(ctx_, 200, 31, SYLPH_READS_PAIRED, 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
+            std::vector<uint8_t> b(8 * 150, 'A');
+            for (size_t i = 0; i < b.size(); i++) b[i] = "ACGT"[(i * 2654435761u >> 7) & 3];
+            std::vector<uint64_t> off(9);
+            for (size_t i = 0; i < off.size(); i++) off[i] = i * 150;
+            uint64_t* k = nullptr; uint32_t* c = nullptr; uint64_t n = 0, dup = 0;
+            const int rc = sylph_sketch_push(sk, b.data(), off.data(), 8, SYLPH_MEM_HOST) ||
+                           sylph_sketch_finish(sk, &k, &c, &n, &dup);
+            sylph_free(k); sylph_free(c);
+            sylph_sketch_destroy(sk);
+            if (rc) hip_check(rc, "warm-up");
+        } catch (const Error& e) { init_error_ = e.msg; init_code_ = e.code ? e.code : 1; }
+    });
+}
+sylph_ctx* Engine::context() {
+    if (init_.joinable()) init_.join();
+    if (init_code_) throw Error{init_code_, init_error_};
+    return ctx_;
+}
+Engine::~Engine() {
+    if (init_.joinable()) init_.join();
+    if (ctx_) sylph_ctx_destroy(ctx_);
+}
 
 namespace {
 // prefix sums of the sequence lengths of an indexed file: cum[i] = bases of records [0, i)
@@ -103,17 +132,47 @@ std::vector<uint64_t> cumulative(const FastqIndex& ix) {
 }
 // Uncompressed 4-line FASTQ (the common case): the files are indexed by parse_threads() workers, whole batches are gathered
 // into page-locked memory in parallel and pushed; the record loop of the reference shrinks to its one sequential piece, the
-// running mean of the read lengths (f64, file order: sketch.rs:941-943, :825-826).  Returns false — nothing pushed — when
-// a file is not that simple, and the caller runs the sequential reader with needletail's exact record/error semantics.
-bool sketch_indexed(Engine& e, sylph_sketch* sk, const std::string& f1, const std::string* f2, double& mean_read_length) {
-    if (getenv("SYLPH_HIP_SEQUENTIAL_FEED")) return false;
+// running mean of the read lengths (f64, file order: sketch.rs:941-943, :825-826), which runs on its own thread meanwhile.
+// index_inputs returns nothing when a file is not that simple (gzip, FASTA, blank lines, a malformed record anywhere): the
+// caller then runs the sequential reader with needletail's exact record/error semantics.  No GPU call happens before the
+// files are indexed, so the engine's background bring-up overlaps with it.
+struct IndexedInput { std::unique_ptr<FastqIndex> a, b; };
+std::optional<IndexedInput> index_inputs(const std::string& f1, const std::string* f2) {
+    if (getenv("SYLPH_HIP_SEQUENTIAL_FEED")) return std::nullopt;
     const unsigned T = parse_threads();
-    FastqIndex a(f1, T);
-    if (!a.ok) return false;
-    std::unique_ptr<FastqIndex> b;
-    if (f2) { b.reset(new FastqIndex(*f2, T)); if (!b->ok) return false; }
+    IndexedInput in;
+    std::thread tb;
+    if (f2) tb = std::thread([&] { in.b.reset(new FastqIndex(*f2, T)); });   // the two mate files are indexed concurrently
+    in.a.reset(new FastqIndex(f1, T));
+    if (tb.joinable()) tb.join();
+    if (!in.a->ok || (f2 && !in.b->ok)) return std::nullopt;
+    return in;
+}
+void sketch_indexed(Engine& e, sylph_sketch* sk, const IndexedInput& in, double& mean_read_length) {
+    const unsigned T = parse_threads();
+    static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const double t = now();
+        fprintf(stderr, "[sylph_hip feed] %-28s %8.3f ms\n", what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
+    const FastqIndex& a = *in.a;
+    const FastqIndex* b = in.b.get();
     const size_t n = b ? std::min(a.n_records(), b->n_records()) : a.n_records();   // lock-step readers: sketch.rs:813-815
-    const std::vector<uint64_t> ca = cumulative(a), cb = b ? cumulative(*b) : std::vector<uint64_t>();
+    std::vector<uint64_t> ca, cb;
+    {
+        std::thread tb;
+        if (b) tb = std::thread([&] { cb = cumulative(*b); });
+        ca = cumulative(a);
+        if (tb.joinable()) tb.join();
+    }
+    lap("prefix sums");
+    // the one sequential piece of the reference's record loop, on its own thread while the batches travel
+    double mean = 0.;
+    std::thread tm([&] { double counter = 0.; for (size_t i = 0; i < n; i++) { counter += 1.; mean = mean + ((double)a.seq_len[i] - mean) / counter; } });
     e.batch.flush(sk);
     size_t i0 = 0;
     while (i0 < n) {
@@ -124,23 +183,24 @@ bool sketch_indexed(Engine& e, sylph_sketch* sk, const std::string& f1, const st
             const size_t mid = lo + (hi - lo + 1) / 2;
             if (bases_upto(mid) <= PinnedBatch::BATCH_BASES) lo = mid; else hi = mid - 1;
         }
-        e.batch.push_indexed(sk, a, b.get(), ca, b ? &cb : nullptr, i0, lo, T);
+        e.batch.push_indexed(sk, a, b, ca, b ? &cb : nullptr, i0, lo, T);
+        lap("batch: gather + push");
         i0 = lo;
     }
-    double mean = 0., counter = 0.;
-    for (size_t i = 0; i < n; i++) { counter += 1.; mean = mean + ((double)a.seq_len[i] - mean) / counter; }
+    tm.join();
     mean_read_length = mean;
-    return true;
+    lap("running mean (joined)");
 }
 }  // namespace
 
 // sketch.rs:897-959
 std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
                                                        std::optional<std::string> sample_name, bool no_dedup) {
-    {
+    if (auto in = index_inputs(read_file, nullptr)) {   // uncompressed 4-line FASTQ: block-parallel feed
         Session s(e, c, k, false, no_dedup);
         double mean = 0.;
-        if (sketch_indexed(e, s.sk, read_file, nullptr, mean)) {
+        sketch_indexed(e, s.sk, *in, mean);
+        {
             SequencesSketch out;
             s.finish(out);
             out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
@@ -178,10 +238,11 @@ std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::str
 std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                      uint64_t c, uint64_t k, std::optional<std::string> sample_name,
                                                      bool no_dedup, double /*dedup_fpr*/) {
-    {
+    if (auto in = index_inputs(read_file1, &read_file2)) {
         Session s(e, c, k, true, no_dedup);
         double mean = 0.;
-        if (sketch_indexed(e, s.sk, read_file1, &read_file2, mean)) {
+        sketch_indexed(e, s.sk, *in, mean);
+        {
             SequencesSketch out;
             s.finish(out);
             out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;
@@ -294,7 +355,7 @@ struct GenomeBatch {
         const uint64_t G = pending.size();
         std::vector<uint64_t> koff(G + 1), toff(G + 1);
         uint64_t *gk = nullptr, *tr = nullptr;
-        hip_check(sylph_sketch_genomes(e.ctx, bases.data(), off.data(), off.size() - 1, goff.data(), G, (uint32_t)c, (uint32_t)k,
+        hip_check(sylph_sketch_genomes(e.context(), bases.data(), off.data(), off.size() - 1, goff.data(), G, (uint32_t)c, (uint32_t)k,
                                        SYLPH_SEED_AVX2_COMPAT, min_spacing, pseudotax ? 1 : 0, SYLPH_MEM_HOST, &gk, koff.data(), &tr,
                                        toff.data()),
                   "sylph_sketch_genomes");
@@ -550,7 +611,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
     std::vector<uint64_t> flat, goff{0};
     for (const auto& g : genome_sketches) { flat.insert(flat.end(), g.genome_kmers.begin(), g.genome_kmers.end()); goff.push_back(flat.size()); }
     sylph_db* db = nullptr;
-    hip_check(sylph_db_upload(e.ctx, flat.data(), goff.data(), genome_sketches.size(), SYLPH_MEM_HOST, &db), "sylph_db_upload");
+    hip_check(sylph_db_upload(e.context(), flat.data(), goff.data(), genome_sketches.size(), SYLPH_MEM_HOST, &db), "sylph_db_upload");
     struct DbGuard { sylph_db* d; ~DbGuard() { sylph_db_destroy(d); } } guard{db};
     { std::vector<uint64_t>().swap(flat); }
     if (args.pseudotax) {   // the winner table also ranges over pseudotax_tracked_nonused_kmers (contain.rs:421-428)

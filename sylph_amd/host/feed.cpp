@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -267,7 +268,10 @@ void PinnedBatch::push_indexed(sylph_sketch* sk, const FastqIndex& a, const Fast
     const size_t n_items = i1 - i0, nrec = b ? 2 * n_items : n_items;
     const uint64_t base0 = cum_a[i0] + (b ? (*cum_b)[i0] : 0);
     const uint64_t total = cum_a[i1] + (b ? (*cum_b)[i1] : 0) - base0;
+    static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     reserve(std::max<size_t>(total + 64, cap_bases_), std::max<size_t>(nrec, cap_recs_));
+    const auto t1 = std::chrono::steady_clock::now();
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n_items / 4096 + 1));
     off_[0] = 0;
     run_workers(T, [&](unsigned w) {
@@ -286,7 +290,12 @@ void PinnedBatch::push_indexed(sylph_sketch* sk, const FastqIndex& a, const Fast
     });
     n_recs_ = nrec;
     n_bases_ = total;
+    const auto t2 = std::chrono::steady_clock::now();
     flush(sk);
+    if (trace)
+        fprintf(stderr, "[sylph_hip feed]   pinned reserve %.3f ms, gather %.3f ms (%.1f MB), push %.3f ms\n",
+                std::chrono::duration<double>(t1 - t0).count() * 1e3, std::chrono::duration<double>(t2 - t1).count() * 1e3, total / 1e6,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() * 1e3);
 }
 
 }  // namespace sylph_host

@@ -11,6 +11,7 @@
 #include <memory>
 #include <optional>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -117,6 +118,7 @@ class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinne
     // appends one record (pair = false) or the two mates of a pair, flushing to the session first when the batch is full
     void add(sylph_sketch* sk, const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb, bool pair);
     void flush(sylph_sketch* sk);
+    void prealloc() { if (!bases_) reserve(BATCH_BASES, BATCH_RECS); }   // the page-locked allocation itself takes ~50 ms
     // records [i0, i1) of an indexed file (single-end), or pairs [i0, i1) of two indexed files interleaved mate 1, mate 2,
     // copied into the batch by `threads` workers and pushed; the batch must be empty (flush() first)
     void push_indexed(sylph_sketch* sk, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
@@ -132,11 +134,19 @@ bool is_fasta(const std::string& f);   // sketch.rs:109
 
 // ---- sketching (GPU through the C ABI) ----
 struct Engine {   // one GPU context shared by the drivers
-    sylph_ctx* ctx = nullptr;
     int device = -1;
     PinnedBatch batch;   // reused by every sample sketched through this engine
+    // GPU bring-up (runtime initialisation, context, page-locked batch, first-use loading of the sketch kernels: ~0.3 s) runs on a
+    // background thread from the moment the engine exists, so that it overlaps with argument handling and the indexing of the
+    // first input file; context() waits for it (and rethrows its error).
     explicit Engine(int device = -1);
     ~Engine();
+    sylph_ctx* context();
+   private:
+    sylph_ctx* ctx_ = nullptr;
+    std::thread init_;
+    std::string init_error_;
+    int init_code_ = 0;
 };
 // sketch.rs:897 / :771 / :550 / :481 — return nullopt where the reference returns None (warn + skip).
 std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,

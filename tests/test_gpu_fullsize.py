@@ -78,3 +78,51 @@ def test_one_gbp_sample_against_the_oracle(ctx):
     assert np.array_equal(cc, ecc) and cc[:24].min() > 1000
     for gi in list(range(24)) + list(np.nonzero(ecc[24:])[0][:50] + 24):
         assert np.array_equal(covs[int(coff2[gi]):int(coff2[gi + 1])], np.sort(ecov[gi]))
+
+
+def test_long_read_sample_in_two_pushes_at_c100_against_a_c200_database(ctx):
+    """BASELINE configs[4] (C5) in small: ONT-like reads (log-normal lengths, N50 10 kb, 5 % substitutions; 1.2 Gbp — the oracle
+    sketches that in seconds) sketched at c = 100 in TWO pushes of whole reads (a push holds < 2^32 bases: the real 5 Gbp sample
+    needs two as well; the second push starts at an unaligned device address), through the position kernel (no record fits the
+    read-per-lane kernel), compared bit for bit with the oracle; then profiled against a database sketched at c = 200 — reads may
+    be denser than the database (contain.rs:562-568, :616-623): half of the sample's k-mers lie above the database's threshold
+    and must simply find nothing."""
+    import torch
+    from sylph_amd import synth
+    dev = torch.device("cuda", 0)
+    k = 31
+    genomes = synth.random_genomes(12, 3_000_000, dev, 21, mutated_frac=0.0)
+    bases, off = synth.long_reads(genomes, 1_200_000_000, seed=5)
+    torch.cuda.synchronize()
+    n_rec = off.numel() - 1
+    n_bases = int(off[-1].item())
+    cut = int(torch.searchsorted(off, off[-1] // 2).item())
+    sk = S.ReadSketcher(ctx, c=100, k=k, paired=False)
+    for a, z in ((0, cut), (cut, n_rec)):
+        o = (off[a:z + 1] - off[a]).contiguous()
+        torch.cuda.synchronize()
+        sk.push_device(bases.data_ptr() + int(off[a].item()), o.data_ptr(), z - a, int(o[-1].item()))
+    g = sk.finish()
+    sk.close()
+    hb = bases[:n_bases].cpu().numpy()
+    ho = off.cpu().numpy().astype(np.uint64)
+    e = O.sketch_reads(hb, ho, c=100, k=k, paired=False)
+    assert np.array_equal(g["kmers"], e["kmers"]) and np.array_equal(g["counts"], e["counts"]) and g["dup_removed"] == e["dup_removed"] == 0
+    thr200 = (2**64 - 1) // 200
+    assert 0.4 < float((g["kmers"] >= thr200).mean()) < 0.6
+    # database at c = 200: the source genomes + decoys
+    gb = genomes.reshape(-1).cpu().numpy()
+    coff = np.arange(13, dtype=np.uint64) * np.uint64(3_000_000)
+    km, koff, _, _ = ctx.sketch_genomes(gb, coff, np.arange(13, dtype=np.uint64), c=200, k=k)
+    dk, doff = synth.decoy_sketches(2000, c=200, device=dev, seed=9)
+    dk, doff = dk.cpu().numpy().view(np.uint64), doff.cpu().numpy().astype(np.uint64)
+    db_k = np.concatenate([km, dk])
+    db_off = np.concatenate([koff, doff[1:] + koff[-1]])
+    db = S.Database(ctx, db_k, db_off)
+    cc, coff2, covs = db.contain_batch([(g["kmers"], g["counts"])])
+    cc, coff2, covs = cc.copy(), coff2.copy(), covs.astype(np.uint32)
+    db.close()
+    ecc, ecov, _ = O.contain(g["kmers"], g["counts"], db_k, db_off, n_threads=8)
+    assert np.array_equal(cc, ecc) and cc[:12].min() > 1000
+    for gi in list(range(12)) + list(np.nonzero(ecc[12:])[0][:50] + 12):
+        assert np.array_equal(covs[int(coff2[gi]):int(coff2[gi + 1])], np.sort(ecov[gi]))
