@@ -214,12 +214,13 @@ __device__ __forceinline__ void hit_stage_flush(HitStage& st, bool force, uint64
     __syncthreads();
 }
 
-__global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const SampleRef* __restrict__ refs, uint32_t n_samples, uint32_t n_chunks,
-                                                          LineView v, uint32_t n_genomes, const uint32_t* __restrict__ glen,
+__global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const SampleRef* __restrict__ refs_mem, RefPack pack, uint32_t n_samples,
+                                                          uint32_t n_chunks, LineView v, uint32_t n_genomes, const uint32_t* __restrict__ glen,
                                                           double min_number_kmers, int check_len, uint64_t* __restrict__ hits,
                                                           uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
     __shared__ HitStage st;
     hit_stage_init(st);
+    const SampleRef* __restrict__ refs = n_samples <= REFS_INLINE ? pack.r : refs_mem;   // (kernel-argument segment, or HBM)
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         uint32_t s = 0, hi = n_samples;                  // sample of this chunk: largest s with chunk0[s] <= chunk (uniform)
         while (hi - s > 1) {
@@ -462,8 +463,13 @@ uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_numb
     SY_REQUIRE((uint64_t)refs.size() * std::max<uint64_t>(G, 1) < (1ull << 32) - 1, "samples x genomes must stay below 2^32: split the batch");
     *max_count = 0;
     if (!total || !db->kept.n_postings) return 0;
-    db->q_refs.reserve(refs.size() * sizeof(SampleRef));
-    ctx->h2d(db->q_refs.p, refs.data(), refs.size() * sizeof(SampleRef));
+    RefPack pack{};
+    if (refs.size() <= REFS_INLINE) {
+        for (size_t i = 0; i < refs.size(); i++) pack.r[i] = refs[i];
+    } else {
+        db->q_refs.reserve(refs.size() * sizeof(SampleRef));
+        ctx->h2d(db->q_refs.p, refs.data(), refs.size() * sizeof(SampleRef));
+    }
     uint64_t cap = std::max<uint64_t>(total * 2, 1u << 20);
     uint32_t* d_cnt = db->counter.as<uint32_t>();   // [0] = number of hits, [1] = largest count among the hits
     const int check_len = (double)db->min_glen < min_number_kmers;
@@ -475,7 +481,7 @@ uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_numb
         {
             ScopedKernelTimer t(ctx, "probe");
             hipLaunchKernelGGL(probe_kernel, dim3(std::min<uint32_t>((uint32_t)chunks, probe_grid())), dim3(PROBE_TPB), 0, ctx->stream,
-                               db->q_refs.as<SampleRef>(), (uint32_t)refs.size(), (uint32_t)chunks, db->kept.view(), (uint32_t)G,
+                               db->q_refs.as<SampleRef>(), pack, (uint32_t)refs.size(), (uint32_t)chunks, db->kept.view(), (uint32_t)G,
                                db->glen.as<uint32_t>(), min_number_kmers, check_len, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
             SY_HIP(hipGetLastError());
         }

@@ -36,6 +36,10 @@ struct SampleRef {
     uint32_t chunk0, pad;
 };
 
+// Up to REFS_INLINE tables travel in the kernel arguments (no host->device copy of the descriptor array, no wait for it).
+constexpr uint32_t REFS_INLINE = 8;
+struct RefPack { SampleRef r[REFS_INLINE]; };
+
 #ifdef __HIPCC__
 // Calls f(genome id) for every posting of k-mer `km`.  One 64 B line read (4 x global_load_dwordx4); the overflow run of
 // a crowded bucket is walked only when the 7 postings kept in the line do not already exceed the remainder looked for.

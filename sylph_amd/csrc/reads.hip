@@ -19,6 +19,8 @@
 // instead of the 8 of a rolling update (r01), then the same hash / threshold sequences as the position kernel.
 // Hits are accumulated as bit masks (one bit per k-mer, 32 k-mers per LDS word), counted, scanned across the workgroup —
 // lanes are in record order, so the scan gives file order — and only then re-hashed and written.
+#include <cstddef>
+
 #include "common.h"
 #include "device_common.h"
 #include "sketch_session.h"
@@ -120,9 +122,13 @@ __device__ __forceinline__ uint32_t pack16_fwd(uint4 v) {
 }
 
 // blk_rec[b] = first record whose aligned start coordinate (off + bias) is >= b * rt, for b in [0, n_blk]
+// (also clears the words the short-read kernel accumulates into: the scan sentinel behind the block counts and the
+//  long-record / overflow flags — two memset dispatches less per batch)
 __global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __restrict__ off, uint64_t n_rec, uint32_t bias,
-                                                            uint32_t rt, uint32_t n_entries, uint32_t* __restrict__ blk_rec) {
+                                                            uint32_t rt, uint32_t n_entries, uint32_t* __restrict__ blk_rec,
+                                                            uint32_t* __restrict__ count_sentinel, uint32_t* __restrict__ state_words) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) { *count_sentinel = 0; state_words[0] = 0; state_words[1] = 0; }
     if (b >= n_entries) return;
     const uint64_t target = (uint64_t)b * rt;
     uint64_t lo = 0, hi = n_rec;   // first r in [0, n_rec] with off[r] + bias >= target (off is non-decreasing)
@@ -352,15 +358,16 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
     const uint64_t thr = UINT64_MAX / (uint64_t)sk->c;
     DevBuf &b_sr = ctx->scratch[1], &b_meta = ctx->scratch[4];
     b_sr.reserve((size_t)n_blk * slot_cap * sizeof(OccRec));
-    // [blk_rec (n_blk+1) | blk_count (n_blk+1) | blk_off (n_blk+1) | spill_slot_of_blk (n_blk+1) | ReadsState]
+    // [blk_rec (n_blk+1) | blk_count (n_blk+1) | spill_slot_of_blk (n_blk+1) | blk_off (n_blk+1) | ReadsState]: the total
+    // (blk_off[n_blk]) and the two flag words of the state sit side by side and leave in ONE 12-byte copy
     b_meta.reserve(((size_t)n_blk + 1) * 4 * 4 + sizeof(ReadsState) + 16);
     uint32_t* blk_rec = b_meta.as<uint32_t>();
     uint32_t* blk_count = blk_rec + (n_blk + 1);
-    uint32_t* blk_off = blk_count + (n_blk + 1);
-    uint32_t* spill_slot = blk_off + (n_blk + 1);
-    ReadsState* d_state = reinterpret_cast<ReadsState*>(spill_slot + (n_blk + 1));
-    SY_HIP(hipMemsetAsync(blk_count + n_blk, 0, 4, ctx->stream));   // scan sentinel
-    SY_HIP(hipMemsetAsync(d_state, 0, 8, ctx->stream));             // long_record, spill.n_tiles
+    uint32_t* spill_slot = blk_count + (n_blk + 1);
+    uint32_t* blk_off = spill_slot + (n_blk + 1);
+    ReadsState* d_state = reinterpret_cast<ReadsState*>(blk_off + (n_blk + 1));
+    static_assert(offsetof(ReadsState, long_record) == 0 && offsetof(ReadsState, spill) == 4 && offsetof(SpillState, n_tiles) == 0,
+                  "long_record and spill.n_tiles are the first two words");
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
@@ -382,7 +389,7 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         {
             ScopedKernelTimer t(ctx, "annotate");   // the record lookup this kernel replaces
             hipLaunchKernelGGL(block_records_kernel, dim3(grid_for(n_blk + 1)), dim3(256), 0, ctx->stream, d_off, n_records, bias, rt,
-                               n_blk + 1, blk_rec);
+                               n_blk + 1, blk_rec, blk_count + n_blk, reinterpret_cast<uint32_t*>(d_state));
         }
         {
             ScopedKernelTimer t(ctx, "seeds");
@@ -391,8 +398,7 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         exclusive_sum_u32(ctx, blk_count, blk_off, (size_t)n_blk + 1);
     }
     uint32_t res[3] = {0, 0, 0};   // total occurrences, long_record flag, overflowing blocks
-    SY_HIP(hipMemcpyAsync(ctx->pinned, blk_off + n_blk, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 4, d_state, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipMemcpyAsync(ctx->pinned, blk_off + n_blk, 12, hipMemcpyDeviceToHost, ctx->stream));
     SY_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(res, ctx->pinned, 12);
     if (!ctx->pending.empty()) profile_collect(ctx);

@@ -46,9 +46,16 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, const BucketMap m) {
     return min(__umulhi((uint32_t)(h >> m.sh), m.mult), m.B - 1u);
 }
 
+// (also clears what the replay accumulates into — per-bucket counters, the two list heads, the tail words — instead of four
+//  memset dispatches)
 __global__ __launch_bounds__(256) void bucket_key_kernel(const uint64_t* __restrict__ hash, uint32_t n, BucketMap bm, uint32_t B,
-                                                         uint32_t* __restrict__ bk, uint32_t* __restrict__ idx) {
+                                                         uint32_t* __restrict__ bk, uint32_t* __restrict__ idx,
+                                                         uint32_t* __restrict__ zero, uint32_t n_zero, uint32_t* __restrict__ tail16,
+                                                         uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) zero[i] = 0;
+    if (i < 16) tail16[i] = 0;
+    if (i == 0) { *list_a = 0; *list_b = 0; }
     if (i >= n) return;
     const uint64_t h = hash[i];
     bk[i] = (h == INVALID_HASH) ? B : bucket_of(h, bm);
@@ -367,7 +374,10 @@ __global__ __launch_bounds__(1024) void sum_removed_kernel(const uint32_t* __res
 __global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t* __restrict__ tmp_k, const uint32_t* __restrict__ tmp_c,
                                                              const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_off,
                                                              const uint32_t* __restrict__ n_distinct, uint32_t n_buckets,
-                                                             uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c) {
+                                                             uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
+                                                             const uint32_t* __restrict__ ovf_list, uint32_t* __restrict__ tail) {
+    // tail = {removed u64, overflow u32, n_seg u32, n_ovf u32}: everything the host reads back, side by side (ONE copy)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { tail[3] = d_off[n_buckets]; tail[4] = ovf_list[0]; }
     for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
         const uint32_t n = n_distinct[b], s = boff[b], d = d_off[b];
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_k[d + i] = tmp_k[s + i]; out_c[d + i] = tmp_c[s + i]; }
@@ -481,10 +491,7 @@ bool finish_bucketed(sylph_sketch* sk) {
     unsigned long long* d_removed = b_small.as<unsigned long long>();
     uint32_t* d_overflow = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 8);
     const uint32_t* d_nv = boff + B;            // boff[B] = number of valid occurrences
-    SY_HIP(hipMemsetAsync(b_small.p, 0, 64, ctx->stream));
-    SY_HIP(hipMemsetAsync(large_list, 0, 4, ctx->stream));
-    SY_HIP(hipMemsetAsync(ovf_list, 0, 4, ctx->stream));
-    SY_HIP(hipMemsetAsync(n_distinct, 0, (size_t)(B + 2) * 4 * 2, ctx->stream));   // n_distinct and removed
+    const uint32_t n_zero = (B + 2) * 2;                                            // n_distinct and removed (cleared by bucket_key_kernel)
     // partition: stable radix sort of (bucket id -> occurrence index) on bit_length(B) bits (2-3 passes of 4-byte keys
     // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
     uint32_t* bk_in = b_keys.as<uint32_t>();
@@ -494,8 +501,9 @@ bool finish_bucketed(sylph_sketch* sk) {
     sk->out_c.reserve((size_t)n_all * 4);
     {
         HostPhase ph(ctx, "finish(bucket): partition + LDS replay + compact");
-        hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(n_all)), dim3(256), 0, ctx->stream, sk->hash.as<uint64_t>(), n_all, bm,
-                           B, bk_in, b_idx.as<uint32_t>());
+        hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(std::max(n_all, std::max(n_zero, 16u)))), dim3(256), 0, ctx->stream,
+                           sk->hash.as<uint64_t>(), n_all, bm, B, bk_in, b_idx.as<uint32_t>(), n_distinct, n_zero, b_small.as<uint32_t>(),
+                           large_list, ovf_list);
         sort_pairs_u32_u32(ctx, bk_in, bk_sorted, b_idx.as<uint32_t>(), b_perm.as<uint32_t>(), n_all, 0, bit_length(B));
         {
             ScopedKernelTimer t(ctx, "replay");
@@ -517,15 +525,13 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>());
+                               sk->out_c.as<uint32_t>(), ovf_list, b_small.as<uint32_t>());
         }
         SY_HIP(hipGetLastError());
     }
     struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf; } host{};
     auto read_tail = [&] {
-        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 12, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 12, d_off + B, 4, hipMemcpyDeviceToHost, ctx->stream));
-        SY_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned + 16, ovf_list, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 20, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
         memcpy(&host, ctx->pinned, 20);
         if (!ctx->pending.empty()) profile_collect(ctx);
@@ -565,7 +571,7 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>());
+                               sk->out_c.as<uint32_t>(), ovf_list, b_small.as<uint32_t>());
         }
         SY_HIP(hipGetLastError());
         read_tail();

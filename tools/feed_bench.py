@@ -68,6 +68,21 @@ def main():
     for ln in p.stderr.split("\n"):
         if "timing:" in ln:
             res["paired_plain_sequential_feed"] = {"sample_gbp_per_s": round(gbp / float(ln.split(" in ")[1].split(" s")[0]), 3)}
+    # four uncompressed paired samples in ONE command (GPU bring-up paid once; -t 1: one sample after the other)
+    for i in range(4):
+        for m in (1, 2):
+            dst = f"{d}/p{i}_{m}.fq"
+            if os.path.lexists(dst):
+                os.remove(dst)
+            os.symlink(f"{d}/s_{m}.fq", dst)
+    tm = time.perf_counter()
+    p = subprocess.run([BIN, "sketch", "-1", *[f"{d}/p{i}_1.fq" for i in range(4)], "-2", *[f"{d}/p{i}_2.fq" for i in range(4)], "-d", f"{d}/out",
+                        "-t", "1"], capture_output=True, text=True)
+    dt = time.perf_counter() - tm
+    assert p.returncode == 0, p.stderr[-2000:]
+    per = sorted(float(ln.split(" in ")[1].split(" s")[0]) for ln in p.stderr.split("\n") if "timing:" in ln)
+    res["four_paired_plain_samples_t1"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(4 * gbp / dt, 3),
+                                           "fastest_sample_gbp_per_s": round(gbp / per[0], 3) if per else None}
     # several samples in one command: -t worker threads, one GPU context each
     for i in range(4):
         for m in (1, 2):
