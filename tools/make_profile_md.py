@@ -1,68 +1,101 @@
 #!/usr/bin/env python3
-"""Assemble profiles/r01_kernel_stats.md, profiles/r01_bench_c3.json and profiles/seeds_traffic.json from the outputs of
-tools/r01_profile.sh (gpurun_out/final/)."""
-import csv
+"""Assemble profiles/r02_* from the outputs of tools/r02_profile.sh (gpurun_out/r02_final/): bench lines, the rocprofv3
+kernel-trace timeline, the PMC summary of reads_kernel / probe_kernel, the instruction-rate microbenchmark, the feed numbers."""
 import json
 import os
 import shutil
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "final")
+src = os.path.join(ROOT, "gpurun_out", "r02_final")
 dst = os.path.join(ROOT, "profiles")
-bench = json.load(open(os.path.join(src, "bench_c3.json")))
-shutil.copy(os.path.join(src, "bench_c3.json"), os.path.join(dst, "r01_bench_c3.json"))
+
+
+def load(name):
+    with open(os.path.join(src, name)) as f:
+        return json.loads(f.read().strip().split("\n")[-1])
+
+
+head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+subject = subprocess.run(["git", "log", "-1", "--format=%s"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+dirty = subprocess.run(["git", "status", "--porcelain", "--", "sylph_amd", "bench.py", "include"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+b = {}
+for wl in ("c3", "c3r", "c2", "c5", "c4"):
+    try:
+        b[wl] = load(f"bench_{wl}.json")
+        shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"r02_bench_{wl}.json"))
+    except Exception as e:
+        print("missing", wl, e)
+pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
 timeline = open(os.path.join(src, "step_timeline.md")).read()
-f = list(csv.DictReader(open(os.path.join(src, "pmc_fetch", "s_counter_collection.csv"))))
-w = list(csv.DictReader(open(os.path.join(src, "pmc_write", "s_counter_collection.csv"))))
-fe = float(f[-1]["Counter_Value"]) * 1024 * 2
-wr = float(w[-1]["Counter_Value"]) * 1024
-commit = subprocess.run(["git", "log", "-1", "--format=%h %s"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-rf = bench["roofline"]
+c3 = b["c3"]
+rf, rp = c3["roofline"], c3["roofline_profile"]
+fetch = pmc["pmc_FETCH_SIZE"]
+write = pmc["pmc_WRITE_SIZE"]
+sq = pmc["pmc_SQ"]
+sq2 = pmc.get("pmc_SQ2", {})
+sqr = pmc.get("pmc_SQ_c3r", {})
+# gfx950 rocprofv3: FETCH_SIZE is reported in KB of 64 B requests while streaming loads are 128 B requests -> x2 for wide coalesced
+# streams (MI355X_MICROARCH.md, HBM section); random 64 B line reads (the probe) are counted as they are.
+reads_fetch = fetch["reads.FETCH_SIZE"] * 1024 * 2
+reads_write = write["reads.WRITE_SIZE"] * 1024
+probe_fetch_raw = fetch["probe.FETCH_SIZE"] * 1024
+probe_write = write["probe.WRITE_SIZE"] * 1024
+kmers = rf["valu_ceiling"]["kmers_per_launch"]
+cyc = sq["reads.GRBM_GUI_ACTIVE"] / 8
+valu_per_kmer = sq["reads.SQ_INSTS_VALU"] / (kmers / 64)
+valu_busy = sq["reads.SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)
+pcyc = sq["probe.GRBM_GUI_ACTIVE"] / 8
 out = [
-    "# r01 — rocprofv3 --kernel-trace --stats of bench.py C3 (1 Gbp of 2x150 bp reads vs 113,104-genome DB), one MI355X", "",
-    "Recipe: `tools/r01_profile.sh` (run on the GPU box through gpurun), summarised by `tools/step_timeline.py` and this script.",
-    "", "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -o c3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline",
-    "", f"Code state: `{commit}` (or its parent if this file was committed together with code).",
-    f"Un-profiled run of the same build (profiles/r01_bench_c3.json): **{bench['ms_per_step']} ms/step = {bench['value']} Gbp/s**, sketch",
-    f"{bench['sketch_ms']} ms, profile {bench['profile_ms']} ms; dominant kernel `{rf['kernel']}` {rf['avg_launch_ms']} ms/launch by HIP events in",
-    "bench.py vs the rocprofv3 average in the table below — they agree within the profiler's per-dispatch overhead.", "",
-    "The first table is the complete dispatch sequence of ONE timed step (sketch + profile of one sample) with the idle gap before",
-    "each dispatch; `__amd_rocclr_copyBuffer` rows are the runtime's copy kernels (the 136 us one is the device->host copy of the",
-    "coverage lists, 7.4 MB over PCIe), `fillBufferAligned` are hipMemsetAsync.  The second table aggregates the last 5 steps.", "",
+    "# r02 — rocprofv3 of bench.py C3 (1 Gbp of 2x150 bp reads vs 113,104-genome DB), one MI355X", "",
+    f"Code state: `{head}` ({subject}){' + uncommitted changes' if dirty else ''} — the tree the GPU box ran is the tree of this commit's parent plus",
+    "this file; recipe `tools/r02_profile.sh` (through gpurun), assembled by `tools/make_profile_md.py`.", "",
+    "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_final/stats -o c3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-h2d --no-verify", "",
+    f"Un-profiled run of the same build (profiles/r02_bench_c3.json, 20 steps): **{c3['ms_per_step']} ms/step = {c3['value']} Gbp/s**, sketch {c3['sketch_ms']} ms,",
+    f"profile {c3['profile_ms']} ms; `{rf['kernel']}` {rf['avg_launch_ms']} ms/launch and `probe_kernel` {rp['avg_launch_ms']} ms/launch by HIP events inside the library",
+    "vs the rocprofv3 averages in the second table below.", "",
+    "First table: the complete dispatch sequence of ONE timed step (sketch + profile of one sample) with the idle gap before each",
+    "dispatch (`__amd_rocclr_copyBuffer` = the runtime's copy kernels, `fillBufferAligned` = hipMemsetAsync).  Second table: totals over the last 5 steps.", "",
     timeline, "",
-    "## PMC passes for the dominant kernel (separate runs, counters only, no trace domains)", "",
-    "    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex reads_kernel --output-format csv -d gpurun_out/final/pmc_fetch -o s -- python tools/trace_run.py",
-    "    rocprofv3 --pmc WRITE_SIZE --kernel-include-regex reads_kernel --output-format csv -d gpurun_out/final/pmc_write -o s -- python tools/trace_run.py",
-    "", "| dispatch | FETCH_SIZE (KB, raw) | WRITE_SIZE (KB, raw) | duration (us) |", "|---|---|---|---|"]
-for i, (a, b) in enumerate(zip(f, w)):
-    out.append(f"| {i + 1} | {float(a['Counter_Value']):.1f} | {float(b['Counter_Value']):.1f} | {(int(a['End_Timestamp']) - int(a['Start_Timestamp'])) / 1e3:.1f} |")
+    "## PMC passes (each counter group in its own run, counters only — no trace domains)", "",
+    "    rocprofv3 --pmc FETCH_SIZE  --kernel-include-regex 'reads_kernel|probe_kernel' ... -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-verify --no-kernel-timers",
+    "    rocprofv3 --pmc WRITE_SIZE  (same)      rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE (same)", "",
+    "Means over the last 3 dispatches of each kernel (the timed steps).", "",
+    "### `reads_kernel<31,1,0>` (one launch = the whole 1 Gbp batch)", "",
+    f"* FETCH_SIZE {fetch['reads.FETCH_SIZE']:.4g} KB raw → read bytes = x 1024 x 2 (gfx950: wide coalesced streaming reads are 128 B requests counted as 64 B,",
+    f"  MI355X_MICROARCH.md HBM section) = **{reads_fetch:.4e} B**; WRITE_SIZE {write['reads.WRITE_SIZE']:.4g} KB → **{reads_write:.3e} B** (finished 32 B occurrence records into per-block slots).",
+    f"* HBM traffic per launch = **{reads_fetch + reads_write:.4e} B** vs {rf['algorithmic_bytes_per_launch']:.4e} B algorithmic = {(reads_fetch + reads_write) / rf['algorithmic_bytes_per_launch']:.2f}x: no wasted re-reads",
+    "  (the surplus: the 2 x 400-base halo per block, 32 B records where 8 B of seed would do).",
+    f"* achieved = algorithmic bytes / {rf['avg_launch_ms']} ms = **{rf['achieved']} GB/s = {100 * rf['frac']:.1f} % of 8 TB/s**.",
+    f"* SQ_INSTS_VALU {sq['reads.SQ_INSTS_VALU']:.4g} per launch / ({kmers:.3e} hashed k-mers / 64 lanes) = **{valu_per_kmer:.1f} VALU wave-instructions per hashed k-mer** (r01: 44.2);",
+    f"  GRBM_GUI_ACTIVE / 8 XCDs = {cyc:.4g} cycles; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles) = **{100 * valu_busy:.0f} %**.",
+    "", "| counter | reads_kernel | probe_kernel |", "|---|---|---|"]
+names = sorted({k.split(".", 1)[1] for k in list(sq) + list(sq2)})
+allsq = dict(sq)
+allsq.update(sq2)
+for n in names:
+    out.append(f"| {n} | {allsq.get('reads.' + n, float('nan')):.4g} | {allsq.get('probe.' + n, float('nan')):.4g} |")
 out += ["",
-        f"Read bytes = FETCH_SIZE x 1024 x 2 (gfx950 correction for wide coalesced streaming reads, MI355X_MICROARCH.md HBM section) = {fe:.4e} B",
-        f"(1.0000e9 bases + the 2 x 400-base halo per 38,400-base block + record offsets); written = WRITE_SIZE x 1024 = {wr:.3e} B (4.0 M",
-        f"occurrences x 40 B into per-block slots).  HBM bytes per launch = **{fe + wr:.4e} B** vs {rf['algorithmic_bytes_per_launch']:.4e} algorithmic",
-        "(the finished 32 B occurrence record is written here instead of 8 B hash + 4 B position; the annotate kernel's traffic is gone).",
-        f"Achieved = algorithmic bytes / {rf['avg_launch_ms']} ms = {rf['achieved']} GB/s = {100 * rf['frac']:.1f} % of the 8 TB/s HBM peak; the kernel is integer-VALU bound",
-        "(SQ counters below): every VALU wave-instruction occupies its SIMD for 4 cycles."]
-sq = os.path.join(src, "pmc_sq", "s_counter_collection.csv")
-if os.path.exists(sq):
-    import collections
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(sq)):
-        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    v = {k: sum(x) / len(x) for k, x in agg.items()}
-    cyc = v.get("GRBM_GUI_ACTIVE", 0) / 8
-    out += ["", "## SQ counters of the dominant kernel (one more separate pass)", "",
-            "    rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex reads_kernel ...",
-            "", "| counter | per launch (mean of 3) |", "|---|---|"]
-    for k2 in sorted(v):
-        out.append(f"| {k2} | {v[k2]:.4g} |")
-    if cyc and v.get("SQ_INSTS_VALU"):
-        out += ["", f"GRBM_GUI_ACTIVE / 8 XCDs = {cyc:.3g} cycles per launch; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles) = "
-                f"**{100 * v['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * cyc):.0f} %**; SQ_INSTS_VALU / (8.0e8 hashed k-mers / 64 lanes) = "
-                f"**{v['SQ_INSTS_VALU'] / 1.25e7:.1f} VALU instructions per hashed k-mer**."]
-open(os.path.join(dst, "r01_kernel_stats.md"), "w").write("\n".join(out) + "\n")
-json.dump({"hbm_bytes_per_launch": int(fe + wr), "kernel": "reads_kernel<31,1>",
-           "source": "profiles/r01_kernel_stats.md PMC section (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"},
+        "### `probe_kernel` (one launch = one 1.9 M-entry sample table, four distinct samples rotated: nothing is cache-warm)", "",
+        f"* FETCH_SIZE {fetch['probe.FETCH_SIZE']:.4g} KB → **{probe_fetch_raw:.4e} B** per launch = **{probe_fetch_raw / rp['probes_per_launch']:.0f} B per probe** as counted",
+        f"  (64 B requests: the table in (12 B per probe, streamed) + one 64 B index line + overflow runs; r01: 180 B per probe with a cache-warm sample);",
+        f"  WRITE_SIZE {write['probe.WRITE_SIZE']:.4g} KB → {probe_write:.3e} B ({rp['hits_per_launch']} hits x 8 B staged through LDS).",
+        f"* algorithmic bytes = probes x (12 + 64) + 8 x hits = {rp['algorithmic_bytes_per_launch']:.4e} B; / {rp['avg_launch_ms']} ms = **{rp['achieved']} GB/s = {100 * rp['frac']:.1f} % of 8 TB/s**",
+        f"  (latency-bound random line reads; {pcyc:.3g} cycles per launch).",
+        f"* a batch of 8 samples per launch (profiles/r02_bench_c4.json): {b['c4']['roofline_profile']['avg_launch_ms']} ms = {100 * b['c4']['roofline_profile']['frac']:.1f} % of peak." if "c4" in b else ""]
+if sqr:
+    k3 = b["c3r"]["roofline"]["valu_ceiling"]["kmers_per_launch"]
+    c3c = sqr["reads.GRBM_GUI_ACTIVE"] / 8
+    out += ["", "### ragged input (c3r: 2 x 35-151 bp uniform, 0.1 % N)", "",
+            f"SQ_INSTS_VALU {sqr['reads.SQ_INSTS_VALU']:.4g} / ({k3:.3e} hashed k-mers / 64) = **{sqr['reads.SQ_INSTS_VALU'] / (k3 / 64):.1f} VALU wave-instructions per hashed k-mer** —",
+            "wave-instructions are issued for the longest read of each wavefront while the shorter lanes idle; VALU busy "
+            f"{100 * sqr['reads.SQ_ACTIVE_INST_VALU'] * 4 / (1024 * c3c):.0f} %, {b['c3r']['roofline']['avg_launch_ms']} ms per 0.62 Gbp launch."]
+open(os.path.join(dst, "r02_kernel_stats.md"), "w").write("\n".join(out) + "\n")
+json.dump({"hbm_bytes_per_launch": int(reads_fetch + reads_write), "kernel": "reads_kernel<31,1,0>", "valu_per_kmer": round(valu_per_kmer, 1),
+           "valu_per_kmer_position_kernel": 38, "valu_busy": round(valu_busy, 3), "probe_fetch_bytes_per_probe": round(probe_fetch_raw / rp["probes_per_launch"], 1),
+           "head": head, "source": "profiles/r02_kernel_stats.md PMC section (FETCH_SIZE x2 gfx950 correction for the streaming reads + WRITE_SIZE, separate --pmc passes)"},
           open(os.path.join(dst, "seeds_traffic.json"), "w"))
-print("ok", fe + wr)
+for name in ("valu_rates.txt", "feed.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, "r02_" + name))
+print("ok: traffic", reads_fetch + reads_write, "valu/kmer", valu_per_kmer, "busy", valu_busy, "probe B/probe", probe_fetch_raw / rp["probes_per_launch"])
