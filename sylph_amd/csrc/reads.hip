@@ -108,17 +108,32 @@ __device__ __forceinline__ void kmer_steps8(uint32_t A0, uint32_t A1, uint32_t A
     kmer_step<K, T0 + 7, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
 }
 
-// 16 ASCII bases -> forward stream word (base j at bits 30-2j); the F half of pack16
+// 16 ASCII bases -> forward stream word (base j at bits 30-2j).  Per dword: the 2-bit code of every byte ((b>>1 ^ b>>2) & 3,
+// one v_bitop3 after the two shifts), the proof that every byte was one of ACGTacgt (v_perm_b32 rebuilds the letter from the
+// code), then ONE multiply gathers the four codes into the top byte, first base most significant: the code of byte k sits at
+// bit 8k and must land at bit 30 - 2k, i.e. move left by 30 - 10k; 2^30 + 2^20 + 2^10 + 1 does the four moves at once and no
+// partial product reaches bits 24..31 from anywhere else (v_mul_lo_u32 issues at the rate of v_perm_b32, tools/valu_rates.hip:
+// 4 of them replace the 8 + 4 permutes and shift-ors of a 4x4 byte transpose).  Two byte-selects and an OR assemble the word.
+__device__ __forceinline__ uint32_t codes4_bitop(uint32_t w, uint32_t& diff) {
+    uint32_t c;
+    const uint32_t a = w >> 1, b = w >> 2, m = 0x03030303u, up = 0xDFDFDFDFu;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(c) : "v"(a), "v"(b), "v"(m));      // (a ^ b) & m
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* 'T','G','C','A' */, c);
+    // (w & 0xDF..) ^ expect in one instruction; kept opaque so that the four results are OR-ed and tested ONCE (left to itself
+    // the compiler turns `bad |= ...; if (bad)` into four compares and a chain of 16-bit boolean ops: 17 instructions for 7)
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6a" : "=v"(diff) : "v"(w), "v"(up), "v"(expect));   // (a & b) ^ c
+    return c;
+}
 __device__ __forceinline__ uint32_t pack16_fwd(uint4 v) {
-    uint32_t bad = 0;
-    uint32_t c0 = codes4_fast(v.x, bad), c1 = codes4_fast(v.y, bad), c2 = codes4_fast(v.z, bad), c3 = codes4_fast(v.w, bad);
+    uint32_t d0, d1, d2, d3, bad;
+    uint32_t c0 = codes4_bitop(v.x, d0), c1 = codes4_bitop(v.y, d1), c2 = codes4_bitop(v.z, d2), c3 = codes4_bitop(v.w, d3);
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(bad) : "v"(d0), "v"(d1), "v"(d2));
+    asm("v_or_b32 %0, %1, %2" : "=v"(bad) : "v"(bad), "v"(d3));
     if (bad) { c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w); }
-    const uint32_t t0 = __builtin_amdgcn_perm(c1, c0, 0x05010400u), t1 = __builtin_amdgcn_perm(c1, c0, 0x07030602u);
-    const uint32_t t2 = __builtin_amdgcn_perm(c3, c2, 0x05010400u), t3 = __builtin_amdgcn_perm(c3, c2, 0x07030602u);
-    const uint32_t d0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u), d1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
-    const uint32_t d2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u), d3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-    const uint32_t g = (d0 << 6) | (d1 << 4) | (d2 << 2) | d3;
-    return __builtin_amdgcn_perm(0u, g, 0x00010203u);
+    constexpr uint32_t GATHER = (1u << 30) | (1u << 20) | (1u << 10) | 1u;
+    const uint32_t p0 = c0 * GATHER, p1 = c1 * GATHER, p2 = c2 * GATHER, p3 = c3 * GATHER;
+    // __builtin_amdgcn_perm(hi, lo, sel): selector 0-3 = bytes of lo, 4-7 = bytes of hi, 0x0C = constant 0
+    return __builtin_amdgcn_perm(p0, p1, 0x07030C0Cu) | __builtin_amdgcn_perm(p2, p3, 0x0C0C0703u);
 }
 
 // blk_rec[b] = first record whose aligned start coordinate (off + bias) is >= b * rt, for b in [0, n_blk]
@@ -153,6 +168,13 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
     const uint32_t n_words = (rt + 2 * RH) / 16 + 3;
     __shared__ uint32_t s_mask[MASKW][RTPB];
     __shared__ uint32_t s_wave[RTPB / 64];
+    // per lane: the record's markers (they take over the offsets' LDS once the lanes hold their offsets in registers: a
+    // block with several passes keeps its offsets in global memory instead), its first hit of the pass (bit 31: has markers),
+    // its stream base
+    static_assert((OFFS + 4) >= 2 * RTPB, "the marker arrays alias the staged offsets");
+    uint64_t* const s_m0 = s_off;
+    uint64_t* const s_m1 = s_off + RTPB;
+    __shared__ uint32_t s_first[RTPB + 1], s_rel[RTPB];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the
     // blocks, so that the halo a block shares with its neighbour is found in the same L2.  (Outputs are indexed by block,
@@ -163,23 +185,35 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
         if (it >= n_blk) continue;                                   // padding of the last XCD's range (uniform per workgroup)
         const uint32_t blk = blk_list ? blk_list[it] : it;
         const int64_t a0 = (int64_t)blk * rt - RH;                 // aligned coordinate of stream base 0 (multiple of 16)
-        for (uint32_t ci = tid; ci < n_words; ci += RTPB) {
-            const int64_t a = a0 + (int64_t)ci * 16;                  // aligned base coordinate of this word's first base
-            if constexpr (ENC == 0) {                                  // ASCII: 16 bytes -> one word
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (a >= 0 && (uint64_t)a < n_al) v = *reinterpret_cast<const uint4*>(bases_al + a);
-                sF[ci] = pack16_fwd(v);
-            } else {                                                   // packed input: 4 bytes, first base in bits 7:6 of byte 0
-                uint32_t w = 0;
-                if (a >= 0 && (uint64_t)a < n_al) w = *reinterpret_cast<const uint32_t*>(bases_al + (a >> 2));
-                sF[ci] = __builtin_amdgcn_perm(0u, w, 0x00010203u);
+        // (only the first and the last block of a batch reach outside [0, n_al): every other block loads unconditionally)
+        const bool interior = a0 >= 0 && (uint64_t)(a0 + (int64_t)n_words * 16) <= n_al;
+        if (interior) {
+            if constexpr (ENC == 0) {
+                const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bases_al + a0);
+                for (uint32_t ci = tid; ci < n_words; ci += RTPB) sF[ci] = pack16_fwd(src[ci]);
+            } else {
+                const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(bases_al + (a0 >> 2));
+                for (uint32_t ci = tid; ci < n_words; ci += RTPB) sF[ci] = __builtin_amdgcn_perm(0u, src[ci], 0x00010203u);
+            }
+        } else {
+            for (uint32_t ci = tid; ci < n_words; ci += RTPB) {
+                const int64_t a = a0 + (int64_t)ci * 16;              // aligned base coordinate of this word's first base
+                if constexpr (ENC == 0) {                              // ASCII: 16 bytes -> one word
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (a >= 0 && (uint64_t)a < n_al) v = *reinterpret_cast<const uint4*>(bases_al + a);
+                    sF[ci] = pack16_fwd(v);
+                } else {                                               // packed input: 4 bytes, first base in bits 7:6 of byte 0
+                    uint32_t w = 0;
+                    if (a >= 0 && (uint64_t)a < n_al) w = *reinterpret_cast<const uint32_t*>(bases_al + (a >> 2));
+                    sF[ci] = __builtin_amdgcn_perm(0u, w, 0x00010203u);
+                }
             }
         }
         const uint64_t R0 = blk_rec[blk], R1 = blk_rec[blk + 1];
         // offsets of the block's records (+ the mate-1 offset in front of a block that starts with a mate 2, + two behind)
         const uint64_t w_lo = paired ? (R0 & ~1ull) : R0;
         const uint64_t w_hi = min(R1 + 2, n_rec);                   // last offset index needed
-        const bool in_lds = (w_hi - w_lo + 1) <= (uint64_t)(OFFS + 4);
+        const bool in_lds = (w_hi - w_lo + 1) <= (uint64_t)(OFFS + 4) && (R1 - R0) <= (uint64_t)RTPB;
         if (in_lds)
             for (uint64_t t = tid; t <= w_hi - w_lo; t += RTPB) s_off[t] = off[w_lo + t];
         __syncthreads();
@@ -260,16 +294,20 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                 if ((uint32_t)w < wave) before += t;
                 total += t;
             }
-            uint32_t o = base_prev + before + x - cnt;
-            if (cnt) {
-                uint64_t rid = rec_base + r, m0 = 0, m1 = 0;
-                if (want_markers) {
-                    bool has = false;
+            // Survivors (1 in c k-mers) are finished COOPERATIVELY: lanes publish where their hits start in the pass and their
+            // record's markers; then the pass's hits are dealt one per lane — owner found by a search over the 256 start
+            // offsets, k-mer index from the owner's hit masks — re-hashed from the LDS stream and written as finished 32 B
+            // records, consecutive lanes to consecutive slots.  (Each lane looping over its own hits made every wavefront run
+            // the ~95-instruction body as often as its busiest lane had hits: 3-4 times for ~0.6 hits per lane.)
+            {
+                uint64_t m0 = 0, m1 = 0;
+                uint32_t has = 0;
+                if (cnt && want_markers) {
                     uint32_t ba = 0, bb = 0;
                     if (!paired) {
-                        if (L >= 66 && L <= 400) { has = true; ba = rel; bb = rel + (uint32_t)(L / 2); }   // sketch.rs:625-656, :923
+                        if (L >= 66 && L <= 400) { has = 1; ba = rel; bb = rel + (uint32_t)(L / 2); }       // sketch.rs:625-656, :923
                     } else if (s2 - s1 >= 33 && e2 - s2 >= 33) {                                             // sketch.rs:659-688
-                        has = true;
+                        has = 1;
                         ba = (uint32_t)((int64_t)(s1 + bias) - a0);
                         bb = (uint32_t)((int64_t)(s2 + bias) - a0);
                     }
@@ -277,23 +315,41 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                         const uint64_t wa64 = win64(sF, ba), wb64 = win64(sF, bb);
                         m0 = (uint64_t)even16(wa64) | ((uint64_t)even16(wb64) << 32);
                         m1 = (uint64_t)even16(wa64 << 2) | ((uint64_t)even16(wb64 << 2) << 32);
-                        rid |= RID_MARKER_BIT;
                     }
                 }
-                for (uint32_t w = 0; w < nw; w++) {
-                    uint32_t m = s_mask[w][tid];
-                    while (m) {   // highest bit first = ascending k-mer index
-                        const uint32_t b = 31u - (uint32_t)__clz((int)m);
-                        m &= ~(1u << b);
-                        const uint32_t i = w * 32 + (31u - b);
-                        if (o < slot_cap) {
-                            const uint64_t ft = win64(sF, rel + i);
-                            const uint64_t fk = ft >> (64 - 2 * K), rk = revcomp_top<K>(ft);
-                            const uint64_t h = mm_hash64(fk < rk ? fk : rk);
-                            slot_rec[out0 + o] = OccRec{h, rid, m0, m1};
-                        }
-                        o++;
-                    }
+                s_m0[tid] = m0;
+                s_m1[tid] = m1;
+                s_first[tid] = (before + x - cnt) | (has << 31);
+                s_rel[tid] = rel;
+                if (tid == 0) s_first[RTPB] = total;
+            }
+            __syncthreads();
+            for (uint32_t hix = tid; hix < total; hix += RTPB) {
+                uint32_t lo = 0, hi = RTPB;                                     // owner: the last lane whose first hit is <= hix
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((s_first[mid] & 0x7FFFFFFFu) <= hix) lo = mid; else hi = mid;
+                }
+                // (lanes without hits share the start offset of the next lane with hits: the LAST lane with that offset that
+                //  actually owns hix is the one whose successor starts beyond it — the search above returns exactly that lane)
+                const uint32_t f = s_first[lo];
+                uint32_t j = hix - (f & 0x7FFFFFFFu);                           // the j-th hit of lane `lo`
+                uint32_t i = 0;
+                for (uint32_t w = 0; w < MASKW; w++) {
+                    uint32_t m = s_mask[w][lo];
+                    const uint32_t c = (uint32_t)__popc(m);
+                    if (j >= c) { j -= c; continue; }
+                    for (; j; j--) m &= ~(0x80000000u >> __clz((int)m));       // drop the j highest set bits
+                    i = w * 32 + (uint32_t)__clz((int)m);
+                    break;
+                }
+                const uint32_t o = base_prev + hix;
+                if (o < slot_cap) {
+                    const uint64_t ft = win64(sF, s_rel[lo] + i);
+                    const uint64_t fk = ft >> (64 - 2 * K), rk = revcomp_top<K>(ft);
+                    const uint64_t h = mm_hash64(fk < rk ? fk : rk);
+                    const uint64_t rid = (rec_base + pass + lo) | ((f >> 31) ? RID_MARKER_BIT : 0ull);
+                    slot_rec[out0 + o] = OccRec{h, rid, s_m0[lo], s_m1[lo]};
                 }
             }
             base_prev += total;
