@@ -253,19 +253,21 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                 };
                 uint32_t A0 = next_word(0), A1 = next_word(1), A2 = next_word(2);
                 uint32_t Bm = 0, B0 = rcword(A0), B1 = rcword(A1), B2 = rcword(A2);  // (Bm only feeds garbage bits of group 0)
-                uint32_t mask = 0;
                 const uint32_t n_half = (nh_max + 7) >> 3;                           // half-groups of 8 k-mers (uniform per wave)
                 for (uint32_t hg = 0; hg < n_half; hg += 2) {
+                    uint32_t mask = 0;
                     kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
                     if (hg + 1 < n_half) {
                         kmer_steps8<K, 8, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
                         A0 = A1; A1 = A2; A2 = next_word((hg >> 1) + 3);
                         Bm = B0; B0 = B1; B1 = B2; B2 = rcword(A2);
+                    } else {
+                        mask <<= 8;                                                  // a last half-group: its 8 k-mers are the top byte
                     }
-                    // 32 k-mers per mask word: k-mer i <-> bit 31 - (i & 31) of word i >> 5
-                    const uint32_t done = min(hg + 2, n_half);                       // half-groups finished so far
-                    if ((done & 3u) == 0) { s_mask[(done >> 2) - 1][tid] = mask; mask = 0; }
-                    else if (done == n_half) s_mask[done >> 2][tid] = mask << (8 * (4 - (done & 3u)));   // last, partly filled word
+                    // k-mer i <-> bit 31 - (i & 31) of word i >> 5: a group of 16 is one 16-bit half of its word, even groups the
+                    // upper half.  Stored as halves (ds_write_b16): no "is the word complete" bookkeeping in the loop; whatever a
+                    // half that was never written holds lies beyond nh and is cleared with the tail below.
+                    reinterpret_cast<uint16_t*>(&s_mask[hg >> 2][tid])[((hg >> 1) & 1u) ^ 1u] = (uint16_t)mask;
                 }
             }
             // count this lane's real hits (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)
