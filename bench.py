@@ -139,7 +139,7 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     del dk
     torch.cuda.synchronize()
     t2 = time.time()
-    if world > 1 and db_mode == "shard":      # every rank generated the same database and keeps the postings of its k-mer range
+    if db_mode == "shard":      # every rank generated the same database and keeps the postings of its k-mer range
         bounds = S.shard_bounds((2**64 - 1) // c - 1, world)
         db = S.Database(ctx, kmers.data_ptr(), goff.data_ptr(), device_ptrs=True, n_genomes=n_total, shard=(bounds, world, rank))
     else:
@@ -217,6 +217,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 during the run (RCCL prints a
+    # version banner there when a communicator is created) is sent to stderr until the line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -255,8 +260,11 @@ def main():
     log(f"[bench] building workload {wl} on {world} GPU(s), db {db_mode} ...")
     db, n_total, community, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
     comm = None
-    if world > 1 and db_mode == "shard":
-        comm = SH.torch_callback_comm(dist, device) if (shared_gpu or dist.get_backend() != "nccl") else SH.rccl_comm(dist, ctx, device)
+    if db_mode == "shard":
+        if world == 1:      # the sharded code path with a one-rank RCCL communicator: the exchange's own cost, nothing on the wire
+            comm = S.Comm(0, 1, ctx=ctx, rccl_id=S.Comm.rccl_unique_id())
+        else:
+            comm = SH.torch_callback_comm(dist, device) if (shared_gpu or dist.get_backend() != "nccl") else SH.rccl_comm(dist, ctx, device)
     t0 = time.time()
     read_sets = []                           # distinct samples, rotated over the steps so that the probe is never cache-warm
     for i in range(n_sets):
@@ -497,6 +505,14 @@ def main():
                                    "note": "C++ restatement of the reference CPU path (oracle/); the reference sketches one sample on one thread and probes genomes on all threads; value = extrapolation to one whole step"}
         except Exception as e:  # the baseline leg must never sink the GPU measurement
             out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    sys.stdout.flush()
+    try:                      # C stdio of the libraries (RCCL's banner) is still buffered: flush it while fd 1 is stderr
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
     db.close()

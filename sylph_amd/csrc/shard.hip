@@ -161,33 +161,67 @@ __device__ __forceinline__ uint32_t owner_of(uint64_t hit, uint64_t n_genomes, c
     return lo;
 }
 constexpr uint32_t MAX_WORLD = 64;
+// Wavefront-aggregated "take a slot in bin r": lanes of a wave that want the same bin are served by ONE atomic (hits arrive in
+// runs of one sample, i.e. one owner: a plain per-lane atomic would serialise 64 lanes on one LDS word).  Returns the lane's
+// slot; every active lane must call it.
+__device__ __forceinline__ uint32_t wave_take(uint32_t* bins, uint32_t r, bool valid) {
+    uint32_t slot = 0;
+    unsigned long long todo = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63;
+    while (todo) {
+        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1;
+        const uint32_t r0 = (uint32_t)__shfl((int)r, (int)leader);
+        const unsigned long long same = __ballot(valid && r == r0) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&bins[r0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, (int)leader);
+        if (valid && r == r0) slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
 // counts[r] = hits owned by rank r (LDS histogram per workgroup, one global atomic per bin and workgroup)
 __global__ __launch_bounds__(256) void owner_count_kernel(const uint64_t* __restrict__ hits, uint32_t n, uint64_t n_genomes,
                                                           const uint64_t* __restrict__ prefix, uint32_t world, uint32_t* __restrict__ counts) {
     __shared__ uint32_t bins[MAX_WORLD];
     if (threadIdx.x < MAX_WORLD) bins[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&bins[owner_of(hits[i], n_genomes, prefix, world)], 1u);
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool valid = i < n;
+        (void)wave_take(bins, valid ? owner_of(hits[i], n_genomes, prefix, world) : 0u, valid);
+    }
     __syncthreads();
     if (threadIdx.x < world && bins[threadIdx.x]) atomicAdd(&counts[threadIdx.x], bins[threadIdx.x]);
 }
-// out[start[r] + k] = k-th hit of owner r (any order inside a group: the owner sorts), rows re-based to the owner's samples
+// out[start[r] + k] = k-th hit of owner r (any order inside a group: the owner sorts), rows re-based to the owner's samples.
+// A workgroup bins SCATTER_ITEMS x 256 hits in LDS before it takes its ranges with one global atomic per bin: a single word
+// sustains only ~90 atomics per microsecond on this chip, and with one atomic per 256 hits the cursors were the whole kernel.
+constexpr int SCATTER_ITEMS = 16;
 __global__ __launch_bounds__(256) void owner_scatter_kernel(const uint64_t* __restrict__ hits, uint32_t n, uint64_t n_genomes,
                                                             const uint64_t* __restrict__ prefix, uint32_t world, const uint32_t* __restrict__ start,
                                                             uint32_t* __restrict__ cursor, uint64_t* __restrict__ out) {
     __shared__ uint32_t bins[MAX_WORLD], base[MAX_WORLD];
-    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+    const uint32_t tile = 256 * SCATTER_ITEMS;
+    for (uint32_t i0 = blockIdx.x * tile; i0 < n; i0 += gridDim.x * tile) {
         if (threadIdx.x < MAX_WORLD) bins[threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t i = i0 + threadIdx.x;
-        uint32_t r = 0, slot = 0;
-        uint64_t h = 0;
-        if (i < n) { h = hits[i]; r = owner_of(h, n_genomes, prefix, world); slot = atomicAdd(&bins[r], 1u); }
+        uint64_t h[SCATTER_ITEMS];
+        uint32_t r[SCATTER_ITEMS], slot[SCATTER_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SCATTER_ITEMS; j++) {
+            const uint32_t i = i0 + j * 256 + threadIdx.x;
+            const bool valid = i < n;
+            h[j] = valid ? hits[i] : 0;
+            r[j] = valid ? owner_of(h[j], n_genomes, prefix, world) : 0xFFFFFFFFu;
+            slot[j] = wave_take(bins, valid ? r[j] : 0u, valid);
+        }
         __syncthreads();
         if (threadIdx.x < world && bins[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], bins[threadIdx.x]);
         __syncthreads();
-        if (i < n) out[start[r] + base[r] + slot] = h - ((prefix[r] * n_genomes) << 32);
+#pragma unroll
+        for (int j = 0; j < SCATTER_ITEMS; j++)
+            if (r[j] != 0xFFFFFFFFu) out[start[r[j]] + base[r[j]] + slot[j]] = h[j] - ((prefix[r[j]] * n_genomes) << 32);
         __syncthreads();
     }
 }
@@ -263,6 +297,8 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         const uint64_t G = db->n_genomes;
         hipStream_t st = ctx->stream;
 
+        HostPhase ph_all(ctx, "sharded contain: total");
+        std::unique_ptr<HostPhase> ph(new HostPhase(ctx, "shard 0: stage tables"));
         // ---- local tables on the device
         std::vector<SampleRef> mine(n_local);
         uint64_t total = 0;
@@ -289,6 +325,7 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         }
         for (auto& r : mine) { r.chunk0 = 0; r.pad = 0; }
 
+        ph.reset(); ph.reset(new HostPhase(ctx, "shard 1: split + all-gather meta"));
         // ---- 1. slice boundaries of every local table, all-gathered: block = [n_local | split[MAX_LOCAL][W + 1]] u64
         const uint64_t meta_words = 1 + (uint64_t)MAX_LOCAL * (W + 1);
         // x_meta: [my block | gathered blocks (W) | bounds (W + 1) | refs | segs]
@@ -324,6 +361,7 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         const uint64_t S_total = prefix[W];
         SY_REQUIRE(S_total * std::max<uint64_t>(G, 1) < (1ull << 32) - 1, "samples x genomes of one step must stay below 2^32");
 
+        ph.reset(); ph.reset(new HostPhase(ctx, "shard 2: pack + all-to-all slices"));
         // ---- 2. all-to-all of the slices.  Block for rank d: [k-mers of slice (s, d), s = 0.. | counts of slice (s, d) | pad to 8]
         std::vector<uint64_t> send_off(W + 1, 0), recv_off(W + 1, 0);
         auto block_bytes = [&](uint32_t src, uint32_t dst) {
@@ -353,13 +391,14 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
             }
             if (!segs.empty()) {
                 ctx->h2d(d_segs, segs.data(), segs.size() * sizeof(Seg));
-                const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (max_words + 256 * 16 - 1) / (256 * 16));
+                const uint32_t gy = (uint32_t)std::min<uint64_t>(1024, (max_words + 256 * 4 - 1) / (256 * 4));
                 hipLaunchKernelGGL(copy_segments_kernel, dim3((uint32_t)segs.size(), std::max(1u, gy)), dim3(256), 0, st, d_segs);
                 SY_HIP(hipGetLastError());
             }
         }
         comm->all_to_all(db->x_send.p, send_off.data(), db->x_recv.p, recv_off.data(), st);
 
+        ph.reset(); ph.reset(new HostPhase(ctx, "shard 3: probe"));
         // ---- 3. probe every received slice against the resident shard; row = global sample index * G + genome
         std::vector<SampleRef> refs(S_total);
         for (uint32_t r = 0; r < W; r++) {
@@ -377,6 +416,7 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         uint32_t max_count = 0, n_hits = 0;
         if (S_total) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
 
+        ph.reset(); ph.reset(new HostPhase(ctx, "shard 4: owner counts + all-gather sizes"));
         // ---- 4. group the hits by owner rank; all-gather the group sizes: block = [count for rank 0..W-1 | largest count value]
         SY_REQUIRE(W <= MAX_WORLD, "at most %u ranks", MAX_WORLD);
         // x_meta (reused): [prefix (W + 1) u64 | my sizes (W + 1) u32 | cursors (W) u32 | starts (W) u32 | gathered sizes W x (W + 1) u32]
@@ -397,6 +437,7 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         std::vector<uint32_t> sizes((size_t)W * (W + 1));
         ctx->d2h(sizes.data(), d_allsizes, sizes.size() * 4);
         auto n_from_to = [&](uint32_t src, uint32_t dst) { return (uint64_t)sizes[(size_t)src * (W + 1) + dst]; };
+        ph.reset(); ph.reset(new HostPhase(ctx, "shard 5: scatter + all-to-all hits"));
         // ---- 5. all-to-all of the hit groups
         std::vector<uint64_t> hs_off(W + 1, 0), hr_off(W + 1, 0);
         std::vector<uint32_t> start(W, 0);
@@ -412,7 +453,7 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         db->x_send.reserve(hs_off[W] + 64);
         if (n_hits) {
             ctx->h2d(d_start, start.data(), (size_t)W * 4);
-            hipLaunchKernelGGL(owner_scatter_kernel, dim3((uint32_t)std::min<uint64_t>(1024, grid_for64(n_hits))), dim3(256), 0, st,
+            hipLaunchKernelGGL(owner_scatter_kernel, dim3((uint32_t)std::min<uint64_t>(1024, grid_for64(n_hits, 256 * SCATTER_ITEMS))), dim3(256), 0, st,
                                db->hits.as<uint64_t>(), n_hits, G, d_prefix, W, d_start, d_cursor, db->x_send.as<uint64_t>());
             SY_HIP(hipGetLastError());
         }
@@ -422,8 +463,10 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
             ScopedKernelTimer t(ctx, "exchange");
             comm->all_to_all(db->x_send.p, hs_off.data(), db->hits.p, hr_off.data(), st);
         }
+        ph.reset(); ph.reset(new HostPhase(ctx, "shard 6: sort + assemble + copy out"));
         // ---- 6. sort + assemble this rank's samples
         finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false);
+        ph.reset();
         const ResultLayout& lay = db->lay;
         const char* h = (const char*)db->h_res;
         *cov_off = (const uint64_t*)h;
