@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
+    ap.add_argument("--sketch-workers", type=int, default=0,
+                    help="samples of a step sketched concurrently, each worker with its own context/stream (default: 2 when a step has "
+                         "several samples — the reference sketches samples on parallel threads too, sketch.rs:313 — else 1)")
     ap.add_argument("--seed", type=int, default=20250711)
     args = ap.parse_args()
 
@@ -294,21 +297,41 @@ def main():
 
     step_no = [0]
     last = {}
+    # several samples per step: two sketch workers, each with its own context (stream, memory pool), run on two host threads — the
+    # small launch-bound kernels of one sample's dedup/count stage fill the gaps of the other's seeding kernel
+    n_workers = args.sketch_workers or (2 if spg > 1 else 1)
+    n_workers = max(1, min(n_workers, spg))
+    worker_ctx = [ctx] + [S.Context(local) for _ in range(n_workers - 1)]
+    pool = None
+    if n_workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=n_workers)
+
+    def sketch_one(wctx, rs):
+        sk = S.ReadSketcher(wctx, c=c_reads, k=k, paired=not long_mode)
+        if long_mode:
+            for start, o, nrec, nb in rs["batches"]:
+                sk.push_device(rs["bases"].data_ptr() + start, o.data_ptr(), nrec, nb)
+        else:
+            sk.push_device(rs["bases"].data_ptr(), rs["rec_off"].data_ptr(), rs["n_records"], rs["n_bases"])
+        dk, dc, n, dup = sk.finish_device()
+        return sk, (dk, dc, n, dup)
 
     def step(collect=None):
         t_a = time.perf_counter()
-        sessions, tables = [], []
-        for s in range(spg):
-            rs = read_sets[(step_no[0] * spg + s) % n_sets]
-            sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode)
-            if long_mode:
-                for start, o, nrec, nb in rs["batches"]:
-                    sk.push_device(rs["bases"].data_ptr() + start, o.data_ptr(), nrec, nb)
-            else:
-                sk.push_device(rs["bases"].data_ptr(), rs["rec_off"].data_ptr(), rs["n_records"], rs["n_bases"])
-            dk, dc, n, dup = sk.finish_device()
-            sessions.append(sk)
-            tables.append((dk, dc, n, dup))
+        sets = [read_sets[(step_no[0] * spg + s) % n_sets] for s in range(spg)]
+        if pool is None:
+            done = [sketch_one(ctx, rs) for rs in sets]
+        else:   # worker w takes samples w, w + n_workers, ...; results keep the sample order
+            def run(w):
+                return [sketch_one(worker_ctx[w], sets[i]) for i in range(w, spg, n_workers)]
+            parts = list(pool.map(run, range(n_workers)))
+            done = [None] * spg
+            for w, part in enumerate(parts):
+                for j, item in enumerate(part):
+                    done[w + j * n_workers] = item
+        sessions = [d[0] for d in done]
+        tables = [d[1] for d in done]
         t_b = time.perf_counter()
         refs = [(dk, dc, n) for dk, dc, n, _ in tables]
         if comm is not None:
@@ -337,7 +360,8 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    ctx.profile(not args.no_kernel_timers)
+    for wc in worker_ctx:
+        wc.profile(not args.no_kernel_timers)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -356,8 +380,16 @@ def main():
 
     # ---- per-kernel timing from HIP events recorded on the launch stream inside the library ----
     fams = ("seeds", "compact", "annotate", "sort", "replay", "probe", "exchange")
-    fam = {f: ctx.kernel_stats(f) for f in fams}
-    ctx.profile(False)
+    fam = {}
+    for f in fams:   # summed over the sketch workers' contexts
+        tot = [0.0, 0]
+        for wc in worker_ctx:
+            ms, nl = wc.kernel_stats(f)
+            tot[0] += ms
+            tot[1] += nl
+        fam[f] = tuple(tot)
+    for wc in worker_ctx:
+        wc.profile(False)
     step("final")   # untimed: seed occurrences for the roofline's algorithmic bytes, results for --verify
     t_sketch = float(np.mean([r[0] for r in rows]))
     t_profile = float(np.mean([r[1] for r in rows]))
@@ -373,7 +405,7 @@ def main():
         "value": round(value, 3), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": spg, "reads_per_sample_gbp": round(n_bases / 1e9, 4),
+        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": spg, "sketch_workers_per_gpu": n_workers, "reads_per_sample_gbp": round(n_bases / 1e9, 4),
                    "distinct_read_sets_rotated": n_sets, "genomes": n_total, "db_kmers_per_shard": dbstats["shard_kmers"],
                    "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)",
                    "seed_mode": "avx2_compat", "parallelism": parallelism,
@@ -413,7 +445,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "seeds_slots_kernel<31,1>" if long_mode else "reads_kernel<31,1>", "achieved": round(achieved, 1),
                            "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
-                           "note": f"integer-VALU issue bound: {ipk} VALU wave-instructions per hashed k-mer (SQ counters in profiles/)",
+                           "note": f"integer-VALU issue bound: {ipk} VALU wave-instructions per hashed k-mer (SQ counters in profiles/)" +
+                                   (f"; {n_workers} sketch workers: launch durations include time shared with the other worker's kernels" if n_workers > 1 else ""),
                            # secondary ceiling: VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s
                            "valu_ceiling": {"instr_per_kmer": ipk, "kmers_per_launch": int(hashed),
                                             "min_ms": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3, 4),
@@ -518,6 +551,10 @@ def main():
     db.close()
     if comm is not None:
         comm.close()
+    if pool is not None:
+        pool.shutdown()
+    for wc in worker_ctx[1:]:
+        wc.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
