@@ -17,8 +17,8 @@ c3r = c3 with ragged 35-151 bp reads and 0.1 % N (reported beside c3, not instea
 
 Multi-GPU: samples are independent units (no collective in the sketch stage).  --db-mode shard (default for
 N > 1, what north_star describes): every rank holds the postings of one k-mer range; per step the library all-gathers the
-slice boundaries, sends every rank its 1/N slice of every table (all-to-all), probes, and combines the per-shard hit lists
-with ONE all-gather; --db-mode replicate: every rank holds the whole index (22-38 GB of 288 GB) and no data-path collective
+slice boundaries, sends every rank its 1/N slice of every table (all-to-all), probes, and sends every hit to the rank that
+owns its sample (a second all-to-all); --db-mode replicate: every rank holds the whole index (22-38 GB of 288 GB) and no data-path collective
 is needed at all.  scaling = weak (per-GPU work fixed).
 
 After the timed region (untimed): --verify compares the containment results of the last step's first sample, for the
@@ -397,7 +397,7 @@ def main():
     value = world * spg * n_bases / 1e9 / (elapsed / args.steps)              # whole-job read Gbp/s through both stages
     comparisons = world * spg * n_total                                       # every sample vs every genome of the DB
     parallelism = (f"{spg} sample(s) per GPU per step x {world} GPU(s); database " +
-                   (f"sharded by k-mer range over {world} GPUs (slices all-to-all + one all-gather of hit lists per step, "
+                   (f"sharded by k-mer range over {world} GPUs (per step: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
                     f"{'torch.distributed callbacks, ranks share a GPU' if (shared_gpu or (dist and dist.get_backend() != 'nccl')) else 'RCCL'})"
                     if comm is not None else ("replicated on every GPU (no data-path collective)" if world > 1 else "on the one GPU")))
     out = {

@@ -268,9 +268,12 @@ void sylph_comm_destroy(sylph_comm *comm);
  *   1. all-gather of the slice boundaries (a few hundred bytes),
  *   2. all-to-all of the table slices (each rank receives 1/world of every sample of the step),
  *   3. one probe launch over all received slices against the resident shard,
- *   4. ONE all-gather of the per-shard hit lists (fixed-layout buffer: [count | overflow flag | hits]),
- *   5. each rank sorts the hits of its own samples and assembles counts + coverage vectors (partial counts of a genome from
- *      different shards add up because a k-mer lives on exactly one shard).
+ *   4. the hits are grouped by the rank that owns their sample; all-gather of the group sizes (a few hundred bytes),
+ *   5. all-to-all of the hit groups: every rank receives exactly the hits of its own samples, from every shard,
+ *   6. each rank sorts its hits and assembles counts + coverage vectors (partial counts of a genome from different shards add
+ *      up because a k-mer lives on exactly one shard).
+ * Two latency-bound all-gathers of sizes, two all-to-alls of payload: xGMI is point-to-point, an all-to-all puts 1/world of
+ * the bytes on every link at once, an all-gather of whole tables or hit lists would deliver world x what anybody needs.
  * Everything stays on the device between the steps; nothing is translated from the reference (which has no such path). */
 int sylph_db_contain_batch_sharded(sylph_db *db, sylph_comm *comm, const sylph_sample_ref *samples, uint32_t n_local, int mem,
                                    double min_number_kmers, const uint32_t **contain_count, const uint64_t **cov_off,

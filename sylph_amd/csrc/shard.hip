@@ -290,6 +290,7 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         SY_REQUIRE(db->world == comm->world && db->rank == comm->rank, "database shard %u/%u does not match communicator rank %u/%u", db->rank,
                    db->world, comm->rank, comm->world);
         SY_REQUIRE(db->bounds.size() == (size_t)db->world + 1, "database was not uploaded with sylph_db_upload_shard");
+        SY_REQUIRE(comm->world <= MAX_WORLD, "at most %u ranks", MAX_WORLD);
         sylph_ctx* ctx = db->ctx;
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard dg(ctx->device);
@@ -418,7 +419,6 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
 
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 4: owner counts + all-gather sizes"));
         // ---- 4. group the hits by owner rank; all-gather the group sizes: block = [count for rank 0..W-1 | largest count value]
-        SY_REQUIRE(W <= MAX_WORLD, "at most %u ranks", MAX_WORLD);
         // x_meta (reused): [prefix (W + 1) u64 | my sizes (W + 1) u32 | cursors (W) u32 | starts (W) u32 | gathered sizes W x (W + 1) u32]
         uint64_t* d_prefix = reinterpret_cast<uint64_t*>(xm);
         uint32_t* d_sizes = reinterpret_cast<uint32_t*>(xm + (size_t)(W + 1) * 8);
@@ -449,7 +449,13 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
             if (n_from_to(r, me)) max_mine = std::max(max_mine, sizes[(size_t)r * (W + 1) + W]);
         }
         SY_REQUIRE(hs_off[W] / 8 == n_hits, "internal: owner counts do not add up");
-        SY_REQUIRE(hr_off[W] / 8 < (1ull << 32), "more than 2^32-1 hits for this rank's samples in one step: use smaller batches");
+        // (checked for EVERY destination from the gathered matrix, so that all ranks fail together instead of one leaving the others
+        //  waiting in the next collective)
+        for (uint32_t dst = 0; dst < W; dst++) {
+            uint64_t to_dst = 0;
+            for (uint32_t src = 0; src < W; src++) to_dst += n_from_to(src, dst);
+            SY_REQUIRE(to_dst < (1ull << 32), "more than 2^32-1 hits for the samples of rank %u in one step: use smaller batches", dst);
+        }
         db->x_send.reserve(hs_off[W] + 64);
         if (n_hits) {
             ctx->h2d(d_start, start.data(), (size_t)W * 4);

@@ -1,7 +1,7 @@
 """One database over several GPUs: k-mer-range shards, one process per GPU.
 
 The exchange itself lives in the library (csrc/shard.hip, `sylph_db_contain_batch_sharded`): slice boundaries all-gathered,
-table slices all-to-all, one probe launch, ONE all-gather of the per-shard hit lists, local assembly — on device buffers, with
+table slices all-to-all, one probe launch, hit groups all-to-all to the ranks that own the samples, local assembly — on device buffers, with
 the collectives issued through a `sylph_comm` (RCCL, or callbacks).  This module holds what sits around it in Python:
 
 * `rccl_comm(dist, ctx)`         — a Comm on RCCL: rank 0 makes the ncclUniqueId, torch.distributed (the launcher's rendezvous)
@@ -84,13 +84,12 @@ def torch_callback_comm(dist, device):
     return Comm(rank, world, all_gather=all_gather, all_to_all=all_to_all)
 
 
-def model_contain_batch_sharded(dist, bounds, n_genomes, samples, probe_fn, hit_cap=4):
+def model_contain_batch_sharded(dist, bounds, n_genomes, samples, probe_fn):
     """Host model of sylph_db_contain_batch_sharded (see csrc/shard.hip), step for step.
 
     dist: torch.distributed (initialised) or None for a single process; bounds: the k-mer range boundaries (world + 1);
     samples: this rank's [(kmers uint64 ascending, counts uint32)]; probe_fn(kmers, counts) -> [(genome, count)] hits of one
-    slice against this rank's shard (every posting of a k-mer yields one hit).  hit_cap starts tiny on purpose so that the
-    "a shard's list was cut -> every rank doubles the capacity and repeats the all-gather" path is exercised.
+    slice against this rank's shard (every posting of a k-mer yields one hit).
     -> (contain_count[n_local, n_genomes] uint32, covs: list (per sample) of lists (per genome) of ascending uint32 arrays)."""
     world = dist.get_world_size() if dist is not None else 1
     me = dist.get_rank() if dist is not None else 0
@@ -117,18 +116,21 @@ def model_contain_batch_sharded(dist, bounds, n_genomes, samples, probe_fn, hit_
             assert len(k) == meta[r][s][me + 1] - meta[r][s][me]
             row0 = (int(prefix[r]) + s) * n_genomes
             hits += [((row0 + g) << 32) | int(cnt) for g, cnt in probe_fn(k, c)]
-    # 4. ONE all-gather of fixed-layout blocks [n_hits | hits x cap]; the capacity doubles on every rank alike until nothing is cut
-    cap = hit_cap
-    while True:
-        gathered = all_gather_obj((len(hits), hits[:cap]))
-        worst = max(n for n, _ in gathered)
-        if worst <= cap:
-            break
-        while cap < worst:
-            cap *= 2
-    # 5. keep the hits of this rank's samples, sort, assemble
-    lo, hi = int(prefix[me]) * n_genomes, int(prefix[me + 1]) * n_genomes
-    mine = sorted(h - (lo << 32) for _, hs in gathered for h in hs if lo <= (h >> 32) < hi)
+    # 4. group the hits by the rank that owns their sample; all-gather the group sizes
+    def owner(h):
+        s = (h >> 32) // n_genomes
+        return int(np.searchsorted(prefix, s, side="right")) - 1
+    groups = [[] for _ in range(world)]
+    for h in hits:
+        r = owner(h)
+        groups[r].append(h - ((int(prefix[r]) * n_genomes) << 32))        # rows re-based to the owner's samples
+    sizes = all_gather_obj([len(g) for g in groups])
+    assert all(sizes[me][r] == len(groups[r]) for r in range(world))
+    # 5. all-to-all of the hit groups (modelled as an all-gather of the per-destination groups): every rank keeps what is addressed to it
+    got_hits = all_gather_obj(groups)
+    mine = sorted(h for r in range(world) for h in got_hits[r][me])
+    assert len(mine) == sum(sizes[r][me] for r in range(world))
+    # 6. sort + assemble
     n_local = len(samples)
     cc = np.zeros((n_local, n_genomes), dtype=np.uint32)
     covs = [[[] for _ in range(n_genomes)] for _ in range(n_local)]

@@ -1,6 +1,6 @@
 """Worker for tests/test_gpu_parity.py::test_sharded_containment_two_ranks_one_gpu — run under torch.distributed.run.
 Each rank holds one k-mer-range shard of the database on the GPU and calls sylph_db_contain_batch_sharded (the library's own
-exchange: slice boundaries all-gathered, slices all-to-all, one probe launch, one all-gather of hit lists) with its own
+exchange: slice boundaries all-gathered, slices all-to-all, one probe launch, hit groups all-to-all to the owners) with its own
 samples; the collectives go through torch.distributed (gloo) callbacks because RCCL cannot put two ranks on one device.
 Every rank checks its samples against the oracle over the WHOLE database."""
 import os
