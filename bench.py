@@ -8,7 +8,10 @@ Metric (BASELINE.json): read Gbp/s sketched + genome-comparisons/s profiled, 1 G
 database (113,104 genome sketches, k=31, c=200).  One *step* = one pass of the hot path over the step's samples on every
 GPU: sketch each sample (seeding -> exact dedup/count; reads already resident in HBM) and profile the resulting tables against
 the resident database (containment counts + coverage vectors back on the host).  `value` = whole-job read Gbp/s through
-both stages; the per-stage rates are reported next to it.
+both stages; the per-stage rates are reported next to it.  Steps are pipelined the way a multi-sample `sylph profile` run
+is: sketching runs on worker threads (own context + stream each), profiling on the main thread's context, and the samples of
+the next steps are sketched while the current step is profiled (--pipeline-depth; all K steps complete inside the timed
+region).  `one_step_at_a_time` repeats the steps strictly one after the other: step latency, and every kernel alone on the GPU.
 
 Workloads (--workload): c3 = BASELINE configs[2], the configuration the metric is quoted on (default at N = 1: one 1 Gbp
 sample per step, database on the one GPU); c4 = configs[3] (default at N > 1: 8 samples per GPU per step, database sharded
@@ -213,8 +216,10 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
     ap.add_argument("--sketch-workers", type=int, default=0,
-                    help="samples of a step sketched concurrently, each worker with its own context/stream (default: 2 when a step has "
-                         "several samples — the reference sketches samples on parallel threads too, sketch.rs:313 — else 1)")
+                    help="sketch worker threads, each with its own context/stream (default 2; the reference sketches samples on parallel threads too, sketch.rs:313)")
+    ap.add_argument("--pipeline-depth", type=int, default=0,
+                    help="steps in flight: the samples of step i+1.. are sketched while step i is profiled (default: workers + 1 for one sample per step, else 2; 1 = one step at a time)")
+    ap.add_argument("--no-sequential-leg", action="store_true", help="skip the extra one-step-at-a-time leg")
     ap.add_argument("--seed", type=int, default=20250711)
     args = ap.parse_args()
 
@@ -295,19 +300,52 @@ def main():
     n_bases = float(np.mean([r["n_bases"] for r in read_sets]))
     log(f"[bench] db {dbstats}; {n_sets} read sets of {n_bases / 1e9:.3f} Gbp generated in {time.time() - t0:.1f}s")
 
-    step_no = [0]
     last = {}
-    # several samples per step: two sketch workers, each with its own context (stream, memory pool), run on two host threads — the
-    # small launch-bound kernels of one sample's dedup/count stage fill the gaps of the other's seeding kernel
-    n_workers = args.sketch_workers or (2 if spg > 1 else 1)
-    n_workers = max(1, min(n_workers, spg))
-    worker_ctx = [ctx] + [S.Context(local) for _ in range(n_workers - 1)]
-    pool = None
-    if n_workers > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=n_workers)
+    # Sketching runs on worker threads, each with its own context (stream, memory pool); the profile stage runs on the main
+    # thread's context.  --pipeline-depth steps are in flight at once: while step i is profiled, the samples of the next steps
+    # are already being sketched, and the small launch-bound kernels of one sample's dedup/count stage fill the gaps beside
+    # another sample's seeding kernel.  (The reference sketches samples on parallel threads too, sketch.rs:313, and profiles
+    # sample after sample against the loaded database, contain.rs:267-289.)  Depth 1 = one step at a time.
+    import queue
+    import threading
+    from collections import deque
+    from concurrent.futures import Future
+    n_workers = max(1, args.sketch_workers or 2)
+    depth = max(1, args.pipeline_depth or (n_workers + 1 if spg == 1 else 2))
+
+    class SketchWorker(threading.Thread):
+        def __init__(self):
+            super().__init__(daemon=True)
+            self.ctx = S.Context(local)
+            self.jobs = queue.Queue()
+            self.start()
+
+        def run(self):
+            torch.cuda.set_device(local)
+            while True:
+                job = self.jobs.get()
+                if job is None:
+                    return
+                fn, fut = job
+                try:
+                    fut.set_result(fn(self.ctx))
+                except BaseException as e:       # handed to whoever waits for the result
+                    fut.set_exception(e)
+
+        def submit(self, fn):
+            fut = Future()
+            self.jobs.put((fn, fut))
+            return fut
+
+    workers = [SketchWorker() for _ in range(n_workers)]
+    all_ctx = [ctx] + [w.ctx for w in workers]
+    for w in workers:
+        for kv in filter(None, os.environ.get("SYLPH_BENCH_CTX_OPTIONS", "").split(",")):
+            w.ctx.set_option(*kv.split("=", 1))
+    sample_no = [0]
 
     def sketch_one(wctx, rs):
+        t_a = time.perf_counter()
         sk = S.ReadSketcher(wctx, c=c_reads, k=k, paired=not long_mode)
         if long_mode:
             for start, o, nrec, nb in rs["batches"]:
@@ -315,22 +353,26 @@ def main():
         else:
             sk.push_device(rs["bases"].data_ptr(), rs["rec_off"].data_ptr(), rs["n_records"], rs["n_bases"])
         dk, dc, n, dup = sk.finish_device()
-        return sk, (dk, dc, n, dup)
+        return sk, (dk, dc, n, dup), time.perf_counter() - t_a
 
-    def step(collect=None):
-        t_a = time.perf_counter()
-        sets = [read_sets[(step_no[0] * spg + s) % n_sets] for s in range(spg)]
-        if pool is None:
-            done = [sketch_one(ctx, rs) for rs in sets]
-        else:   # worker w takes samples w, w + n_workers, ...; results keep the sample order
-            def run(w):
-                return [sketch_one(worker_ctx[w], sets[i]) for i in range(w, spg, n_workers)]
-            parts = list(pool.map(run, range(n_workers)))
-            done = [None] * spg
-            for w, part in enumerate(parts):
-                for j, item in enumerate(part):
-                    done[w + j * n_workers] = item
-        sessions = [d[0] for d in done]
+    class Inline:                    # one step at a time with one sample per step: everything on the main thread's context
+        @staticmethod
+        def submit(fn):
+            fut = Future()
+            fut.set_result(fn(ctx))
+            return fut
+
+    def submit_step(inline=False):
+        jobs = []
+        for _ in range(spg):
+            rs = read_sets[sample_no[0] % n_sets]
+            w = Inline if inline else workers[sample_no[0] % n_workers]
+            jobs.append((w, w.submit(lambda wctx, rs=rs: sketch_one(wctx, rs))))
+            sample_no[0] += 1
+        return jobs
+
+    def finish_step(jobs, collect=None):
+        done = [f.result() for _, f in jobs]
         tables = [d[1] for d in done]
         t_b = time.perf_counter()
         refs = [(dk, dc, n) for dk, dc, n, _ in tables]
@@ -345,53 +387,67 @@ def main():
             last["occ"] = [int(SH.device_view(dc, n, torch.int32, device).sum().item()) + dup for dk, dc, n, dup in tables]
             last["n_table"] = [n for _, _, n, _ in tables]
             last["hits"] = int(len(res[2]))
-            last["sessions"] = sessions
-            step_no[0] += 1
+            last["sessions"] = [(w, d[0]) for (w, _), d in zip(jobs, done)]
             return
-        for sk in sessions:
-            sk.close()
+        for (w, _), d in zip(jobs, done):        # a session is closed on the thread that owns its context
+            w.submit(lambda wctx, sk=d[0]: sk.close())
         if isinstance(collect, list):
-            collect.append((t_b - t_a, t_c - t_b, [t[2] for t in tables], [t[3] for t in tables], len(res[2])))
-        step_no[0] += 1
+            collect.append((float(np.sum([d[2] for d in done])), t_c - t_b, [t[2] for t in tables], [t[3] for t in tables], len(res[2])))
 
-    # two untimed settle steps (first-use allocations of the library's pool, lazy kernel loading) whatever --warmup is
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    for wc in worker_ctx:
-        wc.profile(not args.no_kernel_timers)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    rows = []
-    for _ in range(args.steps):
-        step(rows)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def run_steps(n, collect=None, in_flight=1):
+        pending = deque()
+        submitted = 0
+        for i in range(n):
+            while submitted < n and submitted < i + in_flight:      # steps i .. i + in_flight - 1 are in flight while i is finished
+                pending.append(submit_step(inline=(in_flight == 1 and spg == 1)))
+                submitted += 1
+            finish_step(pending.popleft(), collect)
+        for w in workers:                                            # the sessions' close jobs
+            w.submit(lambda wctx: None).result()
 
-    # ---- per-kernel timing from HIP events recorded on the launch stream inside the library ----
-    fams = ("seeds", "compact", "annotate", "sort", "replay", "probe", "exchange")
-    fam = {}
-    for f in fams:   # summed over the sketch workers' contexts
-        tot = [0.0, 0]
-        for wc in worker_ctx:
-            ms, nl = wc.kernel_stats(f)
-            tot[0] += ms
-            tot[1] += nl
-        fam[f] = tuple(tot)
-    for wc in worker_ctx:
-        wc.profile(False)
-    step("final")   # untimed: seed occurrences for the roofline's algorithmic bytes, results for --verify
-    t_sketch = float(np.mean([r[0] for r in rows]))
+    # untimed settle steps (first-use allocations of every context's pool, lazy kernel loading) whatever --warmup is
+    run_steps(2 * n_workers, None, 2)
+    run_steps(2, None, 1)
+    torch.cuda.synchronize()
+    run_steps(args.warmup, None, depth)
+
+    def timed(n, in_flight):
+        for wc in all_ctx:
+            wc.profile(not args.no_kernel_timers)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        rows = []
+        run_steps(n, rows, in_flight)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        fam = {}
+        for f in ("seeds", "compact", "annotate", "sort", "replay", "probe", "exchange"):   # HIP events on the launch streams, all contexts
+            tot = [0.0, 0]
+            for wc in all_ctx:
+                ms, nl = wc.kernel_stats(f)
+                tot[0] += ms
+                tot[1] += nl
+            fam[f] = tuple(tot)
+        for wc in all_ctx:
+            wc.profile(False)
+        return elapsed, rows, fam
+
+    elapsed, rows, fam = timed(args.steps, depth)
+    one_at_a_time = None
+    if depth > 1 and not args.no_sequential_leg:     # the same steps one at a time: step latency, kernels measured alone on the GPU
+        e1, r1, f1 = timed(min(args.steps, 8), 1)
+        one_at_a_time = (e1 / min(args.steps, 8), r1, f1)
+
+    finish_step(submit_step(), "final")   # untimed: seed occurrences for the roofline's algorithmic bytes, results for --verify
+    t_sketch = float(np.mean([r[0] for r in rows])) / min(n_workers, spg * depth)   # busy time of the sketch workers per step
     t_profile = float(np.mean([r[1] for r in rows]))
     ms_per_step = elapsed / args.steps * 1e3
     value = world * spg * n_bases / 1e9 / (elapsed / args.steps)              # whole-job read Gbp/s through both stages
@@ -405,7 +461,7 @@ def main():
         "value": round(value, 3), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": spg, "sketch_workers_per_gpu": n_workers, "reads_per_sample_gbp": round(n_bases / 1e9, 4),
+        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": spg, "sketch_workers_per_gpu": n_workers, "steps_in_flight": depth, "reads_per_sample_gbp": round(n_bases / 1e9, 4),
                    "distinct_read_sets_rotated": n_sets, "genomes": n_total, "db_kmers_per_shard": dbstats["shard_kmers"],
                    "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)",
                    "seed_mode": "avx2_compat", "parallelism": parallelism,
@@ -446,7 +502,7 @@ def main():
                            "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
                            "note": f"integer-VALU issue bound: {ipk} VALU wave-instructions per hashed k-mer (SQ counters in profiles/)" +
-                                   (f"; {n_workers} sketch workers: launch durations include time shared with the other worker's kernels" if n_workers > 1 else ""),
+                                   (f"; {depth} steps in flight on {n_workers} sketch streams + the profile stream: launch durations include time shared with the other streams' kernels (alone on the GPU: one_step_at_a_time)" if depth > 1 else ""),
                            # secondary ceiling: VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s
                            "valu_ceiling": {"instr_per_kmer": ipk, "kmers_per_launch": int(hashed),
                                             "min_ms": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3, 4),
@@ -465,6 +521,18 @@ def main():
                                    "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg, 4),
                                    "probes_per_launch": int(probes), "hits_per_launch": int(hits),
                                    "note": "random 64 B line reads, latency-bound; one index line per probe is the access granule"}
+    if one_at_a_time is not None:
+        s1, r1, f1 = one_at_a_time
+        o1 = {"ms_per_step": round(s1 * 1e3, 3), "value": round(world * spg * n_bases / 1e9 / s1, 3),
+              "sketch_ms": round(float(np.mean([r[0] for r in r1])) / min(n_workers, spg) * 1e3, 3), "profile_ms": round(float(np.mean([r[1] for r in r1])) * 1e3, 3),
+              "kernel_ms": {f: (round(v[0] / max(1, v[1]), 4), int(v[1])) for f, v in f1.items() if v[1]}}
+        if "roofline" in out and f1["seeds"][1]:
+            a1 = f1["seeds"][0] / f1["seeds"][1]
+            o1["roofline_frac"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (a1 * 1e-3) / 1e9 / 8000.0, 4)
+            o1["valu_ceiling_frac"] = round(out["roofline"]["valu_ceiling"]["min_ms"] / a1, 3)
+        if "roofline_profile" in out and f1["probe"][1]:
+            o1["roofline_profile_frac"] = round(out["roofline_profile"]["algorithmic_bytes_per_launch"] / (f1["probe"][0] / f1["probe"][1] * 1e-3) / 1e9 / 8000.0, 4)
+        out["one_step_at_a_time"] = o1
     if not args.no_verify and last.get("res") is not None:
         try:
             G = n_total
@@ -472,8 +540,8 @@ def main():
             out["verify"] = verify_against_oracle(ctx, (cc[:G], off[:G + 1], covs), G, last["table"], verify_set, device)
         except Exception as e:
             out["verify"] = {"genomes_checked": 0, "mismatches": None, "error": str(e)}
-    for sk in last.get("sessions", []):
-        sk.close()
+    for w, sk in last.get("sessions", []):
+        w.submit(lambda wctx, sk=sk: sk.close()).result()
     # ---- host-fed leg (untimed w.r.t. `value`): the same step with the reads starting in PAGE-LOCKED HOST memory, as ASCII and
     # as the packed 2-bit stream a feed would hand over (sylph_sketch_push_enc cuts the batch into chunks that travel on a copy
     # stream while the previous chunk is sketched): pinned host -> HBM -> sketch -> profile -> results on the host.
@@ -551,10 +619,10 @@ def main():
     db.close()
     if comm is not None:
         comm.close()
-    if pool is not None:
-        pool.shutdown()
-    for wc in worker_ctx[1:]:
-        wc.close()
+    for w in workers:
+        w.jobs.put(None)
+        w.join()
+        w.ctx.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -277,6 +277,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long long v = strtoll(value, nullptr, 10);
             SY_REQUIRE(v >= 64 && v <= (1ll << 31), "push_chunk_bytes must be in [64, 2^31]");
             ctx->push_chunk_bytes = (uint64_t)v;
+        } else if (!strcmp(key, "reads_wg_per_cu")) {
+            const long v = strtol(value, nullptr, 10);
+            SY_REQUIRE(v >= 0 && v <= 64, "reads_wg_per_cu must be in [0, 64]");
+            ctx->reads_wg_per_cu = (uint32_t)v;
         } else if (!strcmp(key, "index_lambda")) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 1 && v <= 8, "index_lambda must be in [1, 8]");

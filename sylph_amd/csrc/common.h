@@ -128,6 +128,7 @@ struct sylph_ctx {
     uint32_t bucket_target = 128;           // mean occurrences per replay bucket aimed for ("bucket_target")
     uint32_t index_lambda = 3;              // postings per 64-byte bucket line of a database index aimed for ("index_lambda")
     uint64_t index_pass_max = 1ull << 30;   // postings sorted per pass of the index build ("index_pass_max"; tests lower it)
+    uint32_t reads_wg_per_cu = 0;             // "reads_wg_per_cu": 0 = one workgroup per block of reads (measured best: 0.75 ms vs 0.84 ms with 8 looping workgroups per CU), n = n looping workgroups per CU
     uint64_t push_chunk_bytes = 64ull << 20;  // bytes of bases per chunk of a host batch ("push_chunk_bytes"; tests lower it)
     int seeds_mode = 0;                     // 0 auto: read-per-lane kernel for short reads, else ordered slots; 1 unordered kernel + radix sort; 2 ordered slots only ("seeds")
     std::atomic<int> refs{1};               // the creator + every live session / db; freed when it drops to 0

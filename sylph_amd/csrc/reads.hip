@@ -430,7 +430,7 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
     auto launch = [&](uint32_t n_it, uint32_t cap, OccRec* sr, const uint32_t* list) {
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * 8);
+        const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * ctx->reads_wg_per_cu) : n_it;
 #define SY_LAUNCH_READS(KK, HH, EE)                                                                                                   \
     hipLaunchKernelGGL((reads_kernel<KK, HH, EE>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
                        blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr,          \
