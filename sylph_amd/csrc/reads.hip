@@ -175,6 +175,7 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
     uint64_t* const s_m0 = s_off;
     uint64_t* const s_m1 = s_off + RTPB;
     __shared__ uint32_t s_first[RTPB + 1], s_rel[RTPB];
+    __shared__ uint16_t s_perm[RTPB], s_nh[RTPB];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the
     // blocks, so that the halo a block shares with its neighbour is found in the same L2.  (Outputs are indexed by block,
@@ -238,12 +239,40 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
             if (too_long) state->long_record = 1u;                  // the host reruns the batch through the position kernel
             const uint32_t nh = (active && !too_long) ? (uint32_t)n_hashed_kmers(L, K, avx2_compat, 0) : 0u;
             const uint32_t rel = active ? (uint32_t)((int64_t)(start + bias) - a0) : 0u;   // stream base of the record
-            uint32_t nh_max = nh;
+            // A wavefront walks as many k-mer groups as its LONGEST record has: deal the pass's records to the lanes in order of
+            // length (counting sort by the number of half-groups, longest first; ties in any order), so that trimmed reads of
+            // 35..151 bp cost a wavefront what its own quartile needs instead of what the longest read of 64 needs.  Only the
+            // hash loop runs in this order — hit masks are stored under the record's own slot and everything after the loop is
+            // indexed by record again, so the output does not depend on the dealing.  A pass of equally long records (every
+            // lane in one bin) is hashed as it lies.
+            uint32_t* const s_hist = s_first;                         // (s_first is not in use before the survivor pass)
+            if (tid < 64) s_hist[tid] = 0;
+            s_rel[tid] = rel;
+            s_nh[tid] = (uint16_t)nh;
+            __syncthreads();
+            const uint32_t bin = 63u - ((nh + 7) >> 3);              // nh <= RH - 20: at most 48 half-groups
+            const uint32_t arrival = atomicAdd(&s_hist[bin], 1u);
+            __syncthreads();
+            const uint32_t hc = s_hist[lane];
+            const bool dealt = s_hist[bin] != (uint32_t)RTPB;         // uniform over the workgroup
+            if (dealt) {
+                uint32_t incl = hc;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(incl, d);
+                    if (lane >= (uint32_t)d) incl += y;
+                }
+                s_perm[(uint32_t)__shfl((int)(incl - hc), (int)bin) + arrival] = (uint16_t)tid;
+                __syncthreads();
+            }
+            const uint32_t slot = dealt ? s_perm[tid] : tid;         // the record slot this lane hashes
+            const uint32_t rel_h = dealt ? s_rel[slot] : rel, nh_h = dealt ? s_nh[slot] : nh;
+            uint32_t nh_max = nh_h;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d));
             if (nh_max) {
                 // lane-aligned stream words A(j) = bases [rel + 16 j, rel + 16 j + 16): one LDS read and one 64-bit shift each
-                const uint32_t w0 = rel >> 4, sh = 32u - (rel & 15u) * 2u;          // sh in [2, 32]
+                const uint32_t w0 = rel_h >> 4, sh = 32u - (rel_h & 15u) * 2u;      // sh in [2, 32]
                 uint32_t raw = sF[w0], nxt = sF[w0 + 1];
                 auto next_word = [&](uint32_t j) {                                   // A(j), advancing the raw pair to j + 1
                     const uint32_t a = (uint32_t)((((uint64_t)raw << 32) | nxt) >> sh);
@@ -267,10 +296,11 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                     // k-mer i <-> bit 31 - (i & 31) of word i >> 5: a group of 16 is one 16-bit half of its word, even groups the
                     // upper half.  Stored as halves (ds_write_b16): no "is the word complete" bookkeeping in the loop; whatever a
                     // half that was never written holds lies beyond nh and is cleared with the tail below.
-                    reinterpret_cast<uint16_t*>(&s_mask[hg >> 2][tid])[((hg >> 1) & 1u) ^ 1u] = (uint16_t)mask;
+                    reinterpret_cast<uint16_t*>(&s_mask[hg >> 2][slot])[((hg >> 1) & 1u) ^ 1u] = (uint16_t)mask;
                 }
             }
-            // count this lane's real hits (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)
+            if (dealt) __syncthreads();                                 // masks were written by other lanes
+            // count the real hits of this lane's own record (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)
             uint32_t cnt = 0;
             const uint32_t nw = (nh + 31) >> 5;
             for (uint32_t w = 0; w < nw; w++) {
@@ -322,7 +352,6 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                 s_m0[tid] = m0;
                 s_m1[tid] = m1;
                 s_first[tid] = (before + x - cnt) | (has << 31);
-                s_rel[tid] = rel;
                 if (tid == 0) s_first[RTPB] = total;
             }
             __syncthreads();
