@@ -267,12 +267,34 @@ def main():
     db_mode = args.db_mode if args.db_mode != "auto" else ("shard" if world > 1 else "replicate")
     log(f"[bench] building workload {wl} on {world} GPU(s), db {db_mode} ...")
     db, n_total, community, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
-    comm = None
+    comm, comm_kind, fallbacks = None, None, []
+
+    def agreed_failure(failed):            # a rank that failed takes every rank down the same fallback
+        if dist is None:
+            return bool(failed)
+        t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item())
+
     if db_mode == "shard":
         if world == 1:      # the sharded code path with a one-rank RCCL communicator: the exchange's own cost, nothing on the wire
-            comm = S.Comm(0, 1, ctx=ctx, rccl_id=S.Comm.rccl_unique_id())
+            comm, comm_kind = S.Comm(0, 1, ctx=ctx, rccl_id=S.Comm.rccl_unique_id()), "RCCL (one rank)"
+        elif shared_gpu or dist.get_backend() != "nccl":
+            comm, comm_kind = SH.torch_callback_comm(dist, device), "torch.distributed callbacks on host copies, ranks share a GPU"
         else:
-            comm = SH.torch_callback_comm(dist, device) if (shared_gpu or dist.get_backend() != "nccl") else SH.rccl_comm(dist, ctx, device)
+            err = None
+            if os.environ.get("SYLPH_BENCH_COMM", "library") == "library":
+                try:
+                    comm, comm_kind = SH.rccl_comm(dist, ctx, device), "RCCL, communicator created by the library"
+                except Exception as e:
+                    err = e
+            else:
+                err = "SYLPH_BENCH_COMM"
+            if agreed_failure(err is not None):
+                if comm is not None:
+                    comm.close()
+                fallbacks.append(f"library RCCL communicator: {err}")
+                comm, comm_kind = SH.torch_device_comm(dist, device), "RCCL through torch.distributed collectives on the device buffers"
     t0 = time.time()
     read_sets = []                           # distinct samples, rotated over the steps so that the probe is never cache-warm
     for i in range(n_sets):
@@ -406,6 +428,24 @@ def main():
             w.submit(lambda wctx: None).result()
 
     # untimed settle steps (first-use allocations of every context's pool, lazy kernel loading) whatever --warmup is
+    if comm is not None and world > 1:
+        # the first sharded step ever run on this node: if the exchange fails on any rank, every rank drops to the replicated
+        # database (no data-path collective) and says so in the result line
+        err = None
+        try:
+            run_steps(1, None, 1)
+        except Exception as e:
+            err = e
+        if agreed_failure(err is not None):
+            fallbacks.append(f"sharded exchange ({comm_kind}): {err}")
+            log(f"[bench] rank {rank}: sharded step failed ({err}); falling back to the replicated database")
+            try:
+                comm.close()
+                db.close()
+            except Exception:
+                pass
+            comm, comm_kind, db_mode = None, None, "replicate"
+            db, n_total, _, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
     run_steps(2 * n_workers, None, 2)
     run_steps(2, None, 1)
     torch.cuda.synchronize()
@@ -454,14 +494,14 @@ def main():
     comparisons = world * spg * n_total                                       # every sample vs every genome of the DB
     parallelism = (f"{spg} sample(s) per GPU per step x {world} GPU(s); database " +
                    (f"sharded by k-mer range over {world} GPUs (per step: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
-                    f"{'torch.distributed callbacks, ranks share a GPU' if (shared_gpu or (dist and dist.get_backend() != 'nccl')) else 'RCCL'})"
+                    f"{comm_kind})"
                     if comm is not None else ("replicated on every GPU (no data-path collective)" if world > 1 else "on the one GPU")))
     out = {
         "metric": "read Gbp/s sketched + genome-comparisons/s profiled, 1 Gbp vs GTDB-R220",
         "value": round(value, 3), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": spg, "sketch_workers_per_gpu": n_workers, "steps_in_flight": depth, "reads_per_sample_gbp": round(n_bases / 1e9, 4),
+        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": spg, "sketch_workers_per_gpu": n_workers, "steps_in_flight": depth, **({"fallbacks": fallbacks} if fallbacks else {}), "reads_per_sample_gbp": round(n_bases / 1e9, 4),
                    "distinct_read_sets_rotated": n_sets, "genomes": n_total, "db_kmers_per_shard": dbstats["shard_kmers"],
                    "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)",
                    "seed_mode": "avx2_compat", "parallelism": parallelism,

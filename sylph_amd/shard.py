@@ -84,6 +84,26 @@ def torch_callback_comm(dist, device):
     return Comm(rank, world, all_gather=all_gather, all_to_all=all_to_all)
 
 
+def torch_device_comm(dist, device):
+    """Comm whose collectives are torch.distributed calls ON the device buffers (backend nccl = RCCL): torch's own communicator
+    instead of one created by the library.  The collectives are ordered with the library's stream by making it torch's current
+    stream for the call."""
+    from .binding import Comm
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def all_gather(send, recv, nbytes, stream):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=device)):
+            dist.all_gather_into_tensor(device_view(recv, world * nbytes, torch.uint8, device), device_view(send, nbytes, torch.uint8, device))
+
+    def all_to_all(send, send_off, recv, recv_off, stream):
+        ins = [int(send_off[r + 1] - send_off[r]) for r in range(world)]
+        outs = [int(recv_off[r + 1] - recv_off[r]) for r in range(world)]
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=device)):
+            dist.all_to_all_single(device_view(recv, sum(outs), torch.uint8, device), device_view(send, sum(ins), torch.uint8, device), outs, ins)
+
+    return Comm(rank, world, all_gather=all_gather, all_to_all=all_to_all)
+
+
 def model_contain_batch_sharded(dist, bounds, n_genomes, samples, probe_fn):
     """Host model of sylph_db_contain_batch_sharded (see csrc/shard.hip), step for step.
 

@@ -640,6 +640,19 @@ def test_sharded_database_one_rank_over_rccl(ctx):
     d1.close(); d0.close(); comm.close()
 
 
+def test_sharded_database_through_torch_distributed_rccl():
+    """The same call with the collectives served by torch.distributed's nccl (= RCCL) process group on the device buffers, and
+    with the library's communicator bootstrapped through that process group — the two ways bench.py --gpus N forms its
+    communicator (tests/rccl_torch_worker.py, one rank: all a 1-GPU box can form)."""
+    import subprocess
+    import sys
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "rccl_torch_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_TORCH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 # ---------------------------------------------------------------------------------------------- end to end
 def test_end_to_end_sketch_then_contain_device_resident(ctx):
     """Reads -> device-resident table -> containment without a host round trip; checked against the oracle end to end,
