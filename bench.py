@@ -448,6 +448,7 @@ def main():
             db, n_total, _, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
     run_steps(2 * n_workers, None, 2)
     run_steps(2, None, 1)
+    run_steps(2 * depth, None, depth)      # ... and with as many sessions alive per context as the pipelined region will have
     torch.cuda.synchronize()
     run_steps(args.warmup, None, depth)
 

@@ -309,7 +309,7 @@ void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint
     const uint32_t n_tiles = (uint32_t)(((uint64_t)n_bases + TILE_BASES - 1) / TILE_BASES);
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);   // looping workgroups: the staging area is flushed with one global atomic per flush
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
     ScopedKernelTimer t(ctx, "seeds");
 #define SY_LAUNCH_SEEDS(KK, HH)                                                                                         \
@@ -340,7 +340,7 @@ void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases
     if (d_tile_list) slot_cap = TILE_BASES;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);
+    const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * ctx->reads_wg_per_cu) : n_tiles;
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
     ScopedKernelTimer t(ctx, "seeds");
 #define SY_LAUNCH_SLOTS(KK, HH)                                                                                              \

@@ -3,6 +3,7 @@
 // (interleaving the mates of a pair) and pushes it with SYLPH_MEM_HOST_PINNED.  Parsing therefore overlaps with the H2D copy
 // and the GPU work of the previous batch, the two mate files are read concurrently, and the library needs no staging memcpy.
 // Record semantics are those of FastxReader (needletail 0.5.1: seq() without newlines, errors per record).
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -14,6 +15,8 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+
+#include <zlib.h>
 
 #include "sylph_host.hpp"
 
@@ -181,6 +184,97 @@ inline size_t next_line(const uint8_t* d, size_t n, size_t p) {   // start of th
 
 FastqIndex::~FastqIndex() { if (data) munmap((void*)data, size); }
 
+namespace {
+// ---- BGZF (blocked gzip, what `bgzip` writes): every member is a complete deflate stream of <= 64 KiB whose compressed size
+// stands in its header (extra subfield 'B','C') and whose inflated size stands in its trailer, so the members can be found
+// without inflating and inflated independently — by all parse threads at once, straight to their final offsets.  An ordinary
+// .gz is ONE deflate stream: nothing to split, it stays with the sequential reader (needletail does the same, one thread).
+struct BgzfBlock { size_t in, in_len, out; uint32_t out_len, crc; };
+
+// libdeflate (2-3x zlib's inflate rate) when the system has it — bound with dlopen, there is no header to build against —
+// else zlib.  Both inflate one raw deflate stream into a buffer of known size.
+struct Deflate {
+    void* lib = nullptr;
+    void* (*alloc)() = nullptr;
+    int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+    Deflate() {
+        if (getenv("SYLPH_HIP_NO_LIBDEFLATE")) return;
+        lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return;
+        alloc = (decltype(alloc))dlsym(lib, "libdeflate_alloc_decompressor");
+        run = (decltype(run))dlsym(lib, "libdeflate_deflate_decompress");
+        release = (decltype(release))dlsym(lib, "libdeflate_free_decompressor");
+        crc = (decltype(crc))dlsym(lib, "libdeflate_crc32");
+        if (!alloc || !run || !release || !crc) lib = nullptr;
+    }
+};
+const Deflate& deflate_lib() { static const Deflate d; return d; }
+
+bool bgzf_blocks(const uint8_t* d, size_t n, std::vector<BgzfBlock>& blocks, size_t& total) {
+    size_t p = 0;
+    total = 0;
+    while (p < n) {
+        if (n - p < 28 || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) return false;
+        const size_t xlen = d[p + 10] | (size_t)d[p + 11] << 8;
+        if (p + 12 + xlen > n) return false;
+        size_t bsize = 0;
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {             // the extra field's subfields
+            const size_t slen = d[q + 2] | (size_t)d[q + 3] << 8;
+            if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2 && q + 6 <= p + 12 + xlen) bsize = (d[q + 4] | (size_t)d[q + 5] << 8) + 1;
+            q += 4 + slen;
+        }
+        if (d[p + 3] != 4 || bsize < 12 + xlen + 8 || p + bsize > n) return false;   // (bgzip sets no other flag)
+        const uint8_t* t = d + p + bsize - 8;
+        BgzfBlock b;
+        b.in = p + 12 + xlen;
+        b.in_len = bsize - 12 - xlen - 8;
+        b.crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        b.out_len = t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+        b.out = total;
+        if (b.out_len > (1u << 16)) return false;
+        total += b.out_len;
+        blocks.push_back(b);
+        p += bsize;
+    }
+    return !blocks.empty();
+}
+
+bool bgzf_inflate(const uint8_t* d, const std::vector<BgzfBlock>& blocks, uint8_t* out, unsigned threads) {
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, blocks.size() / 64 + 1));
+    std::vector<char> good(T, 1);
+    const Deflate& L = deflate_lib();
+    run_workers(T, [&](unsigned w) {
+        const size_t b0 = blocks.size() * w / T, b1 = blocks.size() * (w + 1) / T;
+        void* dec = L.lib ? L.alloc() : nullptr;
+        z_stream z;
+        memset(&z, 0, sizeof(z));
+        if (!dec && inflateInit2(&z, -15) != Z_OK) { good[w] = 0; return; }
+        for (size_t i = b0; i < b1 && good[w]; i++) {
+            const BgzfBlock& b = blocks[i];
+            if (dec) {
+                size_t got = 0;
+                if (L.run(dec, d + b.in, b.in_len, out + b.out, b.out_len, &got) != 0 || got != b.out_len) good[w] = 0;
+                else if (L.crc(0, out + b.out, b.out_len) != b.crc) good[w] = 0;
+            } else {
+                z.next_in = const_cast<Bytef*>(d + b.in);
+                z.avail_in = (uInt)b.in_len;
+                z.next_out = out + b.out;
+                z.avail_out = b.out_len;
+                const int r = inflate(&z, Z_FINISH);
+                if (r != Z_STREAM_END || z.avail_out != 0) good[w] = 0;
+                else if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out + b.out, b.out_len) != b.crc) good[w] = 0;
+                inflateReset(&z);
+            }
+        }
+        if (dec) L.release(dec); else inflateEnd(&z);
+    });
+    for (unsigned w = 0; w < T; w++) if (!good[w]) return false;
+    return true;
+}
+}  // namespace
+
 FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return;
@@ -192,9 +286,25 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     if (m == MAP_FAILED) { data = nullptr; return; }
     data = (const uint8_t*)m;
     (void)madvise(m, size, MADV_WILLNEED);
+    if (data[0] == 0x1f && data[1] == 0x8b) {
+        // blocked gzip: inflate all members in parallel into an anonymous mapping that takes the file mapping's place
+        std::vector<BgzfBlock> blocks;
+        size_t total = 0;
+        if (!bgzf_blocks(data, size, blocks, total) || total < 4) return;          // ordinary gzip: sequential reader
+        void* buf = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (buf == MAP_FAILED) return;
+        (void)madvise(buf, total, MADV_HUGEPAGE);                                  // first touch by many threads: 2 MiB pages where the system allows
+        // (inflating is pure compute per member: it takes more threads than the memory-bound index does)
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const bool inflated = bgzf_inflate(data, blocks, (uint8_t*)buf, getenv("SYLPH_HIP_PARSE_THREADS") ? threads : std::max(threads, std::min(64u, hw / 2)));
+        munmap((void*)data, size);
+        data = (const uint8_t*)buf;
+        size = total;
+        if (!inflated) return;                                                     // (the sequential reader reports the damage)
+    }
     const uint8_t* d = data;
     const size_t n = size;
-    if (d[0] != '@' || (d[0] == 0x1f && d[1] == 0x8b)) return;   // not plain FASTQ: sequential reader
+    if (d[0] != '@') return;                                      // not FASTQ: sequential reader
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / (1u << 20)));
     // a record starts at a line that begins with '@' and whose line after next begins with '+' (a QUALITY line may begin
     // with '@' too, but then the line after next is a sequence line)

@@ -34,3 +34,19 @@ def concat(records):
         off[1:] = np.cumsum([len(r) for r in records], dtype=np.uint64)
     bases = np.concatenate([np.asarray(r, dtype=np.uint8) for r in records]) if records else np.zeros(0, dtype=np.uint8)
     return bases.astype(np.uint8), off
+
+
+def bgzf_compress(data, block=65280, level=6):
+    """What `bgzip` writes: gzip members of <= 64 KiB, each with the 'BC' extra subfield holding its compressed size, and the
+    empty end-of-file member."""
+    import struct
+    import zlib
+    out = bytearray()
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    return bytes(out)

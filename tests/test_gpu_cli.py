@@ -11,7 +11,7 @@ import pytest
 from oracle import oracle as O
 from oracle import pyref as P
 
-from .helpers import ACGT, random_seq, revcomp
+from .helpers import ACGT, bgzf_compress, random_seq, revcomp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -364,3 +364,14 @@ def test_parallel_feed_equals_sequential_feed(data):
         outs.append(((o / "s_1.fq.paired.sylsp").read_bytes(), (o / "s_1.fq.sylsp").read_bytes()))
     assert outs[0] == outs[1] == outs[2]
     assert len(outs[0][0]) > 1000
+    # blocked gzip (bgzip) input: members inflated in parallel, then the same index; the sketch records the file name, so the
+    # comparison is on the k-mer tables the query prints
+    for m in ("1", "2"):
+        (d / f"z_{m}.fq.gz").write_bytes(bgzf_compress((d / f"s_{m}.fq").read_bytes(), block=4000))
+    o = d / "feed_bgzf"
+    p = subprocess.run([BIN, "sketch", "-1", str(d / "z_1.fq.gz"), "-2", str(d / "z_2.fq.gz"), "--fpr", "0", "-d", str(o)],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SYLPH_HIP_FEED_TRACE="1"))
+    assert p.returncode == 0 and "gather" in p.stderr, p.stderr[-2000:]          # (the trace line of the indexed path)
+    a, b = (o / "z_1.fq.gz.paired.sylsp").read_bytes(), outs[0][0]
+    n_tab = 8 + 12 * int.from_bytes(b[:8], "little")                               # the k-mer table leads the file (types.rs:145-155)
+    assert n_tab > 1000 and a[:n_tab] == b[:n_tab] and a[n_tab:n_tab + 16] == b[n_tab:n_tab + 16]   # + c, k; the file names differ

@@ -10,6 +10,8 @@ import pytest
 from oracle import oracle as O
 from oracle import pyref as P
 
+from .helpers import bgzf_compress
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -354,3 +356,51 @@ def test_block_parallel_fastq_index_matches_the_sequential_reader(host, tmp_path
             w = [C.c_uint64(0) for _ in range(3)]
             assert host.sylph_host_fastq_index_digest(str(path).encode(), threads, C.byref(ok), *[C.byref(x) for x in w]) == 0
             assert ok.value == 0, (name, threads)
+
+
+def test_blocked_gzip_is_inflated_in_parallel_and_indexed(host, tmp_path, monkeypatch):
+    """feed.cpp: a BGZF file's members are located from their headers, inflated by all parse threads (libdeflate when the
+    system has it, zlib otherwise — both are run) and indexed like a plain FASTQ; gzip.decompress accepts the same bytes (the
+    file IS a valid multi-member gzip); a damaged member or an ordinary one-stream gzip is declined (sequential reader)."""
+    import gzip
+    host.sylph_host_fastx_digest.argtypes = [C.c_char_p, C.c_int] + [C.POINTER(C.c_uint64)] * 4
+    host.sylph_host_fastq_index_digest.argtypes = [C.c_char_p, C.c_uint, C.POINTER(C.c_int)] + [C.POINTER(C.c_uint64)] * 3
+    rng = np.random.default_rng(81)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(n))) for n in rng.integers(1, 300, size=60000)]
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs))
+    plain = tmp_path / "p.fq"
+    plain.write_bytes(fq)
+    z = bgzf_compress(fq)
+    assert gzip.decompress(z) == fq and len(z) // 65536 > 40
+    bg = tmp_path / "b.fq.gz"
+    bg.write_bytes(z)
+    v = [C.c_uint64(0) for _ in range(4)]
+    assert host.sylph_host_fastx_digest(str(plain).encode(), 0, *[C.byref(x) for x in v]) == 0
+    u = [C.c_uint64(0) for _ in range(4)]
+    assert host.sylph_host_fastx_digest(str(bg).encode(), 0, *[C.byref(x) for x in u]) == 0          # the sequential gz reader
+    assert [x.value for x in u] == [x.value for x in v]
+
+    def index(path, threads):
+        ok = C.c_int(0)
+        w = [C.c_uint64(0) for _ in range(3)]
+        assert host.sylph_host_fastq_index_digest(str(path).encode(), threads, C.byref(ok), *[C.byref(x) for x in w]) == 0
+        return ok.value, (w[0].value, w[1].value, w[2].value)
+    for threads in (1, 5, 16):
+        assert index(bg, threads) == (1, (v[0].value, v[2].value, v[3].value))
+    # a flipped byte inside one member's deflate data: CRC / inflate failure -> declined
+    bad = bytearray(z)
+    bad[len(z) // 2] ^= 0x55
+    (tmp_path / "bad.fq.gz").write_bytes(bytes(bad))
+    assert index(tmp_path / "bad.fq.gz", 4)[0] == 0
+    (tmp_path / "trunc.fq.gz").write_bytes(z[:len(z) // 2])
+    assert index(tmp_path / "trunc.fq.gz", 4)[0] == 0
+    (tmp_path / "plain.fq.gz").write_bytes(gzip.compress(fq[:200000], 1))
+    assert index(tmp_path / "plain.fq.gz", 4)[0] == 0
+    # the zlib inflater (what runs where libdeflate is not installed): a fresh process, the choice is made once
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; h = C.CDLL(sys.argv[1]); ok = C.c_int(0); w = [C.c_uint64(0) for _ in range(3)];"
+            "h.sylph_host_fastq_index_digest.argtypes = [C.c_char_p, C.c_uint, C.POINTER(C.c_int)] + [C.POINTER(C.c_uint64)] * 3;"
+            "h.sylph_host_fastq_index_digest(sys.argv[2].encode(), 4, C.byref(ok), *[C.byref(x) for x in w]); print(ok.value, w[0].value, w[1].value, w[2].value)")
+    r = subprocess.run([sys.executable, "-c", code, host._name, str(bg)], capture_output=True, text=True, env=dict(os.environ, SYLPH_HIP_NO_LIBDEFLATE="1"))
+    assert r.stdout.split() == ["1", str(v[0].value), str(v[2].value), str(v[3].value)], r.stdout + r.stderr

@@ -3,18 +3,24 @@
 # roofline object, the instruction-rate microbenchmark, the host-feed measurement.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 out=gpurun_out/r02_final; mkdir -p $out
-git rev-parse HEAD > $out/head.txt 2>/dev/null || echo "snapshot (no .git on the box)" > $out/head.txt
+# (the box has no .git: tools/run_r02_profile.sh records HEAD and the clean state of the tree when it starts this script)
 python bench.py --steps 20 --warmup 5 > $out/bench_c3.json 2> $out/bench_c3.err
 tail -c 300 $out/bench_c3.json
 for wl in c3r c2 c5 c4; do
   python bench.py --workload $wl --steps 6 --warmup 2 --no-cpu-baseline --no-h2d > $out/bench_$wl.json 2> $out/bench_$wl.err
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o c3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-h2d --no-verify > $out/bench_prof.json 2> $out/prof.err
+# (a) the default (pipelined) command under the tracer: per-kernel averages to set beside the line's HIP-event numbers
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_p -o c3 -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-h2d --no-verify --no-sequential-leg > $out/bench_prof.json 2> $out/prof.err
+f=$(find $out/stats_p -name '*kernel_trace.csv' | head -1)
+python tools/step_timeline.py $f --steps 10 --anchor reads_kernel --summary-only > $out/kernels_pipelined.md
+rm -f $f
+# (b) one step at a time: the dispatch sequence of a step with its gaps, every kernel alone on the GPU
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o c3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-h2d --no-verify --pipeline-depth 1 > $out/bench_prof_seq.json 2>> $out/prof.err
 f=$(find $out/stats -name '*kernel_trace.csv' | head -1)
 python tools/step_timeline.py $f --steps 5 --anchor reads_kernel > $out/step_timeline.md
 find $out/stats -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 rm -f $f
-B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-verify --no-kernel-timers"
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-verify --no-kernel-timers --pipeline-depth 1"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-include-regex 'reads_kernel|probe_kernel' --output-format csv -d $out/pmc_$c -o s -- $B > /dev/null 2>&1
 done
@@ -23,6 +29,7 @@ rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLI
 # the same counters for the ragged workload (lanes of a wavefront walk reads of different lengths)
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-include-regex 'reads_kernel' --output-format csv -d $out/pmc_SQ_c3r -o s -- $B --workload c3r > /dev/null 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_rates.hip -o /tmp/valu_rates 2> /dev/null && /tmp/valu_rates > $out/valu_rates.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/atomic_rates.hip -o /tmp/atomic_rates 2> /dev/null && /tmp/atomic_rates > $out/atomic_rates.txt 2>&1
 python tools/feed_bench.py 3333334 > $out/feed.txt 2> $out/feed.err
 python - <<'PY'
 import csv, glob, collections, json

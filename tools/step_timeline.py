@@ -20,12 +20,15 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--anchor", default="seeds_slots_kernel")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--summary-only", action="store_true", help="steps overlap (pipelined run): only the per-kernel table")
     a = ap.parse_args()
     rows = sorted(csv.DictReader(open(a.csv)), key=lambda r: int(r["Start_Timestamp"]))
     anchors = [i for i, r in enumerate(rows) if a.anchor in r["Kernel_Name"]]
     gmax = max(int(rows[i]["Grid_Size_X"]) for i in anchors)
     anchors = [i for i in anchors if int(rows[i]["Grid_Size_X"]) == gmax]
     last = anchors[-a.steps:]
+    if a.summary_only:
+        return summary(rows, last)
     # timeline of the last complete step (second to last anchor .. last anchor)
     lo, hi = (anchors[-2], anchors[-1]) if len(anchors) >= 2 else (anchors[-1], len(rows))
     t0 = int(rows[lo]["Start_Timestamp"])
@@ -40,7 +43,10 @@ def main():
         busy += (e - s) / 1e3
         prev_end = max(prev_end, e)
     print(f"\nkernel time in the step: {busy:.1f} us")
-    # summary over the last steps
+    summary(rows, last)
+
+
+def summary(rows, last):
     agg = collections.defaultdict(list)
     for r in rows[last[0]:]:
         agg[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
