@@ -32,7 +32,13 @@ __device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {   // 
 }
 __device__ __forceinline__ uint64_t mm_hash64_gfx950(uint64_t key) {
     uint64_t t = lshl_add_u64<0>(key << 21, key);                 // key + (key << 21)
-    t = (t ^ (t >> 24)) ^ 0xFFFFFF0000000000ull;                  // ~t, then ^= >> 24
+    {                                                             // ~t, then ^= >> 24: the high word takes ONE three-input xor
+        uint64_t sh;                                              // (gfx9 VOP3 has no literals: the constant rides in an SGPR;
+        asm("v_lshrrev_b64 %0, 24, %1" : "=v"(sh) : "v"(t));      //  the shift pinned to ONE 64-bit instruction, not lshr + alignbit)
+        uint32_t hi;
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(hi) : "v"((uint32_t)(t >> 32)), "v"((uint32_t)(sh >> 32)), "s"(0xFFFFFF00u));
+        t = ((uint64_t)hi << 32) | ((uint32_t)t ^ (uint32_t)sh);
+    }
     t = lshl_add_u64<0>(t << 8, lshl_add_u64<3>(t, t));           // * 265 = (t << 8) + 9t
     t = t ^ (t >> 14);
     t = lshl_add_u64<4>(t, lshl_add_u64<2>(t, t));                // * 21
