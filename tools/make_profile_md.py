@@ -16,9 +16,9 @@ def load(name):
         return json.loads(f.read().strip().split("\n")[-1])
 
 
-head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-subject = subprocess.run(["git", "log", "-1", "--format=%s"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-dirty = subprocess.run(["git", "status", "--porcelain", "--", "sylph_amd", "bench.py", "include"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+# tools/run_r02_profile.sh refuses to start with a dirty tree and records the commit the snapshot was taken from
+hl = open(os.path.join(src, "head_local.txt")).read().strip().split("\n")
+head, subject = hl[0], hl[1] if len(hl) > 1 else ""
 b = {}
 for wl in ("c3", "c3r", "c2", "c5", "c4"):
     try:
@@ -46,19 +46,29 @@ cyc = sq["reads.GRBM_GUI_ACTIVE"] / 8
 valu_per_kmer = sq["reads.SQ_INSTS_VALU"] / (kmers / 64)
 valu_busy = sq["reads.SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)
 pcyc = sq["probe.GRBM_GUI_ACTIVE"] / 8
+kp = open(os.path.join(src, "kernels_pipelined.md")).read()
+seq = c3.get("one_step_at_a_time", {})
 out = [
     "# r02 — rocprofv3 of bench.py C3 (1 Gbp of 2x150 bp reads vs 113,104-genome DB), one MI355X", "",
-    f"Code state: `{head}` ({subject}){' + uncommitted changes' if dirty else ''} — the tree the GPU box ran is the tree of this commit's parent plus",
-    "this file; recipe `tools/r02_profile.sh` (through gpurun), assembled by `tools/make_profile_md.py`.", "",
-    "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_final/stats -o c3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-h2d --no-verify", "",
-    f"Un-profiled run of the same build (profiles/r02_bench_c3.json, 20 steps): **{c3['ms_per_step']} ms/step = {c3['value']} Gbp/s**, sketch {c3['sketch_ms']} ms,",
-    f"profile {c3['profile_ms']} ms; `{rf['kernel']}` {rf['avg_launch_ms']} ms/launch and `probe_kernel` {rp['avg_launch_ms']} ms/launch by HIP events inside the library",
-    "vs the rocprofv3 averages in the second table below.", "",
-    "First table: the complete dispatch sequence of ONE timed step (sketch + profile of one sample) with the idle gap before each",
+    f"Code state: `{head}` ({subject}) — the GPU box ran a snapshot of exactly this commit (clean working tree, checked by",
+    "`tools/run_r02_profile.sh`); recipe `tools/r02_profile.sh`, assembled by `tools/make_profile_md.py`.", "",
+    f"Un-profiled default run of the same build (profiles/r02_bench_c3.json, {c3['steps']} steps, {c3['config']['steps_in_flight']} steps in flight on {c3['config']['sketch_workers_per_gpu']} sketch streams",
+    f"+ the profile stream): **{c3['ms_per_step']} ms/step = {c3['value']} Gbp/s**; `{rf['kernel']}` {rf['avg_launch_ms']} ms/launch and `probe_kernel` {rp['avg_launch_ms']} ms/launch",
+    "by HIP events inside the library (durations include the time shared with the other streams' kernels).",
+    f"One step at a time (same run, `one_step_at_a_time`): **{seq.get('ms_per_step')} ms/step = {seq.get('value')} Gbp/s**, `reads_kernel` {seq.get('kernel_ms', {}).get('seeds', [None])[0]} ms,",
+    f"`probe_kernel` {seq.get('kernel_ms', {}).get('probe', [None])[0]} ms alone on the GPU: {100 * seq.get('roofline_frac', 0):.1f} % / {100 * seq.get('roofline_profile_frac', 0):.1f} % of the 8 TB/s peak.", "",
+    "## (a) the default, pipelined command under the tracer", "",
+    "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_final/stats_p -o c3 -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-h2d --no-verify --no-sequential-leg", "",
+    "Per kernel over the 10 timed steps (+ the untimed final step); dispatches of different streams overlap, so the durations",
+    "are what the bench line's HIP events see:", "",
+    kp, "",
+    "## (b) one step at a time under the tracer", "",
+    "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_final/stats -o c3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-h2d --no-verify --pipeline-depth 1", "",
+    "First table: the complete dispatch sequence of ONE step (sketch + profile of one sample, everything on one stream) with the idle gap before each",
     "dispatch (`__amd_rocclr_copyBuffer` = the runtime's copy kernels, `fillBufferAligned` = hipMemsetAsync).  Second table: totals over the last 5 steps.", "",
     timeline, "",
     "## PMC passes (each counter group in its own run, counters only — no trace domains)", "",
-    "    rocprofv3 --pmc FETCH_SIZE  --kernel-include-regex 'reads_kernel|probe_kernel' ... -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-verify --no-kernel-timers",
+    "    rocprofv3 --pmc FETCH_SIZE  --kernel-include-regex 'reads_kernel|probe_kernel' ... -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-verify --no-kernel-timers --pipeline-depth 1",
     "    rocprofv3 --pmc WRITE_SIZE  (same)      rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE (same)", "",
     "Means over the last 3 dispatches of each kernel (the timed steps).", "",
     "### `reads_kernel<31,1,0>` (one launch = the whole 1 Gbp batch)", "",
@@ -66,8 +76,9 @@ out = [
     f"  MI355X_MICROARCH.md HBM section) = **{reads_fetch:.4e} B**; WRITE_SIZE {write['reads.WRITE_SIZE']:.4g} KB → **{reads_write:.3e} B** (finished 32 B occurrence records into per-block slots).",
     f"* HBM traffic per launch = **{reads_fetch + reads_write:.4e} B** vs {rf['algorithmic_bytes_per_launch']:.4e} B algorithmic = {(reads_fetch + reads_write) / rf['algorithmic_bytes_per_launch']:.2f}x: no wasted re-reads",
     "  (the surplus: the 2 x 400-base halo per block, 32 B records where 8 B of seed would do).",
-    f"* achieved = algorithmic bytes / {rf['avg_launch_ms']} ms = **{rf['achieved']} GB/s = {100 * rf['frac']:.1f} % of 8 TB/s**.",
-    f"* SQ_INSTS_VALU {sq['reads.SQ_INSTS_VALU']:.4g} per launch / ({kmers:.3e} hashed k-mers / 64 lanes) = **{valu_per_kmer:.1f} VALU wave-instructions per hashed k-mer** (r01: 44.2);",
+    f"* achieved = algorithmic bytes / {rf['avg_launch_ms']} ms (pipelined steps) = **{rf['achieved']} GB/s = {100 * rf['frac']:.1f} % of 8 TB/s**;",
+    f"  alone on the GPU {seq.get('kernel_ms', {}).get('seeds', [None])[0]} ms = {100 * seq.get('roofline_frac', 0):.1f} %.",
+    f"* SQ_INSTS_VALU {sq['reads.SQ_INSTS_VALU']:.4g} per launch / ({kmers:.3e} hashed k-mers / 64 lanes) = **{valu_per_kmer:.1f} VALU wave-instructions per hashed k-mer** (r01: 44.2, first r02 profile: 41.9);",
     f"  GRBM_GUI_ACTIVE / 8 XCDs = {cyc:.4g} cycles; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles) = **{100 * valu_busy:.0f} %**.",
     "", "| counter | reads_kernel | probe_kernel |", "|---|---|---|"]
 names = sorted({k.split(".", 1)[1] for k in list(sq) + list(sq2)})
@@ -95,7 +106,7 @@ json.dump({"hbm_bytes_per_launch": int(reads_fetch + reads_write), "kernel": "re
            "valu_per_kmer_position_kernel": 38, "valu_busy": round(valu_busy, 3), "probe_fetch_bytes_per_probe": round(probe_fetch_raw / rp["probes_per_launch"], 1),
            "head": head, "source": "profiles/r02_kernel_stats.md PMC section (FETCH_SIZE x2 gfx950 correction for the streaming reads + WRITE_SIZE, separate --pmc passes)"},
           open(os.path.join(dst, "seeds_traffic.json"), "w"))
-for name in ("valu_rates.txt", "feed.txt"):
+for name in ("valu_rates.txt", "feed.txt", "atomic_rates.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "r02_" + name))
 print("ok: traffic", reads_fetch + reads_write, "valu/kmer", valu_per_kmer, "busy", valu_busy, "probe B/probe", probe_fetch_raw / rp["probes_per_launch"])
