@@ -59,14 +59,20 @@ __device__ __forceinline__ uint64_t revcomp_top(uint64_t x) {
     return (~y) & KC<K>::MASK;
 }
 
-// every other base of a 32-base window, first base most significant (the order pair_kmer builds its 16-mers in)
-__device__ __forceinline__ uint32_t even16(uint64_t x) {
-    x &= 0xCCCCCCCCCCCCCCCCull;
-    x = (x | (x << 2)) & 0xF0F0F0F0F0F0F0F0ull;
-    x = (x | (x << 4)) & 0xFF00FF00FF00FF00ull;
-    x = (x | (x << 8)) & 0xFFFF0000FFFF0000ull;
-    x = (x | (x << 16)) & 0xFFFFFFFF00000000ull;
-    return (uint32_t)(x >> 32);
+// every other base of a 32-base window, first base most significant (the order pair_kmer builds its 16-mers in): ev = bases
+// 0, 2, .., 30, od = bases 1, 3, .., 31.  Done on the two 32-bit halves: two shift-or steps bring the wanted fields of every
+// byte pair side by side (bytes 3 and 1 then hold four bases each), and ONE v_perm_b32 picks those bytes out of both halves —
+// 9-11 instructions per 16-mer where five 64-bit shift/or/and stages took about 25.
+__device__ __forceinline__ uint32_t even_fields_to_bytes31(uint32_t w) {
+    uint32_t t = w & 0xCCCCCCCCu;
+    t = (t | (t << 2)) & 0xF0F0F0F0u;
+    return t | (t << 4);                       // byte 3 = bases 0,2,4,6 of the half, byte 1 = bases 8,10,12,14
+}
+__device__ __forceinline__ void evenodd16(uint64_t x, uint32_t& ev, uint32_t& od) {
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    // __builtin_amdgcn_perm(a, b, sel): selector 0-3 = bytes of b, 4-7 = bytes of a
+    ev = __builtin_amdgcn_perm(even_fields_to_bytes31(hi), even_fields_to_bytes31(lo), 0x07050301u);
+    od = __builtin_amdgcn_perm(even_fields_to_bytes31(hi << 2), even_fields_to_bytes31(lo << 2), 0x07050301u);
 }
 
 // reverse-complement image of a stream word: base i of `a` (bits 31-2i, 30-2i) -> its complement at bits 2i+1, 2i
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __re
 }
 
 template <int K, int HV, int ENC>
-__global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
+__global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(5, 5))) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
                                                      const uint64_t* __restrict__ off, uint64_t n_rec,
                                                      const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
                                                      int avx2_compat, int paired, int want_markers, uint64_t rec_base,
@@ -283,20 +289,26 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                 uint32_t A0 = next_word(0), A1 = next_word(1), A2 = next_word(2);
                 uint32_t Bm = 0, B0 = rcword(A0), B1 = rcword(A1), B2 = rcword(A2);  // (Bm only feeds garbage bits of group 0)
                 const uint32_t n_half = (nh_max + 7) >> 3;                           // half-groups of 8 k-mers (uniform per wave)
-                for (uint32_t hg = 0; hg < n_half; hg += 2) {
+                // k-mer i <-> bit 31 - (i & 31) of word i >> 5: a group of 16 is one 16-bit half of its word, even groups the
+                // upper half.  Stored as halves (ds_write_b16): no "is the word complete" bookkeeping in the loop; whatever a
+                // half that was never written holds lies beyond nh and is cleared with the tail below.
+                uint16_t* const mask_half = reinterpret_cast<uint16_t*>(&s_mask[0][slot]);
+                const uint32_t n_grp = n_half >> 1;
+                // whole groups of 16: one straight-line block (the odd half-group of a record's tail is done after the loop —
+                // with the test inside the loop the second half of every group lived in its own basic block and took two
+                // extra register moves per k-mer)
+                for (uint32_t g = 0; g < n_grp; g++) {
                     uint32_t mask = 0;
                     kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
-                    if (hg + 1 < n_half) {
-                        kmer_steps8<K, 8, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
-                        A0 = A1; A1 = A2; A2 = next_word((hg >> 1) + 3);
-                        Bm = B0; B0 = B1; B1 = B2; B2 = rcword(A2);
-                    } else {
-                        mask <<= 8;                                                  // a last half-group: its 8 k-mers are the top byte
-                    }
-                    // k-mer i <-> bit 31 - (i & 31) of word i >> 5: a group of 16 is one 16-bit half of its word, even groups the
-                    // upper half.  Stored as halves (ds_write_b16): no "is the word complete" bookkeeping in the loop; whatever a
-                    // half that was never written holds lies beyond nh and is cleared with the tail below.
-                    reinterpret_cast<uint16_t*>(&s_mask[hg >> 2][slot])[((hg >> 1) & 1u) ^ 1u] = (uint16_t)mask;
+                    kmer_steps8<K, 8, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+                    A0 = A1; A1 = A2; A2 = next_word(g + 3);
+                    Bm = B0; B0 = B1; B1 = B2; B2 = rcword(A2);
+                    mask_half[((g >> 1) * RTPB * 2) + ((g & 1u) ^ 1u)] = (uint16_t)mask;
+                }
+                if (n_half & 1u) {                                                   // a last half-group: its 8 k-mers are the top byte
+                    uint32_t mask = 0;
+                    kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+                    mask_half[((n_grp >> 1) * RTPB * 2) + ((n_grp & 1u) ^ 1u)] = (uint16_t)(mask << 8);
                 }
             }
             if (dealt) __syncthreads();                                 // masks were written by other lanes
@@ -345,8 +357,11 @@ __global__ __launch_bounds__(RTPB) void reads_kernel(const uint8_t* __restrict__
                     }
                     if (has) {
                         const uint64_t wa64 = win64(sF, ba), wb64 = win64(sF, bb);
-                        m0 = (uint64_t)even16(wa64) | ((uint64_t)even16(wb64) << 32);
-                        m1 = (uint64_t)even16(wa64 << 2) | ((uint64_t)even16(wb64 << 2) << 32);
+                        uint32_t ea, oa, eb, ob;
+                        evenodd16(wa64, ea, oa);
+                        evenodd16(wb64, eb, ob);
+                        m0 = (uint64_t)ea | ((uint64_t)eb << 32);
+                        m1 = (uint64_t)oa | ((uint64_t)ob << 32);
                     }
                 }
                 s_m0[tid] = m0;
