@@ -390,3 +390,46 @@ def derep_if_reassign_threshold(old_contain, new_contain, n_kmers, ani_thresh=99
     """True = the genome is kept."""
     threshold = (ani_thresh / 100.0) ** k
     return float(old_contain - new_contain) < threshold * float(n_kmers)
+
+
+# ---- --estimate-unknown (-u) ------------------------------------------------------------------------------------------------
+MED_KMER_FOR_ID_EST = 3.0   # constants.rs:17
+
+
+# contain.rs:901-951.  `counts`: the sample's k-mer counts in the order they are walked.  The reference walks its hash map
+# (hashbrown order, not reproducible here); the host walks the table in ascending k-mer order, and callers of this restatement
+# pass the counts in that order.  Only the moving "median" depends on the order; eps does not.
+def get_kmer_identity(counts, k, mean_read_length):
+    median = 0
+    mov_avg_median = 0.0
+    n = 1.0
+    for count in counts:
+        if count > 1:
+            median += 1 if count > median else -1
+            mov_avg_median += float(median)
+            n += 1.0
+    mov_avg_median /= n
+    num_1s = sum(1 for c in counts if c == 1)
+    num_not1s = sum(c for c in counts if c != 1) & 0xFFFFFFFF      # a u32 in the reference
+    eps = float(num_not1s) / (float(num_not1s) + float(num_1s) + 0.1)
+    if mov_avg_median < MED_KMER_FOR_ID_EST and mean_read_length < 400.0:
+        return 0.995 ** float(k)
+    return eps if eps < 1.0 else 1.0
+
+
+# contain.rs:377-390 (covs: the final_est_cov values) -> scaled values
+def estimate_true_cov(covs, kmer_id, read_length, k):
+    multiplier = read_length / (read_length - float(k) + 1.0)
+    return [c / kmer_id * multiplier for c in covs]
+
+
+# contain.rs:392-408
+def estimate_covered_bases(gn_sizes, covs, c, total_counts, read_length, k):
+    multiplier = read_length / (read_length - float(k) + 1.0)
+    covered = 0.0
+    for g, cv in zip(gn_sizes, covs):
+        covered += float(g) * cv
+    tentative = float(c * total_counts) * multiplier
+    if tentative == 0.0:
+        return 0.0
+    return min(covered / tentative, 1.0)

@@ -34,6 +34,26 @@ int sylph_host_stats(const uint32_t* covs, uint64_t n, uint64_t n_genome_kmers, 
     return 1;
 }
 
+// -u: read k-mer identity of a sample table given in the order it is walked (contain.rs:901-951), and the share of the sample's
+// bases that genomes of sizes gn_size[i] at coverages cov[i] explain (contain.rs:392-408)
+double sylph_host_kmer_identity(const uint32_t* counts, uint64_t n, uint64_t k, double mean_read_length) {
+    SequencesSketch S;
+    S.counts.assign(counts, counts + n);
+    S.k = k;
+    S.mean_read_length = mean_read_length;
+    return *get_kmer_identity(S, true);
+}
+double sylph_host_covered_bases(const uint64_t* gn_size, const double* cov, uint64_t n_genomes, const uint32_t* counts, uint64_t n,
+                                uint64_t c, uint64_t k, double mean_read_length) {
+    SequencesSketch S;
+    S.counts.assign(counts, counts + n);
+    S.k = k; S.c = c;
+    std::vector<GenomeSketch> gs(n_genomes);
+    std::vector<AniResult> rs(n_genomes);
+    for (uint64_t i = 0; i < n_genomes; i++) { gs[i].gn_size = gn_size[i]; rs[i].final_est_cov = cov[i]; rs[i].genome_index = i; }
+    return estimate_covered_bases(rs, gs, S, mean_read_length, k);
+}
+
 double sylph_host_poisson_cdf(double lambda, uint64_t x) { return poisson_cdf(lambda, x); }
 
 // round trip helpers: write a .sylsp from arrays, read it back into caller buffers (sizes via the first call)

@@ -557,11 +557,64 @@ void print_header(bool pseudotax, FILE* out, bool estimate_unknown) {         //
 
 }  // namespace
 
+// --estimate-unknown (-u), contain.rs:901-951 get_kmer_identity: k-mer identity of the reads (identity ^ k) from the share of
+// multiplicity-1 k-mers.  The estimate itself (eps) is a sum over the table.  The reference's "continuous median" of the counts
+// above 1 is a walk over `kmer_counts.values()` in hashbrown's iteration order, which this host does not reproduce: here the
+// walk goes over the table in ascending k-mer order (an arbitrary order with respect to the counts, as the hash map's is).
+// It only decides whether a short-read sample counts as "depth < 3" and gets the fixed 99.5 % identity — a sample right at
+// that limit may take the other branch than `sylph profile -u` does; -I (contain.rs:275) bypasses the walk altogether.
+// The integer types are the reference's: `num_not1s` is a u32 that wraps in a release build.
+std::optional<double> get_kmer_identity(const SequencesSketch& S, bool estimate_unknown) {
+    if (!estimate_unknown) return std::nullopt;
+    uint32_t median = 0;
+    double mov_avg_median = 0., n = 1.;
+    for (const uint32_t count : S.counts) {
+        if (count > 1) {
+            if (count > median) median += 1; else median -= 1;
+            mov_avg_median += (double)median;
+            n += 1.;
+        }
+    }
+    mov_avg_median /= n;
+    int32_t num_1s = 0;
+    uint32_t num_not1s = 0;
+    for (const uint32_t count : S.counts) {
+        if (count == 1) num_1s += 1; else num_not1s += count;
+    }
+    const double eps = (double)num_not1s / ((double)num_not1s + (double)num_1s + 0.1);
+    if (mov_avg_median < MED_KMER_FOR_ID_EST && S.mean_read_length < 400.) {
+        info(S.file_name + " short-read sample has high diversity compared to sequencing depth (approx. avg depth < 3). Using 99.5% as "
+             "read accuracy estimate instead of automatic detection for --estimate-unknown.");
+        return std::pow(0.995, (double)S.k);
+    }
+    return eps < 1. ? eps : 1.;
+}
+
+// contain.rs:377-390
+void estimate_true_cov(std::vector<AniResult>& results, std::optional<double> kmer_id_opt, bool estimate_unknown, double read_length,
+                       uint64_t k) {
+    double multiplier = 1.;
+    if (estimate_unknown) multiplier = read_length / (read_length - (double)k + 1.);
+    if (estimate_unknown && kmer_id_opt)
+        for (auto& r : results) r.final_est_cov = r.final_est_cov / *kmer_id_opt * multiplier;
+}
+
+// contain.rs:392-408: share of the sample's bases the profiled genomes account for
+double estimate_covered_bases(const std::vector<AniResult>& results, const std::vector<GenomeSketch>& genomes, const SequencesSketch& S,
+                              double read_length, uint64_t k) {
+    const double multiplier = read_length / (read_length - (double)k + 1.);
+    double num_covered_bases = 0.;
+    for (const auto& r : results) num_covered_bases += (double)genomes[r.genome_index].gn_size * r.final_est_cov;
+    uint64_t num_total_counts = 0;
+    for (const uint32_t count : S.counts) num_total_counts += count;
+    const double num_tentative_bases = (double)(S.c * num_total_counts) * multiplier;
+    if (num_tentative_bases == 0.) return 0.;
+    return std::min(num_covered_bases / num_tentative_bases, 1.);
+}
+
 // contain.rs:115-351
 int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
     if (pseudotax_in) args.pseudotax = true;
-    if (args.estimate_unknown)
-        throw Error{1, "--estimate-unknown (-u) is not supported: it depends on hash-map iteration order in the reference"};
     std::vector<std::string> genome_sketch_files, genome_files, read_sketch_files;
     std::vector<std::vector<std::string>> read_files;
     std::vector<std::string> all_files = args.files;
@@ -678,6 +731,10 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                 });
                 for (auto& r : res) if (r) stats.push_back(*r);
             }
+            std::optional<double> kmer_id_opt;                               // contain.rs:274-281
+            if (args.seq_id) kmer_id_opt = std::pow(*args.seq_id / 100., (double)S.k);
+            else kmer_id_opt = get_kmer_identity(S, args.estimate_unknown);
+            estimate_true_cov(stats, kmer_id_opt, args.estimate_unknown, S.mean_read_length, S.k);   // :295
             if (args.pseudotax) {
                 info(files[0] + " taxonomic profiling; reassigning k-mers for " + std::to_string(stats.size()) + " genomes...");
                 // winner_table (contain.rs:410-430) + second get_stats pass with the winner map (:300-307, :637-646) on the
@@ -707,11 +764,19 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                     if ((double)(stats[i].contain_count - r->contain_count) < thr) stats2.push_back(*r);
                 }
                 stats.swap(stats2);
+                estimate_true_cov(stats, kmer_id_opt, args.estimate_unknown, S.mean_read_length, S.k);   // :310
                 info(files[0] + " has " + std::to_string(stats.size()) + " genomes passing profiling threshold. ");
+                double bases_explained = 1.;                                 // :313-317
+                if (args.estimate_unknown) {
+                    bases_explained = estimate_covered_bases(stats, genome_sketches, S, S.mean_read_length, S.k);
+                    char buf[64];
+                    snprintf(buf, sizeof buf, "%.2f", bases_explained * 100.);
+                    info(files[0] + " has " + buf + "% of reads detected in database by profile");
+                }
                 double total_cov = 0, total_seq_cov = 0;                     // contain.rs:319-326
                 for (const auto& r : stats) { total_cov += r.final_est_cov; total_seq_cov += r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size; }
                 for (auto& r : stats) r.rel_abund = r.final_est_cov / total_cov * 100.;
-                for (auto& r : stats) r.seq_abund = r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size / total_seq_cov * 100. * 1.;
+                for (auto& r : stats) r.seq_abund = r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size / total_seq_cov * 100. * bases_explained;
                 std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return *y.rel_abund < *x.rel_abund; });   // :330
             } else {
                 std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return y.final_est_ani < x.final_est_ani; });   // :333

@@ -74,7 +74,7 @@ int run_contain(Argv a, bool profile) {
         else if (t == "-t") c.threads = std::max<uint64_t>(1, strtoull(a.one().c_str(), nullptr, 10));
         else if (t == "-s" || t == "--sample-threads") a.one();
         else if (t == "-u" || t == "--estimate-unknown") { c.estimate_unknown = true; a.i++; }
-        else if (t == "-I" || t == "--read-seq-id") a.one();
+        else if (t == "-I" || t == "--read-seq-id") c.seq_id = atof(a.one().c_str());
         else if (t == "-R" || t == "--redundancy-threshold") c.redundant_ani = atof(a.one().c_str());
         else if (t == "-r" || t == "--reads") append(c.reads, a.multi());
         else if (t == "-1" || t == "--first-pairs") append(c.first_pair, a.multi());

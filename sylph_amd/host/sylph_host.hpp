@@ -26,6 +26,7 @@ constexpr double MEDIAN_ANI_THRESHOLD = 2.;
 constexpr double MIN_ANI_DEF = 0.9, MIN_ANI_P_DEF = 0.95;
 constexpr double MAX_MEDIAN_FOR_MEAN_FINAL_EST = 15.;
 constexpr double DEFAULT_FPR = 0.0001;
+constexpr double MED_KMER_FOR_ID_EST = 3.;   // constants.rs:17
 constexpr const char* QUERY_FILE_SUFFIX = ".syldb";
 constexpr const char* SAMPLE_FILE_SUFFIX = ".sylsp";
 
@@ -177,6 +178,7 @@ struct ContainArgs {   // the cmdline.rs:88-160 fields the statistics read
     bool pseudotax = false, no_ci = false, no_adj = false, mean_coverage = false, estimate_unknown = false;
     bool debug_f64 = false;   // --debug-f64: float columns as %.17g (test aid, not in the reference)
     double redundant_ani = 99.0;
+    std::optional<double> seq_id;   // -I/--read-seq-id (per cent): overrides the automatic read identity of -u (contain.rs:275)
     uint64_t threads = 3;   // -t: genomes whose statistics run concurrently (cmdline.rs default 3)
 };
 std::optional<double> ratio_lambda(const std::vector<uint32_t>& full_covs, double min_count_correct);   // inference.rs:207
@@ -203,6 +205,11 @@ struct ContainCmdArgs : ContainArgs {   // cmdline.rs:88-160
     uint64_t k = 31, c = 200, min_spacing_kmer = 30;
     bool individual = false;
 };
+// --estimate-unknown (contain.rs:901-951, :377-408)
+std::optional<double> get_kmer_identity(const SequencesSketch& S, bool estimate_unknown);
+void estimate_true_cov(std::vector<AniResult>& results, std::optional<double> kmer_id_opt, bool estimate_unknown, double read_length, uint64_t k);
+double estimate_covered_bases(const std::vector<AniResult>& results, const std::vector<GenomeSketch>& genomes, const SequencesSketch& S,
+                              double read_length, uint64_t k);
 int sketch(Engine& e, const SketchArgs& args);                              // sketch.rs:276; returns the exit code
 int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out);  // contain.rs:115 (query: false, profile: true)
 

@@ -247,7 +247,7 @@ def test_raw_inputs_equal_presketched(data):
     assert L.sylph_host_syldb_size(h) == len(g["O157"][1])
 
 
-def expected_floats(data, sample, paired, pseudotax, genome_order):
+def expected_floats(data, sample, paired, pseudotax, genome_order, unknown=False, seq_id=None):
     """The float columns recomputed by the INDEPENDENT restatement (oracle/pyref.py: Python ints/dicts, scipy Poisson tail —
     no code shared with sylph_amd/host/inference.cpp or with the C++ oracle): statistics, winner table, reassignment
     threshold, abundances, sort order."""
@@ -265,7 +265,16 @@ def expected_floats(data, sample, paired, pseudotax, genome_order):
         else:
             cache[("s", paired)] = P.sketch_sequences_needle([bytes(r) for r in data["m1"]], 200, 31)
     counts = cache[("s", paired)]["kmer_counts"]
+    mean_len = cache[("s", paired)]["mean_read_length"]
     min_ani = 0.95 if pseudotax else 0.90
+    kmer_id = None
+    if unknown:      # -u: read identity from -I, else from the table walked in ascending k-mer order (the host's order)
+        kmer_id = (seq_id / 100.0) ** 31 if seq_id is not None else P.get_kmer_identity([counts[km] for km in sorted(counts)], 31, mean_len)
+
+    def true_cov(rs):
+        if kmer_id is not None:
+            for r, cv in zip(rs, P.estimate_true_cov([r["st"]["final_est_cov"] for r in rs], kmer_id, mean_len, 31)):
+                r["st"] = dict(r["st"], final_est_cov=cv)
     res = []
     for i, g in enumerate(gs):
         pr = P.probe(g["kmers"], counts)
@@ -274,6 +283,7 @@ def expected_floats(data, sample, paired, pseudotax, genome_order):
         st = P.stats(pr[0], pr[1], len(g["kmers"]), min_ani=min_ani)
         if st["passed"]:
             res.append(dict(i=i, st=st, lost=None))
+    true_cov(res)
     if pseudotax:
         winner = P.winner_table([(r["i"], r["st"]["final_est_ani"], gs[r["i"]]["kmers"], gs[r["i"]]["tracked"]) for r in res])
         res2 = []
@@ -286,11 +296,16 @@ def expected_floats(data, sample, paired, pseudotax, genome_order):
             if st["passed"] and P.derep_if_reassign_threshold(r["st"]["contain_count"], cc, len(g["kmers"])):
                 res2.append(dict(i=r["i"], st=st, lost=lost))
         res = res2
+        true_cov(res)
+        explained = 1.0
+        if unknown:
+            explained = P.estimate_covered_bases([gs[r["i"]]["gn_size"] for r in res], [r["st"]["final_est_cov"] for r in res], 200,
+                                                 sum(counts.values()), mean_len, 31)
         tot = sum(r["st"]["final_est_cov"] for r in res)
         tots = sum(r["st"]["final_est_cov"] * gs[r["i"]]["gn_size"] for r in res)
         for r in res:
             r["rel"] = r["st"]["final_est_cov"] / tot * 100.0
-            r["seq"] = r["st"]["final_est_cov"] * gs[r["i"]]["gn_size"] / tots * 100.0
+            r["seq"] = r["st"]["final_est_cov"] * gs[r["i"]]["gn_size"] / tots * 100.0 * explained
         res.sort(key=lambda r: -r["rel"])
     else:
         res.sort(key=lambda r: -r["st"]["final_est_ani"])
@@ -339,6 +354,32 @@ def test_float_columns_1e6_vs_independent_restatement(data):
             res, gs = expected_floats(data, None, paired, pseudotax, order)
             assert len(res) >= 1
             compare_f64(p.stdout, res, gs, pseudotax)
+
+
+def test_estimate_unknown_columns_vs_independent_restatement(data):
+    """-u/--estimate-unknown (contain.rs:901-951, :377-408): True_cov header, coverages divided by the read k-mer identity and
+    scaled by L / (L - k + 1), Sequence_abundance scaled by the share of explained bases — with -I (identity given: no
+    order-dependent step anywhere) and with the automatic estimate, at 1e-6 against oracle/pyref.py."""
+    d = data["dir"]
+    g = data["genomes"]
+    order = ["EC590", "K12", "O157", "rand"]
+    out = d / "out6"
+    run("sketch", *[g[n][0] for n in order], "-o", out / "db", "-d", out, "-1", d / "s_1.fq", "-2", d / "s_2.fq", "--fpr", "0",
+        "-r", d / "single.fastq.gz")
+    plain = run("profile", out / "db.syldb", out / "single.fastq.gz.sylsp", "--debug-f64").stdout
+    for sample, paired in ((out / "s_1.fq.paired.sylsp", True), (out / "single.fastq.gz.sylsp", False)):
+        for extra, seq_id in ((("-u", "-I", "98.5"), 98.5), (("-u",), None)):
+            p = run("profile", out / "db.syldb", sample, "--debug-f64", *extra)
+            assert p.stdout.split("\n")[0].split("\t")[5] == "True_cov"
+            res, gs = expected_floats(data, None, paired, True, order, unknown=True, seq_id=seq_id)
+            assert len(res) >= 1
+            compare_f64(p.stdout, res, gs, True)
+            q = run("query", out / "db.syldb", sample, "--debug-f64", *extra)      # query: coverages scaled, header unchanged
+            assert q.stdout.split("\n")[0].split("\t")[3] == "Eff_cov"
+            res, gs = expected_floats(data, None, paired, False, order, unknown=True, seq_id=seq_id)
+            compare_f64(q.stdout, res, gs, False)
+    with_u = run("profile", out / "db.syldb", out / "single.fastq.gz.sylsp", "--debug-f64", "-u", "-I", "98.5").stdout
+    assert with_u != plain                                # the option changes the coverage and abundance columns
 
 
 def test_paired_default_fpr_warns_about_exact_semantics(data):

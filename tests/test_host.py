@@ -79,6 +79,38 @@ def test_stats_match_oracle(host):
             assert abs(host.sylph_host_poisson_cdf(lam, x) - O.poisson_cdf(lam, x)) < 1e-12
 
 
+def test_estimate_unknown_pieces_vs_independent_restatement(host):
+    """-u (contain.rs:901-951, :392-408): the read k-mer identity from the count table (both branches: shallow short-read samples
+    get 0.995^k, everything else the share of multiplicity > 1 counts) and the explained share of bases, against oracle/pyref.py."""
+    from oracle import pyref as P
+    host.sylph_host_kmer_identity.restype = C.c_double
+    host.sylph_host_kmer_identity.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double]
+    host.sylph_host_covered_bases.restype = C.c_double
+    host.sylph_host_covered_bases.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double]
+    rng = np.random.default_rng(7)
+    branches = set()
+    for trial in range(200):
+        n = int(rng.choice([0, 1, 7, 300, 5000]))
+        lam = float(rng.choice([0.05, 0.8, 2.0, 3.5, 9.0]))
+        counts = (rng.poisson(lam, size=n) + 1).astype(np.uint32)
+        if trial % 9 == 0 and n:
+            counts[rng.integers(0, n, size=2)] = 4_000_000_000                     # the u32 accumulator of the reference wraps
+        mean_len = float(rng.choice([100.0, 150.5, 399.9, 400.0, 9000.0]))
+        k = int(rng.choice([21, 31]))
+        want = P.get_kmer_identity([int(x) for x in counts], k, mean_len)
+        got = host.sylph_host_kmer_identity(counts.ctypes.data_as(C.c_void_p), n, k, mean_len)
+        assert abs(got - want) <= 1e-12 * max(1.0, abs(want)), (trial, got, want)
+        branches.add("fixed" if want == 0.995 ** float(k) else ("one" if want == 1.0 else "eps"))
+        G = int(rng.integers(0, 6))
+        gn = rng.integers(100_000, 9_000_000, size=G).astype(np.uint64)
+        cov = rng.uniform(0.01, 50.0, size=G)
+        want = P.estimate_covered_bases([int(x) for x in gn], [float(x) for x in cov], 200, int(counts.astype(np.uint64).sum()), mean_len, k)
+        got = host.sylph_host_covered_bases(gn.ctypes.data_as(C.c_void_p), cov.ctypes.data_as(C.c_void_p), G,
+                                            counts.ctypes.data_as(C.c_void_p), n, 200, k, mean_len)
+        assert abs(got - want) <= 1e-12 * max(1.0, abs(want)), (trial, got, want)
+    assert {"fixed", "eps"} <= branches
+
+
 def test_poisson_cdf_against_mpmath_table(host, golden_dir):
     """The Poisson tail behind the coverage cap (contain.rs:664-675; statrs Poisson::cdf = Q(x+1, lambda)) against a table
     computed with mpmath at 50 digits (tests/golden/make_poisson_table.py) — NOT against the oracle, whose incomplete-gamma
