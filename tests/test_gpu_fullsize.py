@@ -80,6 +80,52 @@ def test_one_gbp_sample_against_the_oracle(ctx):
         assert np.array_equal(covs[int(coff2[gi]):int(coff2[gi + 1])], np.sort(ecov[gi]))
 
 
+def test_ragged_reads_with_n_against_the_oracle(ctx):
+    """The c3r shape at size: 1.5 M pairs trimmed to 35-151 bp each (0.28 Gbp), 0.1 % N.  No two lanes of a wavefront walk the
+    same number of k-mers (records are dealt to the lanes by length), blocks hold a varying number of records (some need a
+    second pass), mates of 33 bp and more carry markers and shorter ones do not, N takes the exact ASCII path: bit for bit
+    against the oracle, paired and single-end (single-end reads the same bytes as 3 M records with the cut-off at 4), through
+    the read-per-lane kernel and the position kernel, in one push and in three."""
+    import torch
+    from sylph_amd import synth
+    dev = torch.device("cuda", 0)
+    c, k, n_pairs = 200, 31, 1_500_000
+    genomes = synth.random_genomes(12, 1_000_000, dev, 5, mutated_frac=0.0)
+    bases, off = synth.ragged_paired_reads(genomes, n_pairs, min_len=31, seed=23)     # 31/32: below / at the seeding minimum
+    torch.cuda.synchronize()
+    n_rec = 2 * n_pairs
+    n_bases = int(off[-1].item())
+    hb = bases[:n_bases].cpu().numpy()
+    ho = off.cpu().numpy().astype(np.uint64)
+    assert (hb == ord("N")).sum() > 100_000
+
+    def sketch(paired, seeds, batches=1):
+        ctx.set_option("seeds", seeds)
+        try:
+            sk = S.ReadSketcher(ctx, c=c, k=k, paired=paired)
+            step = ((n_rec // batches + 1) // 2) * 2
+            keep = []
+            for a in range(0, n_rec, step):
+                z = min(n_rec, a + step)
+                o = (off[a:z + 1] - off[a]).contiguous()
+                keep.append(o)
+                torch.cuda.synchronize()
+                sk.push_device(bases.data_ptr() + int(off[a].item()), o.data_ptr(), z - a, int(o[-1].item()))
+            r = sk.finish()
+            sk.close()
+            return r
+        finally:
+            ctx.set_option("seeds", "auto")
+
+    for paired in (True, False):
+        e = O.sketch_reads(hb, ho, c=c, k=k, paired=paired)
+        assert e["dup_removed"] > 100
+        for seeds, batches in (("auto", 1), ("slots", 1), ("auto", 3)):
+            g = sketch(paired, seeds, batches)
+            assert np.array_equal(g["kmers"], e["kmers"]) and np.array_equal(g["counts"], e["counts"]), (paired, seeds, batches)
+            assert g["dup_removed"] == e["dup_removed"], (paired, seeds, batches)
+
+
 def test_long_read_sample_in_two_pushes_at_c100_against_a_c200_database(ctx):
     """BASELINE configs[4] (C5) in small: ONT-like reads (log-normal lengths, N50 10 kb, 5 % substitutions; 1.2 Gbp — the oracle
     sketches that in seconds) sketched at c = 100 in TWO pushes of whole reads (a push holds < 2^32 bases: the real 5 Gbp sample
