@@ -544,7 +544,9 @@ def main():
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
                            "note": f"integer-VALU issue bound: {ipk} VALU wave-instructions per hashed k-mer (SQ counters in profiles/)" +
                                    (f"; {depth} steps in flight on {n_workers} sketch streams + the profile stream: launch durations include time shared with the other streams' kernels (alone on the GPU: one_step_at_a_time)" if depth > 1 else ""),
-                           # secondary ceiling: VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s
+                           # secondary ceiling: VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s, i.e. 4 cycles per
+                           # wave-instruction; plain VOP2 integer ops issue faster than that on this chip (profiles/r02_valu_rates.txt),
+                           # so a launch alone on the GPU can come out a few per cent above 1.0
                            "valu_ceiling": {"instr_per_kmer": ipk, "kmers_per_launch": int(hashed),
                                             "min_ms": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3, 4),
                                             "frac": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3 / avg_ms, 3)}}
@@ -557,8 +559,15 @@ def main():
         # ... which, sharded, is also what this rank probes: 1/N of each of the N x spg tables of the step
         alg = probes * (12 + 64) + 8 * hits
         avg = probe_ms / probe_launches
+        ptraffic = None
+        try:       # FETCH_SIZE + WRITE_SIZE per probe of the C3 probe (rocprofv3 --pmc passes, profiles/r02_kernel_stats.md) x this launch's probes
+            per_probe = json.load(open(os.path.join(ROOT, "profiles", "seeds_traffic.json"))).get("probe_hbm_bytes_per_probe")
+            if per_probe and wl in ("c3", "c4", "c3r"):
+                ptraffic = int(per_probe * probes)
+        except Exception:
+            ptraffic = None
         out["roofline_profile"] = {"bound": "hbm", "kernel": "probe_kernel", "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "peak": 8000.0,
-                                   "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                                   "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / 8000.0, 4), "traffic": ptraffic,
                                    "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg, 4),
                                    "probes_per_launch": int(probes), "hits_per_launch": int(hits),
                                    "note": "random 64 B line reads, latency-bound; one index line per probe is the access granule"}
@@ -571,8 +580,14 @@ def main():
             a1 = f1["seeds"][0] / f1["seeds"][1]
             o1["roofline_frac"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (a1 * 1e-3) / 1e9 / 8000.0, 4)
             o1["valu_ceiling_frac"] = round(out["roofline"]["valu_ceiling"]["min_ms"] / a1, 3)
+            # the same launches with nothing else on the GPU (same run, HIP events of the one-step-at-a-time leg): the kernel's own speed
+            out["roofline"]["alone_on_gpu"] = {"avg_launch_ms": round(a1, 4), "achieved": round(out["roofline"]["algorithmic_bytes_per_launch"] / (a1 * 1e-3) / 1e9, 1),
+                                               "frac": o1["roofline_frac"], "launches": int(f1["seeds"][1])}
         if "roofline_profile" in out and f1["probe"][1]:
-            o1["roofline_profile_frac"] = round(out["roofline_profile"]["algorithmic_bytes_per_launch"] / (f1["probe"][0] / f1["probe"][1] * 1e-3) / 1e9 / 8000.0, 4)
+            p1 = f1["probe"][0] / f1["probe"][1]
+            o1["roofline_profile_frac"] = round(out["roofline_profile"]["algorithmic_bytes_per_launch"] / (p1 * 1e-3) / 1e9 / 8000.0, 4)
+            out["roofline_profile"]["alone_on_gpu"] = {"avg_launch_ms": round(p1, 4), "achieved": round(out["roofline_profile"]["algorithmic_bytes_per_launch"] / (p1 * 1e-3) / 1e9, 1),
+                                                       "frac": o1["roofline_profile_frac"], "launches": int(f1["probe"][1])}
         out["one_step_at_a_time"] = o1
     if not args.no_verify and last.get("res") is not None:
         try:

@@ -91,19 +91,23 @@ out += ["",
         f"* FETCH_SIZE {fetch['probe.FETCH_SIZE']:.4g} KB → **{probe_fetch_raw:.4e} B** per launch = **{probe_fetch_raw / rp['probes_per_launch']:.0f} B per probe** as counted",
         f"  (64 B requests: the table in (12 B per probe, streamed) + one 64 B index line + overflow runs; r01: 180 B per probe with a cache-warm sample);",
         f"  WRITE_SIZE {write['probe.WRITE_SIZE']:.4g} KB → {probe_write:.3e} B ({rp['hits_per_launch']} hits x 8 B staged through LDS).",
-        f"* algorithmic bytes = probes x (12 + 64) + 8 x hits = {rp['algorithmic_bytes_per_launch']:.4e} B; / {rp['avg_launch_ms']} ms = **{rp['achieved']} GB/s = {100 * rp['frac']:.1f} % of 8 TB/s**",
-        f"  (latency-bound random line reads; {pcyc:.3g} cycles per launch).",
-        f"* a batch of 8 samples per launch (profiles/r02_bench_c4.json): {b['c4']['roofline_profile']['avg_launch_ms']} ms = {100 * b['c4']['roofline_profile']['frac']:.1f} % of peak." if "c4" in b else ""]
+        f"* algorithmic bytes = probes x (12 + 64) + 8 x hits = {rp['algorithmic_bytes_per_launch']:.4e} B; alone on the GPU {seq.get('kernel_ms', {}).get('probe', [None])[0]} ms = "
+        f"**{100 * seq.get('roofline_profile_frac', 0):.1f} % of 8 TB/s** (latency-bound random line reads; {pcyc:.3g} cycles per launch);",
+        f"  in the pipelined steps, beside two seeding kernels, {rp['avg_launch_ms']} ms = {rp['achieved']} GB/s = {100 * rp['frac']:.1f} %.",
+        (f"* a batch of 8 samples per launch (profiles/r02_bench_c4.json): alone {b['c4'].get('one_step_at_a_time', {}).get('kernel_ms', {}).get('probe', [None])[0]} ms = "
+         f"{100 * b['c4'].get('one_step_at_a_time', {}).get('roofline_profile_frac', 0):.1f} % of peak; pipelined {b['c4']['roofline_profile']['avg_launch_ms']} ms = {100 * b['c4']['roofline_profile']['frac']:.1f} %.") if "c4" in b else ""]
 if sqr:
     k3 = b["c3r"]["roofline"]["valu_ceiling"]["kmers_per_launch"]
     c3c = sqr["reads.GRBM_GUI_ACTIVE"] / 8
     out += ["", "### ragged input (c3r: 2 x 35-151 bp uniform, 0.1 % N)", "",
             f"SQ_INSTS_VALU {sqr['reads.SQ_INSTS_VALU']:.4g} / ({k3:.3e} hashed k-mers / 64) = **{sqr['reads.SQ_INSTS_VALU'] / (k3 / 64):.1f} VALU wave-instructions per hashed k-mer** —",
             "wave-instructions are issued for the longest read of each wavefront while the shorter lanes idle; VALU busy "
-            f"{100 * sqr['reads.SQ_ACTIVE_INST_VALU'] * 4 / (1024 * c3c):.0f} %, {b['c3r']['roofline']['avg_launch_ms']} ms per 0.62 Gbp launch."]
+            f"{100 * sqr['reads.SQ_ACTIVE_INST_VALU'] * 4 / (1024 * c3c):.0f} %; {b['c3r'].get('one_step_at_a_time', {}).get('kernel_ms', {}).get('seeds', [None])[0]} ms per 0.62 Gbp launch alone "
+            f"({b['c3r']['roofline']['avg_launch_ms']} ms in the pipelined steps)."]
 open(os.path.join(dst, "r02_kernel_stats.md"), "w").write("\n".join(out) + "\n")
 json.dump({"hbm_bytes_per_launch": int(reads_fetch + reads_write), "kernel": "reads_kernel<31,1,0>", "valu_per_kmer": round(valu_per_kmer, 1),
            "valu_per_kmer_position_kernel": 38, "valu_busy": round(valu_busy, 3), "probe_fetch_bytes_per_probe": round(probe_fetch_raw / rp["probes_per_launch"], 1),
+           "probe_hbm_bytes_per_probe": round((probe_fetch_raw + probe_write) / rp["probes_per_launch"], 1),
            "head": head, "source": "profiles/r02_kernel_stats.md PMC section (FETCH_SIZE x2 gfx950 correction for the streaming reads + WRITE_SIZE, separate --pmc passes)"},
           open(os.path.join(dst, "seeds_traffic.json"), "w"))
 for name in ("valu_rates.txt", "feed.txt", "atomic_rates.txt"):
