@@ -54,6 +54,16 @@ double sylph_host_covered_bases(const uint64_t* gn_size, const double* cov, uint
     return estimate_covered_bases(rs, gs, S, mean_read_length, k);
 }
 
+// `inspect` scalars (tests): returns the length written (without the terminator), 0 if the buffer is too small
+static uint64_t copy_out(const std::string& s, char* buf, uint64_t cap) {
+    if (s.size() + 1 > cap) return 0;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return s.size();
+}
+uint64_t sylph_host_inspect_f32(float v, char* buf, uint64_t cap) { return copy_out(inspect_f32(v), buf, cap); }
+uint64_t sylph_host_inspect_f64(double v, char* buf, uint64_t cap) { return copy_out(inspect_f64(v), buf, cap); }
+uint64_t sylph_host_inspect_str(const char* s, char* buf, uint64_t cap) { return copy_out(inspect_str(s), buf, cap); }
+
 double sylph_host_poisson_cdf(double lambda, uint64_t x) { return poisson_cdf(lambda, x); }
 
 // round trip helpers: write a .sylsp from arrays, read it back into caller buffers (sizes via the first call)

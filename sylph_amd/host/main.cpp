@@ -1,5 +1,5 @@
 // main.cpp — `sylph-hip sketch|profile|query`: the reference's command surface for the hot path only (flag names and
-// defaults from cmdline.rs:28-160; `inspect`, hidden estimators and logging flags are not carried).
+// defaults from cmdline.rs:28-173; hidden estimators and logging flags are not carried).
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -103,16 +103,35 @@ int run_contain(Argv a, bool profile) {
     return rc;
 }
 
+int run_inspect(Argv a) {   // cmdline.rs:166-173; no GPU involved
+    InspectArgs c;
+    while (a.more()) {
+        const std::string t = a.cur();
+        if (t == "-o" || t == "--output-file") c.out_file_name = a.one();
+        else if (t[0] == '-' && t.size() > 1) throw Error{2, "unknown option " + t};
+        else { c.files.push_back(t); a.i++; }
+    }
+    FILE* out = stdout;
+    if (c.out_file_name) {
+        out = fopen(c.out_file_name->c_str(), "w");
+        if (!out) throw Error{1, "could not create " + *c.out_file_name};
+    }
+    const int rc = inspect(c, out);
+    if (out != stdout) fclose(out);
+    return rc;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: sylph-hip <sketch|profile|query> ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: sylph-hip <sketch|profile|query|inspect> ...\n"); return 2; }
     try {
         const std::string cmd = argv[1];
         Argv a{argc, argv};
         if (cmd == "sketch") return run_sketch(a);
         if (cmd == "profile") return run_contain(a, true);
         if (cmd == "query") return run_contain(a, false);
+        if (cmd == "inspect") return run_inspect(a);
         fprintf(stderr, "unknown subcommand %s\n", argv[1]);
         return 2;
     } catch (const Error& e) {

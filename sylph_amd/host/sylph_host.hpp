@@ -210,6 +210,15 @@ std::optional<double> get_kmer_identity(const SequencesSketch& S, bool estimate_
 void estimate_true_cov(std::vector<AniResult>& results, std::optional<double> kmer_id_opt, bool estimate_unknown, double read_length, uint64_t k);
 double estimate_covered_bases(const std::vector<AniResult>& results, const std::vector<GenomeSketch>& genomes, const SequencesSketch& S,
                               double read_length, uint64_t k);
+// `inspect` (inspect.rs:117): YAML summary of *.syldb / *.sylsp files; host only
+struct InspectArgs {   // cmdline.rs:166-173
+    std::vector<std::string> files;
+    std::optional<std::string> out_file_name;
+};
+int inspect(const InspectArgs& args, FILE* out);
+std::string inspect_f32(float v);                 // the scalars as serde_yaml 0.9 / ryu would print them (tests)
+std::string inspect_f64(double v);
+std::string inspect_str(const std::string& s);
 int sketch(Engine& e, const SketchArgs& args);                              // sketch.rs:276; returns the exit code
 int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out);  // contain.rs:115 (query: false, profile: true)
 

@@ -252,6 +252,94 @@ def test_syldb_layout(host, tmp_path):
     assert not host.sylph_host_read_syldb(p)   # truncated file -> error, no crash
 
 
+def test_inspect_command_yaml(host, tmp_path):
+    """`sylph-hip inspect` (inspect.rs:117-233, no GPU involved) on files written by the independent bincode encoders: the
+    reference's own assertions (the output names the sketched files, tests/integration_test.rs:505-549), the documents parsed
+    with PyYAML field by field, and the serde_yaml layout (block sequences not indented under their key, field order of the
+    structs, `null` for a missing sample name)."""
+    import subprocess
+    import yaml
+    rng = np.random.default_rng(5)
+    b = struct.pack("<Q", 2)
+    gen = []
+    for i, (fn, cn) in enumerate(((b"test_files/e.coli-EC590.fasta.gz", b"NZ_CP016182.2 Escherichia coli strain EC590 chromosome, complete genome"),
+                                  (b"test_files/e.coli-K12.fasta.gz", b"contig: with a colon # and a hash"))):
+        gk = rng.integers(0, 2**63, size=100 + i, dtype=np.uint64)
+        b += struct.pack("<Q", len(gk)) + gk.tobytes() + b"\x00"
+        b += struct.pack("<Q", len(fn)) + fn + struct.pack("<Q", len(cn)) + cn
+        b += struct.pack("<QQQQ", 200, 31, 4_600_000 + i, 30)
+        gen.append((fn.decode(), cn.decode(), len(gk), 4_600_000 + i))
+    db = tmp_path / "db.syldb"
+    db.write_bytes(b)
+    km = np.sort(rng.integers(0, 2**62, size=777, dtype=np.uint64))
+    cnt = rng.integers(1, 9, size=777, dtype=np.uint32)
+    sp = tmp_path / "k12_R1.fq.paired.sylsp"
+    sp.write_bytes(bincode_sylsp(km, cnt, 200, 31, b"test_files/k12_R1.fq", None, True, 148.25))
+    sp2 = tmp_path / "named.sylsp"
+    sp2.write_bytes(bincode_sylsp(km[:10], cnt[:10], 100, 21, b"reads.fq.gz", b"12345", False, 150.0))
+    exe = os.path.join(ROOT, "sylph_amd", "sylph-hip")
+    r = subprocess.run([exe, "inspect", str(db), str(sp), str(sp2), str(tmp_path / "notes.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "notes.txt file is not a .sylsp or .syldb file" in r.stderr
+    out = r.stdout
+    assert "e.coli-EC590.fasta.gz" in out and "e.coli-K12.fasta.gz" in out and "k12_R1.fq" in out      # the reference's assertions
+    docs = yaml.safe_load(out)
+    assert docs[0] == {"database_file": str(db), "c": 200, "k": 31, "min_spacing_parameter": 30,
+                       "genome_files": [{"file_name": f, "genome_kmers_num": n, "first_contig_name": c, "genome_size": g} for f, c, n, g in gen]}
+    approx = np.float32(148.25 + 31 - 1) / np.float32(148.25) * np.float32(200) * np.float32(777)
+    assert docs[1]["file_name"] == "test_files/k12_R1.fq" and docs[1]["num_sketched_kmers"] == 777 and docs[1]["paired"] is True
+    assert docs[1]["sample_name"] is None and docs[1]["mean_read_length"] == 148.25 and docs[1]["c"] == 200 and docs[1]["k"] == 31
+    assert np.float32(docs[1]["approximate_number_bases"]) == approx
+    assert docs[2]["sample_name"] == "12345" and docs[2]["paired"] is False and docs[2]["mean_read_length"] == 150.0
+    lines = out.split("\n")
+    assert lines[0] == f"- database_file: {db}" and lines[4] == "  genome_files:" and lines[5].startswith("  - file_name: ")
+    assert "    first_contig_name: 'contig: with a colon # and a hash'" in lines
+    assert "  sample_name: null" in lines and "  sample_name: '12345'" in lines and "  mean_read_length: 150.0" in lines
+    assert [l.split(":")[0].strip("- ") for l in lines[13:21]] == ["file_name", "c", "k", "num_sketched_kmers", "approximate_number_bases",
+                                                                   "mean_read_length", "sample_name", "paired"]
+    # -o writes the same text to a file
+    r2 = subprocess.run([exe, "inspect", str(sp), "-o", str(tmp_path / "o.yaml")], capture_output=True, text=True)
+    assert r2.returncode == 0 and (tmp_path / "o.yaml").read_text() == "\n".join(lines[13:21]) + "\n"
+
+
+def test_inspect_scalars(host):
+    """Floats as ryu prints them (shortest round-trip digits; fixed notation up to 16 / 13 integer digits, a trailing .0 on
+    integers) against numpy's shortest-digit formatter, and strings that must be quoted to stay strings."""
+    for fn in (host.sylph_host_inspect_f32, host.sylph_host_inspect_f64, host.sylph_host_inspect_str):
+        fn.restype = C.c_uint64
+    host.sylph_host_inspect_f32.argtypes = [C.c_float, C.c_char_p, C.c_uint64]
+    host.sylph_host_inspect_f64.argtypes = [C.c_double, C.c_char_p, C.c_uint64]
+    host.sylph_host_inspect_str.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
+    buf = C.create_string_buffer(256)
+
+    def f32(v):
+        assert host.sylph_host_inspect_f32(float(np.float32(v)), buf, 256)
+        return buf.value.decode()
+
+    def f64(v):
+        assert host.sylph_host_inspect_f64(float(v), buf, 256)
+        return buf.value.decode()
+
+    def st(x):
+        assert host.sylph_host_inspect_str(x.encode(), buf, 256)
+        return buf.value.decode()
+
+    rng = np.random.default_rng(9)
+    for v in list(rng.uniform(1, 2e12, size=200)) + list(rng.uniform(1e-4, 1, size=50)) + [1.0, 150.0, 0.5, 1234567936.0, 16777216.0]:
+        want = np.format_float_positional(np.float32(v), unique=True, trim="0")
+        assert f32(v) == want and np.float32(f32(v)) == np.float32(v), (v, f32(v), want)
+        want = np.format_float_positional(np.float64(v), unique=True, trim="0")
+        assert f64(v) == want and float(f64(v)) == float(v), (v, f64(v), want)
+    assert f64(1e16) == "1e16" and f64(1.5e16) == "1.5e16" and f64(1e15) == "1000000000000000.0" and f64(1e-5) == "0.00001" and f64(1e-6) == "1e-6"
+    assert f32(1e13) == "1e13" and f32(3e12) == "3000000000000.0" and f64(0.0) == "0.0"
+    assert f64(float("inf")) == ".inf" and f64(float("-inf")) == "-.inf" and f64(float("nan")) == ".nan"
+    for plain in ("test_files/k12_R1.fq", "NZ_CP016182.2 Escherichia coli strain EC590 chromosome, complete genome", "a-b", "x:y", "1.2.3", "e5"):
+        assert st(plain) == plain
+    for quoted in ("12345", "1e5", "-3", "0x1F", "true", "null", "~", "", " lead", "trail ", "a: b", "a #b", "- item", "#c", "'q", "[x]", "key:", "1_000"):
+        assert st(quoted) == "'" + quoted.replace("'", "''") + "'", quoted
+    assert st("tab\there") == '"tab\\there"'
+
+
 # ---------------------------------------------------------------------------------------------- FASTX records (host feed)
 def _py_records(text):
     """Independent reading of needletail's record semantics: 4-line FASTQ, multi-line FASTA, CR stripped, blank lines
