@@ -872,7 +872,7 @@ def test_reassign_on_device_matches_reference_semantics(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- fuzz over read shapes
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SYLPH_FUZZ_SEEDS", "6"))))   # (a longer campaign: SYLPH_FUZZ_SEEDS=200)
 def test_read_shapes_fuzz(ctx, seed):
     """Random mixtures of record lengths around every threshold of the seeding kernels (k, k+1, 33, 66, 400, 401, tiny reads
     that put more than 256 records into one block of the read-per-lane kernel, long reads that make it decline), random
