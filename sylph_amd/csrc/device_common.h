@@ -70,16 +70,34 @@ __device__ __forceinline__ uint32_t codes4_exact(uint32_t w) {
            (byte_to_seq(w >> 24) << 24);
 }
 
+// Bytes that are not ACGTacgt, without leaving the fast path: d = the difference codes4_fast / codes4_bitop found for the dword
+// (nonzero byte <=> the byte failed the letter test).  Every such byte that BYTE_TO_SEQ maps to 0 — N, n, IUPAC letters, gaps,
+// anything else — just loses its two code bits in c.  The bytes it maps to something else (U / u -> 3, the raw values 1, 2, 3;
+// 0 is lumped in) are reported through `other`: only they need codes4_exact.  With 0.1 % N two of three wavefront iterations
+// of a load loop see an odd byte somewhere in their 64 x 16 bytes; the exact path costs ~200 instructions, this one 11 per dword.
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {                 // bit 7 of every byte of x that is not 0
+    return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ void clear_invalid_codes(uint32_t w, uint32_t d, uint32_t& c, uint32_t& other) {
+    const uint32_t inv = nonzero_bytes(d);
+    const uint32_t not_u = nonzero_bytes((w & 0xDFDFDFDFu) ^ 0x55555555u), not_small = nonzero_bytes(w & 0xFCFCFCFCu);
+    other |= inv & ~(not_u & not_small);
+    c &= ~((inv >> 6) | (inv >> 7));
+}
+
 // 16 ASCII bases (memory order x,y,z,w) -> F: base j at bits 30-2j (big-endian), R: (3-base j) at bits 2j.
 // The four code dwords hold base 4q+j in byte j of dword q.  A 4x4 byte transpose (8 v_perm_b32) gives D_j = byte q holds
 // base 4q+j; then three shift-ors put the four bases of every byte side by side: that is R's layout directly (after the
 // complement) and F's layout after reversing the bytes.  16 full-rate instructions; the previous formulation used eight
 // v_mul_lo_u32, which issue at quarter rate on gfx950.
 __device__ __forceinline__ void pack16(uint4 v, uint32_t& F, uint32_t& R) {
-    uint32_t bad = 0;
-    uint32_t c0 = codes4_fast(v.x, bad), c1 = codes4_fast(v.y, bad), c2 = codes4_fast(v.z, bad), c3 = codes4_fast(v.w, bad);
-    if (bad) {   // rare: N / lower-case U / raw 1,2,3 / anything else
-        c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w);
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    uint32_t c0 = codes4_fast(v.x, e0), c1 = codes4_fast(v.y, e1), c2 = codes4_fast(v.z, e2), c3 = codes4_fast(v.w, e3);
+    if (e0 | e1 | e2 | e3) {   // N and the like: codes cleared in place; U, u, raw 0-3: the exact path
+        uint32_t other = 0;
+        clear_invalid_codes(v.x, e0, c0, other); clear_invalid_codes(v.y, e1, c1, other);
+        clear_invalid_codes(v.z, e2, c2, other); clear_invalid_codes(v.w, e3, c3, other);
+        if (other) { c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w); }
     }
     // __builtin_amdgcn_perm(hi, lo, sel): selector bytes 0-3 pick from lo, 4-7 from hi
     const uint32_t t0 = __builtin_amdgcn_perm(c1, c0, 0x05010400u);   // c0.0 c1.0 c0.1 c1.1

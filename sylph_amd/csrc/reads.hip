@@ -135,7 +135,14 @@ __device__ __forceinline__ uint32_t pack16_fwd(uint4 v) {
     uint32_t c0 = codes4_bitop(v.x, d0), c1 = codes4_bitop(v.y, d1), c2 = codes4_bitop(v.z, d2), c3 = codes4_bitop(v.w, d3);
     asm("v_or3_b32 %0, %1, %2, %3" : "=v"(bad) : "v"(d0), "v"(d1), "v"(d2));
     asm("v_or_b32 %0, %1, %2" : "=v"(bad) : "v"(bad), "v"(d3));
-    if (bad) { c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w); }
+    if (bad) {
+        // an odd byte somewhere in the wavefront's 64 x 16: N and the like lose their code bits in place, only U, u and raw 0-3
+        // take the exact path (device_common.h)
+        uint32_t other = 0;
+        clear_invalid_codes(v.x, d0, c0, other); clear_invalid_codes(v.y, d1, c1, other);
+        clear_invalid_codes(v.z, d2, c2, other); clear_invalid_codes(v.w, d3, c3, other);
+        if (other) { c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w); }
+    }
     constexpr uint32_t GATHER = (1u << 30) | (1u << 20) | (1u << 10) | 1u;
     const uint32_t p0 = c0 * GATHER, p1 = c1 * GATHER, p2 = c2 * GATHER, p3 = c3 * GATHER;
     // __builtin_amdgcn_perm(hi, lo, sel): selector 0-3 = bytes of lo, 4-7 = bytes of hi, 0x0C = constant 0

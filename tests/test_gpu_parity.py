@@ -913,6 +913,37 @@ def test_read_shapes_fuzz(ctx, seed):
             assert_same_sketch(g, e)
 
 
+def test_short_reads_over_the_whole_byte_alphabet(ctx):
+    """BYTE_TO_SEQ (types.rs:50-59) inside the short-read kernel: reads salted with N / n, IUPAC letters, U / u (code 3), the
+    raw values 0-3 (codes 0-3) and arbitrary bytes, at rates from "one odd byte per wavefront" to "every byte odd", plus reads
+    written entirely in raw codes.  The ASCII -> 2-bit pack clears the codes of bytes that map to 0 in place and sends only U,
+    u and raw 0-3 through its exact path: both must agree with the oracle, in sessions (read-per-lane and position kernel)."""
+    rng = np.random.default_rng(4242)
+    genome = random_seq(rng, 20000)
+    pools = [np.frombuffer(b"Nn", dtype=np.uint8), np.frombuffer(b"RYKMSWBDHVrykmswbdhv-.*", dtype=np.uint8), np.frombuffer(b"Uu", dtype=np.uint8),
+             np.array([0, 1, 2, 3], dtype=np.uint8), np.arange(256, dtype=np.uint8)]
+    recs = []
+    for i in range(4000):
+        L = int(rng.integers(60, 152))
+        s0 = int(rng.integers(0, len(genome) - L))
+        r = genome[s0:s0 + L].copy()
+        if rng.random() < 0.3:
+            r = np.char.lower(r.view("S1")).view(np.uint8).copy()
+        rate = float(rng.choice([0.0, 0.001, 0.01, 0.2, 1.0], p=[0.2, 0.3, 0.3, 0.15, 0.05]))
+        hit = rng.random(L) < rate
+        pool = pools[int(rng.integers(0, len(pools)))]
+        r[hit] = rng.choice(pool, size=int(hit.sum()))
+        if i % 50 == 0:                                     # a read in raw 2-bit codes: A/C/G/T as 0/1/2/3
+            r = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), genome[s0:s0 + L]).astype(np.uint8)
+        recs.append(r)
+    b, off = concat(recs)
+    for paired in (False, True):
+        for gm, om in MODES:
+            e = O.sketch_reads(b, off, c=5, mode=om, paired=paired)
+            assert len(e["kmers"]) > 1000
+            assert_same_sketch(sketch_gpu(ctx, b, off, paired=paired, seed_mode=gm, c=5), e)
+
+
 def test_tiny_reads_many_records_per_block(ctx):
     """Reads of 0-45 bases: a block of the read-per-lane kernel holds more records than lanes (several passes per block), most
     records have no k-mer at all, mates shorter than 33 bases carry no marker (sketch.rs:661)."""
