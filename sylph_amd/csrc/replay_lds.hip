@@ -23,8 +23,13 @@ namespace {
 // slower); the rare larger buckets (high-abundance k-mers) are redone by the CAP_LARGE configuration; only beyond that
 // does finish() fall back to the device-wide path.
 constexpr int CAP_SMALL = 256, RTPB_SMALL = 128;
-constexpr int CAP_LARGE = 1024, RTPB_LARGE = 256;
+constexpr int CAP_MID = 512, RTPB_MID = 256;       // hashed marker test, ~31 KiB of LDS: 5 workgroups per CU
+constexpr int CAP_LARGE = 1024, RTPB_LARGE = 256;   // hashed marker test, ~59 KiB of LDS: 2 workgroups per CU
 constexpr int IDX_BITS = 10;         // arrival index inside a bucket (< CAP_LARGE)
+// The marker test of the small configuration looks at every earlier occurrence of the k-mer: quadratic in a k-mer's coverage.
+// A bucket holding a k-mer with SEG_LIMIT or more occurrences (a genome at ~100x and above) is handed to the medium / large
+// configuration, whose marker test is a hash table in LDS: linear in the bucket size.
+constexpr uint32_t SEG_LIMIT = 96;
 
 // boff[b] = first position (in the array sorted by bucket id) whose bucket is >= b, for b in [0, B].  Invalid occurrences
 // carry bucket id B and sort last, so boff[B] is also the number of valid occurrences (read by the replay kernels from
@@ -51,11 +56,12 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, const BucketMap m) {
 __global__ __launch_bounds__(256) void bucket_key_kernel(const uint64_t* __restrict__ hash, uint32_t n, BucketMap bm, uint32_t B,
                                                          uint32_t* __restrict__ bk, uint32_t* __restrict__ idx,
                                                          uint32_t* __restrict__ zero, uint32_t n_zero, uint32_t* __restrict__ tail16,
-                                                         uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b) {
+                                                         uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b,
+                                                         uint32_t* __restrict__ list_c) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_zero) zero[i] = 0;
     if (i < 16) tail16[i] = 0;
-    if (i == 0) { *list_a = 0; *list_b = 0; }
+    if (i == 0) { *list_a = 0; *list_b = 0; *list_c = 0; }
     if (i >= n) return;
     const uint64_t h = hash[i];
     bk[i] = (h == INVALID_HASH) ? B : bucket_of(h, bm);
@@ -103,7 +109,8 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
                                                              uint32_t cutoff, BucketMap bm, uint64_t* __restrict__ tmp_k,
                                                              uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
                                                              uint32_t* __restrict__ removed_b,
-                                                             uint32_t* __restrict__ overflow, uint32_t* __restrict__ large_list,
+                                                             uint32_t* __restrict__ overflow, uint32_t* __restrict__ mid_list,
+                                                             uint32_t* __restrict__ large_list,
                                                              uint32_t* __restrict__ ovf_list, int dbg_stage) {
     constexpr int ITEMS = CAP / RTPB;     // records per lane
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
@@ -121,8 +128,8 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
     // host, which sends the occurrences of such buckets through the device-wide path (ovf_list, same layout)
     if (n > CAP) {
         if (tid == 0) {
-            if (large_list) large_list[1 + atomicAdd(&large_list[0], 1u)] = b;
-            else ovf_list[1 + atomicAdd(&ovf_list[0], 1u)] = b;
+            uint32_t* list = (CAP < CAP_MID && n <= (uint32_t)CAP_MID) ? mid_list : (CAP < CAP_LARGE && n <= (uint32_t)CAP_LARGE) ? large_list : ovf_list;
+            list[1 + atomicAdd(&list[0], 1u)] = b;
         }
         return;
     }
@@ -218,6 +225,28 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
         }
     }
     __syncthreads();
+    constexpr bool HASHED = CAP != CAP_SMALL;
+    constexpr uint32_t MARKER_TAB = 4 * CAP;    // slots of the marker table: 2 x (2 entries per occurrence)
+    if constexpr (!HASHED) {
+        // a long k-mer segment: not for the quadratic marker test below
+        if (!no_dedup) {
+            __shared__ uint32_t s_longest;
+            if (tid == 0) s_longest = 0;
+            __syncthreads();
+            uint32_t mine = 0;
+            for (uint32_t t = 0; t < items; t++) {
+                const uint32_t j = j0 + t;
+                if (j >= n) break;
+                mine = max(mine, j - (uint32_t)s_seg[j]);
+            }
+            if (mine + 1 >= SEG_LIMIT) atomicMax(&s_longest, mine + 1);
+            __syncthreads();
+            if (s_longest >= SEG_LIMIT) {
+                if (tid == 0) mid_list[1 + atomicAdd(&mid_list[0], 1u)] = b;
+                return;
+            }
+        }
+    }
     // ---- mate-2 skip (sketch.rs:852) and duplicate flags ----------------------------------------------------------
     for (uint32_t t = 0; t < items; t++) {
         const uint32_t j = j0 + t;
@@ -240,26 +269,78 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
     __syncthreads();
     uint32_t my_u = 0;
     uint8_t ubits = 0;
-    for (uint32_t t = 0; t < items; t++) {
-        const uint32_t j = j0 + t;
-        if (j >= n) break;
-        uint8_t fl = s_fl[j];
-        if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT)) {
-            const uint64_t a = s_m0[j], bb = s_m1[j];
-            bool any_prev = false, hit = false;
-            for (uint32_t q = s_seg[j]; q < j; q++) {
-                if (s_fl[q] & 1) continue;
-                any_prev = true;
-                if (s_rid[q] & RID_MARKER_BIT) {
-                    const uint64_t x = s_m0[q], y = s_m1[q];
-                    if (x == a || y == a || x == bb || y == bb) { hit = true; break; }
+    if constexpr (HASHED) {
+        // Marker test through a hash table in LDS.  Every processed occurrence with markers enters both of them under the key
+        // (k-mer segment, marker value); a slot belongs to the first entry that claims it (owner entry in the high half of the
+        // word, never changes) and keeps the smallest sorted position among the entries with its key in the low half.  An
+        // occurrence is a duplicate when one of its two keys was entered from an earlier position (sketch.rs:709-722: markers
+        // go into the set whether the occurrence is then counted or dropped), or when its two markers are equal — and it is
+        // not the first of its k-mer: the head of a segment is never a skipped mate 2 (the mate-1 occurrence that would make
+        // it one precedes it in the segment), so "a processed occurrence precedes j" is simply "j is not the head".
+        __shared__ uint32_t s_tab[MARKER_TAB];
+        __shared__ uint16_t s_slot[2 * CAP];
+        static_assert((MARKER_TAB & (MARKER_TAB - 1)) == 0 && 2 * CAP <= 0xFFFF, "marker table geometry");
+        for (uint32_t t = tid; t < MARKER_TAB; t += RTPB) s_tab[t] = 0xFFFFFFFFu;
+        __syncthreads();
+        auto marker_of = [&](uint32_t e) { return (e & 1u) ? s_m1[e >> 1] : s_m0[e >> 1]; };
+        if (!no_dedup) {
+            for (uint32_t t = 0; t < items; t++) {
+                const uint32_t j = j0 + t;
+                if (j >= n) break;
+                if ((s_fl[j] & 1) || !(s_rid[j] & RID_MARKER_BIT)) continue;
+                const uint32_t seg = s_seg[j];
+                for (uint32_t w = 0; w < 2; w++) {
+                    const uint32_t e = 2 * j + w;
+                    const uint64_t v = marker_of(e);
+                    uint32_t h = (uint32_t)(((v ^ (v >> 31) ^ ((uint64_t)seg << 17)) * 0x9E3779B97F4A7C15ull) >> 40) & (MARKER_TAB - 1);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&s_tab[h], 0xFFFFFFFFu, (e << 16) | j);
+                        const uint32_t o = old == 0xFFFFFFFFu ? e : old >> 16;
+                        if (marker_of(o) == v && s_seg[o >> 1] == seg) {
+                            if (old != 0xFFFFFFFFu) atomicMin(&s_tab[h], (o << 16) | j);
+                            s_slot[e] = (uint16_t)h;
+                            break;
+                        }
+                        h = (h + 1) & (MARKER_TAB - 1);
+                    }
                 }
             }
-            if (any_prev && (hit || a == bb)) fl |= 2;
         }
-        const bool u = !(fl & 1) && (no_dedup || !(fl & 2));
-        if (u) { my_u++; ubits |= (uint8_t)(1u << t); }
-        s_fl[j] = fl;   // NB: later lanes only read bit0 of earlier positions, which does not change here
+        __syncthreads();
+        for (uint32_t t = 0; t < items; t++) {
+            const uint32_t j = j0 + t;
+            if (j >= n) break;
+            uint8_t fl = s_fl[j];
+            if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT) && j != (uint32_t)s_seg[j]) {
+                const bool hit = (s_tab[s_slot[2 * j]] & 0xFFFFu) < j || (s_tab[s_slot[2 * j + 1]] & 0xFFFFu) < j;
+                if (hit || s_m0[j] == s_m1[j]) fl |= 2;
+            }
+            const bool u = !(fl & 1) && (no_dedup || !(fl & 2));
+            if (u) { my_u++; ubits |= (uint8_t)(1u << t); }
+            s_fl[j] = fl;
+        }
+    } else {
+        for (uint32_t t = 0; t < items; t++) {
+            const uint32_t j = j0 + t;
+            if (j >= n) break;
+            uint8_t fl = s_fl[j];
+            if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT)) {
+                const uint64_t a = s_m0[j], bb = s_m1[j];
+                bool any_prev = false, hit = false;
+                for (uint32_t q = s_seg[j]; q < j; q++) {
+                    if (s_fl[q] & 1) continue;
+                    any_prev = true;
+                    if (s_rid[q] & RID_MARKER_BIT) {
+                        const uint64_t x = s_m0[q], y = s_m1[q];
+                        if (x == a || y == a || x == bb || y == bb) { hit = true; break; }
+                    }
+                }
+                if (any_prev && (hit || a == bb)) fl |= 2;
+            }
+            const bool u = !(fl & 1) && (no_dedup || !(fl & 2));
+            if (u) { my_u++; ubits |= (uint8_t)(1u << t); }
+            s_fl[j] = fl;   // NB: later lanes only read bit0 of earlier positions, which does not change here
+        }
     }
     if (dbg_stage == 3) { if (tid == 0) n_distinct[b] = 0; return; }
     // ---- P_i = would-be-counted occurrences before i in its k-mer; counted_i (cut-off rule, sketch.rs:706) ------
@@ -304,14 +385,38 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
     }
     __syncthreads();
     // heads emit (k-mer, count); the distinct index of a head = number of heads before it
-    {
+    if constexpr (HASHED) {
+        // segment end = position of the next head: the heads publish their positions by distinct index (s_a is free by now)
+        uint16_t* const s_headpos = s_a;
+        {
+            uint32_t rh = base_h;
+            for (uint32_t t = 0; t < items; t++) {
+                const uint32_t j = j0 + t;
+                if (j >= n) break;
+                if (headbits & (1u << t)) s_headpos[rh++] = (uint16_t)j;
+            }
+            if (tid == 0) s_headpos[total_heads] = (uint16_t)n;
+        }
+        __syncthreads();
+        uint32_t rh = base_h;
+        for (uint32_t t = 0; t < items; t++) {
+            const uint32_t j = j0 + t;
+            if (j >= n) break;
+            if (headbits & (1u << t)) {
+                const uint32_t e = s_headpos[rh + 1];
+                tmp_k[first + rh] = s_hash[j];
+                tmp_c[first + rh] = (uint32_t)s_b[e] - (uint32_t)s_b[j];
+                rh++;
+            }
+        }
+    } else {
         uint32_t rh = base_h;
         const uint32_t out0 = first;
         for (uint32_t t = 0; t < items; t++) {
             const uint32_t j = j0 + t;
             if (j >= n) break;
             if (headbits & (1u << t)) {
-                // segment end = next head or n: walk (k-mers have few occurrences; bounded by the bucket size)
+                // segment end = next head or n: walk (segments here are shorter than SEG_LIMIT)
                 uint32_t e = j + 1;
                 while (e < n && s_seg[e] == j) e++;
                 tmp_k[out0 + rh] = s_hash[j];
@@ -331,10 +436,11 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
                                                              int paired, int no_dedup, uint32_t cutoff, BucketMap bm,
                                                              uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
                                                              uint32_t* __restrict__ n_distinct, uint32_t* __restrict__ removed_b,
-                                                             uint32_t* __restrict__ overflow, uint32_t* __restrict__ large_list,
+                                                             uint32_t* __restrict__ overflow, uint32_t* __restrict__ mid_list,
+                                                             uint32_t* __restrict__ large_list, uint32_t* __restrict__ ovf_list,
                                                              int dbg_stage) {
     replay_bucket<CAP, RTPB>(blockIdx.x, recs, perm, boff, p_nv, paired, no_dedup, cutoff, bm, tmp_k, tmp_c, n_distinct, removed_b,
-                             overflow, large_list, nullptr, dbg_stage);
+                             overflow, mid_list, large_list, ovf_list, dbg_stage);
 }
 
 // second configuration: a fixed, small grid walks the (usually empty) list of buckets the first one queued
@@ -344,12 +450,13 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_list_kernel(const OccRec* 
                                                                   int paired, int no_dedup, uint32_t cutoff, BucketMap bm,
                                                                   uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
                                                                   uint32_t* __restrict__ n_distinct, uint32_t* __restrict__ removed_b,
-                                                                  uint32_t* __restrict__ overflow, const uint32_t* __restrict__ large_list,
-                                                                  uint32_t* __restrict__ ovf_list, int dbg_stage) {
-    const uint32_t n_large = large_list[0];
-    for (uint32_t i = blockIdx.x; i < n_large; i += gridDim.x) {
-        replay_bucket<CAP, RTPB>(large_list[1 + i], recs, perm, boff, p_nv, paired, no_dedup, cutoff, bm, tmp_k, tmp_c, n_distinct,
-                                 removed_b, overflow, nullptr, ovf_list, dbg_stage);
+                                                                  uint32_t* __restrict__ overflow, const uint32_t* __restrict__ my_list,
+                                                                  uint32_t* __restrict__ large_list, uint32_t* __restrict__ ovf_list,
+                                                                  int dbg_stage) {
+    const uint32_t n_listed = my_list[0];
+    for (uint32_t i = blockIdx.x; i < n_listed; i += gridDim.x) {
+        replay_bucket<CAP, RTPB>(my_list[1 + i], recs, perm, boff, p_nv, paired, no_dedup, cutoff, bm, tmp_k, tmp_c, n_distinct,
+                                 removed_b, overflow, nullptr, large_list, ovf_list, dbg_stage);
         __syncthreads();   // the LDS arrays are reused by the next bucket
     }
 }
@@ -481,13 +588,14 @@ bool finish_bucketed(sylph_sketch* sk) {
     b_tmpk.reserve((size_t)n_all * 8);
     b_tmpc.reserve((size_t)n_all * 4);
     b_small.reserve(64);
-    b_bk.reserve((size_t)(B + 2) * 4 * 6);      // boff | large_list | ovf_list | n_distinct | removed | d_off   (each B+2)
+    b_bk.reserve((size_t)(B + 2) * 4 * 7);      // boff | large_list | ovf_list | n_distinct | removed | d_off | mid_list   (each B+2)
     uint32_t* boff = b_bk.as<uint32_t>();
     uint32_t* large_list = boff + (B + 2);      // [0] = number of buckets queued for the large configuration, [1..] = ids
     uint32_t* ovf_list = large_list + (B + 2);  // [0] = number of buckets beyond the large configuration, [1..] = ids
     uint32_t* n_distinct = ovf_list + (B + 2);
     uint32_t* removed_b = n_distinct + (B + 2);
     uint32_t* d_off = removed_b + (B + 2);
+    uint32_t* mid_list = d_off + (B + 2);       // buckets for the medium configuration (n <= CAP_MID, or a long k-mer segment)
     unsigned long long* d_removed = b_small.as<unsigned long long>();
     uint32_t* d_overflow = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 8);
     const uint32_t* d_nv = boff + B;            // boff[B] = number of valid occurrences
@@ -503,7 +611,7 @@ bool finish_bucketed(sylph_sketch* sk) {
         HostPhase ph(ctx, "finish(bucket): partition + LDS replay + compact");
         hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(std::max(n_all, std::max(n_zero, 16u)))), dim3(256), 0, ctx->stream,
                            sk->hash.as<uint64_t>(), n_all, bm, B, bk_in, b_idx.as<uint32_t>(), n_distinct, n_zero, b_small.as<uint32_t>(),
-                           large_list, ovf_list);
+                           large_list, ovf_list, mid_list);
         sort_pairs_u32_u32(ctx, bk_in, bk_sorted, b_idx.as<uint32_t>(), b_perm.as<uint32_t>(), n_all, 0, bit_length(B));
         {
             ScopedKernelTimer t(ctx, "replay");
@@ -513,11 +621,17 @@ bool finish_bucketed(sylph_sketch* sk) {
             const uint32_t cutoff = sk->paired ? 0u : 4u;   // MAX_DEDUP_COUNT, constants.rs:14
             hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
                                sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
-                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, large_list, dbg);
-            hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(B, 256u)),
+                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, mid_list, large_list,
+                               ovf_list, dbg);
+            // the two list-driven configurations: a fixed grid (as many workgroups as fit the chip) walks what the first one queued
+            hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_MID, RTPB_MID>), dim3(std::min<uint32_t>(B, 1280u)),
+                               dim3(RTPB_MID), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
+                               sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
+                               d_overflow, mid_list, large_list, ovf_list, dbg);
+            hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(B, 512u)),
                                dim3(RTPB_LARGE), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
                                sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
-                               d_overflow, large_list, ovf_list, dbg);
+                               d_overflow, large_list, large_list, ovf_list, dbg);
             hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
         }
         exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);

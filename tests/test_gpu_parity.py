@@ -361,6 +361,43 @@ def test_bucket_path_large_buckets(ctx):
         ctx.set_option("finish", "auto")
 
 
+@pytest.mark.parametrize("depth", [70, 130, 300, 700, 1500])
+def test_replay_configurations_by_kmer_depth(ctx, depth):
+    """The three in-LDS configurations of the dedup/count stage and what lies beyond them, by k-mer depth: below 96 occurrences
+    per k-mer the quadratic marker test of the 256-slot configuration, from 96 on the hash-table marker test of the 512- and
+    1024-slot configurations, above 1024 the device-wide path.  Pairs with exact duplicates (PCR), pairs that share only one
+    mate's start (partial marker overlap), mates on the same k-mer (mate-2 skip), reads that carry no markers, single-end with
+    its cut-off at 4 — bucket-only finish up to depth 300 (no silent fall back to the device-wide path), in one push
+    and in three, against the oracle."""
+    rng = np.random.default_rng(depth)
+    genome = random_seq(rng, 400)                  # ~370 k-mers, all at `depth`
+    filler = random_seq(rng, 40000)
+    n_pairs = depth * 400 // 160
+    recs = make_reads(rng, genome, n_pairs, 100, err=0.002, dup_frac=0.2, paired=True, insert=180, ragged=False)
+    # pairs that share mate 1 with an earlier pair but not mate 2 (one marker half equal), and short mates without markers
+    for _ in range(n_pairs // 10):
+        j = 2 * int(rng.integers(0, len(recs) // 2))
+        s0 = int(rng.integers(0, len(genome) - 100))
+        recs += [recs[j].copy(), revcomp(genome[s0:s0 + 100])]
+    for _ in range(n_pairs // 10):
+        s0 = int(rng.integers(0, len(genome) - 100))
+        recs += [genome[s0:s0 + 100].copy(), genome[s0 + 5:s0 + 5 + 31].copy()]      # mate 2 of 31 bases: no markers, same k-mers
+    recs += make_reads(rng, filler, 2000, 100, dup_frac=0.1, paired=True, insert=300, ragged=False)
+    pairs = [(recs[i], recs[i + 1]) for i in range(0, len(recs), 2)]
+    order = rng.permutation(len(pairs))
+    b, off = concat([m for i in order for m in pairs[i]])
+    ctx.set_option("finish", "bucket" if depth <= 300 else "auto")   # (deeper: some bucket passes 1024 occurrences)
+    try:
+        for paired in (True, False):
+            e = O.sketch_reads(b, off, c=7, paired=paired)
+            assert e["dup_removed"] > 50 and (paired or e["counts"].max() >= depth // 2)
+            for batches in (1, 3):
+                assert_same_sketch(_sketch_gpu_once(ctx, b, off, paired, False, S.SEED_AVX2_COMPAT, 7, 31, batches), e)
+    finally:
+        ctx.set_option("finish", "auto")
+    assert_same_sketch(sketch_gpu(ctx, b, off, paired=True, c=7), O.sketch_reads(b, off, c=7, paired=True))   # all three flavours agree
+
+
 def test_deep_kmers_of_distinct_reads_are_not_quadratic(ctx):
     """100 k-mers with 6,000 occurrences each, every occurrence in a DIFFERENT read (random flanks => distinct markers): the
     buckets overflow the in-LDS replay and go through the device-wide path, whose marker test used to scan all earlier
