@@ -7,7 +7,8 @@ import sylph_amd as S
 from sylph_amd import synth
 dev = torch.device("cuda", 0)
 ctx = S.Context(0)
-CASES = {"1": ((1, 5_000_000),), "all": ((1, 5_000_000), (4, 5_000_000), (100, 5_000_000))}[os.environ.get("DEEP_CASES", "all")]
+CASES = {"1": ((1, 5_000_000),), "all": ((1, 5_000_000), (4, 5_000_000), (100, 5_000_000)),
+         "extreme": ((1, 1_000_000), (1, 200_000), (1, 30_000), (20, 30_000))}[os.environ.get("DEEP_CASES", "all")]
 for n_gen, glen in CASES:
     genomes = synth.random_genomes(n_gen, glen, dev, 3, mutated_frac=0.0)
     bases, off = synth.paired_reads(genomes, 3_333_334, seed=11)
@@ -23,6 +24,7 @@ for n_gen, glen in CASES:
             dk, dc, n, dup = sk.finish_device()
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
             st = {f: ctx.kernel_stats(f) for f in ("seeds", "compact", "sort", "replay", "replay_overflow")}
+            st = {k: (round(v[0], 3), v[1]) for k, v in st.items()}
             ctx.profile(False)
             sk.close()
         print(f"{n_gen} genomes x {glen} ({nb/n_gen/glen:.0f}x coverage) paired={paired}: sketch {min(ts)*1e3:.2f} ms, table {n}, dup {dup}, kernels {st}", flush=True)
