@@ -10,10 +10,13 @@ constexpr uint64_t SLOT_EMPTY = ~0ull;
 
 // What the kernels need to probe an index (POD, passed by value).
 //   bucket(km) = (km - base) / div;   slot = ((km - base) % div) << gshift | flag << (gshift - 1) | genome id
+//   descriptor (slot 7 of a bucket with more than 8 postings) = first entry of its overflow run << gshift | flag | min(length of
+//   the run, 2^(gshift-1) - 1) in the genome field
 struct LineView {
     const uint64_t* lines;   // n_buckets x LINE_SLOTS
     const uint64_t* ovf;     // overflow runs, each closed by SLOT_EMPTY
     uint64_t base, div, magic;   // magic = floor(2^64 / div) for div >= 2
+    uint64_t n_ovf;          // entries of ovf (the wavefront-wide walk of a long run reads 64 at a time)
     uint32_t n_buckets;
     int gshift;
 };
@@ -25,7 +28,7 @@ struct LineIndex {
     int gshift = 2;
     LineIndex() = default;
     explicit LineIndex(sylph_ctx* c) : lines(c), ovf(c) {}
-    LineView view() const { return LineView{lines.as<uint64_t>(), ovf.as<uint64_t>(), base, div, magic, n_buckets, gshift}; }
+    LineView view() const { return LineView{lines.as<uint64_t>(), ovf.as<uint64_t>(), base, div, magic, n_ovf, n_buckets, gshift}; }
 };
 
 // One sample table of a batch: n (k-mer, count) entries; chunk0 = index of its first 256-entry chunk in the batch.
@@ -43,8 +46,13 @@ struct RefPack { SampleRef r[REFS_INLINE]; };
 #ifdef __HIPCC__
 // Calls f(genome id) for every posting of k-mer `km`.  One 64 B line read (4 x global_load_dwordx4); the overflow run of
 // a crowded bucket is walked only when the 7 postings kept in the line do not already exceed the remainder looked for.
+// LONG_RUN > 0: an overflow run of at least LONG_RUN entries is not walked here; its first entry is returned through
+// *long_start (else ~0) with the remainder in *long_rem, for the caller's wavefront-wide walk (probe_long_run).
+constexpr uint32_t LONG_RUN_MIN = 48;
 template <class F>
-__device__ __forceinline__ void for_each_posting(const LineView& v, uint64_t km, F&& f) {
+__device__ __forceinline__ void for_each_posting(const LineView& v, uint64_t km, F&& f, uint64_t* long_start = nullptr,
+                                                 uint64_t* long_rem = nullptr) {
+    if (long_start) *long_start = ~0ull;
     if (km < v.base) return;
     const uint64_t x = km - v.base;
     uint64_t q, rem;
@@ -66,6 +74,7 @@ __device__ __forceinline__ void for_each_posting(const LineView& v, uint64_t km,
         if ((s[j] >> v.gshift) == rem && !(s[j] & flag)) f((uint32_t)(s[j] & gmask));
     const uint64_t last = s[LINE_SLOTS - 1];
     if ((last & flag) && last != SLOT_EMPTY && (s[LINE_SLOTS - 2] >> v.gshift) <= rem) {   // descriptor: rest of the bucket
+        if (long_start && (last & gmask) >= LONG_RUN_MIN) { *long_start = last >> v.gshift; *long_rem = rem; return; }
         for (uint64_t i = last >> v.gshift;; i++) {
             const uint64_t y = v.ovf[i];
             if (y == SLOT_EMPTY) break;

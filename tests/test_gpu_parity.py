@@ -617,6 +617,49 @@ def test_contain_crowded_buckets_and_index_shapes(ctx):
         ctx.set_option("index_pass_max", str(1 << 30))
 
 
+def test_contain_kmers_shared_by_thousands_of_genomes(ctx):
+    """Strains of one species in an undereplicated database: 1,500 genomes hold (almost) the same k-mers, so the overflow run
+    behind a bucket's line is 1,500 postings long and one sample k-mer yields 1,500 hits.  Such runs are walked by the whole
+    wavefront (64 entries per step, matches counted, space taken once, hits written from the lanes): runs that end inside the
+    first step, runs of many steps, several long runs per wavefront, neighbouring sample k-mers whose hits overflow the
+    workgroup's stage inside one chunk (the rest goes straight to the hit array), genomes below min_number_kmers filtered inside
+    the run, a batch of samples — counts and every coverage vector against the oracle."""
+    rng = np.random.default_rng(77)
+    thr = O.threshold(200)
+    core = np.unique(rng.integers(0, thr, size=300, dtype=np.uint64))
+    core = np.concatenate([core, core[10] + np.arange(1, 40, dtype=np.uint64)])      # 40 consecutive values: one bucket, many remainders
+    genomes = []
+    for g in range(1500):
+        keep = rng.random(len(core)) < (0.97 if g % 50 else 0.1)                     # every 50th strain is a fragment (short genome)
+        own = rng.integers(0, thr, size=int(rng.integers(0, 60)), dtype=np.uint64)
+        genomes.append(np.concatenate([core[keep], own]))
+    # a 60-strain and a 100-strain species: shorter runs (one or two steps)
+    sp60 = rng.integers(0, thr, size=150, dtype=np.uint64)
+    sp100 = rng.integers(0, thr, size=150, dtype=np.uint64)
+    genomes += [np.concatenate([sp60[rng.random(150) < 0.9], rng.integers(0, thr, size=20, dtype=np.uint64)]) for _ in range(60)]
+    genomes += [np.concatenate([sp100[rng.random(150) < 0.9], rng.integers(0, thr, size=20, dtype=np.uint64)]) for _ in range(100)]
+    genomes += [rng.integers(0, thr, size=int(rng.integers(50, 400)), dtype=np.uint64) for _ in range(300)]
+    db, goff = flat_db(genomes)
+    sk = np.unique(np.concatenate([core, sp60[:100], sp100[::2], rng.integers(0, thr, size=5000, dtype=np.uint64)]))
+    sc = rng.integers(0, 40, size=len(sk)).astype(np.uint32)
+    for min_kmers in (0.0, 100.0):                                                    # 100: the fragment strains drop out inside the runs
+        cc = check_contain(ctx, db, goff, sk, sc, min_kmers=min_kmers)
+        assert cc[:1500].max() > 250 and int(cc.sum()) > 300_000
+    # batch: the same table three times (one of them thinned) in one launch
+    dbh = S.Database(ctx, db, goff)
+    thin = rng.random(len(sk)) < 0.5
+    tables = [(sk, sc), (sk[thin], sc[thin]), (sk, sc)]
+    bcc, boff, bcovs = dbh.contain_batch(tables)
+    G = len(genomes)
+    for s_i, (k_i, c_i) in enumerate(tables):
+        ecc, ecov, _ = O.contain(k_i, c_i, db, goff)
+        assert np.array_equal(bcc[s_i * G:(s_i + 1) * G], ecc)
+        for g in range(0, G, 13):
+            r = s_i * G + g
+            assert np.array_equal(np.asarray(bcovs[int(boff[r]):int(boff[r + 1])]).astype(np.uint32), np.sort(ecov[g]))
+    dbh.close()
+
+
 def test_contain_batch_matches_single_samples(ctx):
     """sylph_db_contain_batch: S tables in one probe launch / sort / copy — row s * G + g must equal what the single-sample
     call gives for sample s (and the oracle), with empty tables, zero counts and wide counts in the batch."""
