@@ -482,9 +482,13 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t* __r
                                                              const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_off,
                                                              const uint32_t* __restrict__ n_distinct, uint32_t n_buckets,
                                                              uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
-                                                             const uint32_t* __restrict__ ovf_list, uint32_t* __restrict__ tail) {
-    // tail = {removed u64, overflow u32, n_seg u32, n_ovf u32}: everything the host reads back, side by side (ONE copy)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { tail[3] = d_off[n_buckets]; tail[4] = ovf_list[0]; }
+                                                             const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ mid_list,
+                                                             const uint32_t* __restrict__ large_list, uint32_t* __restrict__ tail) {
+    // tail = {removed u64, overflow u32, n_seg u32, n_ovf u32, n_mid u32, n_large u32}: everything the host reads back, side by
+    // side (ONE copy)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        tail[3] = d_off[n_buckets]; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
+    }
     for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
         const uint32_t n = n_distinct[b], s = boff[b], d = d_off[b];
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_k[d + i] = tmp_k[s + i]; out_c[d + i] = tmp_c[s + i]; }
@@ -604,7 +608,10 @@ bool finish_bucketed(sylph_sketch* sk) {
     // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
     uint32_t* bk_in = b_keys.as<uint32_t>();
     uint32_t* bk_sorted = bk_in + n_all;
-    // every launch below takes its sizes from device memory; the host synchronises ONCE, at the end
+    // every launch below takes its sizes from device memory; the host synchronises ONCE, at the end (unless some buckets need
+    // the list-driven configurations or the device-wide path)
+    const int dbg = getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0;
+    const uint32_t cutoff = sk->paired ? 0u : 4u;   // MAX_DEDUP_COUNT, constants.rs:14
     sk->out_k.reserve((size_t)n_all * 8);          // upper bound: distinct k-mers <= occurrences
     sk->out_c.reserve((size_t)n_all * 4);
     {
@@ -617,21 +624,16 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)n_all + 1)), dim3(256), 0, ctx->stream, bk_sorted, n_all, B,
                                boff);
-            const int dbg = getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0;
-            const uint32_t cutoff = sk->paired ? 0u : 4u;   // MAX_DEDUP_COUNT, constants.rs:14
             hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
                                sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, mid_list, large_list,
                                ovf_list, dbg);
-            // the two list-driven configurations: a fixed grid (as many workgroups as fit the chip) walks what the first one queued
-            hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_MID, RTPB_MID>), dim3(std::min<uint32_t>(B, 1280u)),
-                               dim3(RTPB_MID), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
-                               sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
-                               d_overflow, mid_list, large_list, ovf_list, dbg);
-            hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(B, 512u)),
-                               dim3(RTPB_LARGE), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
-                               sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
-                               d_overflow, large_list, large_list, ovf_list, dbg);
+        }
+    }
+    // removed counts, table offsets, compaction, and everything the host needs to know in one 28-byte block
+    auto close_table = [&] {
+        {
+            ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
         }
         exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
@@ -639,19 +641,43 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>(), ovf_list, b_small.as<uint32_t>());
+                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, b_small.as<uint32_t>());
         }
         SY_HIP(hipGetLastError());
-    }
-    struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf; } host{};
+    };
+    struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf, n_mid, n_large; } host{};
     auto read_tail = [&] {
-        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 20, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 28, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
-        memcpy(&host, ctx->pinned, 20);
+        memcpy(&host, ctx->pinned, 28);
         if (!ctx->pending.empty()) profile_collect(ctx);
     };
+    close_table();
     read_tail();
     if (host.overflow) return false;             // inconsistent bounds (defensive): the generic path redoes the sample
+    if (host.n_mid || host.n_large) {
+        // Buckets the 256-slot configuration passed on (more than 256 occurrences, or a k-mer 96+ deep: abundant genomes).  The
+        // list-driven configurations are launched only now, with grids that match the lists: launched speculatively with every
+        // sample they are two dispatches of large-LDS workgroups that find nothing to do, but cannot even START beside another
+        // stream's seeding kernel (which leaves 10 KiB of LDS per CU) — in the pipelined bench they held the stream up for 0.3 ms.
+        HostPhase ph(ctx, "finish(bucket): medium / large configurations");
+        {
+            ScopedKernelTimer t(ctx, "replay");
+            if (host.n_mid)
+                hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_MID, RTPB_MID>), dim3(std::min<uint32_t>(host.n_mid, 1280u)),
+                                   dim3(RTPB_MID), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
+                                   sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
+                                   d_overflow, mid_list, large_list, ovf_list, dbg);
+            if (host.n_large)
+                hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(host.n_large, 512u)),
+                                   dim3(RTPB_LARGE), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
+                                   sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
+                                   d_overflow, large_list, large_list, ovf_list, dbg);
+        }
+        close_table();
+        read_tail();
+        if (host.overflow) return false;
+    }
     unsigned long long removed_extra = 0;
     if (host.n_ovf) {
         // Some buckets exceed even the large configuration (k-mers with thousands of occurrences: low-complexity reads,
@@ -685,7 +711,7 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>(), ovf_list, b_small.as<uint32_t>());
+                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, b_small.as<uint32_t>());
         }
         SY_HIP(hipGetLastError());
         read_tail();
