@@ -8,8 +8,8 @@
 // dup_removal_lsh_full_exact as sketch.hip, see its header) -> distinct (k-mer, count) pairs.  Buckets are ordered
 // by hash, so concatenating their outputs gives the table in ascending k-mer order.
 // HBM traffic: 40 B (histogram) + 64 B (scatter) + 32 B (replay) per occurrence instead of ~16 radix passes.
-// A bucket that does not fit (a k-mer with thousands of occurrences) makes finish() fall back to the generic
-// device-wide path in sketch.hip.
+// A bucket beyond 1024 occurrences (a k-mer more than ~1000 deep) goes through the device-wide path of sketch.hip, as a
+// small sample of its own.
 #include "common.h"
 #include "device_common.h"
 #include "sketch_session.h"
@@ -17,11 +17,12 @@
 namespace sylph {
 namespace {
 
-// Two launches of the same kernel template: buckets of up to CAP_SMALL occurrences (all of them, for ordinary samples) run
-// with 10 KiB of LDS per workgroup -> 16 workgroups = 32 wavefronts per CU, which is what hides the latency of this
-// barrier- and gather-heavy kernel (with a single 512-slot configuration occupancy was 14 wavefronts and the kernel 1.4x
-// slower); the rare larger buckets (high-abundance k-mers) are redone by the CAP_LARGE configuration; only beyond that
-// does finish() fall back to the device-wide path.
+// Three configurations of the same kernel template.  Buckets of up to CAP_SMALL occurrences (all of them, for ordinary
+// samples) run with 10 KiB of LDS per workgroup -> 16 workgroups = 32 wavefronts per CU, which is what hides the latency of
+// this barrier- and gather-heavy kernel (with a single 512-slot configuration occupancy was 14 wavefronts and the kernel 1.4x
+// slower).  Larger buckets, and buckets that hold a deep k-mer (SEG_LIMIT), are queued for the CAP_MID / CAP_LARGE
+// configurations, which replace the scan over a k-mer's earlier occurrences by a hash table in LDS and are launched only
+// when something was queued; only beyond CAP_LARGE does a bucket take the device-wide path.
 constexpr int CAP_SMALL = 256, RTPB_SMALL = 128;
 constexpr int CAP_MID = 512, RTPB_MID = 256;       // hashed marker test, ~31 KiB of LDS: 5 workgroups per CU
 constexpr int CAP_LARGE = 1024, RTPB_LARGE = 256;   // hashed marker test, ~59 KiB of LDS: 2 workgroups per CU
