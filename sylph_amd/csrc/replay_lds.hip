@@ -229,7 +229,8 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
     constexpr bool HASHED = CAP != CAP_SMALL;
     constexpr uint32_t MARKER_TAB = 4 * CAP;    // slots of the marker table: 2 x (2 entries per occurrence)
     if constexpr (!HASHED) {
-        // a long k-mer segment: not for the quadratic marker test below
+        // a long k-mer segment of occurrences that carry markers: not for the quadratic marker test below (reads above 400 bases
+        // carry none — the test does not run for them, however deep the k-mer)
         if (!no_dedup) {
             __shared__ uint32_t s_longest;
             if (tid == 0) s_longest = 0;
@@ -238,9 +239,9 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             for (uint32_t t = 0; t < items; t++) {
                 const uint32_t j = j0 + t;
                 if (j >= n) break;
-                mine = max(mine, j - (uint32_t)s_seg[j]);
+                if (s_rid[j] & RID_MARKER_BIT) mine = max(mine, j - (uint32_t)s_seg[j] + 1);
             }
-            if (mine + 1 >= SEG_LIMIT) atomicMax(&s_longest, mine + 1);
+            if (mine >= SEG_LIMIT) atomicMax(&s_longest, mine);
             __syncthreads();
             if (s_longest >= SEG_LIMIT) {
                 if (tid == 0) mid_list[1 + atomicAdd(&mid_list[0], 1u)] = b;
@@ -484,12 +485,16 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t* __r
                                                              const uint32_t* __restrict__ n_distinct, uint32_t n_buckets,
                                                              uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
                                                              const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ mid_list,
-                                                             const uint32_t* __restrict__ large_list, uint32_t* __restrict__ tail) {
+                                                             const uint32_t* __restrict__ large_list, int skip_if_listed,
+                                                             uint32_t* __restrict__ tail) {
     // tail = {removed u64, overflow u32, n_seg u32, n_ovf u32, n_mid u32, n_large u32}: everything the host reads back, side by
     // side (ONE copy)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         tail[3] = d_off[n_buckets]; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
     }
+    // buckets are still waiting for the list-driven configurations: the host will come back after running them (a long-read
+    // table has tens of millions of rows: copying it twice would cost more than the configurations themselves)
+    if (skip_if_listed && (mid_list[0] | large_list[0])) return;
     for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
         const uint32_t n = n_distinct[b], s = boff[b], d = d_off[b];
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_k[d + i] = tmp_k[s + i]; out_c[d + i] = tmp_c[s + i]; }
@@ -632,7 +637,7 @@ bool finish_bucketed(sylph_sketch* sk) {
         }
     }
     // removed counts, table offsets, compaction, and everything the host needs to know in one 28-byte block
-    auto close_table = [&] {
+    auto close_table = [&](int skip_if_listed) {
         {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
@@ -642,7 +647,7 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, b_small.as<uint32_t>());
+                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, skip_if_listed, b_small.as<uint32_t>());
         }
         SY_HIP(hipGetLastError());
     };
@@ -653,7 +658,7 @@ bool finish_bucketed(sylph_sketch* sk) {
         memcpy(&host, ctx->pinned, 28);
         if (!ctx->pending.empty()) profile_collect(ctx);
     };
-    close_table();
+    close_table(1);
     read_tail();
     if (host.overflow) return false;             // inconsistent bounds (defensive): the generic path redoes the sample
     if (host.n_mid || host.n_large) {
@@ -675,7 +680,7 @@ bool finish_bucketed(sylph_sketch* sk) {
                                    sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
                                    d_overflow, large_list, large_list, ovf_list, dbg);
         }
-        close_table();
+        close_table(0);
         read_tail();
         if (host.overflow) return false;
     }
@@ -712,7 +717,7 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, b_small.as<uint32_t>());
+                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, 0, b_small.as<uint32_t>());
         }
         SY_HIP(hipGetLastError());
         read_tail();
