@@ -296,55 +296,87 @@ struct GenomeBatch {
     GenomeBatch(Engine& en, uint64_t c_, uint64_t k_, uint64_t sp, bool pt, std::vector<GenomeSketch>& o)
         : e(en), c(c_), k(k_), min_spacing(sp), pseudotax(pt), out(o) {}
 
-    // sketch_genome (individual = false) or sketch_genome_individual (true) up to the k-mer work; false = file skipped
-    bool add_file(const std::string& ref_file, bool individual) {
+    // One genome file read into memory: records concatenated, one offset per record.  Touches nothing of the batch, so any
+    // number of files can be parsed (and inflated) at the same time (the reference reads its genome files on the rayon pool,
+    // sketch.rs:422-476); warnings travel with the result so that they come out in file order.
+    struct Parsed {
+        std::string file;
+        std::vector<uint8_t> bases;
+        std::vector<uint64_t> ends;                 // end of every record in `bases`
+        std::vector<std::string> ids;               // first record only unless `individual`
+        std::vector<std::string> warnings;
+        bool ok = false;
+    };
+    static Parsed parse_file(const std::string& ref_file, bool individual) {
+        Parsed p;
+        p.file = ref_file;
         std::unique_ptr<FastxReader> reader;
         try { reader.reset(new FastxReader(ref_file)); }
-        catch (const Error&) { warn(ref_file + " is not a valid fasta/fastq file; skipping."); return false; }
-        const size_t bases0 = bases.size(), off0 = off.size(), goff0 = goff.size(), pend0 = pending.size();
+        catch (const Error&) { p.warnings.push_back(ref_file + " is not a valid fasta/fastq file; skipping."); return p; }
         FastxRecord rec;
-        GenomeSketch whole;
-        bool first = true;
         try {
             while (reader->next(rec)) {
-                if (first) { whole.first_contig_name = rec.id; first = false; }
-                bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
-                off.push_back(bases.size());
-                if (individual) {
-                    GenomeSketch g;
-                    g.file_name = ref_file; g.first_contig_name = rec.id; g.gn_size = rec.seq.size();
-                    pending.push_back(std::move(g));
-                    goff.push_back(off.size() - 1);
-                }
+                if (individual || p.ids.empty()) p.ids.push_back(rec.id);
+                p.bases.insert(p.bases.end(), rec.seq.begin(), rec.seq.end());
+                p.ends.push_back(p.bases.size());
             }
         } catch (const Error&) {                                             // :586-589: the whole file is dropped
-            warn("File " + ref_file + " is not a valid fasta/fastq file");
-            bases.resize(bases0); off.resize(off0); goff.resize(goff0); pending.resize(pend0);
-            return false;
+            p.warnings.push_back("File " + ref_file + " is not a valid fasta/fastq file");
+            return p;
         }
-        if (!individual) {
-            whole.file_name = ref_file;
-            whole.gn_size = bases.size() - bases0;
-            pending.push_back(std::move(whole));
-            goff.push_back(off.size() - 1);
+        p.ok = true;
+        return p;
+    }
+
+    // sketch_genome (individual = false) or sketch_genome_individual (true) up to the k-mer work; false = file skipped
+    bool add_file(const std::string& ref_file, bool individual) { return append(parse_file(ref_file, individual), individual); }
+
+    // files [0, n) parsed on up to `threads` threads, a window of them at a time, appended (and flushed) in file order
+    void add_files(const std::vector<std::string>& files, bool individual, uint64_t threads) {
+        const size_t window = std::max<size_t>(1, std::min<size_t>(threads, 64)) * 2;
+        for (size_t lo = 0; lo < files.size(); lo += window) {
+            const size_t n = std::min(window, files.size() - lo);
+            std::vector<Parsed> parsed(n);
+            std::atomic<size_t> next{0};
+            auto work = [&] { for (size_t i = next++; i < n; i = next++) parsed[i] = parse_file(files[lo + i], individual); };
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < std::min<size_t>(std::max<uint64_t>(threads, 1), n); w++) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+            for (auto& p : parsed) append(std::move(p), individual);
         }
+    }
+
+    bool append(Parsed p, bool individual) {
+        for (const auto& w : p.warnings) warn(w);
+        if (!p.ok) return false;
+        const std::string& ref_file = p.file;
         // one sylph_sketch_genomes call holds < 2^32 bases: a file that would push the batch over the limit starts a new batch,
         // and a single genome beyond it is skipped with a warning instead of aborting the whole run
         constexpr uint64_t LIMIT = (1ull << 32) - 4096;
-        if (bases.size() >= LIMIT) {
-            const std::vector<uint8_t> nb(bases.begin() + bases0, bases.end());
-            std::vector<uint64_t> noff(off.begin() + off0, off.end()), ngoff(goff.begin() + goff0, goff.end());
-            std::vector<GenomeSketch> npend(std::make_move_iterator(pending.begin() + pend0), std::make_move_iterator(pending.end()));
-            bases.resize(bases0); off.resize(off0); goff.resize(goff0); pending.resize(pend0);
-            flush();
-            if (nb.size() >= LIMIT) {
-                warn(ref_file + " holds " + std::to_string(nb.size()) + " bases, more than one device batch (2^32): skipping it");
-                return false;
+        if (p.bases.size() >= LIMIT) {
+            warn(ref_file + " holds " + std::to_string(p.bases.size()) + " bases, more than one device batch (2^32): skipping it");
+            return false;
+        }
+        if (bases.size() + p.bases.size() >= LIMIT) flush();
+        const uint64_t bases0 = bases.size();
+        bases.insert(bases.end(), p.bases.begin(), p.bases.end());
+        for (size_t r = 0; r < p.ends.size(); r++) {
+            off.push_back(bases0 + p.ends[r]);
+            if (individual) {
+                GenomeSketch g;
+                g.file_name = ref_file; g.first_contig_name = p.ids[r]; g.gn_size = p.ends[r] - (r ? p.ends[r - 1] : 0);
+                pending.push_back(std::move(g));
+                goff.push_back(off.size() - 1);
             }
-            for (uint64_t o : noff) off.push_back(o - bases0);
-            for (uint64_t g : ngoff) goff.push_back(g - (off0 - 1));
-            bases = nb;
-            pending = std::move(npend);
+        }
+        if (!individual) {
+            GenomeSketch whole;
+            whole.file_name = ref_file;
+            if (!p.ids.empty()) whole.first_contig_name = p.ids.front();
+            whole.gn_size = p.bases.size();
+            pending.push_back(std::move(whole));
+            goff.push_back(off.size() - 1);
         }
         if (bases.size() >= BATCH_BASES) flush();
         return true;
@@ -496,7 +528,7 @@ int sketch(Engine& e, const SketchArgs& args) {
         create_dir_all(dirname_of(path));
         std::vector<GenomeSketch> all;
         GenomeBatch batch(e, args.c, args.k, args.min_spacing_kmer, !args.no_pseudotax, all);
-        for (const auto& gf : genome_inputs) batch.add_file(gf, args.individual);
+        batch.add_files(genome_inputs, args.individual, args.threads);
         batch.flush();
         if (all.empty()) warn("No valid genomes to sketch; " + path + " is not output");
         else { write_syldb(path, all); info("Wrote all genome sketches to " + path); }
@@ -649,11 +681,13 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         for (auto& g : v) genome_sketches.push_back(std::move(g));
     }
     GenomeBatch batch(e, args.c, args.k, args.min_spacing_kmer, args.pseudotax, genome_sketches);
+    std::vector<std::string> genome_files_ok;
     for (const auto& gf : genome_files) {
         if (lowest_genome_c && *lowest_genome_c < args.c) { fprintf(stderr, "ERROR [sylph_hip] Value of -c for contain is %llu -- greater than the smallest value of -c for a genome sketch %llu. Continuing without sketching.\n", (unsigned long long)args.c, (unsigned long long)*lowest_genome_c); continue; }
         if (current_k && *current_k != args.k) { fprintf(stderr, "ERROR [sylph_hip] -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", (unsigned long long)args.k, (unsigned long long)*current_k); continue; }
-        batch.add_file(gf, args.individual);
+        genome_files_ok.push_back(gf);
     }
+    batch.add_files(genome_files_ok, args.individual, args.threads);
     batch.flush();
     info("Finished obtaining genome sketches.");
     if (genome_sketches.empty()) throw Error{1, "No genome sketches found; see sylph query/profile -h for help. Exiting"};
