@@ -334,6 +334,26 @@ __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const SampleRef* __res
 // hold it in genome_kmers or in pseudotax_tracked_nonused_kmers; ties go to the genome that comes first in the passing
 // list (the reference replaces only on strictly greater ANI, :417).  For every passing genome, sample k-mers of its
 // genome_kmers that it does not own count as kmers_lost, the others yield (genome, count) hits as in the first pass.
+// every matching posting of a long overflow run, 64 entries per step, for the whole wavefront (same arguments in every lane):
+// f(genome id) is called by the lane that holds the match
+template <class F>
+__device__ __forceinline__ void long_run_for_each(const LineView& v, uint64_t start, uint64_t rem, F&& f) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t gmask = (1ull << (v.gshift - 1)) - 1;
+    for (uint64_t base = start;; base += 64) {
+        const uint64_t idx = base + lane;
+        const uint64_t y = idx < v.n_ovf ? v.ovf[idx] : SLOT_EMPTY;
+        const uint64_t r = y >> v.gshift;
+        const unsigned long long stop = __ballot(y == SLOT_EMPTY || r > rem);              // the run is sorted by (remainder, genome)
+        const uint32_t first_stop = stop ? (uint32_t)__ffsll((long long)stop) - 1 : 64u;
+        if (lane < first_stop && r == rem) f((uint32_t)(y & gmask));
+        if (stop) break;
+    }
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src) {
+    return ((uint64_t)(uint32_t)__shfl((int)(x >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)x, src);
+}
+
 __global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(const uint64_t* __restrict__ s_kmers, const uint32_t* __restrict__ s_counts,
                                                              uint32_t n_sample, LineView kept, LineView tracked, int have_tracked,
                                                              const uint32_t* __restrict__ rank, const double* __restrict__ ani,
@@ -342,29 +362,70 @@ __global__ __launch_bounds__(PROBE_TPB) void reassign_kernel(const uint64_t* __r
     __shared__ HitStage st;
     hit_stage_init(st);
     const uint32_t n_chunks = (n_sample + PROBE_TPB - 1) / PROBE_TPB;
+    const int lane = (int)(threadIdx.x & 63);
+    // (genome, first-pass ANI) candidates: the best is the highest ANI, ties to the lowest rank in the passing list
+    auto consider = [&](uint32_t g, double& ba, uint32_t& br) {
+        const uint32_t r = rank[g];
+        if (r == 0xFFFFFFFFu) return;
+        const double a = ani[r];
+        if (a > ba || (a == ba && r < br)) { ba = a; br = r; }
+    };
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint32_t i = chunk * PROBE_TPB + threadIdx.x;
-        const uint32_t cnt = i < n_sample ? s_counts[i] : 0;
-        if (cnt != 0) {                                                          // contain.rs:634
-            const uint64_t km = s_kmers[i];
-            uint32_t best_rank = 0xFFFFFFFFu, n_kept = 0;
-            double best_ani = -1.0;
-            auto consider = [&](uint32_t g) {
-                const uint32_t r = rank[g];
-                if (r == 0xFFFFFFFFu) return;
-                const double a = ani[r];
-                if (a > best_ani || (a == best_ani && r < best_rank)) { best_ani = a; best_rank = r; }
-            };
-            for_each_posting(kept, km, [&](uint32_t g) { n_kept++; consider(g); });
-            if (n_kept) {
-                if (have_tracked) for_each_posting(tracked, km, consider);
-                for_each_posting(kept, km, [&](uint32_t g) {
-                    const uint32_t r = rank[g];
-                    if (r == 0xFFFFFFFFu) return;                                // not in remaining_genomes
-                    if (r != best_rank) { atomicAdd(&lost[g], 1u); return; }     // contain.rs:639-642
-                    hit_stage_push(st, ((uint64_t)g << 32) | cnt, hits, hit_cap, hit_count);
-                });
+        const uint32_t cnt = i < n_sample ? s_counts[i] : 0;                         // contain.rs:634: nothing for a zero count
+        const uint64_t km = cnt != 0 ? s_kmers[i] : 0;
+        uint32_t best_rank = 0xFFFFFFFFu, n_kept = 0;
+        double best_ani = -1.0;
+        // Three passes over the k-mer's postings, as in the reference (winner among kept + tracked, then lost / kept per genome).
+        // Each pass takes the line and short overflow runs lane by lane; long runs (k-mers shared by hundreds of genomes) are
+        // handed to the whole wavefront, one after the other, and their outcome is merged into the owning lane before the next
+        // pass begins.
+        uint64_t ls = ~0ull, lr = 0;
+        if (cnt != 0) for_each_posting(kept, km, [&](uint32_t g) { n_kept++; consider(g, best_ani, best_rank); }, &ls, &lr);
+        for (unsigned long long todo = __ballot(ls != ~0ull); todo; todo &= todo - 1) {
+            const int src = __ffsll((long long)todo) - 1;
+            uint32_t c_l = 0, r_l = 0xFFFFFFFFu;
+            double a_l = -1.0;
+            long_run_for_each(kept, shfl_u64(ls, src), shfl_u64(lr, src), [&](uint32_t g) { c_l++; consider(g, a_l, r_l); });
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const uint32_t c_o = (uint32_t)__shfl_xor((int)c_l, d), r_o = (uint32_t)__shfl_xor((int)r_l, d);
+                const double a_o = __shfl_xor(a_l, d);
+                c_l += c_o;
+                if (a_o > a_l || (a_o == a_l && r_o < r_l)) { a_l = a_o; r_l = r_o; }
             }
+            if (lane == src) {
+                n_kept += c_l;
+                if (a_l > best_ani || (a_l == best_ani && r_l < best_rank)) { best_ani = a_l; best_rank = r_l; }
+            }
+        }
+        uint64_t lts = ~0ull, ltr = 0;
+        if (n_kept && have_tracked) for_each_posting(tracked, km, [&](uint32_t g) { consider(g, best_ani, best_rank); }, &lts, &ltr);
+        for (unsigned long long todo = __ballot(lts != ~0ull); todo; todo &= todo - 1) {
+            const int src = __ffsll((long long)todo) - 1;
+            uint32_t r_l = 0xFFFFFFFFu;
+            double a_l = -1.0;
+            long_run_for_each(tracked, shfl_u64(lts, src), shfl_u64(ltr, src), [&](uint32_t g) { consider(g, a_l, r_l); });
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const uint32_t r_o = (uint32_t)__shfl_xor((int)r_l, d);
+                const double a_o = __shfl_xor(a_l, d);
+                if (a_o > a_l || (a_o == a_l && r_o < r_l)) { a_l = a_o; r_l = r_o; }
+            }
+            if (lane == src && (a_l > best_ani || (a_l == best_ani && r_l < best_rank))) { best_ani = a_l; best_rank = r_l; }
+        }
+        auto settle = [&](uint32_t g, uint32_t winner, uint32_t c) {
+            const uint32_t r = rank[g];
+            if (r == 0xFFFFFFFFu) return;                                            // not in remaining_genomes
+            if (r != winner) { atomicAdd(&lost[g], 1u); return; }                    // contain.rs:639-642
+            hit_stage_push(st, ((uint64_t)g << 32) | c, hits, hit_cap, hit_count);
+        };
+        uint64_t ls3 = ~0ull, lr3 = 0;
+        if (n_kept) for_each_posting(kept, km, [&](uint32_t g) { settle(g, best_rank, cnt); }, &ls3, &lr3);
+        for (unsigned long long todo = __ballot(ls3 != ~0ull); todo; todo &= todo - 1) {
+            const int src = __ffsll((long long)todo) - 1;
+            const uint32_t winner = (uint32_t)__shfl((int)best_rank, src), c_s = (uint32_t)__shfl((int)cnt, src);
+            long_run_for_each(kept, shfl_u64(ls3, src), shfl_u64(lr3, src), [&](uint32_t g) { settle(g, winner, c_s); });
         }
         hit_stage_flush(st, chunk + gridDim.x >= n_chunks, hits, hit_cap, hit_count);
     }

@@ -951,6 +951,62 @@ def test_reassign_on_device_matches_reference_semantics(ctx):
     db.close()
 
 
+def test_reassign_with_kmers_shared_by_hundreds_of_genomes(ctx):
+    """The winner pass when 400 strains hold (almost) the same k-mers in genome_kmers AND in their tracked sets: overflow runs of
+    hundreds of postings in both indexes, walked by the whole wavefront; winner = highest first-pass ANI, ties to the first in
+    the passing list; strains outside the passing list neither win nor lose; every genome's kept coverages and kmers_lost
+    against a direct restatement of winner_table + the winner pass (contain.rs:410-430, :637-646)."""
+    rng = np.random.default_rng(123)
+    thr = O.threshold(200)
+    core = np.unique(rng.integers(0, thr, size=250, dtype=np.uint64))
+    tcore = np.unique(rng.integers(0, thr, size=120, dtype=np.uint64))
+    G = 460
+    genomes, tracked = [], []
+    for g in range(G):
+        if g < 400:
+            genomes.append(np.concatenate([core[rng.random(len(core)) < 0.95], rng.integers(0, thr, size=20, dtype=np.uint64)]))
+            # tracked sets: the shared tracked core + some of the OTHER strains' genome k-mers (they can steal ownership)
+            tracked.append(np.concatenate([tcore[rng.random(len(tcore)) < 0.9], core[rng.random(len(core)) < 0.05]]))
+        else:
+            genomes.append(np.concatenate([rng.integers(0, thr, size=200, dtype=np.uint64), tcore[:30], core[:5]]))
+            tracked.append(np.zeros(0, dtype=np.uint64))
+    db_k, goff = flat_db(genomes)
+    t_k, toff = flat_db(tracked)
+    sk = np.unique(np.concatenate([core, tcore, rng.integers(0, thr, size=3000, dtype=np.uint64)] + [g[-20:] for g in genomes[:50]]))
+    sc = rng.integers(0, 5, size=len(sk)).astype(np.uint32)
+    smap = dict(zip(sk.tolist(), sc.tolist()))
+    db = S.Database(ctx, db_k, goff)
+    db.attach_tracked(t_k, toff)
+    for trial in range(3):
+        passing = rng.permutation(G)[: int(rng.integers(250, G + 1))]
+        ani = rng.choice([0.95, 0.96, 0.97, 0.97, 0.99], size=len(passing)) if trial else np.full(len(passing), 0.97)   # trial 0: all tied
+        winner = {}
+        for r, g in enumerate(passing):
+            for km in list(genomes[g].tolist()) + list(tracked[g].tolist()):
+                if km not in winner or ani[r] > winner[km][0]:
+                    winner[km] = (ani[r], int(g))
+        cc, off, covs, lost = db.reassign_view(sk, sc, passing, ani)
+        pset = set(int(x) for x in passing)
+        for g in range(G):
+            got = covs[int(off[g]):int(off[g + 1])]
+            if g not in pset:
+                assert cc[g] == 0 and len(got) == 0 and lost[g] == 0
+                continue
+            exp, exp_lost = [], 0
+            for km in genomes[g].tolist():
+                c = smap.get(km, 0)
+                if c == 0:
+                    continue
+                if winner[km][1] != g:
+                    exp_lost += 1
+                else:
+                    exp.append(c)
+            assert cc[g] == len(exp) and lost[g] == exp_lost, (trial, g)
+            assert np.array_equal(got, np.sort(np.array(exp, dtype=np.uint32)))
+        assert int(lost.sum()) > 10000
+    db.close()
+
+
 # ---------------------------------------------------------------------------------------------- fuzz over read shapes
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SYLPH_FUZZ_SEEDS", "6"))))   # (a longer campaign: SYLPH_FUZZ_SEEDS=200)
 def test_read_shapes_fuzz(ctx, seed):
