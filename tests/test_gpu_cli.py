@@ -416,3 +416,22 @@ def test_parallel_feed_equals_sequential_feed(data):
     a, b = (o / "z_1.fq.gz.paired.sylsp").read_bytes(), outs[0][0]
     n_tab = 8 + 12 * int.from_bytes(b[:8], "little")                               # the k-mer table leads the file (types.rs:145-155)
     assert n_tab > 1000 and a[:n_tab] == b[:n_tab] and a[n_tab:n_tab + 16] == b[n_tab:n_tab + 16]   # + c, k; the file names differ
+
+
+def test_database_does_not_depend_on_threads(data):
+    """Genome files are parsed and inflated on the -t threads and appended in file order: the .syldb must be the same bytes for
+    every -t, with plain and gzip files, a file that is not FASTA in the middle of the list (warned about, skipped), `-i`."""
+    d = data["dir"]
+    g = data["genomes"]
+    files = [g[n][0] for n in ("EC590", "K12", "O157", "rand")] * 3
+    bad = d / "not_a_genome.fa"
+    bad.write_text("this is not fasta\n")
+    files.insert(5, str(bad))
+    for extra in ((), ("-i",)):
+        outs = []
+        for t in ("1", "2", "16"):
+            o = d / f"dbt_{t}{'_i' if extra else ''}"
+            p = run("sketch", *files, "-o", o, "-t", t, *extra)
+            assert "not_a_genome.fa is not a valid fasta/fastq file" in p.stderr
+            outs.append((d / f"{o}.syldb").read_bytes())
+        assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 10000
