@@ -5,29 +5,36 @@
                                                             under `python -m torch.distributed.run` it is one of them)
 
 Metric (BASELINE.json): read Gbp/s sketched + genome-comparisons/s profiled, 1 Gbp of 2x150 bp reads vs a GTDB-R220-scale
-database (113,104 genome sketches, k=31, c=200).  One *step* = one pass of the hot path over the step's samples on every
-GPU: sketch each sample (seeding -> exact dedup/count; reads already resident in HBM) and profile the resulting tables against
-the resident database (containment counts + coverage vectors back on the host).  `value` = whole-job read Gbp/s through
-both stages; the per-stage rates are reported next to it.  Steps are pipelined the way a multi-sample `sylph profile` run
-is: sketching runs on worker threads (own context + stream each), profiling on the main thread's context, and the samples of
-the next steps are sketched while the current step is profiled (--pipeline-depth; all K steps complete inside the timed
-region).  `one_step_at_a_time` repeats the steps strictly one after the other: step latency, and every kernel alone on the GPU.
+database (113,104 genome sketches, k=31, c=200).  The unit of work is one SAMPLE through both stages: sketch it (seeding ->
+exact dedup/count; reads already resident in HBM) and profile the table against the resident database (containment counts +
+coverage vectors back on the host).  One *step* = one pass of the hot path over a batch of `samples_per_step` samples on every
+GPU; the batch size is fixed BEFORE the timed region (from the untimed calibration, so that the K timed steps last at least
+--min-seconds, default 2 s: a 60 ms region — 20 one-sample steps — let a single scheduler hiccup or an rocm-smi poll move the
+result by double-digit percentages) and reported in the line.  `value` = whole-job read Gbp/s through both stages = all bases
+of the K steps / the time of the K steps; per-step and per-sample percentiles are printed next to it so that a stall is visible.
 
-Workloads (--workload): c3 = BASELINE configs[2], the configuration the metric is quoted on (default at N = 1: one 1 Gbp
-sample per step, database on the one GPU); c4 = configs[3] (default at N > 1: 8 samples per GPU per step, database sharded
-by k-mer range over the N GPUs, RCCL exchange inside sylph_db_contain_batch_sharded); c2 / c5 = configs[1] / [4];
-c3r = c3 with ragged 35-151 bp reads and 0.1 % N (reported beside c3, not instead of it).
+Two ways of running the same samples, both measured in every run, `value` taken from the faster one (`mode`; the calibration
+decides before the timed region, all ranks agree):
+  pipelined   sylph_pipeline_* (csrc/pipeline.hip): C++ sketch worker threads with a context each + one profile thread inside
+              the library, a few samples in flight, the way a multi-sample `sylph profile` run overlaps its samples on the rayon
+              pool (sketch.rs:313, contain.rs:267-289).  No Python thread takes part in the overlap.
+  sequential  one sample at a time on one context: step latency, and every kernel alone on the GPU (`one_step_at_a_time`).
+
+Workloads (--workload): c3 = BASELINE configs[2], the configuration the metric is quoted on (default at N = 1: database on the
+one GPU); c4 = configs[3] (default at N > 1: 8 samples per GPU per probe batch, database sharded by k-mer range over the N GPUs,
+RCCL exchange inside sylph_db_contain_batch_sharded); c2 / c5 = configs[1] / [4]; c3r = c3 with ragged 35-151 bp reads and
+0.1 % N (reported beside c3, not instead of it).
 
 Multi-GPU: samples are independent units (no collective in the sketch stage).  --db-mode shard (default for
-N > 1, what north_star describes): every rank holds the postings of one k-mer range; per step the library all-gathers the
+N > 1, what north_star describes): every rank holds the postings of one k-mer range; per probe batch the library all-gathers the
 slice boundaries, sends every rank its 1/N slice of every table (all-to-all), probes, and sends every hit to the rank that
 owns its sample (a second all-to-all); --db-mode replicate: every rank holds the whole index (22-38 GB of 288 GB) and no data-path collective
 is needed at all.  scaling = weak (per-GPU work fixed).
 
-After the timed region (untimed): --verify compares the containment results of the last step's first sample, for the
-sequence-backed genomes + a sample of the decoys, against the CPU oracle on the same table; the CPU baseline leg (rank 0,
-N = 1) times the oracle — the C++ restatement of the reference's AVX2/rayon path — on a bounded sample of the same inputs.
-These two legs are the only places bench.py touches oracle/.
+After the timed region (untimed): --verify compares the containment results of one more sample, for the sequence-backed genomes
++ a sample of the decoys, against the CPU oracle on the same table; the CPU baseline leg (rank 0, N = 1) times the oracle — the
+C++ restatement of the reference's AVX2/rayon path — on a bounded sample of the same inputs.  These two legs are the only places
+bench.py touches oracle/.
 """
 import argparse
 import json
@@ -44,7 +51,7 @@ sys.path.insert(0, ROOT)
 
 import sylph_amd as S  # noqa: E402
 from sylph_amd import shard as SH  # noqa: E402
-from sylph_amd import synth  # noqa: E402
+import synth  # noqa: E402  (workload generators: beside bench.py, not in the product package)
 
 WORKLOADS = {
     # name: (n_pairs, n_community, n_seq_backed, n_genomes_total, genome_len, samples per GPU per step, distinct read sets)
@@ -203,6 +210,23 @@ def verify_against_oracle(ctx, res, G, sample_ptrs, verify_set, device):
             "what": "contain_count + sorted coverage vector per genome vs the CPU oracle on the same sample table (first sample of the last step)"}
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources: the PMC traffic figures in profiles/ are only quoted for the code they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sylph_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(q * len(xs)))] if xs else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,16 +234,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SYLPH_BENCH_WORKLOAD", "auto"), choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--db-mode", default=os.environ.get("SYLPH_BENCH_DB_MODE", "auto"), choices=["auto", "replicate", "shard"])
-    ap.add_argument("--samples-per-step", type=int, default=0, help="samples per GPU per step (default: the workload's)")
+    ap.add_argument("--mode", default=os.environ.get("SYLPH_BENCH_MODE", "auto"), choices=["auto", "pipelined", "sequential"],
+                    help="which way of running the samples `value` is taken from (auto: the faster one of the untimed calibration)")
+    ap.add_argument("--min-seconds", type=float, default=float(os.environ.get("SYLPH_BENCH_MIN_SECONDS", "2.0")),
+                    help="the K timed steps last at least this long: samples_per_step is sized for it before the timed region")
+    ap.add_argument("--samples-per-step", type=int, default=0, help="samples per GPU per step (default: sized from --min-seconds)")
+    ap.add_argument("--probe-batch", type=int, default=0, help="sample tables per probe launch (default: the workload's; c4: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
-    ap.add_argument("--sketch-workers", type=int, default=0,
-                    help="sketch worker threads, each with its own context/stream (default 2; the reference sketches samples on parallel threads too, sketch.rs:313)")
-    ap.add_argument("--pipeline-depth", type=int, default=0,
-                    help="steps in flight: the samples of step i+1.. are sketched while step i is profiled (default: workers + 1 for one sample per step, else 2; 1 = one step at a time)")
-    ap.add_argument("--no-sequential-leg", action="store_true", help="skip the extra one-step-at-a-time leg")
+    ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 2)")
+    ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 2; sharded: two probe batches)")
+    ap.add_argument("--no-second-leg", action="store_true", help="skip the leg of the mode `value` is NOT taken from")
     ap.add_argument("--seed", type=int, default=20250711)
     args = ap.parse_args()
 
@@ -249,20 +276,28 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    def agree(value, op="max"):            # one number every rank ends up with
+        if dist is None:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN)
+        return float(t.item())
+
     c, k, read_len = 200, 31, 150
-    n_pairs, _, _, _, _, spg, n_sets = WORKLOADS[wl]
-    if args.samples_per_step:
-        spg = args.samples_per_step
-        n_sets = max(n_sets, spg)
+    n_pairs, _, _, _, _, spb, n_sets = WORKLOADS[wl]
+    if args.probe_batch:
+        spb = args.probe_batch
+    n_sets = max(n_sets, spb)
     long_mode = wl == "c5"
     c_reads = 100 if long_mode else c        # reads may be sketched denser than the DB (contain.rs:562-568,616-623)
-    # One HIP stream for everything: the library launches on a torch-owned stream, so torch-side generation, the
-    # library's kernels and the timing events are stream-ordered without cross-queue synchronisation.
+    # The main context launches on a torch-owned stream, so torch-side generation, the library's kernels on this context and the
+    # timing events are stream-ordered without cross-queue synchronisation.
     tstream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(tstream)
     ctx = S.Context(local, stream=tstream.cuda_stream)
-    for kv in filter(None, os.environ.get("SYLPH_BENCH_CTX_OPTIONS", "").split(",")):   # tuning experiments only
-        ctx.set_option(*kv.split("=", 1))
+    ctx_options = [kv.split("=", 1) for kv in filter(None, os.environ.get("SYLPH_BENCH_CTX_OPTIONS", "").split(","))]   # tuning experiments only
+    for kv in ctx_options:
+        ctx.set_option(*kv)
 
     db_mode = args.db_mode if args.db_mode != "auto" else ("shard" if world > 1 else "replicate")
     log(f"[bench] building workload {wl} on {world} GPU(s), db {db_mode} ...")
@@ -270,11 +305,7 @@ def main():
     comm, comm_kind, fallbacks = None, None, []
 
     def agreed_failure(failed):            # a rank that failed takes every rank down the same fallback
-        if dist is None:
-            return bool(failed)
-        t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return bool(t.item())
+        return bool(agree(1 if failed else 0))
 
     if db_mode == "shard":
         if world == 1:      # the sharded code path with a one-rank RCCL communicator: the exchange's own cost, nothing on the wire
@@ -296,7 +327,7 @@ def main():
                 fallbacks.append(f"library RCCL communicator: {err}")
                 comm, comm_kind = SH.torch_device_comm(dist, device), "RCCL through torch.distributed collectives on the device buffers"
     t0 = time.time()
-    read_sets = []                           # distinct samples, rotated over the steps so that the probe is never cache-warm
+    read_sets = []                           # distinct samples, rotated so that the probe is never cache-warm
     for i in range(n_sets):
         sd = args.seed + 1_000_003 * (rank + 1) + 7919 * i
         if long_mode:
@@ -306,289 +337,314 @@ def main():
             while cuts[-1] < n_records:
                 nxt = int(torch.searchsorted(rec_off, rec_off[cuts[-1]] + 3_000_000_000).item())
                 cuts.append(max(cuts[-1] + 1, min(nxt, n_records)))
-            batches = []
+            batches, keep = [], []
             for a, b in zip(cuts[:-1], cuts[1:]):
                 o = (rec_off[a:b + 1] - rec_off[a]).contiguous()
-                batches.append((int(rec_off[a].item()), o, b - a, int(o[-1].item())))
-            read_sets.append(dict(bases=bases, rec_off=rec_off, n_bases=int(rec_off[-1].item()), n_records=n_records, batches=batches))
+                keep.append(o)
+                batches.append((bases.data_ptr() + int(rec_off[a].item()), o.data_ptr(), b - a, int(o[-1].item())))
+            read_sets.append(dict(bases=bases, rec_off=rec_off, keep=keep, n_bases=int(rec_off[-1].item()), n_records=n_records, batches=batches))
         else:
             if wl == "c3r":
                 bases, rec_off = synth.ragged_paired_reads(community, n_pairs, seed=sd)
             else:
                 bases, rec_off = synth.paired_reads(community, n_pairs, read_len=read_len, seed=sd)
-            read_sets.append(dict(bases=bases, rec_off=rec_off, n_bases=int(rec_off[-1].item()), n_records=2 * n_pairs, batches=None))
+            nb = int(rec_off[-1].item())
+            read_sets.append(dict(bases=bases, rec_off=rec_off, n_bases=nb, n_records=2 * n_pairs,
+                                  batches=[(bases.data_ptr(), rec_off.data_ptr(), 2 * n_pairs, nb)]))
     torch.cuda.synchronize()
     del community
     n_bases = float(np.mean([r["n_bases"] for r in read_sets]))
     log(f"[bench] db {dbstats}; {n_sets} read sets of {n_bases / 1e9:.3f} Gbp generated in {time.time() - t0:.1f}s")
 
-    last = {}
-    # Sketching runs on worker threads, each with its own context (stream, memory pool); the profile stage runs on the main
-    # thread's context.  --pipeline-depth steps are in flight at once: while step i is profiled, the samples of the next steps
-    # are already being sketched, and the small launch-bound kernels of one sample's dedup/count stage fill the gaps beside
-    # another sample's seeding kernel.  (The reference sketches samples on parallel threads too, sketch.rs:313, and profiles
-    # sample after sample against the loaded database, contain.rs:267-289.)  Depth 1 = one step at a time.
-    import queue
-    import threading
-    from collections import deque
-    from concurrent.futures import Future
+    # ---- the two ways of running samples ------------------------------------------------------------------------------------
     n_workers = max(1, args.sketch_workers or 2)
-    depth = max(1, args.pipeline_depth or (n_workers + 1 if spg == 1 else 2))
-
-    class SketchWorker(threading.Thread):
-        def __init__(self):
-            super().__init__(daemon=True)
-            self.ctx = S.Context(local)
-            self.jobs = queue.Queue()
-            self.start()
-
-        def run(self):
-            torch.cuda.set_device(local)
-            while True:
-                job = self.jobs.get()
-                if job is None:
-                    return
-                fn, fut = job
-                try:
-                    fut.set_result(fn(self.ctx))
-                except BaseException as e:       # handed to whoever waits for the result
-                    fut.set_exception(e)
-
-        def submit(self, fn):
-            fut = Future()
-            self.jobs.put((fn, fut))
-            return fut
-
-    workers = [SketchWorker() for _ in range(n_workers)]
-    all_ctx = [ctx] + [w.ctx for w in workers]
-    for w in workers:
-        for kv in filter(None, os.environ.get("SYLPH_BENCH_CTX_OPTIONS", "").split(",")):
-            w.ctx.set_option(*kv.split("=", 1))
+    depth = max(1, args.pipeline_depth or (2 * spb if comm is not None else max(n_workers + 2, spb + n_workers)))
+    if comm is not None:
+        depth = max(depth, spb)
     sample_no = [0]
 
-    def sketch_one(wctx, rs):
-        t_a = time.perf_counter()
-        sk = S.ReadSketcher(wctx, c=c_reads, k=k, paired=not long_mode)
-        if long_mode:
-            for start, o, nrec, nb in rs["batches"]:
-                sk.push_device(rs["bases"].data_ptr() + start, o.data_ptr(), nrec, nb)
-        else:
-            sk.push_device(rs["bases"].data_ptr(), rs["rec_off"].data_ptr(), rs["n_records"], rs["n_bases"])
-        dk, dc, n, dup = sk.finish_device()
-        return sk, (dk, dc, n, dup), time.perf_counter() - t_a
+    def next_read_set():
+        rs = read_sets[sample_no[0] % n_sets]
+        sample_no[0] += 1
+        return rs
 
-    class Inline:                    # one step at a time with one sample per step: everything on the main thread's context
-        @staticmethod
-        def submit(fn):
-            fut = Future()
-            fut.set_result(fn(ctx))
-            return fut
+    def make_pipeline():
+        p = S.Pipeline(db, c=c_reads, k=k, paired=not long_mode, n_workers=n_workers, depth=depth, max_batch=spb if comm is not None else max(spb, 8),
+                       comm=comm)
+        for kv in ctx_options:
+            p.set_option(*kv)
+        return p
 
-    def submit_step(inline=False):
-        jobs = []
-        for _ in range(spg):
-            rs = read_sets[sample_no[0] % n_sets]
-            w = Inline if inline else workers[sample_no[0] % n_workers]
-            jobs.append((w, w.submit(lambda wctx, rs=rs: sketch_one(wctx, rs))))
-            sample_no[0] += 1
-        return jobs
+    pipe_box = [None]
 
-    def finish_step(jobs, collect=None):
-        done = [f.result() for _, f in jobs]
-        tables = [d[1] for d in done]
-        t_b = time.perf_counter()
-        refs = [(dk, dc, n) for dk, dc, n, _ in tables]
-        if comm is not None:
-            res = db.contain_batch_sharded(comm, refs, device_ptrs=True)
-        else:
-            res = db.contain_batch(refs, device_ptrs=True)      # borrowed pinned views
-        t_c = time.perf_counter()
-        if collect == "final":       # untimed extra step: keep what the verify / roofline legs need
-            last["res"] = tuple(np.array(x) for x in res)
-            last["table"] = tables[0][:3]
-            last["occ"] = [int(SH.device_view(dc, n, torch.int32, device).sum().item()) + dup for dk, dc, n, dup in tables]
-            last["n_table"] = [n for _, _, n, _ in tables]
-            last["hits"] = int(len(res[2]))
-            last["sessions"] = [(w, d[0]) for (w, _), d in zip(jobs, done)]
-            return
-        for (w, _), d in zip(jobs, done):        # a session is closed on the thread that owns its context
-            w.submit(lambda wctx, sk=d[0]: sk.close())
-        if isinstance(collect, list):
-            collect.append((float(np.sum([d[2] for d in done])), t_c - t_b, [t[2] for t in tables], [t[3] for t in tables], len(res[2])))
+    def run_pipelined(n, stamps=None, rows=None):
+        """n samples through sylph_pipeline_*; stamps: completion time of every sample (perf_counter)"""
+        p = pipe_box[0]
+        sub = done = 0
+        while done < n:
+            while sub < n and p.outstanding < depth:
+                rs = next_read_set()
+                if not p.submit_device(rs["batches"], tag=sub):
+                    raise RuntimeError("pipeline refused a sample below its depth")
+                sub += 1
+                if sub == n and comm is not None:
+                    p.flush()                # the last probe batch of this call may be a partial one (the same on every rank)
+            r = p.next(views=False)
+            done += 1
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+            if rows is not None:
+                t = r["t"]
+                rows.append((t[2] - t[1], t[4] - t[3], r["n_table"], r["dup_removed"], r["n_covs"], r["probe_batch"]))
 
-    def run_steps(n, collect=None, in_flight=1):
-        pending = deque()
-        submitted = 0
-        for i in range(n):
-            while submitted < n and submitted < i + in_flight:      # steps i .. i + in_flight - 1 are in flight while i is finished
-                pending.append(submit_step(inline=(in_flight == 1 and spg == 1)))
-                submitted += 1
-            finish_step(pending.popleft(), collect)
-        for w in workers:                                            # the sessions' close jobs
-            w.submit(lambda wctx: None).result()
+    def sketch_inline(rs):
+        sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode)
+        for bptr, optr, nrec, nb in rs["batches"]:
+            sk.push_device(bptr, optr, nrec, nb)
+        return sk, sk.finish_device()
 
-    # untimed settle steps (first-use allocations of every context's pool, lazy kernel loading) whatever --warmup is
+    def run_sequential(n, stamps=None, rows=None, keep_last=None):
+        """n samples one at a time on the main context (probe batches of spb: their sketches run one after the other first)"""
+        done = 0
+        while done < n:
+            m = min(spb, n - done)
+            t_a = time.perf_counter()
+            sess = [sketch_inline(next_read_set()) for _ in range(m)]
+            t_b = time.perf_counter()
+            refs = [(dk, dc, nt) for _, (dk, dc, nt, _) in sess]
+            if comm is not None:
+                res = db.contain_batch_sharded(comm, refs, device_ptrs=True)
+            else:
+                res = db.contain_batch(refs, device_ptrs=True)      # borrowed pinned views
+            t_c = time.perf_counter()
+            if keep_last is not None:
+                keep_last["res"] = tuple(np.array(x) for x in res)
+                keep_last["table"] = sess[0][1][:3]
+                keep_last["occ"] = [int(SH.device_view(dc, nt, torch.int32, device).sum().item()) + dup for _, (dk, dc, nt, dup) in sess]
+                keep_last["sessions"] = [s for s, _ in sess]
+            else:
+                for s, _ in sess:
+                    s.close()
+            for j, (_, (dk, dc, nt, dup)) in enumerate(sess):
+                if stamps is not None:
+                    stamps.append(t_c)
+                if rows is not None:
+                    rows.append(((t_b - t_a) / m, (t_c - t_b) / m, nt, dup, len(res[2]) // m, m))
+            done += m
+
+    runners = {"pipelined": run_pipelined, "sequential": run_sequential}
+
+    # ---- untimed: first-use allocations of every context's pool, lazy kernel loading, then the calibration -------------------
+    pipe_box[0] = make_pipeline()
     if comm is not None and world > 1:
-        # the first sharded step ever run on this node: if the exchange fails on any rank, every rank drops to the replicated
+        # the first sharded batches ever run on this node: if the exchange fails on any rank, every rank drops to the replicated
         # database (no data-path collective) and says so in the result line
         err = None
         try:
-            run_steps(1, None, 1)
+            run_sequential(spb)
         except Exception as e:
             err = e
         if agreed_failure(err is not None):
             fallbacks.append(f"sharded exchange ({comm_kind}): {err}")
             log(f"[bench] rank {rank}: sharded step failed ({err}); falling back to the replicated database")
             try:
+                pipe_box[0].close()
                 comm.close()
                 db.close()
             except Exception:
                 pass
             comm, comm_kind, db_mode = None, None, "replicate"
             db, n_total, _, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
-    run_steps(2 * n_workers, None, 2)
-    run_steps(2, None, 1)
-    run_steps(2 * depth, None, depth)      # ... and with as many sessions alive per context as the pipelined region will have
+            pipe_box[0] = make_pipeline()
+    run_sequential(2 * spb)
+    run_pipelined(max(2 * depth, 2 * spb))
     torch.cuda.synchronize()
-    run_steps(args.warmup, None, depth)
 
-    def timed(n, in_flight):
-        for wc in all_ctx:
-            wc.profile(not args.no_kernel_timers)
+    def measure(mode, n):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        runners[mode](n)
+        torch.cuda.synchronize()
+        return agree((time.perf_counter() - t_s) / n)      # slowest rank's seconds per sample
+
+    n_cal = spb * max(2, int(round(0.25 / (spb * max(n_bases, 1e8) / 1e9 * 1.5e-3))))       # ~0.25 s per mode
+    cal = {"samples_per_mode": n_cal}
+    for mode in ("pipelined", "sequential"):
+        if args.mode in ("auto", mode) or not args.no_second_leg:
+            cal[mode + "_ms_per_sample"] = round(measure(mode, n_cal) * 1e3, 4)
+    if args.mode != "auto":
+        mode = args.mode
+    else:
+        mode = "pipelined" if cal["pipelined_ms_per_sample"] <= cal["sequential_ms_per_sample"] else "sequential"
+    other = "sequential" if mode == "pipelined" else "pipelined"
+    est = cal[mode + "_ms_per_sample"] * 1e-3
+    # samples per step: a multiple of the probe batch, sized so that the K timed steps last --min-seconds
+    if args.samples_per_step:
+        sps = max(spb, args.samples_per_step // spb * spb)
+    else:
+        sps = int(agree(max(1, int(np.ceil(args.min_seconds * 1.1 / max(1, args.steps) / est / spb))) * spb))
+    log(f"[bench] calibration {cal}: value from the {mode} mode, {sps} sample(s) per step")
+
+    def timed(mode, n_steps, per_step):
+        """-> elapsed seconds (max over ranks), per-step seconds, per-sample completion stamps, rows, kernel families"""
+        profiled = [pipe_box[0]] if mode == "pipelined" else [ctx]
+        for o in profiled:
+            o.profile(not args.no_kernel_timers)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
-        rows = []
-        run_steps(n, rows, in_flight)
+        stamps, rows, bounds = [], [], [t_start]
+        for _ in range(n_steps):
+            # (pipelined: the pipeline drains at the end of every step — its last samples have nothing to overlap with; with
+            #  hundreds of samples per step that tail is below one per cent, and a step stays a closed unit of work)
+            runners[mode](per_step, stamps, rows)
+            bounds.append(time.perf_counter())
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t_start
-        if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        elapsed = agree(time.perf_counter() - t_start)
         fam = {}
         for f in ("seeds", "compact", "annotate", "sort", "replay", "probe", "exchange"):   # HIP events on the launch streams, all contexts
-            tot = [0.0, 0]
-            for wc in all_ctx:
-                ms, nl = wc.kernel_stats(f)
-                tot[0] += ms
-                tot[1] += nl
-            fam[f] = tuple(tot)
-        for wc in all_ctx:
-            wc.profile(False)
-        return elapsed, rows, fam
+            fam[f] = profiled[0].kernel_stats(f) if not args.no_kernel_timers else (0.0, 0)
+        for o in profiled:
+            o.profile(False)
+        return elapsed, list(np.diff(bounds)), list(np.diff([t_start] + stamps)), rows, fam
 
-    elapsed, rows, fam = timed(args.steps, depth)
-    one_at_a_time = None
-    if depth > 1 and not args.no_sequential_leg:     # the same steps one at a time: step latency, kernels measured alone on the GPU
-        e1, r1, f1 = timed(min(args.steps, 8), 1)
-        one_at_a_time = (e1 / min(args.steps, 8), r1, f1)
+    for _ in range(args.warmup):
+        runners[mode](sps)
+    elapsed, step_s, gaps, rows, fam = timed(mode, args.steps, sps)
+    second = None
+    if not args.no_second_leg:               # the same samples the other way, ~0.6 s of them
+        n2 = max(spb, int(0.6 / max(cal.get(other + "_ms_per_sample", 1.5) * 1e-3, 1e-6) / spb) * spb)
+        steps2 = max(1, min(args.steps, 4))
+        per2 = max(spb, n2 // steps2 // spb * spb)
+        second = (other, per2) + timed(other, steps2, per2)
 
-    finish_step(submit_step(), "final")   # untimed: seed occurrences for the roofline's algorithmic bytes, results for --verify
-    t_sketch = float(np.mean([r[0] for r in rows])) / min(n_workers, spg * depth)   # busy time of the sketch workers per step
-    t_profile = float(np.mean([r[1] for r in rows]))
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * spg * n_bases / 1e9 / (elapsed / args.steps)              # whole-job read Gbp/s through both stages
-    comparisons = world * spg * n_total                                       # every sample vs every genome of the DB
-    parallelism = (f"{spg} sample(s) per GPU per step x {world} GPU(s); database " +
-                   (f"sharded by k-mer range over {world} GPUs (per step: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
+    last = {}
+    run_sequential(spb, keep_last=last)      # untimed: seed occurrences for the roofline's algorithmic bytes, results for --verify
+
+    def leg_summary(mode_name, per_step, n_steps, elapsed_s, step_list, gap_list, rws, fm):
+        n_samples = per_step * n_steps
+        s_per_sample = elapsed_s / n_samples
+        workers_busy = n_workers if mode_name == "pipelined" else 1
+        d = {"mode": mode_name, "samples_per_step": per_step, "steps": n_steps, "timed_region_s": round(elapsed_s, 4),
+             "ms_per_step": round(elapsed_s / n_steps * 1e3, 3), "ms_per_sample": round(s_per_sample * 1e3, 4),
+             "value": round(world * n_bases / 1e9 / s_per_sample, 3),
+             "step_ms": {"p50": round(pct(step_list, 0.5) * 1e3, 3), "p90": round(pct(step_list, 0.9) * 1e3, 3), "max": round(max(step_list) * 1e3, 3)},
+             # time between consecutive sample completions on rank 0 (a probe batch completes together: zeros inside a batch)
+             "sample_interval_ms": {"p50": round(pct(gap_list, 0.5) * 1e3, 4), "p90": round(pct(gap_list, 0.9) * 1e3, 4),
+                                    "p99": round(pct(gap_list, 0.99) * 1e3, 4), "max": round(max(gap_list) * 1e3, 4)},
+             # stage times as the sample saw them (wall clock inside its stage; pipelined: stages of different samples overlap)
+             "sketch_ms": round(float(np.mean([r[0] for r in rws])) * 1e3, 3), "profile_ms": round(float(np.mean([r[1] for r in rws])) * 1e3, 3),
+             "probe_batch_mean": round(float(np.mean([r[5] for r in rws])), 2),
+             "kernel_ms": {f: (round(v[0] / max(1, v[1]), 4), int(v[1])) for f, v in fm.items() if v[1]}}
+        d["sketch_gbp_per_s"] = round(world * n_bases / 1e9 / max(d["sketch_ms"] * 1e-3 / workers_busy, 1e-9), 3)
+        d["genome_comparisons_per_s"] = round(world * n_total / max(d["profile_ms"] * 1e-3, 1e-9), 1)
+        return d
+
+    main_leg = leg_summary(mode, sps, args.steps, elapsed, step_s, gaps, rows, fam)
+    comparisons = world * n_total                                             # every sample vs every genome of the DB
+    parallelism = (f"{world} GPU(s), {mode}: " + (f"{n_workers} sketch worker contexts + 1 profile context per GPU, {depth} samples in flight, <= {max(spb, 8) if comm is None else spb} tables per probe launch" if mode == "pipelined" else f"one context per GPU, {spb} table(s) per probe launch") + "; database " +
+                   (f"sharded by k-mer range over {world} GPUs (per probe batch: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
                     f"{comm_kind})"
                     if comm is not None else ("replicated on every GPU (no data-path collective)" if world > 1 else "on the one GPU")))
     out = {
         "metric": "read Gbp/s sketched + genome-comparisons/s profiled, 1 Gbp vs GTDB-R220",
-        "value": round(value, 3), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": main_leg["value"], "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": spg, "sketch_workers_per_gpu": n_workers, "steps_in_flight": depth, **({"fallbacks": fallbacks} if fallbacks else {}), "reads_per_sample_gbp": round(n_bases / 1e9, 4),
+        "config": {"workload": DESCR[wl], "samples_per_gpu_per_step": sps, "samples_per_probe_batch": spb, "mode": mode,
+                   "sketch_workers_per_gpu": n_workers if mode == "pipelined" else 0, "samples_in_flight": depth if mode == "pipelined" else 1,
+                   **({"fallbacks": fallbacks} if fallbacks else {}), "reads_per_sample_gbp": round(n_bases / 1e9, 4),
                    "distinct_read_sets_rotated": n_sets, "genomes": n_total, "db_kmers_per_shard": dbstats["shard_kmers"],
                    "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)",
                    "seed_mode": "avx2_compat", "parallelism": parallelism,
                    "inputs": "reads + database resident in HBM before the timed region",
                    "rng": "torch (Philox) generators on the device, seed 20250711 + 1000003*(rank+1) + 7919*set — not the splitmix64 streams of SURVEY 8d"},
-        "sketch_gbp_per_s": round(world * spg * n_bases / 1e9 / t_sketch, 3),
-        "genome_comparisons_per_s": round(comparisons / t_profile, 1),
-        "sketch_ms": round(t_sketch * 1e3, 3), "profile_ms": round(t_profile * 1e3, 3),
-        "sample_table_entries": int(np.mean([np.mean(r[2]) for r in rows])), "dup_removed": int(np.mean([np.mean(r[3]) for r in rows])),
-        "kernel_ms": {f: (round(v[0] / max(1, v[1]), 4), int(v[1])) for f, v in fam.items() if v[1]},
+        "mode": mode, "value_is": f"{mode}: all bases of the {args.steps} timed steps / their wall time (max over ranks)",
+        "timed_region_s": main_leg["timed_region_s"], "ms_per_sample": main_leg["ms_per_sample"],
+        "step_ms": main_leg["step_ms"], "sample_interval_ms": main_leg["sample_interval_ms"],
+        "calibration": cal,
+        "sketch_gbp_per_s": main_leg["sketch_gbp_per_s"], "genome_comparisons_per_s": main_leg["genome_comparisons_per_s"],
+        "genome_comparisons_per_s_whole_step": round(comparisons / (elapsed / (sps * args.steps)), 1),
+        "sketch_ms": main_leg["sketch_ms"], "profile_ms": main_leg["profile_ms"], "probe_batch_mean": main_leg["probe_batch_mean"],
+        "sample_table_entries": int(np.mean([r[2] for r in rows])), "dup_removed": int(np.mean([r[3] for r in rows])),
+        "kernel_ms": main_leg["kernel_ms"],
         "setup": dbstats,
     }
+    legs = {mode: (fam, rows)}
+    if second is not None:
+        o_mode, per2, e2, st2, g2, r2, f2 = second
+        steps2 = len(st2)
+        leg2 = leg_summary(o_mode, per2, steps2, e2, st2, g2, r2, f2)
+        out["one_step_at_a_time" if o_mode == "sequential" else "pipelined"] = leg2
+        legs[o_mode] = (f2, r2)
+    out["one_step_at_a_time" if mode == "sequential" else "pipelined"] = {k_: main_leg[k_] for k_ in main_leg if k_ not in ("kernel_ms",)} | {"same_as": "the top-level fields"}
+
     # roofline of the dominant kernel (seeds): algorithmic bytes per launch = 1 B/base + 8 B/record offset + 8 B/seed
     # occurrence out (SURVEY §8d), over the HIP-event duration of that launch.
+    fp = csrc_fingerprint()
+    meta = {}
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", "seeds_traffic.json")))
+    except Exception:
+        pass
+    meta_ok = meta.get("csrc_sha") == fp     # PMC figures measured on exactly these kernel sources
+    tsrc = f"profiles/seeds_traffic.json@{meta.get('head', '?')[:12]} (rocprofv3 --pmc passes of tools/r03_profile.sh; csrc {meta.get('csrc_sha', '?')})"
     seeds_ms, seeds_launches = fam["seeds"]
     if seeds_launches:
         n_rec = float(np.mean([r["n_records"] for r in read_sets]))
         n_occ = float(np.mean(last["occ"]))
-        launches_per_sample = max(1, round(seeds_launches / (args.steps * spg)))
+        launches_per_sample = max(1, round(seeds_launches / (args.steps * sps)))
         alg_bytes = (n_bases + 8 * n_rec + 8 * n_occ) / launches_per_sample   # a sample > 2^32 bases is pushed in batches
         avg_ms = seeds_ms / seeds_launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "seeds_traffic.json")
-        if os.path.exists(tf) and wl in ("c2", "c3", "c4"):   # measured on this read set with rocprofv3 --pmc (profiles/)
-            try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        meta = {}
-        try:
-            meta = json.load(open(os.path.join(ROOT, "profiles", "seeds_traffic.json")))
-        except Exception:
-            pass
-        ipk = meta.get("valu_per_kmer_position_kernel", 38) if long_mode else meta.get("valu_per_kmer", 44)
+        traffic = meta.get("hbm_bytes_per_launch") if (meta_ok and wl in ("c2", "c3", "c4")) else None
+        ipk = (meta.get("valu_per_kmer_position_kernel") if long_mode else meta.get("valu_per_kmer")) if meta_ok else None
         hashed = (n_bases if long_mode else max(0.0, n_bases - n_rec * (k - 1))) / launches_per_sample
         out["roofline"] = {"bound": "hbm", "kernel": "seeds_slots_kernel<31,1>" if long_mode else "reads_kernel<31,1>", "achieved": round(achieved, 1),
                            "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
-                           "note": f"integer-VALU issue bound: {ipk} VALU wave-instructions per hashed k-mer (SQ counters in profiles/)" +
-                                   (f"; {depth} steps in flight on {n_workers} sketch streams + the profile stream: launch durations include time shared with the other streams' kernels (alone on the GPU: one_step_at_a_time)" if depth > 1 else ""),
-                           # secondary ceiling: VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s, i.e. 4 cycles per
-                           # wave-instruction; plain VOP2 integer ops issue faster than that on this chip (profiles/r02_valu_rates.txt),
-                           # so a launch alone on the GPU can come out a few per cent above 1.0
-                           "valu_ceiling": {"instr_per_kmer": ipk, "kmers_per_launch": int(hashed),
-                                            "min_ms": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3, 4),
-                                            "frac": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3 / avg_ms, 3)}}
-    # roofline of the profile half: probe_kernel, one launch per step over all tables it probes.  Inverted-index formulation
+                           "traffic_source": tsrc if traffic is not None else f"none: no PMC figures for these kernel sources (csrc {fp}; profiles/seeds_traffic.json holds {meta.get('csrc_sha', 'nothing')})",
+                           "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4), "launches": int(seeds_launches),
+                           "note": "integer-VALU issue bound (SQ counters in profiles/)" +
+                                   (f"; pipelined: launch durations include time shared with the other streams' kernels (alone on the GPU: alone_on_gpu)" if mode == "pipelined" else "")}
+        if ipk:
+            # secondary ceiling (SURVEY 8d): VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s, i.e. 4 cycles per
+            # wave-instruction; plain VOP2 integer ops issue faster than that on this chip (profiles/r02_valu_rates.txt),
+            # so a launch alone on the GPU can come out a few per cent above 1.0
+            out["roofline"]["valu_ceiling"] = {"instr_per_kmer": ipk, "kmers_per_launch": int(hashed),
+                                               "min_ms": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3, 4),
+                                               "frac": round(ipk * hashed / (256 * 4 * 16 * 2.4e9) * 1e3 / avg_ms, 3)}
+        if "sequential" in legs and legs["sequential"][0]["seeds"][1]:
+            f1 = legs["sequential"][0]
+            a1 = f1["seeds"][0] / f1["seeds"][1]
+            out["roofline"]["alone_on_gpu"] = {"avg_launch_ms": round(a1, 4), "achieved": round(alg_bytes / (a1 * 1e-3) / 1e9, 1),
+                                               "frac": round(alg_bytes / (a1 * 1e-3) / 1e9 / 8000.0, 4), "launches": int(f1["seeds"][1])}
+    # roofline of the profile half: probe_kernel, one launch per probe batch over all tables it probes.  Inverted-index formulation
     # (SURVEY 8d): B = N_s * (8 + 4 table in + 64 one index line per probe) + 8 * hits out.
     probe_ms, probe_launches = fam["probe"]
     if probe_launches:
-        probes = float(np.mean([np.sum(r[2]) for r in rows]))      # table entries of this rank's samples per step ...
-        hits = float(np.mean([r[4] for r in rows]))
-        # ... which, sharded, is also what this rank probes: 1/N of each of the N x spg tables of the step
-        alg = probes * (12 + 64) + 8 * hits
-        avg = probe_ms / probe_launches
-        ptraffic = None
-        try:       # FETCH_SIZE + WRITE_SIZE per probe of the C3 probe (rocprofv3 --pmc passes, profiles/r02_kernel_stats.md) x this launch's probes
-            per_probe = json.load(open(os.path.join(ROOT, "profiles", "seeds_traffic.json"))).get("probe_hbm_bytes_per_probe")
-            if per_probe and wl in ("c3", "c4", "c3r"):
-                ptraffic = int(per_probe * probes)
-        except Exception:
-            ptraffic = None
-        out["roofline_profile"] = {"bound": "hbm", "kernel": "probe_kernel", "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "peak": 8000.0,
-                                   "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / 8000.0, 4), "traffic": ptraffic,
-                                   "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg, 4),
-                                   "probes_per_launch": int(probes), "hits_per_launch": int(hits),
+        def probe_roof(fm, rws):
+            pms, pl = fm["probe"]
+            batch = len(rws) / pl                                      # tables per launch
+            probes = float(np.mean([r[2] for r in rws])) * batch
+            hits = float(np.mean([r[4] for r in rws])) * batch
+            alg = probes * (12 + 64) + 8 * hits
+            avg = pms / pl
+            return {"achieved": round(alg / (avg * 1e-3) / 1e9, 1), "frac": round(alg / (avg * 1e-3) / 1e9 / 8000.0, 4),
+                    "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg, 4), "launches": int(pl),
+                    "tables_per_launch": round(batch, 2), "probes_per_launch": int(probes), "hits_per_launch": int(hits)}
+        pr = probe_roof(fam, rows)
+        per_probe = meta.get("probe_hbm_bytes_per_probe") if (meta_ok and wl in ("c3", "c4", "c3r")) else None
+        out["roofline_profile"] = {"bound": "hbm", "kernel": "probe_kernel", "peak": 8000.0, "unit": "GB/s", **pr,
+                                   "traffic": int(per_probe * pr["probes_per_launch"]) if per_probe else None,
+                                   "traffic_source": tsrc if per_probe else "none: no PMC figures for these kernel sources",
                                    "note": "random 64 B line reads, latency-bound; one index line per probe is the access granule"}
-    if one_at_a_time is not None:
-        s1, r1, f1 = one_at_a_time
-        o1 = {"ms_per_step": round(s1 * 1e3, 3), "value": round(world * spg * n_bases / 1e9 / s1, 3),
-              "sketch_ms": round(float(np.mean([r[0] for r in r1])) / min(n_workers, spg) * 1e3, 3), "profile_ms": round(float(np.mean([r[1] for r in r1])) * 1e3, 3),
-              "kernel_ms": {f: (round(v[0] / max(1, v[1]), 4), int(v[1])) for f, v in f1.items() if v[1]}}
-        if "roofline" in out and f1["seeds"][1]:
-            a1 = f1["seeds"][0] / f1["seeds"][1]
-            o1["roofline_frac"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (a1 * 1e-3) / 1e9 / 8000.0, 4)
-            o1["valu_ceiling_frac"] = round(out["roofline"]["valu_ceiling"]["min_ms"] / a1, 3)
-            # the same launches with nothing else on the GPU (same run, HIP events of the one-step-at-a-time leg): the kernel's own speed
-            out["roofline"]["alone_on_gpu"] = {"avg_launch_ms": round(a1, 4), "achieved": round(out["roofline"]["algorithmic_bytes_per_launch"] / (a1 * 1e-3) / 1e9, 1),
-                                               "frac": o1["roofline_frac"], "launches": int(f1["seeds"][1])}
-        if "roofline_profile" in out and f1["probe"][1]:
-            p1 = f1["probe"][0] / f1["probe"][1]
-            o1["roofline_profile_frac"] = round(out["roofline_profile"]["algorithmic_bytes_per_launch"] / (p1 * 1e-3) / 1e9 / 8000.0, 4)
-            out["roofline_profile"]["alone_on_gpu"] = {"avg_launch_ms": round(p1, 4), "achieved": round(out["roofline_profile"]["algorithmic_bytes_per_launch"] / (p1 * 1e-3) / 1e9, 1),
-                                                       "frac": o1["roofline_profile_frac"], "launches": int(f1["probe"][1])}
-        out["one_step_at_a_time"] = o1
+        if "sequential" in legs and legs["sequential"][0]["probe"][1]:
+            out["roofline_profile"]["alone_on_gpu"] = probe_roof(*legs["sequential"])
     if not args.no_verify and last.get("res") is not None:
         try:
             G = n_total
@@ -596,8 +652,9 @@ def main():
             out["verify"] = verify_against_oracle(ctx, (cc[:G], off[:G + 1], covs), G, last["table"], verify_set, device)
         except Exception as e:
             out["verify"] = {"genomes_checked": 0, "mismatches": None, "error": str(e)}
-    for w, sk in last.get("sessions", []):
-        w.submit(lambda wctx, sk=sk: sk.close()).result()
+    for sk in last.get("sessions", []):
+        sk.close()
+    pipe_box[0].close()
     # ---- host-fed leg (untimed w.r.t. `value`): the same step with the reads starting in PAGE-LOCKED HOST memory, as ASCII and
     # as the packed 2-bit stream a feed would hand over (sylph_sketch_push_enc cuts the batch into chunks that travel on a copy
     # stream while the previous chunk is sketched): pinned host -> HBM -> sketch -> profile -> results on the host.
@@ -659,7 +716,7 @@ def main():
             out["cpu_baseline"] = {"value": round(n_bases / 1e9 / t_cpu, 4), "unit": "Gbp/s", "cores": cb["probe_cores"], "kind": "port",
                                    "sample": cb["sample"], "sketch_gbp_per_s": round(cb["sketch_gbp_per_s"], 4),
                                    "sketch_cores": 1, "genome_comparisons_per_s": round(cb["comparisons_per_s"], 1),
-                                   "note": "C++ restatement of the reference CPU path (oracle/); the reference sketches one sample on one thread and probes genomes on all threads; value = extrapolation to one whole step"}
+                                   "note": "C++ restatement of the reference CPU path (oracle/); the reference sketches one sample on one thread and probes genomes on all threads; value = extrapolation to one whole sample"}
         except Exception as e:  # the baseline leg must never sink the GPU measurement
             out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
     sys.stdout.flush()
@@ -675,10 +732,6 @@ def main():
     db.close()
     if comm is not None:
         comm.close()
-    for w in workers:
-        w.jobs.put(None)
-        w.join()
-        w.ctx.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -280,6 +280,69 @@ int sylph_db_contain_batch_sharded(sylph_db *db, sylph_comm *comm, const sylph_s
                                    double min_number_kmers, const uint32_t **contain_count, const uint64_t **cov_off,
                                    const void **covs, uint32_t *cov_width, uint64_t *out_n_covs);
 
+
+/* ---- a stream of samples through both stages (sketch -> profile), overlapped inside the library -------------------------- */
+
+/* The reference runs its samples on the rayon pool (sketch.rs:313,371 sketches files on parallel workers; contain.rs:267-289 walks
+ * sample chunks x genomes on all threads).  The GPU counterpart: `n_workers` sketch threads, each with a context (stream +
+ * memory pool) of its own, and one profile thread on the database's context, so that the small launch-bound kernels of one
+ * sample's dedup/count and profile stages run beside the (VALU-bound) seeding kernel of another and the result copies hide
+ * behind both.  The caller submits samples and takes their results in submission order; nothing observable depends on how the
+ * threads interleave.  A sample is given either as batches of records (what sylph_sketch_push_enc takes; the memory is
+ * borrowed until sylph_pipeline_next has returned the sample) or as a session the caller has been pushing into
+ * (sylph_pipeline_submit_session: the pipeline finishes it and owns it from then on).
+ * The profile thread probes the oldest sketched sample together with every consecutive sample that is ready by then, up to
+ * `max_batch` tables per launch.  With a sharded database (`comm` set; every rank runs a pipeline with the same max_batch and
+ * submits the same number of samples) a batch is always exactly the next max_batch samples — or, after sylph_pipeline_flush,
+ * what is left up to the flush point — so that all ranks enter the exchange of sylph_db_contain_batch_sharded together. */
+typedef struct sylph_pipeline sylph_pipeline;
+typedef struct sylph_read_batch {   /* the arguments of sylph_sketch_push_enc */
+    const uint8_t *bases;
+    const uint64_t *rec_off;
+    uint64_t n_records, n_bases;
+} sylph_read_batch;
+typedef struct sylph_pipeline_config {
+    uint32_t struct_size;     /* sizeof(sylph_pipeline_config) */
+    uint32_t n_workers;       /* sketch threads / contexts; 0 = default (2) */
+    uint32_t depth;           /* samples that may be outstanding (submitted, not yet returned by sylph_pipeline_next); 0 = n_workers + 2 */
+    uint32_t max_batch;       /* sample tables per probe launch at most (<= 64); 0 = default (8) */
+    uint32_t c, k;            /* sylph_sketch_begin's arguments for the samples submitted as batches */
+    int reads_mode, no_dedup, seed_mode;
+    int want_table;           /* also copy every sample's (k-mer, count) table to host memory (result.kmers / .counts) */
+    double min_number_kmers;  /* contain.rs:627 */
+    sylph_comm *comm;         /* NULL, or the communicator of a sharded database */
+} sylph_pipeline_config;
+typedef struct sylph_pipeline_result {
+    uint64_t tag;             /* the caller's tag of the sample */
+    int status;               /* SYLPH_OK, or the error code of the stage that failed for THIS sample (message in `error`) */
+    const char *error;
+    uint64_t n_table, dup_removed;                  /* what sylph_sketch_finish reports */
+    const uint64_t *dev_kmers; const uint32_t *dev_counts;   /* the table in HBM (e.g. for sylph_db_reassign_view) */
+    const uint64_t *kmers; const uint32_t *counts;           /* host copy, when want_table */
+    /* containment of the sample against every genome, as sylph_db_contain_view_packed returns it: contain_count[g];
+     * coverage values of genome g = covs[cov_off[g] .. cov_off[g + 1]) (ascending, cov_width bytes each); n_covs of them in total */
+    const uint32_t *contain_count; const uint64_t *cov_off; const void *covs; uint32_t cov_width; uint64_t n_covs;
+    uint32_t probe_batch;     /* tables in the probe launch this sample was part of */
+    double t_submit, t_sketch_begin, t_sketch_end, t_profile_begin, t_done;   /* CLOCK_MONOTONIC seconds */
+} sylph_pipeline_result;
+int sylph_pipeline_create(sylph_db *db, const sylph_pipeline_config *cfg, sylph_pipeline **out);
+/* SYLPH_ERR_STATE when `depth` samples are outstanding already (take one with sylph_pipeline_next first). */
+int sylph_pipeline_submit(sylph_pipeline *p, const sylph_read_batch *batches, uint32_t n_batches, int mem, int enc, uint64_t tag);
+int sylph_pipeline_submit_session(sylph_pipeline *p, sylph_sketch *sk, uint64_t tag);
+/* Sharded pipelines only need it: everything submitted so far may be probed in a batch smaller than max_batch. */
+int sylph_pipeline_flush(sylph_pipeline *p);
+/* Blocks until the OLDEST outstanding sample is done.  Every pointer of *out stays valid until the next sylph_pipeline_next /
+ * sylph_pipeline_destroy on this pipeline (the sample's session and its share of the result block are released then). */
+int sylph_pipeline_next(sylph_pipeline *p, sylph_pipeline_result *out);
+uint32_t sylph_pipeline_outstanding(sylph_pipeline *p);
+/* sylph_ctx_set_option on every worker context; sylph_ctx_profile / sylph_ctx_kernel_stats summed over the workers' and the
+ * database's contexts. */
+int sylph_pipeline_set_option(sylph_pipeline *p, const char *key, const char *value);
+int sylph_pipeline_profile(sylph_pipeline *p, int enable);
+int sylph_pipeline_kernel_stats(sylph_pipeline *p, const char *family, double *total_ms, uint64_t *launches);
+/* Finishes what is outstanding, stops the threads, releases the contexts. */
+void sylph_pipeline_destroy(sylph_pipeline *p);
+
 #ifdef __cplusplus
 }
 #endif

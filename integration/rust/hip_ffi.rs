@@ -11,6 +11,19 @@ use std::os::raw::{c_char, c_int, c_void};
     pub all_to_all: extern "C" fn(user: *mut c_void, send: *const c_void, send_off: *const u64, recv: *mut c_void,
                                   recv_off: *const u64, stream: *mut c_void) -> c_int,
 }
+#[repr(C)] pub struct SylphPipeline { _p: [u8; 0] }
+#[repr(C)] pub struct SylphReadBatch { pub bases: *const u8, pub rec_off: *const u64, pub n_records: u64, pub n_bases: u64 }
+#[repr(C)] pub struct SylphPipelineConfig {
+    pub struct_size: u32, pub n_workers: u32, pub depth: u32, pub max_batch: u32, pub c: u32, pub k: u32,
+    pub reads_mode: c_int, pub no_dedup: c_int, pub seed_mode: c_int, pub want_table: c_int,
+    pub min_number_kmers: f64, pub comm: *mut SylphComm,
+}
+#[repr(C)] pub struct SylphPipelineResult {
+    pub tag: u64, pub status: c_int, pub error: *const c_char, pub n_table: u64, pub dup_removed: u64,
+    pub dev_kmers: *const u64, pub dev_counts: *const u32, pub kmers: *const u64, pub counts: *const u32,
+    pub contain_count: *const u32, pub cov_off: *const u64, pub covs: *const c_void, pub cov_width: u32, pub n_covs: u64,
+    pub probe_batch: u32, pub t_submit: f64, pub t_sketch_begin: f64, pub t_sketch_end: f64, pub t_profile_begin: f64, pub t_done: f64,
+}
 pub const ENC_ASCII: c_int = 0; pub const ENC_2BIT: c_int = 1;
 pub const SEED_AVX2_COMPAT: c_int = 1;   // what extract_markers does on every AVX2 host (sketch.rs:53-63)
 pub const READS_SINGLE: c_int = 0; pub const READS_PAIRED: c_int = 1;
@@ -103,4 +116,17 @@ extern "C" {
                                           cov_off: *mut *const u64, covs: *mut *const c_void, cov_width: *mut u32,
                                           out_n_covs: *mut u64) -> c_int;
     pub fn sylph_db_destroy(db: *mut SylphDb);
+    // ---- round 3: the sample loop of `sylph profile` (contain.rs:267-289 over sketch.rs:313,371) as a pipeline inside the
+    // library: sketch workers + one profile thread; submit samples, take results in submission order
+    pub fn sylph_pipeline_create(db: *mut SylphDb, cfg: *const SylphPipelineConfig, out: *mut *mut SylphPipeline) -> c_int;
+    pub fn sylph_pipeline_submit(p: *mut SylphPipeline, batches: *const SylphReadBatch, n_batches: u32, mem: c_int, enc: c_int,
+                                 tag: u64) -> c_int;
+    pub fn sylph_pipeline_submit_session(p: *mut SylphPipeline, sk: *mut SylphSketch, tag: u64) -> c_int;
+    pub fn sylph_pipeline_flush(p: *mut SylphPipeline) -> c_int;
+    pub fn sylph_pipeline_next(p: *mut SylphPipeline, out: *mut SylphPipelineResult) -> c_int;
+    pub fn sylph_pipeline_outstanding(p: *mut SylphPipeline) -> u32;
+    pub fn sylph_pipeline_set_option(p: *mut SylphPipeline, key: *const c_char, value: *const c_char) -> c_int;
+    pub fn sylph_pipeline_profile(p: *mut SylphPipeline, enable: c_int) -> c_int;
+    pub fn sylph_pipeline_kernel_stats(p: *mut SylphPipeline, family: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn sylph_pipeline_destroy(p: *mut SylphPipeline);
 }

@@ -29,7 +29,10 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_sketch_finish", "sylph_sketch_finish_device", "sylph_sketch_destroy", "sylph_db_upload",
            "sylph_db_n_genomes", "sylph_db_n_kmers", "sylph_db_contain", "sylph_db_contain_view", "sylph_db_contain_view_packed", "sylph_db_attach_tracked", "sylph_db_reassign_view", "sylph_db_destroy",
            "sylph_sketch_push_enc", "sylph_pack_2bit", "sylph_db_index_bytes", "sylph_db_contain_batch", "sylph_shard_bounds", "sylph_db_upload_shard", "sylph_comm_rccl_unique_id",
-           "sylph_comm_create_rccl", "sylph_comm_create", "sylph_comm_destroy", "sylph_db_contain_batch_sharded"]
+           "sylph_comm_create_rccl", "sylph_comm_create", "sylph_comm_destroy", "sylph_db_contain_batch_sharded",
+           "sylph_pipeline_create", "sylph_pipeline_submit", "sylph_pipeline_submit_session", "sylph_pipeline_flush", "sylph_pipeline_next",
+           "sylph_pipeline_outstanding", "sylph_pipeline_set_option", "sylph_pipeline_profile", "sylph_pipeline_kernel_stats",
+           "sylph_pipeline_destroy"]
 
 
 def load():
@@ -93,6 +96,18 @@ def load():
     L.sylph_comm_destroy.argtypes = [vp]
     L.sylph_comm_destroy.restype = None
     L.sylph_db_contain_batch_sharded.argtypes = [vp, vp, vp, u32, i32, dbl, P(vp), P(vp), P(vp), P(u32), P(u64)]
+    L.sylph_pipeline_create.argtypes = [vp, vp, P(vp)]
+    L.sylph_pipeline_submit.argtypes = [vp, vp, u32, i32, i32, u64]
+    L.sylph_pipeline_submit_session.argtypes = [vp, vp, u64]
+    L.sylph_pipeline_flush.argtypes = [vp]
+    L.sylph_pipeline_next.argtypes = [vp, vp]
+    L.sylph_pipeline_outstanding.argtypes = [vp]
+    L.sylph_pipeline_outstanding.restype = u32
+    L.sylph_pipeline_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.sylph_pipeline_profile.argtypes = [vp, i32]
+    L.sylph_pipeline_kernel_stats.argtypes = [vp, C.c_char_p, P(dbl), P(u64)]
+    L.sylph_pipeline_destroy.argtypes = [vp]
+    L.sylph_pipeline_destroy.restype = None
     _LIB = L
     return L
 
@@ -485,6 +500,116 @@ class Database:
     def close(self):
         if self._h:
             load().sylph_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ReadBatch(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("rec_off", C.c_void_p), ("n_records", C.c_uint64), ("n_bases", C.c_uint64)]
+
+
+class PipelineConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_workers", C.c_uint32), ("depth", C.c_uint32), ("max_batch", C.c_uint32),
+                ("c", C.c_uint32), ("k", C.c_uint32), ("reads_mode", C.c_int), ("no_dedup", C.c_int), ("seed_mode", C.c_int),
+                ("want_table", C.c_int), ("min_number_kmers", C.c_double), ("comm", C.c_void_p)]
+
+
+class PipelineResult(C.Structure):
+    _fields_ = [("tag", C.c_uint64), ("status", C.c_int), ("error", C.c_char_p), ("n_table", C.c_uint64), ("dup_removed", C.c_uint64),
+                ("dev_kmers", C.c_void_p), ("dev_counts", C.c_void_p), ("kmers", C.c_void_p), ("counts", C.c_void_p),
+                ("contain_count", C.c_void_p), ("cov_off", C.c_void_p), ("covs", C.c_void_p), ("cov_width", C.c_uint32),
+                ("n_covs", C.c_uint64), ("probe_batch", C.c_uint32), ("t_submit", C.c_double), ("t_sketch_begin", C.c_double),
+                ("t_sketch_end", C.c_double), ("t_profile_begin", C.c_double), ("t_done", C.c_double)]
+
+
+class Pipeline:
+    """sylph_pipeline: samples in (device / host batches, or sessions), results out in submission order; the overlap of the
+    sketch and profile stages of different samples happens on C++ threads inside the library."""
+
+    def __init__(self, db, c=200, k=31, paired=True, no_dedup=False, seed_mode=SEED_AVX2_COMPAT, n_workers=0, depth=0, max_batch=0,
+                 want_table=False, min_number_kmers=50.0, comm=None):
+        self.db = db
+        self._h = C.c_void_p()
+        cfg = PipelineConfig(C.sizeof(PipelineConfig), n_workers, depth, max_batch, c, k, READS_PAIRED if paired else READS_SINGLE,
+                             int(no_dedup), seed_mode, int(want_table), float(min_number_kmers), comm._h if comm is not None else None)
+        _check(load().sylph_pipeline_create(db._h, C.byref(cfg), C.byref(self._h)))
+        self._res = PipelineResult()
+
+    def submit_device(self, batches, tag=0, enc=ENC_ASCII, mem=MEM_DEVICE):
+        """batches: list of (bases_ptr, rec_off_ptr, n_records, n_bases) integer addresses.  False when `depth` samples are
+        outstanding already."""
+        arr = (ReadBatch * max(1, len(batches)))()
+        for i, b in enumerate(batches):
+            arr[i].bases, arr[i].rec_off, arr[i].n_records, arr[i].n_bases = b
+        rc = load().sylph_pipeline_submit(self._h, arr, len(batches), mem, enc, tag)
+        if rc == -4:
+            return False
+        _check(rc)
+        return True
+
+    def submit_session(self, sketcher, tag=0):
+        """Hands a ReadSketcher's session over (the pipeline finishes and destroys it)."""
+        rc = load().sylph_pipeline_submit_session(self._h, sketcher._h, tag)
+        if rc == -4:
+            return False
+        _check(rc)
+        sketcher._h = C.c_void_p()
+        return True
+
+    def flush(self):
+        _check(load().sylph_pipeline_flush(self._h))
+
+    def next(self, views=True):
+        """-> dict of the oldest outstanding sample (numpy views valid until the next call)."""
+        r = self._res
+        _check(load().sylph_pipeline_next(self._h, C.byref(r)))
+        if r.status != 0:
+            raise SylphHipError(r.status, (r.error or b"").decode("utf-8", "replace"))
+        out = dict(tag=int(r.tag), n_table=int(r.n_table), dup_removed=int(r.dup_removed), dev_kmers=r.dev_kmers or 0,
+                   dev_counts=r.dev_counts or 0, n_covs=int(r.n_covs), probe_batch=int(r.probe_batch),
+                   t=(r.t_submit, r.t_sketch_begin, r.t_sketch_end, r.t_profile_begin, r.t_done))
+        if views:
+            G = self.db.n_genomes
+
+            def view(ptr, count, ctype, dtype):
+                if count == 0 or not ptr:
+                    return np.zeros(0, dtype=dtype)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).view(dtype)
+            ct, dt = {1: (C.c_uint8, np.uint8), 2: (C.c_uint16, np.uint16), 4: (C.c_uint32, np.uint32)}[int(r.cov_width)]
+            off = view(r.cov_off, G + 1, C.c_uint64, np.uint64)
+            out["contain_count"] = view(r.contain_count, G, C.c_uint32, np.uint32)
+            out["cov_off"] = off
+            # covs is the base of the whole batch's values; cov_off indexes it
+            hi = int(off[G]) if G else 0
+            out["covs"] = view(r.covs, hi, ct, dt)
+            if r.kmers:
+                out["kmers"] = view(r.kmers, int(r.n_table), C.c_uint64, np.uint64)
+                out["counts"] = view(r.counts, int(r.n_table), C.c_uint32, np.uint32)
+        return out
+
+    @property
+    def outstanding(self):
+        return int(load().sylph_pipeline_outstanding(self._h))
+
+    def set_option(self, key, value):
+        _check(load().sylph_pipeline_set_option(self._h, key.encode(), value.encode()))
+
+    def profile(self, enable=True):
+        _check(load().sylph_pipeline_profile(self._h, int(enable)))
+
+    def kernel_stats(self, family):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _check(load().sylph_pipeline_kernel_stats(self._h, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            load().sylph_pipeline_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -644,7 +644,7 @@ uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_numb
 
 // cov_width: nullptr = coverage values as u32; else in/out — the values are stored with the narrowest of 1, 2 or 4 bytes
 // that holds the batch's largest count (7.4 MB -> 1.9 MB over PCIe per sample at GTDB scale) and the width is returned.
-void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost) {
+void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost, HostBlock* dst) {
     sylph_ctx* ctx = db->ctx;
     const uint64_t G = db->n_genomes;
     SY_REQUIRE(n_rows < (1ull << 32) - 1, "too many result rows");
@@ -682,16 +682,11 @@ void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_r
                            d_cov_off, d_ccount);
     }
     SY_HIP(hipGetLastError());
-    // straight into pinned host memory owned by the db (no staging copy, nothing pageable registered with HIP)
-    const size_t need = lay.end + 64;
-    if (need > db->h_res_cap) {
-        if (db->h_res) SY_HIP(hipHostFree(db->h_res));
-        db->h_res = nullptr;
-        db->h_res_cap = 0;
-        SY_HIP(hipHostMalloc(&db->h_res, need + need / 2, hipHostMallocDefault));
-        db->h_res_cap = need + need / 2;
-    }
-    char* h = (char*)db->h_res;
+    // straight into pinned host memory (the db's own block or the caller's; no staging copy, nothing pageable registered with HIP)
+    if (!dst) dst = &db->h_block;
+    dst->ensure(lay.end + 64);
+    dst->lay = lay;
+    char* h = (char*)dst->p;
     SY_HIP(hipMemcpyAsync(h, d_res, lay.covs + (size_t)n_hits * width, hipMemcpyDeviceToHost, ctx->stream));   // one copy
     if (with_lost && G) SY_HIP(hipMemcpyAsync(h + lay.lost, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (cov_width) *cov_width = width;
@@ -858,6 +853,45 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
     return n_hits;
 }
 
+uint32_t sylph::contain_batch_impl(sylph_db* db, const sylph_sample_ref* samples, uint32_t n_samples, int mem, double min_number_kmers,
+                                   uint32_t* cov_width, HostBlock* dst) {
+    SY_REQUIRE(db && cov_width, "null argument");
+    SY_REQUIRE(n_samples == 0 || samples, "null samples");
+    SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
+    SY_REQUIRE(db->world == 1, "this database is one shard of %u: use sylph_db_contain_batch_sharded", db->world);
+    sylph_ctx* ctx = db->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    std::vector<SampleRef> refs(n_samples);
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < n_samples; s++) {
+        SY_REQUIRE(samples[s].n == 0 || (samples[s].kmers && samples[s].counts), "null sample %u", s);
+        total += samples[s].n;
+    }
+    if (mem == SYLPH_MEM_HOST && total) {   // stage the tables back to back
+        db->q_kmers.reserve(total * 8);
+        db->q_counts.reserve(total * 4);
+        uint64_t o = 0;
+        for (uint32_t s = 0; s < n_samples; s++) {
+            const uint64_t n = samples[s].n;
+            if (n) {
+                ctx->h2d(db->q_kmers.as<uint64_t>() + o, samples[s].kmers, n * 8);
+                ctx->h2d(db->q_counts.as<uint32_t>() + o, samples[s].counts, n * 4);
+            }
+            refs[s].k = db->q_kmers.as<uint64_t>() + o;
+            refs[s].c = db->q_counts.as<uint32_t>() + o;
+            refs[s].n = n;
+            o += n;
+        }
+    } else {
+        for (uint32_t s = 0; s < n_samples; s++) { refs[s].k = samples[s].kmers; refs[s].c = samples[s].counts; refs[s].n = samples[s].n; }
+    }
+    uint32_t max_count = 0, n_hits = 0;
+    if (n_samples) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
+    finish_hits(db, n_hits, max_count, (uint64_t)n_samples * db->n_genomes, cov_width, false, dst);
+    return n_hits;
+}
+
 extern "C" {
 
 int sylph_db_upload(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
@@ -914,7 +948,7 @@ int sylph_db_contain_view(sylph_db* db, const uint64_t* sample_kmers, const uint
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
         const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_res;
+        const char* h = (const char*)db->h_block.p;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
         *covs = (const uint32_t*)(h + lay.covs);
@@ -931,7 +965,7 @@ int sylph_db_contain_view_packed(sylph_db* db, const uint64_t* sample_kmers, con
         DeviceGuard dg(db->ctx->device);
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers, nullptr, cov_width);
         const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_res;
+        const char* h = (const char*)db->h_block.p;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
         *covs = h + lay.covs;
@@ -944,41 +978,9 @@ int sylph_db_contain_batch(sylph_db* db, const sylph_sample_ref* samples, uint32
                            uint64_t* out_n_covs) {
     return guarded([&] {
         SY_REQUIRE(db && contain_count && cov_off && covs && cov_width, "null argument");
-        SY_REQUIRE(n_samples == 0 || samples, "null samples");
-        SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
-        SY_REQUIRE(db->world == 1, "this database is one shard of %u: use sylph_db_contain_batch_sharded", db->world);
-        sylph_ctx* ctx = db->ctx;
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        DeviceGuard dg(ctx->device);
-        std::vector<SampleRef> refs(n_samples);
-        uint64_t total = 0;
-        for (uint32_t s = 0; s < n_samples; s++) {
-            SY_REQUIRE(samples[s].n == 0 || (samples[s].kmers && samples[s].counts), "null sample %u", s);
-            total += samples[s].n;
-        }
-        if (mem == SYLPH_MEM_HOST && total) {   // stage the tables back to back
-            db->q_kmers.reserve(total * 8);
-            db->q_counts.reserve(total * 4);
-            uint64_t o = 0;
-            for (uint32_t s = 0; s < n_samples; s++) {
-                const uint64_t n = samples[s].n;
-                if (n) {
-                    ctx->h2d(db->q_kmers.as<uint64_t>() + o, samples[s].kmers, n * 8);
-                    ctx->h2d(db->q_counts.as<uint32_t>() + o, samples[s].counts, n * 4);
-                }
-                refs[s].k = db->q_kmers.as<uint64_t>() + o;
-                refs[s].c = db->q_counts.as<uint32_t>() + o;
-                refs[s].n = n;
-                o += n;
-            }
-        } else {
-            for (uint32_t s = 0; s < n_samples; s++) { refs[s].k = samples[s].kmers; refs[s].c = samples[s].counts; refs[s].n = samples[s].n; }
-        }
-        uint32_t max_count = 0, n_hits = 0;
-        if (n_samples) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
-        finish_hits(db, n_hits, max_count, (uint64_t)n_samples * db->n_genomes, cov_width, false);
+        const uint32_t n_hits = contain_batch_impl(db, samples, n_samples, mem, min_number_kmers, cov_width, nullptr);
         const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_res;
+        const char* h = (const char*)db->h_block.p;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
         *covs = h + lay.covs;
@@ -997,7 +999,7 @@ int sylph_db_reassign_view(sylph_db* db, const uint64_t* sample_kmers, const uin
         ReassignArgs re{passing_gids, passing_ani, n_passing};
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, 0.0, &re);
         const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_res;
+        const char* h = (const char*)db->h_block.p;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
         *covs = (const uint32_t*)(h + lay.covs);
@@ -1015,7 +1017,7 @@ int sylph_db_contain(sylph_db* db, const uint64_t* sample_kmers, const uint32_t*
         const uint32_t n_hits = contain_impl(db, sample_kmers, sample_counts, n, mem, min_number_kmers);
         const uint64_t G = db->n_genomes;
         const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_res;
+        const char* h = (const char*)db->h_block.p;
         uint32_t* hcov = (uint32_t*)malloc(std::max<size_t>(1, n_hits) * 4);
         if (!hcov) throw std::bad_alloc();
         memcpy(cov_off, h, (G + 1) * 8);

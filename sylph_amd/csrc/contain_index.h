@@ -96,6 +96,25 @@ struct ResultLayout {
         : ccount((R + 1) * 8), covs(ccount + R * 4), lost((covs + n_hits * width + 7) & ~(size_t)7), end(lost + lost_entries * 4) {}
 };
 
+// A block of page-locked host memory that results are copied into (grow-only).
+struct HostBlock {
+    void* p = nullptr;
+    size_t cap = 0;
+    ResultLayout lay;            // layout of the result block it holds
+    HostBlock() = default;
+    HostBlock(const HostBlock&) = delete;
+    HostBlock& operator=(const HostBlock&) = delete;
+    ~HostBlock() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t need) {
+        if (need <= cap) return;
+        if (p) SY_HIP(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        SY_HIP(hipHostMalloc(&p, need + need / 2, hipHostMallocDefault));
+        cap = need + need / 2;
+    }
+};
+
 void build_line_index(sylph_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d_gid, uint64_t n, uint64_t n_genomes, uint64_t kmer_lo,
                       uint64_t kmer_hi, LineIndex& ix);
 
@@ -117,9 +136,7 @@ struct sylph_db {
     sylph::DevBuf x_send, x_recv, x_meta;    // shard exchange buffers (shard.hip)
     sylph::ResultLayout lay;                 // layout of the last result
     uint64_t last_rows = 0;
-    void* h_res = nullptr;                   // pinned host results
-    size_t h_res_cap = 0;
-    ~sylph_db() { if (h_res) (void)hipHostFree(h_res); }
+    sylph::HostBlock h_block;                // pinned host results of the plain entry points (the pipeline brings its own blocks)
     explicit sylph_db(sylph_ctx* cx)
         : ctx(cx), kept(cx), tracked(cx), glen(cx), rank_of(cx), ani(cx), lost(cx), q_kmers(cx), q_counts(cx), q_refs(cx), hits(cx),
           hits_sorted(cx), res(cx), counter(cx), x_send(cx), x_recv(cx), x_meta(cx) {}
@@ -130,6 +147,14 @@ namespace sylph {
 // kept index and leaves unsorted hits ((row << 32) | count, row = sample * n_genomes + genome) in db->hits.
 // Returns the number of hits; *max_count = largest count among them.
 uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint32_t* max_count);
-// Sorts n_hits hits of db->hits (rows < n_rows) and assembles + copies out the result block (db->h_res, db->lay).
-void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost);
+// Sorts n_hits hits of db->hits (rows < n_rows) and assembles + copies out the result block (layout db->lay) into `dst`
+// (nullptr: the database's own block).
+void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost,
+                 HostBlock* dst = nullptr);
+// The bodies of sylph_db_contain_batch / sylph_db_contain_batch_sharded (they take the context lock themselves); the result
+// block lands in `dst` (nullptr: the database's own).  Return the number of coverage values.
+uint32_t contain_batch_impl(sylph_db* db, const sylph_sample_ref* samples, uint32_t n_samples, int mem, double min_number_kmers,
+                            uint32_t* cov_width, HostBlock* dst);
+uint32_t contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
+                                    double min_number_kmers, uint32_t* cov_width, HostBlock* dst);
 }  // namespace sylph

@@ -1,0 +1,444 @@
+// pipeline.hip — a stream of samples through both stages, overlapped inside the library.
+//
+// The reference runs its samples on the rayon pool: sketch.rs:313,371 sketches files on parallel workers, contain.rs:267-289
+// walks sample chunks x genomes on all threads.  On the GPU the same overlap has to come from several HIP streams: the seeding
+// kernel is VALU-bound and leaves HBM idle, the dedup/count and profile stages are strings of small memory- or latency-bound
+// dispatches — with the samples of several steps in flight the small kernels of one sample run beside the seeding kernel of
+// another, and result copies and host-side assembly disappear behind them.  Rounds 1-2 got that overlap from Python threads in
+// bench.py; this file moves it behind the C ABI so that a Rust (or any) host gets it with three calls:
+//
+//   sylph_pipeline_submit*()   hand over a sample (batches of records, or a session the caller has been pushing into)
+//   sylph_pipeline_next()      the oldest outstanding sample's results: table size, containment counts, coverage vectors
+//
+// Inside: `n_workers` sketch threads, each with a context of its own (stream + memory pool), take samples in submission
+// order (begin -> push -> finish_device); ONE profile thread owns the database's context, waits for the oldest sketched sample
+// and probes it TOGETHER with every consecutive sample that is ready by then (up to `max_batch` tables per launch: one sample
+// per launch leaves the probe at 22 % of the HBM roofline, eight reach 30 %), into a pinned result block of the pipeline.
+// Results come back in submission order, so nothing the caller sees depends on the interleaving of the threads.
+// With a sharded database (cfg.comm) the batches must be the same on every rank: the profile thread then waits for exactly
+// `max_batch` samples (or sylph_pipeline_flush) and runs the exchange of shard.hip.
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <thread>
+
+#include "contain_index.h"
+#include "sketch_session.h"
+
+using namespace sylph;
+
+namespace {
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+struct Block {   // one pinned result block (+ its layout), shared by the samples of one probe batch
+    HostBlock mem;
+    uint32_t width = 4, users = 0;
+    uint64_t n_covs = 0;
+};
+
+enum class JobState { Queued, Sketching, Sketched, Profiled };
+
+struct Job {
+    uint64_t seq = 0, tag = 0;
+    std::vector<sylph_read_batch> batches;
+    int mem = SYLPH_MEM_DEVICE, enc = SYLPH_ENC_ASCII;
+    sylph_sketch* sk = nullptr;
+    bool adopted = false;        // the caller's session (sylph_pipeline_submit_session)
+    int worker = -1;             // the worker whose context owns `sk` (adopted: none)
+    JobState state = JobState::Queued;
+    int status = SYLPH_OK;
+    std::string error;
+    const uint64_t* dev_k = nullptr;
+    const uint32_t* dev_c = nullptr;
+    uint64_t n_table = 0, dup_removed = 0;
+    std::vector<uint64_t> host_k;    // want_table
+    std::vector<uint32_t> host_c;
+    Block* block = nullptr;
+    uint32_t slot_in_block = 0;
+    double t_submit = 0, t_sketch0 = 0, t_sketch1 = 0, t_profile0 = 0, t_done = 0;
+    uint32_t batch_size = 0;
+};
+
+}  // namespace
+
+struct sylph_pipeline {
+    sylph_db* db = nullptr;
+    sylph_comm* comm = nullptr;
+    uint32_t n_workers = 2, depth = 4, max_batch = 8;
+    uint32_t c = 200, k = 31;
+    int reads_mode = SYLPH_READS_PAIRED, no_dedup = 0, seed_mode = SYLPH_SEED_AVX2_COMPAT, want_table = 0;
+    double min_number_kmers = 0;
+    std::vector<sylph_ctx*> wctx;
+    std::vector<std::thread> wthreads;
+    std::thread pthread;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_sketched, cv_done;
+    std::deque<Job*> to_sketch;                  // submitted, not yet taken by a worker
+    std::deque<Job*> order;                      // every outstanding job in submission order (front = next to be returned)
+    std::vector<std::vector<sylph_sketch*>> trash;   // per worker: sessions to destroy on the thread that owns their context
+    std::vector<std::unique_ptr<Block>> blocks;
+    Job* returned = nullptr;                     // the job whose views the caller holds (released by the next call)
+    uint64_t next_seq = 0;
+    uint64_t flush_upto = 0;                     // sharded: jobs with seq < flush_upto may go in a partial batch
+    bool stop = false;
+
+    Block* take_block() {                        // mu held
+        for (auto& b : blocks)
+            if (b->users == 0) return b.get();
+        blocks.emplace_back(new Block());
+        return blocks.back().get();
+    }
+    void fail(Job* j, int rc) {
+        j->status = rc;
+        j->error = sylph_last_error();
+    }
+    void sketch_job(Job* j, int w) {
+        j->t_sketch0 = now_s();
+        int rc = SYLPH_OK;
+        if (!j->sk) {
+            rc = sylph_sketch_begin(wctx[w], c, k, reads_mode, no_dedup, seed_mode, &j->sk);
+            j->worker = w;
+            for (size_t i = 0; rc == SYLPH_OK && i < j->batches.size(); i++) {
+                const sylph_read_batch& b = j->batches[i];
+                rc = sylph_sketch_push_enc(j->sk, b.bases, b.rec_off, b.n_records, b.n_bases, j->mem, j->enc);
+            }
+        }
+        if (rc == SYLPH_OK) rc = sylph_sketch_finish_device(j->sk, &j->dev_k, &j->dev_c, &j->n_table, &j->dup_removed);
+        if (rc != SYLPH_OK) fail(j, rc);
+        j->t_sketch1 = now_s();
+    }
+    void worker_main(int w) {
+        (void)hipSetDevice(wctx[w]->device);
+        for (;;) {
+            Job* j = nullptr;
+            std::vector<sylph_sketch*> dead;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !to_sketch.empty() || !trash[w].empty(); });
+                dead.swap(trash[w]);
+                if (!to_sketch.empty()) {
+                    j = to_sketch.front();
+                    to_sketch.pop_front();
+                    j->state = JobState::Sketching;
+                } else if (stop && dead.empty()) return;
+            }
+            for (sylph_sketch* s : dead) sylph_sketch_destroy(s);
+            if (!j) continue;
+            sketch_job(j, w);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                j->state = JobState::Sketched;
+            }
+            cv_sketched.notify_all();
+        }
+    }
+    // the profile thread: oldest sketched sample + every consecutive one that is ready, one probe launch
+    void profile_main() {
+        (void)hipSetDevice(db->ctx->device);
+        size_t next_idx_seq = 0;                 // seq of the first job not yet profiled
+        for (;;) {
+            std::vector<Job*> batch;
+            Block* blk = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                auto ready = [&] {
+                    batch.clear();
+                    // sharded: the batches must be the same on every rank, whatever the timing of its workers — exactly the next
+                    // max_batch samples, or (after sylph_pipeline_flush) everything up to the flush point
+                    uint64_t want = max_batch;
+                    if (comm && flush_upto > next_idx_seq) want = std::min<uint64_t>(want, flush_upto - next_idx_seq);
+                    for (Job* j : order) {
+                        if (j->seq < next_idx_seq) continue;
+                        if (j->state != JobState::Sketched || batch.size() >= want) break;
+                        batch.push_back(j);
+                    }
+                    if (batch.empty()) return false;
+                    if (comm && (batch.size() < want || (want < max_batch && flush_upto < next_idx_seq + want))) return false;
+                    return true;
+                };
+                cv_sketched.wait(lk, [&] { return stop || ready(); });
+                if (!ready()) return;            // stop, and nothing left to do (destroy drains the outstanding samples first)
+                blk = take_block();
+                blk->users = (uint32_t)batch.size();
+            }
+            const double t0 = now_s();
+            std::vector<sylph_sample_ref> refs;
+            std::vector<Job*> good;
+            for (Job* j : batch)
+                if (j->status == SYLPH_OK) { refs.push_back(sylph_sample_ref{j->dev_k, j->dev_c, j->n_table}); good.push_back(j); }
+            int rc = SYLPH_OK;
+            uint32_t width = 4, n_covs = 0;
+            if (!good.empty() || comm) {
+                rc = guarded([&] {
+                    n_covs = comm ? contain_batch_sharded_impl(db, comm, refs.data(), (uint32_t)refs.size(), SYLPH_MEM_DEVICE, min_number_kmers, &width, &blk->mem)
+                                  : contain_batch_impl(db, refs.data(), (uint32_t)refs.size(), SYLPH_MEM_DEVICE, min_number_kmers, &width, &blk->mem);
+                });
+            }
+            if (rc == SYLPH_OK && want_table) {
+                rc = guarded([&] {
+                    for (Job* j : good) {
+                        sylph_ctx* cx = j->sk->ctx;
+                        std::lock_guard<std::mutex> lock(cx->mu);
+                        DeviceGuard dg(cx->device);
+                        j->host_k.resize(j->n_table);
+                        j->host_c.resize(j->n_table);
+                        if (j->n_table) {
+                            cx->d2h(j->host_k.data(), j->dev_k, j->n_table * 8);
+                            cx->d2h(j->host_c.data(), j->dev_c, j->n_table * 4);
+                        }
+                    }
+                });
+            }
+            const double t1 = now_s();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                blk->width = width;
+                blk->n_covs = n_covs;
+                uint32_t slot = 0;
+                for (Job* j : batch) {
+                    j->t_profile0 = t0;
+                    j->t_done = t1;
+                    j->batch_size = (uint32_t)batch.size();
+                    j->block = blk;
+                    if (j->status == SYLPH_OK) {
+                        if (rc != SYLPH_OK) fail(j, rc);
+                        else j->slot_in_block = slot++;
+                    }
+                    j->state = JobState::Profiled;
+                }
+                next_idx_seq = batch.back()->seq + 1;
+            }
+            cv_done.notify_all();
+        }
+    }
+    // mu held.  Returns a session the CALLER of this function must destroy after dropping the lock (an adopted session lives
+    // on a context of the pipeline's user), or nullptr (sessions of the workers go back to the thread that owns their context).
+    sylph_sketch* release_returned() {
+        Job* j = returned;
+        returned = nullptr;
+        if (!j) return nullptr;
+        if (j->block && j->block->users) j->block->users--;
+        sylph_sketch* dead = j->sk;
+        const bool adopted = j->adopted;
+        const int w = j->worker;
+        delete j;
+        if (!dead) return nullptr;
+        if (!adopted && w >= 0) { trash[w].push_back(dead); cv_work.notify_all(); return nullptr; }
+        return dead;
+    }
+};
+
+namespace {
+
+int submit_job(sylph_pipeline* p, std::unique_ptr<Job> j) {
+    bool full = false;
+    const int rc = guarded([&] {
+        std::unique_lock<std::mutex> lk(p->mu);
+        SY_REQUIRE(!p->stop, "pipeline is shutting down");
+        if (p->order.size() >= p->depth) { full = true; return; }
+        j->seq = p->next_seq++;
+        j->t_submit = now_s();
+        Job* raw = j.release();
+        p->order.push_back(raw);
+        p->to_sketch.push_back(raw);
+        lk.unlock();
+        p->cv_work.notify_one();
+    });
+    if (full) {
+        set_error("sylph_pipeline_submit: %u samples are outstanding already (depth): call sylph_pipeline_next first", p->depth);
+        return SYLPH_ERR_STATE;
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sylph_pipeline_create(sylph_db* db, const sylph_pipeline_config* cfg, sylph_pipeline** out) {
+    return guarded([&] {
+        SY_REQUIRE(db && cfg && out, "null argument");
+        SY_REQUIRE(cfg->struct_size == sizeof(sylph_pipeline_config), "sylph_pipeline_config.struct_size is %u, this library expects %zu",
+                   cfg->struct_size, sizeof(sylph_pipeline_config));
+        SY_REQUIRE(cfg->c >= 1 && (cfg->k == 21 || cfg->k == 31), "bad c / k");
+        SY_REQUIRE(cfg->reads_mode == SYLPH_READS_SINGLE || cfg->reads_mode == SYLPH_READS_PAIRED, "bad reads_mode %d", cfg->reads_mode);
+        SY_REQUIRE(cfg->seed_mode == SYLPH_SEED_SCALAR || cfg->seed_mode == SYLPH_SEED_AVX2_COMPAT, "bad seed_mode %d", cfg->seed_mode);
+        SY_REQUIRE(cfg->n_workers <= 16 && cfg->max_batch <= 64 && cfg->depth <= 4096, "n_workers <= 16, max_batch <= 64, depth <= 4096");
+        SY_REQUIRE((cfg->comm != nullptr) == (db->world > 1 || !db->bounds.empty()), "a sharded database needs cfg.comm (and only a sharded one takes it)");
+        std::unique_ptr<sylph_pipeline> p(new sylph_pipeline());
+        p->db = db;
+        p->comm = cfg->comm;
+        p->n_workers = cfg->n_workers ? cfg->n_workers : 2;
+        p->max_batch = cfg->max_batch ? cfg->max_batch : 8;
+        p->depth = cfg->depth ? cfg->depth : p->n_workers + 2;
+        SY_REQUIRE(!p->comm || p->depth >= p->max_batch, "sharded: depth (%u) must reach max_batch (%u), the fixed batch of the exchange", p->depth, p->max_batch);
+        p->c = cfg->c; p->k = cfg->k;
+        p->reads_mode = cfg->reads_mode; p->no_dedup = cfg->no_dedup; p->seed_mode = cfg->seed_mode; p->want_table = cfg->want_table;
+        p->min_number_kmers = cfg->min_number_kmers;
+        p->trash.resize(p->n_workers);
+        try {
+            for (uint32_t w = 0; w < p->n_workers; w++) {
+                sylph_ctx* cx = nullptr;
+                if (sylph_ctx_create(db->ctx->device, nullptr, &cx) != SYLPH_OK) throw ArgError{sylph_last_error()};
+                p->wctx.push_back(cx);
+            }
+        } catch (...) {
+            for (sylph_ctx* cx : p->wctx) sylph_ctx_destroy(cx);
+            throw;
+        }
+        db->ctx->refs++;                         // the profile thread works on the database's context
+        sylph_pipeline* raw = p.release();
+        for (uint32_t w = 0; w < raw->n_workers; w++) raw->wthreads.emplace_back([raw, w] { raw->worker_main((int)w); });
+        raw->pthread = std::thread([raw] { raw->profile_main(); });
+        *out = raw;
+    });
+}
+
+int sylph_pipeline_submit(sylph_pipeline* p, const sylph_read_batch* batches, uint32_t n_batches, int mem, int enc, uint64_t tag) {
+    if (!p || (n_batches && !batches)) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    std::unique_ptr<Job> j(new Job());
+    j->batches.assign(batches, batches + n_batches);
+    j->mem = mem; j->enc = enc; j->tag = tag;
+    return submit_job(p, std::move(j));
+}
+
+int sylph_pipeline_submit_session(sylph_pipeline* p, sylph_sketch* sk, uint64_t tag) {
+    if (!p || !sk) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (sk->ctx->device != p->db->ctx->device) { set_error("the session lives on another device than the database"); return SYLPH_ERR_INVALID; }
+    std::unique_ptr<Job> j(new Job());
+    j->sk = sk; j->adopted = true; j->tag = tag;
+    return submit_job(p, std::move(j));
+}
+
+int sylph_pipeline_flush(sylph_pipeline* p) {
+    return guarded([&] {
+        SY_REQUIRE(p, "null argument");
+        { std::lock_guard<std::mutex> lk(p->mu); p->flush_upto = p->next_seq; }
+        p->cv_sketched.notify_all();
+    });
+}
+
+int sylph_pipeline_next(sylph_pipeline* p, sylph_pipeline_result* out) {
+    return guarded([&] {
+        SY_REQUIRE(p && out, "null argument");
+        std::unique_lock<std::mutex> lk(p->mu);
+        if (sylph_sketch* dead = p->release_returned()) { lk.unlock(); sylph_sketch_destroy(dead); lk.lock(); }
+        SY_REQUIRE(!p->order.empty(), "sylph_pipeline_next: nothing is outstanding");
+        Job* j = p->order.front();
+        p->cv_done.wait(lk, [&] { return j->state == JobState::Profiled; });
+        p->order.pop_front();
+        p->returned = j;
+        memset(out, 0, sizeof(*out));
+        out->tag = j->tag;
+        out->status = j->status;
+        out->error = j->status == SYLPH_OK ? nullptr : j->error.c_str();
+        out->n_table = j->n_table;
+        out->dup_removed = j->dup_removed;
+        out->dev_kmers = j->dev_k;
+        out->dev_counts = j->dev_c;
+        if (p->want_table && j->status == SYLPH_OK) { out->kmers = j->host_k.data(); out->counts = j->host_c.data(); }
+        out->t_submit = j->t_submit; out->t_sketch_begin = j->t_sketch0; out->t_sketch_end = j->t_sketch1;
+        out->t_profile_begin = j->t_profile0; out->t_done = j->t_done;
+        out->probe_batch = j->batch_size;
+        if (j->status == SYLPH_OK && j->block) {
+            const Block& b = *j->block;
+            const char* h = (const char*)b.mem.p;
+            const uint64_t G = p->db->n_genomes, row0 = (uint64_t)j->slot_in_block * G;
+            out->cov_off = (const uint64_t*)h + row0;                  // G + 1 entries; values index `covs`
+            out->contain_count = (const uint32_t*)(h + b.mem.lay.ccount) + row0;
+            out->covs = h + b.mem.lay.covs;
+            out->cov_width = b.width;
+            out->n_covs = out->cov_off[G] - out->cov_off[0];
+        }
+    });
+}
+
+uint32_t sylph_pipeline_outstanding(sylph_pipeline* p) {
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return (uint32_t)p->order.size();
+}
+
+int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* value) {
+    if (!p) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    for (sylph_ctx* cx : p->wctx) {
+        const int rc = sylph_ctx_set_option(cx, key, value);
+        if (rc != SYLPH_OK) return rc;
+    }
+    return SYLPH_OK;
+}
+
+int sylph_pipeline_profile(sylph_pipeline* p, int enable) {
+    if (!p) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    for (sylph_ctx* cx : p->wctx) {
+        const int rc = sylph_ctx_profile(cx, enable);
+        if (rc != SYLPH_OK) return rc;
+    }
+    return sylph_ctx_profile(p->db->ctx, enable);
+}
+
+int sylph_pipeline_kernel_stats(sylph_pipeline* p, const char* family, double* total_ms, uint64_t* launches) {
+    if (!p || !family) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    double ms = 0;
+    uint64_t n = 0;
+    std::vector<sylph_ctx*> all(p->wctx);
+    all.push_back(p->db->ctx);
+    for (sylph_ctx* cx : all) {
+        double m = 0;
+        uint64_t l = 0;
+        const int rc = sylph_ctx_kernel_stats(cx, family, &m, &l);
+        if (rc != SYLPH_OK) return rc;
+        ms += m;
+        n += l;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    return SYLPH_OK;
+}
+
+void sylph_pipeline_destroy(sylph_pipeline* p) {
+    if (!p) return;
+    sylph_sketch* dead = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        dead = p->release_returned();
+        p->flush_upto = ~0ull;
+    }
+    if (dead) sylph_sketch_destroy(dead);
+    p->cv_sketched.notify_all();
+    // outstanding samples are finished (their inputs are the caller's memory: nothing may still read them afterwards)
+    for (;;) {
+        std::unique_lock<std::mutex> lk(p->mu);
+        if (p->order.empty()) break;
+        Job* j = p->order.front();
+        p->cv_done.wait(lk, [&] { return j->state == JobState::Profiled; });
+        p->order.pop_front();
+        p->returned = j;
+        dead = p->release_returned();
+        lk.unlock();
+        if (dead) sylph_sketch_destroy(dead);
+    }
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_work.notify_all();
+    p->cv_sketched.notify_all();
+    for (auto& t : p->wthreads) t.join();
+    if (p->pthread.joinable()) p->pthread.join();
+    for (size_t w = 0; w < p->wctx.size(); w++) {
+        for (sylph_sketch* s : p->trash[w]) sylph_sketch_destroy(s);
+        sylph_ctx_destroy(p->wctx[w]);
+    }
+    sylph_ctx* dbctx = p->db->ctx;
+    p->blocks.clear();
+    delete p;
+    ctx_unref(dbctx);
+}
+
+}  // extern "C"

@@ -279,11 +279,12 @@ void sylph_comm_destroy(sylph_comm* comm) {
     delete comm;
 }
 
-int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
-                                   double min_number_kmers, const uint32_t** contain_count, const uint64_t** cov_off,
-                                   const void** covs, uint32_t* cov_width, uint64_t* out_n_covs) {
-    return guarded([&] {
-        SY_REQUIRE(db && comm && contain_count && cov_off && covs && cov_width, "null argument");
+}  // extern "C"
+
+uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
+                                           double min_number_kmers, uint32_t* cov_width, HostBlock* dst) {
+    {
+        SY_REQUIRE(db && comm && cov_width, "null argument");
         SY_REQUIRE(n_local == 0 || samples, "null samples");
         SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
         SY_REQUIRE(n_local <= MAX_LOCAL, "at most %u samples per rank and batch", MAX_LOCAL);
@@ -471,10 +472,22 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
         }
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 6: sort + assemble + copy out"));
         // ---- 6. sort + assemble this rank's samples
-        finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false);
+        finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false, dst);
         ph.reset();
+        return n_mine;
+    }
+}
+
+extern "C" {
+
+int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
+                                   double min_number_kmers, const uint32_t** contain_count, const uint64_t** cov_off,
+                                   const void** covs, uint32_t* cov_width, uint64_t* out_n_covs) {
+    return guarded([&] {
+        SY_REQUIRE(db && comm && contain_count && cov_off && covs && cov_width, "null argument");
+        const uint32_t n_mine = contain_batch_sharded_impl(db, comm, samples, n_local, mem, min_number_kmers, cov_width, nullptr);
         const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_res;
+        const char* h = (const char*)db->h_block.p;
         *cov_off = (const uint64_t*)h;
         *contain_count = (const uint32_t*)(h + lay.ccount);
         *covs = h + lay.covs;

@@ -1,4 +1,4 @@
-"""Seeded synthetic workloads of SURVEY.md §8d / BASELINE.md (bench.py and the scale tests use these).
+"""Seeded synthetic workloads of SURVEY.md §8d / BASELINE.md (bench.py and the scale tests use these; not part of the product package).
 
 Everything is generated with torch on the device the caller names (GPU for the full-size configs), so a 1 Gbp
 read set and a GTDB-R220-scale database appear in HBM without touching the host.  Plumbing only — no sylph logic.

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_one_gbp_sample_against_the_oracle(ctx):
     import torch
-    from sylph_amd import synth
+    import synth
     dev = torch.device("cuda", 0)
     c, k, n_pairs, read_len = 200, 31, 3_333_334, 150
     genomes = synth.random_genomes(24, 2_000_000, dev, 3, mutated_frac=0.0)
@@ -87,7 +87,7 @@ def test_ragged_reads_with_n_against_the_oracle(ctx):
     against the oracle, paired and single-end (single-end reads the same bytes as 3 M records with the cut-off at 4), through
     the read-per-lane kernel and the position kernel, in one push and in three."""
     import torch
-    from sylph_amd import synth
+    import synth
     dev = torch.device("cuda", 0)
     c, k, n_pairs = 200, 31, 1_500_000
     genomes = synth.random_genomes(12, 1_000_000, dev, 5, mutated_frac=0.0)
@@ -134,7 +134,7 @@ def test_long_read_sample_in_two_pushes_at_c100_against_a_c200_database(ctx):
     be denser than the database (contain.rs:562-568, :616-623): half of the sample's k-mers lie above the database's threshold
     and must simply find nothing."""
     import torch
-    from sylph_amd import synth
+    import synth
     dev = torch.device("cuda", 0)
     k = 31
     genomes = synth.random_genomes(12, 3_000_000, dev, 21, mutated_frac=0.0)

@@ -1,0 +1,149 @@
+"""GPU tests of sylph_pipeline_* (csrc/pipeline.hip): a stream of samples through sketch workers + the profile thread must give,
+sample by sample and in submission order, exactly what the one-sample-at-a-time entry points and the CPU oracle give — whatever
+the number of workers, the depth and the probe batching."""
+import numpy as np
+import pytest
+
+import sylph_amd as S
+from oracle import oracle as O
+from sylph_amd.binding import MEM_HOST
+
+from .helpers import concat, random_seq
+from .test_gpu_parity import make_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def small_world(seed, n_genomes=5, glen=40000, c=50):
+    rng = np.random.default_rng(seed)
+    genomes = [random_seq(rng, glen) for _ in range(n_genomes)]
+    gk = [O.sketch_genome(g, np.array([0, len(g)], dtype=np.uint64), c=c)["genome_kmers"] for g in genomes]
+    goff = np.zeros(len(gk) + 1, dtype=np.uint64)
+    goff[1:] = np.cumsum([len(x) for x in gk])
+    return rng, genomes, np.concatenate(gk), goff
+
+
+def sample_reads(rng, genomes, which, n, paired=True):
+    recs = []
+    for g in which:
+        recs += make_reads(rng, genomes[g], n, 150, paired=paired, dup_frac=0.05, ragged=False)
+    return concat(recs)
+
+
+def check_result(r, e, db_k, goff, mk=50.0):
+    assert r["n_table"] == len(e["kmers"]) and r["dup_removed"] == e["dup_removed"]
+    ecc, ecov, _ = O.contain(e["kmers"], e["counts"], db_k, goff, min_number_kmers=mk)
+    assert np.array_equal(r["contain_count"], ecc)
+    off, covs = r["cov_off"], r["covs"]
+    for g in range(len(goff) - 1):
+        assert np.array_equal(np.asarray(covs[int(off[g]):int(off[g + 1])]).astype(np.uint32), np.sort(ecov[g])), g
+
+
+@pytest.mark.parametrize("workers,depth,max_batch", [(1, 1, 1), (2, 4, 8), (3, 6, 2)])
+def test_pipeline_matches_oracle_in_submission_order(ctx, workers, depth, max_batch):
+    import torch
+    rng, genomes, db_k, goff = small_world(5)
+    db = S.Database(ctx, db_k, goff)
+    samples = []
+    for i in range(9):
+        b, off = sample_reads(rng, genomes, [i % 5, (i * 2 + 1) % 5][: 1 + i % 2], 400 + 150 * (i % 3))
+        if i == 4:
+            b, off = np.zeros(0, np.uint8), np.zeros(1, np.uint64)           # an empty sample in the middle of the stream
+        samples.append((b, off, O.sketch_reads(b, off, c=50, paired=True)))
+    dev = [(torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()) for b, off, _ in samples]
+    torch.cuda.synchronize()
+    p = S.Pipeline(db, c=50, paired=True, n_workers=workers, depth=depth, max_batch=max_batch, want_table=True)
+    submitted = done = 0
+    while done < len(samples):
+        while submitted < len(samples) and p.outstanding < depth:
+            tb, toff = dev[submitted]
+            b, off, _ = samples[submitted]
+            ok = p.submit_device([(tb.data_ptr(), toff.data_ptr(), len(off) - 1, int(off[-1]))], tag=1000 + submitted)
+            assert ok
+            submitted += 1
+        if submitted < len(samples):      # depth reached: one more must be refused, not block
+            tb, toff = dev[submitted]
+            assert p.submit_device([(tb.data_ptr(), toff.data_ptr(), len(samples[submitted][1]) - 1, int(samples[submitted][1][-1]))]) is False
+        r = p.next()
+        assert r["tag"] == 1000 + done                                        # submission order
+        e = samples[done][2]
+        check_result(r, e, db_k, goff)
+        assert np.array_equal(r["kmers"], e["kmers"]) and np.array_equal(r["counts"], e["counts"])
+        assert 1 <= r["probe_batch"] <= max_batch
+        t = r["t"]
+        assert t[0] <= t[1] <= t[2] <= t[3] <= t[4]
+        done += 1
+    with pytest.raises(S.SylphHipError):
+        p.next()                                                              # nothing outstanding
+    p.close()
+    db.close()
+
+
+def test_pipeline_host_batches_sessions_and_errors(ctx):
+    """Host-memory batches (several per sample), adopted sessions, and a sample that fails (odd number of records in a paired
+    session) — the failure belongs to that sample only, the stream goes on."""
+    rng, genomes, db_k, goff = small_world(6)
+    db = S.Database(ctx, db_k, goff)
+    p = S.Pipeline(db, c=50, paired=True, n_workers=2, depth=4, max_batch=4)
+    b1, o1 = sample_reads(rng, genomes, [0], 500)
+    b2, o2 = sample_reads(rng, genomes, [1, 2], 300)
+    e1, e2 = O.sketch_reads(b1, o1, c=50, paired=True), O.sketch_reads(b2, o2, c=50, paired=True)
+    # sample 0: two host batches (cut at a pair boundary)
+    cut = 400
+    oa = o1[:cut + 1].copy()
+    ob = (o1[cut:] - o1[cut]).copy()
+    ba, bb = b1[:int(o1[cut])].copy(), b1[int(o1[cut]):].copy()
+    assert p.submit_device([(ba.ctypes.data, oa.ctypes.data, cut, int(oa[-1])), (bb.ctypes.data, ob.ctypes.data, len(ob) - 1, int(ob[-1]))],
+                           tag=1, mem=MEM_HOST)
+    # sample 1: a paired batch with an odd record count -> SYLPH_ERR_INVALID for this sample
+    assert p.submit_device([(b2.ctypes.data, o2.ctypes.data, 3, int(o2[3]))], tag=2, mem=MEM_HOST)
+    # sample 2: a session the caller pushed into
+    sk = S.ReadSketcher(ctx, c=50, paired=True)
+    sk.push(b2, o2)
+    assert p.submit_session(sk, tag=3)
+    r = p.next()
+    assert r["tag"] == 1
+    check_result(r, e1, db_k, goff)
+    with pytest.raises(S.SylphHipError) as ei:
+        p.next()
+    assert "even number" in str(ei.value)
+    r = p.next()
+    assert r["tag"] == 3
+    check_result(r, e2, db_k, goff)
+    # kernel timers summed over the contexts
+    p.profile(True)
+    assert p.submit_device([(b1.ctypes.data, o1.ctypes.data, len(o1) - 1, int(o1[-1]))], tag=4, mem=MEM_HOST)
+    check_result(p.next(), e1, db_k, goff)
+    ms, n = p.kernel_stats("probe")
+    assert n >= 1 and ms > 0
+    ms, n = p.kernel_stats("seeds")
+    assert n >= 1
+    p.profile(False)
+    # destroy with samples outstanding: they are finished first (their input memory is still ours)
+    assert p.submit_device([(b1.ctypes.data, o1.ctypes.data, len(o1) - 1, int(o1[-1]))], tag=5, mem=MEM_HOST)
+    p.close()
+    db.close()
+
+
+def test_pipeline_sharded_one_rank(ctx):
+    """The sharded flavour (fixed batches + flush) over a one-rank RCCL communicator equals the unsharded pipeline."""
+    rng, genomes, db_k, goff = small_world(7)
+    comm = S.Comm(0, 1, ctx=ctx, rccl_id=S.Comm.rccl_unique_id())
+    bounds = S.shard_bounds(int(db_k.max()), 1)
+    db = S.Database(ctx, db_k, goff, shard=(bounds, 1, 0))
+    p = S.Pipeline(db, c=50, paired=True, n_workers=2, depth=4, max_batch=3, comm=comm)
+    data = [sample_reads(rng, genomes, [i % 5], 300) for i in range(5)]
+    for i, (b, off) in enumerate(data[:4]):
+        assert p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=i, mem=MEM_HOST)
+    for i in range(3):                     # the first full batch of three
+        r = p.next()
+        assert r["tag"] == i and r["probe_batch"] == 3
+        check_result(r, O.sketch_reads(*data[i], c=50, paired=True), db_k, goff)
+    b, off = data[4]
+    assert p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=4, mem=MEM_HOST)
+    p.flush()                              # the remaining two go in a partial batch
+    for i in (3, 4):
+        r = p.next()
+        assert r["tag"] == i and r["probe_batch"] == 2
+        check_result(r, O.sketch_reads(*data[i], c=50, paired=True), db_k, goff)
+    p.close(); db.close(); comm.close()

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, torch
 import sylph_amd as S
-from sylph_amd import synth
+import synth
 dev = torch.device("cuda", 0)
 ctx = S.Context(0)
 genomes = synth.random_genomes(100, 5_000_000, dev, 3, mutated_frac=0.0)

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, numpy as np, torch
 import sylph_amd as S
-from sylph_amd import synth
+import synth
 dev = torch.device("cuda", 0)
 ctx = S.Context(0)
 CASES = {"1": ((1, 5_000_000),), "all": ((1, 5_000_000), (4, 5_000_000), (100, 5_000_000)),

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, torch
 import sylph_amd as S
-from sylph_amd import synth
+import synth
 dev = torch.device("cuda", 0)
 ctx = S.Context(0)
 for n_gen in (1, 10):

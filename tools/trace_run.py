@@ -1,7 +1,7 @@
 import os, sys, time, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 import sylph_amd as S
-from sylph_amd import synth
+import synth
 dev=torch.device('cuda',0)
 comm=synth.random_genomes(100, 5_000_000, dev, 1, mutated_frac=0.0)
 bases,off=synth.paired_reads(comm, 3_333_334, seed=5)
