@@ -539,6 +539,7 @@ class Pipeline:
                              int(no_dedup), seed_mode, int(want_table), float(min_number_kmers), comm._h if comm is not None else None)
         _check(load().sylph_pipeline_create(db._h, C.byref(cfg), C.byref(self._h)))
         self._res = PipelineResult()
+        self._want_table = bool(want_table)
 
     def submit_device(self, batches, tag=0, enc=ENC_ASCII, mem=MEM_DEVICE):
         """batches: list of (bases_ptr, rec_off_ptr, n_records, n_bases) integer addresses.  False when `depth` samples are
@@ -587,7 +588,7 @@ class Pipeline:
             # covs is the base of the whole batch's values; cov_off indexes it
             hi = int(off[G]) if G else 0
             out["covs"] = view(r.covs, hi, ct, dt)
-            if r.kmers:
+            if self._want_table:
                 out["kmers"] = view(r.kmers, int(r.n_table), C.c_uint64, np.uint64)
                 out["counts"] = view(r.counts, int(r.n_table), C.c_uint32, np.uint32)
         return out
