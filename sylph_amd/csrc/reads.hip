@@ -173,6 +173,7 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(5, 5))) vo
                                                      const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
                                                      int avx2_compat, int paired, int want_markers, uint64_t rec_base,
                                                      uint32_t slot_cap, OccRec* __restrict__ slot_rec,
+                                                     uint32_t* __restrict__ slot_key, int key_sh,
                                                      uint32_t* __restrict__ blk_count,
                                                      ReadsState* __restrict__ state, const uint32_t* __restrict__ blk_list,
                                                      uint32_t* __restrict__ spill_slot_of_blk) {
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(5, 5))) vo
                     const uint64_t h = mm_hash64(fk < rk ? fk : rk);
                     const uint64_t rid = (rec_base + pass + lo) | ((f >> 31) ? RID_MARKER_BIT : 0ull);
                     slot_rec[out0 + o] = OccRec{h, rid, s_m0[lo], s_m1[lo]};
+                    if (slot_key) slot_key[out0 + o] = (uint32_t)(h >> key_sh);   // what finish() partitions by (replay_lds.hip)
                 }
             }
             base_prev += total;
@@ -443,10 +445,65 @@ __global__ __launch_bounds__(64) void compact_occ_kernel(const OccRec* __restric
 
 uint32_t grid_for(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 1) / tpb); }
 
+// total = sum of the blocks' occurrence counts, written to blk_off[n_blk] — next to the two flag words of the state, so that
+// everything the host wants to know about the batch leaves in ONE 12-byte copy (one workgroup: n_blk is a few ten thousand)
+__global__ __launch_bounds__(1024) void block_total_kernel(const uint32_t* __restrict__ blk_count, uint32_t n_blk, uint32_t* __restrict__ total) {
+    __shared__ uint32_t s[16];
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < n_blk; i += 1024) v += blk_count[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; w++) t += s[w];
+        *total = t;
+    }
+}
+
+// layout of sk->slot_meta: [blk_rec (n_blk+1) | blk_count (n_blk+1) | spill_slot_of_blk (n_blk+1) | blk_off (n_blk+1) | ReadsState]
+struct SlotMeta {
+    uint32_t *blk_rec, *blk_count, *spill_slot, *blk_off;
+    ReadsState* state;
+    SlotMeta(sylph_sketch* sk, uint32_t n_blk) {
+        blk_rec = sk->slot_meta.as<uint32_t>();
+        blk_count = blk_rec + (n_blk + 1);
+        spill_slot = blk_count + (n_blk + 1);
+        blk_off = spill_slot + (n_blk + 1);
+        state = reinterpret_cast<ReadsState*>(blk_off + (n_blk + 1));
+    }
+};
+
+// the region's occurrences -> the session's dense file-order arrays (hash + OccRec), behind what is there already
+void compact_region(sylph_sketch* sk, uint32_t n_blk, uint32_t slot_cap, uint32_t n, uint32_t spill_cap, const OccRec* spill_rec) {
+    sylph_ctx* ctx = sk->ctx;
+    SlotMeta m(sk, n_blk);
+    exclusive_sum_u32(ctx, m.blk_count, m.blk_off, (size_t)n_blk + 1);
+    const uint64_t need = sk->n_occ + n;
+    sk->hash.grow_keep(need * 8, sk->n_occ * 8, ctx->stream);
+    sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
+    {
+        ScopedKernelTimer t(ctx, "compact");
+        hipLaunchKernelGGL(compact_occ_kernel, dim3(std::min<uint32_t>(n_blk, 1u << 16)), dim3(64), 0, ctx->stream,
+                           sk->slot_rec.as<OccRec>(), m.blk_count, m.blk_off, n_blk, slot_cap, spill_cap, spill_rec, m.spill_slot,
+                           sk->hash.as<uint64_t>() + sk->n_occ, sk->recs.as<OccRec>() + sk->n_occ);
+        SY_HIP(hipGetLastError());
+    }
+    sk->n_occ = need;
+}
+
 }  // namespace
 
-// Short-read path of sylph_sketch_push: appends the batch's occurrences (hash + OccRec, file order) to the session and
-// returns true; returns false — having appended nothing — when the batch is not for this kernel (a record longer than
+void flush_pending_slots(sylph_sketch* sk) {
+    if (!sk->pend.live) return;
+    compact_region(sk, sk->pend.n_blk, sk->pend.slot_cap, sk->pend.n, 0, nullptr);
+    sk->pend = PendingSlots{};
+}
+
+// Short-read path of sylph_sketch_push: returns true with the batch's occurrences taken over by the session — left in their
+// slots (sk->pend) when this is the session's first batch and no block overflowed, else appended to the dense arrays (hash +
+// OccRec, file order); returns false — having taken nothing — when the batch is not for this kernel (a record longer than
 // READ_HALO, or more overflowing blocks than spill regions), and the caller runs the position kernel + annotate instead.
 bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases,
                       int enc) {
@@ -469,27 +526,24 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
     const uint32_t slot_cap = (uint32_t)std::min<uint64_t>(spill_cap, expect + expect * 3 / 4 + 48);
     const size_t lds_bytes = ((size_t)(rt + 2 * RH) / 16 + 3 + RPAD) * 4;
     const uint64_t thr = UINT64_MAX / (uint64_t)sk->c;
-    DevBuf &b_sr = ctx->scratch[1], &b_meta = ctx->scratch[4];
-    b_sr.reserve((size_t)n_blk * slot_cap * sizeof(OccRec));
-    // [blk_rec (n_blk+1) | blk_count (n_blk+1) | spill_slot_of_blk (n_blk+1) | blk_off (n_blk+1) | ReadsState]: the total
-    // (blk_off[n_blk]) and the two flag words of the state sit side by side and leave in ONE 12-byte copy
-    b_meta.reserve(((size_t)n_blk + 1) * 4 * 4 + sizeof(ReadsState) + 16);
-    uint32_t* blk_rec = b_meta.as<uint32_t>();
-    uint32_t* blk_count = blk_rec + (n_blk + 1);
-    uint32_t* spill_slot = blk_count + (n_blk + 1);
-    uint32_t* blk_off = spill_slot + (n_blk + 1);
-    ReadsState* d_state = reinterpret_cast<ReadsState*>(blk_off + (n_blk + 1));
+    // the slots belong to the SESSION (from the context's pool): they may outlive this call (sk->pend)
+    sk->slot_rec.reserve((size_t)n_blk * slot_cap * sizeof(OccRec));
+    sk->slot_key.reserve((size_t)n_blk * slot_cap * 4);
+    // (the total — blk_off[n_blk] — and the two flag words of the state sit side by side and leave in ONE 12-byte copy)
+    sk->slot_meta.reserve(((size_t)n_blk + 1) * 4 * 4 + sizeof(ReadsState) + 16);
+    SlotMeta m(sk, n_blk);
     static_assert(offsetof(ReadsState, long_record) == 0 && offsetof(ReadsState, spill) == 4 && offsetof(SpillState, n_tiles) == 0,
                   "long_record and spill.n_tiles are the first two words");
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
-    auto launch = [&](uint32_t n_it, uint32_t cap, OccRec* sr, const uint32_t* list) {
+    const int key_sh = key_shift(sk->c);
+    auto launch = [&](uint32_t n_it, uint32_t cap, OccRec* sr, uint32_t* skey, const uint32_t* list) {
         const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * ctx->reads_wg_per_cu) : n_it;
 #define SY_LAUNCH_READS(KK, HH, EE)                                                                                                   \
     hipLaunchKernelGGL((reads_kernel<KK, HH, EE>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
-                       blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr,          \
-                       blk_count, d_state, list, spill_slot)
+                       m.blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr, skey, key_sh,   \
+                       m.blk_count, m.state, list, m.spill_slot)
         if (enc == SYLPH_ENC_2BIT) {
             if (sk->k == 31) SY_LAUNCH_READS(31, 1, 1); else SY_LAUNCH_READS(21, 1, 1);
         } else if (sk->k == 31) { if (hv) SY_LAUNCH_READS(31, 1, 0); else SY_LAUNCH_READS(31, 0, 0); }
@@ -502,22 +556,32 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         {
             ScopedKernelTimer t(ctx, "annotate");   // the record lookup this kernel replaces
             hipLaunchKernelGGL(block_records_kernel, dim3(grid_for(n_blk + 1)), dim3(256), 0, ctx->stream, d_off, n_records, bias, rt,
-                               n_blk + 1, blk_rec, blk_count + n_blk, reinterpret_cast<uint32_t*>(d_state));
+                               n_blk + 1, m.blk_rec, m.blk_count + n_blk, reinterpret_cast<uint32_t*>(m.state));
         }
         {
             ScopedKernelTimer t(ctx, "seeds");
-            launch(n_blk, slot_cap, b_sr.as<OccRec>(), nullptr);
+            launch(n_blk, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
         }
-        exclusive_sum_u32(ctx, blk_count, blk_off, (size_t)n_blk + 1);
+        hipLaunchKernelGGL(block_total_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.blk_count, n_blk, m.blk_off + n_blk);
     }
     uint32_t res[3] = {0, 0, 0};   // total occurrences, long_record flag, overflowing blocks
-    SY_HIP(hipMemcpyAsync(ctx->pinned, blk_off + n_blk, 12, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipMemcpyAsync(ctx->pinned, m.blk_off + n_blk, 12, hipMemcpyDeviceToHost, ctx->stream));
     SY_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(res, ctx->pinned, 12);
     if (!ctx->pending.empty()) profile_collect(ctx);
     if (res[1] || res[2] > SPILL_MAX_TILES) return false;
     const uint32_t n = res[0];
     if (n == 0) return true;
+    // The first batch of a session stays in its slots: a sample that arrives in one batch is partitioned from there (no
+    // compaction pass over its 32 B records at all).  Not with overflowing blocks (their occurrences live in spill regions), not
+    // behind occurrences that are in the dense arrays already, not when the device-wide finish was asked for (it wants them dense).
+    if (res[2] == 0 && sk->n_occ == 0 && ctx->finish_mode != 1 && sk->c >= 2) {
+        sk->pend.live = true;
+        sk->pend.n_blk = n_blk;
+        sk->pend.slot_cap = slot_cap;
+        sk->pend.n = n;
+        return true;
+    }
     const OccRec* sp_r = nullptr;
     if (res[2]) {   // a few blocks (low-complexity reads) are redone with room for every position
         DevBuf& b_x = ctx->scratch[7];   // spill records
@@ -525,20 +589,10 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         OccRec* xr = b_x.as<OccRec>();
         ScopedKernelTimer ts(ctx, "seeds_spill");
         ScopedKernelTimer t(ctx, "seeds");
-        launch(res[2], spill_cap, xr, d_state->spill.tiles);
+        launch(res[2], spill_cap, xr, nullptr, m.state->spill.tiles);
         sp_r = xr;
     }
-    const uint64_t need = sk->n_occ + n;
-    sk->hash.grow_keep(need * 8, sk->n_occ * 8, ctx->stream);
-    sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
-    {
-        ScopedKernelTimer t(ctx, "compact");
-        hipLaunchKernelGGL(compact_occ_kernel, dim3(std::min<uint32_t>(n_blk, 1u << 16)), dim3(64), 0, ctx->stream,
-                           b_sr.as<OccRec>(), blk_count, blk_off, n_blk, slot_cap, spill_cap, sp_r, spill_slot,
-                           sk->hash.as<uint64_t>() + sk->n_occ, sk->recs.as<OccRec>() + sk->n_occ);
-        SY_HIP(hipGetLastError());
-    }
-    sk->n_occ = need;
+    compact_region(sk, n_blk, slot_cap, n, spill_cap, sp_r);
     return true;
 }
 

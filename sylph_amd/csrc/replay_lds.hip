@@ -1,13 +1,19 @@
 // replay_lds.hip — finish() of a read-sketch session without device-wide sorts: bucket partition + in-LDS replay.
 //
 // FracMinHash survivors are uniformly distributed below the threshold (mm_hash64 is a bijection of canonical
-// k-mers), so the top bits of the hash split the sample's occurrences into B buckets of nearly equal size.  One
-// counting pass + one scatter pass puts every occurrence record (hash, rid, m0, m1: 32 B) into its bucket; one
-// workgroup then owns one bucket entirely in LDS: stable counting-rank sort by hash -> k-mer segments in file
+// k-mers), so the top bits of the hash split the sample's occurrences into B buckets of nearly equal size (~128).
+// The PARTITION (round 3: hand-written, four small kernels, no library sort, no memset dispatches) only moves 8-byte
+// (bucket, occurrence index) pairs, in two levels: tiles of occurrences are histogrammed over <= 512 coarse hash ranges, a
+// scan turns the (range x tile) counts into offsets, the pairs are scattered range by range, and one workgroup per coarse
+// range finishes with a counting sort by bucket in LDS, which also yields the bucket offsets.  Neither level keeps the file
+// order inside a bucket (ranks come from LDS atomics): the occurrence index IS the file order, and the replay workgroup
+// re-establishes it for its ~128 occurrences with one rank loop.  The 32 B occurrence records never move: the replay gathers
+// them through the permutation — from the session's dense arrays, or straight from the per-block slots the seeding kernel
+// left them in when the sample came in one batch (no compaction pass at all).
+// One workgroup then owns one bucket entirely in LDS: counting-rank sort by (hash, file order) -> k-mer segments in file
 // order -> mate-2 skip, duplicate flags, cut-off and counts (the same data-parallel formulation of
 // dup_removal_lsh_full_exact as sketch.hip, see its header) -> distinct (k-mer, count) pairs.  Buckets are ordered
 // by hash, so concatenating their outputs gives the table in ascending k-mer order.
-// HBM traffic: 40 B (histogram) + 64 B (scatter) + 32 B (replay) per occurrence instead of ~16 radix passes.
 // A bucket beyond 1024 occurrences (a k-mer more than ~1000 deep) goes through the device-wide path of sketch.hip, as a
 // small sample of its own.
 #include "common.h"
@@ -32,41 +38,181 @@ constexpr int IDX_BITS = 10;         // arrival index inside a bucket (< CAP_LAR
 // configuration, whose marker test is a hash table in LDS: linear in the bucket size.
 constexpr uint32_t SEG_LIMIT = 96;
 
-// boff[b] = first position (in the array sorted by bucket id) whose bucket is >= b, for b in [0, B].  Invalid occurrences
-// carry bucket id B and sort last, so boff[B] is also the number of valid occurrences (read by the replay kernels from
-// device memory: no host round trip before the replay).
-__global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint32_t* __restrict__ bk, uint32_t n_all, uint32_t B,
-                                                            uint32_t* __restrict__ boff) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_all) return;
-    const uint32_t lo = (i == 0) ? 0 : bk[i - 1] + 1;
-    const uint32_t hi = (i == n_all) ? B : min(bk[i], B);
-    for (uint32_t b = lo; b <= hi; b++) boff[b] = i;
-}
-
 // Bucket of a hash: hs = hash >> sh (its 32 most significant bits below the threshold), b = (hs * mult) >> 32 — B
 // equal ranges for ANY B (not only powers of two), monotone in the hash.  Inverse used by the replay kernel: the
 // smallest hs of bucket b is ceil(b * 2^32 / mult).
-struct BucketMap { int sh; uint32_t mult; uint32_t B; int composite; };
-__device__ __forceinline__ uint32_t bucket_of(uint64_t h, const BucketMap m) {
-    return min(__umulhi((uint32_t)(h >> m.sh), m.mult), m.B - 1u);
+// range_hs = widest bucket in hs units; sub_mult[i] = floor(2^32 * CAP_i / range_hs) for the three replay configurations (the
+// sub-range of a hash inside its bucket, see replay_bucket), 0 when a bucket is narrower than CAP_i hs units.
+struct BucketMap { int sh; uint32_t mult; uint32_t B; int composite; uint32_t range_hs; uint32_t sub_mult[3]; };
+
+__device__ __forceinline__ uint32_t bucket_of_key(uint32_t key, const BucketMap m) { return min(__umulhi(key, m.mult), m.B - 1u); }
+
+// ---- partition ------------------------------------------------------------------------------------------------------------
+// Where finish() reads the occurrences from: the dense arrays (hash[i], i < n_dense; INVALID_HASH entries are skipped) or the
+// slots of the session's one batch (slot_key[b * slot_cap + i], i < blk_count[b]; key = hash >> key_sh, written by the seeding
+// kernel).  The index an occurrence is known by — what the replay gathers its record with — is i, resp. b * slot_cap + i: both
+// grow with the file order.
+struct PartIn {
+    const uint64_t* hash;
+    const uint32_t* slot_key;
+    const uint32_t* blk_count;
+    uint32_t n_dense, n_blk, slot_cap, tile_entries;
+    int slotted, key_sh;
+};
+constexpr int PART_TPB = 256;
+constexpr uint32_t BLK_PER_TILE = 16;     // slotted: blocks of the seeding kernel per partition tile (~3,000 occurrences)
+constexpr uint32_t MAX_COARSE = 4096;     // coarse ranges (LDS counters of the histogram / scatter kernels)
+constexpr uint32_t MAX_FINE = 4096;       // buckets per coarse range (LDS counters of the fine kernel)
+constexpr uint32_t STAGE_PAIRS = 4096;    // pairs a scatter workgroup groups in LDS before writing them out in runs
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the tiles, so
+// that the runs two neighbouring tiles append to the same coarse range — adjacent in memory — meet in the same L2.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t n_tiles) {
+    const uint32_t per_xcd = (n_tiles + 7) / 8;
+    return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);      // may be >= n_tiles for the padding of the last XCD's range
 }
 
-// (also clears what the replay accumulates into — per-bucket counters, the two list heads, the tail words — instead of four
-//  memset dispatches)
-__global__ __launch_bounds__(256) void bucket_key_kernel(const uint64_t* __restrict__ hash, uint32_t n, BucketMap bm, uint32_t B,
-                                                         uint32_t* __restrict__ bk, uint32_t* __restrict__ idx,
-                                                         uint32_t* __restrict__ zero, uint32_t n_zero, uint32_t* __restrict__ tail16,
-                                                         uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b,
-                                                         uint32_t* __restrict__ list_c) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_zero) zero[i] = 0;
-    if (i < 16) tail16[i] = 0;
-    if (i == 0) { *list_a = 0; *list_b = 0; *list_c = 0; }
-    if (i >= n) return;
-    const uint64_t h = hash[i];
-    bk[i] = (h == INVALID_HASH) ? B : bucket_of(h, bm);
-    idx[i] = i;
+// f(key, index) for every occurrence of tile t (any order; all threads of the workgroup take part).  Slotted: eight groups of
+// 32 lanes walk eight blocks at a time (independent loads in flight instead of one block after the other).
+template <class F>
+__device__ __forceinline__ void for_tile_entries(const PartIn& in, uint32_t t, F&& f) {
+    if (in.slotted) {
+        const uint32_t grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+        for (uint32_t bl = grp; bl < BLK_PER_TILE; bl += PART_TPB / 32) {
+            const uint32_t b = t * BLK_PER_TILE + bl;
+            if (b >= in.n_blk) break;
+            const uint32_t cnt = min(in.blk_count[b], in.slot_cap), g0 = b * in.slot_cap;
+            for (uint32_t i = l; i < cnt; i += 32) f(in.slot_key[g0 + i], g0 + i);
+        }
+    } else {
+        const uint64_t i0 = (uint64_t)t * in.tile_entries;
+        for (uint32_t e = threadIdx.x; e < in.tile_entries; e += PART_TPB) {
+            const uint64_t i = i0 + e;
+            if (i >= in.n_dense) break;
+            const uint64_t h = in.hash[i];
+            if (h != INVALID_HASH) f((uint32_t)(h >> in.key_sh), (uint32_t)i);
+        }
+    }
+}
+
+// hist[c * n_tiles + t] = occurrences of tile t in coarse range c = bucket >> fine_bits
+// (also clears what the replay accumulates into — per-bucket counters, the list heads, the tail words — instead of memsets)
+__global__ __launch_bounds__(PART_TPB) void part_hist_kernel(PartIn in, BucketMap bm, int fine_bits, uint32_t C, uint32_t n_tiles,
+                                                             uint32_t* __restrict__ hist, uint32_t* __restrict__ zero, uint32_t n_zero,
+                                                             uint32_t* __restrict__ tail16, uint32_t* __restrict__ list_a,
+                                                             uint32_t* __restrict__ list_b, uint32_t* __restrict__ list_c) {
+    __shared__ uint32_t s_h[MAX_COARSE];
+    const uint32_t t = xcd_tile(n_tiles), gtid = blockIdx.x * PART_TPB + threadIdx.x;
+    for (uint32_t i = gtid; i < n_zero; i += gridDim.x * PART_TPB) zero[i] = 0;
+    if (gtid < 16) tail16[gtid] = 0;
+    if (gtid == 0) { *list_a = 0; *list_b = 0; *list_c = 0; }
+    if (t >= n_tiles) return;
+    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_h[c] = 0;
+    __syncthreads();
+    for_tile_entries(in, t, [&](uint32_t key, uint32_t) { atomicAdd(&s_h[bucket_of_key(key, bm) >> fine_bits], 1u); });
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) hist[(size_t)c * n_tiles + t] = s_h[c];
+}
+
+// exclusive prefix sum of one value per lane across the workgroup; total returned through *total
+template <int RTPB>
+__device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave, uint32_t* total);
+
+// one workgroup per coarse range: hist row -> exclusive offsets of the tiles inside the range; total[c] = size of the range
+__global__ __launch_bounds__(PART_TPB) void part_scan_kernel(uint32_t* __restrict__ hist, uint32_t n_tiles, uint32_t* __restrict__ total) {
+    __shared__ uint32_t s_wave[PART_TPB / 64];
+    uint32_t* row = hist + (size_t)blockIdx.x * n_tiles;
+    const uint32_t per = (n_tiles + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(n_tiles, a + per);
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; i++) sum += row[i];
+    uint32_t tot = 0;
+    uint32_t run = block_excl_sum<PART_TPB>(sum, s_wave, &tot);
+    for (uint32_t i = a; i < b; i++) { const uint32_t v = row[i]; row[i] = run; run += v; }
+    if (threadIdx.x == 0) total[blockIdx.x] = tot;
+}
+
+// (bucket, index) pairs of tile t -> their coarse ranges.  The workgroup first groups its pairs by range in LDS (count, scan,
+// place with an LDS atomic), then writes them out position by position: neighbouring lanes write neighbouring pairs of one
+// run (cbase[c] + offset of the tile inside the range + place inside the run) instead of 64 scattered 8-byte words per
+// instruction.  The order inside a run is NOT the file order — the replay restores it from the indices.
+__global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, BucketMap bm, int fine_bits, uint32_t C, uint32_t n_tiles,
+                                                                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ total,
+                                                                uint32_t* __restrict__ cbase, uint2* __restrict__ out) {
+    extern __shared__ uint32_t s_dyn[];                  // [C] cursor (count -> start -> cursor) | [C] gb | STAGE_PAIRS pairs
+    uint32_t* const s_cur = s_dyn;
+    uint32_t* const s_gb = s_dyn + C;                    // global position of the range's run minus its start in the tile order
+    uint2* const s_stage = reinterpret_cast<uint2*>(s_dyn + 2 * (size_t)C + ((2 * C) & 1u));
+    __shared__ uint32_t s_wave[PART_TPB / 64];
+    const uint32_t t = xcd_tile(n_tiles);
+    if (t >= n_tiles) return;
+    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_cur[c] = 0;
+    __syncthreads();
+    for_tile_entries(in, t, [&](uint32_t key, uint32_t) { atomicAdd(&s_cur[bucket_of_key(key, bm) >> fine_bits], 1u); });
+    __syncthreads();
+    uint32_t n_tile = 0;
+    {   // tile order: start[c] = exclusive sum of the tile's counts; cbase = exclusive sum of the range sizes
+        const uint32_t per = (C + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(C, a + per);
+        uint32_t sum_t = 0, sum_g = 0;
+        for (uint32_t c = a; c < b; c++) { sum_t += s_cur[c]; sum_g += total[c]; }
+        uint32_t tot_g = 0;
+        uint32_t run_t = block_excl_sum<PART_TPB>(sum_t, s_wave, &n_tile);
+        uint32_t run_g = block_excl_sum<PART_TPB>(sum_g, s_wave, &tot_g);
+        for (uint32_t c = a; c < b; c++) {
+            const uint32_t cnt = s_cur[c];
+            if (t == 0) cbase[c] = run_g;
+            s_gb[c] = run_g + offs[(size_t)c * n_tiles + t] - run_t;
+            s_cur[c] = run_t;
+            run_t += cnt;
+            run_g += total[c];
+        }
+        if (t == 0 && threadIdx.x == 0) cbase[C] = tot_g;
+    }
+    __syncthreads();
+    for_tile_entries(in, t, [&](uint32_t key, uint32_t idx) {
+        const uint32_t b = bucket_of_key(key, bm), c = b >> fine_bits;
+        const uint32_t p = atomicAdd(&s_cur[c], 1u);     // place in the tile order
+        if (p < STAGE_PAIRS) s_stage[p] = make_uint2(b, idx);
+        else out[s_gb[c] + p] = make_uint2(b, idx);      // (a tile fuller than the stage: the rest goes out directly)
+    });
+    __syncthreads();
+    const uint32_t n_staged = min(n_tile, STAGE_PAIRS);
+    for (uint32_t p = threadIdx.x; p < n_staged; p += PART_TPB) {
+        const uint2 v = s_stage[p];
+        out[s_gb[v.x >> fine_bits] + p] = v;
+    }
+}
+
+// one workgroup per coarse range: counting sort of its pairs by bucket in LDS -> perm (occurrence indices grouped by bucket) and
+// boff[b] = first position of bucket b, boff[B] = number of valid occurrences
+__global__ __launch_bounds__(PART_TPB) void part_fine_kernel(const uint2* __restrict__ pairs,
+                                                             const uint32_t* __restrict__ cbase, int fine_bits, uint32_t C, uint32_t B,
+                                                             uint32_t* __restrict__ boff, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t s_cnt[MAX_FINE];
+    __shared__ uint32_t s_wave[PART_TPB / 64];
+    const uint32_t c = blockIdx.x, F = 1u << fine_bits, b0 = c << fine_bits;
+    const uint32_t lo = cbase[c], hi = cbase[c + 1];
+    for (uint32_t f = threadIdx.x; f < F; f += PART_TPB) s_cnt[f] = 0;
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += PART_TPB) atomicAdd(&s_cnt[pairs[e].x - b0], 1u);
+    __syncthreads();
+    {
+        const uint32_t per = (F + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(F, a + per);
+        uint32_t sum = 0;
+        for (uint32_t f = a; f < b; f++) sum += s_cnt[f];
+        uint32_t run = lo + block_excl_sum<PART_TPB>(sum, s_wave, nullptr);
+        for (uint32_t f = a; f < b; f++) {
+            const uint32_t v = s_cnt[f];
+            s_cnt[f] = run;                              // becomes the bucket's cursor
+            if (b0 + f < B) boff[b0 + f] = run;
+            run += v;
+        }
+    }
+    if (c + 1 == C && threadIdx.x == 0) boff[B] = hi;
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += PART_TPB) {
+        const uint2 v = pairs[e];
+        perm[atomicAdd(&s_cnt[v.x - b0], 1u)] = v.y;
+    }
 }
 
 // exclusive prefix sum of one value per lane across the workgroup (4 waves); total returned through *total
@@ -95,13 +241,15 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave,
 
 // One workgroup = one bucket.  SINGLE_CUTOFF = 4 for single-end (sketch.rs:937), 0 for pairs.
 //
-// Ordering inside the bucket: the partition sort is stable and occurrences were appended in file order, so a bucket's
-// occurrences arrive ordered by (record, position); what is left is a STABLE sort by hash.  Each lane keeps its (up to
-// ITEMS) records in registers, publishes one 64-bit key per record in LDS and finds the record's sorted position by
-// counting smaller keys — every lane reads the same LDS word per step (a broadcast, no bank conflicts), the loop has no
-// barriers and no dependent LDS round trips, and it is O(n^2 / lanes) with n ~ 200.  Keys are unique: the bucket's hashes
-// lie in one narrow range, so key = (hash - lowest hash of the bucket) << 10 | arrival index whenever that difference fits
-// in 54 bits (bm.composite, decided by the host; else — tiny samples — the two-part comparison is spelled out).  Records are then written straight to their sorted slots.
+// Ordering inside the bucket: the partition hands over the bucket's occurrences in no particular order, but the index an
+// occurrence is gathered by (position in the dense arrays / slot number) grows with the file order: a first rank loop over the
+// indices gives every occurrence its ARRIVAL number (its place by (record, position) inside the bucket); what is left is a
+// sort by (hash, arrival).  Each lane keeps its (up to ITEMS) records in registers, publishes one 64-bit key per record in
+// LDS and finds the record's sorted position by counting smaller keys — every lane reads the same LDS word per step (a
+// broadcast, no bank conflicts), the loop has no barriers and no dependent LDS round trips, and it is O(n^2 / lanes) with
+// n ~ 200.  Keys are unique: the bucket's hashes lie in one narrow range, so key = (hash - lowest hash of the bucket) << 10 |
+// arrival number whenever that difference fits in 54 bits (bm.composite, decided by the host; else — tiny samples — the
+// two-part comparison is spelled out).  Records are then written straight to their sorted slots.
 // Handles buckets with min_n < n <= CAP; larger ones bump `overflow` (when count_overflow) and are left to the caller.
 template <int CAP, int RTPB>
 __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
@@ -115,7 +263,7 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
                                                              uint32_t* __restrict__ ovf_list, int dbg_stage) {
     constexpr int ITEMS = CAP / RTPB;     // records per lane
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
-    __shared__ uint16_t s_seg[CAP];       // first sorted position of the k-mer each sorted position belongs to
+    __shared__ __attribute__((aligned(8))) uint16_t s_seg[CAP];   // first sorted position of the k-mer each sorted position belongs to
     __shared__ uint8_t s_fl[CAP];         // bit0 skip, bit1 would-be-dropped
     __shared__ uint16_t s_a[CAP + 2], s_b[CAP + 2];   // exclusive counts <= CAP
     __shared__ uint32_t s_wave[RTPB / 64];
@@ -134,47 +282,126 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
         }
         return;
     }
-    // ---- gather (through the partition permutation, one 32 B sector per occurrence) + stable sort by hash ------------
+    // ---- gather (through the partition permutation, one 32 B sector per occurrence) + sort by (hash, file order) -------
     uint64_t* s_key = s_m0;               // keys live in s_m0 until the sorted records are written
     const bool composite = bm.composite != 0;
     // lowest hash that maps to this bucket: hs >= ceil(b * 2^32 / mult)  (exact inverse of bucket_of)
     const uint64_t lo_hash = composite ? (((((uint64_t)b << 32) + bm.mult - 1u) / bm.mult) << bm.sh) : 0ull;
     OccRec r[ITEMS];
-    uint64_t key[ITEMS];
+    uint32_t pidx[ITEMS], rank[ITEMS];
+    uint32_t* const s_pidx = reinterpret_cast<uint32_t*>(s_rid);   // (s_rid is free until the sorted records are written)
+    const int levels = (int)((n + RTPB - 1) / RTPB);   // lanes of level q hold a record iff q < levels (wave-uniform)
 #pragma unroll
     for (int q = 0; q < ITEMS; q++) {
         const uint32_t i = tid + q * RTPB;
-        key[q] = ~0ull;
+        pidx[q] = 0xFFFFFFFFu;
+        rank[q] = 0;
         if (i < n) {
-            r[q] = recs[perm[first + i]];
-            key[q] = composite ? (((r[q].hash - lo_hash) << IDX_BITS) | i) : r[q].hash;
-            s_key[i] = key[q];
+            pidx[q] = perm[first + i];
+            r[q] = recs[pidx[q]];
         }
     }
-    __syncthreads();
-    if (dbg_stage == 1) { if (tid == 0) n_distinct[b] = 0; return; }
-    uint32_t rank[ITEMS];
-#pragma unroll
-    for (int q = 0; q < ITEMS; q++) rank[q] = 0;
-    const int levels = (int)((n + RTPB - 1) / RTPB);   // lanes of level q hold a record iff q < levels (wave-uniform)
     if (composite) {
-#pragma unroll 8
-        for (uint32_t j = 0; j < n; j++) {
-            const uint64_t kj = s_key[j];
+        // Sub-bin sort, linear in the bucket: the bucket's hashes are uniform over its narrow range, so CAP equal sub-ranges hold
+        // about half an occurrence each.  Count per sub-range (LDS atomics), scan, drop every (hash, index) into its sub-range
+        // (any order), then each occurrence ranks itself among the few members of its own sub-range: sorted position =
+        // start of the sub-range + members with a smaller (hash, index).  The occurrences of one k-mer share a sub-range: for
+        // them that loop is as long as the k-mer is deep, like the marker test below.  (Rounds 1-2 ranked every occurrence
+        // against the whole bucket, n^2 comparisons; with the partition no longer stable a second such loop over the indices
+        // would have been needed on top.)
+        uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_m1);   // CAP + 1 counters (s_m1 is free until the sorted records are written)
+        const uint32_t sub_mult = bm.sub_mult[CAP == CAP_SMALL ? 0 : CAP == CAP_MID ? 1 : 2];
+        uint32_t sub[ITEMS];
+        for (uint32_t t = tid; t <= (uint32_t)CAP; t += RTPB) s_cnt[t] = 0;
+        __syncthreads();
 #pragma unroll
-            for (int q = 0; q < ITEMS; q++)
-                if (q < levels) rank[q] += (kj < key[q]) ? 1u : 0u;
+        for (int q = 0; q < ITEMS; q++) {
+            const uint32_t i = tid + q * RTPB;
+            sub[q] = 0;
+            if (i < n) {
+                const uint32_t hsres = (uint32_t)((r[q].hash - lo_hash) >> bm.sh);          // < bm.range_hs
+                sub[q] = sub_mult ? min(__umulhi(hsres, sub_mult), (uint32_t)CAP - 1u) : min(hsres, (uint32_t)CAP - 1u);
+                atomicAdd(&s_cnt[sub[q]], 1u);
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of the CAP counters (CAP / RTPB per lane): s_cnt[t] = start of sub-range t, s_cnt[CAP] = n
+            constexpr int PER = CAP / RTPB;
+            uint32_t v[PER], sum = 0;
+#pragma unroll
+            for (int e = 0; e < PER; e++) { v[e] = s_cnt[tid * PER + e]; sum += v[e]; }
+            uint32_t run = block_excl_sum<RTPB>(sum, s_wave, nullptr);
+#pragma unroll
+            for (int e = 0; e < PER; e++) { s_cnt[tid * PER + e] = run; run += v[e]; }
+            if (tid == RTPB - 1) s_cnt[CAP] = run;
+        }
+        __syncthreads();
+        // place (cursor = a second counter array would cost LDS: take places from the END of each sub-range instead, counting the
+        // start words' neighbours down is not possible either — so the places come from s_seg, which is free until the segments)
+        uint16_t* const s_fill = s_seg;                               // members placed so far per sub-range (<= CAP: 16 bits do)
+        for (uint32_t t = tid; t < (uint32_t)CAP; t += RTPB) s_fill[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const uint32_t i = tid + q * RTPB;
+            if (i < n) {
+                // 16-bit LDS atomics do not exist: the counter pairs share a word; add 1 or 65536 to the word and take the half
+                uint32_t* const w = reinterpret_cast<uint32_t*>(s_fill) + (sub[q] >> 1);
+                const uint32_t old = atomicAdd(w, (sub[q] & 1u) ? 65536u : 1u);
+                const uint32_t place = s_cnt[sub[q]] + ((sub[q] & 1u) ? (old >> 16) : (old & 0xFFFFu));
+                s_key[place] = r[q].hash;
+                s_pidx[place] = pidx[q];
+            }
+        }
+        __syncthreads();
+        if (dbg_stage == 1) { if (tid == 0) n_distinct[b] = 0; return; }
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const uint32_t i = tid + q * RTPB;
+            if (i < n) {
+                const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
+                uint32_t smaller = 0;
+                for (uint32_t p = lo; p < hi; p++) {
+                    const uint64_t kp = s_key[p];
+                    smaller += (kp < r[q].hash || (kp == r[q].hash && s_pidx[p] < pidx[q])) ? 1u : 0u;
+                }
+                rank[q] = lo + smaller;
+            }
         }
     } else {
-#pragma unroll 4
+        // tiny samples (the bucket's hash range does not fit the key): every occurrence against every other, as in rounds 1-2
+        uint16_t* const s_arr = s_a;                                  // (free until the counts)
+        uint32_t arrival[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const uint32_t i = tid + q * RTPB;
+            arrival[q] = 0;
+            if (i < n) s_pidx[i] = pidx[q];
+        }
+        __syncthreads();
+        // arrival number = how many of the bucket's occurrences come earlier in the file (their indices are distinct)
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t pj = s_pidx[j];
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++)
+                if (q < levels) arrival[q] += (pj < pidx[q]) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const uint32_t i = tid + q * RTPB;
+            if (i < n) { s_key[i] = r[q].hash; s_arr[i] = (uint16_t)arrival[q]; }
+        }
+        __syncthreads();
+        if (dbg_stage == 1) { if (tid == 0) n_distinct[b] = 0; return; }
         for (uint32_t j = 0; j < n; j++) {
             const uint64_t kj = s_key[j];
 #pragma unroll
             for (int q = 0; q < ITEMS; q++)
-                if (q < levels) rank[q] += ((kj < key[q]) || (kj == key[q] && j < tid + q * RTPB)) ? 1u : 0u;
+                if (q < levels && tid + q * RTPB < n)
+                    rank[q] += ((kj < r[q].hash) || (kj == r[q].hash && (uint32_t)s_arr[j] < arrival[q])) ? 1u : 0u;
         }
     }
-    __syncthreads();                      // every lane is done with s_key (= s_m0)
+    __syncthreads();                      // every lane is done with s_key (= s_m0), s_pidx (= s_rid), the counters (= s_m1, s_seg, s_a)
 #pragma unroll
     for (int q = 0; q < ITEMS; q++) {
         const uint32_t i = tid + q * RTPB;
@@ -463,6 +690,73 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_list_kernel(const OccRec* 
     }
 }
 
+// Table offsets in two levels, no library scan: workgroup w scans the 1024 buckets of its chunk — d_loc[b] = table rows of the
+// chunk's buckets before b — and leaves the chunk's row total and removed total; the compaction kernel adds the chunk totals
+// before w (at most 256 of them: B <= 2^18 on this path).
+constexpr uint32_t SCAN_CHUNK = 1024;
+__global__ __launch_bounds__(SCAN_CHUNK) void table_scan_kernel(const uint32_t* __restrict__ n_distinct, const uint32_t* __restrict__ removed_b,
+                                                                uint32_t B, uint32_t* __restrict__ d_loc, uint32_t* __restrict__ chunk_rows,
+                                                                unsigned long long* __restrict__ chunk_removed) {
+    __shared__ uint32_t s_wave[SCAN_CHUNK / 64];
+    __shared__ unsigned long long s_rem[SCAN_CHUNK / 64];
+    const uint32_t b = blockIdx.x * SCAN_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t v = b < B ? n_distinct[b] : 0u;
+    unsigned long long rem = b < B ? removed_b[b] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) rem += __shfl_xor(rem, d);
+    if (lane == 63) s_wave[wave] = x;
+    if (lane == 0) s_rem[wave] = rem;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < SCAN_CHUNK / 64; w++) { const uint32_t t = s_wave[w]; if (w < wave) base += t; tot += t; }
+    if (b < B) d_loc[b] = base + x - v;
+    if (threadIdx.x == 0) {
+        unsigned long long r = 0;
+        for (uint32_t w = 0; w < SCAN_CHUNK / 64; w++) r += s_rem[w];
+        chunk_rows[blockIdx.x] = tot;
+        chunk_removed[blockIdx.x] = r;
+    }
+}
+// out[rows before bucket b + i] = tmp[boff[b] + i] for i < n_distinct[b]; a workgroup walks buckets with its four wavefronts
+// (one bucket holds ~50 rows).  Also assembles the 28-byte tail block the host reads: {removed u64, overflow u32 (set by the
+// replay), n_seg u32, n_ovf u32, n_mid u32, n_large u32}.
+__global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __restrict__ tmp_k, const uint32_t* __restrict__ tmp_c,
+                                                            const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_loc,
+                                                            const uint32_t* __restrict__ chunk_rows, const unsigned long long* __restrict__ chunk_removed,
+                                                            const uint32_t* __restrict__ n_distinct, uint32_t B,
+                                                            uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
+                                                            const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ mid_list,
+                                                            const uint32_t* __restrict__ large_list, int skip_if_listed,
+                                                            uint32_t* __restrict__ tail) {
+    __shared__ uint32_t s_base[257];
+    const uint32_t n_chunks = (B + SCAN_CHUNK - 1) / SCAN_CHUNK;        // <= 256
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        unsigned long long rem = 0;
+        for (uint32_t w = 0; w < n_chunks; w++) { s_base[w] = run; run += chunk_rows[w]; rem += chunk_removed[w]; }
+        s_base[n_chunks] = run;
+        if (blockIdx.x == 0) {
+            *reinterpret_cast<unsigned long long*>(tail) = rem;
+            tail[3] = run; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
+        }
+    }
+    __syncthreads();
+    // buckets are still waiting for the list-driven configurations: the host will come back after running them (a long-read
+    // table has tens of millions of rows: copying it twice would cost more than the configurations themselves)
+    if (skip_if_listed && (mid_list[0] | large_list[0])) return;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        const uint32_t n = n_distinct[b], s0 = boff[b], d = s_base[b / SCAN_CHUNK] + d_loc[b];
+        for (uint32_t i = lane; i < n; i += 64) { out_k[d + i] = tmp_k[s0 + i]; out_c[d + i] = tmp_c[s0 + i]; }
+    }
+}
+// (large B: the per-bucket removed counts summed on their own, the scan left to the library)
 __global__ __launch_bounds__(1024) void sum_removed_kernel(const uint32_t* __restrict__ removed_b, uint32_t B,
                                                            unsigned long long* __restrict__ out) {
     __shared__ unsigned long long s[16];
@@ -526,17 +820,21 @@ __global__ __launch_bounds__(1024) void ovf_offsets_kernel(const uint32_t* __res
     }
 }
 
-// copies the occurrences of listed bucket i (file order inside the bucket) to sub_*[sub_off[i] ..)
-__global__ __launch_bounds__(256) void ovf_gather_kernel(const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ sub_off,
-                                                         const uint32_t* __restrict__ boff, const uint32_t* __restrict__ perm,
-                                                         const OccRec* __restrict__ recs, uint64_t* __restrict__ sub_hash,
-                                                         OccRec* __restrict__ sub_recs) {
+// the occurrence indices of listed bucket i -> sub_idx[sub_off[i] ..): sorted afterwards, they are the listed buckets'
+// occurrences in FILE order (what the device-wide path expects of its input)
+__global__ __launch_bounds__(256) void ovf_indices_kernel(const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ sub_off,
+                                                          const uint32_t* __restrict__ boff, const uint32_t* __restrict__ perm,
+                                                          uint32_t* __restrict__ sub_idx) {
     const uint32_t b = ovf_list[1 + blockIdx.x], first = boff[b], n = boff[b + 1] - first, o = sub_off[blockIdx.x];
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        const OccRec r = recs[perm[first + j]];
-        sub_hash[o + j] = r.hash;
-        sub_recs[o + j] = r;
-    }
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) sub_idx[o + j] = perm[first + j];
+}
+__global__ __launch_bounds__(256) void ovf_gather_kernel(const uint32_t* __restrict__ sorted_idx, uint32_t n, const OccRec* __restrict__ recs,
+                                                         uint64_t* __restrict__ sub_hash, OccRec* __restrict__ sub_recs) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const OccRec r = recs[sorted_idx[j]];
+    sub_hash[j] = r.hash;
+    sub_recs[j] = r;
 }
 
 // the (k-mer, count) rows the device-wide path produced for listed bucket i go to the bucket's slots of the temporary table
@@ -573,7 +871,8 @@ uint32_t grid_of(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 
 
 bool finish_bucketed(sylph_sketch* sk) {
     sylph_ctx* ctx = sk->ctx;
-    const uint32_t n_all = (uint32_t)sk->n_occ;
+    const bool slotted = sk->pend.live;                // the sample's one batch, still in its slots (reads.hip)
+    const uint32_t n_all = slotted ? sk->pend.n : (uint32_t)sk->n_occ;
     sk->n_out = 0;
     sk->dup_removed = 0;
     if (n_all == 0) return true;
@@ -583,22 +882,56 @@ bool finish_bucketed(sylph_sketch* sk) {
     const uint32_t TARGET = ctx->bucket_target;
     const uint32_t B = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, n_all / TARGET), 1u << 24);
     BucketMap bm;
-    bm.sh = std::max(0, bit_length(thr) - 32);
+    bm.sh = key_shift(sk->c);
     const uint64_t hs_max = thr >> bm.sh;                              // hashes are < thr
     bm.mult = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)B << 32) / (hs_max + 1));
     bm.B = B;
     // widest bucket in hs units is ceil(2^32 / mult) + 1; the key needs (range << sh) to fit in 64 - IDX_BITS bits
     const uint64_t range_hs = (0x100000000ull + bm.mult - 1) / std::max<uint32_t>(1, bm.mult) + 1;
     bm.composite = bm.mult >= 1 && bit_length(range_hs) + bm.sh <= 64 - IDX_BITS;
-    DevBuf &b_idx = ctx->scratch[0], &b_keys = ctx->scratch[1], &b_perm = ctx->scratch[2], &b_tmpk = ctx->scratch[3],
+    bm.range_hs = (uint32_t)std::min<uint64_t>(range_hs, 0xFFFFFFFFull);
+    {
+        const uint32_t caps[3] = {(uint32_t)CAP_SMALL, (uint32_t)CAP_MID, (uint32_t)CAP_LARGE};
+        for (int i = 0; i < 3; i++) bm.sub_mult[i] = range_hs > caps[i] ? (uint32_t)(((uint64_t)caps[i] << 32) / range_hs) : 0u;
+    }
+    // partition geometry: F = 2^fine_bits buckets per coarse range (about 512 ranges), tiles of occurrences
+    int fine_bits = 6;
+    while ((1u << fine_bits) < MAX_FINE && ((B + (1u << fine_bits) - 1) >> fine_bits) > 512) fine_bits++;
+    const uint32_t C = (B + (1u << fine_bits) - 1) >> fine_bits;
+    SY_REQUIRE(C <= MAX_COARSE, "internal: %u coarse ranges", C);
+    PartIn in{};
+    in.slotted = slotted ? 1 : 0;
+    in.key_sh = bm.sh;
+    uint32_t n_tiles;
+    const OccRec* recs;
+    if (slotted) {
+        in.slot_key = sk->slot_key.as<uint32_t>();
+        in.n_blk = sk->pend.n_blk;
+        in.slot_cap = sk->pend.slot_cap;
+        in.blk_count = sk->slot_meta.as<uint32_t>() + (sk->pend.n_blk + 1);   // (layout: reads.hip SlotMeta)
+        n_tiles = (in.n_blk + BLK_PER_TILE - 1) / BLK_PER_TILE;
+        recs = sk->slot_rec.as<OccRec>();
+    } else {
+        in.hash = sk->hash.as<uint64_t>();
+        in.n_dense = n_all;
+        in.tile_entries = (uint32_t)std::max<uint64_t>(4096, ((uint64_t)n_all + 65535) / 65536);   // at most 65,536 tiles
+        n_tiles = (uint32_t)(((uint64_t)n_all + in.tile_entries - 1) / in.tile_entries);
+        recs = sk->recs.as<OccRec>();
+    }
+    DevBuf &b_hist = ctx->scratch[0], &b_pairs = ctx->scratch[1], &b_perm = ctx->scratch[2], &b_tmpk = ctx->scratch[3],
            &b_tmpc = ctx->scratch[4], &b_small = ctx->scratch[5], &b_bk = ctx->scratch[6];
-    b_idx.reserve((size_t)n_all * 4);
-    b_keys.reserve((size_t)n_all * 8);
+    b_hist.reserve(((size_t)C * n_tiles + 2 * (size_t)C + 2) * 4);      // hist (C x n_tiles) | total (C) | cbase (C + 1)
+    b_pairs.reserve((size_t)n_all * 8);                                 // (bucket, occurrence index) pairs grouped by coarse range
     b_perm.reserve((size_t)n_all * 4);
     b_tmpk.reserve((size_t)n_all * 8);
     b_tmpc.reserve((size_t)n_all * 4);
     b_small.reserve(64);
-    b_bk.reserve((size_t)(B + 2) * 4 * 7);      // boff | large_list | ovf_list | n_distinct | removed | d_off | mid_list   (each B+2)
+    // boff | large_list | ovf_list | n_distinct | removed | d_off | mid_list (each B+2) | chunk_rows (264) | chunk_removed (264 u64)
+    b_bk.reserve((size_t)(B + 2) * 4 * 7 + 264 * 4 + 264 * 8 + 16);
+    uint32_t* hist = b_hist.as<uint32_t>();
+    uint32_t* ctotal = hist + (size_t)C * n_tiles;
+    uint32_t* cbase = ctotal + C;
+    uint2* pairs = b_pairs.as<uint2>();
     uint32_t* boff = b_bk.as<uint32_t>();
     uint32_t* large_list = boff + (B + 2);      // [0] = number of buckets queued for the large configuration, [1..] = ids
     uint32_t* ovf_list = large_list + (B + 2);  // [0] = number of buckets beyond the large configuration, [1..] = ids
@@ -606,14 +939,12 @@ bool finish_bucketed(sylph_sketch* sk) {
     uint32_t* removed_b = n_distinct + (B + 2);
     uint32_t* d_off = removed_b + (B + 2);
     uint32_t* mid_list = d_off + (B + 2);       // buckets for the medium configuration (n <= CAP_MID, or a long k-mer segment)
+    uint32_t* chunk_rows = mid_list + (B + 2) + ((B & 1u) ? 1 : 0);       // (8-byte aligned: 7 * (B + 2) words is odd for odd B)
+    unsigned long long* chunk_removed = reinterpret_cast<unsigned long long*>(chunk_rows + 264);
     unsigned long long* d_removed = b_small.as<unsigned long long>();
     uint32_t* d_overflow = reinterpret_cast<uint32_t*>(b_small.as<uint8_t>() + 8);
     const uint32_t* d_nv = boff + B;            // boff[B] = number of valid occurrences
-    const uint32_t n_zero = (B + 2) * 2;                                            // n_distinct and removed (cleared by bucket_key_kernel)
-    // partition: stable radix sort of (bucket id -> occurrence index) on bit_length(B) bits (2-3 passes of 4-byte keys
-    // instead of 8 passes of 8-byte keys); occurrences were appended in file order and the sort is stable
-    uint32_t* bk_in = b_keys.as<uint32_t>();
-    uint32_t* bk_sorted = bk_in + n_all;
+    const uint32_t n_zero = (B + 2) * 2;                                            // n_distinct and removed (cleared by part_hist_kernel)
     // every launch below takes its sizes from device memory; the host synchronises ONCE, at the end (unless some buckets need
     // the list-driven configurations or the device-wide path)
     const int dbg = getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0;
@@ -622,27 +953,44 @@ bool finish_bucketed(sylph_sketch* sk) {
     sk->out_c.reserve((size_t)n_all * 4);
     {
         HostPhase ph(ctx, "finish(bucket): partition + LDS replay + compact");
-        hipLaunchKernelGGL(bucket_key_kernel, dim3(grid_of(std::max(n_all, std::max(n_zero, 16u)))), dim3(256), 0, ctx->stream,
-                           sk->hash.as<uint64_t>(), n_all, bm, B, bk_in, b_idx.as<uint32_t>(), n_distinct, n_zero, b_small.as<uint32_t>(),
-                           large_list, ovf_list, mid_list);
-        sort_pairs_u32_u32(ctx, bk_in, bk_sorted, b_idx.as<uint32_t>(), b_perm.as<uint32_t>(), n_all, 0, bit_length(B));
+        {
+            ScopedKernelTimer t(ctx, "sort");   // the partition: what the library's radix sort of (bucket, index) pairs used to do
+            const uint32_t tile_grid = ((n_tiles + 7) / 8) * 8;      // (padded: xcd_tile deals every XCD a contiguous eighth)
+            hipLaunchKernelGGL(part_hist_kernel, dim3(tile_grid), dim3(PART_TPB), 0, ctx->stream, in, bm, fine_bits, C, n_tiles, hist, n_distinct,
+                               n_zero, b_small.as<uint32_t>(), large_list, ovf_list, mid_list);
+            hipLaunchKernelGGL(part_scan_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, hist, n_tiles, ctotal);
+            hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)C + 2 * (size_t)STAGE_PAIRS) * 4, ctx->stream, in, bm,
+                               fine_bits, C, n_tiles, hist, ctotal, cbase, pairs);
+            hipLaunchKernelGGL(part_fine_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
+                               b_perm.as<uint32_t>());
+        }
         {
             ScopedKernelTimer t(ctx, "replay");
-            hipLaunchKernelGGL(bucket_bounds_kernel, dim3(grid_of((uint64_t)n_all + 1)), dim3(256), 0, ctx->stream, bk_sorted, n_all, B,
-                               boff);
             hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
-                               sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
+                               recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
                                b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, mid_list, large_list,
                                ovf_list, dbg);
         }
     }
     // removed counts, table offsets, compaction, and everything the host needs to know in one 28-byte block
     auto close_table = [&](int skip_if_listed) {
-        {
+        if (B <= (1u << 18)) {      // two levels of 1024: scan + compaction, two dispatches
             ScopedKernelTimer t(ctx, "replay");
-            hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
+            hipLaunchKernelGGL(table_scan_kernel, dim3((B + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_CHUNK), 0, ctx->stream, n_distinct, removed_b, B,
+                               d_off, chunk_rows, chunk_removed);
+            hipLaunchKernelGGL(table_compact_kernel, dim3(std::min<uint32_t>((B + 3) / 4, 1u << 15)), dim3(256), 0, ctx->stream,
+                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, chunk_rows, chunk_removed, n_distinct, B,
+                               sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, skip_if_listed,
+                               b_small.as<uint32_t>());
+            SY_HIP(hipGetLastError());
+            return;
+        } else {
+            {
+                ScopedKernelTimer t(ctx, "replay");
+                hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
+            }
+            exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
         }
-        exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
         {
             ScopedKernelTimer t(ctx, "replay");
             hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
@@ -671,12 +1019,12 @@ bool finish_bucketed(sylph_sketch* sk) {
             ScopedKernelTimer t(ctx, "replay");
             if (host.n_mid)
                 hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_MID, RTPB_MID>), dim3(std::min<uint32_t>(host.n_mid, 1280u)),
-                                   dim3(RTPB_MID), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
+                                   dim3(RTPB_MID), 0, ctx->stream, recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
                                    sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
                                    d_overflow, mid_list, large_list, ovf_list, dbg);
             if (host.n_large)
                 hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(host.n_large, 512u)),
-                                   dim3(RTPB_LARGE), 0, ctx->stream, sk->recs.as<OccRec>(), b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
+                                   dim3(RTPB_LARGE), 0, ctx->stream, recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
                                    sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
                                    d_overflow, large_list, large_list, ovf_list, dbg);
         }
@@ -692,17 +1040,23 @@ bool finish_bucketed(sylph_sketch* sk) {
         if (ctx->finish_mode == 2 || host.n_ovf > 4096) return false;
         HostPhase ph(ctx, "finish(bucket): overflowing buckets through the device-wide path");
         const uint32_t m = host.n_ovf;
-        DevBuf b_so(ctx), b_sh(ctx), b_sr(ctx), sub_k(ctx), sub_c(ctx);
+        DevBuf b_so(ctx), b_si(ctx), b_sh(ctx), b_sr(ctx), sub_k(ctx), sub_c(ctx);
         b_so.reserve(((size_t)m + 1) * 4);
         hipLaunchKernelGGL(ovf_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, ovf_list, boff, b_so.as<uint32_t>());
         uint32_t n_sub = 0;
         ctx->read_back(&n_sub, b_so.as<uint32_t>() + m, 4);
+        b_si.reserve((size_t)n_sub * 8);            // indices | sorted indices
         b_sh.reserve((size_t)n_sub * 8);
         b_sr.reserve((size_t)n_sub * sizeof(OccRec));
+        uint32_t* sub_idx = b_si.as<uint32_t>();
+        uint32_t* sub_sorted = sub_idx + n_sub;
+        hipLaunchKernelGGL(ovf_indices_kernel, dim3(m), dim3(256), 0, ctx->stream, ovf_list, b_so.as<uint32_t>(), boff,
+                           b_perm.as<uint32_t>(), sub_idx);
+        sort_keys_u32(ctx, sub_idx, sub_sorted, n_sub, 0, 32);       // ascending index = file order
         {
             ScopedKernelTimer t(ctx, "replay_overflow");   // (family of its own so that tests can see this path was taken)
-            hipLaunchKernelGGL(ovf_gather_kernel, dim3(m), dim3(256), 0, ctx->stream, ovf_list, b_so.as<uint32_t>(), boff,
-                               b_perm.as<uint32_t>(), sk->recs.as<OccRec>(), b_sh.as<uint64_t>(), b_sr.as<OccRec>());
+            hipLaunchKernelGGL(ovf_gather_kernel, dim3(grid_of(n_sub)), dim3(256), 0, ctx->stream, sub_sorted, n_sub, recs,
+                               b_sh.as<uint64_t>(), b_sr.as<OccRec>());
         }
         uint64_t n_sub_out = 0, removed_sub = 0;
         generic_replay(ctx, b_sh.as<uint64_t>(), b_sr.as<OccRec>(), n_sub, sk->paired, sk->no_dedup, sub_k, sub_c, n_sub_out, removed_sub);
@@ -712,14 +1066,7 @@ bool finish_bucketed(sylph_sketch* sk) {
             hipLaunchKernelGGL(ovf_patch_kernel, dim3(m), dim3(256), 0, ctx->stream, ovf_list, bm, sub_k.as<uint64_t>(),
                                sub_c.as<uint32_t>(), (uint32_t)n_sub_out, boff, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct);
         }
-        exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
-        {
-            ScopedKernelTimer t(ctx, "replay");
-            hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
-                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, 0, b_small.as<uint32_t>());
-        }
-        SY_HIP(hipGetLastError());
+        close_table(0);
         read_tail();
     }
     sk->n_out = host.n_seg;

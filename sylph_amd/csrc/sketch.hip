@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t* __r
 static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases,
                           int enc) {
     sylph_ctx* ctx = sk->ctx;
+    flush_pending_slots(sk);   // a further batch: the previous one's occurrences (still in their slots) go to the dense arrays first
     // short-read batches (mean record length <= 300): one lane per record, seeding + markers fused (reads.hip); it declines
     // (returns false) when some record is longer than its halo, and the position kernel + annotate below take over
     bool done = false;
@@ -754,13 +755,14 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
     HostPhase ph_total(ctx, "finish: total incl. readback");
-    SY_REQUIRE(sk->n_occ < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
+    SY_REQUIRE(sk->n_occ + sk->pend.n < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
     // fast path: bucket partition + in-LDS replay (replay_lds.hip); falls through to the device-wide sort path
     // below when a bucket does not fit in LDS (some k-mer with thousands of occurrences)
     if (ctx->finish_mode != 1) {
         if (finish_bucketed(sk)) { sk->finished = true; return; }
         SY_REQUIRE(ctx->finish_mode != 2, "bucket finish overflowed and finish=bucket forbids the fallback");
     }
+    flush_pending_slots(sk);   // the device-wide path works on the dense file-order arrays
     sk->n_out = 0;
     sk->dup_removed = 0;
     generic_replay(ctx, sk->hash.as<uint64_t>(), sk->recs.as<OccRec>(), (uint32_t)sk->n_occ, sk->paired, sk->no_dedup, sk->out_k,

@@ -1,5 +1,7 @@
 // sketch_session.h — state of one read-sketch session (shared by sketch.hip and replay_lds.hip).
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace sylph {
@@ -12,9 +14,23 @@ struct alignas(32) OccRec { uint64_t hash, rid, m0, m1; };
 }  // namespace sylph
 
 namespace sylph {
+void flush_pending_slots(sylph_sketch* sk);   // reads.hip
+// bits of a hash kept in the 32-bit bucket key of an occurrence: key = hash >> key_shift(c) (hashes are below u64::MAX / c)
+inline int key_shift(uint32_t c) { return std::max(0, bit_length(UINT64_MAX / (uint64_t)std::max<uint32_t>(c, 1)) - 32); }
 void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, bool no_dedup,
                     DevBuf& out_k, DevBuf& out_c, uint64_t& n_out, uint64_t& removed_out);   // sketch.hip
 }
+
+namespace sylph {
+// The occurrences of the last short-read batch, still in the per-block slots the seeding kernel wrote them to (reads.hip).
+// A sample that arrives in ONE batch — the device-resident case — never has them compacted: finish() partitions straight from
+// the slots (replay_lds.hip).  A further batch, a batch with overflowing blocks, or the device-wide finish move them to the
+// dense file-order arrays first (flush_pending_slots).
+struct PendingSlots {
+    bool live = false;
+    uint32_t n_blk = 0, slot_cap = 0, n = 0;   // blocks, slots per block, occurrences in the region
+};
+}  // namespace sylph
 
 struct sylph_sketch {
     sylph_ctx* ctx;
@@ -26,12 +42,14 @@ struct sylph_sketch {
     sylph::DevBuf hash;                   // hash of every occurrence, file order (sort key)
     sylph::DevBuf recs;                   // OccRec of every occurrence, file order
     sylph::DevBuf slot_bases[2], slot_off[2];   // device slots of the host-batch pipeline (copy stream fills one, kernels read the other)
+    sylph::DevBuf slot_rec, slot_key, slot_meta;   // reads.hip: per-block occurrence slots (OccRec | 32-bit bucket key) and block tables
+    sylph::PendingSlots pend;
     sylph::DevBuf batch_ascii;            // a packed batch expanded to ASCII for the position-kernel path
     sylph::DevBuf out_k, out_c;           // final table
     uint64_t n_out = 0, dup_removed = 0;
     sylph::DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
     explicit sylph_sketch(sylph_ctx* cx)
         : ctx(cx), hash(cx), recs(cx), slot_bases{sylph::DevBuf(cx), sylph::DevBuf(cx)}, slot_off{sylph::DevBuf(cx), sylph::DevBuf(cx)},
-          batch_ascii(cx), out_k(cx), out_c(cx), counters(cx) {}
+          slot_rec(cx), slot_key(cx), slot_meta(cx), batch_ascii(cx), out_k(cx), out_c(cx), counters(cx) {}
 };
 
