@@ -469,7 +469,10 @@ def main():
         torch.cuda.synchronize()
         return agree((time.perf_counter() - t_s) / n)      # slowest rank's seconds per sample
 
-    n_cal = spb * max(2, int(round(0.25 / (spb * max(n_bases, 1e8) / 1e9 * 1.5e-3))))       # ~0.25 s per mode
+    # ~0.25 s per mode, sized from one probe batch timed first (all ranks agree on the count; a debug run with several ranks on
+    # one GPU and host-copy collectives is orders of magnitude slower per batch than the real thing)
+    t_batch = measure("sequential", spb) * spb
+    n_cal = spb * int(min(400, max(2, round(0.25 / max(t_batch, 1e-6)))))
     cal = {"samples_per_mode": n_cal}
     for mode in ("pipelined", "sequential"):
         if args.mode in ("auto", mode) or not args.no_second_leg:
@@ -492,6 +495,8 @@ def main():
         profiled = [pipe_box[0]] if mode == "pipelined" else [ctx]
         for o in profiled:
             o.profile(not args.no_kernel_timers)
+        if comm is not None:
+            db.exchange_stats(reset=True)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -509,6 +514,8 @@ def main():
         fam = {}
         for f in ("seeds", "compact", "annotate", "sort", "replay", "probe", "exchange"):   # HIP events on the launch streams, all contexts
             fam[f] = profiled[0].kernel_stats(f) if not args.no_kernel_timers else (0.0, 0)
+        if comm is not None:
+            fam["_exchange_totals"] = db.exchange_stats()
         for o in profiled:
             o.profile(False)
         return elapsed, list(np.diff(bounds)), list(np.diff([t_start] + stamps)), rows, fam
@@ -540,7 +547,13 @@ def main():
              # stage times as the sample saw them (wall clock inside its stage; pipelined: stages of different samples overlap)
              "sketch_ms": round(float(np.mean([r[0] for r in rws])) * 1e3, 3), "profile_ms": round(float(np.mean([r[1] for r in rws])) * 1e3, 3),
              "probe_batch_mean": round(float(np.mean([r[5] for r in rws])), 2),
-             "kernel_ms": {f: (round(v[0] / max(1, v[1]), 4), int(v[1])) for f, v in fm.items() if v[1]}}
+             "kernel_ms": {f: (round(v[0] / max(1, v[1]), 4), int(v[1])) for f, v in fm.items() if not f.startswith("_") and v[1]}}
+        if fm.get("_exchange_totals", (0,))[0]:
+            nb, tb, hb = fm["_exchange_totals"]
+            xt = fm.get("exchange", (0.0, 0))
+            # the two payload all-to-alls of a probe batch on THIS rank (rank 0): bytes sent to the other ranks, HIP-event time
+            d["exchange"] = {"probe_batches": nb, "table_slice_bytes_sent_per_batch": int(tb / nb), "hit_bytes_sent_per_batch": int(hb / nb),
+                             "all_to_all_ms_per_batch": round(xt[0] / nb, 4) if xt[1] else None}
         d["sketch_gbp_per_s"] = round(world * n_bases / 1e9 / max(d["sketch_ms"] * 1e-3 / workers_busy, 1e-9), 3)
         d["genome_comparisons_per_s"] = round(world * n_total / max(d["profile_ms"] * 1e-3, 1e-9), 1)
         return d
@@ -573,6 +586,7 @@ def main():
         "sketch_ms": main_leg["sketch_ms"], "profile_ms": main_leg["profile_ms"], "probe_batch_mean": main_leg["probe_batch_mean"],
         "sample_table_entries": int(np.mean([r[2] for r in rows])), "dup_removed": int(np.mean([r[3] for r in rows])),
         "kernel_ms": main_leg["kernel_ms"],
+        **({"exchange": main_leg["exchange"]} if "exchange" in main_leg else {}),
         "setup": dbstats,
     }
     legs = {mode: (fam, rows)}

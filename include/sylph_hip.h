@@ -281,6 +281,10 @@ int sylph_db_contain_batch_sharded(sylph_db *db, sylph_comm *comm, const sylph_s
                                    const void **covs, uint32_t *cov_width, uint64_t *out_n_covs);
 
 
+/* Exchange totals of a sharded database since the last reset: batches run, bytes of table slices and of hits this rank SENT to
+ * other ranks (the payload of the two all-to-alls; the all-gathers of sizes carry a few KB).  For scaling reports. */
+int sylph_db_exchange_stats(sylph_db *db, uint64_t *batches, uint64_t *table_bytes_sent, uint64_t *hit_bytes_sent, int reset);
+
 /* ---- a stream of samples through both stages (sketch -> profile), overlapped inside the library -------------------------- */
 
 /* The reference runs its samples on the rayon pool (sketch.rs:313,371 sketches files on parallel workers; contain.rs:267-289 walks

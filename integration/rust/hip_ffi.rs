@@ -116,6 +116,7 @@ extern "C" {
                                           cov_off: *mut *const u64, covs: *mut *const c_void, cov_width: *mut u32,
                                           out_n_covs: *mut u64) -> c_int;
     pub fn sylph_db_destroy(db: *mut SylphDb);
+    pub fn sylph_db_exchange_stats(db: *mut SylphDb, batches: *mut u64, table_bytes_sent: *mut u64, hit_bytes_sent: *mut u64, reset: c_int) -> c_int;
     // ---- round 3: the sample loop of `sylph profile` (contain.rs:267-289 over sketch.rs:313,371) as a pipeline inside the
     // library: sketch workers + one profile thread; submit samples, take results in submission order
     pub fn sylph_pipeline_create(db: *mut SylphDb, cfg: *const SylphPipelineConfig, out: *mut *mut SylphPipeline) -> c_int;

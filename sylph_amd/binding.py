@@ -32,7 +32,7 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_comm_create_rccl", "sylph_comm_create", "sylph_comm_destroy", "sylph_db_contain_batch_sharded",
            "sylph_pipeline_create", "sylph_pipeline_submit", "sylph_pipeline_submit_session", "sylph_pipeline_flush", "sylph_pipeline_next",
            "sylph_pipeline_outstanding", "sylph_pipeline_set_option", "sylph_pipeline_profile", "sylph_pipeline_kernel_stats",
-           "sylph_pipeline_destroy"]
+           "sylph_pipeline_destroy", "sylph_db_exchange_stats"]
 
 
 def load():
@@ -96,6 +96,7 @@ def load():
     L.sylph_comm_destroy.argtypes = [vp]
     L.sylph_comm_destroy.restype = None
     L.sylph_db_contain_batch_sharded.argtypes = [vp, vp, vp, u32, i32, dbl, P(vp), P(vp), P(vp), P(u32), P(u64)]
+    L.sylph_db_exchange_stats.argtypes = [vp, P(u64), P(u64), P(u64), i32]
     L.sylph_pipeline_create.argtypes = [vp, vp, P(vp)]
     L.sylph_pipeline_submit.argtypes = [vp, vp, u32, i32, i32, u64]
     L.sylph_pipeline_submit_session.argtypes = [vp, vp, u64]
@@ -475,6 +476,12 @@ class Database:
         _check(load().sylph_db_contain_batch_sharded(self._h, comm._h, arr, len(samples), MEM_DEVICE if device_ptrs else MEM_HOST,
                                                      float(min_number_kmers), C.byref(pc), C.byref(po), C.byref(pv), C.byref(cw), C.byref(nh)))
         return self._batch_views(len(samples), pc, po, pv, nh, cw)
+
+    def exchange_stats(self, reset=False):
+        """-> (batches, table bytes sent to other ranks, hit bytes sent to other ranks) of a sharded database"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(load().sylph_db_exchange_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)))
+        return int(a.value), int(b.value), int(c.value)
 
     def attach_tracked(self, tracked_kmers, tracked_off):
         k, off = _np(tracked_kmers, np.uint64), _np(tracked_off, np.uint64)

@@ -130,6 +130,7 @@ struct sylph_db {
     std::vector<uint64_t> bounds;
     uint32_t world = 1, rank = 0;
     uint64_t shard_hit_cap = 1ull << 20;     // hits per rank in the all-gathered block; doubles identically on every rank
+    uint64_t x_batches = 0, x_table_bytes = 0, x_hit_bytes = 0;   // exchange totals (sylph_db_exchange_stats): batches, bytes sent to OTHER ranks
     sylph::DevBuf rank_of, ani, lost;        // reassign pass: rank[g] in the passing list (or ~0), ANI per rank, kmers_lost[g]
     // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
     sylph::DevBuf q_kmers, q_counts, q_refs, hits, hits_sorted, res, counter;   // res: device copy of the result block

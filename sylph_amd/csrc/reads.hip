@@ -167,8 +167,11 @@ __global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __re
     blk_rec[b] = (uint32_t)lo;
 }
 
+#ifndef SYLPH_READS_WAVES
+#define SYLPH_READS_WAVES 5
+#endif
 template <int K, int HV, int ENC>
-__global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(5, 5))) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
+__global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READS_WAVES, SYLPH_READS_WAVES))) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
                                                      const uint64_t* __restrict__ off, uint64_t n_rec,
                                                      const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
                                                      int avx2_compat, int paired, int want_markers, uint64_t rec_base,

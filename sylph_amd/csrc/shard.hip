@@ -398,7 +398,12 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
                 SY_HIP(hipGetLastError());
             }
         }
-        comm->all_to_all(db->x_send.p, send_off.data(), db->x_recv.p, recv_off.data(), st);
+        {
+            ScopedKernelTimer t(ctx, "exchange");
+            comm->all_to_all(db->x_send.p, send_off.data(), db->x_recv.p, recv_off.data(), st);
+        }
+        db->x_batches++;
+        db->x_table_bytes += send_off[W] - (send_off[me + 1] - send_off[me]);
 
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 3: probe"));
         // ---- 3. probe every received slice against the resident shard; row = global sample index * G + genome
@@ -415,29 +420,52 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
                 ok += len * 8; oc += len * 4;
             }
         }
-        uint32_t max_count = 0, n_hits = 0;
-        if (S_total) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
+        // A failure on ONE rank between two collectives (a batch beyond the probe's limits, a hit buffer that cannot grow, a HIP
+        // error) must not leave the others waiting in the next collective: the rank goes on with an empty hit list and raises
+        // an error word in the size block every rank is about to receive — all ranks then fail this call together.
+        uint32_t max_count = 0, n_hits = 0, local_err = 0;
+        std::string local_msg;
+        if (S_total) {
+            try { n_hits = probe_batch(db, refs, min_number_kmers, &max_count); }
+            catch (const ArgError& e) { local_err = 1; local_msg = e.msg; }
+            catch (const HipError& e) { local_err = 2; local_msg = std::string("HIP error in the probe: ") + hipGetErrorString(e.e); (void)hipGetLastError(); }
+            catch (const std::bad_alloc&) { local_err = 3; local_msg = "host allocation failed in the probe"; }
+            if (local_err) { n_hits = 0; max_count = 0; }
+        }
 
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 4: owner counts + all-gather sizes"));
-        // ---- 4. group the hits by owner rank; all-gather the group sizes: block = [count for rank 0..W-1 | largest count value]
-        // x_meta (reused): [prefix (W + 1) u64 | my sizes (W + 1) u32 | cursors (W) u32 | starts (W) u32 | gathered sizes W x (W + 1) u32]
+        // ---- 4. group the hits by owner rank; all-gather the group sizes: block (SZ = W + 3 words) = [count for rank 0..W-1 |
+        // largest count value | error word | number of hits of the rank]
+        // x_meta (reused): [prefix (W + 1) u64 | my sizes SZ u32 | cursors (W) u32 | starts (W) u32 | gathered sizes W x SZ u32]
+        const uint32_t SZ = W + 3;
         uint64_t* d_prefix = reinterpret_cast<uint64_t*>(xm);
         uint32_t* d_sizes = reinterpret_cast<uint32_t*>(xm + (size_t)(W + 1) * 8);
-        uint32_t* d_cursor = d_sizes + (W + 1);
+        uint32_t* d_cursor = d_sizes + SZ;
         uint32_t* d_start = d_cursor + W;
-        uint32_t* d_allsizes = d_start + W + ((W & 1) ? 1 : 0);
+        uint32_t* d_allsizes = d_start + W + ((W & 1) ? 0 : 1);
         ctx->h2d(d_prefix, prefix.data(), (size_t)(W + 1) * 8);
-        SY_HIP(hipMemsetAsync(d_sizes, 0, (size_t)(3 * W + 2) * 4, st));
+        SY_HIP(hipMemsetAsync(d_sizes, 0, (size_t)(3 * W + 4) * 4, st));
         if (n_hits) {
             hipLaunchKernelGGL(owner_count_kernel, dim3((uint32_t)std::min<uint64_t>(1024, grid_for64(n_hits))), dim3(256), 0, st, db->hits.as<uint64_t>(),
                                n_hits, G, d_prefix, W, d_sizes);
             SY_HIP(hipGetLastError());
         }
-        ctx->h2d(d_sizes + W, &max_count, 4);
-        comm->all_gather(d_sizes, d_allsizes, (uint64_t)(W + 1) * 4, st);
-        std::vector<uint32_t> sizes((size_t)W * (W + 1));
+        const uint32_t trailer[3] = {max_count, local_err, n_hits};
+        ctx->h2d(d_sizes + W, trailer, 12);
+        comm->all_gather(d_sizes, d_allsizes, (uint64_t)SZ * 4, st);
+        std::vector<uint32_t> sizes((size_t)W * SZ);
         ctx->d2h(sizes.data(), d_allsizes, sizes.size() * 4);
-        auto n_from_to = [&](uint32_t src, uint32_t dst) { return (uint64_t)sizes[(size_t)src * (W + 1) + dst]; };
+        auto n_from_to = [&](uint32_t src, uint32_t dst) { return (uint64_t)sizes[(size_t)src * SZ + dst]; };
+        // every rank looks at every rank's error word and bookkeeping: the same verdict everywhere
+        for (uint32_t r = 0; r < W; r++) {
+            const uint32_t err_r = sizes[(size_t)r * SZ + W + 1];
+            if (err_r)
+                throw ArgError{r == me ? "sharded containment failed on this rank: " + local_msg
+                                       : "sharded containment failed on rank " + std::to_string(r) + " (error class " + std::to_string(err_r) + "): this rank stops with it"};
+            uint64_t sent = 0;
+            for (uint32_t d2 = 0; d2 < W; d2++) sent += n_from_to(r, d2);
+            SY_REQUIRE(sent == sizes[(size_t)r * SZ + W + 2], "internal: owner counts of rank %u do not add up", r);
+        }
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 5: scatter + all-to-all hits"));
         // ---- 5. all-to-all of the hit groups
         std::vector<uint64_t> hs_off(W + 1, 0), hr_off(W + 1, 0);
@@ -447,9 +475,8 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
             start[r] = (uint32_t)(hs_off[r] / 8);
             hs_off[r + 1] = hs_off[r] + n_from_to(me, r) * 8;
             hr_off[r + 1] = hr_off[r] + n_from_to(r, me) * 8;
-            if (n_from_to(r, me)) max_mine = std::max(max_mine, sizes[(size_t)r * (W + 1) + W]);
+            if (n_from_to(r, me)) max_mine = std::max(max_mine, sizes[(size_t)r * SZ + W]);
         }
-        SY_REQUIRE(hs_off[W] / 8 == n_hits, "internal: owner counts do not add up");
         // (checked for EVERY destination from the gathered matrix, so that all ranks fail together instead of one leaving the others
         //  waiting in the next collective)
         for (uint32_t dst = 0; dst < W; dst++) {
@@ -470,6 +497,7 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
             ScopedKernelTimer t(ctx, "exchange");
             comm->all_to_all(db->x_send.p, hs_off.data(), db->hits.p, hr_off.data(), st);
         }
+        db->x_hit_bytes += hs_off[W] - (hs_off[me + 1] - hs_off[me]);
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 6: sort + assemble + copy out"));
         // ---- 6. sort + assemble this rank's samples
         finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false, dst);
@@ -479,6 +507,17 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
 }
 
 extern "C" {
+
+int sylph_db_exchange_stats(sylph_db* db, uint64_t* batches, uint64_t* table_bytes_sent, uint64_t* hit_bytes_sent, int reset) {
+    return guarded([&] {
+        SY_REQUIRE(db, "null argument");
+        std::lock_guard<std::mutex> lock(db->ctx->mu);
+        if (batches) *batches = db->x_batches;
+        if (table_bytes_sent) *table_bytes_sent = db->x_table_bytes;
+        if (hit_bytes_sent) *hit_bytes_sent = db->x_hit_bytes;
+        if (reset) db->x_batches = db->x_table_bytes = db->x_hit_bytes = 0;
+    });
+}
 
 int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
                                    double min_number_kmers, const uint32_t** contain_count, const uint64_t** cov_off,

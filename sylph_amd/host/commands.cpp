@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
 #include <fstream>
+#include <future>
+#include <map>
 #include <atomic>
 #include <chrono>
 #include <memory>
@@ -81,6 +84,12 @@ struct Session {   // RAII
                                      no_dedup ? 1 : 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
     }
     ~Session() { sylph_sketch_destroy(sk); }
+    // keep != nullptr: the caller takes the pushed, unfinished session (the profile pipeline finishes it on the device and
+    // probes its table where it lies); out's table stays empty
+    void finish_or_keep(SequencesSketch& out, sylph_sketch** keep) {
+        if (keep) { *keep = sk; sk = nullptr; return; }
+        finish(out);
+    }
     void finish(SequencesSketch& out) {
         uint64_t* k = nullptr; uint32_t* c = nullptr; uint64_t n = 0, dup = 0;
         hip_check(sylph_sketch_finish(sk, &k, &c, &n, &dup), "sylph_sketch_finish");
@@ -97,6 +106,7 @@ Engine::Engine(int dev) : device(dev) {
             hip_check(sylph_ctx_create(device, nullptr, &ctx_), "sylph_ctx_create");
             if (getenv("SYLPH_HIP_NO_WARMUP")) return;
             batch.prealloc();
+            batch.prealloc_packed();
             // first use of a kernel loads its code object (~25 ms for the sketch kernels): do it here, with a few dummy pairs
             sylph_sketch* sk = nullptr;
             hip_check(sylph_sketch_begin(ctx_, 200, 31, SYLPH_READS_PAIRED, 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
@@ -137,16 +147,42 @@ std::vector<uint64_t> cumulative(const FastqIndex& ix) {
 // caller then runs the sequential reader with needletail's exact record/error semantics.  No GPU call happens before the
 // files are indexed, so the engine's background bring-up overlaps with it.
 struct IndexedInput { std::unique_ptr<FastqIndex> a, b; };
+struct ThreadJoiner {   // joins on every way out of a scope (an Error thrown past a joinable std::thread is std::terminate)
+    std::thread& t;
+    ~ThreadJoiner() { if (t.joinable()) t.join(); }
+};
 std::optional<IndexedInput> index_inputs(const std::string& f1, const std::string* f2) {
     if (getenv("SYLPH_HIP_SEQUENTIAL_FEED")) return std::nullopt;
     const unsigned T = parse_threads();
     IndexedInput in;
+    std::exception_ptr err_b;
     std::thread tb;
-    if (f2) tb = std::thread([&] { in.b.reset(new FastqIndex(*f2, T)); });   // the two mate files are indexed concurrently
+    ThreadJoiner jb{tb};
+    if (f2) tb = std::thread([&] {                        // the two mate files are indexed concurrently
+        try { in.b.reset(new FastqIndex(*f2, T)); } catch (...) { err_b = std::current_exception(); }
+    });
     in.a.reset(new FastqIndex(f1, T));
     if (tb.joinable()) tb.join();
+    if (err_b) std::rethrow_exception(err_b);
     if (!in.a->ok || (f2 && !in.b->ok)) return std::nullopt;
     return in;
+}
+// Batches of whole records (pairs) of at most BATCH_BASES bases / BATCH_RECS records
+std::vector<std::pair<size_t, size_t>> cut_batches(size_t n, bool paired, const std::vector<uint64_t>& ca, const std::vector<uint64_t>& cb) {
+    std::vector<std::pair<size_t, size_t>> out;
+    size_t i0 = 0;
+    while (i0 < n) {
+        // largest i1 with at most BATCH_BASES bases and BATCH_RECS records in [i0, i1)
+        size_t lo = i0 + 1, hi = std::min(n, i0 + PinnedBatch::BATCH_RECS / (paired ? 2 : 1));
+        auto bases_upto = [&](size_t i) { return ca[i] - ca[i0] + (paired ? cb[i] - cb[i0] : 0); };
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo + 1) / 2;
+            if (bases_upto(mid) <= PinnedBatch::BATCH_BASES) lo = mid; else hi = mid - 1;
+        }
+        out.emplace_back(i0, lo);
+        i0 = lo;
+    }
+    return out;
 }
 void sketch_indexed(Engine& e, sylph_sketch* sk, const IndexedInput& in, double& mean_read_length) {
     const unsigned T = parse_threads();
@@ -164,45 +200,129 @@ void sketch_indexed(Engine& e, sylph_sketch* sk, const IndexedInput& in, double&
     const size_t n = b ? std::min(a.n_records(), b->n_records()) : a.n_records();   // lock-step readers: sketch.rs:813-815
     std::vector<uint64_t> ca, cb;
     {
+        std::exception_ptr err;
         std::thread tb;
-        if (b) tb = std::thread([&] { cb = cumulative(*b); });
+        ThreadJoiner jb{tb};
+        if (b) tb = std::thread([&] { try { cb = cumulative(*b); } catch (...) { err = std::current_exception(); } });
         ca = cumulative(a);
         if (tb.joinable()) tb.join();
+        if (err) std::rethrow_exception(err);
     }
     lap("prefix sums");
-    // the one sequential piece of the reference's record loop, on its own thread while the batches travel
+    // the one sequential piece of the reference's record loop (f64, file order: sketch.rs:941-943, :825-826), on its own thread
+    // while the batches travel
     double mean = 0.;
     std::thread tm([&] { double counter = 0.; for (size_t i = 0; i < n; i++) { counter += 1.; mean = mean + ((double)a.seq_len[i] - mean) / counter; } });
+    ThreadJoiner jm{tm};
     e.batch.flush(sk);
-    size_t i0 = 0;
-    while (i0 < n) {
-        // largest i1 with at most BATCH_BASES bases and BATCH_RECS records in [i0, i1)
-        size_t lo = i0 + 1, hi = std::min(n, i0 + PinnedBatch::BATCH_RECS / (b ? 2 : 1));
-        auto bases_upto = [&](size_t i) { return ca[i] - ca[i0] + (b ? cb[i] - cb[i0] : 0); };
-        while (lo < hi) {
-            const size_t mid = lo + (hi - lo + 1) / 2;
-            if (bases_upto(mid) <= PinnedBatch::BATCH_BASES) lo = mid; else hi = mid - 1;
+    // Batches are gathered AND packed to 2 bits per base by the parse threads into one of two page-locked slots while the other
+    // slot is on its way to the device: the push of batch i (PCIe + kernels) hides behind the gather of batch i + 1.
+    const auto batches = cut_batches(n, b != nullptr, ca, cb);
+    if (!batches.empty()) e.batch.gather_packed(0, a, b, ca, b ? &cb : nullptr, batches[0].first, batches[0].second, T);
+    lap("batch 0: gather + pack");
+    for (size_t bi = 0; bi < batches.size(); bi++) {
+        std::exception_ptr err;
+        std::thread tg;
+        ThreadJoiner jg{tg};
+        if (bi + 1 < batches.size())
+            tg = std::thread([&, bi] {
+                try { e.batch.gather_packed((int)((bi + 1) & 1), a, b, ca, b ? &cb : nullptr, batches[bi + 1].first, batches[bi + 1].second, T); }
+                catch (...) { err = std::current_exception(); }
+            });
+        e.batch.push_packed(sk, (int)(bi & 1));
+        if (tg.joinable()) tg.join();
+        if (err) std::rethrow_exception(err);
+        // everything before the next batch's first record has been gathered: an inflated copy gives those pages back
+        if (bi + 1 < batches.size()) {
+            a.release_behind(a.seq_off[batches[bi + 1].first]);
+            if (b) b->release_behind(b->seq_off[batches[bi + 1].first]);
         }
-        e.batch.push_indexed(sk, a, b, ca, b ? &cb : nullptr, i0, lo, T);
-        lap("batch: gather + push");
-        i0 = lo;
+        lap("batch: push || gather next");
     }
     tm.join();
     mean_read_length = mean;
     lap("running mean (joined)");
 }
+
+// The index of the NEXT sample's files is built on a background thread while the current sample is gathered and pushed
+// (the files of a sample are independent of everything before them).  get(j) hands over what start(j) began — or builds it
+// now; at most `ahead` samples are in flight, so the memory of their mappings and index arrays stays bounded.
+class IndexAhead {
+   public:
+    using Files = std::pair<std::string, std::optional<std::string>>;
+    IndexAhead(std::vector<Files> files) : files_(std::move(files)) {}
+    ~IndexAhead() { for (auto& kv : fut_) if (kv.second.valid()) kv.second.wait(); }
+    void start(size_t j) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (j >= files_.size() || fut_.count(j)) return;
+        const Files f = files_[j];
+        fut_[j] = std::async(std::launch::async, [f] { return index_inputs(f.first, f.second ? &*f.second : nullptr); });
+    }
+    std::optional<IndexedInput> get(size_t j) {
+        std::future<std::optional<IndexedInput>> f;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = fut_.find(j);
+            if (it != fut_.end()) { f = std::move(it->second); fut_.erase(it); }
+        }
+        if (f.valid()) return f.get();
+        const Files& fl = files_.at(j);
+        return index_inputs(fl.first, fl.second ? &*fl.second : nullptr);
+    }
+   private:
+    std::vector<Files> files_;
+    std::mutex mu_;
+    std::map<size_t, std::future<std::optional<IndexedInput>>> fut_;
+};
+
+// MemAvailable of /proc/meminfo in bytes (0 if unknown)
+size_t mem_available() {
+    std::ifstream f("/proc/meminfo");
+    std::string key;
+    unsigned long long kb = 0;
+    while (f >> key) {
+        if (key == "MemAvailable:") { f >> kb; return (size_t)kb * 1024; }
+        f.ignore(1 << 20, '\n');
+    }
+    return 0;
+}
+// what ONE index may hold in anonymous memory when `concurrent` of them can be alive at the same time: half of what is available
+void set_feed_budget(size_t concurrent) {
+    if (const char* e = getenv("SYLPH_HIP_FEED_MEM_GB")) { set_index_memory_budget((size_t)(atof(e) * (1ull << 30))); return; }
+    const size_t avail = mem_available();
+    set_index_memory_budget(avail ? avail / 2 / std::max<size_t>(1, concurrent) : 0);
+}
+}  // namespace
+
+namespace {
+// `pre`: the files' index if somebody built it ahead of time (nullptr: build it here; an empty optional: the files are not for
+// the block-parallel feed)
+std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
+                                                            std::optional<std::string> sample_name, bool no_dedup,
+                                                            std::optional<IndexedInput>* pre, sylph_sketch** keep = nullptr);
+std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::string& read_file1, const std::string& read_file2,
+                                                          uint64_t c, uint64_t k, std::optional<std::string> sample_name,
+                                                          bool no_dedup, std::optional<IndexedInput>* pre, sylph_sketch** keep = nullptr);
 }  // namespace
 
 // sketch.rs:897-959
 std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
                                                        std::optional<std::string> sample_name, bool no_dedup) {
-    if (auto in = index_inputs(read_file, nullptr)) {   // uncompressed 4-line FASTQ: block-parallel feed
+    return sketch_sequences_needle_impl(e, read_file, c, k, std::move(sample_name), no_dedup, nullptr);
+}
+namespace {
+std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
+                                                            std::optional<std::string> sample_name, bool no_dedup,
+                                                            std::optional<IndexedInput>* pre, sylph_sketch** keep) {
+    std::optional<IndexedInput> own;
+    if (!pre) { own = index_inputs(read_file, nullptr); pre = &own; }
+    if (auto& in = *pre) {   // uncompressed 4-line FASTQ: block-parallel feed
         Session s(e, c, k, false, no_dedup);
         double mean = 0.;
         sketch_indexed(e, s.sk, *in, mean);
         {
             SequencesSketch out;
-            s.finish(out);
+            s.finish_or_keep(out, keep);
             out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
             out.sample_name = std::move(sample_name);
             out.mean_read_length = mean;
@@ -226,25 +346,34 @@ std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::str
     }
     e.batch.flush(s.sk);
     SequencesSketch out;
-    s.finish(out);
+    s.finish_or_keep(out, keep);
     out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
     out.sample_name = std::move(sample_name);
     out.mean_read_length = mean_read_length;
     return out;
 }
+}  // namespace
 
 // sketch.rs:771-895.  The exact marker set (--fpr 0, :829-838) is the only dedup structure on the GPU; the reference's
 // default for pairs is an approximate cuckoo filter (third-party crate) with the same intent.
 std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                      uint64_t c, uint64_t k, std::optional<std::string> sample_name,
                                                      bool no_dedup, double /*dedup_fpr*/) {
-    if (auto in = index_inputs(read_file1, &read_file2)) {
+    return sketch_pair_sequences_impl(e, read_file1, read_file2, c, k, std::move(sample_name), no_dedup, nullptr);
+}
+namespace {
+std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::string& read_file1, const std::string& read_file2,
+                                                          uint64_t c, uint64_t k, std::optional<std::string> sample_name,
+                                                          bool no_dedup, std::optional<IndexedInput>* pre, sylph_sketch** keep) {
+    std::optional<IndexedInput> own;
+    if (!pre) { own = index_inputs(read_file1, &read_file2); pre = &own; }
+    if (auto& in = *pre) {
         Session s(e, c, k, true, no_dedup);
         double mean = 0.;
         sketch_indexed(e, s.sk, *in, mean);
         {
             SequencesSketch out;
-            s.finish(out);
+            s.finish_or_keep(out, keep);
             out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;
             out.sample_name = std::move(sample_name);
             out.mean_read_length = mean;
@@ -273,12 +402,13 @@ std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::strin
     }
     e.batch.flush(s.sk);
     SequencesSketch out;
-    s.finish(out);
+    s.finish_or_keep(out, keep);
     out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;
     out.sample_name = std::move(sample_name);
     out.mean_read_length = mean_read_length;
     return out;
 }
+}  // namespace
 
 // A batch of parsed genomes sketched by ONE sylph_sketch_genomes call (seeding, genome-wide duplicate removal and the spacing
 // filter all run on the device; sketch.rs:550-622 / :481-548 per genome).  Files are parsed on the host and appended until
@@ -465,7 +595,16 @@ int sketch(Engine& e, const SketchArgs& args) {
     // The parsing / inflating of different samples overlaps; the GPU work of one sample is ~2 ms per Gbp.
     create_dir_all(args.sample_output_dir);
     const size_t n_jobs = first_pairs.size() + read_inputs.size();
+    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(args.threads, n_jobs));
+    // the next sample of every worker is indexed while the current one is gathered and pushed
+    std::vector<IndexAhead::Files> job_files;
+    for (size_t j = 0; j < first_pairs.size(); j++) job_files.push_back({first_pairs[j], second_pairs[j]});
+    for (const auto& r : read_inputs) job_files.push_back({r, std::nullopt});
+    IndexAhead ahead(job_files);
+    set_feed_budget(4 * n_workers);            // two files per sample, the current and the next sample of every worker
     auto run_job = [&](Engine& eng, size_t j) {
+        std::optional<IndexedInput> pre = ahead.get(j);
+        ahead.start(j + n_workers);
         const auto t_job = std::chrono::steady_clock::now();
         auto timing = [&](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_job).count();
@@ -479,7 +618,7 @@ int sketch(Engine& e, const SketchArgs& args) {
         if (j < first_pairs.size()) {                                        // :311-367
             std::optional<std::string> sample_name;
             if (sample_names) sample_name = (*sample_names)[j];
-            auto sk = sketch_pair_sequences(eng, first_pairs[j], second_pairs[j], args.c, args.k, sample_name, args.no_dedup, args.fpr);
+            auto sk = sketch_pair_sequences_impl(eng, first_pairs[j], second_pairs[j], args.c, args.k, sample_name, args.no_dedup, &pre);
             if (!sk) return;
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
@@ -490,7 +629,7 @@ int sketch(Engine& e, const SketchArgs& args) {
             const size_t i = j - first_pairs.size();
             std::optional<std::string> sample_name;
             if (sample_names) sample_name = (*sample_names)[j];
-            auto sk = sketch_sequences_needle(eng, read_inputs[i], args.c, args.k, sample_name, args.no_dedup);
+            auto sk = sketch_sequences_needle_impl(eng, read_inputs[i], args.c, args.k, sample_name, args.no_dedup, &pre);
             if (!sk) return;
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + SAMPLE_FILE_SUFFIX;
@@ -499,7 +638,6 @@ int sketch(Engine& e, const SketchArgs& args) {
             timing(*sk, read_inputs[i]);
         }
     };
-    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(args.threads, n_jobs));
     if (n_workers <= 1) {
         for (size_t j = 0; j < n_jobs; j++) run_job(e, j);
     } else {
@@ -614,6 +752,17 @@ std::optional<double> get_kmer_identity(const SequencesSketch& S, bool estimate_
         if (count == 1) num_1s += 1; else num_not1s += count;
     }
     const double eps = (double)num_not1s / ((double)num_not1s + (double)num_1s + 0.1);
+    {   // which branch the walk chose, and how close the call was (the walk's order is this host's, not hashbrown's: see above)
+        char buf[200];
+        snprintf(buf, sizeof(buf), "%s --estimate-unknown: running median of the counts above 1 = %.4f (limit %.1f, mean read length %.1f): %s",
+                 S.file_name.c_str(), mov_avg_median, MED_KMER_FOR_ID_EST, S.mean_read_length,
+                 (mov_avg_median < MED_KMER_FOR_ID_EST && S.mean_read_length < 400.) ? "fixed 99.5% read identity" : "read identity estimated from the table");
+        info(buf);
+        if (S.mean_read_length < 400. && std::fabs(mov_avg_median - MED_KMER_FOR_ID_EST) <= 0.1 * MED_KMER_FOR_ID_EST)
+            warn(S.file_name + ": the sample's depth is within 10% of the limit that switches --estimate-unknown between the fixed 99.5% read identity and "
+                 "the estimated one; that decision depends on the order the table is walked in (ascending k-mers here, hash-map order in "
+                 "sylph), so True_cov / Sequence_abundance may differ from `sylph profile -u` for this sample: pass -I to fix the identity");
+    }
     if (mov_avg_median < MED_KMER_FOR_ID_EST && S.mean_read_length < 400.) {
         info(S.file_name + " short-read sample has high diversity compared to sequencing depth (approx. avg depth < 3). Using 99.5% as "
              "read accuracy estimate instead of automatic detection for --estimate-unknown.");
@@ -713,111 +862,233 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
 
     print_header(args.pseudotax, out, args.estimate_unknown);
     const uint64_t genome_c = genome_sketches[0].c, genome_k = genome_sketches[0].k;
-    std::vector<std::pair<std::vector<std::string>, bool>> samples;
-    for (auto& r : read_files) samples.push_back({r, false});
-    for (auto& s : read_sketch_files) samples.push_back({{s}, true});
-
-    for (const auto& [files, is_sketch] : samples) {
-        // get_seq_sketch, contain.rs:544-599
-        std::optional<SequencesSketch> seq;
-        if (is_sketch) {
-            SequencesSketch s = read_sylsp(files[0]);
-            if (s.c > genome_c) { fprintf(stderr, "ERROR [sylph_hip] %s value of -c is %llu; this is greater than the smallest value of -c = %llu for a genome sketch. Exiting.\n", files[0].c_str(), (unsigned long long)s.c, (unsigned long long)genome_c); }
-            else seq = std::move(s);
-        } else if (genome_c < args.c) {
-            fprintf(stderr, "ERROR [sylph_hip] %s error: value of -c for contain = %llu -- greater than the smallest value of -c for a genome sketch = %llu. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.c, (unsigned long long)genome_c);
-        } else if (genome_k != args.k) {
-            fprintf(stderr, "ERROR [sylph_hip] %s -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.k, (unsigned long long)genome_k);
-        } else if (files.size() == 1) {
-            seq = sketch_sequences_needle(e, files[0], args.c, args.k, std::nullopt, false);
+    // ---- one sample's results -> statistics -> (profile: reassignment pass) -> TSV rows.  `cc / coff / covs` are the first-pass
+    // views (coverage values cov_width bytes each); the sample table is given where it lies (tk / tc / tn in tmem) for the
+    // reassignment probe; S carries the metadata, and the counts on the host when -u needs them.
+    auto report = [&](const SequencesSketch& S, const std::string& first_file, const uint32_t* cc, const uint64_t* coff, const void* covs,
+                      uint32_t cov_width, const uint64_t* tk, const uint32_t* tc, uint64_t tn, int tmem) {
+        if (genome_k != S.k) throw Error{1, "k parameter for reads != k parameter for genome"};   // contain.rs:608-615
+        const std::string seq_name = S.sample_name ? *S.sample_name : S.file_name;   // :775-781
+        auto cov_vector = [&](const void* base, uint32_t width, uint64_t lo, uint64_t hi) {
+            std::vector<uint32_t> cv(hi - lo);
+            if (width == 4) memcpy(cv.data(), (const uint32_t*)base + lo, (hi - lo) * 4);
+            else if (width == 2) for (uint64_t i = lo; i < hi; i++) cv[i - lo] = ((const uint16_t*)base)[i];
+            else for (uint64_t i = lo; i < hi; i++) cv[i - lo] = ((const uint8_t*)base)[i];
+            return cv;
+        };
+        std::vector<AniResult> stats;
+        {   // the statistics of different genomes are independent (contain.rs:284 runs them on the rayon pool): -t threads,
+            // results gathered in genome order so that the output does not depend on the interleaving
+            std::vector<size_t> with_hits;
+            for (size_t g = 0; g < genome_sketches.size(); g++) {
+                if (genome_sketches[g].c < S.c) throw Error{1, "c parameter for reads > c parameter for genome"};   // :616-623
+                if (cc[g] != 0) with_hits.push_back(g);                  // :654
+            }
+            std::vector<std::optional<AniResult>> res(with_hits.size());
+            parallel_for(with_hits.size(), args.threads, [&](size_t i) {
+                const size_t g = with_hits[i];
+                res[i] = stats_from_covs(args, cov_vector(covs, cov_width, coff[g], coff[g + 1]), genome_sketches[g].genome_kmers.size(), S.k, std::nullopt);
+                if (res[i]) res[i]->genome_index = g;
+            });
+            for (auto& r : res) if (r) stats.push_back(*r);
+        }
+        std::optional<double> kmer_id_opt;                               // contain.rs:274-281
+        if (args.seq_id) kmer_id_opt = std::pow(*args.seq_id / 100., (double)S.k);
+        else kmer_id_opt = get_kmer_identity(S, args.estimate_unknown);
+        estimate_true_cov(stats, kmer_id_opt, args.estimate_unknown, S.mean_read_length, S.k);   // :295
+        if (args.pseudotax) {
+            info(first_file + " taxonomic profiling; reassigning k-mers for " + std::to_string(stats.size()) + " genomes...");
+            // winner_table (contain.rs:410-430) + second get_stats pass with the winner map (:300-307, :637-646) on the
+            // device: one more probe of the resident postings (genome_kmers + tracked k-mers), passing genomes only.
+            std::vector<uint32_t> pg(stats.size());
+            std::vector<double> pa(stats.size());
+            for (size_t i = 0; i < stats.size(); i++) { pg[i] = (uint32_t)stats[i].genome_index; pa[i] = stats[i].final_est_ani; }
+            const uint32_t *cc2 = nullptr, *covs2 = nullptr, *lost2 = nullptr;
+            const uint64_t* coff2 = nullptr;
+            uint64_t ncov2 = 0;
+            hip_check(sylph_db_reassign_view(db, tk, tc, tn, tmem, pg.data(), pa.data(), (uint32_t)pg.size(), &cc2, &coff2, &covs2, &ncov2, &lost2),
+                      "sylph_db_reassign_view");
+            std::vector<AniResult> stats2;
+            std::vector<std::optional<AniResult>> res2(stats.size());
+            parallel_for(stats.size(), args.threads, [&](size_t i) {
+                const size_t g = stats[i].genome_index;
+                std::vector<uint32_t> cv(covs2 + coff2[g], covs2 + coff2[g + 1]);
+                res2[i] = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, (size_t)lost2[g]);
+                if (res2[i]) res2[i]->genome_index = g;
+            });
+            for (size_t i = 0; i < stats.size(); i++) {
+                const auto& r = res2[i];
+                if (!r) continue;
+                // derep_if_reassign_threshold, contain.rs:353-375
+                const double thr = std::pow(args.redundant_ani / 100., (double)S.k) * (double)r->n_kmers;
+                if ((double)(stats[i].contain_count - r->contain_count) < thr) stats2.push_back(*r);
+            }
+            stats.swap(stats2);
+            estimate_true_cov(stats, kmer_id_opt, args.estimate_unknown, S.mean_read_length, S.k);   // :310
+            info(first_file + " has " + std::to_string(stats.size()) + " genomes passing profiling threshold. ");
+            double bases_explained = 1.;                                 // :313-317
+            if (args.estimate_unknown) {
+                bases_explained = estimate_covered_bases(stats, genome_sketches, S, S.mean_read_length, S.k);
+                char buf[64];
+                snprintf(buf, sizeof buf, "%.2f", bases_explained * 100.);
+                info(first_file + " has " + buf + "% of reads detected in database by profile");
+            }
+            double total_cov = 0, total_seq_cov = 0;                     // contain.rs:319-326
+            for (const auto& r : stats) { total_cov += r.final_est_cov; total_seq_cov += r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size; }
+            for (auto& r : stats) r.rel_abund = r.final_est_cov / total_cov * 100.;
+            for (auto& r : stats) r.seq_abund = r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size / total_seq_cov * 100. * bases_explained;
+            std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return *y.rel_abund < *x.rel_abund; });   // :330
         } else {
-            // contain.rs:591 forces the cuckoo default (fpr 1e-4) for raw pairs; here: the exact set (see the warning below)
-            static bool warned = false;
-            if (!warned) {
-                warned = true;
+            std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return y.final_est_ani < x.final_est_ani; });   // :333
+        }
+        for (const auto& r : stats) print_ani_result(r, seq_name, genome_sketches[r.genome_index], args.pseudotax, out, args.debug_f64);
+    };
+    auto finished = [&](const std::vector<std::string>& files) {
+        info(std::string(files.size() > 1 ? "Finished paired sample " : "Finished sample ") + files[0] + ".");
+    };
+
+    // ---- raw read samples (contain.rs:239-291 sketches and profiles them chunk by chunk on the rayon pool).  Here: up to `-t`
+    // sample threads, each with a GPU context of its own, read + index + pack + push their files into sessions, in input order;
+    // the sessions go through a sylph_pipeline (finish on the device -> probe, tables never leave HBM), and this thread takes the
+    // results in input order and does the statistics and the printing: the feed of sample j + 1 .. overlaps with the profile of
+    // sample j and the statistics of sample j - 1.
+    const size_t n_raw = read_files.size();
+    if (n_raw) {
+        struct Prepared { std::optional<SequencesSketch> meta; sylph_sketch* session = nullptr; std::exception_ptr error; };
+        std::vector<std::promise<Prepared>> promises(n_raw);
+        std::vector<std::future<Prepared>> futures;
+        for (auto& p : promises) futures.push_back(p.get_future());
+        const size_t n_workers = std::max<size_t>(1, std::min<size_t>(args.threads, n_raw));
+        const size_t ahead_limit = n_workers + 2;                        // sessions that may wait, sketched, for the profile stage
+        std::vector<IndexAhead::Files> job_files;
+        for (const auto& r : read_files) job_files.push_back({r[0], r.size() > 1 ? std::optional<std::string>(r[1]) : std::nullopt});
+        IndexAhead ahead(job_files);
+        set_feed_budget(4 * n_workers);
+        std::atomic<size_t> next_job{0}, released{0};
+        std::atomic<bool> cancel{false};
+        std::mutex gate_mu;
+        std::condition_variable gate_cv;
+        bool warned_pairs = false;
+        auto prepare = [&](Engine& eng, size_t j) {
+            Prepared pr;
+            try {
+                const auto& files = read_files[j];
+                if (genome_c < args.c) {
+                    fprintf(stderr, "ERROR [sylph_hip] %s error: value of -c for contain = %llu -- greater than the smallest value of -c for a genome sketch = %llu. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.c, (unsigned long long)genome_c);
+                } else if (genome_k != args.k) {
+                    fprintf(stderr, "ERROR [sylph_hip] %s -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.k, (unsigned long long)genome_k);
+                } else {
+                    std::optional<IndexedInput> pre = ahead.get(j);
+                    ahead.start(j + n_workers);
+                    if (files.size() == 1) pr.meta = sketch_sequences_needle_impl(eng, files[0], args.c, args.k, std::nullopt, false, &pre, &pr.session);
+                    else pr.meta = sketch_pair_sequences_impl(eng, files[0], files[1], args.c, args.k, std::nullopt, false, &pre, &pr.session);
+                }
+            } catch (...) { pr.error = std::current_exception(); }
+            promises[j].set_value(std::move(pr));
+        };
+        auto worker = [&] {
+            // every sample thread brings its own context: the database's context (the caller's engine) stays free for the
+            // profile stage and the reassignment probes
+            std::unique_ptr<Engine> own;
+            Engine* eng = nullptr;
+            try { own.reset(new Engine(e.device)); eng = own.get(); }
+            catch (...) { eng = nullptr; }
+            for (;;) {
+                const size_t j = next_job++;
+                if (j >= n_raw) return;
+                {   // do not run further ahead of the consumer than ahead_limit samples (their sessions hold HBM)
+                    std::unique_lock<std::mutex> lk(gate_mu);
+                    gate_cv.wait(lk, [&] { return cancel.load() || j < released.load() + ahead_limit; });
+                }
+                if (cancel) { promises[j].set_value(Prepared{}); continue; }
+                if (!eng) { Prepared pr; pr.error = std::make_exception_ptr(Error{1, "could not create a GPU context for a sample thread"}); promises[j].set_value(std::move(pr)); continue; }
+                prepare(*eng, j);
+            }
+        };
+        for (const auto& r : read_files)
+            if (r.size() > 1 && !warned_pairs) {
+                warned_pairs = true;
+                // contain.rs:591 forces the cuckoo default (fpr 1e-4) for raw pairs; here: the exact set
                 warn("raw paired reads are deduplicated with the EXACT marker set (`--fpr 0` semantics), not the approximate cuckoo "
                      "filter `sylph profile -1 -2` uses (contain.rs:591): results match `sylph sketch --fpr 0` followed by profile");
             }
-            seq = sketch_pair_sequences(e, files[0], files[1], args.c, args.k, std::nullopt, false, DEFAULT_FPR);
+        sylph_pipeline* pipe = nullptr;
+        sylph_pipeline_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.struct_size = sizeof(cfg);
+        cfg.n_workers = 2;                       // (they only finish the sessions the sample threads pushed)
+        cfg.depth = (uint32_t)ahead_limit + 1;
+        cfg.max_batch = 4;
+        cfg.c = (uint32_t)args.c; cfg.k = (uint32_t)args.k;
+        cfg.reads_mode = SYLPH_READS_PAIRED; cfg.seed_mode = SYLPH_SEED_AVX2_COMPAT;
+        cfg.want_table = args.estimate_unknown ? 1 : 0;                 // -u walks the counts on the host
+        cfg.min_number_kmers = args.min_number_kmers;
+        hip_check(sylph_pipeline_create(db, &cfg, &pipe), "sylph_pipeline_create");
+        struct PipeGuard { sylph_pipeline* p; ~PipeGuard() { sylph_pipeline_destroy(p); } } pipe_guard{pipe};
+        std::vector<std::thread> pool;
+        struct PoolJoin {   // on every way out: the sample threads stop taking work and are joined
+            std::vector<std::thread>& pool; std::atomic<bool>& cancel; std::mutex& mu; std::condition_variable& cv;
+            ~PoolJoin() {
+                { std::lock_guard<std::mutex> lk(mu); cancel = true; }
+                cv.notify_all();
+                for (auto& t : pool) if (t.joinable()) t.join();
+            }
+        } pool_join{pool, cancel, gate_mu, gate_cv};
+        for (size_t w = 0; w < n_workers; w++) pool.emplace_back(worker);
+        std::vector<std::optional<SequencesSketch>> metas(n_raw);
+        std::vector<char> submitted_ok(n_raw, 0);
+        size_t submitted = 0, done = 0;
+        auto release_one = [&] { { std::lock_guard<std::mutex> lk(gate_mu); released++; } gate_cv.notify_all(); };
+        while (done < n_raw) {
+            // hand over every prepared sample that is ready, in input order (wait for one only when nothing is outstanding)
+            while (submitted < n_raw && sylph_pipeline_outstanding(pipe) < cfg.depth) {
+                const bool must_wait = sylph_pipeline_outstanding(pipe) == 0 && submitted == done;
+                if (!must_wait && futures[submitted].wait_for(std::chrono::seconds(0)) != std::future_status::ready) break;
+                Prepared pr = futures[submitted].get();
+                if (pr.error) std::rethrow_exception(pr.error);
+                metas[submitted] = std::move(pr.meta);
+                if (metas[submitted] && pr.session) {
+                    hip_check(sylph_pipeline_submit_session(pipe, pr.session, submitted), "sylph_pipeline_submit_session");
+                    submitted_ok[submitted] = 1;
+                } else if (pr.session) sylph_sketch_destroy(pr.session);
+                submitted++;
+            }
+            const size_t j = done;
+            if (j >= submitted) continue;        // (the wait above guarantees progress)
+            if (submitted_ok[j]) {
+                sylph_pipeline_result r;
+                hip_check(sylph_pipeline_next(pipe, &r), "sylph_pipeline_next");
+                if (r.status != SYLPH_OK) throw Error{1, std::string("sample ") + read_files[j][0] + ": " + (r.error ? r.error : "GPU stage failed")};
+                SequencesSketch& S = *metas[j];
+                if (args.estimate_unknown && r.counts) S.counts.assign(r.counts, r.counts + r.n_table);
+                report(S, read_files[j][0], r.contain_count, r.cov_off, r.covs, r.cov_width, r.dev_kmers, r.dev_counts, r.n_table, SYLPH_MEM_DEVICE);
+            }
+            finished(read_files[j]);
+            metas[j].reset();
+            done++;
+            release_one();
+        }
+    }
+
+    // ---- samples given as sketches (*.sylsp): the table is on the host
+    for (const auto& sf : read_sketch_files) {
+        const std::vector<std::string> files{sf};
+        // get_seq_sketch, contain.rs:544-599
+        std::optional<SequencesSketch> seq;
+        {
+            SequencesSketch s = read_sylsp(files[0]);
+            if (s.c > genome_c) { fprintf(stderr, "ERROR [sylph_hip] %s value of -c is %llu; this is greater than the smallest value of -c = %llu for a genome sketch. Exiting.\n", files[0].c_str(), (unsigned long long)s.c, (unsigned long long)genome_c); }
+            else seq = std::move(s);
         }
         if (seq) {
             const SequencesSketch& S = *seq;
-            if (genome_k != S.k) throw Error{1, "k parameter for reads != k parameter for genome"};   // contain.rs:608-615
-            const std::string seq_name = S.sample_name ? *S.sample_name : S.file_name;   // :775-781
             // first pass: GPU probe of every genome, then host statistics
             const uint32_t* cc = nullptr; const uint64_t* coff = nullptr; const uint32_t* covs = nullptr; uint64_t ncov = 0;
             hip_check(sylph_db_contain_view(db, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST,
                                             args.min_number_kmers, &cc, &coff, &covs, &ncov), "sylph_db_contain_view");
-            std::vector<AniResult> stats;
-            {   // the statistics of different genomes are independent (contain.rs:284 runs them on the rayon pool): -t threads,
-                // results gathered in genome order so that the output does not depend on the interleaving
-                std::vector<size_t> with_hits;
-                for (size_t g = 0; g < genome_sketches.size(); g++) {
-                    if (genome_sketches[g].c < S.c) throw Error{1, "c parameter for reads > c parameter for genome"};   // :616-623
-                    if (cc[g] != 0) with_hits.push_back(g);                  // :654
-                }
-                std::vector<std::optional<AniResult>> res(with_hits.size());
-                parallel_for(with_hits.size(), args.threads, [&](size_t i) {
-                    const size_t g = with_hits[i];
-                    std::vector<uint32_t> cv(covs + coff[g], covs + coff[g + 1]);
-                    res[i] = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, std::nullopt);
-                    if (res[i]) res[i]->genome_index = g;
-                });
-                for (auto& r : res) if (r) stats.push_back(*r);
-            }
-            std::optional<double> kmer_id_opt;                               // contain.rs:274-281
-            if (args.seq_id) kmer_id_opt = std::pow(*args.seq_id / 100., (double)S.k);
-            else kmer_id_opt = get_kmer_identity(S, args.estimate_unknown);
-            estimate_true_cov(stats, kmer_id_opt, args.estimate_unknown, S.mean_read_length, S.k);   // :295
-            if (args.pseudotax) {
-                info(files[0] + " taxonomic profiling; reassigning k-mers for " + std::to_string(stats.size()) + " genomes...");
-                // winner_table (contain.rs:410-430) + second get_stats pass with the winner map (:300-307, :637-646) on the
-                // device: one more probe of the resident postings (genome_kmers + tracked k-mers), passing genomes only.
-                std::vector<uint32_t> pg(stats.size());
-                std::vector<double> pa(stats.size());
-                for (size_t i = 0; i < stats.size(); i++) { pg[i] = (uint32_t)stats[i].genome_index; pa[i] = stats[i].final_est_ani; }
-                const uint32_t *cc2 = nullptr, *covs2 = nullptr, *lost2 = nullptr;
-                const uint64_t* coff2 = nullptr;
-                uint64_t ncov2 = 0;
-                hip_check(sylph_db_reassign_view(db, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST, pg.data(),
-                                                 pa.data(), (uint32_t)pg.size(), &cc2, &coff2, &covs2, &ncov2, &lost2),
-                          "sylph_db_reassign_view");
-                std::vector<AniResult> stats2;
-                std::vector<std::optional<AniResult>> res2(stats.size());
-                parallel_for(stats.size(), args.threads, [&](size_t i) {
-                    const size_t g = stats[i].genome_index;
-                    std::vector<uint32_t> cv(covs2 + coff2[g], covs2 + coff2[g + 1]);
-                    res2[i] = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, (size_t)lost2[g]);
-                    if (res2[i]) res2[i]->genome_index = g;
-                });
-                for (size_t i = 0; i < stats.size(); i++) {
-                    const auto& r = res2[i];
-                    if (!r) continue;
-                    // derep_if_reassign_threshold, contain.rs:353-375
-                    const double thr = std::pow(args.redundant_ani / 100., (double)S.k) * (double)r->n_kmers;
-                    if ((double)(stats[i].contain_count - r->contain_count) < thr) stats2.push_back(*r);
-                }
-                stats.swap(stats2);
-                estimate_true_cov(stats, kmer_id_opt, args.estimate_unknown, S.mean_read_length, S.k);   // :310
-                info(files[0] + " has " + std::to_string(stats.size()) + " genomes passing profiling threshold. ");
-                double bases_explained = 1.;                                 // :313-317
-                if (args.estimate_unknown) {
-                    bases_explained = estimate_covered_bases(stats, genome_sketches, S, S.mean_read_length, S.k);
-                    char buf[64];
-                    snprintf(buf, sizeof buf, "%.2f", bases_explained * 100.);
-                    info(files[0] + " has " + buf + "% of reads detected in database by profile");
-                }
-                double total_cov = 0, total_seq_cov = 0;                     // contain.rs:319-326
-                for (const auto& r : stats) { total_cov += r.final_est_cov; total_seq_cov += r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size; }
-                for (auto& r : stats) r.rel_abund = r.final_est_cov / total_cov * 100.;
-                for (auto& r : stats) r.seq_abund = r.final_est_cov * (double)genome_sketches[r.genome_index].gn_size / total_seq_cov * 100. * bases_explained;
-                std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return *y.rel_abund < *x.rel_abund; });   // :330
-            } else {
-                std::stable_sort(stats.begin(), stats.end(), [](const AniResult& x, const AniResult& y) { return y.final_est_ani < x.final_est_ani; });   // :333
-            }
-            for (const auto& r : stats) print_ani_result(r, seq_name, genome_sketches[r.genome_index], args.pseudotax, out, args.debug_f64);
+            report(S, files[0], cc, coff, covs, 4, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST);
         }
-        info(std::string(files.size() > 1 ? "Finished paired sample " : "Finished sample ") + files[0] + ".");
+        finished(files);
     }
     fflush(out);
     info("sylph finished.");

@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -114,6 +115,27 @@ PinnedBatch::PinnedBatch() {}
 PinnedBatch::~PinnedBatch() {
     sylph_pinned_free(bases_);
     sylph_pinned_free(off_);
+    for (auto& p : pk_) { sylph_pinned_free(p.bytes); sylph_pinned_free(p.off); }
+}
+
+void PinnedBatch::reserve_packed(Packed& p, size_t bytes, size_t recs) {
+    if (bytes > p.cap_bytes) {
+        sylph_pinned_free(p.bytes);
+        p.bytes = nullptr;
+        p.cap_bytes = 0;
+        if (sylph_pinned_alloc(bytes, (void**)&p.bytes) != SYLPH_OK) throw Error{1, std::string("sylph_pinned_alloc: ") + sylph_last_error()};
+        p.cap_bytes = bytes;
+    }
+    if (recs > p.cap_recs) {
+        sylph_pinned_free(p.off);
+        p.off = nullptr;
+        p.cap_recs = 0;
+        if (sylph_pinned_alloc((recs + 1) * 8, (void**)&p.off) != SYLPH_OK) throw Error{1, std::string("sylph_pinned_alloc: ") + sylph_last_error()};
+        p.cap_recs = recs;
+    }
+}
+void PinnedBatch::prealloc_packed() {
+    for (auto& p : pk_) reserve_packed(p, BATCH_BASES / 4 + 64, BATCH_RECS);
 }
 
 void PinnedBatch::reserve(size_t bases_cap, size_t recs_cap) {
@@ -163,10 +185,15 @@ void PinnedBatch::add(sylph_sketch* sk, const uint8_t* a, uint32_t la, const uin
 unsigned parse_threads() {
     static const unsigned n = [] {
         if (const char* e = getenv("SYLPH_HIP_PARSE_THREADS")) return (unsigned)std::max(1, atoi(e));
-        return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        return std::min(32u, std::max(std::min(hw, 8u), hw / 4));
     }();
     return n;
 }
+
+namespace { std::atomic<size_t> g_index_budget{0}; }
+void set_index_memory_budget(size_t bytes) { g_index_budget = bytes; }
+size_t index_memory_budget() { return g_index_budget; }
 
 namespace {
 template <class F>
@@ -183,6 +210,14 @@ inline size_t next_line(const uint8_t* d, size_t n, size_t p) {   // start of th
 }  // namespace
 
 FastqIndex::~FastqIndex() { if (data) munmap((void*)data, size); }
+
+void FastqIndex::release_behind(size_t byte_offset) const {
+    // only the inflated copy of a blocked-gzip file is real memory of this process (a mapped plain file is page cache the kernel
+    // reclaims by itself): give the pages the feed has gathered from back, so that a large file never stays resident as a whole
+    if (!anonymous || !data) return;
+    const size_t page = 4096, upto = byte_offset / page * page;
+    if (upto) (void)madvise((void*)data, upto, MADV_DONTNEED);
+}
 
 namespace {
 // ---- BGZF (blocked gzip, what `bgzip` writes): every member is a complete deflate stream of <= 64 KiB whose compressed size
@@ -291,6 +326,10 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
         std::vector<BgzfBlock> blocks;
         size_t total = 0;
         if (!bgzf_blocks(data, size, blocks, total) || total < 4) return;          // ordinary gzip: sequential reader
+        // The inflated copy is anonymous memory: with overcommit the mapping always succeeds and a file (times the files indexed
+        // at once) beyond what the machine has ends in the OOM killer instead of in the sequential reader, which runs in
+        // constant memory.  The drivers set the budget from MemAvailable and their concurrency.
+        if (const size_t budget = index_memory_budget(); budget && total > budget) return;
         void* buf = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (buf == MAP_FAILED) return;
         (void)madvise(buf, total, MADV_HUGEPAGE);                                  // first touch by many threads: 2 MiB pages where the system allows
@@ -300,6 +339,7 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
         munmap((void*)data, size);
         data = (const uint8_t*)buf;
         size = total;
+        anonymous = true;
         if (!inflated) return;                                                     // (the sequential reader reports the damage)
     }
     const uint8_t* d = data;
@@ -372,40 +412,51 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     ok = true;
 }
 
-void PinnedBatch::push_indexed(sylph_sketch* sk, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
-                               const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads) {
+void PinnedBatch::gather_packed(int slot, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
+                                const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads) {
+    Packed& p = pk_[slot & 1];
+    p.n_recs = p.n_bases = 0;
     if (i1 <= i0) return;
     const size_t n_items = i1 - i0, nrec = b ? 2 * n_items : n_items;
     const uint64_t base0 = cum_a[i0] + (b ? (*cum_b)[i0] : 0);
     const uint64_t total = cum_a[i1] + (b ? (*cum_b)[i1] : 0) - base0;
-    static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    reserve(std::max<size_t>(total + 64, cap_bases_), std::max<size_t>(nrec, cap_recs_));
-    const auto t1 = std::chrono::steady_clock::now();
+    reserve_packed(p, std::max<size_t>((total + 3) / 4 + 64, p.cap_bytes), std::max<size_t>(nrec, p.cap_recs));
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n_items / 4096 + 1));
-    off_[0] = 0;
+    p.off[0] = 0;
+    std::vector<Pack2Bit> writers;
+    writers.reserve(T);
+    for (unsigned w = 0; w < T; w++) {
+        const size_t j0 = i0 + n_items * w / T;
+        writers.emplace_back(p.bytes, cum_a[j0] + (b ? (*cum_b)[j0] : 0) - base0);
+    }
     run_workers(T, [&](unsigned w) {
         const size_t j0 = i0 + n_items * w / T, j1 = i0 + n_items * (w + 1) / T;
+        Pack2Bit& wr = writers[w];
         for (size_t i = j0; i < j1; i++) {
             uint64_t o = cum_a[i] + (b ? (*cum_b)[i] : 0) - base0;
-            memcpy(bases_ + o, a.data + a.seq_off[i], a.seq_len[i]);
+            wr.append(a.data + a.seq_off[i], a.seq_len[i]);
             o += a.seq_len[i];
             const size_t r = (b ? 2 * (i - i0) : (i - i0)) + 1;
-            off_[r] = o;
+            p.off[r] = o;
             if (b) {
-                memcpy(bases_ + o, b->data + b->seq_off[i], b->seq_len[i]);
-                off_[r + 1] = o + b->seq_len[i];
+                wr.append(b->data + b->seq_off[i], b->seq_len[i]);
+                p.off[r + 1] = o + b->seq_len[i];
             }
         }
+        wr.finish();
     });
-    n_recs_ = nrec;
-    n_bases_ = total;
-    const auto t2 = std::chrono::steady_clock::now();
-    flush(sk);
-    if (trace)
-        fprintf(stderr, "[sylph_hip feed]   pinned reserve %.3f ms, gather %.3f ms (%.1f MB), push %.3f ms\n",
-                std::chrono::duration<double>(t1 - t0).count() * 1e3, std::chrono::duration<double>(t2 - t1).count() * 1e3, total / 1e6,
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() * 1e3);
+    merge_pack_edges(p.bytes, writers.data(), writers.size());
+    memset(p.bytes + (total + 3) / 4, 0, 64);            // (slack the device side may read)
+    p.n_recs = nrec;
+    p.n_bases = total;
+}
+
+void PinnedBatch::push_packed(sylph_sketch* sk, int slot) {
+    Packed& p = pk_[slot & 1];
+    if (!p.n_recs) return;
+    if (sylph_sketch_push_enc(sk, p.bytes, p.off, p.n_recs, p.n_bases, SYLPH_MEM_HOST_PINNED, SYLPH_ENC_2BIT) != SYLPH_OK)
+        throw Error{1, std::string("sylph_sketch_push: ") + sylph_last_error()};
+    p.n_recs = p.n_bases = 0;
 }
 
 }  // namespace sylph_host

@@ -216,9 +216,8 @@ FastxReader::FastxReader(const std::string& path) {
     if (n < 0) { gzclose((gzFile)gz_); gz_ = nullptr; throw Error{1, path + " is not a valid fasta/fastq file; skipping."}; }
     buf_.resize((size_t)n);
     if (n == 0) eof_ = true;
-    size_t q = 0;
-    while (q < buf_.size() && (buf_[q] == '\n' || buf_[q] == '\r')) q++;
-    if (q >= buf_.size() || (buf_[q] != '>' && buf_[q] != '@')) {
+    // (the very first byte decides, as in needletail's parse_fastx_reader: a file that begins with a blank line is rejected too)
+    if (buf_.empty() || (buf_[0] != '>' && buf_[0] != '@')) {
         gzclose((gzFile)gz_);
         gz_ = nullptr;
         throw Error{1, path + " is not a valid fasta/fastq file; skipping."};

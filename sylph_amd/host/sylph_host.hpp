@@ -100,6 +100,8 @@ struct FastqIndex {
     bool ok = false;
     const uint8_t* data = nullptr;   // the mapping (owned)
     size_t size = 0;
+    bool anonymous = false;          // `data` is the inflated copy of a blocked-gzip file (release_behind gives its pages back)
+    void release_behind(size_t byte_offset) const;   // the feed is done with everything before byte_offset
     std::vector<uint64_t> seq_off;   // byte offset of every record's sequence line
     std::vector<uint32_t> seq_len;
     FastqIndex() = default;
@@ -109,7 +111,33 @@ struct FastqIndex {
     FastqIndex& operator=(const FastqIndex&) = delete;
     size_t n_records() const { return seq_len.size(); }
 };
-unsigned parse_threads();   // worker threads of the parallel feed: SYLPH_HIP_PARSE_THREADS, else min(16, hardware threads)
+unsigned parse_threads();   // worker threads of the parallel feed: SYLPH_HIP_PARSE_THREADS, else a quarter of the hardware threads (<= 32)
+// Bytes a FastqIndex may hold in ANONYMOUS memory (the inflated copy of a blocked-gzip file); 0 = no limit.  The drivers set it
+// from MemAvailable and the number of files they index at the same time: beyond it the file goes to the sequential reader,
+// which runs in constant memory.
+void set_index_memory_budget(size_t bytes);
+size_t index_memory_budget();
+
+// BYTE_TO_SEQ + 2-bit packing into one part of a shared stream (pack2bit.cpp)
+class Pack2Bit {
+   public:
+    Pack2Bit(uint8_t* out, uint64_t base_offset);   // `out` = start of the whole stream; this writer begins at base `base_offset`
+    void append(const uint8_t* seq, size_t len);
+    void finish();
+    // the bytes this part shares with its neighbours (not stored by the writer): merge_pack_edges puts them together
+    uint64_t first_byte = 0, last_byte = 0;
+    uint8_t first_val = 0, last_val = 0;
+    bool first_partial = false, last_partial = false;
+   private:
+    void emit(uint64_t word, unsigned n_bytes);
+    void push64(uint64_t v);
+    uint8_t* outp_;
+    uint8_t* base_ = nullptr;
+    uint64_t acc_ = 0;
+    unsigned nacc_ = 0;      // pending bits in acc_ (its most significant ones)
+    bool skip_first_ = false;
+};
+void merge_pack_edges(uint8_t* out, const Pack2Bit* writers, size_t n);
 
 class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinned_alloc), pushed with SYLPH_MEM_HOST_PINNED
    public:
@@ -121,14 +149,20 @@ class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinne
     void flush(sylph_sketch* sk);
     void prealloc() { if (!bases_) reserve(BATCH_BASES, BATCH_RECS); }   // the page-locked allocation itself takes ~50 ms
     // records [i0, i1) of an indexed file (single-end), or pairs [i0, i1) of two indexed files interleaved mate 1, mate 2,
-    // copied into the batch by `threads` workers and pushed; the batch must be empty (flush() first)
-    void push_indexed(sylph_sketch* sk, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
-                      const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads);
+    // PACKED (2 bits per base) into page-locked slot 0 or 1 by `threads` workers — no GPU call: the other slot may be on its way
+    // to the device meanwhile; push_packed hands the slot over (sylph_sketch_push_enc, SYLPH_ENC_2BIT, SYLPH_MEM_HOST_PINNED)
+    void gather_packed(int slot, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
+                       const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads);
+    void push_packed(sylph_sketch* sk, int slot);
+    void prealloc_packed();
    private:
     void reserve(size_t bases_cap, size_t recs_cap);
     uint8_t* bases_ = nullptr;
     uint64_t* off_ = nullptr;
     size_t cap_bases_ = 0, cap_recs_ = 0, n_bases_ = 0, n_recs_ = 0;
+    struct Packed { uint8_t* bytes = nullptr; uint64_t* off = nullptr; size_t cap_bytes = 0, cap_recs = 0, n_bases = 0, n_recs = 0; };
+    Packed pk_[2];
+    void reserve_packed(Packed& p, size_t bytes, size_t recs);
 };
 bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109

@@ -147,3 +147,27 @@ def test_pipeline_sharded_one_rank(ctx):
         assert r["tag"] == i and r["probe_batch"] == 2
         check_result(r, O.sketch_reads(*data[i], c=50, paired=True), db_k, goff)
     p.close(); db.close(); comm.close()
+
+
+def test_bench_two_ranks_on_one_gpu_small_workload():
+    """`bench.py --gpus 2` end to end on whatever the box has (one GPU: the two ranks share it and the collectives of the sharded
+    exchange run through torch.distributed callbacks): the N > 1 code path of the bench — self-launch, sharded database, the
+    pipeline's fixed probe batches with flush, agreement on mode and step size across ranks — prints ONE line with n_gpus = 2
+    whose verify leg matches the oracle, and reports the exchange's time and bytes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "3", "--warmup", "1",
+                        "--min-seconds", "0.3", "--no-cpu-baseline", "--no-h2d"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["verify"]["mismatches"] == 0 and d["verify"]["genomes_checked"] > 0
+    assert "sharded by k-mer range over 2 GPUs" in d["config"]["parallelism"]
+    legs = [d] + [d[k] for k in ("pipelined", "one_step_at_a_time") if k in d and "exchange" in d[k]]
+    assert any("exchange" in leg and leg["exchange"]["probe_batches"] > 0 and leg["exchange"]["hit_bytes_sent_per_batch"] > 0 for leg in legs)

@@ -524,3 +524,46 @@ def test_blocked_gzip_is_inflated_in_parallel_and_indexed(host, tmp_path, monkey
             "h.sylph_host_fastq_index_digest(sys.argv[2].encode(), 4, C.byref(ok), *[C.byref(x) for x in w]); print(ok.value, w[0].value, w[1].value, w[2].value)")
     r = subprocess.run([sys.executable, "-c", code, host._name, str(bg)], capture_output=True, text=True, env=dict(os.environ, SYLPH_HIP_NO_LIBDEFLATE="1"))
     assert r.stdout.split() == ["1", str(v[0].value), str(v[2].value), str(v[3].value)], r.stdout + r.stderr
+
+
+def test_parallel_2bit_packer_matches_byte_to_seq(host):
+    """Pack2Bit (host/pack2bit.cpp): records packed by several writers into one 2-bit stream — parts that begin and end at any
+    base offset, shared bytes merged afterwards, the AVX2 path and the table path — against BYTE_TO_SEQ spelled out here and
+    against the library's own sylph_pack_2bit."""
+    import sylph_amd as S
+    host.sylph_host_pack_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, v in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"TtUu", 3)):
+        for b in ch:
+            code[b] = v
+    code[1], code[2], code[3] = 1, 2, 3
+    rng = np.random.default_rng(12)
+    for trial in range(60):
+        n_rec = int(rng.integers(0, 40))
+        kind = trial % 3
+        recs = []
+        for _ in range(n_rec):
+            L = int(rng.integers(0, 260))
+            if kind == 0:
+                r = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)            # the fast path only
+            elif kind == 1:
+                r = rng.choice(np.frombuffer(b"ACGTacgtNnUu-", dtype=np.uint8), size=L)     # odd bytes inside 32-base groups
+            else:
+                r = rng.integers(0, 256, size=L).astype(np.uint8)                           # the whole byte alphabet
+            recs.append(r.astype(np.uint8))
+        bases = np.concatenate(recs + [np.zeros(0, np.uint8)]).astype(np.uint8)
+        off = np.zeros(n_rec + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in recs])
+        total = int(off[-1])
+        c = code[bases]
+        pad = (-total) % 4
+        c4 = np.concatenate([c, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+        expect = ((c4[:, 0] << 6) | (c4[:, 1] << 4) | (c4[:, 2] << 2) | c4[:, 3]).astype(np.uint8)
+        assert np.array_equal(S.pack_2bit(bases)[:len(expect)], expect)
+        for parts in (1, 2, 3, 7):
+            out = np.full(len(expect) + 8, 0xAB, dtype=np.uint8)                           # stale bytes of a reused buffer
+            padded = np.concatenate([bases, np.zeros(64, np.uint8)])
+            host.sylph_host_pack_records(padded.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n_rec, parts,
+                                         out.ctypes.data_as(C.c_void_p))
+            # bytes wholly inside the stream must match; the last (partial) byte too — the writers zero-fill its unused bits
+            assert np.array_equal(out[:len(expect)], expect), (trial, parts)
