@@ -290,6 +290,10 @@ __device__ __forceinline__ void probe_long_run(HitStage& st, const LineView& v, 
     }
 }
 
+// PROBE_ILP k-mers per lane and step: their index lines are requested back to back (16 outstanding 16-byte loads per lane
+// at ILP 4) before the first one is looked at — with one line per lane in flight the wavefronts sat waiting 80 % of their
+// cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES, round 2) and a single-sample launch reached 22 % of the HBM roofline.
+template <int PROBE_ILP>
 __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const SampleRef* __restrict__ refs_mem, RefPack pack, uint32_t n_samples,
                                                           uint32_t n_chunks, LineView v, uint32_t n_genomes, const uint32_t* __restrict__ glen,
                                                           double min_number_kmers, int check_len, uint64_t* __restrict__ hits,
@@ -297,6 +301,7 @@ __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const SampleRef* __res
     __shared__ HitStage st;
     hit_stage_init(st);
     const SampleRef* __restrict__ refs = n_samples <= REFS_INLINE ? pack.r : refs_mem;   // (kernel-argument segment, or HBM)
+    // a chunk = PROBE_TPB * PROBE_ILP consecutive entries of ONE sample table (chunk0 counts such chunks)
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         uint32_t s = 0, hi = n_samples;                  // sample of this chunk: largest s with chunk0[s] <= chunk (uniform)
         while (hi - s > 1) {
@@ -305,25 +310,35 @@ __global__ __launch_bounds__(PROBE_TPB) void probe_kernel(const SampleRef* __res
         }
         const uint64_t* __restrict__ sk = refs[s].k;
         const uint32_t* __restrict__ sc = refs[s].c;
-        const uint64_t i = (uint64_t)(chunk - refs[s].chunk0) * PROBE_TPB + threadIdx.x;
+        const uint64_t n_s = refs[s].n;
+        const uint64_t i0 = (uint64_t)(chunk - refs[s].chunk0) * (PROBE_TPB * PROBE_ILP) + threadIdx.x;
         const uint64_t row0 = (uint64_t)s * n_genomes;
-        uint64_t long_start = ~0ull, long_rem = 0;
-        uint32_t cnt = 0;
-        if (i < refs[s].n) {
-            cnt = sc[i];
-            if (cnt != 0) {                                                          // contain.rs:634
-                for_each_posting(v, sk[i], [&](uint32_t g) {
-                    if (check_len && (double)glen[g] < min_number_kmers) return;     // contain.rs:627
-                    hit_stage_push(st, ((row0 + g) << 32) | cnt, hits, hit_cap, hit_count);
-                }, &long_start, &long_rem);
-            }
+        uint32_t cnt[PROBE_ILP];
+        uint64_t km[PROBE_ILP];
+#pragma unroll
+        for (int e = 0; e < PROBE_ILP; e++) {
+            const uint64_t i = i0 + (uint64_t)e * PROBE_TPB;
+            cnt[e] = i < n_s ? sc[i] : 0u;               // contain.rs:634: nothing for a zero count
+            km[e] = i < n_s ? sk[i] : 0ull;
         }
-        // long overflow runs, one after the other, by the whole wavefront (uniform loop: the ballot is the same in every lane)
-        for (unsigned long long todo = __ballot(long_start != ~0ull); todo; todo &= todo - 1) {
-            const int src = __ffsll((long long)todo) - 1;
-            const uint64_t rs = ((uint64_t)(uint32_t)__shfl((int)(long_start >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)long_start, src);
-            const uint64_t rm = ((uint64_t)(uint32_t)__shfl((int)(long_rem >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)long_rem, src);
-            probe_long_run(st, v, rs, rm, row0, (uint32_t)__shfl((int)cnt, src), glen, min_number_kmers, check_len, hits, hit_cap, hit_count);
+        LineFetch lf[PROBE_ILP];
+#pragma unroll
+        for (int e = 0; e < PROBE_ILP; e++) lf[e] = line_fetch(v, km[e], cnt[e] != 0);
+#pragma unroll
+        for (int e = 0; e < PROBE_ILP; e++) {
+            uint64_t long_start = ~0ull, long_rem = 0;
+            const uint32_t c_e = cnt[e];
+            line_scan(v, lf[e], [&](uint32_t g) {
+                if (check_len && (double)glen[g] < min_number_kmers) return;     // contain.rs:627
+                hit_stage_push(st, ((row0 + g) << 32) | c_e, hits, hit_cap, hit_count);
+            }, &long_start, &long_rem);
+            // long overflow runs, one after the other, by the whole wavefront (uniform loop: the ballot is the same in every lane)
+            for (unsigned long long todo = __ballot(long_start != ~0ull); todo; todo &= todo - 1) {
+                const int src = __ffsll((long long)todo) - 1;
+                const uint64_t rs = ((uint64_t)(uint32_t)__shfl((int)(long_start >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)long_start, src);
+                const uint64_t rm = ((uint64_t)(uint32_t)__shfl((int)(long_rem >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)long_rem, src);
+                probe_long_run(st, v, rs, rm, row0, (uint32_t)__shfl((int)c_e, src), glen, min_number_kmers, check_len, hits, hit_cap, hit_count);
+            }
         }
         hit_stage_flush(st, chunk + gridDim.x >= n_chunks, hits, hit_cap, hit_count);
     }
@@ -597,12 +612,14 @@ uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_numb
     sylph_ctx* ctx = db->ctx;
     const uint64_t G = db->n_genomes;
     uint64_t total = 0, chunks = 0;
+    static const int ilp_env = getenv("SYLPH_HIP_PROBE_ILP") ? atoi(getenv("SYLPH_HIP_PROBE_ILP")) : 0;   // tuning knob
+    const uint64_t ilp = ilp_env == 1 || ilp_env == 2 || ilp_env == 4 ? (uint64_t)ilp_env : 2;   // measured: 2 is best (profiles/r03_probe_ilp.txt)
     for (auto& r : refs) {
         SY_REQUIRE(r.n < (1ull << 32), "sample table larger than 2^32-1 entries");
         SY_REQUIRE(chunks < (1ull << 32), "batch too large");
         r.chunk0 = (uint32_t)chunks;
         r.pad = 0;
-        chunks += (r.n + PROBE_TPB - 1) / PROBE_TPB;
+        chunks += (r.n + PROBE_TPB * ilp - 1) / (PROBE_TPB * ilp);
         total += r.n;
     }
     SY_REQUIRE(chunks < (1ull << 32) && total < (1ull << 32), "batch holds more than 2^32-1 k-mers: split it");
@@ -626,9 +643,12 @@ uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_numb
         SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
         {
             ScopedKernelTimer t(ctx, "probe");
-            hipLaunchKernelGGL(probe_kernel, dim3(std::min<uint32_t>((uint32_t)chunks, probe_grid())), dim3(PROBE_TPB), 0, ctx->stream,
-                               db->q_refs.as<SampleRef>(), pack, (uint32_t)refs.size(), (uint32_t)chunks, db->kept.view(), (uint32_t)G,
-                               db->glen.as<uint32_t>(), min_number_kmers, check_len, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt);
+#define SY_LAUNCH_PROBE(I)                                                                                                                   \
+    hipLaunchKernelGGL(probe_kernel<I>, dim3(std::min<uint32_t>((uint32_t)chunks, probe_grid())), dim3(PROBE_TPB), 0, ctx->stream,            \
+                       db->q_refs.as<SampleRef>(), pack, (uint32_t)refs.size(), (uint32_t)chunks, db->kept.view(), (uint32_t)G,               \
+                       db->glen.as<uint32_t>(), min_number_kmers, check_len, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt)
+            if (ilp == 4) SY_LAUNCH_PROBE(4); else if (ilp == 2) SY_LAUNCH_PROBE(2); else SY_LAUNCH_PROBE(1);
+#undef SY_LAUNCH_PROBE
             SY_HIP(hipGetLastError());
         }
         uint32_t hc[2] = {0, 0};

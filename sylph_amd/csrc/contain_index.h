@@ -84,6 +84,60 @@ __device__ __forceinline__ void for_each_posting(const LineView& v, uint64_t km,
         }
     }
 }
+
+// The same in two halves, so that a lane can have the lines of several k-mers in flight before it looks at any of them (the
+// probe is latency-bound: random 64 B reads): line_fetch computes the bucket and issues the four loads, line_scan walks the
+// slots (and the short overflow run) exactly as for_each_posting does.
+struct LineFetch {
+    uint4 a, b, c, d;
+    uint64_t rem;
+    bool live;
+};
+__device__ __forceinline__ LineFetch line_fetch(const LineView& v, uint64_t km, bool wanted) {
+    LineFetch f;
+    f.live = false;
+    f.rem = 0;
+    f.a = f.b = f.c = f.d = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (!wanted || km < v.base) return f;
+    const uint64_t x = km - v.base;
+    uint64_t q, rem;
+    if (v.div == 1) { q = x; rem = 0; }
+    else {
+        q = __umul64hi(x, v.magic);                       // floor(x * floor(2^64/div) / 2^64) is q or q - 1
+        rem = x - q * v.div;
+        if (rem >= v.div) { rem -= v.div; q++; }
+    }
+    if (q >= v.n_buckets) return f;
+    const uint4* lp = reinterpret_cast<const uint4*>(v.lines + q * LINE_SLOTS);
+    f.a = lp[0]; f.b = lp[1]; f.c = lp[2]; f.d = lp[3];
+    f.rem = rem;
+    f.live = true;
+    return f;
+}
+template <class F>
+__device__ __forceinline__ void line_scan(const LineView& v, const LineFetch& l, F&& f, uint64_t* long_start, uint64_t* long_rem) {
+    *long_start = ~0ull;
+    if (!l.live) return;
+    const uint64_t rem = l.rem;
+    const uint64_t s[LINE_SLOTS] = {((uint64_t)l.a.y << 32) | l.a.x, ((uint64_t)l.a.w << 32) | l.a.z, ((uint64_t)l.b.y << 32) | l.b.x,
+                                    ((uint64_t)l.b.w << 32) | l.b.z, ((uint64_t)l.c.y << 32) | l.c.x, ((uint64_t)l.c.w << 32) | l.c.z,
+                                    ((uint64_t)l.d.y << 32) | l.d.x, ((uint64_t)l.d.w << 32) | l.d.z};
+    const uint64_t flag = 1ull << (v.gshift - 1), gmask = flag - 1;
+#pragma unroll
+    for (int j = 0; j < LINE_SLOTS; j++)
+        if ((s[j] >> v.gshift) == rem && !(s[j] & flag)) f((uint32_t)(s[j] & gmask));
+    const uint64_t last = s[LINE_SLOTS - 1];
+    if ((last & flag) && last != SLOT_EMPTY && (s[LINE_SLOTS - 2] >> v.gshift) <= rem) {   // descriptor: rest of the bucket
+        if ((last & gmask) >= LONG_RUN_MIN) { *long_start = last >> v.gshift; *long_rem = rem; return; }
+        for (uint64_t i = last >> v.gshift;; i++) {
+            const uint64_t y = v.ovf[i];
+            if (y == SLOT_EMPTY) break;
+            const uint64_t r = y >> v.gshift;
+            if (r > rem) break;                            // the run is sorted by (remainder, genome)
+            if (r == rem) f((uint32_t)(y & gmask));
+        }
+    }
+}
 #endif
 
 // Layout of the result block, identical on the device (one buffer, ONE device->host copy) and in pinned host memory:

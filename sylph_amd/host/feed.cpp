@@ -186,7 +186,7 @@ unsigned parse_threads() {
     static const unsigned n = [] {
         if (const char* e = getenv("SYLPH_HIP_PARSE_THREADS")) return (unsigned)std::max(1, atoi(e));
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        return std::min(32u, std::max(std::min(hw, 8u), hw / 4));
+        return std::min(64u, std::max(std::min(hw, 8u), hw / 4));
     }();
     return n;
 }
@@ -317,10 +317,43 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     if (fstat(fd, &st) != 0 || st.st_size < 4 || !S_ISREG(st.st_mode)) { close(fd); return; }
     size = (size_t)st.st_size;
     void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) { data = nullptr; return; }
+    if (m == MAP_FAILED) { close(fd); data = nullptr; return; }
     data = (const uint8_t*)m;
     (void)madvise(m, size, MADV_WILLNEED);
+    // An uncompressed file is COPIED into anonymous memory (2 MiB pages where the system gives them) by all parse threads with
+    // pread: walking a file mapping costs one minor fault per 64 KiB, all of them under the process's one address-space lock —
+    // with 2 x 64 threads indexing the two mate files that lock, not the memory, set the pace (70 ms per GB; the copy takes
+    // ~15).  Within the memory budget only (beyond it the file stays a mapping: page cache, reclaimable), and the copy's pages
+    // are given back behind the gather cursor like those of an inflated file.
+    if (!(data[0] == 0x1f && data[1] == 0x8b) && !getenv("SYLPH_HIP_FEED_MMAP")) {
+        const size_t budget = index_memory_budget();
+        if (!budget || size <= budget) {
+            void* buf = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (buf != MAP_FAILED) {
+                (void)madvise(buf, size, MADV_HUGEPAGE);
+                const unsigned Tc = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, size / (8u << 20) + 1));
+                std::vector<char> good(Tc, 1);
+                run_workers(Tc, [&](unsigned w) {
+                    size_t p = size / Tc * w;
+                    const size_t end = w + 1 == Tc ? size : size / Tc * (w + 1);
+                    while (p < end) {
+                        const ssize_t r = pread(fd, (uint8_t*)buf + p, std::min<size_t>(end - p, 8u << 20), (off_t)p);
+                        if (r <= 0) { good[w] = 0; return; }
+                        p += (size_t)r;
+                    }
+                });
+                bool all = true;
+                for (char g : good) all = all && g;
+                if (all) {
+                    munmap(m, size);
+                    data = (const uint8_t*)buf;
+                    anonymous = true;
+                } else
+                    munmap(buf, size);
+            }
+        }
+    }
+    close(fd);
     if (data[0] == 0x1f && data[1] == 0x8b) {
         // blocked gzip: inflate all members in parallel into an anonymous mapping that takes the file mapping's place
         std::vector<BgzfBlock> blocks;
@@ -345,6 +378,8 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     const uint8_t* d = data;
     const size_t n = size;
     if (d[0] != '@') return;                                      // not FASTQ: sequential reader
+    static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
+    const auto t_ix0 = std::chrono::steady_clock::now();
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / (1u << 20)));
     // a record starts at a line that begins with '@' and whose line after next begins with '+' (a QUALITY line may begin
     // with '@' too, but then the line after next is a sequence line)
@@ -410,6 +445,9 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
         }
     });
     ok = true;
+    if (trace)
+        fprintf(stderr, "[sylph_hip feed] index of %-40s %8.3f ms (%zu records, %u threads)\n", path.c_str(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ix0).count() * 1e3, seq_len.size(), T);
 }
 
 void PinnedBatch::gather_packed(int slot, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
@@ -434,12 +472,12 @@ void PinnedBatch::gather_packed(int slot, const FastqIndex& a, const FastqIndex*
         Pack2Bit& wr = writers[w];
         for (size_t i = j0; i < j1; i++) {
             uint64_t o = cum_a[i] + (b ? (*cum_b)[i] : 0) - base0;
-            wr.append(a.data + a.seq_off[i], a.seq_len[i]);
+            wr.append(a.data + a.seq_off[i], a.seq_len[i], a.size - a.seq_off[i]);
             o += a.seq_len[i];
             const size_t r = (b ? 2 * (i - i0) : (i - i0)) + 1;
             p.off[r] = o;
             if (b) {
-                wr.append(b->data + b->seq_off[i], b->seq_len[i]);
+                wr.append(b->data + b->seq_off[i], b->seq_len[i], b->size - b->seq_off[i]);
                 p.off[r + 1] = o + b->seq_len[i];
             }
         }

@@ -31,14 +31,14 @@ const Lut& lut() { static const Lut l; return l; }
 #if defined(__x86_64__)
 // 32 bases -> 64 bits, first base most significant; false when some byte is not one of ACGTacgt (the caller then takes the
 // table: N, U, raw codes ...)
-__attribute__((target("avx2"))) bool pack32_avx2(const uint8_t* p, uint64_t* out) {
+__attribute__((target("avx2"))) bool pack32_avx2(const uint8_t* p, uint64_t* out, uint32_t valid_mask = 0xFFFFFFFFu) {
     const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
     const __m256i three = _mm256_set1_epi8(3);
     const __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);   // ((b>>1)^(b>>2))&3
     const __m256i letters = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
     const __m256i expect = _mm256_shuffle_epi8(letters, c);
     const __m256i upper = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));
-    if ((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(upper, expect)) != 0xFFFFFFFFu) return false;
+    if (((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(upper, expect)) & valid_mask) != valid_mask) return false;
     const __m256i w = _mm256_setr_epi8(64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1);
     const __m256i t = _mm256_madd_epi16(_mm256_maddubs_epi16(c, w), _mm256_set1_epi16(1));   // 8 x i32: the packed byte of bases 4j .. 4j+3
     const __m256i y = _mm256_packus_epi32(t, t);
@@ -78,7 +78,18 @@ void Pack2Bit::push64(uint64_t v) {
     acc_ = v << (64 - nacc_);
 }
 
-void Pack2Bit::append(const uint8_t* seq, size_t len) {
+void Pack2Bit::push_bits(uint64_t v, unsigned nbits) {   // the nbits (even, 2 .. 62) most significant bits of v
+    v &= ~0ull << (64 - nbits);
+    acc_ |= v >> nacc_;
+    if (nacc_ + nbits >= 64) {
+        emit(acc_, 8);
+        acc_ = nacc_ ? v << (64 - nacc_) : 0;
+        nacc_ = nacc_ + nbits - 64;
+    } else
+        nacc_ += nbits;
+}
+
+void Pack2Bit::append(const uint8_t* seq, size_t len, size_t readable) {
     const uint8_t* L = lut().v;
 #if defined(__x86_64__)
     if (have_avx2()) {
@@ -91,6 +102,13 @@ void Pack2Bit::append(const uint8_t* seq, size_t len) {
             push64(v);
             seq += 32;
             len -= 32;
+            readable = readable > 32 ? readable - 32 : 0;
+        }
+        // the last 1 .. 31 bases of a record: one more 32-byte load when the bytes behind them are readable (inside a FASTQ
+        // file they are the '+' and quality lines), validated and kept only as far as the record goes
+        if (len && readable >= 32) {
+            uint64_t v;
+            if (pack32_avx2(seq, &v, (1u << len) - 1u)) { push_bits(v, (unsigned)len * 2); return; }
         }
     }
 #endif
@@ -133,15 +151,15 @@ void merge_pack_edges(uint8_t* out, const Pack2Bit* w, size_t n) {
 
 extern "C" {
 // test entry: packs `n_rec` records (concatenated in `bases`, offsets `off`) with `parts` writers over equal shares of the
-// records, merges the shared bytes, returns the packed stream in out ((total + 3) / 4 bytes, zero-initialised by the caller)
-int sylph_host_pack_records(const uint8_t* bases, const uint64_t* off, uint64_t n_rec, uint32_t parts, uint8_t* out) {
+// records, merges the shared bytes, returns the packed stream in out ((total + 3) / 4 bytes); buf_len = readable bytes of `bases`
+int sylph_host_pack_records(const uint8_t* bases, const uint64_t* off, uint64_t n_rec, uint32_t parts, uint8_t* out, uint64_t buf_len) {
     using sylph_host::Pack2Bit;
     if (parts == 0) parts = 1;
     std::vector<Pack2Bit> w;
     for (uint32_t p = 0; p < parts; p++) {
         const uint64_t r0 = n_rec * p / parts, r1 = n_rec * (p + 1) / parts;
         w.emplace_back(out, off[r0]);
-        for (uint64_t r = r0; r < r1; r++) w.back().append(bases + off[r], (size_t)(off[r + 1] - off[r]));
+        for (uint64_t r = r0; r < r1; r++) w.back().append(bases + off[r], (size_t)(off[r + 1] - off[r]), (size_t)(buf_len - off[r]));
         w.back().finish();
     }
     sylph_host::merge_pack_edges(out, w.data(), w.size());

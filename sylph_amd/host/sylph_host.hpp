@@ -122,7 +122,8 @@ size_t index_memory_budget();
 class Pack2Bit {
    public:
     Pack2Bit(uint8_t* out, uint64_t base_offset);   // `out` = start of the whole stream; this writer begins at base `base_offset`
-    void append(const uint8_t* seq, size_t len);
+    // `readable`: bytes that may be read from seq on (>= len; more lets the last bases of the record take the vector path too)
+    void append(const uint8_t* seq, size_t len, size_t readable = 0);
     void finish();
     // the bytes this part shares with its neighbours (not stored by the writer): merge_pack_edges puts them together
     uint64_t first_byte = 0, last_byte = 0;
@@ -131,6 +132,7 @@ class Pack2Bit {
    private:
     void emit(uint64_t word, unsigned n_bytes);
     void push64(uint64_t v);
+    void push_bits(uint64_t v, unsigned nbits);
     uint8_t* outp_;
     uint8_t* base_ = nullptr;
     uint64_t acc_ = 0;

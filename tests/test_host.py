@@ -389,13 +389,19 @@ def test_fastx_reader_and_threaded_feed_agree(host, tmp_path):
             list(rng.integers(0, 400, size=3000)) + [0, 1, 70000]]
     fq = b"".join(b"@r%d some text\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs))
     fa = b"".join(b">c%d\n" % i + b"".join(s[j:j + 60] + b"\n" for j in range(0, len(s), 60)) for i, s in enumerate(seqs))
-    cases = {"a.fq": fq, "b.fastq": fq.replace(b"\n", b"\r\n"), "c.fa": fa, "d.fasta": b"\n\n" + fa.replace(b"\n>", b"\n\n>"),
+    cases = {"a.fq": fq, "b.fastq": fq.replace(b"\n", b"\r\n"), "c.fa": fa, "d.fasta": fa.replace(b"\n>", b"\n\n>"),
              "f.fa": b">only header\n"}
     for name, text in cases.items():
         for gz in (False, True):
             path = tmp_path / (name + (".gz" if gz else ""))
             path.write_bytes(gzip.compress(text, 1) if gz else text)
             exp = _py_records(text)
+            if name == "a.fq" and not gz:
+                # the very first byte decides the format (needletail's parse_fastx_reader): a leading blank line is an error
+                blank = tmp_path / "leading_blank.fq"
+                blank.write_bytes(b"\n" + text)
+                v = [C.c_uint64(0) for _ in range(4)]
+                assert host.sylph_host_fastx_digest(str(blank).encode(), 0, *[C.byref(x) for x in v]) != 0
             got = []
             for threaded in (0, 1):
                 v = [C.c_uint64(0) for _ in range(4)]
@@ -531,7 +537,7 @@ def test_parallel_2bit_packer_matches_byte_to_seq(host):
     base offset, shared bytes merged afterwards, the AVX2 path and the table path — against BYTE_TO_SEQ spelled out here and
     against the library's own sylph_pack_2bit."""
     import sylph_amd as S
-    host.sylph_host_pack_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    host.sylph_host_pack_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64]
     code = np.zeros(256, dtype=np.uint8)
     for ch, v in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"TtUu", 3)):
         for b in ch:
@@ -562,8 +568,12 @@ def test_parallel_2bit_packer_matches_byte_to_seq(host):
         assert np.array_equal(S.pack_2bit(bases)[:len(expect)], expect)
         for parts in (1, 2, 3, 7):
             out = np.full(len(expect) + 8, 0xAB, dtype=np.uint8)                           # stale bytes of a reused buffer
-            padded = np.concatenate([bases, np.zeros(64, np.uint8)])
-            host.sylph_host_pack_records(padded.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n_rec, parts,
-                                         out.ctypes.data_as(C.c_void_p))
+            # bytes behind the stream: readable (the vector path of a record's last bases loads them) or not (table path)
+            for slack in (64, 0):
+                padded = np.concatenate([bases, rng.integers(0, 256, size=64).astype(np.uint8)])
+                out[:] = 0xAB
+                host.sylph_host_pack_records(padded.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n_rec, parts,
+                                             out.ctypes.data_as(C.c_void_p), total + slack)
+                assert np.array_equal(out[:len(expect)], expect), (trial, parts, slack)
             # bytes wholly inside the stream must match; the last (partial) byte too — the writers zero-fill its unused bits
             assert np.array_equal(out[:len(expect)], expect), (trial, parts)
