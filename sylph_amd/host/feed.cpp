@@ -319,13 +319,14 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (m == MAP_FAILED) { close(fd); data = nullptr; return; }
     data = (const uint8_t*)m;
-    (void)madvise(m, size, MADV_WILLNEED);
     // An uncompressed file is COPIED into anonymous memory (2 MiB pages where the system gives them) by all parse threads with
     // pread: walking a file mapping costs one minor fault per 64 KiB, all of them under the process's one address-space lock —
     // with 2 x 64 threads indexing the two mate files that lock, not the memory, set the pace (70 ms per GB; the copy takes
     // ~15).  Within the memory budget only (beyond it the file stays a mapping: page cache, reclaimable), and the copy's pages
     // are given back behind the gather cursor like those of an inflated file.
-    if (!(data[0] == 0x1f && data[1] == 0x8b) && !getenv("SYLPH_HIP_FEED_MMAP")) {
+    // (opt-in, SYLPH_HIP_FEED_COPY=1: measured on the GPU box, the copy halves the index time but its page zeroing and the extra
+    //  pass over the data slow the gather of the sample being pushed meanwhile by more than that)
+    if (!(data[0] == 0x1f && data[1] == 0x8b) && getenv("SYLPH_HIP_FEED_COPY")) {
         const size_t budget = index_memory_budget();
         if (!budget || size <= budget) {
             void* buf = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
@@ -386,6 +387,11 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     std::vector<size_t> starts(T + 1, n);
     starts[0] = 0;
     run_workers(T, [&](unsigned w) {
+        {   // read-ahead for this worker's share of a file mapping, asked for by the worker itself (one call over the whole
+            // file walks a quarter of a million page-cache entries on the caller's thread before anything else happens)
+            const size_t a = n / T * w / 4096 * 4096, b = w + 1 == T ? n : n / T * (w + 1);
+            if (!anonymous && b > a) (void)madvise((void*)(d + a), b - a, MADV_WILLNEED);
+        }
         if (w == 0) return;
         size_t p = next_line(d, n, n / T * w);
         while (p < n) {

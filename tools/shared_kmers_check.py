@@ -40,8 +40,8 @@ for n_strains in (10, 100, 1000, 5000):
         ctx.profile(False)
     n_hits = int(off[-1])
     ok = ""
-    if n_strains <= 1000:     # the oracle on the same inputs (counts and every coverage vector)
-        ecc, ecov, _ = O.contain(sk, sc, kmers, goff, n_threads=32)
+    if True:                  # the oracle on the same inputs, for every case incl. the 5,000 strains (counts of all genomes, every 7th coverage vector)
+        ecc, ecov, _ = O.contain(sk, sc, kmers, goff, n_threads=min(64, os.cpu_count() or 1))
         same = bool(np.array_equal(cc, ecc)) and all(np.array_equal(np.asarray(covs[int(off[g]):int(off[g + 1])]).astype(np.uint32), np.sort(ecov[g]))
                                                        for g in range(0, len(gs), 7))
         ok = f", oracle agrees: {same}"
