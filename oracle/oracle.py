@@ -55,6 +55,8 @@ def lib():
                                                 C.c_void_p, C.c_uint64]
     L.orc_pair_kmer_single.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     L.orc_pair_kmer.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.orc_sketch_reads_cuckoo.restype = C.c_void_p
+    L.orc_sketch_reads_cuckoo.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_uint64]
     L.orc_sketch_reads.restype = C.c_void_p
     L.orc_sketch_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
     for f in ("orc_sketch_size", "orc_sketch_dup_removed"):
@@ -162,6 +164,25 @@ def sketch_reads(bases, off, c=200, k=31, mode=MODE_AVX2_COMPAT, paired=False, n
     h = lib().orc_sketch_reads(_ptr(bases), _ptr(off), n, c, k, mode, int(paired), int(no_dedup))
     if not h:
         raise ValueError("oracle sketch failed (k unsupported on AVX2 path)")
+    try:
+        m = lib().orc_sketch_size(h)
+        kmers = np.empty(m, dtype=np.uint64)
+        counts = np.empty(m, dtype=np.uint32)
+        lib().orc_sketch_copy(h, _ptr(kmers), _ptr(counts))
+        return dict(kmers=kmers, counts=counts, dup_removed=int(lib().orc_sketch_dup_removed(h)),
+                    mean_read_length=float(lib().orc_sketch_mean_read_length(h)))
+    finally:
+        lib().orc_sketch_free(h)
+
+
+def sketch_reads_cuckoo_model(bases, off, c=200, k=31, mode=MODE_AVX2_COMPAT, fpr=1e-4, initial_capacity=10_000_000):
+    """sketch_pair_sequences with the DEFAULT dedup (sketch.rs:733-769 over a scalable cuckoo filter; --fpr 1e-4, capacity 10^7
+    at :796-804), the filter restated from the paper — a model of the third-party crate, not its bits (see sylph_oracle.cpp)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    h = lib().orc_sketch_reads_cuckoo(_ptr(bases), _ptr(off), len(off) - 1, c, k, mode, float(fpr), int(initial_capacity))
+    if not h:
+        raise ValueError("oracle sketch failed")
     try:
         m = lib().orc_sketch_size(h)
         kmers = np.empty(m, dtype=np.uint64)

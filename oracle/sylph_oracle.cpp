@@ -397,6 +397,121 @@ int sketch_paired(ReadSketch& sk, const uint8_t* bases, const uint64_t* off, uin
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// a10: the APPROXIMATE paired-end dedup the reference uses by default (sketch.rs:733-769 dup_removal_lsh_full over a
+// scalable_cuckoo_filter 0.2.4, built at :796-804 with initial capacity 10^7 and --fpr 1e-4).  The crate is NOT in /root/reference:
+// what follows is the published structure (Fan et al., "Cuckoo Filter: Practically Better Than Bloom", CoNEXT 2014) with the
+// crate's defaults AS DOCUMENTED — 4 entries per bucket, fingerprint width ceil(log2(1/fpr) + log2(2 * 4)) bits, 512 kicks, a
+// further filter of twice the capacity and fpr * 0.9 when one fills up.  Its hash bits, eviction choices and growth points are
+// not the crate's: this is a MODEL of the default path for measuring how far the exact set (what the GPU implements) is from it,
+// not a parity target ("parity unpinned").
+struct CuckooFilter {
+    std::vector<uint32_t> slots;            // n_buckets x 4 fingerprints (0 = empty)
+    uint64_t n_buckets = 0, n_items = 0, capacity = 0;
+    int fp_bits = 17;
+    uint64_t rng = 0x9E3779B97F4A7C15ULL;
+    void init(uint64_t cap, double fpr) {
+        capacity = cap;
+        fp_bits = (int)std::ceil(std::log2(1.0 / fpr) + std::log2(8.0));
+        if (fp_bits > 31) fp_bits = 31;
+        n_buckets = 1;
+        while (n_buckets * 4 < cap) n_buckets <<= 1;       // next power of two of capacity / entries per bucket
+        slots.assign(n_buckets * 4, 0);
+        n_items = 0;
+    }
+    uint32_t fingerprint(uint64_t h) const { const uint32_t f = (uint32_t)(h >> 32) & ((1u << fp_bits) - 1u); return f ? f : 1u; }
+    uint64_t alt(uint64_t i, uint32_t f) const { return (i ^ (fx_add(0, f) >> 11)) & (n_buckets - 1); }
+    bool contains(uint64_t h) const {
+        const uint32_t f = fingerprint(h);
+        const uint64_t i1 = h & (n_buckets - 1), i2 = alt(i1, f);
+        for (int e = 0; e < 4; e++) if (slots[i1 * 4 + e] == f || slots[i2 * 4 + e] == f) return true;
+        return false;
+    }
+    bool insert(uint64_t h) {
+        uint32_t f = fingerprint(h);
+        uint64_t i = h & (n_buckets - 1);
+        for (int side = 0; side < 2; side++) {
+            const uint64_t b = side ? alt(i, f) : i;
+            for (int e = 0; e < 4; e++) if (!slots[b * 4 + e]) { slots[b * 4 + e] = f; n_items++; return true; }
+        }
+        for (int kick = 0; kick < 512; kick++) {
+            rng = rng * 6364136223846793005ULL + 1442695040888963407ULL;
+            const int e = (int)(rng >> 62);
+            std::swap(f, slots[i * 4 + e]);
+            i = alt(i, f);
+            for (int e2 = 0; e2 < 4; e2++) if (!slots[i * 4 + e2]) { slots[i * 4 + e2] = f; n_items++; return true; }
+        }
+        return false;                                       // full (the displaced fingerprint is lost, as in the paper's algorithm)
+    }
+};
+struct ScalableCuckoo {
+    std::vector<CuckooFilter> filters;
+    double fpr;
+    uint64_t cap0;
+    ScalableCuckoo(uint64_t initial_capacity, double f) : fpr(f), cap0(initial_capacity) { grow(); }
+    void grow() {
+        CuckooFilter cf;
+        const size_t n = filters.size();
+        cf.init(cap0 << n, fpr * std::pow(0.9, (double)n));
+        filters.push_back(std::move(cf));
+    }
+    static uint64_t hash(uint64_t a, uint64_t b) { return PairSet::hash(a, b) * 0x9E3779B97F4A7C15ULL; }   // (FxHasher of the tuple, mixed)
+    bool contains(uint64_t a, uint64_t b) const {
+        const uint64_t h = hash(a, b);
+        for (const auto& f : filters) if (f.contains(h)) return true;
+        return false;
+    }
+    void insert(uint64_t a, uint64_t b) {
+        const uint64_t h = hash(a, b);
+        if (filters.back().n_items >= filters.back().capacity || !filters.back().insert(h)) { grow(); filters.back().insert(h); }
+    }
+};
+// sketch.rs:733-769 dup_removal_lsh_full
+inline void dup_removal_lsh_full(CountMap& counts, ScalableCuckoo& set, uint64_t km, const Markers& pair, uint64_t& num_dup_removed,
+                                 bool no_dedup) {
+    uint32_t* c = counts.entry(km);                                // :743
+    if (!no_dedup && pair.some) {                                  // :744-745
+        bool ret = false;
+        const uint64_t m0 = (uint64_t)pair.m[0] | ((uint64_t)pair.m[1] << 32);
+        const uint64_t m1 = (uint64_t)pair.m[2] | ((uint64_t)pair.m[3] << 32);
+        if (set.contains(km, m0)) { if (*c > 0) ret = true; }      // :747-753
+        else set.insert(km, m0);
+        if (set.contains(km, m1)) { if (*c > 0) ret = true; }      // :754-760
+        else set.insert(km, m1);
+        if (ret) { num_dup_removed++; return; }                    // :761-764
+    }
+    *c += 1;                                                       // :767
+}
+// sketch.rs:771-895 with dedup_fpr != 0 (the default): the same record loop as sketch_paired, the filter in place of the set
+int sketch_paired_cuckoo(ReadSketch& sk, const uint8_t* bases, const uint64_t* off, uint64_t n_pairs, uint64_t c, uint64_t k, int mode,
+                         double fpr, uint64_t initial_capacity) {
+    ScalableCuckoo set(initial_capacity, fpr);
+    std::vector<uint64_t> v1, v2;
+    double mean = 0.0, counter = 0.0;
+    for (uint64_t p = 0; p < n_pairs; p++) {
+        const uint8_t* s1 = bases + off[2 * p];
+        const uint64_t l1 = off[2 * p + 1] - off[2 * p];
+        const uint8_t* s2 = bases + off[2 * p + 1];
+        const uint64_t l2 = off[2 * p + 2] - off[2 * p + 1];
+        v1.clear(); v2.clear();
+        int rc = seeds_dispatch(s1, l1, c, k, mode, false, [&](uint64_t, uint64_t h) { v1.push_back(h); });
+        if (rc) return rc;
+        rc = seeds_dispatch(s2, l2, c, k, mode, false, [&](uint64_t, uint64_t h) { v2.push_back(h); });
+        if (rc) return rc;
+        Markers kmer_pair = pair_kmer(s1, l1, s2, l2);
+        counter += 1.0;
+        mean = mean + ((double)l1 - mean) / counter;
+        for (uint64_t km : v1) dup_removal_lsh_full(sk.counts, set, km, kmer_pair, sk.num_dup_removed, false);
+        for (uint64_t km : v2) {
+            if (std::find(v1.begin(), v1.end(), km) != v1.end()) continue;   // :852
+            dup_removal_lsh_full(sk.counts, set, km, kmer_pair, sk.num_dup_removed, false);
+        }
+    }
+    sk.mean_read_length = mean;
+    sk.n_records = n_pairs;
+    return 0;
+}
+
 // sketch.rs:550-622 sketch_genome on already-parsed contigs (contig i = bases[off[i], off[i+1])).
 // types.rs:88-90 MMHashSet only decides membership, so std::unordered_set is equivalent.
 struct GenomeSketchO {
@@ -560,6 +675,14 @@ void* orc_sketch_reads(const uint8_t* bases, const uint64_t* off, uint64_t n_rec
     int rc = paired ? sketch_paired(*sk, bases, off, n_records / 2, c, k, mode, no_dedup != 0)
                     : sketch_single(*sk, bases, off, n_records, c, k, mode, no_dedup != 0);
     if (rc) { delete sk; return nullptr; }
+    sk->finalize();
+    return sk;
+}
+// the default (approximate) paired dedup, as modelled above
+void* orc_sketch_reads_cuckoo(const uint8_t* bases, const uint64_t* off, uint64_t n_records, uint64_t c, uint64_t k, int mode, double fpr,
+                              uint64_t initial_capacity) {
+    ReadSketch* sk = new ReadSketch();
+    if (sketch_paired_cuckoo(*sk, bases, off, n_records / 2, c, k, mode, fpr, initial_capacity)) { delete sk; return nullptr; }
     sk->finalize();
     return sk;
 }
