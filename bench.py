@@ -96,8 +96,8 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     t0 = time.time()
     n_mut = n_seq // 10
     community = synth.random_genomes(n_comm, glen, device, seed, mutated_frac=0.0)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed + 17)
+    idx_g = torch.arange(glen, dtype=torch.int64, device=device)
+    mut_thr = int(0.03 * (1 << 32))
     sub = torch.tensor([67, 71, 84, 65], dtype=torch.uint8, device=device)   # A->C, C->G, G->T, T->A
     lut = torch.zeros(256, dtype=torch.uint8, device=device)
     lut[torch.tensor([65, 67, 71, 84], device=device)] = sub
@@ -113,7 +113,7 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
                 seq = community[g]
             elif g >= n_seq - n_mut:
                 src = community[(g - (n_seq - n_mut)) % n_comm]
-                mask = torch.rand(glen, generator=gen, device=device) < 0.03
+                mask = synth._u32(synth.sm64(synth.stream(seed, 2_000_000 + g), idx_g)) < mut_thr   # 97 % identity, substitutions only
                 seq = torch.where(mask, lut[src.long()], src)
             else:
                 seq = synth.random_genomes(1, glen, device, seed + 1000 + g, mutated_frac=0.0)[0]
@@ -576,7 +576,8 @@ def main():
                    "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)",
                    "seed_mode": "avx2_compat", "parallelism": parallelism,
                    "inputs": "reads + database resident in HBM before the timed region",
-                   "rng": "torch (Philox) generators on the device, seed 20250711 + 1000003*(rank+1) + 7919*set — not the splitmix64 streams of SURVEY 8d"},
+                   "rng": "splitmix64 counter streams (synth.py: every random number = one word of a stream addressed by its index, integer arithmetic "
+                          "only; host float tables for the abundances / decoy lengths), read set seed 20250711 + 1000003*(rank+1) + 7919*set"},
         "mode": mode, "value_is": f"{mode}: all bases of the {args.steps} timed steps / their wall time (max over ranks)",
         "timed_region_s": main_leg["timed_region_s"], "ms_per_sample": main_leg["ms_per_sample"],
         "step_ms": main_leg["step_ms"], "sample_interval_ms": main_leg["sample_interval_ms"],
