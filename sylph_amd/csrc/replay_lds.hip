@@ -43,7 +43,10 @@ constexpr uint32_t SEG_LIMIT = 96;
 // smallest hs of bucket b is ceil(b * 2^32 / mult).
 // range_hs = widest bucket in hs units; sub_mult[i] = floor(2^32 * CAP_i / range_hs) for the three replay configurations (the
 // sub-range of a hash inside its bucket, see replay_bucket), 0 when a bucket is narrower than CAP_i hs units.
-struct BucketMap { int sh; uint32_t mult; uint32_t B; int composite; uint32_t range_hs; uint32_t sub_mult[3]; };
+// rank_bits[i] > 0: (hash - lowest hash the sub-range can hold) << rank_bits | gather index fits in 64 bits for configuration
+// i — the key the occurrences of a sub-range are ranked by with ONE compare; sub_width[i] = floor(range_hs / CAP_i) hs units (a
+// lower bound of where sub-range s begins: s * sub_width).
+struct BucketMap { int sh; uint32_t mult; uint32_t B; int composite; uint32_t range_hs; uint32_t sub_mult[3]; uint32_t sub_width[3]; int rank_bits[3]; };
 
 __device__ __forceinline__ uint32_t bucket_of_key(uint32_t key, const BucketMap m) { return min(__umulhi(key, m.mult), m.B - 1u); }
 
@@ -331,41 +334,77 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
 #pragma unroll
             for (int e = 0; e < PER; e++) { v[e] = s_cnt[tid * PER + e]; sum += v[e]; }
             uint32_t run = block_excl_sum<RTPB>(sum, s_wave, nullptr);
+            bool deep = false;
 #pragma unroll
-            for (int e = 0; e < PER; e++) { s_cnt[tid * PER + e] = run; run += v[e]; }
+            for (int e = 0; e < PER; e++) { s_cnt[tid * PER + e] = run; run += v[e]; deep |= v[e] >= SEG_LIMIT; }
             if (tid == RTPB - 1) s_cnt[CAP] = run;
+            // A k-mer SEG_LIMIT deep fills its sub-range that far (equal hashes share a sub-range): such a bucket is for the
+            // hashed marker test of the next configuration — pass it on now, before the placement, the ranking (as long as the k-mer
+            // is deep, per occurrence) and the segment scans are spent on it here.  (A sub-range that full without a deep k-mer
+            // does not happen with ~0.5 occurrences per sub-range; the next configuration is right for any bucket it can hold.)
+            if constexpr (CAP == CAP_SMALL) {
+                if (__syncthreads_or(deep && !no_dedup)) {
+                    if (tid == 0) mid_list[1 + atomicAdd(&mid_list[0], 1u)] = b;
+                    return;
+                }
+            } else
+                __syncthreads();
         }
-        __syncthreads();
         // place (cursor = a second counter array would cost LDS: take places from the END of each sub-range instead, counting the
         // start words' neighbours down is not possible either — so the places come from s_seg, which is free until the segments)
         uint16_t* const s_fill = s_seg;                               // members placed so far per sub-range (<= CAP: 16 bits do)
         for (uint32_t t = tid; t < (uint32_t)CAP; t += RTPB) s_fill[t] = 0;
         __syncthreads();
+        constexpr int CFG = CAP == CAP_SMALL ? 0 : CAP == CAP_MID ? 1 : 2;
+        const int rank_bits = bm.rank_bits[CFG];
+        // ranking key of an occurrence inside its sub-range: (hash - a lower bound of the sub-range's hashes, index) in one word
+        // when the host found room for both (rank_bits > 0), else the hash with the indices in a second array
+        uint64_t rkey[ITEMS];
 #pragma unroll
         for (int q = 0; q < ITEMS; q++) {
             const uint32_t i = tid + q * RTPB;
+            rkey[q] = 0;
             if (i < n) {
                 // 16-bit LDS atomics do not exist: the counter pairs share a word; add 1 or 65536 to the word and take the half
                 uint32_t* const w = reinterpret_cast<uint32_t*>(s_fill) + (sub[q] >> 1);
                 const uint32_t old = atomicAdd(w, (sub[q] & 1u) ? 65536u : 1u);
                 const uint32_t place = s_cnt[sub[q]] + ((sub[q] & 1u) ? (old >> 16) : (old & 0xFFFFu));
-                s_key[place] = r[q].hash;
-                s_pidx[place] = pidx[q];
+                if (rank_bits) {
+                    const uint64_t res = (r[q].hash - lo_hash) - ((uint64_t)(sub[q] * bm.sub_width[CFG]) << bm.sh);
+                    rkey[q] = (res << rank_bits) | pidx[q];
+                    s_key[place] = rkey[q];
+                } else {
+                    s_key[place] = r[q].hash;
+                    s_pidx[place] = pidx[q];
+                }
             }
         }
         __syncthreads();
         if (dbg_stage == 1) { if (tid == 0) n_distinct[b] = 0; return; }
+        if (rank_bits) {
 #pragma unroll
-        for (int q = 0; q < ITEMS; q++) {
-            const uint32_t i = tid + q * RTPB;
-            if (i < n) {
-                const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
-                uint32_t smaller = 0;
-                for (uint32_t p = lo; p < hi; p++) {
-                    const uint64_t kp = s_key[p];
-                    smaller += (kp < r[q].hash || (kp == r[q].hash && s_pidx[p] < pidx[q])) ? 1u : 0u;
+            for (int q = 0; q < ITEMS; q++) {
+                const uint32_t i = tid + q * RTPB;
+                if (i < n) {
+                    const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
+                    uint32_t smaller = 0;
+                    for (uint32_t p = lo; p < hi; p++) smaller += s_key[p] < rkey[q] ? 1u : 0u;
+                    rank[q] = lo + smaller;
                 }
-                rank[q] = lo + smaller;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++) {
+                const uint32_t i = tid + q * RTPB;
+                if (i < n) {
+                    const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
+                    uint32_t smaller = 0;
+                    for (uint32_t p = lo; p < hi; p++) {
+                        const uint64_t kp = s_key[p];
+                        smaller += (kp < r[q].hash || (kp == r[q].hash && s_pidx[p] < pidx[q])) ? 1u : 0u;
+                    }
+                    rank[q] = lo + smaller;
+                }
             }
         }
     } else {
@@ -893,6 +932,20 @@ bool finish_bucketed(sylph_sketch* sk) {
     {
         const uint32_t caps[3] = {(uint32_t)CAP_SMALL, (uint32_t)CAP_MID, (uint32_t)CAP_LARGE};
         for (int i = 0; i < 3; i++) bm.sub_mult[i] = range_hs > caps[i] ? (uint32_t)(((uint64_t)caps[i] << 32) / range_hs) : 0u;
+        // one-word ranking keys: sub-range s of configuration i (sub = floor(hs * sub_mult / 2^32), sub_mult rounded down) holds
+        // hs values from s * width on (width = floor(range_hs / caps[i]) <= 2^32 / sub_mult) and below (s + 1) * 2^32 / sub_mult;
+        // the distance between the two grows with s: the last sub-range gives the span every residue stays below
+        const uint64_t max_index = slotted ? (uint64_t)sk->pend.n_blk * sk->pend.slot_cap : (uint64_t)n_all;
+        const int index_bits = bit_length(max_index | 1);
+        for (int i = 0; i < 3; i++) {
+            bm.sub_width[i] = bm.sub_mult[i] ? (uint32_t)(range_hs / caps[i]) : 1u;
+            uint64_t span_hs = 1;
+            if (bm.sub_mult[i]) {
+                const uint64_t top = std::min<uint64_t>(range_hs, (((uint64_t)caps[i] << 32) + bm.sub_mult[i] - 1) / bm.sub_mult[i]);
+                span_hs = top - (uint64_t)(caps[i] - 1) * bm.sub_width[i] + 1;
+            }
+            bm.rank_bits[i] = (bm.composite && bit_length(span_hs) + bm.sh + index_bits <= 64) ? index_bits : 0;
+        }
     }
     // partition geometry: F = 2^fine_bits buckets per coarse range (about 512 ranges), tiles of occurrences
     int fine_bits = 6;
