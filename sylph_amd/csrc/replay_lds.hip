@@ -315,7 +315,16 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
         uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_m1);   // CAP + 1 counters (s_m1 is free until the sorted records are written)
         const uint32_t sub_mult = bm.sub_mult[CAP == CAP_SMALL ? 0 : CAP == CAP_MID ? 1 : 2];
         uint32_t sub[ITEMS];
+        constexpr int CFG = CAP == CAP_SMALL ? 0 : CAP == CAP_MID ? 1 : 2;
+        const int rank_bits = bm.rank_bits[CFG];
+        // hashed configurations (deep buckets): lowest and highest hash of every sub-range (s_hash / s_rid are free until the
+        // sorted records are written) — a sub-range whose two are equal holds ONE k-mer, see the second level below
+        constexpr bool TWO_LEVEL = CAP != CAP_SMALL;
+        unsigned long long* const s_min = reinterpret_cast<unsigned long long*>(s_hash);
+        unsigned long long* const s_max = reinterpret_cast<unsigned long long*>(s_rid);
         for (uint32_t t = tid; t <= (uint32_t)CAP; t += RTPB) s_cnt[t] = 0;
+        if constexpr (TWO_LEVEL)
+            for (uint32_t t = tid; t < (uint32_t)CAP; t += RTPB) { s_min[t] = ~0ull; s_max[t] = 0ull; }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < ITEMS; q++) {
@@ -325,6 +334,10 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
                 const uint32_t hsres = (uint32_t)((r[q].hash - lo_hash) >> bm.sh);          // < bm.range_hs
                 sub[q] = sub_mult ? min(__umulhi(hsres, sub_mult), (uint32_t)CAP - 1u) : min(hsres, (uint32_t)CAP - 1u);
                 atomicAdd(&s_cnt[sub[q]], 1u);
+                if constexpr (TWO_LEVEL) {
+                    atomicMin(&s_min[sub[q]], (unsigned long long)r[q].hash);
+                    atomicMax(&s_max[sub[q]], (unsigned long long)r[q].hash);
+                }
             }
         }
         __syncthreads();
@@ -350,13 +363,53 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             } else
                 __syncthreads();
         }
+        // Second level (hashed configurations): the occurrences of a DEEP k-mer all sit in one sub-range, and ranking them among
+        // each other by index is quadratic in the depth.  A sub-range that holds one k-mer only (lowest hash = highest hash) and
+        // at least DEEP_SUB occurrences is therefore cut once more, by INDEX: cnt equal index ranges own one place each of the
+        // sub-range's cnt places (the occurrences of a k-mer are spread over the file like the reads are, so the ranges hold
+        // about one each; whatever they hold is ranked inside its range, so any spread is sorted correctly).  Bin of an
+        // occurrence = first place of its sub-range (+ its index range): bins are places, they order like (hash, index).
+        uint32_t bin[ITEMS];
+        const uint32_t* starts = s_cnt;
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) bin[q] = sub[q];
+        if constexpr (TWO_LEVEL) {
+            if (rank_bits) {
+                constexpr uint32_t DEEP_SUB = 32;
+                uint32_t* const s_c2 = reinterpret_cast<uint32_t*>(s_m0);       // CAP + 1 counters (s_key is not written before the placement)
+                uint32_t* const s_s2 = reinterpret_cast<uint32_t*>(s_hash);     // their scan (s_min is done with by then)
+                for (uint32_t t = tid; t <= (uint32_t)CAP; t += RTPB) s_c2[t] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < ITEMS; q++) {
+                    const uint32_t i = tid + q * RTPB;
+                    if (i < n) {
+                        const uint32_t lo = s_cnt[sub[q]], cnt = s_cnt[sub[q] + 1] - lo;
+                        const bool pure = cnt >= DEEP_SUB && s_min[sub[q]] == s_max[sub[q]];
+                        bin[q] = lo + (pure ? min(cnt - 1u, (uint32_t)(((uint64_t)pidx[q] * cnt) >> rank_bits)) : 0u);
+                        atomicAdd(&s_c2[bin[q]], 1u);
+                    }
+                }
+                __syncthreads();
+                {
+                    constexpr int PER = CAP / RTPB;
+                    uint32_t v[PER], sum = 0;
+#pragma unroll
+                    for (int e = 0; e < PER; e++) { v[e] = s_c2[tid * PER + e]; sum += v[e]; }
+                    uint32_t run = block_excl_sum<RTPB>(sum, s_wave, nullptr);
+#pragma unroll
+                    for (int e = 0; e < PER; e++) { s_s2[tid * PER + e] = run; run += v[e]; }
+                    if (tid == RTPB - 1) s_s2[CAP] = run;
+                }
+                __syncthreads();
+                starts = s_s2;
+            }
+        }
         // place (cursor = a second counter array would cost LDS: take places from the END of each sub-range instead, counting the
         // start words' neighbours down is not possible either — so the places come from s_seg, which is free until the segments)
         uint16_t* const s_fill = s_seg;                               // members placed so far per sub-range (<= CAP: 16 bits do)
         for (uint32_t t = tid; t < (uint32_t)CAP; t += RTPB) s_fill[t] = 0;
         __syncthreads();
-        constexpr int CFG = CAP == CAP_SMALL ? 0 : CAP == CAP_MID ? 1 : 2;
-        const int rank_bits = bm.rank_bits[CFG];
         // ranking key of an occurrence inside its sub-range: (hash - a lower bound of the sub-range's hashes, index) in one word
         // when the host found room for both (rank_bits > 0), else the hash with the indices in a second array
         uint64_t rkey[ITEMS];
@@ -366,9 +419,9 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             rkey[q] = 0;
             if (i < n) {
                 // 16-bit LDS atomics do not exist: the counter pairs share a word; add 1 or 65536 to the word and take the half
-                uint32_t* const w = reinterpret_cast<uint32_t*>(s_fill) + (sub[q] >> 1);
-                const uint32_t old = atomicAdd(w, (sub[q] & 1u) ? 65536u : 1u);
-                const uint32_t place = s_cnt[sub[q]] + ((sub[q] & 1u) ? (old >> 16) : (old & 0xFFFFu));
+                uint32_t* const w = reinterpret_cast<uint32_t*>(s_fill) + (bin[q] >> 1);
+                const uint32_t old = atomicAdd(w, (bin[q] & 1u) ? 65536u : 1u);
+                const uint32_t place = starts[bin[q]] + ((bin[q] & 1u) ? (old >> 16) : (old & 0xFFFFu));
                 if (rank_bits) {
                     const uint64_t res = (r[q].hash - lo_hash) - ((uint64_t)(sub[q] * bm.sub_width[CFG]) << bm.sh);
                     rkey[q] = (res << rank_bits) | pidx[q];
@@ -386,7 +439,7 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             for (int q = 0; q < ITEMS; q++) {
                 const uint32_t i = tid + q * RTPB;
                 if (i < n) {
-                    const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
+                    const uint32_t lo = starts[bin[q]], hi = starts[bin[q] + 1];
                     uint32_t smaller = 0;
                     for (uint32_t p = lo; p < hi; p++) smaller += s_key[p] < rkey[q] ? 1u : 0u;
                     rank[q] = lo + smaller;
@@ -397,7 +450,7 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             for (int q = 0; q < ITEMS; q++) {
                 const uint32_t i = tid + q * RTPB;
                 if (i < n) {
-                    const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
+                    const uint32_t lo = starts[bin[q]], hi = starts[bin[q] + 1];
                     uint32_t smaller = 0;
                     for (uint32_t p = lo; p < hi; p++) {
                         const uint64_t kp = s_key[p];
