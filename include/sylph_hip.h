@@ -76,7 +76,9 @@ int sylph_ctx_synchronize(sylph_ctx *ctx);
  * index aimed for ("1".."8", default 3; applies to databases uploaded afterwards), "index_pass_max" = postings sorted per pass
  * of the index build (tests lower it to force several passes), "push_chunk_bytes" = bytes of bases per chunk of a host batch
  * (default 64 MiB), "reads_wg_per_cu" = workgroups of the read-per-lane kernel per CU, each looping over blocks of reads
- * ("0".."64"; default 0 = one workgroup per block, measured 10 % faster than 8 looping workgroups per CU). */
+ * ("0".."64"; default 0 = one workgroup per block, measured 10 % faster than 8 looping workgroups per CU).
+ * "fail_next_shard_probe" = "1": fault injection for the tests — the next sylph_db_contain_batch_sharded on this context fails
+ * in its probe, between the collectives (every rank of the batch must then return the same error, nobody may hang). */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
 
 /* Per-kernel timing (hipEvent pairs on the ctx stream around every launch of the named kernel family) for

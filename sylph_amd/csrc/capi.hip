@@ -273,6 +273,8 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 16 && v <= 256, "bucket_target must be in [16, 256]");
             ctx->bucket_target = (uint32_t)v;
+        } else if (!strcmp(key, "fail_next_shard_probe")) {
+            ctx->fail_next_shard_probe = (uint32_t)strtol(value, nullptr, 10);   // tests only: one rank of a sharded batch fails between the collectives
         } else if (!strcmp(key, "push_chunk_bytes")) {
             const long long v = strtoll(value, nullptr, 10);
             SY_REQUIRE(v >= 64 && v <= (1ll << 31), "push_chunk_bytes must be in [64, 2^31]");

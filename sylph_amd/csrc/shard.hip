@@ -426,7 +426,10 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         uint32_t max_count = 0, n_hits = 0, local_err = 0;
         std::string local_msg;
         if (S_total) {
-            try { n_hits = probe_batch(db, refs, min_number_kmers, &max_count); }
+            try {
+                if (ctx->fail_next_shard_probe) { ctx->fail_next_shard_probe = 0; throw ArgError{"injected failure of the sharded probe (fail_next_shard_probe)"}; }
+                n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
+            }
             catch (const ArgError& e) { local_err = 1; local_msg = e.msg; }
             catch (const HipError& e) { local_err = 2; local_msg = std::string("HIP error in the probe: ") + hipGetErrorString(e.e); (void)hipGetLastError(); }
             catch (const std::bad_alloc&) { local_err = 3; local_msg = "host allocation failed in the probe"; }

@@ -62,6 +62,21 @@ def main():
             for g in range(G):
                 assert np.array_equal(covs[int(off[s * G + g]):int(off[s * G + g + 1])].astype(np.uint32), np.sort(ecov[g])), (rank, step, s, g)
             assert len(k) == 0 or int(ecc.sum()) > 0
+    # one rank fails between the collectives of a batch: EVERY rank must come back from the call with an error (nobody waits in
+    # the second all-to-all for hits that never come), and the next batch works as if nothing had happened
+    k = np.sort(r2.choice(pool, size=5000, replace=False))
+    c = np.ones(len(k), np.uint32)
+    if rank == world - 1:
+        ctx.set_option("fail_next_shard_probe", "1")
+    try:
+        db.contain_batch_sharded(comm, [(k, c)])
+        raise AssertionError(f"rank {rank}: the batch with a failing rank returned normally")
+    except S.SylphHipError as e:
+        assert ("injected failure" in str(e)) == (rank == world - 1), str(e)
+        assert rank == world - 1 or f"rank {world - 1}" in str(e), str(e)
+    cc, off, covs = db.contain_batch_sharded(comm, [(k, c)])
+    ecc, _, _ = O.contain(k, c, full, goff)
+    assert np.array_equal(cc, ecc)
     db.close()
     comm.close()
     ctx.close()

@@ -113,7 +113,9 @@ def main():
     assert p.returncode == 0, p.stderr[-2000:]
     per = sorted(float(ln.split(" in ")[1].split(" s")[0]) for ln in p.stderr.split("\n") if "timing:" in ln)
     res["four_paired_plain_samples_t1"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(4 * gbp / dt, 3),
-                                           "fastest_sample_gbp_per_s": round(gbp / per[0], 3) if per else None}
+                                           "fastest_sample_gbp_per_s": round(gbp / per[0], 3) if per else None,
+                                           "sample_seconds_sorted": [round(x, 4) for x in per],
+                                           "note": "the first sample of a process includes GPU bring-up and the un-hidden index of its files; the later ones are warm"}
     # several samples in one command: -t worker threads, one GPU context each
     for i in range(4):
         for m in (1, 2):
