@@ -326,7 +326,9 @@ typedef struct sylph_pipeline_result {
     const uint64_t *dev_kmers; const uint32_t *dev_counts;   /* the table in HBM (e.g. for sylph_db_reassign_view) */
     const uint64_t *kmers; const uint32_t *counts;           /* host copy, when want_table */
     /* containment of the sample against every genome, as sylph_db_contain_view_packed returns it: contain_count[g];
-     * coverage values of genome g = covs[cov_off[g] .. cov_off[g + 1]) (ascending, cov_width bytes each); n_covs of them in total */
+     * coverage values of genome g = covs[cov_off[g] .. cov_off[g + 1]) (ascending, cov_width bytes each); n_covs of them for this
+     * sample.  The samples of one probe batch share a result block: `covs` is the block's base, so cov_off[0] is 0 only for the
+     * first sample of a batch — always index through cov_off. */
     const uint32_t *contain_count; const uint64_t *cov_off; const void *covs; uint32_t cov_width; uint64_t n_covs;
     uint32_t probe_batch;     /* tables in the probe launch this sample was part of */
     double t_submit, t_sketch_begin, t_sketch_end, t_profile_begin, t_done;   /* CLOCK_MONOTONIC seconds */
