@@ -272,6 +272,11 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
             __syncthreads();
             const uint32_t hc = s_hist[lane];
             const bool dealt = s_hist[bin] != (uint32_t)RTPB;         // uniform over the workgroup
+            // the longest record of the pass (uniform over the workgroup: every wavefront reads the same histogram): its lowest
+            // non-empty bin; the mask rows above its words are free in this pass (see the survivors' list below)
+            const uint64_t bins_used = __ballot(hc != 0u);
+            const uint32_t hg_max = bins_used ? 63u - (uint32_t)(__ffsll((unsigned long long)bins_used) - 1) : 0u;   // half-groups of 8 k-mers
+            const uint32_t rows_used = min((uint32_t)MASKW, (hg_max * 8u + 31u) >> 5);
             if (dealt) {
                 uint32_t incl = hc;
 #pragma unroll
@@ -326,11 +331,11 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
             // count the real hits of this lane's own record (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)
             uint32_t cnt = 0;
             const uint32_t nw = (nh + 31) >> 5;
-            for (uint32_t w = 0; w < nw; w++) {
-                uint32_t m = s_mask[w][tid];
-                const uint32_t left = nh - w * 32;
-                if (left < 32) m &= ~(0xFFFFFFFFu >> left);
-                s_mask[w][tid] = m;
+            for (uint32_t w = 0; w + 1 < nw; w++) cnt += __popc(s_mask[w][tid]);
+            if (nw) {                                                   // the record's last word: bits beyond k-mer nh - 1 are not its own
+                const uint32_t left = nh - (nw - 1) * 32;               // 1 .. 32 k-mers in it
+                const uint32_t m = s_mask[nw - 1][tid] & (uint32_t)(0xFFFFFFFF00000000ull >> left);
+                s_mask[nw - 1][tid] = m;
                 cnt += __popc(m);
             }
             uint32_t x = cnt;
@@ -380,25 +385,51 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                 s_first[tid] = (before + x - cnt) | (has << 31);
                 if (tid == 0) s_first[RTPB] = total;
             }
+            // The pass's survivors as a list, hit number -> (lane, k-mer index), written by the lanes that own them (a lane has
+            // 0.6 hits on average: a short loop over its own mask words) into the mask rows no record of this pass reaches.
+            // Without room for the whole list (records near READ_HALO, or c so small that a pass has thousands of hits) the
+            // cooperative pass below finds owner and k-mer by a search over the lanes' start offsets and a walk over the owner's
+            // masks instead — what it always did before round 3: ~150 instructions per wavefront and pass more.
+            uint32_t* const s_owner = &s_mask[0][0] + rows_used * RTPB;
+            const bool listed = total <= ((uint32_t)MASKW - rows_used) * (uint32_t)RTPB;
+            if (listed && cnt) {
+                uint32_t p = before + x - cnt;
+                for (uint32_t w = 0; w < nw; w++) {
+                    uint32_t m = s_mask[w][tid];
+                    while (m) {
+                        const uint32_t bpos = (uint32_t)__clz((int)m);
+                        s_owner[p++] = tid | ((w * 32 + bpos) << 8);
+                        m &= ~(0x80000000u >> bpos);
+                    }
+                }
+            }
             __syncthreads();
             for (uint32_t hix = tid; hix < total; hix += RTPB) {
-                uint32_t lo = 0, hi = RTPB;                                     // owner: the last lane whose first hit is <= hix
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((s_first[mid] & 0x7FFFFFFFu) <= hix) lo = mid; else hi = mid;
-                }
-                // (lanes without hits share the start offset of the next lane with hits: the LAST lane with that offset that
-                //  actually owns hix is the one whose successor starts beyond it — the search above returns exactly that lane)
-                const uint32_t f = s_first[lo];
-                uint32_t j = hix - (f & 0x7FFFFFFFu);                           // the j-th hit of lane `lo`
-                uint32_t i = 0;
-                for (uint32_t w = 0; w < MASKW; w++) {
-                    uint32_t m = s_mask[w][lo];
-                    const uint32_t c = (uint32_t)__popc(m);
-                    if (j >= c) { j -= c; continue; }
-                    for (; j; j--) m &= ~(0x80000000u >> __clz((int)m));       // drop the j highest set bits
-                    i = w * 32 + (uint32_t)__clz((int)m);
-                    break;
+                uint32_t lo, i = 0, f;
+                if (listed) {
+                    const uint32_t ow = s_owner[hix];
+                    lo = ow & 0xFFu;
+                    i = ow >> 8;
+                    f = s_first[lo];
+                } else {
+                    lo = 0;
+                    uint32_t hi = RTPB;                                         // owner: the last lane whose first hit is <= hix
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((s_first[mid] & 0x7FFFFFFFu) <= hix) lo = mid; else hi = mid;
+                    }
+                    // (lanes without hits share the start offset of the next lane with hits: the LAST lane with that offset that
+                    //  actually owns hix is the one whose successor starts beyond it — the search above returns exactly that lane)
+                    f = s_first[lo];
+                    uint32_t j = hix - (f & 0x7FFFFFFFu);                       // the j-th hit of lane `lo`
+                    for (uint32_t w = 0; w < MASKW; w++) {
+                        uint32_t m = s_mask[w][lo];
+                        const uint32_t c = (uint32_t)__popc(m);
+                        if (j >= c) { j -= c; continue; }
+                        for (; j; j--) m &= ~(0x80000000u >> __clz((int)m));   // drop the j highest set bits
+                        i = w * 32 + (uint32_t)__clz((int)m);
+                        break;
+                    }
                 }
                 const uint32_t o = base_prev + hix;
                 if (o < slot_cap) {
