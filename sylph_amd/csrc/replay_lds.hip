@@ -187,22 +187,31 @@ __global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, Bucke
 
 // one workgroup per coarse range: counting sort of its pairs by bucket in LDS -> perm (occurrence indices grouped by bucket) and
 // boff[b] = first position of bucket b, boff[B] = number of valid occurrences
-__global__ __launch_bounds__(PART_TPB) void part_fine_kernel(const uint2* __restrict__ pairs,
+template <int TPB>
+__global__ __launch_bounds__(TPB) void part_fine_kernel(const uint2* __restrict__ pairs,
                                                              const uint32_t* __restrict__ cbase, int fine_bits, uint32_t C, uint32_t B,
                                                              uint32_t* __restrict__ boff, uint32_t* __restrict__ perm) {
     __shared__ uint32_t s_cnt[MAX_FINE];
-    __shared__ uint32_t s_wave[PART_TPB / 64];
+    __shared__ uint32_t s_wave[TPB / 64];
     const uint32_t c = blockIdx.x, F = 1u << fine_bits, b0 = c << fine_bits;
     const uint32_t lo = cbase[c], hi = cbase[c + 1];
-    for (uint32_t f = threadIdx.x; f < F; f += PART_TPB) s_cnt[f] = 0;
+    for (uint32_t f = threadIdx.x; f < F; f += TPB) s_cnt[f] = 0;
     __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += PART_TPB) atomicAdd(&s_cnt[pairs[e].x - b0], 1u);
+    // (four independent loads in flight per lane: with one, a range of 10^5 pairs is a chain of load latencies)
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * TPB) {
+        uint32_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) k[u] = e + u * TPB < hi ? pairs[e + u * TPB].x : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (k[u] != 0xFFFFFFFFu) atomicAdd(&s_cnt[k[u] - b0], 1u);
+    }
     __syncthreads();
     {
-        const uint32_t per = (F + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(F, a + per);
+        const uint32_t per = (F + TPB - 1) / TPB, a = threadIdx.x * per, b = min(F, a + per);
         uint32_t sum = 0;
         for (uint32_t f = a; f < b; f++) sum += s_cnt[f];
-        uint32_t run = lo + block_excl_sum<PART_TPB>(sum, s_wave, nullptr);
+        uint32_t run = lo + block_excl_sum<TPB>(sum, s_wave, nullptr);
         for (uint32_t f = a; f < b; f++) {
             const uint32_t v = s_cnt[f];
             s_cnt[f] = run;                              // becomes the bucket's cursor
@@ -212,9 +221,13 @@ __global__ __launch_bounds__(PART_TPB) void part_fine_kernel(const uint2* __rest
     }
     if (c + 1 == C && threadIdx.x == 0) boff[B] = hi;
     __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += PART_TPB) {
-        const uint2 v = pairs[e];
-        perm[atomicAdd(&s_cnt[v.x - b0], 1u)] = v.y;
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * TPB) {
+        uint2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = e + u * TPB < hi ? pairs[e + u * TPB] : make_uint2(0xFFFFFFFFu, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (v[u].x != 0xFFFFFFFFu) perm[atomicAdd(&s_cnt[v[u].x - b0], 1u)] = v[u].y;
     }
 }
 
@@ -787,13 +800,16 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_list_kernel(const OccRec* 
 // before w (at most 256 of them: B <= 2^18 on this path).
 constexpr uint32_t SCAN_CHUNK = 1024;
 __global__ __launch_bounds__(SCAN_CHUNK) void table_scan_kernel(const uint32_t* __restrict__ n_distinct, const uint32_t* __restrict__ removed_b,
-                                                                uint32_t B, uint32_t* __restrict__ d_loc, uint32_t* __restrict__ chunk_rows,
-                                                                unsigned long long* __restrict__ chunk_removed) {
+                                                                uint32_t B, uint32_t ipt, uint32_t* __restrict__ d_loc,
+                                                                uint32_t* __restrict__ chunk_rows, unsigned long long* __restrict__ chunk_removed) {
+    // a workgroup scans a chunk of SCAN_CHUNK * ipt buckets, every lane `ipt` consecutive ones (ipt = 1 up to 2^18 buckets; a
+    // long-read sample at c = 100 has 4e5: at most 256 chunks whatever B, so that the second level fits one workgroup's LDS)
     __shared__ uint32_t s_wave[SCAN_CHUNK / 64];
     __shared__ unsigned long long s_rem[SCAN_CHUNK / 64];
-    const uint32_t b = blockIdx.x * SCAN_CHUNK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t v = b < B ? n_distinct[b] : 0u;
-    unsigned long long rem = b < B ? removed_b[b] : 0u;
+    const uint32_t b0 = (blockIdx.x * SCAN_CHUNK + threadIdx.x) * ipt, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v = 0;
+    unsigned long long rem = 0;
+    for (uint32_t i = 0; i < ipt && b0 + i < B; i++) { v += n_distinct[b0 + i]; rem += removed_b[b0 + i]; }
     uint32_t x = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -807,7 +823,8 @@ __global__ __launch_bounds__(SCAN_CHUNK) void table_scan_kernel(const uint32_t* 
     __syncthreads();
     uint32_t base = 0, tot = 0;
     for (uint32_t w = 0; w < SCAN_CHUNK / 64; w++) { const uint32_t t = s_wave[w]; if (w < wave) base += t; tot += t; }
-    if (b < B) d_loc[b] = base + x - v;
+    uint32_t run = base + x - v;
+    for (uint32_t i = 0; i < ipt && b0 + i < B; i++) { d_loc[b0 + i] = run; run += n_distinct[b0 + i]; }
     if (threadIdx.x == 0) {
         unsigned long long r = 0;
         for (uint32_t w = 0; w < SCAN_CHUNK / 64; w++) r += s_rem[w];
@@ -821,21 +838,31 @@ __global__ __launch_bounds__(SCAN_CHUNK) void table_scan_kernel(const uint32_t* 
 __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __restrict__ tmp_k, const uint32_t* __restrict__ tmp_c,
                                                             const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_loc,
                                                             const uint32_t* __restrict__ chunk_rows, const unsigned long long* __restrict__ chunk_removed,
-                                                            const uint32_t* __restrict__ n_distinct, uint32_t B,
+                                                            const uint32_t* __restrict__ n_distinct, uint32_t B, uint32_t ipt,
                                                             uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
                                                             const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ mid_list,
                                                             const uint32_t* __restrict__ large_list, int skip_if_listed,
                                                             uint32_t* __restrict__ tail) {
     __shared__ uint32_t s_base[257];
-    const uint32_t n_chunks = (B + SCAN_CHUNK - 1) / SCAN_CHUNK;        // <= 256
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        unsigned long long rem = 0;
-        for (uint32_t w = 0; w < n_chunks; w++) { s_base[w] = run; run += chunk_rows[w]; rem += chunk_removed[w]; }
-        s_base[n_chunks] = run;
-        if (blockIdx.x == 0) {
-            *reinterpret_cast<unsigned long long*>(tail) = rem;
-            tail[3] = run; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
+    __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_rem[4];
+    const uint32_t chunk = SCAN_CHUNK * ipt, n_chunks = (B + chunk - 1) / chunk;        // <= 256: one chunk total per lane
+    {
+        const uint32_t v = threadIdx.x < n_chunks ? chunk_rows[threadIdx.x] : 0u;
+        uint32_t tot = 0;
+        const uint32_t ex = block_excl_sum<256>(v, s_wave, &tot);
+        if (threadIdx.x < n_chunks) s_base[threadIdx.x] = ex;
+        if (threadIdx.x == 0) s_base[n_chunks] = tot;
+        if (blockIdx.x == 0) {                                                       // the tail block, once
+            unsigned long long rem = threadIdx.x < n_chunks ? chunk_removed[threadIdx.x] : 0ull;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) rem += __shfl_xor(rem, d);
+            if ((threadIdx.x & 63) == 0) s_rem[threadIdx.x >> 6] = rem;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                *reinterpret_cast<unsigned long long*>(tail) = s_rem[0] + s_rem[1] + s_rem[2] + s_rem[3];
+                tail[3] = tot; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
+            }
         }
     }
     __syncthreads();
@@ -844,49 +871,10 @@ __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __re
     if (skip_if_listed && (mid_list[0] | large_list[0])) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
-        const uint32_t n = n_distinct[b], s0 = boff[b], d = s_base[b / SCAN_CHUNK] + d_loc[b];
+        const uint32_t n = n_distinct[b], s0 = boff[b], d = s_base[b / chunk] + d_loc[b];
         for (uint32_t i = lane; i < n; i += 64) { out_k[d + i] = tmp_k[s0 + i]; out_c[d + i] = tmp_c[s0 + i]; }
     }
 }
-// (large B: the per-bucket removed counts summed on their own, the scan left to the library)
-__global__ __launch_bounds__(1024) void sum_removed_kernel(const uint32_t* __restrict__ removed_b, uint32_t B,
-                                                           unsigned long long* __restrict__ out) {
-    __shared__ unsigned long long s[16];
-    unsigned long long v = 0;
-    for (uint32_t i = threadIdx.x; i < B; i += 1024) v += removed_b[i];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < 16; w++) t += s[w];
-        *out = t;
-    }
-}
-
-// out[d_off[b] + i] = tmp[boff[b] + i] for i < n_distinct[b]: one workgroup per bucket
-__global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t* __restrict__ tmp_k, const uint32_t* __restrict__ tmp_c,
-                                                             const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_off,
-                                                             const uint32_t* __restrict__ n_distinct, uint32_t n_buckets,
-                                                             uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
-                                                             const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ mid_list,
-                                                             const uint32_t* __restrict__ large_list, int skip_if_listed,
-                                                             uint32_t* __restrict__ tail) {
-    // tail = {removed u64, overflow u32, n_seg u32, n_ovf u32, n_mid u32, n_large u32}: everything the host reads back, side by
-    // side (ONE copy)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        tail[3] = d_off[n_buckets]; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
-    }
-    // buckets are still waiting for the list-driven configurations: the host will come back after running them (a long-read
-    // table has tens of millions of rows: copying it twice would cost more than the configurations themselves)
-    if (skip_if_listed && (mid_list[0] | large_list[0])) return;
-    for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
-        const uint32_t n = n_distinct[b], s = boff[b], d = d_off[b];
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { out_k[d + i] = tmp_k[s + i]; out_c[d + i] = tmp_c[s + i]; }
-    }
-}
-
 // ---- buckets beyond the large configuration: their occurrences go through the device-wide path as one small sample --------
 // sub_off[i] = occurrences of the listed buckets before bucket i (single workgroup; the list is short); sub_off[m] = total
 __global__ __launch_bounds__(1024) void ovf_offsets_kernel(const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ boff,
@@ -1067,8 +1055,14 @@ bool finish_bucketed(sylph_sketch* sk) {
             hipLaunchKernelGGL(part_scan_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, hist, n_tiles, ctotal);
             hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)C + 2 * (size_t)STAGE_PAIRS) * 4, ctx->stream, in, bm,
                                fine_bits, C, n_tiles, hist, ctotal, cbase, pairs);
-            hipLaunchKernelGGL(part_fine_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
-                               b_perm.as<uint32_t>());
+            // (a sample of tens of millions of occurrences — long reads at c = 100 — has ~10^5 pairs per coarse range: 1024
+            //  threads walk them instead of 256; c5: 1.27 -> see profiles)
+            if ((uint64_t)n_all / C > 32768)
+                hipLaunchKernelGGL((part_fine_kernel<1024>), dim3(C), dim3(1024), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
+                                   b_perm.as<uint32_t>());
+            else
+                hipLaunchKernelGGL((part_fine_kernel<PART_TPB>), dim3(C), dim3(PART_TPB), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
+                                   b_perm.as<uint32_t>());
         }
         {
             ScopedKernelTimer t(ctx, "replay");
@@ -1080,29 +1074,15 @@ bool finish_bucketed(sylph_sketch* sk) {
     }
     // removed counts, table offsets, compaction, and everything the host needs to know in one 28-byte block
     auto close_table = [&](int skip_if_listed) {
-        if (B <= (1u << 18)) {      // two levels of 1024: scan + compaction, two dispatches
-            ScopedKernelTimer t(ctx, "replay");
-            hipLaunchKernelGGL(table_scan_kernel, dim3((B + SCAN_CHUNK - 1) / SCAN_CHUNK), dim3(SCAN_CHUNK), 0, ctx->stream, n_distinct, removed_b, B,
-                               d_off, chunk_rows, chunk_removed);
-            hipLaunchKernelGGL(table_compact_kernel, dim3(std::min<uint32_t>((B + 3) / 4, 1u << 15)), dim3(256), 0, ctx->stream,
-                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, chunk_rows, chunk_removed, n_distinct, B,
-                               sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, skip_if_listed,
-                               b_small.as<uint32_t>());
-            SY_HIP(hipGetLastError());
-            return;
-        } else {
-            {
-                ScopedKernelTimer t(ctx, "replay");
-                hipLaunchKernelGGL(sum_removed_kernel, dim3(1), dim3(1024), 0, ctx->stream, removed_b, B, d_removed);
-            }
-            exclusive_sum_u32(ctx, n_distinct, d_off, B + 1);
-        }
-        {
-            ScopedKernelTimer t(ctx, "replay");
-            hipLaunchKernelGGL(bucket_compact_kernel, dim3(std::min<uint32_t>(B, 1u << 16)), dim3(256), 0, ctx->stream,
-                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, n_distinct, B, sk->out_k.as<uint64_t>(),
-                               sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, skip_if_listed, b_small.as<uint32_t>());
-        }
+        // two levels: chunks of 1024 x ipt buckets (at most 256 of them), then the compaction, which scans the chunk totals itself
+        const uint32_t ipt = (B + (1u << 18) - 1) >> 18;
+        ScopedKernelTimer t(ctx, "replay");
+        hipLaunchKernelGGL(table_scan_kernel, dim3((B + SCAN_CHUNK * ipt - 1) / (SCAN_CHUNK * ipt)), dim3(SCAN_CHUNK), 0, ctx->stream, n_distinct,
+                           removed_b, B, ipt, d_off, chunk_rows, chunk_removed);
+        hipLaunchKernelGGL(table_compact_kernel, dim3(std::min<uint32_t>((B + 3) / 4, 1u << 15)), dim3(256), 0, ctx->stream,
+                           b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, chunk_rows, chunk_removed, n_distinct, B, ipt,
+                           sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, skip_if_listed,
+                           b_small.as<uint32_t>());
         SY_HIP(hipGetLastError());
     };
     struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf, n_mid, n_large; } host{};
