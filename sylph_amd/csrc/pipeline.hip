@@ -407,7 +407,8 @@ void sylph_pipeline_destroy(sylph_pipeline* p) {
     {
         std::unique_lock<std::mutex> lk(p->mu);
         dead = p->release_returned();
-        p->flush_upto = ~0ull;
+        p->flush_upto = p->next_seq;             // sharded: what is outstanding goes in a last, partial batch (as after sylph_pipeline_flush;
+                                                 // every rank destroys its pipeline with the same number of samples outstanding)
     }
     if (dead) sylph_sketch_destroy(dead);
     p->cv_sketched.notify_all();

@@ -125,6 +125,7 @@ def test_pipeline_host_batches_sessions_and_errors(ctx):
     db.close()
 
 
+@pytest.mark.timeout(300)
 def test_pipeline_sharded_one_rank(ctx):
     """The sharded flavour (fixed batches + flush) over a one-rank RCCL communicator equals the unsharded pipeline."""
     rng, genomes, db_k, goff = small_world(7)
@@ -146,6 +147,10 @@ def test_pipeline_sharded_one_rank(ctx):
         r = p.next()
         assert r["tag"] == i and r["probe_batch"] == 2
         check_result(r, O.sketch_reads(*data[i], c=50, paired=True), db_k, goff)
+    # closing with fewer samples outstanding than a batch holds, never flushed: close flushes them itself (it used to wait for
+    # a full batch that could not come any more)
+    b, off = data[0]
+    assert p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=9, mem=MEM_HOST)
     p.close(); db.close(); comm.close()
 
 
