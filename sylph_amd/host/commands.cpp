@@ -134,12 +134,6 @@ Engine::~Engine() {
 }
 
 namespace {
-// prefix sums of the sequence lengths of an indexed file: cum[i] = bases of records [0, i)
-std::vector<uint64_t> cumulative(const FastqIndex& ix) {
-    std::vector<uint64_t> c(ix.n_records() + 1, 0);
-    for (size_t i = 0; i < ix.n_records(); i++) c[i + 1] = c[i] + ix.seq_len[i];
-    return c;
-}
 // Uncompressed 4-line FASTQ (the common case): the files are indexed by parse_threads() workers, whole batches are gathered
 // into page-locked memory in parallel and pushed; the record loop of the reference shrinks to its one sequential piece, the
 // running mean of the read lengths (f64, file order: sketch.rs:941-943, :825-826), which runs on its own thread meanwhile.
@@ -198,17 +192,9 @@ void sketch_indexed(Engine& e, sylph_sketch* sk, const IndexedInput& in, double&
     const FastqIndex& a = *in.a;
     const FastqIndex* b = in.b.get();
     const size_t n = b ? std::min(a.n_records(), b->n_records()) : a.n_records();   // lock-step readers: sketch.rs:813-815
-    std::vector<uint64_t> ca, cb;
-    {
-        std::exception_ptr err;
-        std::thread tb;
-        ThreadJoiner jb{tb};
-        if (b) tb = std::thread([&] { try { cb = cumulative(*b); } catch (...) { err = std::current_exception(); } });
-        ca = cumulative(a);
-        if (tb.joinable()) tb.join();
-        if (err) std::rethrow_exception(err);
-    }
-    lap("prefix sums");
+    static const std::vector<uint64_t> no_cum;
+    const std::vector<uint64_t>& ca = a.cum;                             // prefix sums of the read lengths, from the index workers
+    const std::vector<uint64_t>& cb = b ? b->cum : no_cum;
     // the one sequential piece of the reference's record loop (f64, file order: sketch.rs:941-943, :825-826), on its own thread
     // while the batches travel
     double mean = 0.;

@@ -407,7 +407,9 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
     std::vector<std::vector<uint64_t>> offs(T);
     std::vector<std::vector<uint32_t>> lens(T);
     std::vector<char> good(T, 1);
+    std::vector<uint64_t> range_bases(T, 0);
     run_workers(T, [&](unsigned w) {
+        uint64_t sum = 0;
         size_t p = starts[w];
         const size_t end = starts[w + 1];
         auto& o = offs[w];
@@ -435,19 +437,30 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
             if (sl != ql || sl > 0xFFFFFFFEu) { good[w] = 0; return; }
             o.push_back(s);
             l.push_back((uint32_t)sl);
+            sum += sl;
             p = nx;
         }
+        range_bases[w] = sum;
         if (p != end && !(end == n && p >= n)) good[w] = 0;        // the next range must begin exactly where this one ended
     });
     for (unsigned w = 0; w < T; w++) if (!good[w]) return;
     std::vector<size_t> pre(T + 1, 0);
-    for (unsigned w = 0; w < T; w++) pre[w + 1] = pre[w] + lens[w].size();
+    std::vector<uint64_t> bases_before(T + 1, 0);
+    for (unsigned w = 0; w < T; w++) {
+        pre[w + 1] = pre[w] + lens[w].size();
+        bases_before[w + 1] = bases_before[w] + range_bases[w];
+    }
     seq_off.resize(pre[T]);
     seq_len.resize(pre[T]);
+    cum.resize(pre[T] + 1);                                       // cum[i] = bases of records [0, i): what the batches are cut by
+    cum[0] = 0;
     run_workers(T, [&](unsigned w) {
         if (!lens[w].empty()) {
             memcpy(seq_off.data() + pre[w], offs[w].data(), offs[w].size() * 8);
             memcpy(seq_len.data() + pre[w], lens[w].data(), lens[w].size() * 4);
+            uint64_t run = bases_before[w];
+            uint64_t* c = cum.data() + pre[w] + 1;
+            for (size_t i = 0; i < lens[w].size(); i++) { run += lens[w][i]; c[i] = run; }
         }
     });
     ok = true;

@@ -104,6 +104,7 @@ struct FastqIndex {
     void release_behind(size_t byte_offset) const;   // the feed is done with everything before byte_offset
     std::vector<uint64_t> seq_off;   // byte offset of every record's sequence line
     std::vector<uint32_t> seq_len;
+    std::vector<uint64_t> cum;       // cum[i] = sequence bases of records [0, i) (n_records + 1 entries)
     FastqIndex() = default;
     FastqIndex(const std::string& path, unsigned threads);
     ~FastqIndex();
