@@ -85,32 +85,53 @@ __device__ __forceinline__ void clear_invalid_codes(uint32_t w, uint32_t d, uint
     c &= ~((inv >> 6) | (inv >> 7));
 }
 
-// 16 ASCII bases (memory order x,y,z,w) -> F: base j at bits 30-2j (big-endian), R: (3-base j) at bits 2j.
-// The four code dwords hold base 4q+j in byte j of dword q.  A 4x4 byte transpose (8 v_perm_b32) gives D_j = byte q holds
-// base 4q+j; then three shift-ors put the four bases of every byte side by side: that is R's layout directly (after the
-// complement) and F's layout after reversing the bytes.  16 full-rate instructions; the previous formulation used eight
-// v_mul_lo_u32, which issue at quarter rate on gfx950.
-__device__ __forceinline__ void pack16(uint4 v, uint32_t& F, uint32_t& R) {
-    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-    uint32_t c0 = codes4_fast(v.x, e0), c1 = codes4_fast(v.y, e1), c2 = codes4_fast(v.z, e2), c3 = codes4_fast(v.w, e3);
-    if (e0 | e1 | e2 | e3) {   // N and the like: codes cleared in place; U, u, raw 0-3: the exact path
+// 16 ASCII bases -> forward stream word (base j at bits 30-2j).  Per dword: the 2-bit code of every byte ((b>>1 ^ b>>2) & 3,
+// one v_bitop3 after the two shifts), the proof that every byte was one of ACGTacgt (v_perm_b32 rebuilds the letter from the
+// code), then ONE multiply gathers the four codes into the top byte, first base most significant: the code of byte k sits at
+// bit 8k and must land at bit 30 - 2k, i.e. move left by 30 - 10k; 2^30 + 2^20 + 2^10 + 1 does the four moves at once and no
+// partial product reaches bits 24..31 from anywhere else (v_mul_lo_u32 issues at the rate of v_perm_b32, tools/valu_rates.hip:
+// 4 of them replace the 8 + 4 permutes and shift-ors of a 4x4 byte transpose).  Two byte-selects and an OR assemble the word.
+__device__ __forceinline__ uint32_t codes4_bitop(uint32_t w, uint32_t& diff) {
+    uint32_t c;
+    const uint32_t a = w >> 1, b = w >> 2, m = 0x03030303u, up = 0xDFDFDFDFu;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(c) : "v"(a), "v"(b), "v"(m));      // (a ^ b) & m
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* 'T','G','C','A' */, c);
+    // (w & 0xDF..) ^ expect in one instruction; kept opaque so that the four results are OR-ed and tested ONCE (left to itself
+    // the compiler turns `bad |= ...; if (bad)` into four compares and a chain of 16-bit boolean ops: 17 instructions for 7)
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6a" : "=v"(diff) : "v"(w), "v"(up), "v"(expect));   // (a & b) ^ c
+    return c;
+}
+__device__ __forceinline__ uint32_t pack16_fwd(uint4 v) {
+    uint32_t d0, d1, d2, d3, bad;
+    uint32_t c0 = codes4_bitop(v.x, d0), c1 = codes4_bitop(v.y, d1), c2 = codes4_bitop(v.z, d2), c3 = codes4_bitop(v.w, d3);
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(bad) : "v"(d0), "v"(d1), "v"(d2));
+    asm("v_or_b32 %0, %1, %2" : "=v"(bad) : "v"(bad), "v"(d3));
+    if (bad) {
+        // an odd byte somewhere in the wavefront's 64 x 16: N and the like lose their code bits in place, only U, u and raw 0-3
+        // take the exact path (device_common.h)
         uint32_t other = 0;
-        clear_invalid_codes(v.x, e0, c0, other); clear_invalid_codes(v.y, e1, c1, other);
-        clear_invalid_codes(v.z, e2, c2, other); clear_invalid_codes(v.w, e3, c3, other);
+        clear_invalid_codes(v.x, d0, c0, other); clear_invalid_codes(v.y, d1, c1, other);
+        clear_invalid_codes(v.z, d2, c2, other); clear_invalid_codes(v.w, d3, c3, other);
         if (other) { c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w); }
     }
-    // __builtin_amdgcn_perm(hi, lo, sel): selector bytes 0-3 pick from lo, 4-7 from hi
-    const uint32_t t0 = __builtin_amdgcn_perm(c1, c0, 0x05010400u);   // c0.0 c1.0 c0.1 c1.1
-    const uint32_t t1 = __builtin_amdgcn_perm(c1, c0, 0x07030602u);   // c0.2 c1.2 c0.3 c1.3
-    const uint32_t t2 = __builtin_amdgcn_perm(c3, c2, 0x05010400u);   // c2.0 c3.0 c2.1 c3.1
-    const uint32_t t3 = __builtin_amdgcn_perm(c3, c2, 0x07030602u);
-    const uint32_t d0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);   // byte q = base 4q+0
-    const uint32_t d1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);   // byte q = base 4q+1
-    const uint32_t d2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
-    const uint32_t d3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-    R = ~(d0 | (d1 << 2) | (d2 << 4) | (d3 << 6));                     // complement of base 4q+j at bits 8q+2j
-    const uint32_t g = (d0 << 6) | (d1 << 4) | (d2 << 2) | d3;        // base 4q+j at bits 8q+6-2j
-    F = __builtin_amdgcn_perm(0u, g, 0x00010203u);                     // bytes reversed: base b at bits 30-2b
+    constexpr uint32_t GATHER = (1u << 30) | (1u << 20) | (1u << 10) | 1u;
+    const uint32_t p0 = c0 * GATHER, p1 = c1 * GATHER, p2 = c2 * GATHER, p3 = c3 * GATHER;
+    // __builtin_amdgcn_perm(hi, lo, sel): selector 0-3 = bytes of lo, 4-7 = bytes of hi, 0x0C = constant 0
+    return __builtin_amdgcn_perm(p0, p1, 0x07030C0Cu) | __builtin_amdgcn_perm(p2, p3, 0x0C0C0703u);
+}
+
+// reverse-complement image of a stream word: base i of `a` (bits 31-2i, 30-2i) -> its complement at bits 2i+1, 2i
+__device__ __forceinline__ uint32_t rcword(uint32_t a) {
+    const uint32_t r = __brev(a);
+    return ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+}
+
+// 16 ASCII bases (memory order x,y,z,w) -> F: base j at bits 30-2j (big-endian), R: (3 - base j) at bits 2j: the forward word and
+// its reverse-complement image (rounds 1-2 built R with a second 4x4 byte transpose: 8 v_perm_b32 + 6 shift-ors where the bit
+// reversal of F takes 5 instructions).
+__device__ __forceinline__ void pack16(uint4 v, uint32_t& F, uint32_t& R) {
+    F = pack16_fwd(v);
+    R = rcword(F);
 }
 
 // Number of k-mer start positions of a length-L sequence that the reference hashes.

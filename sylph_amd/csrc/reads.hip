@@ -75,12 +75,6 @@ __device__ __forceinline__ void evenodd16(uint64_t x, uint32_t& ev, uint32_t& od
     od = __builtin_amdgcn_perm(even_fields_to_bytes31(hi << 2), even_fields_to_bytes31(lo << 2), 0x07050301u);
 }
 
-// reverse-complement image of a stream word: base i of `a` (bits 31-2i, 30-2i) -> its complement at bits 2i+1, 2i
-__device__ __forceinline__ uint32_t rcword(uint32_t a) {
-    const uint32_t r = __brev(a);
-    return ~(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
-}
-
 // One k-mer of a group of 16: T = index inside the group.  A0..A2: the lane-aligned forward words of the group and the two
 // behind it; Bm, B0..B2: reverse-complement images of the word before the group and of A0..A2.  Forward window = bases
 // [T, T + 32) of A0:A1:A2; reverse-complement window = bits [2T - D, 2T - D + 64) of the little-endian multiword Bm:B0:B1:B2
@@ -112,41 +106,6 @@ __device__ __forceinline__ void kmer_steps8(uint32_t A0, uint32_t A1, uint32_t A
     kmer_step<K, T0 + 5, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
     kmer_step<K, T0 + 6, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
     kmer_step<K, T0 + 7, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
-}
-
-// 16 ASCII bases -> forward stream word (base j at bits 30-2j).  Per dword: the 2-bit code of every byte ((b>>1 ^ b>>2) & 3,
-// one v_bitop3 after the two shifts), the proof that every byte was one of ACGTacgt (v_perm_b32 rebuilds the letter from the
-// code), then ONE multiply gathers the four codes into the top byte, first base most significant: the code of byte k sits at
-// bit 8k and must land at bit 30 - 2k, i.e. move left by 30 - 10k; 2^30 + 2^20 + 2^10 + 1 does the four moves at once and no
-// partial product reaches bits 24..31 from anywhere else (v_mul_lo_u32 issues at the rate of v_perm_b32, tools/valu_rates.hip:
-// 4 of them replace the 8 + 4 permutes and shift-ors of a 4x4 byte transpose).  Two byte-selects and an OR assemble the word.
-__device__ __forceinline__ uint32_t codes4_bitop(uint32_t w, uint32_t& diff) {
-    uint32_t c;
-    const uint32_t a = w >> 1, b = w >> 2, m = 0x03030303u, up = 0xDFDFDFDFu;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(c) : "v"(a), "v"(b), "v"(m));      // (a ^ b) & m
-    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* 'T','G','C','A' */, c);
-    // (w & 0xDF..) ^ expect in one instruction; kept opaque so that the four results are OR-ed and tested ONCE (left to itself
-    // the compiler turns `bad |= ...; if (bad)` into four compares and a chain of 16-bit boolean ops: 17 instructions for 7)
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6a" : "=v"(diff) : "v"(w), "v"(up), "v"(expect));   // (a & b) ^ c
-    return c;
-}
-__device__ __forceinline__ uint32_t pack16_fwd(uint4 v) {
-    uint32_t d0, d1, d2, d3, bad;
-    uint32_t c0 = codes4_bitop(v.x, d0), c1 = codes4_bitop(v.y, d1), c2 = codes4_bitop(v.z, d2), c3 = codes4_bitop(v.w, d3);
-    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(bad) : "v"(d0), "v"(d1), "v"(d2));
-    asm("v_or_b32 %0, %1, %2" : "=v"(bad) : "v"(bad), "v"(d3));
-    if (bad) {
-        // an odd byte somewhere in the wavefront's 64 x 16: N and the like lose their code bits in place, only U, u and raw 0-3
-        // take the exact path (device_common.h)
-        uint32_t other = 0;
-        clear_invalid_codes(v.x, d0, c0, other); clear_invalid_codes(v.y, d1, c1, other);
-        clear_invalid_codes(v.z, d2, c2, other); clear_invalid_codes(v.w, d3, c3, other);
-        if (other) { c0 = codes4_exact(v.x); c1 = codes4_exact(v.y); c2 = codes4_exact(v.z); c3 = codes4_exact(v.w); }
-    }
-    constexpr uint32_t GATHER = (1u << 30) | (1u << 20) | (1u << 10) | 1u;
-    const uint32_t p0 = c0 * GATHER, p1 = c1 * GATHER, p2 = c2 * GATHER, p3 = c3 * GATHER;
-    // __builtin_amdgcn_perm(hi, lo, sel): selector 0-3 = bytes of lo, 4-7 = bytes of hi, 0x0C = constant 0
-    return __builtin_amdgcn_perm(p0, p1, 0x07030C0Cu) | __builtin_amdgcn_perm(p2, p3, 0x0C0C0703u);
 }
 
 // blk_rec[b] = first record whose aligned start coordinate (off + bias) is >= b * rt, for b in [0, n_blk]

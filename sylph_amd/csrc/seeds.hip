@@ -28,6 +28,7 @@ constexpr int TILE_BASES = TILE_WORDS * 16;   // 16384
 constexpr int HALO_WORDS = 2;                 // k-1 <= 31 bases beyond the tile
 constexpr int STAGE_CAP = 1024;               // LDS survivor staging (12 KiB)
 constexpr int FLUSH_AT = 512;
+constexpr int LIST_CAP = 2048;                // survivors of a tile finished cooperatively (ordered-slots kernel); 16384 / c expected
 
 template <int S>
 __device__ __forceinline__ uint64_t shr96(uint32_t hi, uint32_t mid, uint32_t lo) {
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(TPB) void seeds_slots_kernel(const uint8_t* __restr
     __shared__ __attribute__((aligned(16))) uint32_t sF[TILE_WORDS + 8];
     __shared__ __attribute__((aligned(16))) uint32_t sR[TILE_WORDS + 8];
     __shared__ uint32_t s_wave[TPB / 64];
+    __shared__ uint16_t s_list[LIST_CAP];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // first pass: it = tile; redo pass (tile_list != nullptr): it = index into the list of tiles that overflowed their slots,
     // which now get a slot region of TILE_BASES entries each (n_tiles = length of the list)
@@ -246,12 +248,36 @@ __global__ __launch_bounds__(TPB) void seeds_slots_kernel(const uint8_t* __restr
             total += t;
         }
         uint32_t o = base + x - cnt;
-        if (cnt) {
-            const uint64_t out0 = (uint64_t)it * slot_cap;
+        const uint64_t out0 = (uint64_t)it * slot_cap;
+        if (total <= (uint32_t)LIST_CAP) {
+            // The tile's survivors are finished COOPERATIVELY (round 3, as in the read-per-lane kernel): the lanes that own them
+            // only write a 16-bit descriptor (stream word, offset in the word) at the survivor's place in the tile's list — a
+            // few instructions per hit — then the list is dealt one survivor per lane and re-hashed from the LDS streams.  With
+            // every lane re-hashing its own hits, a wavefront ran the ~80-instruction body as often as its busiest lane had
+            // hits: 3-4 times at c = 100 for 0.6 hits per lane.
+            if (cnt) {
+                uint32_t q = o;
+#pragma unroll
+                for (int j = 0; j < WPT; j++) {
+                    uint32_t m = masks[j];
+                    while (m) {   // bit 15-O <-> in-dword offset O: highest bit first = ascending position
+                        const uint32_t b = 31u - (uint32_t)__clz((int)m);
+                        m &= ~(1u << b);
+                        s_list[q++] = (uint16_t)(((w0 + j) << 4) | (15u - b));
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t hix = tid; hix < min(total, slot_cap); hix += TPB) {
+                const uint32_t e = s_list[hix], w = e >> 4, off = e & 15u;
+                slot_hash[out0 + hix] = hash_at_dyn<K>(off, sF[w], sF[w + 1], sF[w + 2], sR[w], sR[w + 1], sR[w + 2]);
+                slot_pos[out0 + hix] = (uint32_t)tile_base + w * 16 + off;
+            }
+        } else if (cnt) {       // more survivors than the list holds (low-complexity sequence, tiny c): every lane its own
 #pragma unroll
             for (int j = 0; j < WPT; j++) {
                 uint32_t m = masks[j];
-                while (m) {   // bit 15-O <-> in-dword offset O: highest bit first = ascending position
+                while (m) {
                     const uint32_t b = 31u - (uint32_t)__clz((int)m);
                     m &= ~(1u << b);
                     const uint32_t off = 15u - b;
