@@ -77,6 +77,9 @@ int sylph_ctx_synchronize(sylph_ctx *ctx);
  * of the index build (tests lower it to force several passes), "push_chunk_bytes" = bytes of bases per chunk of a host batch
  * (default 64 MiB), "reads_wg_per_cu" = workgroups of the read-per-lane kernel per CU, each looping over blocks of reads
  * ("0".."64"; default 0 = one workgroup per block, measured 10 % faster than 8 looping workgroups per CU).
+ * "plain_records" = "1" (default) / "0": single-end batches whose records carry no dedup marker (reads above 400 bases, or a
+ * --no-dedup session) keep only the hashes of their seed occurrences and are counted without occurrence records; "0" writes
+ * the records for every batch (A/B and tests: the tables are identical).
  * "fail_next_shard_probe" = "1": fault injection for the tests — the next sylph_db_contain_batch_sharded on this context fails
  * in its probe, between the collectives (every rank of the batch must then return the same error, nobody may hang). */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);

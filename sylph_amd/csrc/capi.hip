@@ -273,6 +273,8 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 16 && v <= 256, "bucket_target must be in [16, 256]");
             ctx->bucket_target = (uint32_t)v;
+        } else if (!strcmp(key, "plain_records")) {
+            ctx->plain_records = (uint32_t)strtol(value, nullptr, 10) ? 1u : 0u;   // A/B knob: 0 = occurrence records for every batch
         } else if (!strcmp(key, "fail_next_shard_probe")) {
             ctx->fail_next_shard_probe = (uint32_t)strtol(value, nullptr, 10);   // tests only: one rank of a sharded batch fails between the collectives
         } else if (!strcmp(key, "push_chunk_bytes")) {

@@ -126,6 +126,7 @@ struct sylph_ctx {
     std::mutex mu;                          // serialises calls on this ctx
     int finish_mode = 0;                    // 0 auto, 1 generic, 2 bucket-only (sylph_ctx_set_option "finish")
     uint32_t bucket_target = 128;           // mean occurrences per replay bucket aimed for ("bucket_target")
+    uint32_t plain_records = 1;             // marker-less single-end batches keep no occurrence records ("plain_records" = 0: always write them)
     uint32_t fail_next_shard_probe = 0;     // fault injection for the tests ("fail_next_shard_probe"): the next sharded probe on this context throws
     uint32_t index_lambda = 3;              // postings per 64-byte bucket line of a database index aimed for ("index_lambda")
     uint64_t index_pass_max = 1ull << 30;   // postings sorted per pass of the index build ("index_pass_max"; tests lower it)

@@ -61,6 +61,7 @@ struct PartIn {
     const uint32_t* blk_count;
     uint32_t n_dense, n_blk, slot_cap, tile_entries;
     int slotted, key_sh;
+    int carry;     // marker-less samples (dense only): the pairs ARE the 64-bit hashes — the partition sorts the hashes themselves by bucket
 };
 constexpr int PART_TPB = 256;
 constexpr uint32_t BLK_PER_TILE = 16;     // slotted: blocks of the seeding kernel per partition tile (~3,000 occurrences)
@@ -75,7 +76,7 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t n_tiles) {
     return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);      // may be >= n_tiles for the padding of the last XCD's range
 }
 
-// f(key, index) for every occurrence of tile t (any order; all threads of the workgroup take part).  Slotted: eight groups of
+// f(key, index, hash) for every occurrence of tile t (any order; all threads of the workgroup take part; hash = 0 from slots).  Slotted: eight groups of
 // 32 lanes walk eight blocks at a time (independent loads in flight instead of one block after the other).
 template <class F>
 __device__ __forceinline__ void for_tile_entries(const PartIn& in, uint32_t t, F&& f) {
@@ -85,7 +86,7 @@ __device__ __forceinline__ void for_tile_entries(const PartIn& in, uint32_t t, F
             const uint32_t b = t * BLK_PER_TILE + bl;
             if (b >= in.n_blk) break;
             const uint32_t cnt = min(in.blk_count[b], in.slot_cap), g0 = b * in.slot_cap;
-            for (uint32_t i = l; i < cnt; i += 32) f(in.slot_key[g0 + i], g0 + i);
+            for (uint32_t i = l; i < cnt; i += 32) f(in.slot_key[g0 + i], g0 + i, 0ull);
         }
     } else {
         const uint64_t i0 = (uint64_t)t * in.tile_entries;
@@ -93,7 +94,7 @@ __device__ __forceinline__ void for_tile_entries(const PartIn& in, uint32_t t, F
             const uint64_t i = i0 + e;
             if (i >= in.n_dense) break;
             const uint64_t h = in.hash[i];
-            if (h != INVALID_HASH) f((uint32_t)(h >> in.key_sh), (uint32_t)i);
+            if (h != INVALID_HASH) f((uint32_t)(h >> in.key_sh), (uint32_t)i, h);
         }
     }
 }
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(PART_TPB) void part_hist_kernel(PartIn in, BucketMa
     if (t >= n_tiles) return;
     for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_h[c] = 0;
     __syncthreads();
-    for_tile_entries(in, t, [&](uint32_t key, uint32_t) { atomicAdd(&s_h[bucket_of_key(key, bm) >> fine_bits], 1u); });
+    for_tile_entries(in, t, [&](uint32_t key, uint32_t, uint64_t) { atomicAdd(&s_h[bucket_of_key(key, bm) >> fine_bits], 1u); });
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) hist[(size_t)c * n_tiles + t] = s_h[c];
 }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, Bucke
     if (t >= n_tiles) return;
     for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_cur[c] = 0;
     __syncthreads();
-    for_tile_entries(in, t, [&](uint32_t key, uint32_t) { atomicAdd(&s_cur[bucket_of_key(key, bm) >> fine_bits], 1u); });
+    for_tile_entries(in, t, [&](uint32_t key, uint32_t, uint64_t) { atomicAdd(&s_cur[bucket_of_key(key, bm) >> fine_bits], 1u); });
     __syncthreads();
     uint32_t n_tile = 0;
     {   // tile order: start[c] = exclusive sum of the tile's counts; cbase = exclusive sum of the range sizes
@@ -171,17 +172,19 @@ __global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, Bucke
         if (t == 0 && threadIdx.x == 0) cbase[C] = tot_g;
     }
     __syncthreads();
-    for_tile_entries(in, t, [&](uint32_t key, uint32_t idx) {
+    for_tile_entries(in, t, [&](uint32_t key, uint32_t idx, uint64_t h) {
         const uint32_t b = bucket_of_key(key, bm), c = b >> fine_bits;
         const uint32_t p = atomicAdd(&s_cur[c], 1u);     // place in the tile order
-        if (p < STAGE_PAIRS) s_stage[p] = make_uint2(b, idx);
-        else out[s_gb[c] + p] = make_uint2(b, idx);      // (a tile fuller than the stage: the rest goes out directly)
+        const uint2 pr = in.carry ? make_uint2((uint32_t)h, (uint32_t)(h >> 32)) : make_uint2(b, idx);
+        if (p < STAGE_PAIRS) s_stage[p] = pr;
+        else out[s_gb[c] + p] = pr;                      // (a tile fuller than the stage: the rest goes out directly)
     });
     __syncthreads();
     const uint32_t n_staged = min(n_tile, STAGE_PAIRS);
     for (uint32_t p = threadIdx.x; p < n_staged; p += PART_TPB) {
         const uint2 v = s_stage[p];
-        out[s_gb[v.x >> fine_bits] + p] = v;
+        const uint32_t b = in.carry ? bucket_of_key((uint32_t)((((uint64_t)v.y << 32) | v.x) >> in.key_sh), bm) : v.x;
+        out[s_gb[b >> fine_bits] + p] = v;
     }
 }
 
@@ -190,7 +193,8 @@ __global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, Bucke
 template <int TPB>
 __global__ __launch_bounds__(TPB) void part_fine_kernel(const uint2* __restrict__ pairs,
                                                              const uint32_t* __restrict__ cbase, int fine_bits, uint32_t C, uint32_t B,
-                                                             uint32_t* __restrict__ boff, uint32_t* __restrict__ perm) {
+                                                             uint32_t* __restrict__ boff, uint32_t* __restrict__ perm, int carry, int key_sh,
+                                                             BucketMap bm, uint64_t* __restrict__ sorted_hash) {
     __shared__ uint32_t s_cnt[MAX_FINE];
     __shared__ uint32_t s_wave[TPB / 64];
     const uint32_t c = blockIdx.x, F = 1u << fine_bits, b0 = c << fine_bits;
@@ -201,7 +205,13 @@ __global__ __launch_bounds__(TPB) void part_fine_kernel(const uint2* __restrict_
     for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * TPB) {
         uint32_t k[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) k[u] = e + u * TPB < hi ? pairs[e + u * TPB].x : 0xFFFFFFFFu;
+        for (int u = 0; u < 4; u++) {
+            k[u] = 0xFFFFFFFFu;
+            if (e + u * TPB < hi) {
+                if (carry) { const uint2 v = pairs[e + u * TPB]; k[u] = bucket_of_key((uint32_t)((((uint64_t)v.y << 32) | v.x) >> key_sh), bm); }
+                else k[u] = pairs[e + u * TPB].x;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++)
             if (k[u] != 0xFFFFFFFFu) atomicAdd(&s_cnt[k[u] - b0], 1u);
@@ -224,10 +234,16 @@ __global__ __launch_bounds__(TPB) void part_fine_kernel(const uint2* __restrict_
     for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * TPB) {
         uint2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = e + u * TPB < hi ? pairs[e + u * TPB] : make_uint2(0xFFFFFFFFu, 0u);
+        for (int u = 0; u < 4; u++) v[u] = e + u * TPB < hi ? pairs[e + u * TPB] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (v[u].x != 0xFFFFFFFFu) perm[atomicAdd(&s_cnt[v[u].x - b0], 1u)] = v[u].y;
+        for (int u = 0; u < 4; u++) {
+            if (e + u * TPB >= hi) continue;
+            if (carry) {      // the sorted array holds the hashes themselves (marker-less samples: nothing else is ever looked at)
+                const uint64_t h = ((uint64_t)v[u].y << 32) | v[u].x;
+                sorted_hash[atomicAdd(&s_cnt[bucket_of_key((uint32_t)(h >> key_sh), bm) - b0], 1u)] = h;
+            } else
+                perm[atomicAdd(&s_cnt[v[u].x - b0], 1u)] = v[u].y;
+        }
     }
 }
 
@@ -777,6 +793,141 @@ __global__ __launch_bounds__(RTPB) void bucket_replay_kernel(const OccRec* __res
                              overflow, mid_list, large_list, ovf_list, dbg_stage);
 }
 
+// Marker-less samples (single-end; long reads or --no-dedup: sylph_sketch::n_plain): nothing is ever dropped, the table is the
+// histogram of the hashes.  Same bucket, same sub-range sort as replay_bucket, on 8-byte hashes gathered through the permutation
+// instead of 32-byte records (the gather is what bounds the replay: 65 B fetched per occurrence there); no records exist at all.
+// Buckets above CAP go to the next configuration's list (large_list), above that to ovf_list — the host writes the records of
+// the sample then (OccRec{hash, 0, 0, 0}) and sends those buckets the usual way.
+template <int CAP, int RTPB>
+__device__ __forceinline__ void count_bucket(const uint32_t b, const uint64_t* __restrict__ hash, const uint32_t* __restrict__ perm,
+                                             const uint32_t* __restrict__ boff, const uint32_t* __restrict__ p_nv, BucketMap bm,
+                                             uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c, uint32_t* __restrict__ n_distinct,
+                                             uint32_t* __restrict__ removed_b, uint32_t* __restrict__ overflow,
+                                             uint32_t* __restrict__ large_list, uint32_t* __restrict__ ovf_list) {
+    constexpr int ITEMS = CAP / RTPB;
+    __shared__ uint64_t s_key[CAP], s_sorted[CAP];
+    __shared__ uint32_t s_cnt[CAP + 1], s_mult[CAP];
+    __shared__ __attribute__((aligned(8))) uint16_t s_fill[CAP];
+    __shared__ uint32_t s_wave[RTPB / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nv = *p_nv;
+    const uint32_t first = boff[b], last = boff[b + 1];
+    const uint32_t n = last - first;
+    if (last > nv || first > last) { if (tid == 0) atomicAdd(overflow, 1u); return; }
+    if (n == 0) return;
+    if (n > (uint32_t)CAP) {
+        if (tid == 0) {
+            uint32_t* list = (CAP < CAP_LARGE && n <= (uint32_t)CAP_LARGE) ? large_list : ovf_list;
+            list[1 + atomicAdd(&list[0], 1u)] = b;
+        }
+        return;
+    }
+    const uint64_t lo_hash = ((((uint64_t)b << 32) + bm.mult - 1u) / bm.mult) << bm.sh;      // (bm.composite: checked by the host)
+    const uint32_t sub_mult = bm.sub_mult[CAP == CAP_SMALL ? 0 : CAP == CAP_MID ? 1 : 2];
+    uint64_t h[ITEMS];
+    uint32_t sub[ITEMS], place[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RTPB;
+        h[q] = i < n ? (perm ? hash[perm[first + i]] : hash[first + i]) : 0ull;      // perm == nullptr: `hash` is sorted by bucket already
+    }
+    for (uint32_t t = tid; t <= (uint32_t)CAP; t += RTPB) s_cnt[t] = 0;
+    for (uint32_t t = tid; t < (uint32_t)CAP; t += RTPB) s_fill[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RTPB;
+        sub[q] = 0;
+        if (i < n) {
+            const uint32_t hsres = (uint32_t)((h[q] - lo_hash) >> bm.sh);
+            sub[q] = sub_mult ? min(__umulhi(hsres, sub_mult), (uint32_t)CAP - 1u) : min(hsres, (uint32_t)CAP - 1u);
+            atomicAdd(&s_cnt[sub[q]], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t v[ITEMS], sum = 0;
+#pragma unroll
+        for (int e = 0; e < ITEMS; e++) { v[e] = s_cnt[tid * ITEMS + e]; sum += v[e]; }
+        uint32_t run = block_excl_sum<RTPB>(sum, s_wave, nullptr);
+#pragma unroll
+        for (int e = 0; e < ITEMS; e++) { s_cnt[tid * ITEMS + e] = run; run += v[e]; }
+        if (tid == RTPB - 1) s_cnt[CAP] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RTPB;
+        place[q] = 0;
+        if (i < n) {
+            uint32_t* const w = reinterpret_cast<uint32_t*>(s_fill) + (sub[q] >> 1);
+            const uint32_t old = atomicAdd(w, (sub[q] & 1u) ? 65536u : 1u);
+            place[q] = s_cnt[sub[q]] + ((sub[q] & 1u) ? (old >> 16) : (old & 0xFFFFu));
+            s_key[place[q]] = h[q];
+        }
+    }
+    __syncthreads();
+    // sorted position = start of the sub-range + smaller hashes in it + equal hashes placed before; the first of its equals
+    // carries the k-mer's multiplicity
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RTPB;
+        if (i < n) {
+            const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
+            uint32_t less = 0, eq = 0, eq_before = 0;
+            for (uint32_t p = lo; p < hi; p++) {
+                const uint64_t kp = s_key[p];
+                less += kp < h[q] ? 1u : 0u;
+                const uint32_t same = kp == h[q] ? 1u : 0u;
+                eq += same;
+                eq_before += (same && p < place[q]) ? 1u : 0u;
+            }
+            const uint32_t r = lo + less + eq_before;
+            s_sorted[r] = h[q];
+            s_mult[r] = eq_before == 0 ? eq : 0u;
+        }
+    }
+    __syncthreads();
+    const uint32_t items = (n + RTPB - 1) / RTPB, j0 = tid * items;
+    uint32_t heads = 0;
+    for (uint32_t t = 0; t < items; t++) {
+        const uint32_t j = j0 + t;
+        if (j >= n) break;
+        heads += s_mult[j] ? 1u : 0u;
+    }
+    uint32_t total_heads = 0;
+    uint32_t rh = block_excl_sum<RTPB>(heads, s_wave, &total_heads);
+    for (uint32_t t = 0; t < items; t++) {
+        const uint32_t j = j0 + t;
+        if (j >= n) break;
+        const uint32_t m = s_mult[j];
+        if (m) { tmp_k[first + rh] = s_sorted[j]; tmp_c[first + rh] = m; rh++; }
+    }
+    if (tid == 0) { n_distinct[b] = total_heads; removed_b[b] = 0; }
+}
+template <int CAP, int RTPB>
+__global__ __launch_bounds__(RTPB) void bucket_count_kernel(const uint64_t* __restrict__ hash, const uint32_t* __restrict__ perm,
+                                                            const uint32_t* __restrict__ boff, const uint32_t* __restrict__ p_nv, BucketMap bm,
+                                                            uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
+                                                            uint32_t* __restrict__ n_distinct, uint32_t* __restrict__ removed_b,
+                                                            uint32_t* __restrict__ overflow, uint32_t* __restrict__ large_list,
+                                                            uint32_t* __restrict__ ovf_list) {
+    count_bucket<CAP, RTPB>(blockIdx.x, hash, perm, boff, p_nv, bm, tmp_k, tmp_c, n_distinct, removed_b, overflow, large_list, ovf_list);
+}
+template <int CAP, int RTPB>
+__global__ __launch_bounds__(RTPB) void bucket_count_list_kernel(const uint64_t* __restrict__ hash, const uint32_t* __restrict__ perm,
+                                                                 const uint32_t* __restrict__ boff, const uint32_t* __restrict__ p_nv,
+                                                                 BucketMap bm, uint64_t* __restrict__ tmp_k, uint32_t* __restrict__ tmp_c,
+                                                                 uint32_t* __restrict__ n_distinct, uint32_t* __restrict__ removed_b,
+                                                                 uint32_t* __restrict__ overflow, const uint32_t* __restrict__ my_list,
+                                                                 uint32_t* __restrict__ ovf_list) {
+    const uint32_t n_listed = my_list[0];
+    for (uint32_t i = blockIdx.x; i < n_listed; i += gridDim.x) {
+        count_bucket<CAP, RTPB>(my_list[1 + i], hash, perm, boff, p_nv, bm, tmp_k, tmp_c, n_distinct, removed_b, overflow, nullptr, ovf_list);
+        __syncthreads();
+    }
+}
+
 // second configuration: a fixed, small grid walks the (usually empty) list of buckets the first one queued
 template <int CAP, int RTPB>
 __global__ __launch_bounds__(RTPB) void bucket_replay_list_kernel(const OccRec* __restrict__ recs, const uint32_t* __restrict__ perm,
@@ -993,6 +1144,10 @@ bool finish_bucketed(sylph_sketch* sk) {
     while ((1u << fine_bits) < MAX_FINE && ((B + (1u << fine_bits) - 1) >> fine_bits) > 512) fine_bits++;
     const uint32_t C = (B + (1u << fine_bits) - 1) >> fine_bits;
     SY_REQUIRE(C <= MAX_COARSE, "internal: %u coarse ranges", C);
+    // marker-less sample (sketch_session.h): hashes only, counted without occurrence records; tiny samples whose bucket range does
+    // not fit the sub-range arithmetic get their records written and take the usual kernels
+    if (!slotted && sk->n_plain && !(sk->n_plain == sk->n_occ && bm.composite)) materialise_plain_records(sk);
+    bool plain = !slotted && sk->n_plain != 0;
     PartIn in{};
     in.slotted = slotted ? 1 : 0;
     in.key_sh = bm.sh;
@@ -1016,7 +1171,11 @@ bool finish_bucketed(sylph_sketch* sk) {
            &b_tmpc = ctx->scratch[4], &b_small = ctx->scratch[5], &b_bk = ctx->scratch[6];
     b_hist.reserve(((size_t)C * n_tiles + 2 * (size_t)C + 2) * 4);      // hist (C x n_tiles) | total (C) | cbase (C + 1)
     b_pairs.reserve((size_t)n_all * 8);                                 // (bucket, occurrence index) pairs grouped by coarse range
-    b_perm.reserve((size_t)n_all * 4);
+    if (!plain) b_perm.reserve((size_t)n_all * 4);
+    DevBuf& b_sorted = ctx->scratch[7];                                 // marker-less: the hashes sorted by bucket
+    if (plain) b_sorted.reserve((size_t)n_all * 8);
+    uint64_t* sorted_hash = plain ? b_sorted.as<uint64_t>() : nullptr;
+    in.carry = plain ? 1 : 0;
     b_tmpk.reserve((size_t)n_all * 8);
     b_tmpc.reserve((size_t)n_all * 4);
     b_small.reserve(64);
@@ -1059,17 +1218,22 @@ bool finish_bucketed(sylph_sketch* sk) {
             //  threads walk them instead of 256; c5: 1.27 -> see profiles)
             if ((uint64_t)n_all / C > 32768)
                 hipLaunchKernelGGL((part_fine_kernel<1024>), dim3(C), dim3(1024), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
-                                   b_perm.as<uint32_t>());
+                                   b_perm.as<uint32_t>(), in.carry, in.key_sh, bm, sorted_hash);
             else
                 hipLaunchKernelGGL((part_fine_kernel<PART_TPB>), dim3(C), dim3(PART_TPB), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
-                                   b_perm.as<uint32_t>());
+                                   b_perm.as<uint32_t>(), in.carry, in.key_sh, bm, sorted_hash);
         }
         {
             ScopedKernelTimer t(ctx, "replay");
-            hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
-                               recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
-                               b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, mid_list, large_list,
-                               ovf_list, dbg);
+            if (plain)
+                hipLaunchKernelGGL((bucket_count_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
+                                   sorted_hash, (const uint32_t*)nullptr, boff, d_nv, bm, b_tmpk.as<uint64_t>(),
+                                   b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, large_list, ovf_list);
+            else
+                hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
+                                   recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
+                                   b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, mid_list, large_list,
+                                   ovf_list, dbg);
         }
     }
     // removed counts, table offsets, compaction, and everything the host needs to know in one 28-byte block
@@ -1095,6 +1259,12 @@ bool finish_bucketed(sylph_sketch* sk) {
     close_table(1);
     read_tail();
     if (host.overflow) return false;             // inconsistent bounds (defensive): the generic path redoes the sample
+    if (plain && host.n_ovf) {
+        // k-mers more than a thousand deep in a marker-less sample: write the occurrence records after all and take the usual
+        // kernels from the start (their overflow path works on records and on the index permutation)
+        materialise_plain_records(sk);
+        return finish_bucketed(sk);
+    }
     if (host.n_mid || host.n_large) {
         // Buckets the 256-slot configuration passed on (more than 256 occurrences, or a k-mer 96+ deep: abundant genomes).  The
         // list-driven configurations are launched only now, with grids that match the lists: launched speculatively with every
@@ -1103,6 +1273,12 @@ bool finish_bucketed(sylph_sketch* sk) {
         HostPhase ph(ctx, "finish(bucket): medium / large configurations");
         {
             ScopedKernelTimer t(ctx, "replay");
+            if (plain) {
+                if (host.n_large)
+                    hipLaunchKernelGGL((bucket_count_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(host.n_large, 1536u)),
+                                       dim3(RTPB_LARGE), 0, ctx->stream, sorted_hash, (const uint32_t*)nullptr, boff, d_nv, bm,
+                                       b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, large_list, ovf_list);
+            } else {
             if (host.n_mid)
                 hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_MID, RTPB_MID>), dim3(std::min<uint32_t>(host.n_mid, 1280u)),
                                    dim3(RTPB_MID), 0, ctx->stream, recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
@@ -1113,6 +1289,7 @@ bool finish_bucketed(sylph_sketch* sk) {
                                    dim3(RTPB_LARGE), 0, ctx->stream, recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
                                    sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
                                    d_overflow, large_list, large_list, ovf_list, dbg);
+            }
         }
         close_table(0);
         read_tail();

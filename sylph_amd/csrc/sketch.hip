@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void coarse_index_kernel(const uint64_t* __res
 // Survivors arrive sorted by position, so a workgroup's 256 survivors span a short run of records: two lanes bound
 // it through the coarse index (first and last survivor), the run's offsets are staged in LDS and every lane searches
 // only inside that run.
+template <bool LIGHT>   // LIGHT: validity only — o_hash, no markers, no OccRec (marker-less single-end batches)
 __global__ __launch_bounds__(256) void annotate_reads_kernel(
     const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint64_t n_rec, const uint32_t* __restrict__ pos,
     const uint64_t* __restrict__ hash, uint32_t n, uint32_t pos_bias, uint32_t k, int avx2_compat, int paired,
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
         valid = (p - start) < n_hashed_kmers(L, k, avx2_compat, 0);
         if (valid) {
             rid = rec_base + r;
-            if (want_markers) {
+            if (!LIGHT && want_markers) {
                 const uint8_t* a = nullptr;
                 const uint8_t* b = nullptr;
                 if (!paired) {
@@ -162,10 +163,25 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
     if (i < n) {
         const uint64_t hv = valid ? h : INVALID_HASH;
         o_hash[i] = hv;
-        o_rec[i] = OccRec{hv, rid, m0, m1};
+        if constexpr (!LIGHT) o_rec[i] = OccRec{hv, rid, m0, m1};
     }
     // (no counter of valid survivors here: one atomic per wavefront on a single word runs at ~88 atomics/us and was
     //  the whole 0.9 ms of this kernel; finish() finds the count by binary search in the hash-sorted array instead)
+}
+
+// flag[0] |= 1 when some record of the batch has a length that carries a dedup marker for single-end reads (66 .. 400 bases,
+// sketch.rs:627,923)
+__global__ __launch_bounds__(256) void marker_lengths_kernel(const uint64_t* __restrict__ off, uint64_t n_rec, uint32_t* __restrict__ flag) {
+    bool any = false;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t L = off[r + 1] - off[r];
+        any |= L >= 66 && L <= 400;
+    }
+    if (__ballot(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+__global__ __launch_bounds__(256) void plain_records_kernel(const uint64_t* __restrict__ hash, uint64_t n, OccRec* __restrict__ recs) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) recs[i] = OccRec{hash[i], 0ull, 0ull, 0ull};
 }
 
 // Genome flavour: (contig, end position, hash), validated with the positions-variant rules
@@ -466,6 +482,16 @@ __global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t* __r
 
 // One device-resident batch: records d_off[0..n_records] over the stream at d_bases (ASCII, or packed 2-bit starting
 // `phase` bases into the first byte).  Appends the batch's occurrences to the session.
+void materialise_plain_records(sylph_sketch* sk) {
+    if (sk->n_plain == 0) return;
+    sylph_ctx* ctx = sk->ctx;
+    sk->recs.grow_keep(sk->n_occ * sizeof(OccRec), 0, ctx->stream);
+    hipLaunchKernelGGL(plain_records_kernel, dim3(grid_for(sk->n_plain)), dim3(256), 0, ctx->stream, sk->hash.as<uint64_t>(), sk->n_plain,
+                       sk->recs.as<OccRec>());
+    SY_HIP(hipGetLastError());
+    sk->n_plain = 0;
+}
+
 static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, const uint64_t* d_off, uint64_t n_records, uint64_t n_bases,
                           int enc) {
     sylph_ctx* ctx = sk->ctx;
@@ -473,8 +499,20 @@ static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t pha
     // short-read batches (mean record length <= 300): one lane per record, seeding + markers fused (reads.hip); it declines
     // (returns false) when some record is longer than its halo, and the position kernel + annotate below take over
     bool done = false;
-    if (ctx->seeds_mode == 0 && n_bases < (1ull << 32) - 64 && n_records < (1ull << 31) && n_bases <= 300ull * n_records)
-        done = push_short_reads(sk, d_bases, phase, d_off, n_records, n_bases, enc);
+    const bool short_batch = ctx->seeds_mode == 0 && n_bases < (1ull << 32) - 64 && n_records < (1ull << 31) && n_bases <= 300ull * n_records;
+    // Marker-less batch?  Single-end only (a pair's mate-2 rule needs the record ids), everything so far marker-less too, and
+    // either --no-dedup or no record of a length that carries a marker (asked of the offsets by a small kernel whose answer
+    // comes back with the seeding kernel's count).
+    bool plain = !short_batch && !sk->paired && sk->n_plain == sk->n_occ && ctx->plain_records;
+    uint32_t* d_marked = sk->counters.as<uint32_t>() + 6;
+    if (plain && !sk->no_dedup) {
+        SY_HIP(hipMemsetAsync(d_marked, 0, 4, ctx->stream));
+        if (n_records)
+            hipLaunchKernelGGL(marker_lengths_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (n_records + 255) / 256)), dim3(256), 0, ctx->stream,
+                               d_off, n_records, d_marked);
+    }
+    if (!plain) materialise_plain_records(sk);
+    if (short_batch) done = push_short_reads(sk, d_bases, phase, d_off, n_records, n_bases, enc);
     if (!done && enc == SYLPH_ENC_2BIT) {   // the position kernel and the marker loads of annotate read ASCII
         sk->batch_ascii.reserve(n_bases + 64);
         if (n_bases)
@@ -488,23 +526,34 @@ static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t pha
     // pointer into the middle of a larger buffer, e.g. the second batch of a sample, need not be aligned)
     const uint32_t bias = (uint32_t)((uintptr_t)d_bases & 15);
     const uint32_t n = done ? 0 : seeds_sorted_by_pos(ctx, d_bases - bias, n_bases + bias, sk->c, sk->k, d_count);
+    if (plain && !sk->no_dedup && !done) {
+        uint32_t marked = 0;
+        ctx->read_back(&marked, d_marked, 4);        // (the stream is idle: seeds_sorted_by_pos has read its count back)
+        if (marked) { plain = false; materialise_plain_records(sk); }
+    }
     if (n) {
         HostPhase ph(ctx, "push: grow + annotate");
         const uint64_t need = sk->n_occ + n;
         const size_t keep = sk->n_occ * 8;
         sk->hash.grow_keep(need * 8, keep, ctx->stream);
-        sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
+        if (!plain) sk->recs.grow_keep(need * sizeof(OccRec), sk->n_occ * sizeof(OccRec), ctx->stream);
         const uint32_t n_coarse = (uint32_t)(n_bases >> COARSE_SHIFT) + 2;
         ctx->scratch[5].reserve((size_t)n_coarse * 4);
         ScopedKernelTimer t(ctx, "annotate");
         hipLaunchKernelGGL(coarse_index_kernel, dim3(grid_for(n_coarse)), dim3(256), 0, ctx->stream, d_off, n_records, n_coarse,
                            ctx->scratch[5].as<uint32_t>());
-        hipLaunchKernelGGL(annotate_reads_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_bases, d_off, n_records,
-                           ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, bias, sk->k, sk->avx2_compat,
-                           sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, ctx->scratch[5].as<uint32_t>(),
-                           sk->hash.as<uint64_t>() + sk->n_occ,
-                           sk->recs.as<OccRec>() + sk->n_occ);
+        if (plain)
+            hipLaunchKernelGGL(annotate_reads_kernel<true>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_bases, d_off, n_records,
+                               ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, bias, sk->k, sk->avx2_compat,
+                               sk->paired, 0, sk->rec_base, ctx->scratch[5].as<uint32_t>(), sk->hash.as<uint64_t>() + sk->n_occ,
+                               (OccRec*)nullptr);
+        else
+            hipLaunchKernelGGL(annotate_reads_kernel<false>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_bases, d_off, n_records,
+                               ctx->scratch[2].as<uint32_t>(), ctx->scratch[3].as<uint64_t>(), n, bias, sk->k, sk->avx2_compat,
+                               sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, ctx->scratch[5].as<uint32_t>(),
+                               sk->hash.as<uint64_t>() + sk->n_occ, sk->recs.as<OccRec>() + sk->n_occ);
         SY_HIP(hipGetLastError());
+        if (plain) sk->n_plain = need;
         sk->n_occ = need;
     }
     sk->rec_base += n_records;
@@ -762,7 +811,8 @@ static void sketch_finish_impl(sylph_sketch* sk) {
         if (finish_bucketed(sk)) { sk->finished = true; return; }
         SY_REQUIRE(ctx->finish_mode != 2, "bucket finish overflowed and finish=bucket forbids the fallback");
     }
-    flush_pending_slots(sk);   // the device-wide path works on the dense file-order arrays
+    flush_pending_slots(sk);   // the device-wide path works on the dense file-order arrays ...
+    materialise_plain_records(sk);   // ... and on occurrence records
     sk->n_out = 0;
     sk->dup_removed = 0;
     generic_replay(ctx, sk->hash.as<uint64_t>(), sk->recs.as<OccRec>(), (uint32_t)sk->n_occ, sk->paired, sk->no_dedup, sk->out_k,

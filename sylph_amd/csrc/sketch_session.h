@@ -19,6 +19,11 @@ void flush_pending_slots(sylph_sketch* sk);   // reads.hip
 inline int key_shift(uint32_t c) { return std::max(0, bit_length(UINT64_MAX / (uint64_t)std::max<uint32_t>(c, 1)) - 32); }
 void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, bool no_dedup,
                     DevBuf& out_k, DevBuf& out_c, uint64_t& n_out, uint64_t& removed_out);   // sketch.hip
+// A single-end session whose records carry no dedup markers so far (long reads: sketch.rs:922-927 passes no marker above 400
+// bases; --no-dedup) keeps only the hashes of its occurrences — nothing the replay looks at besides the hash exists for them
+// (no marker, no mate) — and finish() counts them without occurrence records.  The first batch that may carry markers (or a
+// finish that needs the records after all) writes the records of what is there: OccRec{hash, 0, 0, 0}.
+void materialise_plain_records(sylph_sketch* sk);   // sketch.hip
 }
 
 namespace sylph {
@@ -39,6 +44,7 @@ struct sylph_sketch {
     bool finished = false;
     uint64_t rec_base = 0;         // records pushed so far
     uint64_t n_occ = 0;            // occurrences (valid + invalid) appended so far
+    uint64_t n_plain = 0;          // the first n_plain of them have no OccRec (marker-less single-end batches, see materialise_plain_records)
     sylph::DevBuf hash;                   // hash of every occurrence, file order (sort key)
     sylph::DevBuf recs;                   // OccRec of every occurrence, file order
     sylph::DevBuf slot_bases[2], slot_off[2];   // device slots of the host-batch pipeline (copy stream fills one, kernels read the other)

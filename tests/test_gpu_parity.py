@@ -1097,3 +1097,60 @@ def test_tiny_reads_many_records_per_block(ctx):
             e = O.sketch_reads(b, off, c=c, paired=paired)
             assert len(e["kmers"]) > 50
             assert_same_sketch(sketch_gpu(ctx, b, off, paired=paired, c=c), e)
+
+
+def _sketch_in_batches(ctx, batches, c, no_dedup=False, plain="1"):
+    ctx.set_option("plain_records", plain)
+    try:
+        sk = S.ReadSketcher(ctx, c=c, paired=False, no_dedup=no_dedup)
+        for recs in batches:
+            b, off = concat(recs)
+            sk.push(b, off)
+        r = sk.finish()
+        sk.close()
+        return r
+    finally:
+        ctx.set_option("plain_records", "1")
+
+
+def test_marker_less_single_end_samples_are_counted_without_records(ctx):
+    """Single-end batches whose records carry no dedup marker (reads above 400 bases, sketch.rs:922-927; --no-dedup) keep only
+    their hashes and are counted by bucket_count_kernel.  Same tables as with occurrence records (`plain_records` = 0) and as the
+    oracle's: (a) long reads only, two batches; (b) a first batch of long reads, then a batch with 66-400 base reads and exact
+    duplicates among them (the records of the first batch are written after the fact, dedup applies to the second);
+    (c) --no-dedup over a mixture of lengths; (d) a k-mer 3,000 deep — beyond the largest count configuration, through the
+    overflow path; (e) reads of 401+ bases that are short on average (the short-read kernel declines, the position kernel runs)."""
+    rng = np.random.default_rng(77)
+    genome = random_seq(rng, 300000)
+
+    def cut(n, lo, hi):
+        out = []
+        for _ in range(n):
+            L = int(rng.integers(lo, hi))
+            s = int(rng.integers(0, len(genome) - L))
+            out.append(genome[s:s + L].copy())
+        return out
+    long_a, long_b = cut(300, 401, 9000), cut(200, 2000, 30000)
+    short = cut(400, 66, 401)
+    short = short + short[:150] + [short[0]] * 5                                  # exact duplicates: dedup must see them
+    deep = [genome[1000:1700].copy()] * 3000
+    cases = {
+        "long_only": ([long_a, long_b], False),
+        "long_then_short": ([long_a, short, long_b], False),
+        "short_then_long": ([short, long_a], False),
+        "no_dedup_mixture": ([long_a + short, long_b + cut(100, 0, 66)], True),
+        "deep_kmers": ([long_a + deep, long_b], False),
+        "just_above_400": ([cut(2000, 401, 420)], False),
+    }
+    for name, (batches, nd) in cases.items():
+        flat = [r for bt in batches for r in bt]
+        b, off = concat(flat)
+        for c in (20, 100):
+            e = O.sketch_reads(b, off, c=c, no_dedup=nd)
+            for plain in ("1", "0"):
+                g = _sketch_in_batches(ctx, batches, c, no_dedup=nd, plain=plain)
+                assert np.array_equal(g["kmers"], e["kmers"]), (name, c, plain)
+                assert np.array_equal(g["counts"], e["counts"]), (name, c, plain)
+                assert g["dup_removed"] == e["dup_removed"], (name, c, plain)
+        if name in ("long_then_short", "short_then_long"):
+            assert e["dup_removed"] > 0

@@ -1,4 +1,5 @@
-# where a warm sample's time goes in `sylph-hip sketch`: four paired 1 Gbp samples in one command (-t 1) with SYLPH_HIP_FEED_TRACE=1
+# where a warm sample's time goes in `sylph-hip sketch`: four paired 1 Gbp samples in one command (-t 1) with SYLPH_HIP_FEED_TRACE=1,
+# for several settings of the parse-thread count (SYLPH_HIP_PARSE_THREADS; default: see parse_threads() in host/feed.cpp)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 out=gpurun_out/feed_trace; mkdir -p $out
 python - <<'PY'
@@ -23,6 +24,9 @@ for i in range(4):
         os.symlink(f"{d}/s_{m}.fq", dst)
 PY
 d=/tmp/feed_trace
-for rep in 1 2; do
-SYLPH_HIP_FEED_TRACE=1 sylph_amd/sylph-hip sketch -1 $d/p0_1.fq $d/p1_1.fq $d/p2_1.fq $d/p3_1.fq -2 $d/p0_2.fq $d/p1_2.fq $d/p2_2.fq $d/p3_2.fq -d $d/out -t 1 --fpr 0 2>&1 | grep -v "^WARN" | tee $out/trace_$rep.txt | cut -c1-200
-done
+lscpu | grep -i "numa\|socket\|model name\|^CPU(s)" | head -8 | tee $out/lscpu.txt
+for pt in default 16 32 128; do for rep in 1 2; do
+  if [ $pt = default ]; then unset SYLPH_HIP_PARSE_THREADS; else export SYLPH_HIP_PARSE_THREADS=$pt; fi
+  echo "== parse threads $pt"
+  SYLPH_HIP_FEED_TRACE=1 sylph_amd/sylph-hip sketch -1 $d/p0_1.fq $d/p1_1.fq $d/p2_1.fq $d/p3_1.fq -2 $d/p0_2.fq $d/p1_2.fq $d/p2_2.fq $d/p3_2.fq -d $d/out -t 1 --fpr 0 2>&1 | grep "index of\|timing" | sed 's/.*index of .*fq *\([0-9.]* ms\).*/index \1/; s/.*sketched + written in \([0-9.]* s\).*/SAMPLE \1/' | tr '\n' ' '; echo
+done; done | tee $out/threads.txt
