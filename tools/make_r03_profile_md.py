@@ -118,7 +118,7 @@ json.dump({"hbm_bytes_per_launch": int(reads_fetch + reads_write), "kernel": "re
            "head": head, "csrc_sha": csrc_fingerprint(),
            "source": "profiles/r03_kernel_stats.md PMC section (FETCH_SIZE x2 gfx950 correction for the streaming reads + WRITE_SIZE, separate --pmc passes)"},
           open(os.path.join(dst, "seeds_traffic.json"), "w"))
-for name in ("feed.txt", "stress_shared_kmers.txt", "stress_deep_coverage.txt", "kernel_stats.csv", "pytest_gpu.txt"):
+for name in ("feed.txt", "stress_shared_kmers.txt", "stress_deep_coverage.txt", "stress_deep_long_reads.txt", "kernel_stats.csv", "pytest_gpu.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "r03_" + name))
 print("ok: traffic", reads_fetch + reads_write, "valu/kmer", valu_per_kmer, "busy", valu_busy, "probe B/probe", probe_fetch_raw / a_probe.get("probes_per_launch", 1), "csrc", csrc_fingerprint())

@@ -50,4 +50,5 @@ python tools/feed_bench.py 3333334 > $out/feed.txt 2> $out/feed.err
 python tools/shared_kmers_check.py 2> /dev/null > $out/stress_shared_kmers.txt
 python tools/deep_coverage_check.py 2> /dev/null > $out/stress_deep_coverage.txt
 DEEP_CASES=extreme python tools/deep_coverage_check.py 2> /dev/null >> $out/stress_deep_coverage.txt
+python tools/deep_long_reads_check.py 2> /dev/null > $out/stress_deep_long_reads.txt
 tail -3 $out/feed.txt $out/stress_shared_kmers.txt $out/stress_deep_coverage.txt
