@@ -40,6 +40,16 @@ struct ArgError { std::string msg; };
         }                                                         \
     } while (0)
 
+struct StateError { std::string msg; };   // -> SYLPH_ERR_STATE
+#define SY_REQUIRE_STATE(cond, ...)                               \
+    do {                                                          \
+        if (!(cond)) {                                            \
+            char _b[512];                                         \
+            snprintf(_b, sizeof(_b), __VA_ARGS__);                \
+            throw ::sylph::StateError{_b};                        \
+        }                                                         \
+    } while (0)
+
 // Translate C++ exceptions into ABI status codes; nothing unwinds across extern "C".
 template <class F>
 int guarded(F&& f) {
@@ -53,6 +63,9 @@ int guarded(F&& f) {
     } catch (const ArgError& e) {
         set_error("%s", e.msg.c_str());
         return SYLPH_ERR_INVALID;
+    } catch (const StateError& e) {
+        set_error("%s", e.msg.c_str());
+        return SYLPH_ERR_STATE;
     } catch (const std::bad_alloc&) {
         set_error("host allocation failed");
         return SYLPH_ERR_NOMEM;

@@ -672,8 +672,7 @@ void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_r
     uint32_t width = 4;
     if (cov_width && n_hits && cb + rb <= 32) width = cb <= 8 ? 1 : cb <= 16 ? 2 : 4;
     const ResultLayout lay(n_rows, n_hits, width, with_lost ? G : 0);
-    db->lay = lay;
-    db->last_rows = n_rows;
+    if (!dst) { db->lay = lay; db->last_rows = n_rows; }   // the database's own block; a caller's block carries its layout itself
     db->res.reserve(lay.lost + 64);
     char* d_res = db->res.as<char>();
     uint64_t* d_cov_off = reinterpret_cast<uint64_t*>(d_res);
@@ -874,7 +873,7 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
 }
 
 uint32_t sylph::contain_batch_impl(sylph_db* db, const sylph_sample_ref* samples, uint32_t n_samples, int mem, double min_number_kmers,
-                                   uint32_t* cov_width, HostBlock* dst) {
+                                   uint32_t* cov_width, HostBlock* dst, ResultViews* views) {
     SY_REQUIRE(db && cov_width, "null argument");
     SY_REQUIRE(n_samples == 0 || samples, "null samples");
     SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
@@ -909,6 +908,7 @@ uint32_t sylph::contain_batch_impl(sylph_db* db, const sylph_sample_ref* samples
     uint32_t max_count = 0, n_hits = 0;
     if (n_samples) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
     finish_hits(db, n_hits, max_count, (uint64_t)n_samples * db->n_genomes, cov_width, false, dst);
+    fill_views(dst ? *dst : db->h_block, views);
     return n_hits;
 }
 
@@ -998,12 +998,11 @@ int sylph_db_contain_batch(sylph_db* db, const sylph_sample_ref* samples, uint32
                            uint64_t* out_n_covs) {
     return guarded([&] {
         SY_REQUIRE(db && contain_count && cov_off && covs && cov_width, "null argument");
-        const uint32_t n_hits = contain_batch_impl(db, samples, n_samples, mem, min_number_kmers, cov_width, nullptr);
-        const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_block.p;
-        *cov_off = (const uint64_t*)h;
-        *contain_count = (const uint32_t*)(h + lay.ccount);
-        *covs = h + lay.covs;
+        ResultViews v;   // taken under the context lock inside the call (a pipeline may share this database)
+        const uint32_t n_hits = contain_batch_impl(db, samples, n_samples, mem, min_number_kmers, cov_width, nullptr, &v);
+        *cov_off = v.cov_off;
+        *contain_count = v.contain_count;
+        *covs = v.covs;
         if (out_n_covs) *out_n_covs = n_hits;
     });
 }

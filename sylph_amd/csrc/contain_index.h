@@ -208,8 +208,19 @@ void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_r
                  HostBlock* dst = nullptr);
 // The bodies of sylph_db_contain_batch / sylph_db_contain_batch_sharded (they take the context lock themselves); the result
 // block lands in `dst` (nullptr: the database's own).  Return the number of coverage values.
+// `views` (optional): the three result pointers into the block the call filled, taken while the context lock is still held —
+// a pipeline's profile thread working on the same database between the lock's release and the caller's own look at
+// db->lay / db->h_block would otherwise hand the caller somebody else's layout.
+struct ResultViews { const uint64_t* cov_off = nullptr; const uint32_t* contain_count = nullptr; const void* covs = nullptr; };
 uint32_t contain_batch_impl(sylph_db* db, const sylph_sample_ref* samples, uint32_t n_samples, int mem, double min_number_kmers,
-                            uint32_t* cov_width, HostBlock* dst);
+                            uint32_t* cov_width, HostBlock* dst, ResultViews* views = nullptr);
 uint32_t contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
-                                    double min_number_kmers, uint32_t* cov_width, HostBlock* dst);
+                                    double min_number_kmers, uint32_t* cov_width, HostBlock* dst, ResultViews* views = nullptr);
+inline void fill_views(const HostBlock& b, ResultViews* v) {
+    if (!v) return;
+    const char* h = (const char*)b.p;
+    v->cov_off = (const uint64_t*)h;
+    v->contain_count = (const uint32_t*)(h + b.lay.ccount);
+    v->covs = h + b.lay.covs;
+}
 }  // namespace sylph

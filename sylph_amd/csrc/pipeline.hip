@@ -330,6 +330,15 @@ int sylph_pipeline_next(sylph_pipeline* p, sylph_pipeline_result* out) {
         if (sylph_sketch* dead = p->release_returned()) { lk.unlock(); sylph_sketch_destroy(dead); lk.lock(); }
         SY_REQUIRE(!p->order.empty(), "sylph_pipeline_next: nothing is outstanding");
         Job* j = p->order.front();
+        if (p->comm && j->state != JobState::Profiled && p->flush_upto <= j->seq) {
+            // sharded: the profile thread waits for exactly max_batch samples (the probe batches must be the same on every rank);
+            // with fewer outstanding and no flush nobody would ever wake this call — refuse instead of hanging a one-thread caller
+            uint64_t unprofiled = 0;
+            for (Job* o : p->order) unprofiled += o->state != JobState::Profiled;
+            SY_REQUIRE_STATE(unprofiled >= p->max_batch,
+                             "sylph_pipeline_next: %llu sample(s) outstanding, the sharded probe batch needs %u: submit more or call sylph_pipeline_flush",
+                             (unsigned long long)unprofiled, p->max_batch);
+        }
         p->cv_done.wait(lk, [&] { return j->state == JobState::Profiled; });
         p->order.pop_front();
         p->returned = j;

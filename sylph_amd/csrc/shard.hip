@@ -282,7 +282,7 @@ void sylph_comm_destroy(sylph_comm* comm) {
 }  // extern "C"
 
 uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const sylph_sample_ref* samples, uint32_t n_local, int mem,
-                                           double min_number_kmers, uint32_t* cov_width, HostBlock* dst) {
+                                           double min_number_kmers, uint32_t* cov_width, HostBlock* dst, ResultViews* views) {
     {
         SY_REQUIRE(db && comm && cov_width, "null argument");
         SY_REQUIRE(n_local == 0 || samples, "null samples");
@@ -504,6 +504,7 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 6: sort + assemble + copy out"));
         // ---- 6. sort + assemble this rank's samples
         finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false, dst);
+        fill_views(dst ? *dst : db->h_block, views);
         ph.reset();
         return n_mine;
     }
@@ -527,12 +528,11 @@ int sylph_db_contain_batch_sharded(sylph_db* db, sylph_comm* comm, const sylph_s
                                    const void** covs, uint32_t* cov_width, uint64_t* out_n_covs) {
     return guarded([&] {
         SY_REQUIRE(db && comm && contain_count && cov_off && covs && cov_width, "null argument");
-        const uint32_t n_mine = contain_batch_sharded_impl(db, comm, samples, n_local, mem, min_number_kmers, cov_width, nullptr);
-        const ResultLayout& lay = db->lay;
-        const char* h = (const char*)db->h_block.p;
-        *cov_off = (const uint64_t*)h;
-        *contain_count = (const uint32_t*)(h + lay.ccount);
-        *covs = h + lay.covs;
+        ResultViews v;   // taken under the context lock inside the call
+        const uint32_t n_mine = contain_batch_sharded_impl(db, comm, samples, n_local, mem, min_number_kmers, cov_width, nullptr, &v);
+        *cov_off = v.cov_off;
+        *contain_count = v.contain_count;
+        *covs = v.covs;
         if (out_n_covs) *out_n_covs = n_mine;
     });
 }

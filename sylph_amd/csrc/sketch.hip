@@ -507,9 +507,11 @@ static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t pha
     uint32_t* d_marked = sk->counters.as<uint32_t>() + 6;
     if (plain && !sk->no_dedup) {
         SY_HIP(hipMemsetAsync(d_marked, 0, 4, ctx->stream));
-        if (n_records)
+        if (n_records) {
             hipLaunchKernelGGL(marker_lengths_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (n_records + 255) / 256)), dim3(256), 0, ctx->stream,
                                d_off, n_records, d_marked);
+            SY_HIP(hipGetLastError());   // a launch that failed would leave d_marked at 0: the batch would pass for marker-less
+        }
     }
     if (!plain) materialise_plain_records(sk);
     if (short_batch) done = push_short_reads(sk, d_bases, phase, d_off, n_records, n_bases, enc);

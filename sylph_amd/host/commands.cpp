@@ -581,7 +581,8 @@ int sketch(Engine& e, const SketchArgs& args) {
     // The parsing / inflating of different samples overlaps; the GPU work of one sample is ~2 ms per Gbp.
     create_dir_all(args.sample_output_dir);
     const size_t n_jobs = first_pairs.size() + read_inputs.size();
-    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(args.threads, n_jobs));
+    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(args.threads, MAX_SAMPLE_THREADS), n_jobs));
+    set_parse_share((unsigned)n_workers);
     // the next sample of every worker is indexed while the current one is gathered and pushed
     std::vector<IndexAhead::Files> job_files;
     for (size_t j = 0; j < first_pairs.size(); j++) job_files.push_back({first_pairs[j], second_pairs[j]});
@@ -738,13 +739,16 @@ std::optional<double> get_kmer_identity(const SequencesSketch& S, bool estimate_
         if (count == 1) num_1s += 1; else num_not1s += count;
     }
     const double eps = (double)num_not1s / ((double)num_not1s + (double)num_1s + 0.1);
-    {   // which branch the walk chose, and how close the call was (the walk's order is this host's, not hashbrown's: see above)
-        char buf[200];
-        snprintf(buf, sizeof(buf), "%s --estimate-unknown: running median of the counts above 1 = %.4f (limit %.1f, mean read length %.1f): %s",
-                 S.file_name.c_str(), mov_avg_median, MED_KMER_FOR_ID_EST, S.mean_read_length,
-                 (mov_avg_median < MED_KMER_FOR_ID_EST && S.mean_read_length < 400.) ? "fixed 99.5% read identity" : "read identity estimated from the table");
-        info(buf);
-        if (S.mean_read_length < 400. && std::fabs(mov_avg_median - MED_KMER_FOR_ID_EST) <= 0.1 * MED_KMER_FOR_ID_EST)
+    {   // which branch the walk chose, and how close the call was (the walk's order is this host's, not hashbrown's: see above).
+        // The reference prints neither line: the first only under SYLPH_HIP_DEBUG, the warning only inside the 10 % band.
+        const bool near_limit = S.mean_read_length < 400. && std::fabs(mov_avg_median - MED_KMER_FOR_ID_EST) <= 0.1 * MED_KMER_FOR_ID_EST;
+        if (getenv("SYLPH_HIP_DEBUG")) {
+            char num[160];
+            snprintf(num, sizeof(num), " --estimate-unknown: running median of the counts above 1 = %.4f (limit %.1f, mean read length %.1f): ",
+                     mov_avg_median, MED_KMER_FOR_ID_EST, S.mean_read_length);
+            info(S.file_name + num + ((mov_avg_median < MED_KMER_FOR_ID_EST && S.mean_read_length < 400.) ? "fixed 99.5% read identity" : "read identity estimated from the table"));
+        }
+        if (near_limit)
             warn(S.file_name + ": the sample's depth is within 10% of the limit that switches --estimate-unknown between the fixed 99.5% read identity and "
                  "the estimated one; that decision depends on the order the table is walked in (ascending k-mers here, hash-map order in "
                  "sylph), so True_cov / Sequence_abundance may differ from `sylph profile -u` for this sample: pass -I to fix the identity");
@@ -944,7 +948,8 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         std::vector<std::promise<Prepared>> promises(n_raw);
         std::vector<std::future<Prepared>> futures;
         for (auto& p : promises) futures.push_back(p.get_future());
-        const size_t n_workers = std::max<size_t>(1, std::min<size_t>(args.threads, n_raw));
+        const size_t n_workers = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(args.threads, MAX_SAMPLE_THREADS), n_raw));
+        set_parse_share((unsigned)n_workers);
         const size_t ahead_limit = n_workers + 2;                        // sessions that may wait, sketched, for the profile stage
         std::vector<IndexAhead::Files> job_files;
         for (const auto& r : read_files) job_files.push_back({r[0], r.size() > 1 ? std::optional<std::string>(r[1]) : std::nullopt});
@@ -1012,6 +1017,16 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         hip_check(sylph_pipeline_create(db, &cfg, &pipe), "sylph_pipeline_create");
         struct PipeGuard { sylph_pipeline* p; ~PipeGuard() { sylph_pipeline_destroy(p); } } pipe_guard{pipe};
         std::vector<std::thread> pool;
+        size_t submitted = 0;
+        struct Unconsumed {   // (declared before PoolJoin: runs after the sample threads are joined) sessions nobody took over
+            std::vector<std::future<Prepared>>& futures; size_t& submitted;
+            ~Unconsumed() {
+                for (size_t j = submitted; j < futures.size(); j++) {
+                    if (!futures[j].valid() || futures[j].wait_for(std::chrono::seconds(0)) != std::future_status::ready) continue;
+                    try { Prepared pr = futures[j].get(); if (pr.session) sylph_sketch_destroy(pr.session); } catch (...) {}
+                }
+            }
+        } unconsumed{futures, submitted};
         struct PoolJoin {   // on every way out: the sample threads stop taking work and are joined
             std::vector<std::thread>& pool; std::atomic<bool>& cancel; std::mutex& mu; std::condition_variable& cv;
             ~PoolJoin() {
@@ -1023,7 +1038,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         for (size_t w = 0; w < n_workers; w++) pool.emplace_back(worker);
         std::vector<std::optional<SequencesSketch>> metas(n_raw);
         std::vector<char> submitted_ok(n_raw, 0);
-        size_t submitted = 0, done = 0;
+        size_t done = 0;
         auto release_one = [&] { { std::lock_guard<std::mutex> lk(gate_mu); released++; } gate_cv.notify_all(); };
         while (done < n_raw) {
             // hand over every prepared sample that is ready, in input order (wait for one only when nothing is outstanding)
@@ -1031,7 +1046,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                 const bool must_wait = sylph_pipeline_outstanding(pipe) == 0 && submitted == done;
                 if (!must_wait && futures[submitted].wait_for(std::chrono::seconds(0)) != std::future_status::ready) break;
                 Prepared pr = futures[submitted].get();
-                if (pr.error) std::rethrow_exception(pr.error);
+                if (pr.error) { if (pr.session) sylph_sketch_destroy(pr.session); submitted++; std::rethrow_exception(pr.error); }
                 metas[submitted] = std::move(pr.meta);
                 if (metas[submitted] && pr.session) {
                     hip_check(sylph_pipeline_submit_session(pipe, pr.session, submitted), "sylph_pipeline_submit_session");

@@ -182,13 +182,17 @@ void PinnedBatch::add(sylph_sketch* sk, const uint8_t* a, uint32_t la, const uin
 }
 
 // ---- block-parallel FASTQ indexing -------------------------------------------------------------------
+namespace { std::atomic<unsigned> g_parse_share{1}; }
+void set_parse_share(unsigned sample_threads) { g_parse_share = std::max(1u, sample_threads); }
 unsigned parse_threads() {
     static const unsigned n = [] {
         if (const char* e = getenv("SYLPH_HIP_PARSE_THREADS")) return (unsigned)std::max(1, atoi(e));
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         return std::min(64u, std::max(std::min(hw, 8u), hw / 4));
     }();
-    return n;
+    // `-t` sample threads index / gather / index-ahead at the same time, each with this many workers: they share the budget
+    // (never below 2 per sample thread), so a large -t on a many-core box does not start thousands of transient threads
+    return std::max(std::min(n, 2u), n / g_parse_share.load());
 }
 
 namespace { std::atomic<size_t> g_index_budget{0}; }

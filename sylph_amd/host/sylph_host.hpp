@@ -112,7 +112,9 @@ struct FastqIndex {
     FastqIndex& operator=(const FastqIndex&) = delete;
     size_t n_records() const { return seq_len.size(); }
 };
-unsigned parse_threads();   // worker threads of the parallel feed: SYLPH_HIP_PARSE_THREADS, else a quarter of the hardware threads (<= 32)
+unsigned parse_threads();   // worker threads of the parallel feed PER sample thread: SYLPH_HIP_PARSE_THREADS, else a quarter of the hardware threads (8..64), divided by set_parse_share
+void set_parse_share(unsigned sample_threads);   // the `-t` sample threads that run a feed each share the parse-thread budget
+constexpr size_t MAX_SAMPLE_THREADS = 16;        // each sample thread owns a GPU context + ~0.5 GB of page-locked batch buffers
 // Bytes a FastqIndex may hold in ANONYMOUS memory (the inflated copy of a blocked-gzip file); 0 = no limit.  The drivers set it
 // from MemAvailable and the number of files they index at the same time: beyond it the file goes to the sequential reader,
 // which runs in constant memory.
