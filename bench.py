@@ -67,7 +67,7 @@ DESCR = {"c3": "1 Gbp synthetic 2x150 bp reads vs GTDB-R220-scale DB (113,104 ge
          "c4": "64 x 1 Gbp samples per 8 GPUs (8 samples per GPU per step) vs GTDB-R220-scale DB sharded over the GPUs (BASELINE configs[3])",
          "c2": "1 Gbp synthetic 2x150 bp reads vs 1,000 synthetic 5 Mbp genomes, k=31 c=200 (BASELINE configs[1])",
          "small": "functional smoke workload (NOT a BASELINE config)",
-         "c5": "ONT-like long reads (N50 10 kb, 5 Gbp, 5 % substitutions) sketched at c=100 vs GTDB-R220-scale DB at c=200 (BASELINE configs[4])"}
+         "c5": "ONT-like long reads (N50 10 kb, 5 Gbp, 5 % errors, substitution:insertion:deletion = 2:1:1) sketched at c=100 vs GTDB-R220-scale DB at c=200 (BASELINE configs[4])"}
 
 
 def log(*a):
@@ -143,7 +143,7 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     v_ids = np.concatenate([np.arange(n_seq), n_seq + vd])
     v_off = np.zeros(len(v_ids) + 1, dtype=np.uint64)
     v_off[1:] = np.cumsum(np.concatenate([np.diff(seq_off), np.diff(doff_h)[vd]]))
-    verify_set = (v_ids, np.concatenate(v_parts), v_off)
+    verify_set = (v_ids, np.concatenate(v_parts), v_off, (seq_k, seq_off))
     kmers = torch.cat([torch.from_numpy(seq_k.view(np.int64)).to(device), dk])
     goff = torch.cat([torch.from_numpy(seq_off).to(device), doff[1:] + int(seq_off[-1])])
     del dk
@@ -166,11 +166,14 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     return db, int(n_total), community, stats, verify_set
 
 
-def cpu_baseline(bases, rec_off, n_pairs, read_len, c, k, db_sample):
-    """Oracle (C++ restatement of the reference CPU path) on a bounded sample, on this box's host cores."""
+def cpu_baseline(bases, rec_off, n_pairs, read_len, c, k, db_host, whole):
+    """Oracle (C++ restatement of the reference CPU path) on this box's host cores.  whole: the WHOLE sample (every read pair on one
+    thread — the reference sketches one sample per thread, sketch.rs:313,371 — and every genome of the database on all threads,
+    contain.rs:284): nothing extrapolated, and the results double as the full-size parity check (verify).  Otherwise a bounded
+    sample, extrapolated (boxes without the host memory for the genome-major database)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    n_s = min(n_pairs, 2_000_000)
+    n_s = n_pairs if whole else min(n_pairs, 2_000_000)
     hb = bases[: n_s * 2 * read_len].cpu().numpy()
     ho = rec_off[: 2 * n_s + 1].cpu().numpy().astype(np.uint64)
     mode = O.MODE_AVX2_FAST if O.lib().orc_has_avx2() else O.MODE_SCALAR
@@ -178,16 +181,19 @@ def cpu_baseline(bases, rec_off, n_pairs, read_len, c, k, db_sample):
     sk = O.sketch_reads(hb, ho, c=c, k=k, mode=mode, paired=True)
     t_sketch = time.perf_counter() - t
     sketch_gbps = n_s * 2 * read_len / t_sketch / 1e9          # one sample = one thread in the reference (sketch.rs:313,371)
-    dbk, dbo = db_sample
+    dbk, dbo = db_host
     ls = O.LoadedSample(sk["kmers"], sk["counts"])
-    _, _, t_probe = ls.probe(dbk, dbo, n_threads=cores)         # genomes in parallel on all cores (contain.rs:284)
+    cc, cov, t_probe = ls.probe(dbk, dbo, n_threads=cores)      # genomes in parallel on all cores (contain.rs:284)
     ls.close()
     G = len(dbo) - 1
-    return dict(sketch_gbp_per_s=sketch_gbps, comparisons_per_s=G / t_probe, sketch_cores=1, probe_cores=cores,
-                sample=f"sketch: first {n_s} read pairs ({n_s * 2 * read_len / 1e6:.0f} Mbp of the 1 Gbp sample) on 1 thread "
-                       f"({'AVX2 intrinsics' if mode == O.MODE_AVX2_FAST else 'scalar'}); "
-                       f"probe: {G} of the 113,104 genomes ({len(dbk) / 1e6:.0f} M k-mers) on {cores} threads vs the {len(sk['kmers'])}-entry "
-                       f"sample table; both rates EXTRAPOLATED linearly to the full workload")
+    what = (f"the WHOLE sample: {n_s} read pairs ({n_s * 2 * read_len / 1e6:.0f} Mbp) sketched on 1 thread in {t_sketch:.2f} s "
+            f"({'AVX2 intrinsics' if mode == O.MODE_AVX2_FAST else 'scalar'}), its {len(sk['kmers'])}-entry table probed against all {G} genomes "
+            f"({len(dbk) / 1e6:.0f} M k-mers) on {cores} threads in {t_probe:.2f} s; nothing extrapolated") if whole else (
+            f"sketch: first {n_s} read pairs ({n_s * 2 * read_len / 1e6:.0f} Mbp of the sample) on 1 thread "
+            f"({'AVX2 intrinsics' if mode == O.MODE_AVX2_FAST else 'scalar'}); probe: {G} of the genomes ({len(dbk) / 1e6:.0f} M k-mers) on {cores} "
+            f"threads vs the {len(sk['kmers'])}-entry sample table; both rates EXTRAPOLATED linearly to the full workload")
+    return dict(sketch_gbp_per_s=sketch_gbps, comparisons_per_s=G / t_probe, sketch_cores=1, probe_cores=cores, sample=what,
+                sketch_s=t_sketch, probe_s=t_probe, table=sk, contain_count=cc, cov=cov, genome_off=dbo)
 
 
 def verify_against_oracle(ctx, res, G, sample_ptrs, verify_set, device):
@@ -197,7 +203,7 @@ def verify_against_oracle(ctx, res, G, sample_ptrs, verify_set, device):
     dk, dc, n = sample_ptrs
     sk = SH.device_view(dk, n, torch.int64, device).cpu().numpy().view(np.uint64)
     sc = SH.device_view(dc, n, torch.int32, device).cpu().numpy().view(np.uint32)
-    v_ids, v_k, v_off = verify_set
+    v_ids, v_k, v_off = verify_set[:3]
     ecc, ecov, _ = O.contain(sk, sc, v_k, v_off, n_threads=min(32, os.cpu_count() or 1))
     cc, off, covs = res
     bad = 0
@@ -241,13 +247,18 @@ def main():
     ap.add_argument("--samples-per-step", type=int, default=0, help="samples per GPU per step (default: sized from --min-seconds)")
     ap.add_argument("--probe-batch", type=int, default=0, help="sample tables per probe launch (default: the workload's; c4: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-bounded", action="store_true", help="time the CPU restatement on a bounded sample (extrapolated) instead of the whole sample")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
     ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 2)")
     ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 2; sharded: two probe batches)")
+    ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the leg of the mode `value` is NOT taken from")
     ap.add_argument("--seed", type=int, default=20250711)
+    ap.add_argument("--sweep", default="", help="tuning runs only: JSON list of pipeline configurations ({name, workers, depth, max_batch, options{}, "
+                                                "pipe_options{}}) measured one after the other on the workload of this run, after the timed region; "
+                                                "results go into the line's `sweep` object (never into `value`)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -363,15 +374,20 @@ def main():
         depth = max(depth, spb)
     sample_no = [0]
 
+    from sylph_amd.binding import ENC_2BIT as _ENC_2BIT, ENC_ASCII as _ENC_ASCII, MEM_DEVICE as _MEM_DEVICE
+    active_sets = [read_sets]                # (the packed-input leg swaps in the 2-bit copies of the same read sets)
+
     def next_read_set():
-        rs = read_sets[sample_no[0] % n_sets]
+        rs = active_sets[0][sample_no[0] % n_sets]
         sample_no[0] += 1
         return rs
+
+    pipe_options = [kv.split("=", 1) for kv in filter(None, os.environ.get("SYLPH_BENCH_PIPE_OPTIONS", "").split(","))]   # tuning experiments only
 
     def make_pipeline():
         p = S.Pipeline(db, c=c_reads, k=k, paired=not long_mode, n_workers=n_workers, depth=depth, max_batch=spb if comm is not None else max(spb, 8),
                        comm=comm)
-        for kv in ctx_options:
+        for kv in ctx_options + pipe_options:
             p.set_option(*kv)
         return p
 
@@ -384,7 +400,7 @@ def main():
         while done < n:
             while sub < n and p.outstanding < depth:
                 rs = next_read_set()
-                if not p.submit_device(rs["batches"], tag=sub):
+                if not p.submit_device(rs["batches"], tag=sub, enc=rs.get("enc", _ENC_ASCII)):
                     raise RuntimeError("pipeline refused a sample below its depth")
                 sub += 1
                 if sub == n and comm is not None:
@@ -400,7 +416,10 @@ def main():
     def sketch_inline(rs):
         sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode)
         for bptr, optr, nrec, nb in rs["batches"]:
-            sk.push_device(bptr, optr, nrec, nb)
+            if rs.get("enc", _ENC_ASCII) == _ENC_ASCII:
+                sk.push_device(bptr, optr, nrec, nb)
+            else:
+                sk.push_enc(bptr, optr, nb, _MEM_DEVICE, rs["enc"], n_records=nrec)
         return sk, sk.finish_device()
 
     def run_sequential(n, stamps=None, rows=None, keep_last=None):
@@ -559,6 +578,42 @@ def main():
         return d
 
     main_leg = leg_summary(mode, sps, args.steps, elapsed, step_s, gaps, rows, fam)
+    # ---- the same samples with the reads resident as the packed 2-bit stream (SYLPH_ENC_2BIT: what the CLI's feed pushes; a
+    # quarter of the bytes, no ASCII -> 2-bit conversion in the seeding kernel).  Reported beside `value`, never instead of it:
+    # SURVEY 8d's 1.085 B/base is the ASCII input.
+    packed_leg = None
+    if not args.no_packed_leg and not long_mode and wl != "c3r" and comm is None:
+        try:
+            packed_sets = []
+            for rs in read_sets:
+                b = rs["bases"][:rs["n_bases"]]
+                pad = (-b.numel()) % 4
+                if pad:
+                    b = torch.cat([b, torch.full((pad,), 65, dtype=torch.uint8, device=device)])
+                cds = (((b >> 1) ^ (b >> 2)) & 3).view(-1, 4)          # ACGT only in these read sets (BYTE_TO_SEQ codes)
+                pk = ((cds[:, 0] << 6) | (cds[:, 1] << 4) | (cds[:, 2] << 2) | cds[:, 3]).contiguous()
+                packed_sets.append(dict(bases=pk, rec_off=rs["rec_off"], n_bases=rs["n_bases"], n_records=rs["n_records"], enc=_ENC_2BIT,
+                                        batches=[(pk.data_ptr(), rs["rec_off"].data_ptr(), rs["n_records"], rs["n_bases"])]))
+                del cds
+            torch.cuda.synchronize()
+            active_sets[0] = packed_sets
+            runners["pipelined"](2 * depth)
+            n_p = max(spb, int(0.5 / max(cal.get("pipelined_ms_per_sample", 1.0) * 1e-3, 1e-6)))
+            e_p, st_p, g_p, r_p, f_p = timed("pipelined", 2, max(1, n_p // 2))
+            leg_p = leg_summary("pipelined", max(1, n_p // 2), 2, e_p, st_p, g_p, r_p, f_p)
+            n_q = max(spb, int(0.2 / max(cal.get("sequential_ms_per_sample", 1.5) * 1e-3, 1e-6)))
+            e_q, st_q, g_q, r_q, f_q = timed("sequential", 1, n_q)
+            leg_q = leg_summary("sequential", n_q, 1, e_q, st_q, g_q, r_q, f_q)
+            packed_leg = {"what": "the same samples with the reads resident in HBM as the packed 2-bit stream (SYLPH_ENC_2BIT, 0.25 B/base in)",
+                          "pipelined": {k_: leg_p[k_] for k_ in ("value", "ms_per_sample", "timed_region_s", "probe_batch_mean", "kernel_ms")},
+                          "one_step_at_a_time": {k_: leg_q[k_] for k_ in ("value", "ms_per_sample", "timed_region_s", "kernel_ms")},
+                          "table_entries_equal_to_ascii": int(np.mean([r[2] for r in r_p])) == int(np.mean([r[2] for r in rows]))}
+        except Exception as e:
+            packed_leg = {"error": str(e)}
+        active_sets[0] = read_sets
+        sample_no[0] = 0
+        packed_sets = None
+
     comparisons = world * n_total                                             # every sample vs every genome of the DB
     parallelism = (f"{world} GPU(s), {mode}: " + (f"{n_workers} sketch worker contexts + 1 profile context per GPU, {depth} samples in flight, <= {max(spb, 8) if comm is None else spb} tables per probe launch" if mode == "pipelined" else f"one context per GPU, {spb} table(s) per probe launch") + "; database " +
                    (f"sharded by k-mer range over {world} GPUs (per probe batch: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
@@ -589,6 +644,7 @@ def main():
         "kernel_ms": main_leg["kernel_ms"],
         **({"exchange": main_leg["exchange"]} if "exchange" in main_leg else {}),
         "setup": dbstats,
+        **({"resident_2bit": packed_leg} if packed_leg is not None else {}),
     }
     legs = {mode: (fam, rows)}
     if second is not None:
@@ -647,15 +703,24 @@ def main():
             batch = len(rws) / pl                                      # tables per launch
             probes = float(np.mean([r[2] for r in rws])) * batch
             hits = float(np.mean([r[4] for r in rws])) * batch
-            alg = probes * (12 + 64) + 8 * hits
+            # SURVEY 8d, inverted-index form: N_s * (8 table in + 16 probe) + 4 * postings hit + 4 * G * S counts out — what
+            # `achieved` / `frac` are quoted on.  The access granule is a whole 64 B index line per probe (and the kernel writes
+            # 8 B per hit): `line_granule` keeps that accounting beside it, it is NOT the roofline figure.
+            alg = probes * 24 + 4 * hits + 4 * n_total * batch
+            granule = probes * (12 + 64) + 8 * hits
             avg = pms / pl
             return {"achieved": round(alg / (avg * 1e-3) / 1e9, 1), "frac": round(alg / (avg * 1e-3) / 1e9 / 8000.0, 4),
-                    "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg, 4), "launches": int(pl),
-                    "tables_per_launch": round(batch, 2), "probes_per_launch": int(probes), "hits_per_launch": int(hits)}
+                    "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes_formula": "N_s*(8+16) + 4*hits + 4*G*S (SURVEY 8d, inverted index)",
+                    "avg_launch_ms": round(avg, 4), "launches": int(pl),
+                    "tables_per_launch": round(batch, 2), "probes_per_launch": int(probes), "hits_per_launch": int(hits),
+                    "line_granule": {"bytes_per_launch": int(granule), "achieved": round(granule / (avg * 1e-3) / 1e9, 1),
+                                     "frac": round(granule / (avg * 1e-3) / 1e9 / 8000.0, 4), "over_algorithmic": round(granule / alg, 2),
+                                     "what": "one 64 B index line + 12 B table entry per probe, 8 B per hit written"}}
         pr = probe_roof(fam, rows)
         per_probe = meta.get("probe_hbm_bytes_per_probe") if (meta_ok and wl in ("c3", "c4", "c3r")) else None
         out["roofline_profile"] = {"bound": "hbm", "kernel": "probe_kernel", "peak": 8000.0, "unit": "GB/s", **pr,
                                    "traffic": int(per_probe * pr["probes_per_launch"]) if per_probe else None,
+                                   "traffic_over_algorithmic": round(per_probe * pr["probes_per_launch"] / max(1, pr["algorithmic_bytes_per_launch"]), 2) if per_probe else None,
                                    "traffic_source": tsrc if per_probe else "none: no PMC figures for these kernel sources",
                                    "note": "random 64 B line reads, latency-bound; one index line per probe is the access granule"}
         if "sequential" in legs and legs["sequential"][0]["probe"][1]:
@@ -670,6 +735,36 @@ def main():
     for sk in last.get("sessions", []):
         sk.close()
     pipe_box[0].close()
+    if args.sweep and comm is None:
+        # tuning: other pipeline shapes / options on the same resident workload, ~0.8 s each, two rounds so that drift shows
+        spec = json.load(open(args.sweep)) if os.path.exists(args.sweep) else json.loads(args.sweep)
+        sweep = []
+        for rnd in range(2):
+            for cfg in spec:
+                w_, d_ = int(cfg.get("workers", 2)), int(cfg.get("depth", 4))
+                p = S.Pipeline(db, c=c_reads, k=k, paired=not long_mode, n_workers=w_, depth=d_, max_batch=int(cfg.get("max_batch", 8)))
+                for k_, v_ in cfg.get("options", {}).items():
+                    p.set_option(k_, str(v_))
+                pipe_box[0] = p
+                depth_saved, depth = depth, d_
+                try:
+                    run_pipelined(3 * d_)
+                    n_s = int(cfg.get("samples", 800))
+                    rows_s = []
+                    torch.cuda.synchronize()
+                    t_s = time.perf_counter()
+                    run_pipelined(n_s, None, rows_s)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t_s) / n_s
+                    rec = {"name": cfg.get("name", "?"), "round": rnd, "ms_per_sample": round(dt * 1e3, 4), "gbp_per_s": round(n_bases / 1e9 / dt, 1),
+                           "probe_batch_mean": round(float(np.mean([r[5] for r in rows_s])), 2)}
+                except Exception as e:
+                    rec = {"name": cfg.get("name", "?"), "round": rnd, "error": str(e)}
+                depth = depth_saved
+                log(f"[sweep] {json.dumps(rec)}")
+                sweep.append(rec)
+                p.close()
+        out["sweep"] = sweep
     # ---- host-fed leg (untimed w.r.t. `value`): the same step with the reads starting in PAGE-LOCKED HOST memory, as ASCII and
     # as the packed 2-bit stream a feed would hand over (sylph_sketch_push_enc cuts the batch into chunks that travel on a copy
     # stream while the previous chunk is sketched): pinned host -> HBM -> sketch -> profile -> results on the host.
@@ -722,16 +817,64 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not long_mode and wl != "c3r":
         try:
             from oracle import oracle as O  # noqa: F401  (cpu_baseline leg only)
-            G_s = min(db.n_genomes, 16000)
-            # bounded DB sample for the CPU probe: the oracle needs the genome-major layout, regenerate decoys of that size
-            dk, doff = synth.decoy_sketches(G_s, c=c, device=device, seed=args.seed + 7)
             rs = read_sets[0]
-            cb = cpu_baseline(rs["bases"], rs["rec_off"], n_pairs, read_len, c, k, (dk.cpu().numpy().view(np.uint64), doff.cpu().numpy().astype(np.uint64)))
+            seq_k, seq_off = verify_set[3]
+            n_decoy = n_total - (len(seq_off) - 1)
+            try:
+                avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+            except Exception:
+                avail = 0
+            need = 8 * dbstats["db_kmers_total"] * 2                      # the genome-major database + the oracle's coverage array
+            whole = avail > need + (16 << 30) and not args.cpu_baseline_bounded
+            G_dec = n_decoy if whole else min(n_decoy, 16000)
+            # the oracle needs the genome-major layout on the host: the sequence-backed sketches are there, the decoys are regenerated
+            if G_dec > 0:
+                dk, doff = synth.decoy_sketches(n_decoy, c=c, device=device, seed=args.seed + 7)
+                doff_h = doff.cpu().numpy().astype(np.uint64)[:G_dec + 1]
+                dk_h = dk[:int(doff_h[-1])].cpu().numpy().view(np.uint64)
+                del dk, doff
+            else:
+                doff_h, dk_h = np.zeros(1, np.uint64), np.zeros(0, np.uint64)
+            if whole:
+                db_host = (np.concatenate([seq_k, dk_h]), np.concatenate([seq_off.astype(np.uint64), doff_h[1:] + np.uint64(seq_off[-1])]))
+            else:
+                db_host = (dk_h, doff_h)
+            del dk_h
+            cb = cpu_baseline(rs["bases"], rs["rec_off"], n_pairs, read_len, c, k, db_host, whole)
             t_cpu = n_bases / 1e9 / cb["sketch_gbp_per_s"] + n_total / cb["comparisons_per_s"]
             out["cpu_baseline"] = {"value": round(n_bases / 1e9 / t_cpu, 4), "unit": "Gbp/s", "cores": cb["probe_cores"], "kind": "port",
                                    "sample": cb["sample"], "sketch_gbp_per_s": round(cb["sketch_gbp_per_s"], 4),
                                    "sketch_cores": 1, "genome_comparisons_per_s": round(cb["comparisons_per_s"], 1),
-                                   "note": "C++ restatement of the reference CPU path (oracle/); the reference sketches one sample on one thread and probes genomes on all threads; value = extrapolation to one whole sample"}
+                                   "sketch_s": round(cb["sketch_s"], 3), "probe_s": round(cb["probe_s"], 3), "extrapolated": not whole,
+                                   "note": "C++ restatement of the reference CPU path (oracle/); the reference sketches one sample on one thread and probes genomes on all threads"}
+            if whole and not args.no_verify:
+                # full-size parity inside the run (untimed): the GPU's table of the SAME read set against the oracle's, then every
+                # genome's containment count and every genome-with-hits' sorted coverage vector against the oracle's probe
+                sk_g, (dk_g, dc_g, nt_g, dup_g) = sketch_inline(rs)
+                gk = SH.device_view(dk_g, nt_g, torch.int64, device).cpu().numpy().view(np.uint64)
+                gc = SH.device_view(dc_g, nt_g, torch.int32, device).cpu().numpy().view(np.uint32)
+                res = db.contain_batch([(dk_g, dc_g, nt_g)], device_ptrs=True)
+                cc_g, off_g, cov_g = (np.array(x) for x in res)
+                sk_g.close()
+                tab = cb["table"]
+                table_ok = bool(np.array_equal(gk, tab["kmers"]) and np.array_equal(gc, tab["counts"]) and int(dup_g) == int(tab["dup_removed"]))
+                ecc, ecov, ego = cb["contain_count"], cb["cov"], cb["genome_off"]
+                bad = int((cc_g[:n_total] != ecc).sum())
+                hit_g = np.nonzero(ecc)[0]
+                for g in hit_g:
+                    got = np.asarray(cov_g[int(off_g[g]):int(off_g[g + 1])]).astype(np.uint32)
+                    exp = np.sort(ecov[int(ego[g]):int(ego[g]) + int(ecc[g])])
+                    if len(got) != len(exp) or not np.array_equal(got, exp):
+                        bad += 1
+                if "verify" in out:
+                    out["verify_subset"] = out["verify"]
+                out["verify"] = {"genomes_checked": int(n_total), "genomes_with_hits": int(len(hit_g)), "hits_checked": int(ecc.sum()),
+                                 "mismatches": int(bad), "sample_table_entries": int(nt_g), "sample_table_equal": table_ok,
+                                 "what": "the whole sample at full size: the GPU's (k-mer, count) table and duplicate count vs the oracle's sketch of the "
+                                         "same 1 Gbp read set; contain_count of EVERY genome of the database and the sorted coverage vector of every "
+                                         "genome with hits vs the oracle's probe of that table"}
+                if not table_ok:
+                    out["verify"]["mismatches"] = int(bad) + 1
         except Exception as e:  # the baseline leg must never sink the GPU measurement
             out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
     sys.stdout.flush()

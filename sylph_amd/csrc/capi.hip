@@ -289,6 +289,29 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 1 && v <= 8, "index_lambda must be in [1, 8]");
             ctx->index_lambda = (uint32_t)v;
+        } else if (!strcmp(key, "cu_mask")) {
+            // "lo:hi" — the context's OWN stream is recreated on the compute units [lo, hi) of the device's CU-mask numbering (the
+            // driver deals consecutive mask bits to the XCDs in turn, so a range of 8 n bits is n CUs on every XCD); "all" undoes it.
+            // An A/B knob for the pipeline (seeding on one part of the chip, the profile stream on the rest): profiles/r04_ab_cu_mask.txt.
+            SY_REQUIRE(ctx->own_stream, "cu_mask: the context runs on a caller-supplied stream");
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            long lo = 0, hi = cus;
+            if (strcmp(value, "all")) {
+                char* end = nullptr;
+                lo = strtol(value, &end, 10);
+                SY_REQUIRE(end && *end == ':', "cu_mask must be lo:hi or all");
+                hi = strtol(end + 1, nullptr, 10);
+            }
+            SY_REQUIRE(lo >= 0 && lo < hi && hi <= cus, "cu_mask range [%ld, %ld) outside the device's %d CUs", lo, hi, cus);
+            DeviceGuard dg(ctx->device);
+            SY_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            for (long i = lo; i < hi; i++) mask[(size_t)i >> 5] |= 1u << (i & 31);
+            hipStream_t ns = nullptr;
+            SY_HIP(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
+            (void)hipStreamDestroy(ctx->stream);
+            ctx->stream = ns;
         } else if (!strcmp(key, "index_pass_max")) {
             const long long v = strtoll(value, nullptr, 10);
             SY_REQUIRE(v >= 1 && v <= (1ll << 31), "index_pass_max must be in [1, 2^31]");

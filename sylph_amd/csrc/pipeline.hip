@@ -17,6 +17,7 @@
 // Results come back in submission order, so nothing the caller sees depends on the interleaving of the threads.
 // With a sharded database (cfg.comm) the batches must be the same on every rank: the profile thread then waits for exactly
 // `max_batch` samples (or sylph_pipeline_flush) and runs the exchange of shard.hip.
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -86,6 +87,10 @@ struct sylph_pipeline {
     uint64_t next_seq = 0;
     uint64_t flush_upto = 0;                     // sharded: jobs with seq < flush_upto may go in a partial batch
     bool stop = false;
+    // tuning (sylph_pipeline_set_option): see the option table in include/sylph_hip.h
+    uint32_t serialize_seeding = 0;              // 1: one worker at a time runs its seeding kernel (the others are in their dedup/count tails)
+    uint32_t min_batch = 1, batch_wait_us = 0;   // the profile thread waits up to batch_wait_us for min_batch ready tables while more are on their way
+    std::mutex seed_mu;
 
     Block* take_block() {                        // mu held
         for (auto& b : blocks)
@@ -105,6 +110,8 @@ struct sylph_pipeline {
             j->worker = w;
             for (size_t i = 0; rc == SYLPH_OK && i < j->batches.size(); i++) {
                 const sylph_read_batch& b = j->batches[i];
+                std::unique_lock<std::mutex> seed_lock(seed_mu, std::defer_lock);
+                if (serialize_seeding) seed_lock.lock();
                 rc = sylph_sketch_push_enc(j->sk, b.bases, b.rec_off, b.n_records, b.n_bases, j->mem, j->enc);
             }
         }
@@ -163,6 +170,20 @@ struct sylph_pipeline {
                 };
                 cv_sketched.wait(lk, [&] { return stop || ready(); });
                 if (!ready()) return;            // stop, and nothing left to do (destroy drains the outstanding samples first)
+                if (!comm && batch_wait_us && batch.size() < std::min(min_batch, max_batch)) {
+                    // a fuller launch is cheaper per table (one probe + one sort + one copy for all of them): wait a little for
+                    // the samples that are still being sketched — never for samples nobody has submitted yet
+                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(batch_wait_us);
+                    auto enough = [&] {
+                        if (stop || !ready()) return true;
+                        if (batch.size() >= std::min(min_batch, max_batch)) return true;
+                        size_t coming = 0;
+                        for (Job* j : order) coming += j->state == JobState::Queued || j->state == JobState::Sketching;
+                        return coming == 0;
+                    };
+                    while (!enough() && cv_sketched.wait_until(lk, deadline) != std::cv_status::timeout) {}
+                    if (!ready()) return;
+                }
                 blk = take_block();
                 blk->users = (uint32_t)batch.size();
             }
@@ -374,7 +395,16 @@ uint32_t sylph_pipeline_outstanding(sylph_pipeline* p) {
 }
 
 int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* value) {
-    if (!p) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (!p || !key || !value) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    {   // the pipeline's own knobs; everything else goes to the workers' contexts
+        uint32_t* dst = !strcmp(key, "serialize_seeding") ? &p->serialize_seeding : !strcmp(key, "min_batch") ? &p->min_batch
+                      : !strcmp(key, "batch_wait_us") ? &p->batch_wait_us : nullptr;
+        if (dst) {
+            std::lock_guard<std::mutex> lk(p->mu);
+            *dst = (uint32_t)strtoul(value, nullptr, 10);
+            return SYLPH_OK;
+        }
+    }
     for (sylph_ctx* cx : p->wctx) {
         const int rc = sylph_ctx_set_option(cx, key, value);
         if (rc != SYLPH_OK) return rc;

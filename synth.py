@@ -223,10 +223,14 @@ def decoy_sketches(n_genomes, c=200, device="cuda", seed=0, mean_len=3.3e6, sigm
 
 
 def long_reads(genomes, total_bases, n50=10_000, sigma=0.8, err=0.05, abundance_sigma=1.0, seed=0, chunk_bases=1 << 28,
-               min_len=500, max_len=200_000):
+               min_len=500, max_len=200_000, indels=True):
     """ONT-like single-end reads: log-normal lengths with the given N50 (length-weighted median = exp(mu + sigma^2); host table),
-    substitution errors only (indels do not change the kernels' work).  Genome / start / strand / errors as in paired_reads
-    (streams 21-24).  -> (bases uint8 [+64 pad], rec_off int64 [n+1])."""
+    `err` errors per emitted base as SURVEY 8d specifies for C5: substitution : insertion : deletion = 2 : 1 : 1 (indels=False:
+    substitutions only, rounds 1-3).  Every emitted base draws one word of stream 23: its high 32 bits < err * 2^32 -> an error, bits
+    33:32 (the lowest two of those) pick its kind (0, 1 substitution; 2 insertion: a random base, the source does not advance; 3 deletion: one source base is
+    skipped before this one is copied), bits 31:30 the random base.  The source offset of a base is the running sum of the advances
+    inside its read; reverse-strand reads walk their source window backwards and are complemented.  Genome / start / strand as in
+    paired_reads (streams 21, 22).  -> (bases uint8 [+64 pad], rec_off int64 [n+1])."""
     device = genomes.device
     n_gen, glen = genomes.shape
     mu = math.log(n50) - sigma * sigma
@@ -243,7 +247,9 @@ def long_reads(genomes, total_bases, n50=10_000, sigma=0.8, err=0.05, abundance_
     r = torch.arange(n, dtype=torch.int64, device=device)
     gid = torch.searchsorted(cum, _u32(sm64(stream(seed, 21), r)) % total_w, right=True).clamp(max=n_gen - 1)
     ws = sm64(stream(seed, 22), r)
-    start = (_u32(ws) * (glen - lens)) >> 32
+    # source window of a read: its length plus room for the deletions it may draw (each skips one source base)
+    win = torch.clamp(lens + (lens >> 3) + 8, max=glen) if indels else lens
+    start = (_u32(ws) * (glen - win)) >> 32
     src0 = gid * glen + start
     flip = (ws & 1) == 1
     comp = torch.zeros(256, dtype=torch.uint8, device=device)
@@ -263,12 +269,25 @@ def long_reads(genomes, total_bases, n50=10_000, sigma=0.8, err=0.05, abundance_
         rel = torch.arange(b1 - b0, device=device)
         rid = torch.repeat_interleave(torch.arange(r0, r1, device=device), lens[r0:r1])
         within = rel - (off[rid] - b0)
-        fwd_idx = src0[rid] + within
-        rev_idx = src0[rid] + (lens[rid] - 1 - within)
+        we = sm64(s_err, rel + b0)
+        is_err = _u32(we) < err_thr
+        if indels:
+            kind = _lsr(we, 32) & 3
+            ins = is_err & (kind == 2)
+            dele = is_err & (kind == 3)
+            adv = 1 - ins.long() + dele.long()                    # source bases consumed by this emitted base
+            cs = torch.cumsum(adv, 0) - adv                       # exclusive, over the chunk (whole reads)
+            within_src = cs - cs[off[rid] - b0] + dele.long()     # offset into the read's source window
+            within_src = torch.minimum(within_src, win[rid] - 1)  # (a read that drew more deletions than its window has room for)
+            random_base = is_err & (kind != 3)                    # substitutions and insertions emit a random base
+        else:
+            within_src = within
+            random_base = is_err
+        fwd_idx = src0[rid] + within_src
+        rev_idx = src0[rid] + (win[rid] - 1 - within_src)
         f = flip[rid]
         bases = flat[torch.where(f, rev_idx, fwd_idx)]
         bases = torch.where(f, comp[bases.long()], bases)
-        we = sm64(s_err, rel + b0)
-        out[b0:b1] = torch.where(_u32(we) < err_thr, lut[(_lsr(we, 30) & 3)], bases)
+        out[b0:b1] = torch.where(random_base, lut[(_lsr(we, 30) & 3)], bases)
         r0 = r1
     return out, off

@@ -127,7 +127,7 @@ def test_ragged_reads_with_n_against_the_oracle(ctx):
 
 
 def test_long_read_sample_in_two_pushes_at_c100_against_a_c200_database(ctx):
-    """BASELINE configs[4] (C5) in small: ONT-like reads (log-normal lengths, N50 10 kb, 5 % substitutions; 1.2 Gbp — the oracle
+    """BASELINE configs[4] (C5) in small: ONT-like reads (log-normal lengths, N50 10 kb, 5 % errors as substitutions : insertions : deletions = 2 : 1 : 1 — SURVEY 8d; 1.2 Gbp — the oracle
     sketches that in seconds) sketched at c = 100 in TWO pushes of whole reads (a push holds < 2^32 bases: the real 5 Gbp sample
     needs two as well; the second push starts at an unaligned device address), through the position kernel (no record fits the
     read-per-lane kernel), compared bit for bit with the oracle; then profiled against a database sketched at c = 200 — reads may

@@ -51,3 +51,52 @@ def test_small_workload_is_reproducible_and_follows_the_documented_rules():
     assert int(doff[-1]) == dk.numel() and int(dk.max()) < (2**64 - 1) // 200 and int(dk.min()) >= 0
     lb, lo = synth.long_reads(g, 300_000, seed=9)
     assert int(lo[-1]) >= 300_000 and lb.numel() == int(lo[-1]) + 64
+
+
+def test_long_reads_indels_event_by_event():
+    """C5's error model (5 % errors, substitution : insertion : deletion = 2 : 1 : 1): a few reads of the generator
+    replayed base by base from the words of the error stream — plain Python, no tensors — and the error mix of a whole set."""
+    import math
+    dev = torch.device("cpu")
+    seed = 9
+    g = synth.random_genomes(3, 200_000, dev, 3, mutated_frac=0.0)
+    glen = g.shape[1]
+    b, o = synth.long_reads(g, 300_000, seed=seed)
+    b, o = b.numpy(), o.numpy()
+    n = len(o) - 1
+    flat = g.reshape(-1).numpy()
+    cum = np.cumsum(synth.abundance_weights(3, seed, 1.0))
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    mask = (1 << 64) - 1
+    word = lambda st, i: synth.mix_int(st + (i + 1) * 0x9E3779B97F4A7C15)   # noqa: E731
+    s21, s22, s23 = synth.stream(seed, 21), synth.stream(seed, 22), synth.stream(seed, 23)
+    err_thr = int(0.05 * (1 << 32))
+    kinds = [0, 0, 0]
+    for r in list(range(4)) + [n - 1]:
+        L = int(o[r + 1] - o[r])
+        gid = min(int(np.searchsorted(cum, (word(s21, r) >> 32) % int(cum[-1]), side="right")), 2)
+        ws = word(s22, r)
+        win = min(L + (L >> 3) + 8, glen)
+        start = ((ws >> 32) * (glen - win)) >> 32
+        flip = ws & 1
+        p = 0
+        for j in range(L):
+            we = word(s23, int(o[r]) + j) & mask
+            is_err = (we >> 32) < err_thr
+            kind = (we >> 32) & 3
+            rnd = (65, 67, 71, 84)[(we >> 30) & 3]
+            if is_err and kind == 3:
+                p += 1
+            q = min(p, win - 1)
+            src = flat[gid * glen + start + (win - 1 - q if flip else q)]
+            src = comp[int(src)] if flip else int(src)
+            exp = rnd if (is_err and kind != 3) else src
+            assert int(b[int(o[r]) + j]) == exp, (r, j)
+            if not (is_err and kind == 2):
+                p += 1
+            if is_err:
+                kinds[0 if kind < 2 else kind - 1] += 1
+    tot = sum(kinds)
+    assert tot > 100 and abs(kinds[0] / tot - 0.5) < 0.1 and abs(kinds[1] / tot - 0.25) < 0.08 and abs(kinds[2] / tot - 0.25) < 0.08
+    assert abs(tot / sum(int(o[r + 1] - o[r]) for r in list(range(4)) + [n - 1]) - 0.05) < 0.01
+    assert math.isclose(float(np.mean(np.isin(b[:int(o[-1])], [65, 67, 71, 84]))), 1.0)
