@@ -27,6 +27,12 @@ void hip_check(int rc, const char* what) {
 }
 void warn(const std::string& m) { fprintf(stderr, "WARN  [sylph_hip] %s\n", m.c_str()); }
 void info(const std::string& m) { fprintf(stderr, "INFO  [sylph_hip] %s\n", m.c_str()); }
+}  // namespace
+bool exact_dedup_accepted(bool flag) {
+    const char* e = getenv("SYLPH_HIP_EXACT_DEDUP");
+    return flag || (e && *e && strcmp(e, "0") != 0);
+}
+namespace {
 
 template <class T>
 std::vector<T> take(T* p, uint64_t n) {
@@ -571,10 +577,15 @@ int sketch(Engine& e, const SketchArgs& args) {
     else if (args.sample_names) sample_names = args.sample_names;
     if (sample_names && sample_names->size() != first_pairs.size() + read_inputs.size())
         throw Error{1, "Sample name length is not equal to the number of reads. Exiting"};   // :288-292
-    if (args.fpr != 0. && !first_pairs.empty())   // a10 (sketch.rs:733-769, default cmdline.rs:77) is not built: say so, once
-        warn("paired-end deduplication uses the EXACT marker set (sylph's `--fpr 0` path, sketch.rs:690-731), not the reference's "
-             "default approximate cuckoo filter (--fpr " + std::to_string(args.fpr) + "): counts can differ from `sylph sketch -1 -2` "
-             "by the filter's false positives; pass --fpr 0 to both tools for identical sketches");
+    // a10 (sketch.rs:733-769, default --fpr 1e-4 cmdline.rs:77) is not built: the only dedup structure on the GPU is the EXACT marker
+    // set (sylph's `--fpr 0` path, sketch.rs:690-731).  A run whose reference semantics would be the cuckoo filter is refused unless
+    // the caller accepts the exact set — silently computing something else under the reference's default flags is not a drop-in.
+    // (--no-dedup never consults the filter: sketch.rs:744.)
+    if (args.fpr != 0. && !first_pairs.empty() && !args.no_dedup && !exact_dedup_accepted(args.exact_dedup))
+        throw Error{1, "paired-end reads with --fpr " + std::to_string(args.fpr) + ": sylph deduplicates them with an approximate cuckoo filter "
+                       "(scalable_cuckoo_filter 0.2.4), which this build does not have — it has the EXACT marker set of `--fpr 0`. "
+                       "Pass --fpr 0 or --exact-dedup (or set SYLPH_HIP_EXACT_DEDUP=1) to accept exact deduplication: identical to "
+                       "`sylph sketch --fpr 0`, about 2e-5 of the k-mer occurrences counted differently from sylph's default"};
 
     // Samples are independent (sketch.rs:313,371 runs them on the rayon pool, `-t`): a pool of `-t` worker threads, each with
     // its own GPU context (calls on one context are serialised) and its own page-locked batch, takes them in input order.
@@ -999,9 +1010,11 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         for (const auto& r : read_files)
             if (r.size() > 1 && !warned_pairs) {
                 warned_pairs = true;
-                // contain.rs:591 forces the cuckoo default (fpr 1e-4) for raw pairs; here: the exact set
-                warn("raw paired reads are deduplicated with the EXACT marker set (`--fpr 0` semantics), not the approximate cuckoo "
-                     "filter `sylph profile -1 -2` uses (contain.rs:591): results match `sylph sketch --fpr 0` followed by profile");
+                // contain.rs:591 forces the cuckoo default (fpr 1e-4) for raw pairs; here there is only the exact set: refuse unless accepted
+                if (!exact_dedup_accepted(args.exact_dedup))
+                    throw Error{1, "raw paired reads: sylph deduplicates them with its approximate cuckoo filter (contain.rs:591), which this build "
+                                   "does not have. Pass --exact-dedup (or set SYLPH_HIP_EXACT_DEDUP=1) to accept the exact marker set: results then "
+                                   "equal `sylph sketch --fpr 0` followed by profile / query on the sketches"};
             }
         sylph_pipeline* pipe = nullptr;
         sylph_pipeline_config cfg;

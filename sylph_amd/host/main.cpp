@@ -53,6 +53,7 @@ int run_sketch(Argv a) {
         else if (t == "--disable-profiling") { s.no_pseudotax = true; a.i++; }
         else if (t == "--min-spacing") s.min_spacing_kmer = strtoull(a.one().c_str(), nullptr, 10);
         else if (t == "--fpr") s.fpr = atof(a.one().c_str());
+        else if (t == "--exact-dedup") { s.exact_dedup = true; a.i++; }
         else if (t == "-1" || t == "--first-pairs") append(s.first_pair, a.multi());
         else if (t == "-2" || t == "--second-pairs") append(s.second_pair, a.multi());
         else if (t == "--debug" || t == "--trace") a.i++;
@@ -88,6 +89,7 @@ int run_contain(Argv a, bool profile) {
         else if (t == "--no-adjust") { c.no_adj = true; a.i++; }
         else if (t == "--mean-coverage") { c.mean_coverage = true; a.i++; }
         else if (t == "--debug-f64") { c.debug_f64 = true; a.i++; }
+        else if (t == "--exact-dedup") { c.exact_dedup = true; a.i++; }
         else if (t == "--debug" || t == "--trace" || t == "--log-reassignments") a.i++;
         else if (t[0] == '-' && t.size() > 1) throw Error{2, "unknown option " + t};
         else { c.files.push_back(t); a.i++; }

@@ -18,8 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "sylph_amd", "sylph-hip")
 
 
-def run(*args, check=True):
-    p = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+def run(*args, check=True, accept_exact=True):
+    # the reference's own integration assertions use default flags on pairs: this build only has the exact marker set and refuses
+    # such runs unless that is accepted (--exact-dedup / SYLPH_HIP_EXACT_DEDUP=1; test_paired_default_fpr_is_refused... below)
+    env = dict(os.environ)
+    env.pop("SYLPH_HIP_EXACT_DEDUP", None)
+    if accept_exact:
+        env["SYLPH_HIP_EXACT_DEDUP"] = "1"
+    p = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
     if check:
         assert p.returncode == 0, p.stderr[-3000:]
     return p
@@ -382,13 +388,24 @@ def test_estimate_unknown_columns_vs_independent_restatement(data):
     assert with_u != plain                                # the option changes the coverage and abundance columns
 
 
-def test_paired_default_fpr_warns_about_exact_semantics(data):
-    """a10 (cuckoo-filter dedup, sketch.rs:733-769, default for pairs cmdline.rs:77) is not built: the command must say so."""
+def test_paired_default_fpr_is_refused_unless_exact_dedup_is_accepted(data):
+    """a10 (cuckoo-filter dedup, sketch.rs:733-769, default for pairs cmdline.rs:77, forced for raw pairs in profile contain.rs:591)
+    is not built: a run whose reference semantics would be that filter exits 1 with a message naming the ways to accept the exact
+    marker set; --exact-dedup, SYLPH_HIP_EXACT_DEDUP=1 and --fpr 0 all give the same bytes; --no-dedup never consults the filter."""
     d = data["dir"]
-    p = run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w1")
-    assert "EXACT marker set" in p.stderr and "--fpr 0" in p.stderr
-    q = run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w2", "--fpr", "0")
-    assert "EXACT marker set" not in q.stderr
+    p = run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w1", check=False, accept_exact=False)
+    assert p.returncode == 1 and "EXACT marker set" in p.stderr and "--exact-dedup" in p.stderr and "--fpr 0" in p.stderr
+    assert not (d / "w1" / "s_1.fq.paired.sylsp").exists()
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w2", "--fpr", "0", accept_exact=False)
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w3", "--exact-dedup", accept_exact=False)
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w4")                       # SYLPH_HIP_EXACT_DEDUP=1
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w5", "--no-dedup", accept_exact=False)
+    ref = (d / "w2" / "s_1.fq.paired.sylsp").read_bytes()
+    assert (d / "w3" / "s_1.fq.paired.sylsp").read_bytes() == ref and (d / "w4" / "s_1.fq.paired.sylsp").read_bytes() == ref
+    g = data["genomes"]
+    q = run("profile", g["K12"][0], "-1", d / "s_1.fq", "-2", d / "s_2.fq", check=False, accept_exact=False)
+    assert q.returncode == 1 and "--exact-dedup" in q.stderr
+    run("profile", g["K12"][0], "-1", d / "s_1.fq", "-2", d / "s_2.fq", "--exact-dedup", accept_exact=False)
 
 
 def test_parallel_feed_equals_sequential_feed(data):
