@@ -251,8 +251,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
-    ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 2)")
-    ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 2; sharded: two probe batches)")
+    ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 3)")
+    ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 3; sharded: two probe batches)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the leg of the mode `value` is NOT taken from")
     ap.add_argument("--seed", type=int, default=20250711)
@@ -368,8 +368,8 @@ def main():
     log(f"[bench] db {dbstats}; {n_sets} read sets of {n_bases / 1e9:.3f} Gbp generated in {time.time() - t0:.1f}s")
 
     # ---- the two ways of running samples ------------------------------------------------------------------------------------
-    n_workers = max(1, args.sketch_workers or 2)
-    depth = max(1, args.pipeline_depth or (2 * spb if comm is not None else max(n_workers + 2, spb + n_workers)))
+    n_workers = max(1, args.sketch_workers or 3)
+    depth = max(1, args.pipeline_depth or (2 * spb if comm is not None else max(n_workers + 3, spb + n_workers)))
     if comm is not None:
         depth = max(depth, spb)
     sample_no = [0]
@@ -607,7 +607,13 @@ def main():
             packed_leg = {"what": "the same samples with the reads resident in HBM as the packed 2-bit stream (SYLPH_ENC_2BIT, 0.25 B/base in)",
                           "pipelined": {k_: leg_p[k_] for k_ in ("value", "ms_per_sample", "timed_region_s", "probe_batch_mean", "kernel_ms")},
                           "one_step_at_a_time": {k_: leg_q[k_] for k_ in ("value", "ms_per_sample", "timed_region_s", "kernel_ms")},
-                          "table_entries_equal_to_ascii": int(np.mean([r[2] for r in r_p])) == int(np.mean([r[2] for r in rows]))}
+                          "table_equal_to_ascii": None}
+            # the packed stream must give the very table the ASCII bytes give (first read set, both encodings, compared on the device)
+            sk_a, (ka, ca, na, da) = sketch_inline(read_sets[0])
+            sk_b, (kb, cb_, nb_, db_) = sketch_inline(packed_sets[0])
+            packed_leg["table_equal_to_ascii"] = bool(na == nb_ and da == db_ and torch.equal(SH.device_view(ka, na, torch.int64, device), SH.device_view(kb, nb_, torch.int64, device))
+                                                      and torch.equal(SH.device_view(ca, na, torch.int32, device), SH.device_view(cb_, nb_, torch.int32, device)))
+            sk_a.close(); sk_b.close()
         except Exception as e:
             packed_leg = {"error": str(e)}
         active_sets[0] = read_sets

@@ -73,13 +73,15 @@ int sylph_ctx_synchronize(sylph_ctx *ctx);
  * position kernel with per-tile ordered slots otherwise), "slots" (always the position kernel with ordered slots) or
  * "unordered" (position kernel with LDS-staged atomics + radix sort by position).  "bucket_target" = mean number of
  * occurrences per replay bucket aimed for, "16".."256".  "index_lambda" = postings per 64-byte bucket line of a database
- * index aimed for ("1".."8", default 3; applies to databases uploaded afterwards), "index_pass_max" = postings sorted per pass
+ * index aimed for ("1".."8", default 4 — 29 GB at GTDB-R220 scale, 3 was 38.5 GB for 3 % less probe time; applies to databases uploaded afterwards), "index_pass_max" = postings sorted per pass
  * of the index build (tests lower it to force several passes), "push_chunk_bytes" = bytes of bases per chunk of a host batch
  * (default 64 MiB), "reads_wg_per_cu" = workgroups of the read-per-lane kernel per CU, each looping over blocks of reads
  * ("0".."64"; default 0 = one workgroup per block, measured 10 % faster than 8 looping workgroups per CU).
  * "plain_records" = "1" (default) / "0": single-end batches whose records carry no dedup marker (reads above 400 bases, or a
  * --no-dedup session) keep only the hashes of their seed occurrences and are counted without occurrence records; "0" writes
  * the records for every batch (A/B and tests: the tables are identical).
+ * "cu_mask" = "lo:hi" / "all": the context's OWN stream is recreated on the compute units [lo, hi) of the device's CU-mask numbering
+ * (A/B knob; restricting the sketch workers' streams lost 25-40 % in r04: profiles/r04_ab_pipeline_sweep.txt).
  * "fail_next_shard_probe" = "1": fault injection for the tests — the next sylph_db_contain_batch_sharded on this context fails
  * in its probe, between the collectives (every rank of the batch must then return the same error, nobody may hang). */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
@@ -312,8 +314,8 @@ typedef struct sylph_read_batch {   /* the arguments of sylph_sketch_push_enc */
 } sylph_read_batch;
 typedef struct sylph_pipeline_config {
     uint32_t struct_size;     /* sizeof(sylph_pipeline_config) */
-    uint32_t n_workers;       /* sketch threads / contexts; 0 = default (2) */
-    uint32_t depth;           /* samples that may be outstanding (submitted, not yet returned by sylph_pipeline_next); 0 = n_workers + 2 */
+    uint32_t n_workers;       /* sketch threads / contexts; 0 = default (3) */
+    uint32_t depth;           /* samples that may be outstanding (submitted, not yet returned by sylph_pipeline_next); 0 = n_workers + 3 */
     uint32_t max_batch;       /* sample tables per probe launch at most (<= 64); 0 = default (8) */
     uint32_t c, k;            /* sylph_sketch_begin's arguments for the samples submitted as batches */
     int reads_mode, no_dedup, seed_mode;
@@ -346,8 +348,13 @@ int sylph_pipeline_flush(sylph_pipeline *p);
  * sylph_pipeline_destroy on this pipeline (the sample's session and its share of the result block are released then). */
 int sylph_pipeline_next(sylph_pipeline *p, sylph_pipeline_result *out);
 uint32_t sylph_pipeline_outstanding(sylph_pipeline *p);
-/* sylph_ctx_set_option on every worker context; sylph_ctx_profile / sylph_ctx_kernel_stats summed over the workers' and the
- * database's contexts. */
+/* The pipeline's own knobs — "serialize_seeding" (default 1: one worker at a time runs its seeding kernel, the others are in
+ * their dedup/count tails; two VALU-bound seeding kernels side by side only slow each other, +3 % in r04), "min_batch" +
+ * "batch_wait_us" (default 1 / 0: the profile thread waits up to batch_wait_us for min_batch ready tables while more samples are
+ * being sketched; unsharded pipelines only) — else sylph_ctx_set_option on every worker context.  sylph_ctx_profile /
+ * sylph_ctx_kernel_stats summed over the workers' and the database's contexts.
+ * sylph_pipeline_next on a sharded pipeline returns SYLPH_ERR_STATE instead of blocking when fewer than max_batch samples are
+ * outstanding and sylph_pipeline_flush has not covered the oldest one (nobody would ever wake the call). */
 int sylph_pipeline_set_option(sylph_pipeline *p, const char *key, const char *value);
 int sylph_pipeline_profile(sylph_pipeline *p, int enable);
 int sylph_pipeline_kernel_stats(sylph_pipeline *p, const char *family, double *total_ms, uint64_t *launches);

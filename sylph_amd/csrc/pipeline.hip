@@ -70,7 +70,7 @@ struct Job {
 struct sylph_pipeline {
     sylph_db* db = nullptr;
     sylph_comm* comm = nullptr;
-    uint32_t n_workers = 2, depth = 4, max_batch = 8;
+    uint32_t n_workers = 3, depth = 6, max_batch = 8;
     uint32_t c = 200, k = 31;
     int reads_mode = SYLPH_READS_PAIRED, no_dedup = 0, seed_mode = SYLPH_SEED_AVX2_COMPAT, want_table = 0;
     double min_number_kmers = 0;
@@ -88,7 +88,8 @@ struct sylph_pipeline {
     uint64_t flush_upto = 0;                     // sharded: jobs with seq < flush_upto may go in a partial batch
     bool stop = false;
     // tuning (sylph_pipeline_set_option): see the option table in include/sylph_hip.h
-    uint32_t serialize_seeding = 0;              // 1: one worker at a time runs its seeding kernel (the others are in their dedup/count tails)
+    uint32_t serialize_seeding = 1;              // 1 (default, r04: +3 %, profiles/r04_ab_pipeline_sweep.txt): one worker at a time runs its seeding kernel —
+                                                 // two VALU-bound seeding kernels side by side only slow each other; the others are in their dedup/count tails
     uint32_t min_batch = 1, batch_wait_us = 0;   // the profile thread waits up to batch_wait_us for min_batch ready tables while more are on their way
     std::mutex seed_mu;
 
@@ -294,9 +295,9 @@ int sylph_pipeline_create(sylph_db* db, const sylph_pipeline_config* cfg, sylph_
         std::unique_ptr<sylph_pipeline> p(new sylph_pipeline());
         p->db = db;
         p->comm = cfg->comm;
-        p->n_workers = cfg->n_workers ? cfg->n_workers : 2;
+        p->n_workers = cfg->n_workers ? cfg->n_workers : 3;
         p->max_batch = cfg->max_batch ? cfg->max_batch : 8;
-        p->depth = cfg->depth ? cfg->depth : p->n_workers + 2;
+        p->depth = cfg->depth ? cfg->depth : p->n_workers + 3;
         SY_REQUIRE(!p->comm || p->depth >= p->max_batch, "sharded: depth (%u) must reach max_batch (%u), the fixed batch of the exchange", p->depth, p->max_batch);
         p->c = cfg->c; p->k = cfg->k;
         p->reads_mode = cfg->reads_mode; p->no_dedup = cfg->no_dedup; p->seed_mode = cfg->seed_mode; p->want_table = cfg->want_table;
