@@ -415,6 +415,8 @@ def main():
 
     def sketch_inline(rs):
         sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode)
+        if len(rs["batches"]) == 1:
+            sk.set_option("borrow_until_finish", 1)     # the resident read sets outlive every session
         for bptr, optr, nrec, nb in rs["batches"]:
             if rs.get("enc", _ENC_ASCII) == _ENC_ASCII:
                 sk.push_device(bptr, optr, nrec, nb)
@@ -531,7 +533,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = agree(time.perf_counter() - t_start)
         fam = {}
-        for f in ("seeds", "compact", "annotate", "sort", "replay", "probe", "exchange"):   # HIP events on the launch streams, all contexts
+        for f in ("seeds", "compact", "annotate", "sort", "replay", "probe", "assemble", "exchange"):   # HIP events on the launch streams, all contexts
             fam[f] = profiled[0].kernel_stats(f) if not args.no_kernel_timers else (0.0, 0)
         if comm is not None:
             fam["_exchange_totals"] = db.exchange_stats()

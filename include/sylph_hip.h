@@ -174,6 +174,14 @@ int sylph_sketch_finish(sylph_sketch *sk, uint64_t **out_kmers, uint32_t **out_c
 int sylph_sketch_finish_device(sylph_sketch *sk, const uint64_t **dev_kmers, const uint32_t **dev_counts,
                                uint64_t *out_n, uint64_t *out_dup_removed);
 void sylph_sketch_destroy(sylph_sketch *sk);
+/* Session options.  "borrow_until_finish" = "1": the caller promises that the SYLPH_MEM_DEVICE batches it pushes stay valid and
+ * unchanged until sylph_sketch_finish[_device] has returned (the reference's &[u8] borrow, stretched from the push to the finish).
+ * The session's first short-read batch then leaves without a host round trip — the seeding kernel's verdict (a record too long
+ * for it, a block of reads that overflowed its slots, the number of seed occurrences) is read together with the finish's own
+ * tail block, and a bad verdict re-runs the batch the checked way from the borrowed memory.  Results are identical; one
+ * synchronisation per sample instead of two.  sylph_pipeline_submit sets it for its device batches (their memory is borrowed
+ * until sylph_pipeline_next has returned the sample anyway). */
+int sylph_sketch_set_option(sylph_sketch *sk, const char *key, const char *value);
 
 /* ---- containment (sample vs every genome of a resident DB shard) ----------------------------------------- */
 

@@ -49,6 +49,8 @@ extern "C" {
     pub fn sylph_sketch_finish(sk: *mut SylphSketch, out_kmers: *mut *mut u64, out_counts: *mut *mut u32,
                                out_n: *mut u64, out_dup_removed: *mut u64) -> c_int;
     pub fn sylph_sketch_destroy(sk: *mut SylphSketch);
+    // "borrow_until_finish" = "1": device batches stay valid until finish -> one host round trip per sample instead of two
+    pub fn sylph_sketch_set_option(sk: *mut SylphSketch, key: *const c_char, value: *const c_char) -> c_int;
     // replace the probe half of get_stats (contain.rs:601-656) for all genomes of a loaded database
     pub fn sylph_db_upload(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,
                            out: *mut *mut SylphDb) -> c_int;

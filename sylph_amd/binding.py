@@ -32,7 +32,7 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_comm_create_rccl", "sylph_comm_create", "sylph_comm_destroy", "sylph_db_contain_batch_sharded",
            "sylph_pipeline_create", "sylph_pipeline_submit", "sylph_pipeline_submit_session", "sylph_pipeline_flush", "sylph_pipeline_next",
            "sylph_pipeline_outstanding", "sylph_pipeline_set_option", "sylph_pipeline_profile", "sylph_pipeline_kernel_stats",
-           "sylph_pipeline_destroy", "sylph_db_exchange_stats"]
+           "sylph_pipeline_destroy", "sylph_db_exchange_stats", "sylph_sketch_set_option"]
 
 
 def load():
@@ -255,6 +255,10 @@ class ReadSketcher:
         self._h = C.c_void_p()
         _check(load().sylph_sketch_begin(ctx._h, c, k, READS_PAIRED if paired else READS_SINGLE, int(no_dedup), seed_mode,
                                          C.byref(self._h)))
+
+    def set_option(self, key, value):
+        """sylph_sketch_set_option ("borrow_until_finish": device batches stay valid until finish)"""
+        _check(load().sylph_sketch_set_option(self._h, key.encode(), str(value).encode()))
 
     def push(self, bases, rec_off):
         a, off = _bases(bases), _np(rec_off, np.uint64)

@@ -608,7 +608,8 @@ static uint32_t probe_grid() {
     return std::max<uint32_t>(1, g);
 }
 
-uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint32_t* max_count) {
+// common front of the two probe entry points: chunk numbering, limits, descriptors; returns the number of chunks (0: nothing to do)
+static uint64_t probe_prepare(sylph_db* db, std::vector<SampleRef>& refs, uint64_t* total_out, RefPack* pack, uint64_t* ilp_out) {
     sylph_ctx* ctx = db->ctx;
     const uint64_t G = db->n_genomes;
     uint64_t total = 0, chunks = 0;
@@ -624,35 +625,51 @@ uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_numb
     }
     SY_REQUIRE(chunks < (1ull << 32) && total < (1ull << 32), "batch holds more than 2^32-1 k-mers: split it");
     SY_REQUIRE((uint64_t)refs.size() * std::max<uint64_t>(G, 1) < (1ull << 32) - 1, "samples x genomes must stay below 2^32: split the batch");
-    *max_count = 0;
+    *total_out = total;
+    *ilp_out = ilp;
     if (!total || !db->kept.n_postings) return 0;
-    RefPack pack{};
     if (refs.size() <= REFS_INLINE) {
-        for (size_t i = 0; i < refs.size(); i++) pack.r[i] = refs[i];
+        for (size_t i = 0; i < refs.size(); i++) pack->r[i] = refs[i];
     } else {
         db->q_refs.reserve(refs.size() * sizeof(SampleRef));
         ctx->h2d(db->q_refs.p, refs.data(), refs.size() * sizeof(SampleRef));
     }
-    uint64_t cap = std::max<uint64_t>(total * 2, 1u << 20);
+    return chunks;
+}
+
+static void probe_launch(sylph_db* db, const std::vector<SampleRef>& refs, const RefPack& pack, uint64_t chunks, uint64_t ilp, double min_number_kmers,
+                         uint64_t cap) {
+    sylph_ctx* ctx = db->ctx;
+    const uint64_t G = db->n_genomes;
     uint32_t* d_cnt = db->counter.as<uint32_t>();   // [0] = number of hits, [1] = largest count among the hits
     const int check_len = (double)db->min_glen < min_number_kmers;
-    uint32_t n_hits = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one batch: split it");
-        db->hits.reserve(cap * 8);
-        SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-        {
-            ScopedKernelTimer t(ctx, "probe");
+    SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one batch: split it");
+    db->hits.reserve(cap * 8);
+    if (db->cnt_dirty) SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));   // (the row assembly leaves the counter zeroed: hits.hip)
+    db->cnt_dirty = true;
+    ScopedKernelTimer t(ctx, "probe");
 #define SY_LAUNCH_PROBE(I)                                                                                                                   \
     hipLaunchKernelGGL(probe_kernel<I>, dim3(std::min<uint32_t>((uint32_t)chunks, probe_grid())), dim3(PROBE_TPB), 0, ctx->stream,            \
                        db->q_refs.as<SampleRef>(), pack, (uint32_t)refs.size(), (uint32_t)chunks, db->kept.view(), (uint32_t)G,               \
                        db->glen.as<uint32_t>(), min_number_kmers, check_len, db->hits.as<uint64_t>(), (uint32_t)cap, d_cnt)
-            if (ilp == 4) SY_LAUNCH_PROBE(4); else if (ilp == 2) SY_LAUNCH_PROBE(2); else SY_LAUNCH_PROBE(1);
+    if (ilp == 4) SY_LAUNCH_PROBE(4); else if (ilp == 2) SY_LAUNCH_PROBE(2); else SY_LAUNCH_PROBE(1);
 #undef SY_LAUNCH_PROBE
-            SY_HIP(hipGetLastError());
-        }
+    SY_HIP(hipGetLastError());
+}
+
+uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint32_t* max_count) {
+    sylph_ctx* ctx = db->ctx;
+    uint64_t total = 0, ilp = 2;
+    RefPack pack{};
+    const uint64_t chunks = probe_prepare(db, refs, &total, &pack, &ilp);
+    *max_count = 0;
+    if (!chunks) return 0;
+    uint64_t cap = std::max<uint64_t>(total * 2, 1u << 20);
+    uint32_t n_hits = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        probe_launch(db, refs, pack, chunks, ilp, min_number_kmers, cap);
         uint32_t hc[2] = {0, 0};
-        ctx->read_back(hc, d_cnt, 8);
+        ctx->read_back(hc, db->counter.p, 8);
         n_hits = hc[0];
         *max_count = hc[1];
         if (n_hits <= cap) break;
@@ -662,9 +679,23 @@ uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_numb
     return n_hits;
 }
 
+bool probe_batch_async(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint64_t want_cap, uint64_t* cap) {
+    sylph_ctx* ctx = db->ctx;
+    uint64_t total = 0, ilp = 2;
+    RefPack pack{};
+    const uint64_t chunks = probe_prepare(db, refs, &total, &pack, &ilp);
+    if (!chunks) return false;
+    *cap = std::max<uint64_t>(std::max<uint64_t>(total * 2, 1u << 20), want_cap);
+    probe_launch(db, refs, pack, chunks, ilp, min_number_kmers, *cap);
+    if (!db->ev_cnt) SY_HIP(hipEventCreateWithFlags(&db->ev_cnt, hipEventDisableTiming));
+    SY_HIP(hipMemcpyAsync((char*)ctx->pinned + 256, db->counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipEventRecord(db->ev_cnt, ctx->stream));
+    return true;
+}
+
 // cov_width: nullptr = coverage values as u32; else in/out — the values are stored with the narrowest of 1, 2 or 4 bytes
 // that holds the batch's largest count (7.4 MB -> 1.9 MB over PCIe per sample at GTDB scale) and the width is returned.
-void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost, HostBlock* dst) {
+static void finish_hits_sorted(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost, HostBlock* dst) {
     sylph_ctx* ctx = db->ctx;
     const uint64_t G = db->n_genomes;
     SY_REQUIRE(n_rows < (1ull << 32) - 1, "too many result rows");
@@ -711,6 +742,93 @@ void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_r
     if (cov_width) *cov_width = width;
     SY_HIP(hipStreamSynchronize(ctx->stream));
     if (!ctx->pending.empty()) profile_collect(ctx);
+}
+
+// width of the coverage values the row assembly stores (hits.hip applies the same rule to the same word on the device)
+static uint32_t narrow_width(bool want_narrow, uint32_t max_count) { return !want_narrow ? 4u : max_count < 256u ? 1u : max_count < 65536u ? 2u : 4u; }
+
+// copies the assembled block out (one copy; + kmers_lost) and waits for it
+static void copy_out_rows(sylph_db* db, uint32_t n_hits, uint32_t width, uint64_t n_rows, bool with_lost, HostBlock* dst) {
+    sylph_ctx* ctx = db->ctx;
+    const uint64_t G = db->n_genomes;
+    const ResultLayout lay(n_rows, n_hits, width, with_lost ? G : 0);
+    if (!dst) { db->lay = lay; db->last_rows = n_rows; dst = &db->h_block; }
+    dst->ensure(lay.end + 64);
+    dst->lay = lay;
+    char* h = (char*)dst->p;
+    SY_HIP(hipMemcpyAsync(h, db->res.p, lay.covs + (size_t)n_hits * width, hipMemcpyDeviceToHost, ctx->stream));
+    if (with_lost && G) SY_HIP(hipMemcpyAsync(h + lay.lost, db->lost.p, G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SY_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->pending.empty()) profile_collect(ctx);
+}
+
+// Host-known hit count (the reassignment pass, the sharded exchange): row assembly when the values fit its histogram, else the
+// sorted path.
+void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost, HostBlock* dst) {
+    sylph_ctx* ctx = db->ctx;
+    SY_REQUIRE(n_rows < (1ull << 32) - 1, "too many result rows");
+    static const bool force_sorted = getenv("SYLPH_HIP_HIT_SORT") != nullptr;   // A/B knob: the sorted path of rounds 1-3
+    const ResultLayout lay0(n_rows, 0, 4, 0);
+    bool taken = false;
+    if (!force_sorted && n_rows) {
+        db->res.reserve(lay0.covs + (size_t)std::max<uint32_t>(n_hits, 1) * 4 + 64);
+        ScopedKernelTimer t(ctx, "assemble");
+        taken = launch_row_assembly(db, nullptr, n_hits, max_count, std::max<uint32_t>(n_hits, 1), n_rows, cov_width ? 1 : 0, db->res.as<char>(), lay0.covs,
+                                    lay0.ccount);
+    }
+    if (!taken) { finish_hits_sorted(db, n_hits, max_count, n_rows, cov_width, with_lost, dst); return; }
+    const uint32_t width = narrow_width(cov_width != nullptr, max_count);
+    if (cov_width) *cov_width = width;
+    copy_out_rows(db, n_hits, width, n_rows, with_lost, dst);
+}
+
+uint32_t probe_and_finish(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint64_t n_rows, uint32_t* cov_width, HostBlock* dst) {
+    sylph_ctx* ctx = db->ctx;
+    SY_REQUIRE(n_rows < (1ull << 32) - 1, "too many result rows");
+    static const bool force_sorted = getenv("SYLPH_HIP_HIT_SORT") != nullptr;
+    if (force_sorted || !n_rows) {
+        uint32_t max_count = 0;
+        const uint32_t n_hits = refs.empty() ? 0 : probe_batch(db, refs, min_number_kmers, &max_count);
+        finish_hits_sorted(db, n_hits, max_count, n_rows, cov_width, false, dst);
+        return n_hits;
+    }
+    const ResultLayout lay0(n_rows, 0, 4, 0);
+    uint64_t want_cap = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        uint64_t cap = 0;
+        const bool probed = !refs.empty() && probe_batch_async(db, refs, min_number_kmers, want_cap, &cap);
+        if (!probed) {   // nothing to probe: an all-zero block through the same kernels (host-known: no hits)
+            finish_hits(db, 0, 0, n_rows, cov_width, false, dst);
+            return 0;
+        }
+        db->res.reserve(lay0.covs + (size_t)cap * 4 + 64);
+        bool taken;
+        {
+            ScopedKernelTimer t(ctx, "assemble");
+            taken = launch_row_assembly(db, db->counter.as<uint32_t>(), 0, 0, (uint32_t)cap, n_rows, cov_width ? 1 : 0, db->res.as<char>(), lay0.covs, lay0.ccount);
+        }
+        SY_HIP(hipEventSynchronize(db->ev_cnt));             // the two counter words (the kernels above are still running)
+        uint32_t hc[2];
+        memcpy(hc, (const char*)ctx->pinned + 256, 8);
+        const uint32_t n_hits = hc[0], max_count = hc[1];
+        if (n_hits > cap) {                                   // the hit array was too small: once more with room for all of them
+            SY_REQUIRE(attempt == 0, "hit buffer overflow persisted");
+            db->rc_dirty = true;                              // (the assembly kernels bailed out half-way: counters are not clean)
+            want_cap = n_hits;
+            continue;
+        }
+        if (!taken || max_count >= row_assembly_max_value()) {   // values beyond the LDS histogram: the sorted path, from the same hit list
+            db->rc_dirty = true;
+            finish_hits_sorted(db, n_hits, max_count, n_rows, cov_width, false, dst);
+            return n_hits;
+        }
+        db->cnt_dirty = false;                                // rows_sort_kernel's last workgroup zeroes the counter
+        const uint32_t width = narrow_width(cov_width != nullptr, max_count);
+        if (cov_width) *cov_width = width;
+        copy_out_rows(db, n_hits, width, n_rows, false, dst);
+        return n_hits;
+    }
+    return 0;
 }
 
 }  // namespace sylph
@@ -824,9 +942,8 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
         if (n) SY_REQUIRE(d_k && d_c, "null sample");
         std::vector<SampleRef> refs(1);
         refs[0].k = d_k; refs[0].c = d_c; refs[0].n = n;
-        n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
-        finish_hits(db, n_hits, max_count, G, cov_width, false);
-        return n_hits;
+        (void)max_count;
+        return probe_and_finish(db, refs, min_number_kmers, G, cov_width, nullptr);
     }
     // rank[g] = position of genome g in the passing list (or ~0), ani[rank], lost[g] = 0
     SY_REQUIRE(re->n_passing == 0 || (re->passing_gids && re->passing_ani), "null passing list");
@@ -850,6 +967,7 @@ static uint32_t contain_impl(sylph_db* db, const uint64_t* sample_kmers, const u
             SY_REQUIRE(cap < (1ull << 32), "more than 2^32-1 hits for one sample");
             db->hits.reserve(cap * 8);
             SY_HIP(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+            db->cnt_dirty = true;                             // (this pass counts into the probe's words and nobody zeroes them after it)
             if (attempt) SY_HIP(hipMemsetAsync(db->lost.p, 0, std::max<uint64_t>(1, G) * 4, ctx->stream));
             {
                 ScopedKernelTimer t(ctx, "probe");
@@ -905,9 +1023,7 @@ uint32_t sylph::contain_batch_impl(sylph_db* db, const sylph_sample_ref* samples
     } else {
         for (uint32_t s = 0; s < n_samples; s++) { refs[s].k = samples[s].kmers; refs[s].c = samples[s].counts; refs[s].n = samples[s].n; }
     }
-    uint32_t max_count = 0, n_hits = 0;
-    if (n_samples) n_hits = probe_batch(db, refs, min_number_kmers, &max_count);
-    finish_hits(db, n_hits, max_count, (uint64_t)n_samples * db->n_genomes, cov_width, false, dst);
+    const uint32_t n_hits = probe_and_finish(db, refs, min_number_kmers, (uint64_t)n_samples * db->n_genomes, cov_width, dst);
     fill_views(dst ? *dst : db->h_block, views);
     return n_hits;
 }

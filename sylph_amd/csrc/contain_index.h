@@ -189,12 +189,20 @@ struct sylph_db {
     // per-query scratch (owned by the db so concurrent dbs on one ctx do not alias)
     sylph::DevBuf q_kmers, q_counts, q_refs, hits, hits_sorted, res, counter;   // res: device copy of the result block
     sylph::DevBuf x_send, x_recv, x_meta;    // shard exchange buffers (shard.hip)
+    // row assembly of the hits (hits.hip): replicated row counters + tile offsets / tickets / row lists.  The kernels leave the
+    // counters (and the probe's hit counter) zeroed; *_dirty = they must be cleared before the next use (first use, a fallback
+    // batch, a failure half-way)
+    sylph::DevBuf row_counters, row_meta;
+    bool rc_dirty = true, cnt_dirty = true;
+    uint32_t rc_rep = 0, rc_rows = 0;
+    hipEvent_t ev_cnt = nullptr;             // "the probe's counter words have arrived in pinned host memory"
     sylph::ResultLayout lay;                 // layout of the last result
     uint64_t last_rows = 0;
     sylph::HostBlock h_block;                // pinned host results of the plain entry points (the pipeline brings its own blocks)
     explicit sylph_db(sylph_ctx* cx)
         : ctx(cx), kept(cx), tracked(cx), glen(cx), rank_of(cx), ani(cx), lost(cx), q_kmers(cx), q_counts(cx), q_refs(cx), hits(cx),
-          hits_sorted(cx), res(cx), counter(cx), x_send(cx), x_recv(cx), x_meta(cx) {}
+          hits_sorted(cx), res(cx), counter(cx), x_send(cx), x_recv(cx), x_meta(cx), row_counters(cx), row_meta(cx) {}
+    ~sylph_db() { if (ev_cnt) (void)hipEventDestroy(ev_cnt); }
 };
 
 namespace sylph {
@@ -202,6 +210,19 @@ namespace sylph {
 // kept index and leaves unsorted hits ((row << 32) | count, row = sample * n_genomes + genome) in db->hits.
 // Returns the number of hits; *max_count = largest count among them.
 uint32_t probe_batch(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint32_t* max_count);
+// The same without waiting for the counts: launches the probe (hit array of *cap entries, grown to fit `want_cap`), queues the copy of
+// the two counter words [hits, largest count] into the context's pinned page (+256) and records db->ev_cnt behind it.  Returns
+// false when there is nothing to probe (no k-mers, empty index): the counts are 0 then and nothing was launched.
+bool probe_batch_async(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint64_t want_cap, uint64_t* cap);
+// hits.hip: hit list in db->hits -> cov_off / contain_count / per-row ascending coverage values in the device result block, five
+// launches, sizes from device memory (d_cnt) or from the host (n_imm, max_imm).  false = not taken (nothing launched).
+bool launch_row_assembly(sylph_db* db, const uint32_t* d_cnt, uint32_t n_imm, uint32_t max_imm, uint32_t cap, uint64_t n_rows, int want_narrow,
+                         char* d_res, size_t covs_offset, size_t ccount_offset);
+uint32_t row_assembly_max_value();
+// Probe + assembly of a batch of device-resident tables (refs) into `dst` (nullptr: the database's block) without a host round trip
+// between the probe and the assembly.  Returns the number of hits.
+uint32_t probe_and_finish(sylph_db* db, std::vector<SampleRef>& refs, double min_number_kmers, uint64_t n_rows, uint32_t* cov_width,
+                          HostBlock* dst);
 // Sorts n_hits hits of db->hits (rows < n_rows) and assembles + copies out the result block (layout db->lay) into `dst`
 // (nullptr: the database's own block).
 void finish_hits(sylph_db* db, uint32_t n_hits, uint32_t max_count, uint64_t n_rows, uint32_t* cov_width, bool with_lost,

@@ -109,6 +109,8 @@ struct sylph_pipeline {
         if (!j->sk) {
             rc = sylph_sketch_begin(wctx[w], c, k, reads_mode, no_dedup, seed_mode, &j->sk);
             j->worker = w;
+            // device batches are borrowed until sylph_pipeline_next has returned the sample: the seeding verdict may wait for finish
+            if (rc == SYLPH_OK && j->mem == SYLPH_MEM_DEVICE && j->batches.size() == 1) rc = sylph_sketch_set_option(j->sk, "borrow_until_finish", "1");
             for (size_t i = 0; rc == SYLPH_OK && i < j->batches.size(); i++) {
                 const sylph_read_batch& b = j->batches[i];
                 std::unique_lock<std::mutex> seed_lock(seed_mu, std::defer_lock);

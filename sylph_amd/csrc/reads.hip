@@ -488,7 +488,24 @@ void compact_region(sylph_sketch* sk, uint32_t n_blk, uint32_t slot_cap, uint32_
 
 }  // namespace
 
+// The verdict of a deferred batch, read now: the block total + the two flags (what push_short_reads reads when it does not
+// defer).  A bad verdict redoes the batch through the checked push; afterwards the session is in the state an ordinary push
+// would have left it in.
+void resolve_deferred_slots(sylph_sketch* sk) {
+    if (!sk->pend.live || !sk->pend.deferred) return;
+    sylph_ctx* ctx = sk->ctx;
+    SlotMeta m(sk, sk->pend.n_blk);
+    hipLaunchKernelGGL(block_total_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.blk_count, sk->pend.n_blk, m.blk_off + sk->pend.n_blk);
+    uint32_t res[3] = {0, 0, 0};
+    ctx->read_back(res, m.blk_off + sk->pend.n_blk, 12);
+    if (res[1] || res[2]) { redo_deferred_batch(sk); return; }
+    sk->pend.deferred = false;
+    sk->pend.n = res[0];
+    if (res[0] == 0) sk->pend = PendingSlots{};
+}
+
 void flush_pending_slots(sylph_sketch* sk) {
+    resolve_deferred_slots(sk);
     if (!sk->pend.live) return;
     compact_region(sk, sk->pend.n_blk, sk->pend.slot_cap, sk->pend.n, 0, nullptr);
     sk->pend = PendingSlots{};
@@ -554,6 +571,23 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         {
             ScopedKernelTimer t(ctx, "seeds");
             launch(n_blk, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
+        }
+        // deferred verdict (sketch_session.h PendingSlots): the caller keeps the batch valid until finish, this is the session's first
+        // batch and nothing forces the dense arrays — no block total, no read-back, no wait; finish reads the flags with its own tail
+        const uint64_t n_expect = (n_bases > n_records * (uint64_t)(sk->k - 1) ? n_bases - n_records * (uint64_t)(sk->k - 1) : 0) / sk->c;
+        if (sk->borrow_until_finish && sk->n_occ == 0 && sk->rec_base == 0 && ctx->finish_mode == 0 && sk->c >= 2 && n_expect >= 4096 &&
+            (uint64_t)n_blk * slot_cap < (1ull << 31)) {
+            sk->pend = PendingSlots{};
+            sk->pend.live = true;
+            sk->pend.deferred = true;
+            sk->pend.n_blk = n_blk;
+            sk->pend.slot_cap = slot_cap;
+            sk->pend.n = n_blk * slot_cap;               // upper bound: no block holds more than its slots (else the verdict says so)
+            sk->pend.n_expect = (uint32_t)std::min<uint64_t>(n_expect, sk->pend.n);
+            sk->pend.bases = d_bases; sk->pend.phase = phase; sk->pend.off = d_off;
+            sk->pend.n_records = n_records; sk->pend.n_bases = n_bases; sk->pend.enc = enc;
+            if (ctx->profile) ctx->stats["deferred"].launches++;     // (tests ask sylph_ctx_kernel_stats whether this road was taken)
+            return true;
         }
         hipLaunchKernelGGL(block_total_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.blk_count, n_blk, m.blk_off + n_blk);
     }

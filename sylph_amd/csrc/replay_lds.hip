@@ -1103,10 +1103,14 @@ uint32_t grid_of(uint64_t n, uint32_t tpb = 256) { return (uint32_t)((n + tpb - 
 bool finish_bucketed(sylph_sketch* sk) {
     sylph_ctx* ctx = sk->ctx;
     const bool slotted = sk->pend.live;                // the sample's one batch, still in its slots (reads.hip)
-    const uint32_t n_all = slotted ? sk->pend.n : (uint32_t)sk->n_occ;
+    // deferred verdict (sketch_session.h PendingSlots): the number of occurrences is not known on the host — geometry from the
+    // expectation, capacities from the upper bound, every count the kernels need from device memory, the verdict read with the tail
+    const bool deferred = slotted && sk->pend.deferred;
+    const uint32_t n_cap = slotted ? sk->pend.n : (uint32_t)sk->n_occ;      // what the arrays must hold
+    const uint32_t n_all = deferred ? std::max<uint32_t>(1, sk->pend.n_expect) : n_cap;
     sk->n_out = 0;
     sk->dup_removed = 0;
-    if (n_all == 0) return true;
+    if (n_cap == 0) return true;
     if (sk->c < 2) return false;   // c = 1: valid hashes reach the top bit that marks invalid occurrences
     // bucket geometry: B = n / TARGET equal hash ranges (see BucketMap)
     const uint64_t thr = UINT64_MAX / (uint64_t)sk->c;
@@ -1170,14 +1174,14 @@ bool finish_bucketed(sylph_sketch* sk) {
     DevBuf &b_hist = ctx->scratch[0], &b_pairs = ctx->scratch[1], &b_perm = ctx->scratch[2], &b_tmpk = ctx->scratch[3],
            &b_tmpc = ctx->scratch[4], &b_small = ctx->scratch[5], &b_bk = ctx->scratch[6];
     b_hist.reserve(((size_t)C * n_tiles + 2 * (size_t)C + 2) * 4);      // hist (C x n_tiles) | total (C) | cbase (C + 1)
-    b_pairs.reserve((size_t)n_all * 8);                                 // (bucket, occurrence index) pairs grouped by coarse range
-    if (!plain) b_perm.reserve((size_t)n_all * 4);
+    b_pairs.reserve((size_t)n_cap * 8);                                 // (bucket, occurrence index) pairs grouped by coarse range
+    if (!plain) b_perm.reserve((size_t)n_cap * 4);
     DevBuf& b_sorted = ctx->scratch[7];                                 // marker-less: the hashes sorted by bucket
-    if (plain) b_sorted.reserve((size_t)n_all * 8);
+    if (plain) b_sorted.reserve((size_t)n_cap * 8);
     uint64_t* sorted_hash = plain ? b_sorted.as<uint64_t>() : nullptr;
     in.carry = plain ? 1 : 0;
-    b_tmpk.reserve((size_t)n_all * 8);
-    b_tmpc.reserve((size_t)n_all * 4);
+    b_tmpk.reserve((size_t)n_cap * 8);
+    b_tmpc.reserve((size_t)n_cap * 4);
     b_small.reserve(64);
     // boff | large_list | ovf_list | n_distinct | removed | d_off | mid_list (each B+2) | chunk_rows (264) | chunk_removed (264 u64)
     b_bk.reserve((size_t)(B + 2) * 4 * 7 + 264 * 4 + 264 * 8 + 16);
@@ -1202,8 +1206,8 @@ bool finish_bucketed(sylph_sketch* sk) {
     // the list-driven configurations or the device-wide path)
     const int dbg = getenv("SYLPH_REPLAY_STAGE") ? atoi(getenv("SYLPH_REPLAY_STAGE")) : 0;
     const uint32_t cutoff = sk->paired ? 0u : 4u;   // MAX_DEDUP_COUNT, constants.rs:14
-    sk->out_k.reserve((size_t)n_all * 8);          // upper bound: distinct k-mers <= occurrences
-    sk->out_c.reserve((size_t)n_all * 4);
+    sk->out_k.reserve((size_t)n_cap * 8);          // upper bound: distinct k-mers <= occurrences
+    sk->out_c.reserve((size_t)n_cap * 4);
     {
         HostPhase ph(ctx, "finish(bucket): partition + LDS replay + compact");
         {
@@ -1250,14 +1254,25 @@ bool finish_bucketed(sylph_sketch* sk) {
         SY_HIP(hipGetLastError());
     };
     struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf, n_mid, n_large; } host{};
+    uint32_t verdict[2] = {0, 0};                  // deferred: long_record flag, overflowing blocks of the seeding kernel
     auto read_tail = [&] {
         SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 28, hipMemcpyDeviceToHost, ctx->stream));
+        if (deferred)   // the two flag words of ReadsState (reads.hip SlotMeta: behind the four block tables)
+            SY_HIP(hipMemcpyAsync((char*)ctx->pinned + 32, sk->slot_meta.as<uint32_t>() + (size_t)(sk->pend.n_blk + 1) * 4, 8, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
         memcpy(&host, ctx->pinned, 28);
+        if (deferred) memcpy(verdict, (const char*)ctx->pinned + 32, 8);
         if (!ctx->pending.empty()) profile_collect(ctx);
     };
     close_table(1);
     read_tail();
+    if (deferred) {
+        if (verdict[0] || verdict[1]) {            // not a batch for the short-read kernel after all: the checked push, then from the top
+            redo_deferred_batch(sk);
+            return finish_bucketed(sk);
+        }
+        sk->pend.deferred = false;                 // the verdict is in: from here on an ordinary slotted sample
+    }
     if (host.overflow) return false;             // inconsistent bounds (defensive): the generic path redoes the sample
     if (plain && host.n_ovf) {
         // k-mers more than a thousand deep in a marker-less sample: write the occurrence records after all and take the usual

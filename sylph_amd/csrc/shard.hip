@@ -30,6 +30,7 @@
 #include <memory>
 
 #include "contain_index.h"
+#include "shard_plan.h"
 
 namespace sylph {
 namespace {
@@ -125,7 +126,8 @@ struct sylph_comm {
 namespace sylph {
 namespace {
 
-constexpr uint32_t MAX_LOCAL = 64;           // samples a rank may contribute to one batch (fixes the size of the meta block)
+using shardplan::MAX_LOCAL;                  // samples a rank may contribute to one batch (shard_plan.h: the exchange's bookkeeping,
+using shardplan::MAX_WORLD;                  // host-compilable — tests/test_dist.py drives it under gloo)
 
 // split[s * (W + 1) + j] = first entry of sample s whose k-mer is >= bounds[j]   (j = 0..W; the tables are ascending)
 __global__ __launch_bounds__(256) void split_kernel(const SampleRef* __restrict__ refs, uint32_t n_samples, const uint64_t* __restrict__ bounds,
@@ -133,14 +135,7 @@ __global__ __launch_bounds__(256) void split_kernel(const SampleRef* __restrict_
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_samples * (W + 1)) return;
     const uint32_t s = t / (W + 1), j = t % (W + 1);
-    const uint64_t* __restrict__ k = refs[s].k;
-    const uint64_t key = bounds[j];
-    uint64_t lo = 0, hi = refs[s].n;
-    while (lo < hi) {
-        const uint64_t mid = lo + ((hi - lo) >> 1);
-        if (k[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    split[t] = lo;
+    split[t] = shardplan::lower_bound_u64(refs[s].k, refs[s].n, bounds[j]);
 }
 
 // segmented copy in 4-byte words: workgroup (x = segment, y strides)
@@ -152,15 +147,8 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const Seg* __restric
 
 // owner of a hit = the rank whose samples include row / n_genomes (prefix[r] <= sample < prefix[r + 1])
 __device__ __forceinline__ uint32_t owner_of(uint64_t hit, uint64_t n_genomes, const uint64_t* __restrict__ prefix, uint32_t world) {
-    const uint64_t s = (hit >> 32) / n_genomes;
-    uint32_t lo = 0, hi = world;                         // largest r with prefix[r] <= s
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (prefix[mid] <= s) lo = mid; else hi = mid;
-    }
-    return lo;
+    return shardplan::owner_of_sample((hit >> 32) / n_genomes, prefix, world);
 }
-constexpr uint32_t MAX_WORLD = 64;
 // Wavefront-aggregated "take a slot in bin r": lanes of a wave that want the same bin are served by ONE atomic (hits arrive in
 // runs of one sample, i.e. one owner: a plain per-lane atomic would serialise 64 lanes on one LDS word).  Returns the lane's
 // slot; every active lane must call it.
@@ -221,7 +209,7 @@ __global__ __launch_bounds__(256) void owner_scatter_kernel(const uint64_t* __re
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SCATTER_ITEMS; j++)
-            if (r[j] != 0xFFFFFFFFu) out[start[r[j]] + base[r[j]] + slot[j]] = h[j] - ((prefix[r[j]] * n_genomes) << 32);
+            if (r[j] != 0xFFFFFFFFu) out[start[r[j]] + base[r[j]] + slot[j]] = shardplan::rebase_hit(h[j], prefix[r[j]], n_genomes);
         __syncthreads();
     }
 }
@@ -329,7 +317,7 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
 
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 1: split + all-gather meta"));
         // ---- 1. slice boundaries of every local table, all-gathered: block = [n_local | split[MAX_LOCAL][W + 1]] u64
-        const uint64_t meta_words = 1 + (uint64_t)MAX_LOCAL * (W + 1);
+        const uint64_t meta_words = shardplan::meta_words(W);
         // x_meta: [my block | gathered blocks (W) | bounds (W + 1) | refs | segs]
         const size_t off_gather = meta_words * 8, off_bounds = off_gather + (size_t)W * meta_words * 8, off_refs = off_bounds + (size_t)(W + 1) * 8;
         const size_t off_segs = off_refs + (size_t)MAX_LOCAL * sizeof(SampleRef);
@@ -353,42 +341,32 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         comm->all_gather(d_myblock, d_gather, meta_words * 8, st);
         std::vector<uint64_t> meta((size_t)W * meta_words);
         ctx->d2h(meta.data(), d_gather, meta.size() * 8);
-        auto n_loc = [&](uint32_t r) { return (uint32_t)meta[(size_t)r * meta_words]; };
-        auto split = [&](uint32_t r, uint32_t s, uint32_t j) { return meta[(size_t)r * meta_words + 1 + (size_t)s * (W + 1) + j]; };
-        std::vector<uint64_t> prefix(W + 1, 0);
-        for (uint32_t r = 0; r < W; r++) {
-            SY_REQUIRE(n_loc(r) <= MAX_LOCAL, "rank %u announced %u samples", r, n_loc(r));
-            prefix[r + 1] = prefix[r] + n_loc(r);
-        }
-        const uint64_t S_total = prefix[W];
-        SY_REQUIRE(S_total * std::max<uint64_t>(G, 1) < (1ull << 32) - 1, "samples x genomes of one step must stay below 2^32");
+        // every offset below comes from shard_plan.h (the same arithmetic on every rank, from the same gathered block)
+        const shardplan::Meta pm{meta.data(), W};
+        auto n_loc = [&](uint32_t r) { return pm.n_loc(r); };
+        auto split = [&](uint32_t r, uint32_t s, uint32_t j) { return pm.split(r, s, j); };
+        const shardplan::SlicePlan sp = shardplan::plan_slices(pm, me, G);
+        SY_REQUIRE(sp.error.empty(), "%s", sp.error.c_str());
+        const std::vector<uint64_t>& prefix = sp.prefix;
+        const uint64_t S_total = sp.S_total;
 
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 2: pack + all-to-all slices"));
         // ---- 2. all-to-all of the slices.  Block for rank d: [k-mers of slice (s, d), s = 0.. | counts of slice (s, d) | pad to 8]
-        std::vector<uint64_t> send_off(W + 1, 0), recv_off(W + 1, 0);
-        auto block_bytes = [&](uint32_t src, uint32_t dst) {
-            uint64_t e = 0;
-            for (uint32_t s = 0; s < n_loc(src); s++) e += split(src, s, dst + 1) - split(src, s, dst);
-            return (e * 12 + 7) & ~7ull;
-        };
-        for (uint32_t r = 0; r < W; r++) { send_off[r + 1] = send_off[r] + block_bytes(me, r); recv_off[r + 1] = recv_off[r] + block_bytes(r, me); }
+        const std::vector<uint64_t>&send_off = sp.send_off, &recv_off = sp.recv_off;
         db->x_send.reserve(send_off[W] + 64);
         db->x_recv.reserve(recv_off[W] + 64);
         if (n_local) {
             std::vector<Seg> segs;
             uint64_t max_words = 1;
             for (uint32_t d = 0; d < W; d++) {
-                uint64_t e = 0;
-                for (uint32_t s = 0; s < n_local; s++) e += split(me, s, d + 1) - split(me, s, d);
                 char* blk = db->x_send.as<char>() + send_off[d];
-                uint64_t ok = 0, oc = e * 8;
                 for (uint32_t s = 0; s < n_local; s++) {
-                    const uint64_t a = split(me, s, d), len = split(me, s, d + 1) - a;
-                    if (!len) continue;
-                    segs.push_back(Seg{reinterpret_cast<const uint32_t*>(mine[s].k + a), reinterpret_cast<uint32_t*>(blk + ok), len * 2});
-                    segs.push_back(Seg{mine[s].c + a, reinterpret_cast<uint32_t*>(blk + oc), len});
-                    ok += len * 8; oc += len * 4;
-                    max_words = std::max(max_words, len * 2);
+                    const shardplan::SliceAt at = shardplan::slice_in_block(pm, me, s, d);
+                    if (!at.len) continue;
+                    const uint64_t a = split(me, s, d);
+                    segs.push_back(Seg{reinterpret_cast<const uint32_t*>(mine[s].k + a), reinterpret_cast<uint32_t*>(blk + at.k_off), at.len * 2});
+                    segs.push_back(Seg{mine[s].c + a, reinterpret_cast<uint32_t*>(blk + at.c_off), at.len});
+                    max_words = std::max(max_words, at.len * 2);
                 }
             }
             if (!segs.empty()) {
@@ -409,15 +387,11 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         // ---- 3. probe every received slice against the resident shard; row = global sample index * G + genome
         std::vector<SampleRef> refs(S_total);
         for (uint32_t r = 0; r < W; r++) {
-            uint64_t e = 0;
-            for (uint32_t s = 0; s < n_loc(r); s++) e += split(r, s, me + 1) - split(r, s, me);
             const char* blk = db->x_recv.as<char>() + recv_off[r];
-            uint64_t ok = 0, oc = e * 8;
             for (uint32_t s = 0; s < n_loc(r); s++) {
-                const uint64_t len = split(r, s, me + 1) - split(r, s, me);
+                const shardplan::SliceAt at = shardplan::slice_in_block(pm, r, s, me);
                 SampleRef& f = refs[prefix[r] + s];
-                f.k = reinterpret_cast<const uint64_t*>(blk + ok); f.c = reinterpret_cast<const uint32_t*>(blk + oc); f.n = len;
-                ok += len * 8; oc += len * 4;
+                f.k = reinterpret_cast<const uint64_t*>(blk + at.k_off); f.c = reinterpret_cast<const uint32_t*>(blk + at.c_off); f.n = at.len;
             }
         }
         // A failure on ONE rank between two collectives (a batch beyond the probe's limits, a hit buffer that cannot grow, a HIP
@@ -440,7 +414,7 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         // ---- 4. group the hits by owner rank; all-gather the group sizes: block (SZ = W + 3 words) = [count for rank 0..W-1 |
         // largest count value | error word | number of hits of the rank]
         // x_meta (reused): [prefix (W + 1) u64 | my sizes SZ u32 | cursors (W) u32 | starts (W) u32 | gathered sizes W x SZ u32]
-        const uint32_t SZ = W + 3;
+        const uint32_t SZ = shardplan::size_words(W);
         uint64_t* d_prefix = reinterpret_cast<uint64_t*>(xm);
         uint32_t* d_sizes = reinterpret_cast<uint32_t*>(xm + (size_t)(W + 1) * 8);
         uint32_t* d_cursor = d_sizes + SZ;
@@ -458,35 +432,18 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         comm->all_gather(d_sizes, d_allsizes, (uint64_t)SZ * 4, st);
         std::vector<uint32_t> sizes((size_t)W * SZ);
         ctx->d2h(sizes.data(), d_allsizes, sizes.size() * 4);
-        auto n_from_to = [&](uint32_t src, uint32_t dst) { return (uint64_t)sizes[(size_t)src * SZ + dst]; };
-        // every rank looks at every rank's error word and bookkeeping: the same verdict everywhere
-        for (uint32_t r = 0; r < W; r++) {
-            const uint32_t err_r = sizes[(size_t)r * SZ + W + 1];
-            if (err_r)
-                throw ArgError{r == me ? "sharded containment failed on this rank: " + local_msg
-                                       : "sharded containment failed on rank " + std::to_string(r) + " (error class " + std::to_string(err_r) + "): this rank stops with it"};
-            uint64_t sent = 0;
-            for (uint32_t d2 = 0; d2 < W; d2++) sent += n_from_to(r, d2);
-            SY_REQUIRE(sent == sizes[(size_t)r * SZ + W + 2], "internal: owner counts of rank %u do not add up", r);
-        }
+        // every rank looks at every rank's error word and bookkeeping (shard_plan.h): the same verdict everywhere
+        const shardplan::HitPlan hp = shardplan::plan_hits(sizes.data(), W, me);
+        if (hp.failed_rank != 0xFFFFFFFFu)
+            throw ArgError{hp.failed_rank == me ? "sharded containment failed on this rank: " + local_msg
+                                                : "sharded containment failed on rank " + std::to_string(hp.failed_rank) + " (error class " +
+                                                      std::to_string(hp.failed_class) + "): this rank stops with it"};
+        SY_REQUIRE(hp.error.empty(), "%s", hp.error.c_str());
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 5: scatter + all-to-all hits"));
         // ---- 5. all-to-all of the hit groups
-        std::vector<uint64_t> hs_off(W + 1, 0), hr_off(W + 1, 0);
-        std::vector<uint32_t> start(W, 0);
-        uint32_t max_mine = 0;
-        for (uint32_t r = 0; r < W; r++) {
-            start[r] = (uint32_t)(hs_off[r] / 8);
-            hs_off[r + 1] = hs_off[r] + n_from_to(me, r) * 8;
-            hr_off[r + 1] = hr_off[r] + n_from_to(r, me) * 8;
-            if (n_from_to(r, me)) max_mine = std::max(max_mine, sizes[(size_t)r * SZ + W]);
-        }
-        // (checked for EVERY destination from the gathered matrix, so that all ranks fail together instead of one leaving the others
-        //  waiting in the next collective)
-        for (uint32_t dst = 0; dst < W; dst++) {
-            uint64_t to_dst = 0;
-            for (uint32_t src = 0; src < W; src++) to_dst += n_from_to(src, dst);
-            SY_REQUIRE(to_dst < (1ull << 32), "more than 2^32-1 hits for the samples of rank %u in one step: use smaller batches", dst);
-        }
+        const std::vector<uint64_t>&hs_off = hp.send_off, &hr_off = hp.recv_off;
+        const std::vector<uint32_t>& start = hp.start;
+        const uint32_t max_mine = hp.max_mine;
         db->x_send.reserve(hs_off[W] + 64);
         if (n_hits) {
             ctx->h2d(d_start, start.data(), (size_t)W * 4);

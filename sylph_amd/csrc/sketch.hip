@@ -561,6 +561,21 @@ static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t pha
     sk->rec_base += n_records;
 }
 
+// A deferred batch whose verdict came back bad (a record too long for the short-read kernel, a block that overflowed its slots):
+// the session goes back to where it was before that push and the batch — its memory is still the caller's, that was the deal —
+// runs through the checked push (which falls back to the position kernel / spill regions as needed).
+void redo_deferred_batch(sylph_sketch* sk) {
+    const PendingSlots d = sk->pend;
+    sk->pend = PendingSlots{};
+    sk->rec_base -= d.n_records;
+    if (sk->ctx->profile) sk->ctx->stats["deferred_redo"].launches++;
+    const bool borrow = sk->borrow_until_finish;
+    sk->borrow_until_finish = false;
+    try { process_batch(sk, d.bases, d.phase, d.off, d.n_records, d.n_bases, d.enc); }
+    catch (...) { sk->borrow_until_finish = borrow; throw; }
+    sk->borrow_until_finish = borrow;
+}
+
 // Host batches (SYLPH_MEM_HOST / SYLPH_MEM_HOST_PINNED) are cut into chunks of whole records (whole pairs) that travel on a
 // COPY stream into two device slots while the compute stream works on the previous chunk: the PCIe transfer (1 B per base,
 // or 1/4 B packed) is the long pole of a host-fed sample — 18 ms per Gbp against ~1 ms of kernels — and everything else
@@ -635,7 +650,13 @@ static void push_host_batch(sylph_sketch* sk, const uint8_t* bases, const uint64
         uint64_t* d_raw = sk->slot_off[slot].as<uint64_t>();
         uint64_t* d_off = d_raw + (n_rec + 1);
         hipLaunchKernelGGL(rebase_offsets_kernel, dim3(grid_for(n_rec + 1)), dim3(256), 0, ctx->stream, d_raw, n_rec + 1, d_off);
-        process_batch(sk, sk->slot_bases[slot].as<uint8_t>(), (uint32_t)(cur.b0 % bpb), d_off, n_rec, cur.b1 - cur.b0, enc);
+        {   // (the device slots are overwritten by the copy after next: nothing here may be deferred to finish)
+            const bool borrow = sk->borrow_until_finish;
+            sk->borrow_until_finish = false;
+            try { process_batch(sk, sk->slot_bases[slot].as<uint8_t>(), (uint32_t)(cur.b0 % bpb), d_off, n_rec, cur.b1 - cur.b0, enc); }
+            catch (...) { sk->borrow_until_finish = borrow; throw; }
+            sk->borrow_until_finish = borrow;
+        }
         // every kernel that reads this slot must be done before the copy after next overwrites it
         SY_HIP(hipStreamSynchronize(ctx->stream));
         if (!more) break;
@@ -986,6 +1007,15 @@ int sylph_sketch_finish(sylph_sketch* sk, uint64_t** out_kmers, uint32_t** out_c
         } catch (...) { free(hk); free(hc); throw; }
         *out_kmers = hk; *out_counts = hc; *out_n = n;
         if (out_dup_removed) *out_dup_removed = sk->dup_removed;
+    });
+}
+
+int sylph_sketch_set_option(sylph_sketch* sk, const char* key, const char* value) {
+    return guarded([&] {
+        SY_REQUIRE(sk && key && value, "null argument");
+        std::lock_guard<std::mutex> lock(sk->ctx->mu);
+        if (!strcmp(key, "borrow_until_finish")) sk->borrow_until_finish = strtol(value, nullptr, 10) != 0;
+        else SY_REQUIRE(false, "unknown session option %s", key);
     });
 }
 

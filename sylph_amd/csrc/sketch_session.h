@@ -33,8 +33,22 @@ namespace sylph {
 // dense file-order arrays first (flush_pending_slots).
 struct PendingSlots {
     bool live = false;
-    uint32_t n_blk = 0, slot_cap = 0, n = 0;   // blocks, slots per block, occurrences in the region
+    uint32_t n_blk = 0, slot_cap = 0, n = 0;   // blocks, slots per block, occurrences in the region (deferred: an upper bound)
+    // Deferred (round 4): the seeding kernel's verdict — a record too long for it, a block that overflowed its slots, the number of
+    // occurrences — has NOT been read back yet.  Only for a session whose caller keeps the batch's memory valid until finish
+    // ("borrow_until_finish": the pipeline's device batches, bench.py): finish_bucketed sizes everything from `n_expect` / `n`
+    // (estimate / upper bound), takes every count from device memory, and reads the verdict together with its own tail block —
+    // one host round trip per sample instead of two.  A bad verdict redoes the batch the ordinary way (redo_deferred_batch).
+    bool deferred = false;
+    uint32_t n_expect = 0;
+    const uint8_t* bases = nullptr;            // the borrowed batch, for the redo
+    uint32_t phase = 0;
+    const uint64_t* off = nullptr;
+    uint64_t n_records = 0, n_bases = 0;
+    int enc = 0;
 };
+void resolve_deferred_slots(sylph_sketch* sk);   // reads.hip: reads the verdict now (block total + flags); may redo the batch
+void redo_deferred_batch(sylph_sketch* sk);      // sketch.hip: the deferred batch once more, through the ordinary (checked) push
 }  // namespace sylph
 
 struct sylph_sketch {
@@ -42,6 +56,7 @@ struct sylph_sketch {
     uint32_t c, k;
     int paired, no_dedup, avx2_compat;
     bool finished = false;
+    bool borrow_until_finish = false;   // the caller keeps device batches valid until finish (sylph_sketch_set_option; see PendingSlots)
     uint64_t rec_base = 0;         // records pushed so far
     uint64_t n_occ = 0;            // occurrences (valid + invalid) appended so far
     uint64_t n_plain = 0;          // the first n_plain of them have no OccRec (marker-less single-end batches, see materialise_plain_records)

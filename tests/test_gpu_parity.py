@@ -613,7 +613,7 @@ def test_contain_crowded_buckets_and_index_shapes(ctx):
             assert cc.max() > 300            # the shared k-mers hit
             check_contain(ctx, db, goff, sk, sc, min_kmers=100.0)
     finally:
-        ctx.set_option("index_lambda", "3")
+        ctx.set_option("index_lambda", "4")
         ctx.set_option("index_pass_max", str(1 << 30))
 
 
@@ -1154,3 +1154,121 @@ def test_marker_less_single_end_samples_are_counted_without_records(ctx):
                 assert g["dup_removed"] == e["dup_removed"], (name, c, plain)
         if name in ("long_then_short", "short_then_long"):
             assert e["dup_removed"] > 0
+
+
+@pytest.mark.gpu
+def test_hit_row_assembly_paths(ctx):
+    """The result block is assembled per row since round 4 (csrc/hits.hip: replicated row counters, scan, scatter, per-row sort;
+    sizes from device memory) instead of radix-sorting the hit list.  Every branch against the oracle: rows of 1..64 hits (ranked
+    inside a wavefront), long rows (LDS histogram over the values), a batch whose largest count does not fit the histogram (4096
+    and above: the sorted path of rounds 1-3 takes it, decided from the device word), a hit list that overflows its first buffer
+    (probe + assembly run twice), row spaces of different sizes one after the other on the same database (batches of 1, 3, 1
+    tables: the counters and tickets must come back clean every time), and the same calls with SYLPH_HIP_HIT_SORT-style sorting
+    giving identical blocks is covered by every other contain test having passed on the old path in round 3."""
+    rng = np.random.default_rng(404)
+    thr = O.threshold(200)
+    big = [np.unique(rng.integers(0, thr, size=n, dtype=np.uint64)) for n in (30_000, 12_000, 5_000)]
+    small = [rng.integers(0, thr, size=int(rng.integers(50, 90)), dtype=np.uint64) for _ in range(400)]
+    clones = [big[0].copy() for _ in range(45)]                     # 45 x 30k shared k-mers: 1.35 M hits > the first hit buffer (1 M)
+    genomes = big + small + clones
+    db_k, goff = flat_db(genomes)
+    sk = np.unique(np.concatenate([big[0], big[1][::2], big[2][::3]] + [g[: int(rng.integers(1, len(g)))] for g in small[::3]] +
+                                  [rng.integers(0, thr, size=4000, dtype=np.uint64)]))
+    counts_small = rng.integers(1, 200, size=len(sk)).astype(np.uint32)      # u8 values
+    counts_mid = counts_small.copy()
+    counts_mid[::7] = rng.integers(256, 4000, size=len(counts_mid[::7]))     # u16 values, still inside the histogram
+    counts_huge = counts_small.copy()
+    counts_huge[5] = 70_000                                                  # beyond the histogram: sorted path, u32 values
+    counts_zero = counts_small.copy()
+    counts_zero[::2] = 0                                                     # contain.rs:634: zero counts are no hits
+    for sc in (counts_small, counts_mid, counts_huge, counts_zero):
+        cc = check_contain(ctx, db_k, goff, sk, sc, min_kmers=0.0)
+        assert cc[0] == len(big[0]) or sc is counts_zero
+        assert int(cc.sum()) > 1_000_000 or sc is counts_zero
+    # the same database object through row spaces of different sizes, and a thinned table whose hits fit the first buffer
+    db = S.Database(ctx, db_k, goff)
+    G = len(goff) - 1
+    thin = sk[::9]
+    tables = [(sk, counts_small), (thin, counts_mid[::9]), (sk, counts_huge), (thin, counts_small[::9])]
+    exp = {}
+    for i, (k_, c_) in enumerate(tables):
+        ecc, ecov, _ = O.contain(k_, c_, db_k, goff, min_number_kmers=0.0)
+        exp[i] = (ecc, [np.sort(x) for x in ecov])
+    for batch in ([1], [1, 3, 0], [3], [0, 1, 2, 3], [2], [1]):
+        cc, off, covs = db.contain_batch([tables[i] for i in batch], min_number_kmers=0.0)
+        cc, off, covs = np.array(cc), np.array(off), np.array(covs).astype(np.uint32)
+        for s, i in enumerate(batch):
+            ecc, ecov = exp[i]
+            assert np.array_equal(cc[s * G:(s + 1) * G], ecc), (batch, s)
+            for g in list(range(3)) + list(range(3, G, 37)) + list(range(G - 45, G, 11)):
+                assert np.array_equal(covs[int(off[s * G + g]):int(off[s * G + g + 1])], ecov[g]), (batch, s, g)
+    db.close()
+
+
+def test_deferred_seeding_verdict_and_its_redo(ctx):
+    """"borrow_until_finish" (round 4): a session whose device batch stays valid until finish does not wait for the seeding kernel's
+    verdict after the push — finish reads it with its own tail block.  The ordinary case, and the three ways the verdict can turn
+    out bad or be needed early: a record too long for the short-read kernel, blocks of reads that overflow their slots (20,000
+    copies of one pair that carries several seeds), a second push on the same session; plus what must NOT be deferred (host
+    memory, tiny batches).  Every table against the oracle; the road taken is read from the context's counters."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2604)
+    genome = random_seq(rng, 400_000)
+
+    def pairs(n, L=150):
+        st = rng.integers(0, len(genome) - 500, size=n)
+        recs = []
+        for s in st:
+            recs.append(genome[s:s + L])
+            recs.append(revcomp(genome[s + 200:s + 200 + L]))
+        return recs
+
+    def run(recs_list, paired=True, borrow=True, host=False, c=200):
+        sk = S.ReadSketcher(ctx, c=c, k=31, paired=paired)
+        if borrow:
+            sk.set_option("borrow_until_finish", 1)
+        keep = []
+        for recs in recs_list:
+            b, o = concat(recs)
+            if host:
+                sk.push(b, o)
+            else:
+                tb = torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).to(dev)
+                to = torch.from_numpy(o.astype(np.int64)).to(dev)
+                torch.cuda.synchronize()
+                keep.append((tb, to))
+                sk.push_device(tb.data_ptr(), to.data_ptr(), len(recs), int(o[-1]))
+        g = sk.finish()
+        sk.close()
+        allrecs = [r for recs in recs_list for r in recs]
+        b, o = concat(allrecs)
+        e = O.sketch_reads(b, o, c=c, k=31, paired=paired)
+        assert np.array_equal(g["kmers"], e["kmers"]) and np.array_equal(g["counts"], e["counts"]) and g["dup_removed"] == e["dup_removed"]
+        return g
+
+    def roads(fn):
+        ctx.profile(True)
+        fn()
+        d, r = ctx.kernel_stats("deferred")[1], ctx.kernel_stats("deferred_redo")[1]
+        ctx.profile(False)
+        return d, r
+
+    normal = pairs(6000) + pairs(50) * 3                                   # ~1.8 Mbp, some exact duplicate pairs
+    assert roads(lambda: run([normal])) == (1, 0)
+    assert roads(lambda: run([normal], borrow=False)) == (0, 0)
+    assert roads(lambda: run([normal], host=True)) == (0, 0)
+    assert roads(lambda: run([pairs(100)])) == (0, 0)                      # too small to be worth deferring
+    long_rec = pairs(3000) + [genome[1000:1600], revcomp(genome[1200:1350])] + pairs(3000)
+    assert roads(lambda: run([long_rec])) == (1, 1)
+    one = None
+    for s in range(0, 5000, 7):                                            # a pair whose mate 1 carries >= 3 seeds at c = 200
+        if len(O.extract_markers(genome[s:s + 150], c=200, k=31)) >= 3:
+            one = [genome[s:s + 150], revcomp(genome[s + 200:s + 350])]
+            break
+    assert one is not None
+    assert roads(lambda: run([one * 20_000])) == (1, 1)                    # every block overflows its slots
+    assert roads(lambda: run([normal, pairs(4000)])) == (1, 0)             # the second push reads the first one's verdict itself
+    assert roads(lambda: run([long_rec, pairs(4000)])) == (1, 1)
+    single = [r for r in pairs(6000)]
+    assert roads(lambda: run([single], paired=False)) == (1, 0)
