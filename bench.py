@@ -149,9 +149,18 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     del dk
     torch.cuda.synchronize()
     t2 = time.time()
+    genome_ranges = None
     if db_mode == "shard":      # every rank generated the same database and keeps the postings of its k-mer range
         bounds = S.shard_bounds((2**64 - 1) // c - 1, world)
         db = S.Database(ctx, kmers.data_ptr(), goff.data_ptr(), device_ptrs=True, n_genomes=n_total, shard=(bounds, world, rank))
+    elif db_mode == "genome":   # north_star's wording: whole genomes per rank (contiguous ranges balanced by k-mer count), an unsharded index each
+        genome_ranges = SH.genome_shard_ranges(goff.cpu().numpy(), world)
+        g0, g1 = int(genome_ranges[rank]), int(genome_ranges[rank + 1])
+        k0 = int(goff[g0].item())
+        goff_loc = (goff[g0:g1 + 1] - goff[g0]).contiguous()
+        db = S.Database(ctx, kmers.data_ptr() + 8 * k0, goff_loc.data_ptr(), device_ptrs=True, n_genomes=g1 - g0)
+        ctx.synchronize()
+        del goff_loc
     else:
         db = S.Database(ctx, kmers.data_ptr(), goff.data_ptr(), device_ptrs=True, n_genomes=n_total)
     ctx.synchronize()
@@ -163,6 +172,7 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     # NB: no torch.cuda.empty_cache() here — returning tens of GB to the driver (hipFree) queues page-table work
     # that stalls this process's GPU queues for 15-40 ms at random moments over the next few hundred ms.
     del kmers, goff
+    stats["genome_ranges"] = [int(x) for x in genome_ranges] if genome_ranges is not None else None
     return db, int(n_total), community, stats, verify_set
 
 
@@ -239,7 +249,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SYLPH_BENCH_WORKLOAD", "auto"), choices=["auto"] + sorted(WORKLOADS))
-    ap.add_argument("--db-mode", default=os.environ.get("SYLPH_BENCH_DB_MODE", "auto"), choices=["auto", "replicate", "shard"])
+    ap.add_argument("--db-mode", default=os.environ.get("SYLPH_BENCH_DB_MODE", "auto"), choices=["auto", "replicate", "shard", "genome"])
     ap.add_argument("--mode", default=os.environ.get("SYLPH_BENCH_MODE", "auto"), choices=["auto", "pipelined", "sequential"],
                     help="which way of running the samples `value` is taken from (auto: the faster one of the untimed calibration)")
     ap.add_argument("--min-seconds", type=float, default=float(os.environ.get("SYLPH_BENCH_MIN_SECONDS", "2.0")),
@@ -435,6 +445,8 @@ def main():
             refs = [(dk, dc, nt) for _, (dk, dc, nt, _) in sess]
             if comm is not None:
                 res = db.contain_batch_sharded(comm, refs, device_ptrs=True)
+            elif db_mode == "genome":
+                res = SH.contain_batch_genome_sharded(dist, db, np.array(dbstats["genome_ranges"]), refs, device)
             else:
                 res = db.contain_batch(refs, device_ptrs=True)      # borrowed pinned views
             t_c = time.perf_counter()
@@ -478,7 +490,8 @@ def main():
             db, n_total, _, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
             pipe_box[0] = make_pipeline()
     run_sequential(2 * spb)
-    run_pipelined(max(2 * depth, 2 * spb))
+    if db_mode != "genome":
+        run_pipelined(max(2 * depth, 2 * spb))
     torch.cuda.synchronize()
 
     def measure(mode, n):
@@ -496,9 +509,13 @@ def main():
     n_cal = spb * int(min(400, max(2, round(0.25 / max(t_batch, 1e-6)))))
     cal = {"samples_per_mode": n_cal}
     for mode in ("pipelined", "sequential"):
+        if db_mode == "genome" and mode == "pipelined":
+            continue
         if args.mode in ("auto", mode) or not args.no_second_leg:
             cal[mode + "_ms_per_sample"] = round(measure(mode, n_cal) * 1e3, 4)
-    if args.mode != "auto":
+    if db_mode == "genome":
+        mode = "sequential"          # the genome-sharded arm is a step-at-a-time composition (sylph_amd/shard.py), not a pipeline
+    elif args.mode != "auto":
         mode = args.mode
     else:
         mode = "pipelined" if cal["pipelined_ms_per_sample"] <= cal["sequential_ms_per_sample"] else "sequential"
@@ -545,7 +562,7 @@ def main():
         runners[mode](sps)
     elapsed, step_s, gaps, rows, fam = timed(mode, args.steps, sps)
     second = None
-    if not args.no_second_leg:               # the same samples the other way, ~0.6 s of them
+    if not args.no_second_leg and db_mode != "genome":               # the same samples the other way, ~0.6 s of them
         n2 = max(spb, int(0.6 / max(cal.get(other + "_ms_per_sample", 1.5) * 1e-3, 1e-6) / spb) * spb)
         steps2 = max(1, min(args.steps, 4))
         per2 = max(spb, n2 // steps2 // spb * spb)
@@ -584,7 +601,7 @@ def main():
     # quarter of the bytes, no ASCII -> 2-bit conversion in the seeding kernel).  Reported beside `value`, never instead of it:
     # SURVEY 8d's 1.085 B/base is the ASCII input.
     packed_leg = None
-    if not args.no_packed_leg and not long_mode and wl != "c3r" and comm is None:
+    if not args.no_packed_leg and not long_mode and wl != "c3r" and comm is None and db_mode != "genome":
         try:
             packed_sets = []
             for rs in read_sets:
@@ -624,7 +641,11 @@ def main():
 
     comparisons = world * n_total                                             # every sample vs every genome of the DB
     parallelism = (f"{world} GPU(s), {mode}: " + (f"{n_workers} sketch worker contexts + 1 profile context per GPU, {depth} samples in flight, <= {max(spb, 8) if comm is None else spb} tables per probe launch" if mode == "pipelined" else f"one context per GPU, {spb} table(s) per probe launch") + "; database " +
-                   (f"sharded by k-mer range over {world} GPUs (per probe batch: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
+                   ("sharded by GENOME over the GPUs (contiguous ranges balanced by k-mer count, an unsharded index each): every table all-gathered to "
+                    "every rank and probed there, ONE all-gather of contain_count[S, G/W] + one of the coverage values (torch.distributed on "
+                    f"{'device tensors (RCCL)' if (dist is not None and dist.get_backend() == 'nccl') else 'host copies'}; sylph_amd/shard.py)"
+                    if db_mode == "genome" else
+                    f"sharded by k-mer range over {world} GPUs (per probe batch: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
                     f"{comm_kind})"
                     if comm is not None else ("replicated on every GPU (no data-path collective)" if world > 1 else "on the one GPU")))
     out = {

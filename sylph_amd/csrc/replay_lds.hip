@@ -984,8 +984,8 @@ __global__ __launch_bounds__(SCAN_CHUNK) void table_scan_kernel(const uint32_t* 
     }
 }
 // out[rows before bucket b + i] = tmp[boff[b] + i] for i < n_distinct[b]; a workgroup walks buckets with its four wavefronts
-// (one bucket holds ~50 rows).  Also assembles the 28-byte tail block the host reads: {removed u64, overflow u32 (set by the
-// replay), n_seg u32, n_ovf u32, n_mid u32, n_large u32}.
+// (one bucket holds ~50 rows).  Also assembles the 36-byte tail block the host reads: {removed u64, overflow u32 (set by the
+// replay), n_seg u32, n_ovf u32, n_mid u32, n_large u32, seeding verdict 2 x u32}.
 __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __restrict__ tmp_k, const uint32_t* __restrict__ tmp_c,
                                                             const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_loc,
                                                             const uint32_t* __restrict__ chunk_rows, const unsigned long long* __restrict__ chunk_removed,
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __re
                                                             uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
                                                             const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ mid_list,
                                                             const uint32_t* __restrict__ large_list, int skip_if_listed,
-                                                            uint32_t* __restrict__ tail) {
+                                                            uint32_t* __restrict__ tail, const uint32_t* __restrict__ verdict) {
     __shared__ uint32_t s_base[257];
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_rem[4];
@@ -1013,6 +1013,8 @@ __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __re
             if (threadIdx.x == 0) {
                 *reinterpret_cast<unsigned long long*>(tail) = s_rem[0] + s_rem[1] + s_rem[2] + s_rem[3];
                 tail[3] = tot; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
+                // deferred seeding verdict (reads.hip ReadsState: long_record, overflowing blocks) rides in the same block: one copy
+                tail[7] = verdict ? verdict[0] : 0u; tail[8] = verdict ? verdict[1] : 0u;
             }
         }
     }
@@ -1250,18 +1252,17 @@ bool finish_bucketed(sylph_sketch* sk) {
         hipLaunchKernelGGL(table_compact_kernel, dim3(std::min<uint32_t>((B + 3) / 4, 1u << 15)), dim3(256), 0, ctx->stream,
                            b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, chunk_rows, chunk_removed, n_distinct, B, ipt,
                            sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, skip_if_listed,
-                           b_small.as<uint32_t>());
+                           b_small.as<uint32_t>(),
+                           deferred ? sk->slot_meta.as<uint32_t>() + (size_t)(sk->pend.n_blk + 1) * 4 : (const uint32_t*)nullptr);
         SY_HIP(hipGetLastError());
     };
     struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf, n_mid, n_large; } host{};
     uint32_t verdict[2] = {0, 0};                  // deferred: long_record flag, overflowing blocks of the seeding kernel
     auto read_tail = [&] {
-        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 28, hipMemcpyDeviceToHost, ctx->stream));
-        if (deferred)   // the two flag words of ReadsState (reads.hip SlotMeta: behind the four block tables)
-            SY_HIP(hipMemcpyAsync((char*)ctx->pinned + 32, sk->slot_meta.as<uint32_t>() + (size_t)(sk->pend.n_blk + 1) * 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 36, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
         memcpy(&host, ctx->pinned, 28);
-        if (deferred) memcpy(verdict, (const char*)ctx->pinned + 32, 8);
+        if (deferred) memcpy(verdict, (const char*)ctx->pinned + 28, 8);   // (the two flag words of ReadsState, copied by table_compact_kernel)
         if (!ctx->pending.empty()) profile_collect(ctx);
     };
     close_table(1);

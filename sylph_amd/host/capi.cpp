@@ -1,6 +1,14 @@
 // capi.cpp — flat C entry points over the host library for ctypes tests (statistics + on-disk formats).
 #include <cstring>
 
+#include <sys/mman.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
 #include "sylph_host.hpp"
 
 using namespace sylph_host;
@@ -172,6 +180,29 @@ int sylph_host_fastq_index_count(const char* path, unsigned threads, uint64_t* n
     FastqIndex ix(path, threads);
     *n_records = ix.ok ? ix.n_records() : 0;
     return ix.ok ? 1 : 0;
+}
+
+// parallel_gunzip (pgunzip.cpp) on a file, for the tests: -> 1 and the inflated bytes' length + CRC-32 (and, if out != null with
+// room for them, the bytes) when the parallel path took the file; 0 when it declined (the feed then reads sequentially); -1: no file
+int sylph_host_pgunzip(const char* path, unsigned threads, uint64_t* out_len, uint32_t* out_crc, uint8_t* out, uint64_t out_cap) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    std::vector<uint8_t> gz;
+    uint8_t buf[1 << 16];
+    for (size_t r; (r = fread(buf, 1, sizeof(buf), f)) > 0;) gz.insert(gz.end(), buf, buf + r);
+    fclose(f);
+    uint8_t* o = nullptr;
+    size_t n = 0;
+    if (!sylph_host::parallel_gunzip(gz.data(), gz.size(), threads, &o, &n, 0)) return 0;
+    if (out_len) *out_len = n;
+    if (out_crc) {
+        uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (size_t q = 0; q < n; q += 1u << 30) c = (uint32_t)crc32(c, o + q, (uInt)std::min<size_t>(n - q, 1u << 30));
+        *out_crc = c;
+    }
+    if (out && out_cap >= n) memcpy(out, o, n);
+    munmap(o, n);
+    return 1;
 }
 
 }  // extern "C"

@@ -363,7 +363,21 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
         // blocked gzip: inflate all members in parallel into an anonymous mapping that takes the file mapping's place
         std::vector<BgzfBlock> blocks;
         size_t total = 0;
-        if (!bgzf_blocks(data, size, blocks, total) || total < 4) return;          // ordinary gzip: sequential reader
+        if (!bgzf_blocks(data, size, blocks, total) || total < 4) {
+            // an ordinary gzip file is ONE deflate stream: pgunzip.cpp inflates it on all parse threads where it can prove the
+            // result (member CRC); otherwise the sequential reader (needletail does the same, one thread)
+            uint8_t* buf = nullptr;
+            size_t n_out = 0;
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const unsigned tz = getenv("SYLPH_HIP_PARSE_THREADS") ? threads : std::max(threads, std::min(64u, hw / 2));
+            if (!parallel_gunzip(data, size, tz, &buf, &n_out, index_memory_budget())) return;
+            munmap((void*)data, size);
+            data = buf;
+            size = n_out;
+            anonymous = true;
+            blocks.clear();
+        }
+        if (!blocks.empty()) {
         // The inflated copy is anonymous memory: with overcommit the mapping always succeeds and a file (times the files indexed
         // at once) beyond what the machine has ends in the OOM killer instead of in the sequential reader, which runs in
         // constant memory.  The drivers set the budget from MemAvailable and their concurrency.
@@ -379,6 +393,7 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
         size = total;
         anonymous = true;
         if (!inflated) return;                                                     // (the sequential reader reports the damage)
+        }
     }
     const uint8_t* d = data;
     const size_t n = size;

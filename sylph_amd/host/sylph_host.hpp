@@ -112,6 +112,9 @@ struct FastqIndex {
     FastqIndex& operator=(const FastqIndex&) = delete;
     size_t n_records() const { return seq_len.size(); }
 };
+// pgunzip.cpp: parallel inflate of a single-member gzip file (block-start search + window-free decoding + CRC check); false = not
+// done (any doubt at all): the caller reads the file sequentially.  *out: anonymous mapping of *out_size bytes (munmap).
+bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** out, size_t* out_size, size_t memory_budget);
 unsigned parse_threads();   // worker threads of the parallel feed PER sample thread: SYLPH_HIP_PARSE_THREADS, else a quarter of the hardware threads (8..64), divided by set_parse_share
 void set_parse_share(unsigned sample_threads);   // the `-t` sample threads that run a feed each share the parse-thread budget
 constexpr size_t MAX_SAMPLE_THREADS = 16;        // each sample thread owns a GPU context + ~0.5 GB of page-locked batch buffers

@@ -159,3 +159,112 @@ def model_contain_batch_sharded(dist, bounds, n_genomes, samples, probe_fn):
         cc[row // n_genomes, row % n_genomes] += 1
         covs[row // n_genomes][row % n_genomes].append(cnt)
     return cc, [[np.array(x, dtype=np.uint32) for x in per] for per in covs]
+
+
+# ---- the other way to shard (north_star's wording): by GENOME, results reduced by one all-gather of containment counts -------------
+#
+# Every rank holds the whole sketches of a contiguous range of genomes (balanced by k-mer count) as an ordinary, unsharded database
+# of its own; every sample table must then be probed by EVERY rank (per-rank probe work per sample does not shrink with the number
+# of GPUs — why the library's default is the k-mer-range exchange of csrc/shard.hip), and what comes back is, per rank, the
+# containment counts of its genomes for all samples of the step: one all-gather of contain_count[S, G/W] (+ an all-gather of the
+# coverage values, sizes first) gives every rank the full answer for its own samples.  This arm exists for the A/B on the first
+# 8-GPU node (bench.py --db-mode genome); it is composed from the unsharded entry points + torch.distributed collectives (RCCL on
+# device tensors), not a second exchange inside the library.
+
+def genome_shard_ranges(genome_off, world):
+    """Contiguous genome ranges [g0, g1) per rank, balanced by the number of k-mers: world + 1 boundaries."""
+    off = np.asarray(genome_off, dtype=np.uint64)
+    G, total = len(off) - 1, int(off[-1])
+    b = [0]
+    for r in range(1, world):
+        b.append(int(np.searchsorted(off, total * r // world, side="left")))
+    b.append(G)
+    for i in range(1, len(b)):
+        b[i] = max(b[i], b[i - 1])
+    return np.array(b, dtype=np.int64)
+
+
+def contain_batch_genome_sharded(dist, db_local, ranges, refs, device, min_number_kmers=50.0):
+    """One step of the genome-sharded arm.  refs: this rank's [(dev_kmers_ptr, dev_counts_ptr, n)] (device-resident tables, the same
+    NUMBER on every rank); db_local: an unsharded Database over genomes [ranges[rank], ranges[rank + 1]).
+    -> (contain_count[n_local * G] uint32, cov_off[n_local * G + 1] int64, covs uint32) for this rank's samples, genomes in global order
+    (row = sample * G + genome: the layout of Database.contain_batch)."""
+    W, me = dist.get_world_size(), dist.get_rank()
+    n_local = len(refs)
+    G = int(ranges[-1])
+    on_dev = dist.get_backend() == "nccl"
+    cdev = device if on_dev else torch.device("cpu")
+
+    def gather(t):                                  # fixed-size all-gather of a tensor -> [W, ...]
+        t = t.to(cdev).contiguous()
+        out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=cdev)
+        dist.all_gather_into_tensor(out, t) if on_dev else dist.all_gather(list(out.unbind(0)), t)
+        return out
+
+    # 1. table sizes, then the tables themselves (padded to the longest one: all-gather wants equal blocks)
+    sizes = gather(torch.tensor([r[2] for r in refs], dtype=torch.int64))                    # [W, n_local]
+    n_max = max(1, int(sizes.max().item()))
+    k_blk = torch.zeros((n_local, n_max), dtype=torch.int64, device=device)
+    c_blk = torch.zeros((n_local, n_max), dtype=torch.int32, device=device)
+    for s, (kp, cp, n) in enumerate(refs):
+        if n:
+            k_blk[s, :n] = device_view(kp, n, torch.int64, device)
+            c_blk[s, :n] = device_view(cp, n, torch.int32, device)
+    all_k, all_c = gather(k_blk).to(device), gather(c_blk).to(device)                        # [W, n_local, n_max]
+    # 2. every table of the step against this rank's genomes
+    S_total = W * n_local
+    tabs = [(all_k[r, s].data_ptr(), all_c[r, s].data_ptr(), int(sizes[r, s].item())) for r in range(W) for s in range(n_local)]
+    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    cc, off, covs = db_local.contain_batch(tabs, min_number_kmers=min_number_kmers, device_ptrs=True)
+    G_loc = int(ranges[me + 1] - ranges[me])
+    cc = torch.from_numpy(np.array(cc, dtype=np.uint32).astype(np.int32)).view(S_total, G_loc)
+    covs = torch.from_numpy(np.asarray(covs).astype(np.int32))
+    off = np.array(off, dtype=np.int64)
+    # 3. THE all-gather of north_star: contain_count[S, G/W] of every shard (padded to the widest shard)
+    G_max = int(max(ranges[r + 1] - ranges[r] for r in range(W)))
+    cc_pad = torch.zeros((S_total, G_max), dtype=torch.int32)
+    cc_pad[:, :G_loc] = cc
+    all_cc = gather(cc_pad).cpu().numpy().astype(np.uint32)                                  # [W, S_total, G_max]
+    # 4. the coverage values: sizes first, then the payload padded to the longest list
+    n_cov = gather(torch.tensor([covs.numel()], dtype=torch.int64)).cpu().numpy().reshape(-1)
+    cov_pad = torch.zeros(max(1, int(n_cov.max())), dtype=torch.int32)
+    cov_pad[:covs.numel()] = covs
+    all_cov = gather(cov_pad).cpu().numpy().astype(np.uint32)                                # [W, max]
+    # 5. this rank's samples, genomes back in global order (rows of one sample are contiguous in every shard's block)
+    out_cc = np.zeros((n_local, G), dtype=np.uint32)
+    pieces = []
+    for s in range(n_local):
+        row = me * n_local + s
+        for r in range(W):
+            g0, g1 = int(ranges[r]), int(ranges[r + 1])
+            counts = all_cc[r, row, :g1 - g0]
+            out_cc[s, g0:g1] = counts
+            start = int(all_cc[r, :row, :g1 - g0].sum())                                    # hits of the shard's rows before this sample
+            pieces.append(all_cov[r, start:start + int(counts.sum())])
+    out_cov = np.concatenate(pieces) if pieces else np.zeros(0, np.uint32)
+    out_off = np.zeros(n_local * G + 1, dtype=np.int64)
+    out_off[1:] = np.cumsum(out_cc.reshape(-1).astype(np.int64))
+    return out_cc.reshape(-1), out_off, out_cov
+
+
+def model_contain_batch_genome_sharded(dist, ranges, samples, probe_fn):
+    """The same protocol on host arrays with a pluggable probe (tests/test_dist.py, gloo): samples = this rank's [(kmers, counts)],
+    probe_fn(kmers, counts) -> (contain_count[G_local], [sorted covs per local genome]).  -> (contain_count[n_local, G], covs[s][g])."""
+    W, me = dist.get_world_size(), dist.get_rank()
+    got = [None] * W
+    dist.all_gather_object(got, samples)                                  # every table to every rank
+    n_local = len(samples)
+    mine = [[probe_fn(k, c) for (k, c) in got[r]] for r in range(W)]      # [owner rank][sample] -> (cc_local, covs_local)
+    allres = [None] * W
+    dist.all_gather_object(allres, mine)                                  # "one all-gather of the containment counts" (+ covs)
+    G = int(ranges[-1])
+    cc = np.zeros((n_local, G), dtype=np.uint32)
+    covs = [[None] * G for _ in range(n_local)]
+    for s in range(n_local):
+        for r in range(W):
+            ccl, covl = allres[r][me][s]
+            g0 = int(ranges[r])
+            cc[s, g0:g0 + len(ccl)] = ccl
+            for j, v in enumerate(covl):
+                covs[s][g0 + j] = np.asarray(v, dtype=np.uint32)
+    return cc, covs

@@ -280,3 +280,59 @@ def test_library_exchange_bookkeeping_gloo(world):
     ret = mgr.dict()
     mp.spawn(_plan_worker, args=(world, port, ret), nprocs=world, join=True)
     assert [ret.get(r) for r in range(world)] == [True] * world
+
+
+# ---- the genome-sharded arm (north_star's wording; bench.py --db-mode genome) -----------------------------------------------------
+
+def _genome_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pool, genomes = make_db()
+        G = len(genomes)
+        goff = np.zeros(G + 1, dtype=np.uint64)
+        goff[1:] = np.cumsum([len(g) for g in genomes])
+        ranges = SH.genome_shard_ranges(goff, world)
+        g0, g1 = int(ranges[rank]), int(ranges[rank + 1])
+        loc = genomes[g0:g1]
+        lflat = np.concatenate(loc) if loc and sum(len(g) for g in loc) else np.zeros(0, np.uint64)
+        loff = np.zeros(len(loc) + 1, dtype=np.uint64)
+        loff[1:] = np.cumsum([len(g) for g in loc])
+
+        def probe(k, c):
+            cc, covs, _ = O.contain(k, c, lflat, loff)
+            return cc, [np.sort(x) for x in covs]
+        samples = make_samples(pool, rank, 2)                 # (the same number on every rank: what the arm's fixed-size all-gathers need)
+        cc, covs = SH.model_contain_batch_genome_sharded(dist, ranges, samples, probe)
+        db = np.concatenate(genomes)
+        ok = cc.shape == (2, G) and int(ranges[0]) == 0 and int(ranges[-1]) == G and all(ranges[i] <= ranges[i + 1] for i in range(world))
+        for s, (k, c) in enumerate(samples):
+            ecc, ecov, _ = O.contain(k, c, db, goff)
+            ok = ok and np.array_equal(cc[s], ecc) and all(np.array_equal(covs[s][g], np.sort(ecov[g])) for g in range(G))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_genome_sharded_arm_gloo(world):
+    """Genomes split into contiguous ranges balanced by k-mer count, every table probed by every rank, one all-gather of the per-shard
+    containment counts (+ coverage values): each rank recovers the single-process answer for its own samples."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_genome_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert [ret.get(r) for r in range(world)] == [True] * world
+
+
+def test_genome_shard_ranges_balance():
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 5000, size=1000)
+    off = np.zeros(1001, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    for w in (1, 2, 3, 8):
+        r = SH.genome_shard_ranges(off, w)
+        assert r[0] == 0 and r[-1] == 1000 and len(r) == w + 1 and all(r[i] <= r[i + 1] for i in range(w))
+        per = [int(off[r[i + 1]] - off[r[i]]) for i in range(w)]
+        assert max(per) - min(per) <= 2 * 5000            # within one genome of each other

@@ -1185,6 +1185,13 @@ def test_hit_row_assembly_paths(ctx):
         cc = check_contain(ctx, db_k, goff, sk, sc, min_kmers=0.0)
         assert cc[0] == len(big[0]) or sc is counts_zero
         assert int(cc.sum()) > 1_000_000 or sc is counts_zero
+    # more distinct rows in one workgroup's stretch of the hit list than its LDS table takes (20,000 genomes, every one hit ~60
+    # times by a table that holds the whole pool): the table freezes and the rest of the rows go straight to the global counters
+    pool = np.unique(rng.integers(0, thr, size=50_000, dtype=np.uint64))
+    many = [rng.choice(pool, size=int(rng.integers(40, 80)), replace=False) for _ in range(20_000)]
+    mk, moff = flat_db(many)
+    cc = check_contain(ctx, mk, moff, pool, rng.integers(1, 250, size=len(pool)).astype(np.uint32), min_kmers=0.0)
+    assert int((cc > 0).sum()) == 20_000
     # the same database object through row spaces of different sizes, and a thinned table whose hits fit the first buffer
     db = S.Database(ctx, db_k, goff)
     G = len(goff) - 1

@@ -176,3 +176,24 @@ def test_bench_two_ranks_on_one_gpu_small_workload():
     assert "sharded by k-mer range over 2 GPUs" in d["config"]["parallelism"]
     legs = [d] + [d[k] for k in ("pipelined", "one_step_at_a_time") if k in d and "exchange" in d[k]]
     assert any("exchange" in leg and leg["exchange"]["probe_batches"] > 0 and leg["exchange"]["hit_bytes_sent_per_batch"] > 0 for leg in legs)
+
+
+def test_bench_two_ranks_genome_sharded_arm():
+    """`bench.py --gpus 2 --db-mode genome`: north_star's wording of the multi-GPU path (whole genomes per rank, one all-gather of the
+    containment counts) as the A/B arm of sylph_amd/shard.py — two ranks on whatever the box has, torch.distributed over gloo on host
+    copies; the verify leg compares a sample's assembled result (genomes of both shards, global order) with the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29579")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small", "--db-mode", "genome", "--steps", "2",
+                        "--warmup", "1", "--min-seconds", "0.2", "--no-cpu-baseline", "--no-h2d"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["mode"] == "sequential"
+    assert d["verify"]["mismatches"] == 0 and d["verify"]["genomes_checked"] > 0 and d["verify"]["genomes_with_hits"] > 0
+    assert "sharded by GENOME" in d["config"]["parallelism"]

@@ -577,3 +577,69 @@ def test_parallel_2bit_packer_matches_byte_to_seq(host):
                 assert np.array_equal(out[:len(expect)], expect), (trial, parts, slack)
             # bytes wholly inside the stream must match; the last (partial) byte too — the writers zero-fill its unused bits
             assert np.array_equal(out[:len(expect)], expect), (trial, parts)
+
+
+def test_parallel_gunzip_of_single_member_gzip(host, tmp_path):
+    """host/pgunzip.cpp: an ORDINARY gzip file inflated by several threads — block starts found by search,
+    every stretch decoded without its 32 KiB window (symbolic back-references), windows handed down the chain, the member's CRC as
+    the final word.  Against Python's gzip for every compression level's block structure (stored / fixed / dynamic blocks), stretch
+    sizes down to 64 KiB (many block-start searches), CRLF and multi-line content; and it must DECLINE — return 0, the feed then
+    reads sequentially — whatever it cannot prove: two members, a damaged byte, bytes no FASTQ holds, a file too small to split."""
+    import gzip
+    host.sylph_host_pgunzip.argtypes = [C.c_char_p, C.c_uint, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(8)
+
+    def fastq(n_reads, crlf=False):
+        nl = b"\r\n" if crlf else b"\n"
+        out = bytearray()
+        base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=200_000)
+        for i in range(n_reads):
+            s = int(rng.integers(0, 199_000))
+            L = int(rng.integers(50, 251))
+            q = rng.integers(35, 45, size=L, dtype=np.uint8).tobytes()
+            out += b"@r%d lane:%d" % (i, i % 8) + nl + base[s:s + L].tobytes() + nl + b"+" + nl + q + nl
+        return bytes(out)
+
+    def run(path, threads, expect):
+        n, c = C.c_uint64(0), C.c_uint32(0)
+        buf = (C.c_uint8 * max(1, len(expect) if expect is not None else 1))()
+        rc = host.sylph_host_pgunzip(str(path).encode(), threads, C.byref(n), C.byref(c), buf, len(buf))
+        if expect is None:
+            return rc
+        assert rc == 1 and n.value == len(expect) and bytes(buf) == expect, (str(path), threads, rc, n.value, len(expect))
+        return rc
+
+    os.environ["SYLPH_HIP_PGZ_STRETCH"] = "65536"
+    try:
+        data = fastq(40_000)
+        for lvl in (1, 4, 6, 9):
+            p = tmp_path / f"l{lvl}.fq.gz"
+            p.write_bytes(gzip.compress(data, compresslevel=lvl))
+            for thr in (2, 5, 16):
+                run(p, thr, data)
+        crlf = fastq(8_000, crlf=True)
+        p = tmp_path / "crlf.fq.gz"
+        p.write_bytes(gzip.compress(crlf, compresslevel=6))
+        run(p, 8, crlf)
+        # level 0: stored blocks only — no dynamic block to start a stretch at: declined
+        p = tmp_path / "stored.fq.gz"
+        p.write_bytes(gzip.compress(data[:2_000_000], compresslevel=0))
+        assert run(p, 8, None) == 0
+        # two members, a flipped byte in the middle, a binary payload, a tiny file: all declined
+        p = tmp_path / "two.fq.gz"
+        p.write_bytes(gzip.compress(data[:3_000_000]) + gzip.compress(data[3_000_000:6_000_000]))
+        assert run(p, 8, None) == 0
+        good = bytearray(gzip.compress(data, compresslevel=6))
+        good[len(good) // 2] ^= 0x40
+        p = tmp_path / "bad.fq.gz"
+        p.write_bytes(bytes(good))
+        assert run(p, 8, None) == 0
+        p = tmp_path / "bin.gz"
+        p.write_bytes(gzip.compress(rng.integers(0, 256, size=3_000_000, dtype=np.uint8).tobytes() + data[:1_000_000], compresslevel=6))
+        assert run(p, 8, None) == 0
+        p = tmp_path / "tiny.fq.gz"
+        p.write_bytes(gzip.compress(data[:20_000]))
+        assert run(p, 8, None) == 0
+        assert run(tmp_path / "nonexistent.gz", 8, None) == -1
+    finally:
+        os.environ.pop("SYLPH_HIP_PGZ_STRETCH", None)
