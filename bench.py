@@ -206,6 +206,62 @@ def cpu_baseline(bases, rec_off, n_pairs, read_len, c, k, db_host, whole):
                 sketch_s=t_sketch, probe_s=t_probe, table=sk, contain_count=cc, cov=cov, genome_off=dbo)
 
 
+def end_to_end_from_files(bases, n_pairs_total, read_len, n_pairs):
+    """Untimed w.r.t. `value`: the first n_pairs pairs of a read set written as FASTQ files on local disk (plain, and `gzip -1`:
+    one ordinary single-member .gz per mate), then the product's own command on them — `sylph-hip sketch -1 .. -2 ..` — wall clock
+    of the WHOLE command (process start, GPU bring-up, parsing / inflating, H2D, kernels, .sylsp written), and the per-sample
+    times the command logs (the first sample of a process pays the bring-up; the later ones of a 4-sample command are warm)."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import feed_bench as FB
+    n_pairs = int(min(n_pairs, n_pairs_total))
+    d = tempfile.mkdtemp(prefix="sylph_e2e_")
+    try:
+        hb = bases[: n_pairs * 2 * read_len].cpu().numpy().reshape(n_pairs, 2, read_len)
+        FB.write_fastq(f"{d}/s_1.fq", np.ascontiguousarray(hb[:, 0, :]).reshape(-1), read_len)
+        FB.write_fastq(f"{d}/s_2.fq", np.ascontiguousarray(hb[:, 1, :]).reshape(-1), read_len)
+        del hb
+        gz = [subprocess.Popen(["gzip", "-1", "-k", "-f", f"{d}/s_{m}.fq"]) for m in (1, 2)]
+        for i in range(1, 4):
+            for m in (1, 2):
+                os.symlink(f"{d}/s_{m}.fq", f"{d}/p{i}_{m}.fq")
+        os.symlink(f"{d}/s_1.fq", f"{d}/p0_1.fq")
+        os.symlink(f"{d}/s_2.fq", f"{d}/p0_2.fq")
+        gbp = 2 * n_pairs * read_len / 1e9
+        env = dict(os.environ, SYLPH_HIP_EXACT_DEDUP="1")
+        exe = os.path.join(ROOT, "sylph_amd", "sylph-hip")
+
+        def run(args):
+            t = time.perf_counter()
+            p = subprocess.run([exe, "sketch", *args, "-d", f"{d}/out"], capture_output=True, text=True, env=env, timeout=600)
+            dt = time.perf_counter() - t
+            if p.returncode != 0:
+                raise RuntimeError(p.stderr[-500:])
+            per = [float(ln.split(" in ")[1].split(" s")[0]) for ln in p.stderr.split("\n") if "timing:" in ln]
+            return dt, per
+        out = {"pairs_per_sample": n_pairs, "gbp_per_sample": round(gbp, 4), "host_threads": os.cpu_count(),
+               "what": "`sylph-hip sketch` on FASTQ files in a temporary directory: whole-command wall clock and the per-sample times it logs"}
+        dt, per = run(["-1", *[f"{d}/p{i}_1.fq" for i in range(4)], "-2", *[f"{d}/p{i}_2.fq" for i in range(4)], "-t", "1"])
+        out["plain_four_samples_one_command"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(4 * gbp / dt, 3),
+                                                 "sample_gbp_per_s_in_order": [round(gbp / x, 2) for x in per]}
+        dt, per = run(["-1", f"{d}/s_1.fq", "-2", f"{d}/s_2.fq"])
+        out["plain_one_sample"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(gbp / dt, 3),
+                                   "sample_gbp_per_s": round(gbp / per[0], 2) if per else None}
+        for g in gz:
+            g.wait()
+        out["gz_bytes_per_file"] = os.path.getsize(f"{d}/s_1.fq.gz")
+        dt, per = run(["-1", f"{d}/s_1.fq.gz", "-2", f"{d}/s_2.fq.gz"])
+        out["gz_one_sample"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(gbp / dt, 3),
+                                "sample_gbp_per_s": round(gbp / per[0], 2) if per else None,
+                                "what": "one ordinary (single-member) gzip -1 file per mate: inflated on the host's threads by host/pgunzip.cpp"}
+        dt, per = run(["-1", f"{d}/s_1.fq.gz", "-2", f"{d}/s_2.fq.gz"])
+        out["gz_one_sample"]["second_run_command_gbp_per_s"] = round(gbp / dt, 3)
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def verify_against_oracle(ctx, res, G, sample_ptrs, verify_set, device):
     """Untimed: the last step's first sample — contain_count and the sorted coverage vector of every genome of the verify set
     (all sequence-backed genomes + 2,000 decoys) against the CPU oracle probing the same table."""
@@ -263,6 +319,8 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
     ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 3)")
     ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 3; sharded: two probe batches)")
+    ap.add_argument("--no-files-leg", action="store_true", help="skip the leg that runs `sylph-hip sketch` on FASTQ files (plain, gzip)")
+    ap.add_argument("--files-leg-pairs", type=int, default=1_000_000, help="read pairs per sample of that leg (default 1 M = 0.3 Gbp)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the leg of the mode `value` is NOT taken from")
     ap.add_argument("--seed", type=int, default=20250711)
@@ -906,6 +964,11 @@ def main():
                     out["verify"]["mismatches"] = int(bad) + 1
         except Exception as e:  # the baseline leg must never sink the GPU measurement
             out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0 and world == 1 and not args.no_files_leg and not args.no_h2d and not long_mode and wl in ("c2", "c3", "c4"):
+        try:
+            out["end_to_end_from_files"] = end_to_end_from_files(read_sets[0]["bases"], n_pairs, read_len, args.files_leg_pairs)
+        except Exception as e:
+            out["end_to_end_from_files"] = {"error": str(e)[:400]}
     sys.stdout.flush()
     try:                      # C stdio of the libraries (RCCL's banner) is still buffered: flush it while fd 1 is stderr
         import ctypes

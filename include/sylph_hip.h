@@ -67,6 +67,21 @@ int sylph_ctx_create(int device, void *stream, sylph_ctx **out);
 void sylph_ctx_destroy(sylph_ctx *ctx);
 int sylph_ctx_synchronize(sylph_ctx *ctx);
 
+/* ---- staged host -> device upload ----------------------------------------------------------------------------------------
+ * A device buffer of `bytes` bytes filled from the host through two page-locked chunks the LIBRARY owns: the caller fills one
+ * (sylph_upload_chunk hands it out, waiting for the copy that last used it) while the other travels (sylph_upload_commit queues the
+ * copy of the chunk's first n bytes to the next device offset).  For data that does not lie in one piece on the host — the
+ * genome_kmers vectors of a 13 GB .syldb file (types.rs:163-173; contain.rs:492-500 deserialises them on one thread, the dominant
+ * cost of a one-sample `sylph profile`) are interleaved with names and tracked k-mers: the host gathers them from the file MAPPING
+ * straight into the chunks with all its threads, and hands the device pointer to sylph_db_upload / sylph_db_attach_tracked with
+ * SYLPH_MEM_DEVICE.  sylph_upload_finish waits for the last copy and returns the device pointer, valid until sylph_upload_destroy. */
+typedef struct sylph_upload sylph_upload;
+int sylph_upload_begin(sylph_ctx *ctx, uint64_t bytes, uint64_t chunk_bytes, sylph_upload **out);
+int sylph_upload_chunk(sylph_upload *u, void **chunk, uint64_t *cap);
+int sylph_upload_commit(sylph_upload *u, uint64_t n);
+int sylph_upload_finish(sylph_upload *u, const void **device_ptr);
+void sylph_upload_destroy(sylph_upload *u);
+
 /* Tuning / test knobs (not needed for normal use).  "finish" = "auto" (default: bucket partition + in-LDS replay,
  * falling back to the device-wide sort path when a bucket does not fit), "generic" (always the device-wide path) or
  * "bucket" (error instead of falling back).  "seeds" = "auto" (default: the read-per-lane kernel for short-read batches, the

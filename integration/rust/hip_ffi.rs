@@ -5,6 +5,7 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct SylphSketch { _p: [u8; 0] }
 #[repr(C)] pub struct SylphDb { _p: [u8; 0] }
 #[repr(C)] pub struct SylphComm { _p: [u8; 0] }
+#[repr(C)] pub struct SylphUpload { _p: [u8; 0] }
 #[repr(C)] pub struct SylphSampleRef { pub kmers: *const u64, pub counts: *const u32, pub n: u64 }   // one sorted (k-mer, count) table
 #[repr(C)] pub struct SylphCommOps {   // caller-supplied collectives on device buffers (stream = hipStream_t); 0 = success
     pub all_gather: extern "C" fn(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes: u64, stream: *mut c_void) -> c_int,
@@ -49,6 +50,12 @@ extern "C" {
     pub fn sylph_sketch_finish(sk: *mut SylphSketch, out_kmers: *mut *mut u64, out_counts: *mut *mut u32,
                                out_n: *mut u64, out_dup_removed: *mut u64) -> c_int;
     pub fn sylph_sketch_destroy(sk: *mut SylphSketch);
+    // staged upload of data that lies in pieces on the host (the genome_kmers of a mapped .syldb): two page-locked chunks owned by the library
+    pub fn sylph_upload_begin(ctx: *mut SylphCtx, bytes: u64, chunk_bytes: u64, out: *mut *mut SylphUpload) -> c_int;
+    pub fn sylph_upload_chunk(u: *mut SylphUpload, chunk: *mut *mut c_void, cap: *mut u64) -> c_int;
+    pub fn sylph_upload_commit(u: *mut SylphUpload, n: u64) -> c_int;
+    pub fn sylph_upload_finish(u: *mut SylphUpload, device_ptr: *mut *const c_void) -> c_int;
+    pub fn sylph_upload_destroy(u: *mut SylphUpload);
     // "borrow_until_finish" = "1": device batches stay valid until finish -> one host round trip per sample instead of two
     pub fn sylph_sketch_set_option(sk: *mut SylphSketch, key: *const c_char, value: *const c_char) -> c_int;
     // replace the probe half of get_stats (contain.rs:601-656) for all genomes of a loaded database

@@ -32,7 +32,8 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_comm_create_rccl", "sylph_comm_create", "sylph_comm_destroy", "sylph_db_contain_batch_sharded",
            "sylph_pipeline_create", "sylph_pipeline_submit", "sylph_pipeline_submit_session", "sylph_pipeline_flush", "sylph_pipeline_next",
            "sylph_pipeline_outstanding", "sylph_pipeline_set_option", "sylph_pipeline_profile", "sylph_pipeline_kernel_stats",
-           "sylph_pipeline_destroy", "sylph_db_exchange_stats", "sylph_sketch_set_option"]
+           "sylph_pipeline_destroy", "sylph_db_exchange_stats", "sylph_sketch_set_option",
+           "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_destroy"]
 
 
 def load():

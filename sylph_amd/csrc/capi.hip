@@ -1,5 +1,6 @@
 // capi.hip — context, error reporting and profiling hooks of the C ABI (include/sylph_hip.h).
 #include <algorithm>
+#include <memory>
 
 #include "common.h"
 
@@ -253,6 +254,98 @@ int sylph_pinned_alloc(uint64_t bytes, void** out) {
 
 void sylph_pinned_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"
+
+struct sylph_upload {
+    sylph_ctx* ctx = nullptr;
+    sylph::DevBuf dev;
+    uint64_t bytes = 0, at = 0, chunk_cap = 0;
+    void* chunk[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    int cur = -1;                            // the chunk handed out and not yet committed
+    int next = 0;
+    hipStream_t stream = nullptr;            // copies travel on a stream of their own (the context's stream may be busy with an index build)
+};
+
+extern "C" {
+
+int sylph_upload_begin(sylph_ctx* ctx, uint64_t bytes, uint64_t chunk_bytes, sylph_upload** out) {
+    return guarded([&] {
+        SY_REQUIRE(ctx && out, "null argument");
+        DeviceGuard dg(ctx->device);
+        std::unique_ptr<sylph_upload> u(new sylph_upload());
+        u->ctx = ctx;
+        u->bytes = bytes;
+        u->chunk_cap = std::max<uint64_t>(1u << 20, std::min<uint64_t>(chunk_bytes ? chunk_bytes : (128ull << 20), 1ull << 30));
+        u->dev.alloc(bytes + 64);             // (plain hipMalloc: a buffer of this size does not belong in the context's pool)
+        try {
+            SY_HIP(hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) {
+                SY_HIP(hipHostMalloc(&u->chunk[i], u->chunk_cap, hipHostMallocDefault));
+                SY_HIP(hipEventCreateWithFlags(&u->ev[i], hipEventDisableTiming));
+            }
+        } catch (...) { sylph_upload_destroy(u.release()); throw; }
+        ctx->refs++;
+        *out = u.release();
+    });
+}
+
+int sylph_upload_chunk(sylph_upload* u, void** chunk, uint64_t* cap) {
+    return guarded([&] {
+        SY_REQUIRE(u && chunk && cap, "null argument");
+        SY_REQUIRE_STATE(u->cur < 0, "sylph_upload_chunk: the previous chunk has not been committed");
+        DeviceGuard dg(u->ctx->device);
+        const int i = u->next;
+        if (u->used[i]) SY_HIP(hipEventSynchronize(u->ev[i]));      // the copy that last read this chunk
+        u->cur = i;
+        *chunk = u->chunk[i];
+        *cap = u->chunk_cap;
+    });
+}
+
+int sylph_upload_commit(sylph_upload* u, uint64_t n) {
+    return guarded([&] {
+        SY_REQUIRE(u, "null argument");
+        SY_REQUIRE_STATE(u->cur >= 0, "sylph_upload_commit without a chunk");
+        SY_REQUIRE(n <= u->chunk_cap && u->at + n <= u->bytes, "sylph_upload_commit: %llu bytes do not fit (%llu of %llu uploaded)",
+                   (unsigned long long)n, (unsigned long long)u->at, (unsigned long long)u->bytes);
+        DeviceGuard dg(u->ctx->device);
+        const int i = u->cur;
+        if (n) SY_HIP(hipMemcpyAsync(u->dev.as<char>() + u->at, u->chunk[i], n, hipMemcpyHostToDevice, u->stream));
+        SY_HIP(hipEventRecord(u->ev[i], u->stream));
+        u->used[i] = true;
+        u->at += n;
+        u->cur = -1;
+        u->next = i ^ 1;
+    });
+}
+
+int sylph_upload_finish(sylph_upload* u, const void** device_ptr) {
+    return guarded([&] {
+        SY_REQUIRE(u && device_ptr, "null argument");
+        SY_REQUIRE_STATE(u->cur < 0, "sylph_upload_finish: a chunk is still out");
+        SY_REQUIRE(u->at == u->bytes, "sylph_upload_finish: %llu of %llu bytes uploaded", (unsigned long long)u->at, (unsigned long long)u->bytes);
+        DeviceGuard dg(u->ctx->device);
+        SY_HIP(hipStreamSynchronize(u->stream));
+        *device_ptr = u->dev.p;
+    });
+}
+
+void sylph_upload_destroy(sylph_upload* u) {
+    if (!u) return;
+    (void)hipSetDevice(u->ctx->device);
+    if (u->stream) { (void)hipStreamSynchronize(u->stream); (void)hipStreamDestroy(u->stream); }
+    for (int i = 0; i < 2; i++) {
+        if (u->chunk[i]) (void)hipHostFree(u->chunk[i]);
+        if (u->ev[i]) (void)hipEventDestroy(u->ev[i]);
+    }
+    u->dev.release();
+    sylph_ctx* ctx = u->ctx;
+    delete u;
+    sylph::ctx_unref(ctx);
 }
 
 int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {

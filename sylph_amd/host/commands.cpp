@@ -821,8 +821,9 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
     // get_genome_sketches, contain.rs:482-541
     std::vector<GenomeSketch> genome_sketches;
     std::optional<uint64_t> lowest_genome_c, current_k;
+    static const bool copy_load = getenv("SYLPH_HIP_DB_COPY_LOAD") != nullptr;   // A/B + tests: every genome copied into vectors first (rounds 1-3)
     for (const auto& f : genome_sketch_files) {
-        auto v = read_syldb(f);
+        auto v = copy_load ? read_syldb(f) : read_syldb_views(f);
         if (v.empty()) continue;
         const uint64_t c = v.front().c, k = v.front().k;
         if (!lowest_genome_c || *lowest_genome_c < c) lowest_genome_c = c;
@@ -841,24 +842,103 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
     batch.flush();
     info("Finished obtaining genome sketches.");
     if (genome_sketches.empty()) throw Error{1, "No genome sketches found; see sylph query/profile -h for help. Exiting"};
-    if (!genome_sketches.front().pseudotax_tracked_nonused_kmers && args.pseudotax)
+    if (!genome_sketches.front().has_tracked() && args.pseudotax)
         throw Error{1, "Attempting profiling, but *.syldb was sketched with the --disable-profiling option. Exiting"};   // :234-237
 
-    // database resident in HBM (replaces the per-genome probe loop of contain.rs:284-291)
-    std::vector<uint64_t> flat, goff{0};
-    for (const auto& g : genome_sketches) { flat.insert(flat.end(), g.genome_kmers.begin(), g.genome_kmers.end()); goff.push_back(flat.size()); }
-    sylph_db* db = nullptr;
-    hip_check(sylph_db_upload(e.context(), flat.data(), goff.data(), genome_sketches.size(), SYLPH_MEM_HOST, &db), "sylph_db_upload");
-    struct DbGuard { sylph_db* d; ~DbGuard() { sylph_db_destroy(d); } } guard{db};
-    { std::vector<uint64_t>().swap(flat); }
-    if (args.pseudotax) {   // the winner table also ranges over pseudotax_tracked_nonused_kmers (contain.rs:421-428)
-        std::vector<uint64_t> tflat, toff{0};
-        for (const auto& g : genome_sketches) {
-            if (g.pseudotax_tracked_nonused_kmers)
-                tflat.insert(tflat.end(), g.pseudotax_tracked_nonused_kmers->begin(), g.pseudotax_tracked_nonused_kmers->end());
-            toff.push_back(tflat.size());
+    // database resident in HBM (replaces the per-genome probe loop of contain.rs:284-291).  The k-mers go from where they lie — the
+    // mapped .syldb files (views), or the vectors of genomes sketched in this run — through the library's page-locked upload chunks
+    // to the device, gathered by all parse threads: no per-genome vector, no flat host copy, the copy of one chunk travels while the
+    // next is gathered (round 4; rounds 1-3: 113,104 vectors + one 11 GB concatenation + a staged pageable copy)
+    const auto t_db0 = std::chrono::steady_clock::now();
+    auto upload_gathered = [&](bool tracked, std::vector<uint64_t>& off, sylph_upload** up_out) -> const uint64_t* {
+        off.assign(1, 0);
+        for (const auto& g : genome_sketches) off.push_back(off.back() + (tracked ? g.n_tracked() : g.n_kmers()));
+        const uint64_t total = off.back() * 8;
+        sylph_upload* up = nullptr;
+        hip_check(sylph_upload_begin(e.context(), total, 256ull << 20, &up), "sylph_upload_begin");
+        *up_out = up;
+        const unsigned T = std::max(1u, parse_threads());
+        uint64_t at = 0;                                   // bytes of the flat array gathered so far
+        size_t g0 = 0;                                     // first genome that still has bytes to give
+        while (at < total) {
+            void* chunk = nullptr;
+            uint64_t cap = 0;
+            hip_check(sylph_upload_chunk(up, &chunk, &cap), "sylph_upload_chunk");
+            const uint64_t n = std::min<uint64_t>(cap & ~7ull, total - at);
+            std::vector<std::thread> th;
+            std::exception_ptr err;
+            auto piece = [&](unsigned w) {
+                const uint64_t b0 = at + n / T * w / 8 * 8, b1 = w + 1 == T ? at + n : at + n / T * (w + 1) / 8 * 8;
+                size_t g = (size_t)(std::upper_bound(off.begin() + (long)g0, off.end(), b0 / 8) - off.begin()) - 1;   // genome holding byte b0
+                for (uint64_t b = b0; b < b1;) {
+                    while (off[g + 1] * 8 <= b) g++;
+                    const GenomeSketch& gs = genome_sketches[g];
+                    const uint8_t* src = tracked ? gs.tracked_bytes() : gs.kmers_bytes();
+                    const uint64_t in_g = b - off[g] * 8, len = std::min<uint64_t>(off[g + 1] * 8 - b, b1 - b);
+                    memcpy((uint8_t*)chunk + (b - at), src + in_g, len);
+                    b += len;
+                }
+            };
+            for (unsigned w = 1; w < T; w++) th.emplace_back(piece, w);
+            piece(0);
+            for (auto& t : th) t.join();
+            hip_check(sylph_upload_commit(up, n), "sylph_upload_commit");
+            at += n;
+            while (g0 + 1 < off.size() && off[g0 + 1] * 8 <= at) g0++;
         }
-        hip_check(sylph_db_attach_tracked(db, tflat.data(), toff.data(), SYLPH_MEM_HOST), "sylph_db_attach_tracked");
+        const void* dev = nullptr;
+        hip_check(sylph_upload_finish(up, &dev), "sylph_upload_finish");
+        return (const uint64_t*)dev;
+    };
+    struct UploadGuard { sylph_upload* u = nullptr; ~UploadGuard() { sylph_upload_destroy(u); } };
+    std::vector<uint64_t> goff;
+    sylph_db* db = nullptr;
+    {
+        UploadGuard ug, og;
+        const uint64_t* d_k = upload_gathered(false, goff, &ug.u);
+        // the offsets travel the same way (a few hundred KB)
+        sylph_upload* uo = nullptr;
+        hip_check(sylph_upload_begin(e.context(), goff.size() * 8, 1u << 20, &uo), "sylph_upload_begin");
+        og.u = uo;
+        for (size_t i = 0; i < goff.size();) {
+            void* chunk = nullptr;
+            uint64_t cap = 0;
+            hip_check(sylph_upload_chunk(uo, &chunk, &cap), "sylph_upload_chunk");
+            const size_t m = std::min<size_t>(goff.size() - i, cap / 8);
+            memcpy(chunk, goff.data() + i, m * 8);
+            hip_check(sylph_upload_commit(uo, m * 8), "sylph_upload_commit");
+            i += m;
+        }
+        const void* d_off = nullptr;
+        hip_check(sylph_upload_finish(uo, &d_off), "sylph_upload_finish");
+        hip_check(sylph_db_upload(e.context(), d_k, (const uint64_t*)d_off, genome_sketches.size(), SYLPH_MEM_DEVICE, &db), "sylph_db_upload");
+    }
+    struct DbGuard { sylph_db* d; ~DbGuard() { sylph_db_destroy(d); } } guard{db};
+    if (args.pseudotax) {   // the winner table also ranges over pseudotax_tracked_nonused_kmers (contain.rs:421-428)
+        UploadGuard ug, og;
+        std::vector<uint64_t> toff;
+        const uint64_t* d_t = upload_gathered(true, toff, &ug.u);
+        sylph_upload* uo = nullptr;
+        hip_check(sylph_upload_begin(e.context(), toff.size() * 8, 1u << 20, &uo), "sylph_upload_begin");
+        og.u = uo;
+        for (size_t i = 0; i < toff.size();) {
+            void* chunk = nullptr;
+            uint64_t cap = 0;
+            hip_check(sylph_upload_chunk(uo, &chunk, &cap), "sylph_upload_chunk");
+            const size_t m = std::min<size_t>(toff.size() - i, cap / 8);
+            memcpy(chunk, toff.data() + i, m * 8);
+            hip_check(sylph_upload_commit(uo, m * 8), "sylph_upload_commit");
+            i += m;
+        }
+        const void* d_off = nullptr;
+        hip_check(sylph_upload_finish(uo, &d_off), "sylph_upload_finish");
+        hip_check(sylph_db_attach_tracked(db, d_t, (const uint64_t*)d_off, SYLPH_MEM_DEVICE), "sylph_db_attach_tracked");
+    }
+    if (getenv("SYLPH_HIP_FEED_TRACE") || getenv("SYLPH_HIP_DEBUG")) {
+        char b[200];
+        snprintf(b, sizeof(b), "timing: database of %zu genomes (%llu k-mers) uploaded and indexed in %.3f s", genome_sketches.size(),
+                 (unsigned long long)goff.back(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_db0).count());
+        info(b);
     }
 
     print_header(args.pseudotax, out, args.estimate_unknown);
@@ -888,7 +968,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             std::vector<std::optional<AniResult>> res(with_hits.size());
             parallel_for(with_hits.size(), args.threads, [&](size_t i) {
                 const size_t g = with_hits[i];
-                res[i] = stats_from_covs(args, cov_vector(covs, cov_width, coff[g], coff[g + 1]), genome_sketches[g].genome_kmers.size(), S.k, std::nullopt);
+                res[i] = stats_from_covs(args, cov_vector(covs, cov_width, coff[g], coff[g + 1]), genome_sketches[g].n_kmers(), S.k, std::nullopt);
                 if (res[i]) res[i]->genome_index = g;
             });
             for (auto& r : res) if (r) stats.push_back(*r);
@@ -914,7 +994,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             parallel_for(stats.size(), args.threads, [&](size_t i) {
                 const size_t g = stats[i].genome_index;
                 std::vector<uint32_t> cv(covs2 + coff2[g], covs2 + coff2[g + 1]);
-                res2[i] = stats_from_covs(args, std::move(cv), genome_sketches[g].genome_kmers.size(), S.k, (size_t)lost2[g]);
+                res2[i] = stats_from_covs(args, std::move(cv), genome_sketches[g].n_kmers(), S.k, (size_t)lost2[g]);
                 if (res2[i]) res2[i]->genome_index = g;
             });
             for (size_t i = 0; i < stats.size(); i++) {

@@ -192,6 +192,35 @@ std::vector<GenomeSketch> read_syldb(const std::string& path) {
     return gs;
 }
 
+std::vector<GenomeSketch> read_syldb_views(const std::string& path) {
+    auto rd = std::make_shared<Reader>(path);
+    Reader& r = *rd;
+    if (r.b.base) (void)madvise((void*)r.b.base, r.b.len, MADV_RANDOM);   // only the record headers are touched here: no read-ahead of the vectors
+    const uint64_t n = r.u64();
+    std::vector<GenomeSketch> gs;
+    gs.reserve(std::min<uint64_t>(n, 1u << 20));
+    auto skip_vec = [&](const uint8_t*& at, uint64_t& len) {
+        len = r.u64();
+        if (len > r.b.size() / 8) r.need(r.b.size() + 1);
+        r.need(len * 8);
+        at = (const uint8_t*)&r.b[r.p];
+        r.p += len * 8;
+    };
+    for (uint64_t i = 0; i < n; i++) {
+        GenomeSketch g;
+        g.view = true;
+        g.mapping = rd;
+        skip_vec(g.view_kmers, g.view_n);
+        if (r.u8()) { g.view_has_tracked = true; skip_vec(g.view_tracked, g.view_tn); }
+        g.file_name = r.str();
+        g.first_contig_name = r.str();
+        g.c = r.u64(); g.k = r.u64(); g.gn_size = r.u64(); g.min_spacing = r.u64();
+        gs.push_back(std::move(g));
+    }
+    if (r.b.base) (void)madvise((void*)r.b.base, r.b.len, MADV_NORMAL);   // (the gather that follows walks the vectors front to back)
+    return gs;
+}
+
 bool is_fastq(const std::string& f) {
     for (const char* s : {".fq", ".fnq", ".fastq", ".fq.gz", ".fnq.gz", ".fastq.gz"}) if (ends_with(f, s)) return true;
     return false;

@@ -50,6 +50,19 @@ struct GenomeSketch {
     std::optional<std::vector<uint64_t>> pseudotax_tracked_nonused_kmers;
     std::string file_name, first_contig_name;
     uint64_t c = 0, k = 0, gn_size = 0, min_spacing = 0;
+    // A sketch read as a VIEW of a mapped .syldb (read_syldb_views): the two vectors above stay empty, the k-mers lie in the file
+    // mapping (unaligned little-endian u64s) that `mapping` keeps alive.  `profile` / `query` never look at a genome's k-mers on the
+    // host — they go to the GPU, the statistics need their number — so a 13 GB database is not copied into 113,104 vectors first.
+    const uint8_t* view_kmers = nullptr;
+    const uint8_t* view_tracked = nullptr;
+    uint64_t view_n = 0, view_tn = 0;
+    bool view = false, view_has_tracked = false;
+    std::shared_ptr<void> mapping;
+    size_t n_kmers() const { return view ? view_n : genome_kmers.size(); }
+    size_t n_tracked() const { return view ? view_tn : (pseudotax_tracked_nonused_kmers ? pseudotax_tracked_nonused_kmers->size() : 0); }
+    bool has_tracked() const { return view ? view_has_tracked : (bool)pseudotax_tracked_nonused_kmers; }
+    const uint8_t* kmers_bytes() const { return view ? view_kmers : (const uint8_t*)genome_kmers.data(); }
+    const uint8_t* tracked_bytes() const { return view ? view_tracked : (pseudotax_tracked_nonused_kmers ? (const uint8_t*)pseudotax_tracked_nonused_kmers->data() : nullptr); }
 };
 
 // ---- on-disk formats: bincode 1.3.3 default options (little-endian, fixed-width ints, u64 lengths) ----
@@ -57,6 +70,9 @@ void write_sylsp(const std::string& path, const SequencesSketch& s);          //
 SequencesSketch read_sylsp(const std::string& path);                          // contain.rs:559
 void write_syldb(const std::string& path, const std::vector<GenomeSketch>& g); // sketch.rs:474
 std::vector<GenomeSketch> read_syldb(const std::string& path);                // contain.rs:495
+// the same without copying a k-mer: one pass over the record headers of the mapped file (contain.rs:492-500 is the reference's
+// single-threaded 13 GB bincode read, the dominant cost of a one-sample profile at GTDB scale)
+std::vector<GenomeSketch> read_syldb_views(const std::string& path);
 
 // ---- FASTA/FASTQ (+gzip) records with needletail 0.5.1 semantics: seq() without newlines, id() = whole header ----
 struct FastxRecord { std::string id; std::string seq; };

@@ -452,3 +452,31 @@ def test_database_does_not_depend_on_threads(data):
             assert "not_a_genome.fa is not a valid fasta/fastq file" in p.stderr
             outs.append((d / f"{o}.syldb").read_bytes())
         assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 10000
+
+
+def test_database_views_equal_copied_database(data):
+    """Round 4: `profile` / `query` read a .syldb as VIEWS of the mapped file and gather the k-mers straight into the library's
+    page-locked upload chunks (sylph_upload_*), instead of copying every genome into a vector and the vectors into one flat array
+    (SYLPH_HIP_DB_COPY_LOAD=1, rounds 1-3).  Same rows, bit for bit: two databases + a raw genome in one command (views and
+    freshly sketched vectors mixed), profile (tracked k-mers, reassignment) and query, several parse-thread counts."""
+    d = data["dir"]
+    g = data["genomes"]
+    out = d / "out_views"
+    run("sketch", g["EC590"][0], g["K12"][0], "-o", out / "db1")
+    run("sketch", g["O157"][0], "-o", out / "db2")
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-r", d / "single.fastq.gz", "-d", out)
+    args = [out / "db1.syldb", g["rand"][0], out / "db2.syldb", out / "s_1.fq.paired.sylsp", out / "single.fastq.gz.sylsp"]
+    ref = {}
+    for cmd in ("profile", "query"):
+        env = dict(os.environ, SYLPH_HIP_DB_COPY_LOAD="1", SYLPH_HIP_EXACT_DEDUP="1")
+        p = subprocess.run([BIN, cmd] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        ref[cmd] = p.stdout
+        assert len(p.stdout.strip().split("\n")) >= 3
+    for threads in ("1", "3", "64"):
+        for cmd in ("profile", "query"):
+            env = dict(os.environ, SYLPH_HIP_PARSE_THREADS=threads, SYLPH_HIP_EXACT_DEDUP="1", SYLPH_HIP_DEBUG="1")
+            p = subprocess.run([BIN, cmd] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+            assert p.returncode == 0, p.stderr[-2000:]
+            assert p.stdout == ref[cmd], (cmd, threads)
+            assert "uploaded and indexed in" in p.stderr
