@@ -920,8 +920,7 @@ int sylph_sketch_begin(sylph_ctx* ctx, uint32_t c, uint32_t k, int reads_mode, i
         sk->no_dedup = no_dedup != 0;
         sk->avx2_compat = seed_mode == SYLPH_SEED_AVX2_COMPAT;
         try {
-            sk->counters.reserve(64);
-            SY_HIP(hipMemsetAsync(sk->counters.p, 0, 64, ctx->stream));
+            sk->counters.reserve(64);     // (every word of it is cleared by the path that uses it, right before: no memset dispatch per sample)
         } catch (...) { delete sk; throw; }
         ctx->refs++;
         *out = sk;

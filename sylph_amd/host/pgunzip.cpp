@@ -18,6 +18,7 @@
 //      the whole attempt return false, and the caller reads the file with the sequential reader as before: this path can make a
 //      file faster, never different.
 // Own decoder (zlib cannot run without its window); zlib only supplies crc32 / crc32_combine.
+#include <dlfcn.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -192,25 +193,29 @@ const BlockCodes& fixed_codes() {
 inline bool fastq_byte(unsigned v) { return v == '\n' || v == '\r' || v == '\t' || (v >= 32 && v <= 126); }
 
 // Output of a stretch: 16-bit cells (0..255 bytes, 256 + w references into the unknown window of WINDOW bytes in front of it).
-struct Cells {   // anonymous mapping with 2 MiB pages where the system gives them: no zero fill by us, a hundredth of the page faults
-    uint16_t* v = nullptr;        // (a thousand 4 KiB faults per MB from dozens of threads queue up on the process's address-space lock)
-    size_t cap = 0, n = 0;
+struct Cells {   // 16-bit cells in anonymous memory with 2 MiB pages where the system gives them.  The stretches' cells are regions of
+    uint16_t* v = nullptr;        // ONE mapping (no per-thread mmap / mremap / munmap: those take the process's address-space lock
+    size_t cap = 0, n = 0;        // exclusively, and dozens of threads growing and freeing 40 MB buffers queued up on it)
+    bool own = false;
     Cells() = default;
     Cells(const Cells&) = delete;
     Cells& operator=(const Cells&) = delete;
     ~Cells() { release(); }
-    bool reserve(size_t want) {
+    bool reserve(size_t want) {                       // own mapping (the block-start search's scratch)
         if (want <= cap) return true;
-        want = (want + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);       // whole 2 MiB of 2-byte cells
+        if (v && !own) return false;                  // a carved region does not grow: the attempt is given up (sequential reader)
+        want = (want + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
         void* nv = v ? mremap(v, cap * 2, want * 2, MREMAP_MAYMOVE) : mmap(nullptr, want * 2, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (nv == MAP_FAILED) return false;
         (void)madvise(nv, want * 2, MADV_HUGEPAGE);
         v = (uint16_t*)nv;
         cap = want;
+        own = true;
         return true;
     }
+    void carve(uint16_t* base, size_t cells) { v = base; cap = cells; n = 0; own = false; }
     inline bool room(size_t extra) { return n + extra <= cap || reserve(std::max(cap * 3 / 2, n + extra + (1u << 20))); }
-    void release() { if (v) munmap(v, cap * 2); v = nullptr; cap = 0; }
+    void release() { if (v && own) munmap(v, cap * 2); v = nullptr; cap = 0; }
 };
 
 enum class Stop { Error, AtStopBit, FinalBlock, OutOfLimit };
@@ -318,6 +323,21 @@ size_t find_block_start(const uint8_t* d, size_t n, size_t from_bit, size_t to_b
     return SIZE_MAX;
 }
 
+// CRC-32 of a buffer: libdeflate's (carry-less multiply, several GB/s) when the system has the library — bound with dlopen, as in
+// feed.cpp — else zlib's (slicing tables, ~1 GB/s: a third of this path's time with 64 threads)
+uint32_t crc32_of(const uint8_t* p, size_t n) {
+    typedef uint32_t (*crc_fn)(uint32_t, const void*, size_t);
+    static const crc_fn fast = [] {
+        if (getenv("SYLPH_HIP_NO_LIBDEFLATE")) return (crc_fn) nullptr;
+        void* lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        return lib ? (crc_fn)dlsym(lib, "libdeflate_crc32") : (crc_fn) nullptr;
+    }();
+    if (fast) return fast(0, p, n);
+    uint32_t x = (uint32_t)crc32(0L, Z_NULL, 0);
+    for (size_t q = 0; q < n; q += 1u << 30) x = (uint32_t)crc32(x, p + q, (uInt)std::min<size_t>(n - q, 1u << 30));
+    return x;
+}
+
 template <class F>
 void run_threads(unsigned n, F&& f) {
     std::vector<std::thread> th;
@@ -345,7 +365,7 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
     const uint8_t* tr = gz + n - 8;
     const uint32_t want_crc = tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
     const uint32_t want_len = tr[4] | (uint32_t)tr[5] << 8 | (uint32_t)tr[6] << 16 | (uint32_t)tr[7] << 24;
-    static const size_t min_stretch = getenv("SYLPH_HIP_PGZ_STRETCH") ? (size_t)atol(getenv("SYLPH_HIP_PGZ_STRETCH")) : (4u << 20);
+    const size_t min_stretch = getenv("SYLPH_HIP_PGZ_STRETCH")   /* (tests lower it; read per call) */ ? (size_t)atol(getenv("SYLPH_HIP_PGZ_STRETCH")) : (2u << 20);
     const size_t body = body_end - body0;
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, body / std::max<size_t>(min_stretch, 1024)));
     if (T < 2) return false;                                               // nothing to gain: the sequential reader
@@ -373,14 +393,24 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
     });
     if (bad) return false;
     lap("block starts");
-    // ---- 2. every stretch into cells
+    // ---- 2. every stretch into cells: regions of one mapping, 12 cells per compressed byte each (address space, not memory: only what
+    // is written gets pages; FASTQ deflates 4-6x, a stretch beyond 12x gives the attempt up)
     std::vector<Cells> cells(T);
+    std::vector<size_t> region(T + 1, 0);
+    for (unsigned w = 0; w < T; w++) {
+        const size_t in_bytes = ((w + 1 < T ? start[w + 1] : body_end * 8) - start[w]) / 8 + 16;
+        region[w + 1] = region[w] + ((in_bytes * 12 + (1u << 20)) & ~(size_t)((1u << 20) - 1));
+    }
+    void* cell_map = mmap(nullptr, region[T] * 2, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (cell_map == MAP_FAILED) return false;
+    (void)madvise(cell_map, region[T] * 2, MADV_HUGEPAGE);
+    struct MapGuard { void* p; size_t n; ~MapGuard() { if (p) munmap(p, n); } } cell_guard{cell_map, region[T] * 2};
+    for (unsigned w = 0; w < T; w++) cells[w].carve((uint16_t*)cell_map + region[w], region[w + 1] - region[w]);
     std::vector<Stop> how(T, Stop::Error);
     std::vector<size_t> end_bit(T, 0);
     run_threads(T, [&](unsigned w) {
         Bits b;
         b.init(gz, body_end, start[w]);
-        if (!cells[w].reserve((size_t)((start[w + 1] == SIZE_MAX ? body_end * 8 : start[w + 1]) - start[w]) / 8 * 5 + (1u << 20))) return;
         const double t0 = trace ? now() : 0;
         how[w] = inflate_cells(b, cells[w], w != 0, w + 1 < T ? start[w + 1] : SIZE_MAX, false, 0, SIZE_MAX);
         end_bit[w] = b.bitpos();
@@ -420,10 +450,8 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
         uint8_t* dst = o + off[w];
         const uint8_t* wn = win[w].data();
         for (size_t i = 0; i < c.n; i++) { const uint16_t v = c.v[i]; dst[i] = v < 256 ? (uint8_t)v : wn[v - 256]; }
-        uint32_t x = (uint32_t)crc32(0L, Z_NULL, 0);
-        for (size_t q = 0; q < c.n; q += 1u << 30) x = (uint32_t)crc32(x, dst + q, (uInt)std::min<size_t>(c.n - q, 1u << 30));
-        crc[w] = x;
-        cells[w].release();                                               // give the cells back as soon as they are resolved
+        crc[w] = crc32_of(dst, c.n);
+        // (the cells go back in one piece when the function returns)
     });
     lap("resolve + crc");
     // ---- 4. the member's CRC-32
