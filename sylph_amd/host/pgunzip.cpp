@@ -26,6 +26,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -338,6 +339,38 @@ uint32_t crc32_of(const uint8_t* p, size_t n) {
     return x;
 }
 
+// The cell mappings are kept for the next file (a feed inflates two mate files per sample, sample after sample): pages that have been
+// touched once need no fault and no zeroing again — on the GPU box the first-touch cost of 2 GB of cells varied between 0.07 and
+// 0.85 s per file (2 MiB page allocation, compaction).  At most four mappings stay cached (mates x index-ahead); they are scratch, not state.
+struct CellPool {
+    struct Map { void* p; size_t bytes; bool busy; };
+    std::mutex mu;
+    std::vector<Map> maps;
+    void* acquire(size_t bytes, size_t* got) {
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (size_t i = 0; i < maps.size(); i++)
+            if (!maps[i].busy && maps[i].bytes >= bytes && (best < 0 || maps[i].bytes < maps[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0) { maps[(size_t)best].busy = true; *got = maps[(size_t)best].bytes; return maps[(size_t)best].p; }
+        for (size_t i = 0; i < maps.size(); i++)                              // none fits: an idle smaller one makes room
+            if (!maps[i].busy) { munmap(maps[i].p, maps[i].bytes); maps.erase(maps.begin() + (long)i); break; }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) return nullptr;
+        (void)madvise(m, bytes, MADV_HUGEPAGE);
+        maps.push_back(Map{m, bytes, true});
+        *got = bytes;
+        return m;
+    }
+    void release(void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t idle = 0;
+        for (auto& m : maps) { if (m.p == p) m.busy = false; idle += !m.busy; }
+        for (size_t i = 0; i < maps.size() && idle > 4;)                       // keep a few, give the rest back
+            if (!maps[i].busy && maps[i].p != p) { munmap(maps[i].p, maps[i].bytes); maps.erase(maps.begin() + (long)i); idle--; } else i++;
+    }
+};
+CellPool& cell_pool() { static CellPool p; return p; }
+
 template <class F>
 void run_threads(unsigned n, F&& f) {
     std::vector<std::thread> th;
@@ -401,10 +434,10 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
         const size_t in_bytes = ((w + 1 < T ? start[w + 1] : body_end * 8) - start[w]) / 8 + 16;
         region[w + 1] = region[w] + ((in_bytes * 12 + (1u << 20)) & ~(size_t)((1u << 20) - 1));
     }
-    void* cell_map = mmap(nullptr, region[T] * 2, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (cell_map == MAP_FAILED) return false;
-    (void)madvise(cell_map, region[T] * 2, MADV_HUGEPAGE);
-    struct MapGuard { void* p; size_t n; ~MapGuard() { if (p) munmap(p, n); } } cell_guard{cell_map, region[T] * 2};
+    size_t cell_map_bytes = 0;
+    void* cell_map = cell_pool().acquire(region[T] * 2, &cell_map_bytes);
+    if (!cell_map) return false;
+    struct MapGuard { void* p; ~MapGuard() { cell_pool().release(p); } } cell_guard{cell_map};
     for (unsigned w = 0; w < T; w++) cells[w].carve((uint16_t*)cell_map + region[w], region[w + 1] - region[w]);
     std::vector<Stop> how(T, Stop::Error);
     std::vector<size_t> end_bit(T, 0);
