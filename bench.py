@@ -162,7 +162,16 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
         ctx.synchronize()
         del goff_loc
     else:
-        db = S.Database(ctx, kmers.data_ptr(), goff.data_ptr(), device_ptrs=True, n_genomes=n_total)
+        # tuning experiment (SYLPH_BENCH_DB_CU_MASK=lo:hi): the database — hence the pipeline's profile thread — on a context of its own
+        # whose stream is confined to a subset of the CUs, so that the latency-bound probe does not hold wave slots on every CU
+        mask = os.environ.get("SYLPH_BENCH_DB_CU_MASK", "")
+        dctx = ctx
+        if mask:
+            dctx = S.Context(device.index)
+            dctx.set_option("cu_mask", mask)
+            build_database.keep = dctx
+        db = S.Database(dctx, kmers.data_ptr(), goff.data_ptr(), device_ptrs=True, n_genomes=n_total)
+        dctx.synchronize()
     ctx.synchronize()
     t3 = time.time()
     stats = dict(n_genomes=int(n_total), db_kmers_total=int(kmers.numel()), shard_kmers=int(db.n_kmers), index_gb=round(db.index_bytes / 1e9, 2),

@@ -371,10 +371,11 @@ int sylph_pipeline_flush(sylph_pipeline *p);
  * sylph_pipeline_destroy on this pipeline (the sample's session and its share of the result block are released then). */
 int sylph_pipeline_next(sylph_pipeline *p, sylph_pipeline_result *out);
 uint32_t sylph_pipeline_outstanding(sylph_pipeline *p);
-/* The pipeline's own knobs — "serialize_seeding" (default 1: one worker at a time runs its seeding kernel, the others are in
- * their dedup/count tails; two VALU-bound seeding kernels side by side only slow each other, +3 % in r04), "min_batch" +
- * "batch_wait_us" (default 1 / 0: the profile thread waits up to batch_wait_us for min_batch ready tables while more samples are
- * being sketched; unsharded pipelines only) — else sylph_ctx_set_option on every worker context.  sylph_ctx_profile /
+/* The pipeline's own knobs — "serialize_seeding" (default 1: one seeding kernel at a time on the GPU — a worker's stream waits
+ * for the event behind the previous worker's seeding kernel, no host blocks — while the other samples are in their dedup/count tails;
+ * two VALU-bound seeding kernels side by side only slow each other, +3 % in r04), "min_batch" +
+ * "batch_wait_us" (default 2 / 400: the profile thread waits up to batch_wait_us for min_batch ready tables while more samples are
+ * being sketched — never for samples nobody has submitted; unsharded pipelines only; +1.2 % in r04) — else sylph_ctx_set_option on every worker context.  sylph_ctx_profile /
  * sylph_ctx_kernel_stats summed over the workers' and the database's contexts.
  * sylph_pipeline_next on a sharded pipeline returns SYLPH_ERR_STATE instead of blocking when fewer than max_batch samples are
  * outstanding and sylph_pipeline_flush has not covered the oldest one (nobody would ever wake the call). */

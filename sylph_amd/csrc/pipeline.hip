@@ -90,8 +90,13 @@ struct sylph_pipeline {
     // tuning (sylph_pipeline_set_option): see the option table in include/sylph_hip.h
     uint32_t serialize_seeding = 1;              // 1 (default, r04: +3 %, profiles/r04_ab_pipeline_sweep.txt): one worker at a time runs its seeding kernel —
                                                  // two VALU-bound seeding kernels side by side only slow each other; the others are in their dedup/count tails
-    uint32_t min_batch = 1, batch_wait_us = 0;   // the profile thread waits up to batch_wait_us for min_batch ready tables while more are on their way
+    uint32_t min_batch = 2, batch_wait_us = 400; // the profile thread waits up to batch_wait_us for min_batch ready tables while more are being sketched (r04: +1.2 %)
     std::mutex seed_mu;
+    // serialize_seeding on the DEVICE: a push with a deferred verdict returns as soon as its kernels are queued, so holding a
+    // mutex around it orders nothing on the GPU — the next worker's stream waits for the event the previous worker recorded
+    // behind its seeding kernel instead (hosts never block on it)
+    std::vector<hipEvent_t> seed_ev;             // one per worker
+    hipEvent_t last_seed_ev = nullptr;           // guarded by seed_mu
 
     Block* take_block() {                        // mu held
         for (auto& b : blocks)
@@ -114,8 +119,12 @@ struct sylph_pipeline {
             for (size_t i = 0; rc == SYLPH_OK && i < j->batches.size(); i++) {
                 const sylph_read_batch& b = j->batches[i];
                 std::unique_lock<std::mutex> seed_lock(seed_mu, std::defer_lock);
-                if (serialize_seeding) seed_lock.lock();
+                if (serialize_seeding) {
+                    seed_lock.lock();
+                    if (last_seed_ev && last_seed_ev != seed_ev[(size_t)w]) (void)hipStreamWaitEvent(wctx[w]->stream, last_seed_ev, 0);
+                }
                 rc = sylph_sketch_push_enc(j->sk, b.bases, b.rec_off, b.n_records, b.n_bases, j->mem, j->enc);
+                if (serialize_seeding && hipEventRecord(seed_ev[(size_t)w], wctx[w]->stream) == hipSuccess) last_seed_ev = seed_ev[(size_t)w];
             }
         }
         if (rc == SYLPH_OK) rc = sylph_sketch_finish_device(j->sk, &j->dev_k, &j->dev_c, &j->n_table, &j->dup_removed);
@@ -310,9 +319,13 @@ int sylph_pipeline_create(sylph_db* db, const sylph_pipeline_config* cfg, sylph_
                 sylph_ctx* cx = nullptr;
                 if (sylph_ctx_create(db->ctx->device, nullptr, &cx) != SYLPH_OK) throw ArgError{sylph_last_error()};
                 p->wctx.push_back(cx);
+                hipEvent_t ev = nullptr;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) throw ArgError{"hipEventCreate failed"};
+                p->seed_ev.push_back(ev);
             }
         } catch (...) {
             for (sylph_ctx* cx : p->wctx) sylph_ctx_destroy(cx);
+            for (hipEvent_t ev : p->seed_ev) (void)hipEventDestroy(ev);
             throw;
         }
         db->ctx->refs++;                         // the profile thread works on the database's context
@@ -478,6 +491,7 @@ void sylph_pipeline_destroy(sylph_pipeline* p) {
         for (sylph_sketch* s : p->trash[w]) sylph_sketch_destroy(s);
         sylph_ctx_destroy(p->wctx[w]);
     }
+    for (hipEvent_t ev : p->seed_ev) (void)hipEventDestroy(ev);
     sylph_ctx* dbctx = p->db->ctx;
     p->blocks.clear();
     delete p;
