@@ -327,7 +327,7 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
     ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 3)")
-    ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 3; sharded: two probe batches)")
+    ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 5; sharded: two probe batches)")
     ap.add_argument("--no-files-leg", action="store_true", help="skip the leg that runs `sylph-hip sketch` on FASTQ files (plain, gzip)")
     ap.add_argument("--files-leg-pairs", type=int, default=1_000_000, help="read pairs per sample of that leg (default 1 M = 0.3 Gbp)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")
@@ -446,7 +446,7 @@ def main():
 
     # ---- the two ways of running samples ------------------------------------------------------------------------------------
     n_workers = max(1, args.sketch_workers or 3)
-    depth = max(1, args.pipeline_depth or (2 * spb if comm is not None else max(n_workers + 3, spb + n_workers)))
+    depth = max(1, args.pipeline_depth or (2 * spb if comm is not None else max(n_workers + 5, spb + n_workers)))
     if comm is not None:
         depth = max(depth, spb)
     sample_no = [0]

@@ -338,7 +338,7 @@ typedef struct sylph_read_batch {   /* the arguments of sylph_sketch_push_enc */
 typedef struct sylph_pipeline_config {
     uint32_t struct_size;     /* sizeof(sylph_pipeline_config) */
     uint32_t n_workers;       /* sketch threads / contexts; 0 = default (3) */
-    uint32_t depth;           /* samples that may be outstanding (submitted, not yet returned by sylph_pipeline_next); 0 = n_workers + 3 */
+    uint32_t depth;           /* samples that may be outstanding (submitted, not yet returned by sylph_pipeline_next); 0 = n_workers + 5 */
     uint32_t max_batch;       /* sample tables per probe launch at most (<= 64); 0 = default (8) */
     uint32_t c, k;            /* sylph_sketch_begin's arguments for the samples submitted as batches */
     int reads_mode, no_dedup, seed_mode;

@@ -70,7 +70,7 @@ struct Job {
 struct sylph_pipeline {
     sylph_db* db = nullptr;
     sylph_comm* comm = nullptr;
-    uint32_t n_workers = 3, depth = 6, max_batch = 8;
+    uint32_t n_workers = 3, depth = 8, max_batch = 8;
     uint32_t c = 200, k = 31;
     int reads_mode = SYLPH_READS_PAIRED, no_dedup = 0, seed_mode = SYLPH_SEED_AVX2_COMPAT, want_table = 0;
     double min_number_kmers = 0;
@@ -308,7 +308,7 @@ int sylph_pipeline_create(sylph_db* db, const sylph_pipeline_config* cfg, sylph_
         p->comm = cfg->comm;
         p->n_workers = cfg->n_workers ? cfg->n_workers : 3;
         p->max_batch = cfg->max_batch ? cfg->max_batch : 8;
-        p->depth = cfg->depth ? cfg->depth : p->n_workers + 3;
+        p->depth = cfg->depth ? cfg->depth : p->n_workers + 5;
         SY_REQUIRE(!p->comm || p->depth >= p->max_batch, "sharded: depth (%u) must reach max_batch (%u), the fixed batch of the exchange", p->depth, p->max_batch);
         p->c = cfg->c; p->k = cfg->k;
         p->reads_mode = cfg->reads_mode; p->no_dedup = cfg->no_dedup; p->seed_mode = cfg->seed_mode; p->want_table = cfg->want_table;
