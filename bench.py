@@ -760,7 +760,7 @@ def main():
     except Exception:
         pass
     meta_ok = meta.get("csrc_sha") == fp     # PMC figures measured on exactly these kernel sources
-    tsrc = f"profiles/seeds_traffic.json@{meta.get('head', '?')[:12]} (rocprofv3 --pmc passes of tools/r03_profile.sh; csrc {meta.get('csrc_sha', '?')})"
+    tsrc = f"profiles/seeds_traffic.json@{meta.get('head', '?')[:12]} (rocprofv3 --pmc passes of tools/r04_profile.sh; csrc {meta.get('csrc_sha', '?')})"
     seeds_ms, seeds_launches = fam["seeds"]
     if seeds_launches:
         n_rec = float(np.mean([r["n_records"] for r in read_sets]))
@@ -770,6 +770,8 @@ def main():
         avg_ms = seeds_ms / seeds_launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = meta.get("hbm_bytes_per_launch") if (meta_ok and wl in ("c2", "c3", "c4")) else None
+        if meta_ok and long_mode:
+            traffic = meta.get("position_kernel_hbm_bytes_per_launch")   # the C5 position kernel's own PMC pass (tools/r04_profile.sh)
         ipk = (meta.get("valu_per_kmer_position_kernel") if long_mode else meta.get("valu_per_kmer")) if meta_ok else None
         hashed = (n_bases if long_mode else max(0.0, n_bases - n_rec * (k - 1))) / launches_per_sample
         out["roofline"] = {"bound": "hbm", "kernel": "seeds_slots_kernel<31,1>" if long_mode else "reads_kernel<31,1>", "achieved": round(achieved, 1),

@@ -400,6 +400,12 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
     const uint32_t want_len = tr[4] | (uint32_t)tr[5] << 8 | (uint32_t)tr[6] << 16 | (uint32_t)tr[7] << 24;
     const size_t min_stretch = getenv("SYLPH_HIP_PGZ_STRETCH")   /* (tests lower it; read per call) */ ? (size_t)atol(getenv("SYLPH_HIP_PGZ_STRETCH")) : (2u << 20);
     const size_t body = body_end - body0;
+    // One file at a time per process, on all the threads the host can spare: two mate files inflated side by side with 64 threads each
+    // took 0.4-0.9 s apiece on the GPU box where one alone takes 0.1-0.2 s (tools/pgunzip_bench.py, profiles/r04_feed.txt) — the
+    // decoders are compute-bound and interfere; queueing the files costs nothing and evens the times out.
+    static std::mutex one_file_at_a_time;
+    std::lock_guard<std::mutex> file_lock(one_file_at_a_time);
+    if (!getenv("SYLPH_HIP_PARSE_THREADS")) threads = std::max(threads, std::min(128u, std::max(1u, std::thread::hardware_concurrency()) / 2));
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, body / std::max<size_t>(min_stretch, 1024)));
     if (T < 2) return false;                                               // nothing to gain: the sequential reader
     // transient memory: 2 B per inflated byte for the cells + the output (estimate: the trailer's length, or 6x the file if that wrapped)

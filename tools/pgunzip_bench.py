@@ -32,12 +32,24 @@ def main():
     L = C.CDLL(os.path.join(ROOT, "sylph_amd", "libsylph_host.so"))
     L.sylph_host_pgunzip.argtypes = [C.c_char_p, C.c_uint, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
     os.environ["SYLPH_HIP_FEED_TRACE"] = "1"
-    for thr in (8, 32, 64, 128):
-        nn, cc = C.c_uint64(0), C.c_uint32(0)
+    import threading
+    for rep in range(2):
+        for thr in (16, 24, 32, 48, 64, 96, 128):
+            nn, cc = C.c_uint64(0), C.c_uint32(0)
+            t = time.perf_counter()
+            rc = L.sylph_host_pgunzip(f"{d}/s.fq.gz".encode(), thr, C.byref(nn), C.byref(cc), None, 0)
+            dt = time.perf_counter() - t
+            print(f"threads {thr}: rc {rc}, {nn.value} B in {dt:.3f} s (incl. reading the file + a second CRC pass in the test hook)", flush=True)
+    # two files at once (the two mates of a pair), each with `thr` threads
+    for thr in (32, 48, 64):
+        def one():
+            nn, cc = C.c_uint64(0), C.c_uint32(0)
+            L.sylph_host_pgunzip(f"{d}/s.fq.gz".encode(), thr, C.byref(nn), C.byref(cc), None, 0)
         t = time.perf_counter()
-        rc = L.sylph_host_pgunzip(f"{d}/s.fq.gz".encode(), thr, C.byref(nn), C.byref(cc), None, 0)
-        dt = time.perf_counter() - t
-        print(f"threads {thr}: rc {rc}, {nn.value} B in {dt:.3f} s (incl. reading the file + a second CRC pass in the test hook)", flush=True)
+        ts = [threading.Thread(target=one) for _ in range(2)]
+        [x.start() for x in ts]
+        [x.join() for x in ts]
+        print(f"TWO files at once, {thr} threads each: {time.perf_counter() - t:.3f} s", flush=True)
 
 
 if __name__ == "__main__":
