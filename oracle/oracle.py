@@ -55,6 +55,8 @@ def lib():
                                                 C.c_void_p, C.c_uint64]
     L.orc_pair_kmer_single.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     L.orc_pair_kmer.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.orc_cuckoo_walk.restype = C.c_uint64
+    L.orc_cuckoo_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_uint64, C.c_void_p]
     L.orc_sketch_reads_cuckoo.restype = C.c_void_p
     L.orc_sketch_reads_cuckoo.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_uint64]
     L.orc_sketch_reads.restype = C.c_void_p
@@ -192,6 +194,15 @@ def sketch_reads_cuckoo_model(bases, off, c=200, k=31, mode=MODE_AVX2_COMPAT, fp
                     mean_read_length=float(lib().orc_sketch_mean_read_length(h)))
     finally:
         lib().orc_sketch_free(h)
+
+
+def cuckoo_walk(km, marker, fpr=1e-4, initial_capacity=10_000_000):
+    """The model's filter walked item by item (test, insert when absent: sketch.rs:747-760) -> (contained[n] bool, number of filters)."""
+    km = np.ascontiguousarray(km, dtype=np.uint64)
+    marker = np.ascontiguousarray(marker, dtype=np.uint64)
+    out = np.zeros(len(km), dtype=np.uint8)
+    nf = lib().orc_cuckoo_walk(_ptr(km), _ptr(marker), len(km), float(fpr), int(initial_capacity), _ptr(out))
+    return out.astype(bool), int(nf)
 
 
 def sketch_genome(bases, off, c=200, k=31, mode=MODE_AVX2_COMPAT, min_spacing=30, pseudotax=True):

@@ -686,6 +686,48 @@ void* orc_sketch_reads_cuckoo(const uint8_t* bases, const uint64_t* off, uint64_
     sk->finalize();
     return sk;
 }
+// The filter alone, walked as sketch.rs:747-760 walks it — test, insert when absent — over a stream of (k-mer, markers) items:
+// contained[i] = what `contains` answered for item i; returns the number of filters at the end.  (The checker of the
+// data-parallel formulation in sylph_amd/csrc/a10.hip: tests/test_oracle.py restates that formulation in numpy against this walk.)
+uint64_t orc_cuckoo_walk(const uint64_t* km, const uint64_t* marker, uint64_t n, double fpr, uint64_t initial_capacity, uint8_t* contained) {
+    ScalableCuckoo set(initial_capacity, fpr);
+    for (uint64_t i = 0; i < n; i++) {
+        contained[i] = set.contains(km[i], marker[i]) ? 1 : 0;
+        if (!contained[i]) set.insert(km[i], marker[i]);
+    }
+    return set.filters.size();
+}
+// The items sketch.rs:828-867 hands to the filter, in the order it does: per pair the seeds of mate 1 as extract_markers pushed
+// them, then those of mate 2 that mate 1 did not produce; two items per seed (markers.0, markers.1); nothing for pairs without
+// markers.  rec / seed = record index and the seed's place in its record's emission order.  Returns the number of items
+// (call with null outputs to size them).
+uint64_t orc_pair_filter_items(const uint8_t* bases, const uint64_t* off, uint64_t n_records, uint64_t c, uint64_t k, int mode,
+                               uint64_t* km, uint64_t* marker, uint64_t* rec, uint32_t* seed) {
+    uint64_t n = 0;
+    std::vector<uint64_t> v1, v2;
+    for (uint64_t p = 0; p < n_records / 2; p++) {
+        const uint8_t* s1 = bases + off[2 * p];
+        const uint64_t l1 = off[2 * p + 1] - off[2 * p];
+        const uint8_t* s2 = bases + off[2 * p + 1];
+        const uint64_t l2 = off[2 * p + 2] - off[2 * p + 1];
+        v1.clear(); v2.clear();
+        if (seeds_dispatch(s1, l1, c, k, mode, false, [&](uint64_t, uint64_t h) { v1.push_back(h); })) return ~0ull;
+        if (seeds_dispatch(s2, l2, c, k, mode, false, [&](uint64_t, uint64_t h) { v2.push_back(h); })) return ~0ull;
+        const Markers pair = pair_kmer(s1, l1, s2, l2);
+        if (!pair.some) continue;
+        const uint64_t m[2] = {(uint64_t)pair.m[0] | ((uint64_t)pair.m[1] << 32), (uint64_t)pair.m[2] | ((uint64_t)pair.m[3] << 32)};
+        auto put = [&](uint64_t h, uint64_t r, uint32_t e) {
+            for (int w = 0; w < 2; w++) {
+                if (km) { km[n] = h; marker[n] = m[w]; rec[n] = r; seed[n] = e; }
+                n++;
+            }
+        };
+        for (size_t e = 0; e < v1.size(); e++) put(v1[e], 2 * p, (uint32_t)e);
+        for (size_t e = 0; e < v2.size(); e++)
+            if (std::find(v1.begin(), v1.end(), v2[e]) == v1.end()) put(v2[e], 2 * p + 1, (uint32_t)e);
+    }
+    return n;
+}
 uint64_t orc_sketch_size(void* h) { return ((ReadSketch*)h)->sorted_keys.size(); }
 uint64_t orc_sketch_dup_removed(void* h) { return ((ReadSketch*)h)->num_dup_removed; }
 double orc_sketch_mean_read_length(void* h) { return ((ReadSketch*)h)->mean_read_length; }

@@ -145,6 +145,15 @@ __device__ __host__ __forceinline__ uint64_t n_hashed_kmers(uint64_t L, uint32_t
     return ((L - k + 1) / 4) * 4;
 }
 
+// Place of the k-mer that starts at base i of a record with nh hashed k-mers in the order extract_markers emits the record's seeds
+// (sketch.rs:53-69): position order for the scalar routine (seeding.rs:86-146); the 4-lane AVX2 routine (avx2_seeding.rs:33-148) walks
+// four quarters of the record in lock step and pushes lane 0..3 of every step: (i mod len4, i div len4) with len4 = nh / 4.
+__device__ __host__ __forceinline__ uint64_t emission_rank(uint32_t i, uint32_t nh, int avx2_compat) {
+    if (!avx2_compat || nh < 4) return i;
+    const uint32_t len4 = nh >> 2, lane = i / len4;
+    return (uint64_t)(i - lane * len4) * 4 + lane;
+}
+
 // Adds the number of lanes with `pred` to *counter with ONE atomic per wavefront (64-bit ballot + s_bcnt1).
 __device__ __forceinline__ void wave_count_add(unsigned int* counter, bool pred) {
     const unsigned long long m = __ballot(pred);

@@ -395,7 +395,11 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                     const uint64_t ft = win64(sF, s_rel[lo] + i);
                     const uint64_t fk = ft >> (64 - 2 * K), rk = revcomp_top<K>(ft);
                     const uint64_t h = mm_hash64(fk < rk ? fk : rk);
-                    const uint64_t rid = (rec_base + pass + lo) | ((f >> 31) ? RID_MARKER_BIT : 0ull);
+                    uint64_t rid = rec_base + pass + lo;
+                    if (f >> 31) {
+                        rid |= RID_MARKER_BIT;
+                        if (paired) rid |= min(emission_rank(i, s_nh[lo], avx2_compat), RID_RANK_MAX) << RID_RANK_SHIFT;   // (sketch_session.h)
+                    }
                     slot_rec[out0 + o] = OccRec{h, rid, s_m0[lo], s_m1[lo]};
                     if (slot_key) slot_key[out0 + o] = (uint32_t)(h >> key_sh);   // what finish() partitions by (replay_lds.hip)
                 }

@@ -294,6 +294,10 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
                                                              uint32_t* __restrict__ large_list,
                                                              uint32_t* __restrict__ ovf_list, int dbg_stage) {
     constexpr int ITEMS = CAP / RTPB;     // records per lane
+    // `no_dedup` arrives as a DEDUP_* mode.  DEDUP_FILTER (the reference's default for pairs, a10.hip): everything as in the exact
+    // mode except the marker test itself, which is the bit a10_mark left in the occurrence's record.
+    const bool filter = no_dedup == DEDUP_FILTER;
+    if (filter) no_dedup = 0;
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
     __shared__ __attribute__((aligned(8))) uint16_t s_seg[CAP];   // first sorted position of the k-mer each sorted position belongs to
     __shared__ uint8_t s_fl[CAP];         // bit0 skip, bit1 would-be-dropped
@@ -633,7 +637,7 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
         for (uint32_t t = tid; t < MARKER_TAB; t += RTPB) s_tab[t] = 0xFFFFFFFFu;
         __syncthreads();
         auto marker_of = [&](uint32_t e) { return (e & 1u) ? s_m1[e >> 1] : s_m0[e >> 1]; };
-        if (!no_dedup) {
+        if (!no_dedup && !filter) {
             for (uint32_t t = 0; t < items; t++) {
                 const uint32_t j = j0 + t;
                 if (j >= n) break;
@@ -662,8 +666,12 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             if (j >= n) break;
             uint8_t fl = s_fl[j];
             if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT) && j != (uint32_t)s_seg[j]) {
-                const bool hit = (s_tab[s_slot[2 * j]] & 0xFFFFu) < j || (s_tab[s_slot[2 * j + 1]] & 0xFFFFu) < j;
-                if (hit || s_m0[j] == s_m1[j]) fl |= 2;
+                if (filter) {      // sketch.rs:747-760: the filter's answers, `*c > 0` = not the head of the k-mer
+                    if (s_rid[j] & RID_A10_BIT) fl |= 2;
+                } else {
+                    const bool hit = (s_tab[s_slot[2 * j]] & 0xFFFFu) < j || (s_tab[s_slot[2 * j + 1]] & 0xFFFFu) < j;
+                    if (hit || s_m0[j] == s_m1[j]) fl |= 2;
+                }
             }
             const bool u = !(fl & 1) && (no_dedup || !(fl & 2));
             if (u) { my_u++; ubits |= (uint8_t)(1u << t); }
@@ -674,7 +682,10 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             const uint32_t j = j0 + t;
             if (j >= n) break;
             uint8_t fl = s_fl[j];
-            if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT)) {
+            if (filter) {
+                // (the head of a k-mer is never a skipped mate 2, so "a processed occurrence precedes j" is "j is not the head")
+                if (!fl && (s_rid[j] & RID_MARKER_BIT) && j != (uint32_t)s_seg[j] && (s_rid[j] & RID_A10_BIT)) fl |= 2;
+            } else if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT)) {
                 const uint64_t a = s_m0[j], bb = s_m1[j];
                 bool any_prev = false, hit = false;
                 for (uint32_t q = s_seg[j]; q < j; q++) {
@@ -1237,7 +1248,7 @@ bool finish_bucketed(sylph_sketch* sk) {
                                    b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, large_list, ovf_list);
             else
                 hipLaunchKernelGGL((bucket_replay_kernel<CAP_SMALL, RTPB_SMALL>), dim3(B), dim3(RTPB_SMALL), 0, ctx->stream,
-                                   recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->no_dedup, cutoff, bm,
+                                   recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired, sk->dedup_mode(), cutoff, bm,
                                    b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b, d_overflow, mid_list, large_list,
                                    ovf_list, dbg);
         }
@@ -1298,12 +1309,12 @@ bool finish_bucketed(sylph_sketch* sk) {
             if (host.n_mid)
                 hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_MID, RTPB_MID>), dim3(std::min<uint32_t>(host.n_mid, 1280u)),
                                    dim3(RTPB_MID), 0, ctx->stream, recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
-                                   sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
+                                   sk->dedup_mode(), cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
                                    d_overflow, mid_list, large_list, ovf_list, dbg);
             if (host.n_large)
                 hipLaunchKernelGGL((bucket_replay_list_kernel<CAP_LARGE, RTPB_LARGE>), dim3(std::min<uint32_t>(host.n_large, 512u)),
                                    dim3(RTPB_LARGE), 0, ctx->stream, recs, b_perm.as<uint32_t>(), boff, d_nv, sk->paired,
-                                   sk->no_dedup, cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
+                                   sk->dedup_mode(), cutoff, bm, b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), n_distinct, removed_b,
                                    d_overflow, large_list, large_list, ovf_list, dbg);
             }
         }
@@ -1338,7 +1349,7 @@ bool finish_bucketed(sylph_sketch* sk) {
                                b_sh.as<uint64_t>(), b_sr.as<OccRec>());
         }
         uint64_t n_sub_out = 0, removed_sub = 0;
-        generic_replay(ctx, b_sh.as<uint64_t>(), b_sr.as<OccRec>(), n_sub, sk->paired, sk->no_dedup, sub_k, sub_c, n_sub_out, removed_sub);
+        generic_replay(ctx, b_sh.as<uint64_t>(), b_sr.as<OccRec>(), n_sub, sk->paired, sk->dedup_mode(), sub_k, sub_c, n_sub_out, removed_sub);
         removed_extra = removed_sub;
         {
             ScopedKernelTimer t(ctx, "replay");

@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256) void annotate_reads_kernel(
                     m0 = (uint64_t)f | ((uint64_t)rr << 32);
                     m1 = (uint64_t)g | ((uint64_t)t << 32);
                     rid |= RID_MARKER_BIT;
+                    if (paired)
+                        rid |= min(emission_rank((uint32_t)(p - start), (uint32_t)n_hashed_kmers(L, k, avx2_compat, 0), avx2_compat), RID_RANK_MAX)
+                               << RID_RANK_SHIFT;
                 }
             }
         }
@@ -303,12 +306,17 @@ __global__ __launch_bounds__(256) void marker_hits_kernel(const uint32_t* __rest
     const uint64_t v = (e & 1) ? m1_s[e >> 1] : m0_s[e >> 1], w = (f & 1) ? m1_s[f >> 1] : m0_s[f >> 1];
     if (v == w) hit[e >> 1] = 1;   // (f >> 1 == e >> 1 only when m0 == m1, which drops the occurrence anyway)
 }
+// DEDUP_FILTER: hit = the bit a10_mark left in the occurrence's record
+__global__ __launch_bounds__(256) void filter_hits_kernel(const uint64_t* __restrict__ rid_s, uint32_t n, uint8_t* __restrict__ hit) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hit[i] = (rid_s[i] & RID_A10_BIT) ? 1 : 0;
+}
 // flags[i]: bit0 = skip, bit1 = would-be-dropped.  Eproc = exclusive count of processed (non-skipped) occurrences.
 __global__ __launch_bounds__(256) void dup_flags_kernel(const uint64_t* __restrict__ rid_s, const uint64_t* __restrict__ m0_s,
                                                         const uint64_t* __restrict__ m1_s,
                                                         const uint32_t* __restrict__ seg_start,
                                                         const uint8_t* __restrict__ skip, const uint32_t* __restrict__ Eproc,
-                                                        const uint8_t* __restrict__ hit, uint32_t n,
+                                                        const uint8_t* __restrict__ hit, uint32_t n, int filter,
                                                         uint8_t* __restrict__ flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -316,7 +324,8 @@ __global__ __launch_bounds__(256) void dup_flags_kernel(const uint64_t* __restri
     if (!fl && (rid_s[i] & RID_MARKER_BIT)) {
         const uint32_t s0 = seg_start[i];
         const bool any_prev = skip ? (Eproc[i] != Eproc[s0]) : (i != s0);
-        if (any_prev && (hit[i] || m0_s[i] == m1_s[i])) fl |= 2;
+        // (filter mode: equal markers are the filter's business too — its second test finds what the first inserted)
+        if (any_prev && (hit[i] || (!filter && m0_s[i] == m1_s[i]))) fl |= 2;
     }
     flags[i] = fl;
 }
@@ -559,6 +568,7 @@ static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t pha
         sk->n_occ = need;
     }
     sk->rec_base += n_records;
+    SY_REQUIRE(sk->rec_base <= RID_MASK, "more than 2^42 records in one sample");
 }
 
 // A deferred batch whose verdict came back bad (a record too long for the short-read kernel, a block that overflowed its slots):
@@ -695,8 +705,9 @@ static void sketch_push_impl(sylph_sketch* sk, const uint8_t* bases, const uint6
 // recs in file order): stable radix sort by hash, then per-occurrence kernels and scans (see the file header).  Writes the
 // (k-mer, count) table in ascending k-mer order.  Used for whole samples (finish = generic, c < 2) and, by the bucket path,
 // for the occurrences of buckets that do not fit in LDS.
-void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, bool no_dedup,
+void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, int dedup,
                     DevBuf& out_k, DevBuf& out_c, uint64_t& n_out, uint64_t& removed_out) {
+    const bool no_dedup = dedup == DEDUP_NONE, filter = dedup == DEDUP_FILTER;
     uint32_t nv = 0;
     n_out = 0;
     removed_out = 0;
@@ -769,6 +780,9 @@ void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs
                 uint32_t* sk_out = sk_in + ne;
                 uint32_t* ent_out = ent_in;      // ent_in is dead after the first sort
                 SY_HIP(hipMemsetAsync(b_hit.p, 0, nv, ctx->stream));
+                if (filter)        // sketch.rs:733-769: the marker test is the filter's answer (a10.hip), no sorting of marker entries
+                    hipLaunchKernelGGL(filter_hits_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(), nv, b_hit.as<uint8_t>());
+                else {
                 hipLaunchKernelGGL(marker_entries_kernel, dim3(grid_for(ne)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
                                    b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), skip_arg, nv, b_key.as<uint64_t>(), ent_in);
                 sort_pairs_u64_u32(ctx, b_key.as<uint64_t>(), b_key2.as<uint64_t>(), ent_in, ent_mid, ne, 0, 64);
@@ -777,6 +791,7 @@ void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs
                 sort_pairs_u32_u32(ctx, sk_in, sk_out, ent_mid, ent_out, ne, 0, std::max(1, bit_length(nv)));
                 hipLaunchKernelGGL(marker_hits_kernel, dim3(grid_for(ne)), dim3(256), 0, ctx->stream, ent_out, sk_out,
                                    b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), nv, b_hit.as<uint8_t>());
+                }
                 const uint32_t* Eproc = nullptr;
                 if (skip_arg) {   // exclusive count of processed occurrences (uc / Ec are free until would_count_kernel)
                     hipLaunchKernelGGL(processed_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, skip_arg, nv, uc);
@@ -784,7 +799,7 @@ void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs
                     Eproc = Ec;
                 }
                 hipLaunchKernelGGL(dup_flags_kernel, dim3(grid_for(nv)), dim3(256), 0, ctx->stream, b_rid.as<uint64_t>(),
-                                   b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), seg_start, skip_arg, Eproc, b_hit.as<uint8_t>(), nv, flags);
+                                   b_m0.as<uint64_t>(), b_m1.as<uint64_t>(), seg_start, skip_arg, Eproc, b_hit.as<uint8_t>(), nv, filter ? 1 : 0, flags);
             } else
                 SY_HIP(hipMemsetAsync(flags, 0, nv, ctx->stream));
             hipLaunchKernelGGL(would_count_kernel, dim3(grid_for(nv1)), dim3(256), 0, ctx->stream, flags, nv, no_dedup ? 1 : 0, uc);
@@ -828,6 +843,7 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     DeviceGuard dg(ctx->device);
     HostPhase ph_total(ctx, "finish: total incl. readback");
     SY_REQUIRE(sk->n_occ + sk->pend.n < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
+    if (sk->filter_dedup()) a10_mark(sk);        // the reference's default dedup for pairs: the filter's answers go into the records first
     // fast path: bucket partition + in-LDS replay (replay_lds.hip); falls through to the device-wide sort path
     // below when a bucket does not fit in LDS (some k-mer with thousands of occurrences)
     if (ctx->finish_mode != 1) {
@@ -838,7 +854,7 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     materialise_plain_records(sk);   // ... and on occurrence records
     sk->n_out = 0;
     sk->dup_removed = 0;
-    generic_replay(ctx, sk->hash.as<uint64_t>(), sk->recs.as<OccRec>(), (uint32_t)sk->n_occ, sk->paired, sk->no_dedup, sk->out_k,
+    generic_replay(ctx, sk->hash.as<uint64_t>(), sk->recs.as<OccRec>(), (uint32_t)sk->n_occ, sk->paired, sk->dedup_mode(), sk->out_k,
                    sk->out_c, sk->n_out, sk->dup_removed);
     sk->finished = true;
 }
@@ -1014,6 +1030,18 @@ int sylph_sketch_set_option(sylph_sketch* sk, const char* key, const char* value
         SY_REQUIRE(sk && key && value, "null argument");
         std::lock_guard<std::mutex> lock(sk->ctx->mu);
         if (!strcmp(key, "borrow_until_finish")) sk->borrow_until_finish = strtol(value, nullptr, 10) != 0;
+        else if (!strcmp(key, "dedup_fpr") || !strcmp(key, "dedup_capacity")) {
+            SY_REQUIRE_STATE(sk->rec_base == 0 && !sk->finished, "%s must be set before the first push", key);
+            if (key[6] == 'f') {
+                const double v = strtod(value, nullptr);
+                SY_REQUIRE(v >= 0. && v < 1., "dedup_fpr must be in [0, 1) (got %s)", value);
+                sk->dedup_fpr = v;
+            } else {
+                const long long v = strtoll(value, nullptr, 10);
+                SY_REQUIRE(v >= 1 && v < (1ll << 31), "dedup_capacity must be in [1, 2^31) (got %s)", value);
+                sk->dedup_capacity = (uint64_t)v;
+            }
+        }
         else SY_REQUIRE(false, "unknown session option %s", key);
     });
 }

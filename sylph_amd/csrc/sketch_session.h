@@ -5,8 +5,16 @@
 #include "common.h"
 
 namespace sylph {
-constexpr uint64_t RID_MARKER_BIT = 1ull << 63;   // rid: bit63 = has marker, low bits = global record index
-constexpr uint64_t RID_MASK = RID_MARKER_BIT - 1;
+// rid: bit 63 = the record (pair) has dedup markers; bit 62 = approximate dedup only (a10.hip): the filter reported one of the
+// occurrence's two (k-mer, markers) items as present; bits 42..61 = paired records with markers only: the occurrence's place in
+// its record's EMISSION order (device_common.h emission_rank — the order extract_markers pushed the record's seeds in, which is the
+// order sketch.rs:828-867 hands them to the dedup: it decides nothing for the exact set, and for the filter which of two items of
+// one pair meets the other); bits 0..41 = global record index (file order; mate = bit 0).
+constexpr uint64_t RID_MARKER_BIT = 1ull << 63;
+constexpr uint64_t RID_A10_BIT = 1ull << 62;
+constexpr int RID_RANK_SHIFT = 42;
+constexpr uint64_t RID_RANK_MAX = (1ull << 20) - 1;
+constexpr uint64_t RID_MASK = (1ull << RID_RANK_SHIFT) - 1;
 constexpr uint64_t INVALID_HASH = ~0ull;
 // One surviving seed occurrence.  Array-of-structs (32 B, one sector) because finish() gathers occurrences through a sort
 // permutation: four scattered 8 B reads per occurrence cost 4x the HBM sectors of one 32 B read.
@@ -17,8 +25,12 @@ namespace sylph {
 void flush_pending_slots(sylph_sketch* sk);   // reads.hip
 // bits of a hash kept in the 32-bit bucket key of an occurrence: key = hash >> key_shift(c) (hashes are below u64::MAX / c)
 inline int key_shift(uint32_t c) { return std::max(0, bit_length(UINT64_MAX / (uint64_t)std::max<uint32_t>(c, 1)) - 32); }
-void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, bool no_dedup,
+// dedup: DEDUP_EXACT (dup_removal_lsh_full_exact), DEDUP_NONE (--no-dedup), DEDUP_FILTER (dup_removal_lsh_full: the marker test is
+// the RID_A10_BIT a10_mark left in the records)
+constexpr int DEDUP_EXACT = 0, DEDUP_NONE = 1, DEDUP_FILTER = 2;
+void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, int dedup,
                     DevBuf& out_k, DevBuf& out_c, uint64_t& n_out, uint64_t& removed_out);   // sketch.hip
+void a10_mark(sylph_sketch* sk);              // a10.hip
 // A single-end session whose records carry no dedup markers so far (long reads: sketch.rs:922-927 passes no marker above 400
 // bases; --no-dedup) keeps only the hashes of its occurrences — nothing the replay looks at besides the hash exists for them
 // (no marker, no mate) — and finish() counts them without occurrence records.  The first batch that may carry markers (or a
@@ -57,6 +69,10 @@ struct sylph_sketch {
     int paired, no_dedup, avx2_compat;
     bool finished = false;
     bool borrow_until_finish = false;   // the caller keeps device batches valid until finish (sylph_sketch_set_option; see PendingSlots)
+    double dedup_fpr = 0.;              // > 0 (paired sessions): the reference's default dedup over a cuckoo filter of this false-positive probability (a10.hip)
+    uint64_t dedup_capacity = 10000000; // its initial capacity (sketch.rs:800)
+    bool filter_dedup() const { return paired && !no_dedup && dedup_fpr > 0.; }
+    int dedup_mode() const { return no_dedup ? sylph::DEDUP_NONE : (filter_dedup() ? sylph::DEDUP_FILTER : sylph::DEDUP_EXACT); }
     uint64_t rec_base = 0;         // records pushed so far
     uint64_t n_occ = 0;            // occurrences (valid + invalid) appended so far
     uint64_t n_plain = 0;          // the first n_plain of them have no OccRec (marker-less single-end batches, see materialise_plain_records)

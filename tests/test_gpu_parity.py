@@ -149,7 +149,7 @@ def test_genome_batch_matches_per_genome_oracle(ctx):
 FINISH_MODES = ("auto", "generic")   # bucket + in-LDS replay (with its fallback) and the device-wide sort path
 
 
-def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_AVX2_COMPAT, c=200, k=31, batches=1):
+def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_AVX2_COMPAT, c=200, k=31, batches=1, **dedup):
     """Sketches with BOTH finish paths and insists that they agree before returning the result."""
     res = []
     # both finish paths x the three seeding flavours (read-per-lane kernel, position kernel with ordered slots / unordered)
@@ -157,7 +157,7 @@ def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_A
         ctx.set_option("finish", mode)
         ctx.set_option("seeds", seeds)
         try:
-            res.append(_sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches))
+            res.append(_sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches, **dedup))
         finally:
             ctx.set_option("finish", "auto")
             ctx.set_option("seeds", "auto")
@@ -167,8 +167,8 @@ def sketch_gpu(ctx, bases, off, paired=False, no_dedup=False, seed_mode=S.SEED_A
     return res[0]
 
 
-def _sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches):
-    sk = S.ReadSketcher(ctx, c=c, k=k, paired=paired, no_dedup=no_dedup, seed_mode=seed_mode)
+def _sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches, **dedup):
+    sk = S.ReadSketcher(ctx, c=c, k=k, paired=paired, no_dedup=no_dedup, seed_mode=seed_mode, **dedup)
     n = len(off) - 1
     step = max(2, ((n // batches + 1) // 2) * 2)
     for s in range(0, max(n, 1), step):
@@ -265,6 +265,34 @@ def test_read_sketch_synthetic(ctx, paired, no_dedup):
                 assert_same_sketch(g, e)
             if not no_dedup:
                 assert e["dup_removed"] > 0
+
+
+@pytest.mark.parametrize("fpr,capacity", [(1e-4, None), (0.02, None), (0.05, 2500), (0.3, 600)])
+def test_read_sketch_paired_filter_dedup(ctx, fpr, capacity):
+    """a10, the reference's DEFAULT for pairs (sketch.rs:733-769 over a scalable cuckoo filter): csrc/a10.hip against the oracle's model
+    of the filter walked pair by pair — bit for bit, through both finish paths, every seeding flavour, one batch and several, with
+    the filter growing (small capacities) and with false positives that really happen (large --fpr)."""
+    rng = np.random.default_rng(77)
+    genome = random_seq(rng, 30000)
+    cap = {} if capacity is None else dict(dedup_capacity=capacity)
+    ocap = {} if capacity is None else dict(initial_capacity=capacity)
+    differs = 0
+    for c, n, L in ((20, 4000, 150), (5, 1500, 100), (200, 3000, 250)):
+        recs = make_reads(rng, genome, n, L, paired=True, dup_frac=0.3)
+        b, off = concat(recs)
+        for gm, om in MODES:
+            e = O.sketch_reads_cuckoo_model(b, off, c=c, mode=om, fpr=fpr, **ocap)
+            x = O.sketch_reads(b, off, c=c, mode=om, paired=True)
+            differs += int(e["dup_removed"] != x["dup_removed"])
+            for batches in (1, 4):
+                g = sketch_gpu(ctx, b, off, paired=True, seed_mode=gm, c=c, batches=batches, dedup_fpr=fpr, **cap)
+                assert_same_sketch(g, e)
+            assert e["dup_removed"] > 0
+    if fpr >= 0.02:
+        assert differs > 0          # the filter's false positives show in the result (else this test checks the exact path twice)
+    # --no-dedup and single-end sessions ignore the option (sketch.rs:744, :897)
+    g = sketch_gpu(ctx, b, off, paired=True, no_dedup=True, c=200, dedup_fpr=fpr, **cap)
+    assert_same_sketch(g, O.sketch_reads(b, off, c=200, paired=True, no_dedup=True))
 
 
 def test_read_sketch_deep_coverage_and_cutoff(ctx):

@@ -256,3 +256,85 @@ def test_a10_default_dedup_model_stays_close_to_the_exact_set():
         assert (d <= 0).all()                                               # a false positive drops an occurrence, never adds one
         assert approx["dup_removed"] - exact["dup_removed"] == -int(d.sum())
         assert -int(d.sum()) <= bound * n_occ, (fpr, int(d.sum()), n_occ)
+
+
+# ---- a10: the data-parallel formulation of the filter walk (sylph_amd/csrc/a10.hip), restated in numpy against the model's walk ----
+_FX_K = np.uint64(0x517cc1b727220a95)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _fx_add(h, w):
+    with np.errstate(over="ignore"):
+        return (((h << np.uint64(5)) | (h >> np.uint64(59))) ^ w) * _FX_K
+
+
+def _a10_item_hash(km, marker):
+    z = np.zeros_like(km)
+    with np.errstate(over="ignore"):
+        return _fx_add(_fx_add(_fx_add(z, km), marker & np.uint64(0xffffffff)), marker >> np.uint64(32)) * _GOLD
+
+
+def _a10_reduced_key(h, fpr_j, cap_j):
+    """(fingerprint, smaller of the item's two buckets): what a cuckoo filter can still tell apart (a10.hip header)"""
+    fp_bits = min(31, max(1, int(np.ceil(np.log2(1.0 / fpr_j) + np.log2(8.0)))))
+    nb = 1
+    while nb * 4 < cap_j:
+        nb <<= 1
+    f = (h >> np.uint64(32)) & np.uint64((1 << fp_bits) - 1)
+    f = np.where(f == 0, np.uint64(1), f)
+    i1 = h & np.uint64(nb - 1)
+    i2 = (i1 ^ (_fx_add(np.zeros_like(f), f) >> np.uint64(11))) & np.uint64(nb - 1)
+    return (f << np.uint64(32)) | np.minimum(i1, i2)
+
+
+def a10_contained_by_classes(km, marker, fpr, cap0):
+    """contained[i] of the walk 'test item i, insert it when absent' WITHOUT walking: an item is contained iff it is not the first
+    of its reduced-key class among the items that reach the current filter, or a closed filter holds its class; the item that
+    opens filter j + 1 is the one with cap_j inserting items of phase j before it."""
+    n = len(km)
+    h = _a10_item_hash(km, marker)
+    contained = np.zeros(n, dtype=bool)
+    closed = []                                   # (fpr_j, cap_j, sorted reduced keys of the filter's members)
+    begin, j = 0, 0
+    while True:
+        fpr_j, cap_j = fpr * 0.9 ** j, cap0 << j
+        idx = np.arange(begin, n)
+        prior = np.zeros(len(idx), dtype=bool)
+        for (fq, cq, members) in closed:
+            prior |= np.isin(_a10_reduced_key(h[idx], fq, cq), members)
+        g = _a10_reduced_key(h[idx], fpr_j, cap_j)
+        reach = np.flatnonzero(~prior)
+        _, first = np.unique(g[reach], return_index=True)           # first occurrence of every class, in item order
+        inserts = np.sort(reach[first])                              # positions (relative to begin) of the inserting items
+        is_insert = np.zeros(len(idx), dtype=bool)
+        is_insert[inserts] = True
+        if len(inserts) <= cap_j:
+            contained[idx] = ~is_insert
+            return contained, j + 1
+        cut = int(inserts[cap_j])                                    # relative position of the item that opens the next filter
+        contained[idx[:cut]] = ~is_insert[:cut]
+        closed.append((fpr_j, cap_j, np.unique(g[inserts[:cap_j]])))
+        begin += cut
+        j += 1
+
+
+@pytest.mark.parametrize("fpr,cap0,n", [(1e-4, 10_000_000, 30_000), (0.05, 2500, 60_000), (0.3, 600, 20_000), (1e-3, 5000, 100_000)])
+def test_a10_filter_walk_equals_first_of_reduced_key_class(fpr, cap0, n):
+    rng = np.random.default_rng(int(n + cap0))
+    km = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+    marker = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+    rep = rng.integers(0, n, size=n // 5)                             # true repeats: a fifth of the items re-appear later
+    at = rng.integers(0, n, size=n // 5)
+    km[at], marker[at] = km[rep], marker[rep]
+    walked, n_filters = O.cuckoo_walk(km, marker, fpr=fpr, initial_capacity=cap0)
+    classes, n_phases = a10_contained_by_classes(km, marker, fpr, cap0)
+    assert n_phases == n_filters
+    assert np.array_equal(walked, classes), np.flatnonzero(walked != classes)[:10]
+    exact = np.zeros(n, dtype=bool)                                   # what an exact set would have answered
+    seen = set()
+    for i, key in enumerate(zip(km.tolist(), marker.tolist())):
+        exact[i] = key in seen
+        seen.add(key)
+    assert (walked | ~exact).all()                                    # no false negatives
+    if fpr >= 0.05:
+        assert (walked & ~exact).sum() > 10                           # and the false positives this test is about do occur
