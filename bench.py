@@ -331,6 +331,7 @@ def main():
     ap.add_argument("--no-files-leg", action="store_true", help="skip the leg that runs `sylph-hip sketch` on FASTQ files (plain, gzip)")
     ap.add_argument("--files-leg-pairs", type=int, default=1_000_000, help="read pairs per sample of that leg (default 1 M = 0.3 Gbp)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")
+    ap.add_argument("--no-filter-leg", action="store_true", help="skip the leg with sylph's default pair dedup (cuckoo filter, --fpr 1e-4)")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the leg of the mode `value` is NOT taken from")
     ap.add_argument("--seed", type=int, default=20250711)
     ap.add_argument("--sweep", default="", help="tuning runs only: JSON list of pipeline configurations ({name, workers, depth, max_batch, options{}, "
@@ -490,8 +491,10 @@ def main():
                 t = r["t"]
                 rows.append((t[2] - t[1], t[4] - t[3], r["n_table"], r["dup_removed"], r["n_covs"], r["probe_batch"]))
 
+    filter_box = [False]                     # the filter leg: sessions get the reference's default pair dedup (dedup_fpr 1e-4)
+
     def sketch_inline(rs):
-        sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode)
+        sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode, dedup_fpr=1e-4 if filter_box[0] else 0.0)
         if len(rs["batches"]) == 1:
             sk.set_option("borrow_until_finish", 1)     # the resident read sets outlive every session
         for bptr, optr, nrec, nb in rs["batches"]:
@@ -617,7 +620,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = agree(time.perf_counter() - t_start)
         fam = {}
-        for f in ("seeds", "compact", "annotate", "sort", "replay", "probe", "assemble", "exchange"):   # HIP events on the launch streams, all contexts
+        for f in ("seeds", "compact", "annotate", "sort", "replay", "a10", "probe", "assemble", "exchange"):   # HIP events on the launch streams, all contexts
             fam[f] = profiled[0].kernel_stats(f) if not args.no_kernel_timers else (0.0, 0)
         if comm is not None:
             fam["_exchange_totals"] = db.exchange_stats()
@@ -706,6 +709,49 @@ def main():
         sample_no[0] = 0
         packed_sets = None
 
+    # ---- the same samples with the pair set behind the reference's DEFAULT cuckoo filter (--fpr 1e-4, sketch.rs:733-769; csrc/a10.hip).
+    # `value` stays on the exact set (sylph's --fpr 0): the filter's hash bits are this repository's model of a crate that is not in
+    # the reference tree, so only the exact set is pinned to the reference's own arithmetic.  Reported beside it.
+    filter_leg = None
+    if not args.no_filter_leg and not long_mode and comm is None and db_mode != "genome":
+        try:
+            def with_filter(on):
+                pipe_box[0].set_option("dedup_fpr", "1e-4" if on else "0")
+                filter_box[0] = on
+            with_filter(True)
+            runners["pipelined"](2 * depth)
+            n_p = max(spb, int(0.5 / max(cal.get("pipelined_ms_per_sample", 1.0) * 1e-3, 1e-6)))
+            e_p, st_p, g_p, r_p, f_p = timed("pipelined", 2, max(1, n_p // 2))
+            leg_p = leg_summary("pipelined", max(1, n_p // 2), 2, e_p, st_p, g_p, r_p, f_p)
+            n_q = max(spb, int(0.2 / max(cal.get("sequential_ms_per_sample", 1.5) * 1e-3, 1e-6)))
+            e_q, st_q, g_q, r_q, f_q = timed("sequential", 1, n_q)
+            leg_q = leg_summary("sequential", n_q, 1, e_q, st_q, g_q, r_q, f_q)
+            filter_leg = {"what": "the same samples with sylph's default pair dedup: the pair set behind a scalable cuckoo filter, --fpr 1e-4, capacity 10^7 "
+                                  "(sketch.rs:733-769); bit-exact against the oracle's model of that filter, whose hash bits are not the crate's",
+                          "pipelined": {k_: leg_p[k_] for k_ in ("value", "ms_per_sample", "timed_region_s", "probe_batch_mean", "kernel_ms")},
+                          "one_step_at_a_time": {k_: leg_q[k_] for k_ in ("value", "ms_per_sample", "timed_region_s", "kernel_ms")},
+                          "dup_removed": int(np.mean([r[3] for r in r_p])), "dup_removed_exact_set": int(np.mean([r[3] for r in rows]))}
+            if not args.no_cpu_baseline and rank == 0:
+                sk_f, (kf, cf, nf, df) = sketch_inline(read_sets[0])
+                hb = read_sets[0]["bases"][:read_sets[0]["n_bases"]].cpu().numpy()
+                ho = read_sets[0]["rec_off"].cpu().numpy().astype(np.uint64)
+                t_o = time.time()
+                from oracle import oracle as O  # noqa: F811  (the checker of this leg's verify, never the thing measured)
+                e = O.sketch_reads_cuckoo_model(hb, ho, c=c_reads, k=k, mode=O.MODE_AVX2_FAST if O.lib().orc_has_avx2() else O.MODE_SCALAR, fpr=1e-4)
+                filter_leg["verify"] = {"what": "the whole table of the first read set vs the oracle's walk of the same filter (one CPU thread)",
+                                        "table_equal": bool(nf == len(e["kmers"]) and df == e["dup_removed"]
+                                                            and np.array_equal(SH.device_view(kf, nf, torch.int64, device).cpu().numpy().view(np.uint64), e["kmers"])
+                                                            and np.array_equal(SH.device_view(cf, nf, torch.int32, device).cpu().numpy().view(np.uint32), e["counts"])),
+                                        "entries": int(nf), "dup_removed": int(df), "oracle_seconds": round(time.time() - t_o, 2)}
+                sk_f.close()
+        except Exception as e:
+            filter_leg = {"error": str(e)}
+        try:
+            with_filter(False)
+        except Exception:
+            pass
+        sample_no[0] = 0
+
     comparisons = world * n_total                                             # every sample vs every genome of the DB
     parallelism = (f"{world} GPU(s), {mode}: " + (f"{n_workers} sketch worker contexts + 1 profile context per GPU, {depth} samples in flight, <= {max(spb, 8) if comm is None else spb} tables per probe launch" if mode == "pipelined" else f"one context per GPU, {spb} table(s) per probe launch") + "; database " +
                    ("sharded by GENOME over the GPUs (contiguous ranges balanced by k-mer count, an unsharded index each): every table all-gathered to "
@@ -741,6 +787,7 @@ def main():
         **({"exchange": main_leg["exchange"]} if "exchange" in main_leg else {}),
         "setup": dbstats,
         **({"resident_2bit": packed_leg} if packed_leg is not None else {}),
+        **({"default_pair_dedup": filter_leg} if filter_leg is not None else {}),
     }
     legs = {mode: (fam, rows)}
     if second is not None:

@@ -44,7 +44,7 @@ extern "C" {
 #define SYLPH_SEED_AVX2_COMPAT 1
 
 #define SYLPH_READS_SINGLE 0     /* sketch_sequences_needle, sketch.rs:897 */
-#define SYLPH_READS_PAIRED 1     /* sketch_pair_sequences with --fpr 0 (exact set), sketch.rs:771 */
+#define SYLPH_READS_PAIRED 1     /* sketch_pair_sequences, sketch.rs:771: the exact pair set (--fpr 0) unless the session option "dedup_fpr" selects the filter */
 
 #define SYLPH_MEM_HOST 0
 #define SYLPH_MEM_DEVICE 1
@@ -151,7 +151,8 @@ int sylph_sketch_genomes(sylph_ctx *ctx, const uint8_t *bases, const uint64_t *c
 /* Replaces sketch_sequences_needle (sketch.rs:897-959) / sketch_pair_sequences (sketch.rs:771-895) after record
  * parsing.  The host keeps what is sequential or textual: mean_read_length (sketch.rs:941-943, :825-826), file
  * and sample names.  Deduplication is the exact rule of dup_removal_lsh_full_exact (sketch.rs:690-731) with
- * MAX_DEDUP_COUNT = 4 for single-end (constants.rs:14, sketch.rs:937) and no cut-off for pairs (:837). */
+ * MAX_DEDUP_COUNT = 4 for single-end (constants.rs:14, sketch.rs:937) and no cut-off for pairs (:837); for pairs the session
+ * option "dedup_fpr" > 0 selects dup_removal_lsh_full (sketch.rs:733-769), the reference's default (see sylph_sketch_set_option). */
 int sylph_sketch_begin(sylph_ctx *ctx, uint32_t c, uint32_t k, int reads_mode, int no_dedup, int seed_mode,
                        sylph_sketch **out);
 
@@ -195,7 +196,15 @@ void sylph_sketch_destroy(sylph_sketch *sk);
  * for it, a block of reads that overflowed its slots, the number of seed occurrences) is read together with the finish's own
  * tail block, and a bad verdict re-runs the batch the checked way from the borrowed memory.  Results are identical; one
  * synchronisation per sample instead of two.  sylph_pipeline_submit sets it for its device batches (their memory is borrowed
- * until sylph_pipeline_next has returned the sample anyway). */
+ * until sylph_pipeline_next has returned the sample anyway).
+ * "dedup_fpr" = "<f>" (paired sessions, before the first push; 0 = off, the default): the pair set of sketch_pair_sequences is kept
+ * behind a scalable cuckoo filter of false-positive probability f, as the reference does for every --fpr != 0 — its default is 1e-4
+ * (cmdline.rs:77; sketch.rs:796-804 builds the filter with initial capacity 10^7, "dedup_capacity" = "<n>" overrides that: tests).
+ * Same walk as sketch.rs:733-769 — test the filter, insert when absent, drop the seed when `*c > 0` — evaluated without walking: a
+ * cuckoo filter reports an item iff an item with the same fingerprint and bucket pair went in before it (csrc/a10.hip).  The
+ * filter's crate (scalable_cuckoo_filter 0.2.4) is not part of the reference tree: geometry and growth follow its documentation,
+ * the hash bits are this library's, so WHICH pairs collide differs from a run of the reference (how many do — about f of the
+ * tests once a filter is full — does not).  Bit-exact against the model of the same filter in the tests' CPU checker. */
 int sylph_sketch_set_option(sylph_sketch *sk, const char *key, const char *value);
 
 /* ---- containment (sample vs every genome of a resident DB shard) ----------------------------------------- */
@@ -371,7 +380,8 @@ int sylph_pipeline_flush(sylph_pipeline *p);
  * sylph_pipeline_destroy on this pipeline (the sample's session and its share of the result block are released then). */
 int sylph_pipeline_next(sylph_pipeline *p, sylph_pipeline_result *out);
 uint32_t sylph_pipeline_outstanding(sylph_pipeline *p);
-/* The pipeline's own knobs — "serialize_seeding" (default 1: one seeding kernel at a time on the GPU — a worker's stream waits
+/* "dedup_fpr" / "dedup_capacity": handed to every session the pipeline opens from then on (sylph_sketch_set_option).
+ * The pipeline's own knobs — "serialize_seeding" (default 1: one seeding kernel at a time on the GPU — a worker's stream waits
  * for the event behind the previous worker's seeding kernel, no host blocks — while the other samples are in their dedup/count tails;
  * two VALU-bound seeding kernels side by side only slow each other, +3 % in r04), "min_batch" +
  * "batch_wait_us" (default 2 / 400: the profile thread waits up to batch_wait_us for min_batch ready tables while more samples are

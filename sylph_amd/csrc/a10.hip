@@ -23,7 +23,7 @@
 // never leaves filter 0 and takes the two passes with no host round trip.
 //
 // The crate (scalable_cuckoo_filter 0.2.4) is not in /root/reference: fingerprint width, bucket count, growth rule follow its
-// documentation, the hash bits are this repository's (oracle/sylph_oracle.cpp ScalableCuckoo — the checker of this file; the
+// documentation, the hash bits are this repository's (the ScalableCuckoo model of the tests' CPU checker; the
 // two agree bit for bit, tests/test_gpu_parity.py).  Which pairs collide therefore differs from a run of the reference;
 // how many do, and what a collision does, does not.  DESIGN.md §1.
 #include <cmath>
@@ -94,7 +94,12 @@ __device__ __forceinline__ void table_enter(const Filter& d, uint64_t g, uint64_
     for (;;) {
         unsigned long long k = load_agent(&d.tab[s].key);
         if (k == 0) k = atomicCAS(&d.tab[s].key, 0ull, (unsigned long long)g);
-        if (k == 0 || k == g) { atomicMax(&d.tab[s].inv_op, (unsigned long long)(NO_OP - op)); return; }
+        if (k == 0 || k == g) {
+            // (threads run roughly in file order: most later operations of a class find an earlier one in place and leave without the atomic)
+            const unsigned long long mine = NO_OP - op;
+            if (k == 0 || load_agent(&d.tab[s].inv_op) < mine) atomicMax(&d.tab[s].inv_op, mine);
+            return;
+        }
         s = (s + 1) & d.tab_mask;
     }
 }
@@ -300,7 +305,7 @@ void a10_mark(sylph_sketch* sk) {
     DevBuf b_tiles(ctx);
     for (int j = 0;; j++) {
         SY_REQUIRE(j < MAX_FILTERS, "the approximate dedup would need more than %d filters: raise dedup_capacity", MAX_FILTERS);
-        // the filter's geometry (oracle/sylph_oracle.cpp CuckooFilter::init, ScalableCuckoo::grow)
+        // the filter's geometry (as CuckooFilter::init / ScalableCuckoo::grow of the tests' CPU checker)
         const uint64_t cap = sk->dedup_capacity << j;
         const double fpr = sk->dedup_fpr * std::pow(0.9, (double)j);
         int fp_bits = (int)std::ceil(std::log2(1.0 / fpr) + std::log2(8.0));
@@ -314,7 +319,6 @@ void a10_mark(sylph_sketch* sk) {
         while (slots < 2 * remaining) slots <<= 1;
         tables.emplace_back(new DevBuf(ctx));
         tables.back()->reserve(slots * sizeof(Ent));
-        SY_HIP(hipMemsetAsync(tables.back()->p, 0, slots * sizeof(Ent), ctx->stream));
         Filter& cur = F.f[j];
         cur.tab = tables.back()->as<Ent>();
         cur.tab_mask = (uint32_t)(slots - 1);
@@ -325,6 +329,7 @@ void a10_mark(sylph_sketch* sk) {
         F.n = j + 1;
         F.end = NO_OP;
         ScopedKernelTimer t(ctx, "a10");
+        SY_HIP(hipMemsetAsync(tables.back()->p, 0, slots * sizeof(Ent), ctx->stream));
         hipLaunchKernelGGL(a10_enter_kernel, dim3(grid), dim3(A10_TPB), 0, ctx->stream, o, F);
         if (const char* dump = getenv("SYLPH_HIP_A10_DUMP")) {
             if (j == 0) {

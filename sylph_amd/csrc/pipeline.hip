@@ -90,6 +90,7 @@ struct sylph_pipeline {
     // tuning (sylph_pipeline_set_option): see the option table in include/sylph_hip.h
     uint32_t serialize_seeding = 1;              // 1 (default, r04: +3 %, profiles/r04_ab_pipeline_sweep.txt): one worker at a time runs its seeding kernel —
                                                  // two VALU-bound seeding kernels side by side only slow each other; the others are in their dedup/count tails
+    std::string dedup_fpr, dedup_capacity;       // "dedup_fpr" / "dedup_capacity": handed to every session the pipeline opens (sylph_sketch_set_option; a10.hip)
     uint32_t min_batch = 2, batch_wait_us = 400; // the profile thread waits up to batch_wait_us for min_batch ready tables while more are being sketched (r04: +1.2 %)
     std::mutex seed_mu;
     // serialize_seeding on the DEVICE: a push with a deferred verdict returns as soon as its kernels are queued, so holding a
@@ -116,6 +117,10 @@ struct sylph_pipeline {
             j->worker = w;
             // device batches are borrowed until sylph_pipeline_next has returned the sample: the seeding verdict may wait for finish
             if (rc == SYLPH_OK && j->mem == SYLPH_MEM_DEVICE && j->batches.size() == 1) rc = sylph_sketch_set_option(j->sk, "borrow_until_finish", "1");
+            std::string fpr, cap;
+            { std::lock_guard<std::mutex> lk(mu); fpr = dedup_fpr; cap = dedup_capacity; }
+            if (rc == SYLPH_OK && !fpr.empty()) rc = sylph_sketch_set_option(j->sk, "dedup_fpr", fpr.c_str());
+            if (rc == SYLPH_OK && !cap.empty()) rc = sylph_sketch_set_option(j->sk, "dedup_capacity", cap.c_str());
             for (size_t i = 0; rc == SYLPH_OK && i < j->batches.size(); i++) {
                 const sylph_read_batch& b = j->batches[i];
                 std::unique_lock<std::mutex> seed_lock(seed_mu, std::defer_lock);
@@ -420,6 +425,11 @@ int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* va
             *dst = (uint32_t)strtoul(value, nullptr, 10);
             return SYLPH_OK;
         }
+    }
+    if (!strcmp(key, "dedup_fpr") || !strcmp(key, "dedup_capacity")) {      // for the sessions opened from now on (checked by the session)
+        std::lock_guard<std::mutex> lk(p->mu);
+        (key[6] == 'f' ? p->dedup_fpr : p->dedup_capacity) = value;
+        return SYLPH_OK;
     }
     for (sylph_ctx* cx : p->wctx) {
         const int rc = sylph_ctx_set_option(cx, key, value);

@@ -85,9 +85,16 @@ void parallel_for(size_t n, uint64_t threads, F&& f) {
 
 struct Session {   // RAII
     sylph_sketch* sk = nullptr;
-    Session(Engine& e, uint64_t c, uint64_t k, bool paired, bool no_dedup) {
+    // dedup_fpr != 0 (pairs): the reference's dup_removal_lsh_full over its cuckoo filter (sketch.rs:839-848); 0: the exact set (:829-838)
+    Session(Engine& e, uint64_t c, uint64_t k, bool paired, bool no_dedup, double dedup_fpr = 0.) {
         hip_check(sylph_sketch_begin(e.context(), (uint32_t)c, (uint32_t)k, paired ? SYLPH_READS_PAIRED : SYLPH_READS_SINGLE,
                                      no_dedup ? 1 : 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
+        if (paired && !no_dedup && dedup_fpr != 0.) {
+            char v[64];
+            snprintf(v, sizeof(v), "%.17g", dedup_fpr);
+            const int rc = sylph_sketch_set_option(sk, "dedup_fpr", v);
+            if (rc != SYLPH_OK) { sylph_sketch_destroy(sk); sk = nullptr; hip_check(rc, "sylph_sketch_set_option(dedup_fpr)"); }
+        }
     }
     ~Session() { sylph_sketch_destroy(sk); }
     // keep != nullptr: the caller takes the pushed, unfinished session (the profile pipeline finishes it on the device and
@@ -294,7 +301,8 @@ std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std
                                                             std::optional<IndexedInput>* pre, sylph_sketch** keep = nullptr);
 std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                           uint64_t c, uint64_t k, std::optional<std::string> sample_name,
-                                                          bool no_dedup, std::optional<IndexedInput>* pre, sylph_sketch** keep = nullptr);
+                                                          bool no_dedup, double dedup_fpr, std::optional<IndexedInput>* pre,
+                                                          sylph_sketch** keep = nullptr);
 }  // namespace
 
 // sketch.rs:897-959
@@ -346,21 +354,22 @@ std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std
 }
 }  // namespace
 
-// sketch.rs:771-895.  The exact marker set (--fpr 0, :829-838) is the only dedup structure on the GPU; the reference's
-// default for pairs is an approximate cuckoo filter (third-party crate) with the same intent.
+// sketch.rs:771-895.  dedup_fpr == 0: the exact marker set (:829-838); else the set behind a cuckoo filter of that false-positive
+// probability (:839-848; the session option "dedup_fpr", csrc/a10.hip).
 std::optional<SequencesSketch> sketch_pair_sequences(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                      uint64_t c, uint64_t k, std::optional<std::string> sample_name,
-                                                     bool no_dedup, double /*dedup_fpr*/) {
-    return sketch_pair_sequences_impl(e, read_file1, read_file2, c, k, std::move(sample_name), no_dedup, nullptr);
+                                                     bool no_dedup, double dedup_fpr) {
+    return sketch_pair_sequences_impl(e, read_file1, read_file2, c, k, std::move(sample_name), no_dedup, dedup_fpr, nullptr);
 }
 namespace {
 std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                           uint64_t c, uint64_t k, std::optional<std::string> sample_name,
-                                                          bool no_dedup, std::optional<IndexedInput>* pre, sylph_sketch** keep) {
+                                                          bool no_dedup, double dedup_fpr, std::optional<IndexedInput>* pre,
+                                                          sylph_sketch** keep) {
     std::optional<IndexedInput> own;
     if (!pre) { own = index_inputs(read_file1, &read_file2); pre = &own; }
     if (auto& in = *pre) {
-        Session s(e, c, k, true, no_dedup);
+        Session s(e, c, k, true, no_dedup, dedup_fpr);
         double mean = 0.;
         sketch_indexed(e, s.sk, *in, mean);
         {
@@ -378,7 +387,7 @@ std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::
         throw Error{1, "Paired end reading failed for '" + read_file1 + "' and '" + read_file2 +
                            "'. Make sure the files are present or the sequences are valid."};   // :781-784
     }
-    Session s(e, c, k, true, no_dedup);
+    Session s(e, c, k, true, no_dedup, dedup_fpr);
     double mean_read_length = 0., counter = 0.;
     const uint8_t *s1 = nullptr, *s2 = nullptr;
     uint32_t l1 = 0, l2 = 0;
@@ -577,15 +586,10 @@ int sketch(Engine& e, const SketchArgs& args) {
     else if (args.sample_names) sample_names = args.sample_names;
     if (sample_names && sample_names->size() != first_pairs.size() + read_inputs.size())
         throw Error{1, "Sample name length is not equal to the number of reads. Exiting"};   // :288-292
-    // a10 (sketch.rs:733-769, default --fpr 1e-4 cmdline.rs:77) is not built: the only dedup structure on the GPU is the EXACT marker
-    // set (sylph's `--fpr 0` path, sketch.rs:690-731).  A run whose reference semantics would be the cuckoo filter is refused unless
-    // the caller accepts the exact set — silently computing something else under the reference's default flags is not a drop-in.
-    // (--no-dedup never consults the filter: sketch.rs:744.)
-    if (args.fpr != 0. && !first_pairs.empty() && !args.no_dedup && !exact_dedup_accepted(args.exact_dedup))
-        throw Error{1, "paired-end reads with --fpr " + std::to_string(args.fpr) + ": sylph deduplicates them with an approximate cuckoo filter "
-                       "(scalable_cuckoo_filter 0.2.4), which this build does not have — it has the EXACT marker set of `--fpr 0`. "
-                       "Pass --fpr 0 or --exact-dedup (or set SYLPH_HIP_EXACT_DEDUP=1) to accept exact deduplication: identical to "
-                       "`sylph sketch --fpr 0`, about 2e-5 of the k-mer occurrences counted differently from sylph's default"};
+    // a10: pairs are deduplicated as the reference does — --fpr != 0 (default 1e-4, cmdline.rs:77): the set behind a cuckoo filter
+    // (sketch.rs:733-769; the session option "dedup_fpr"); --fpr 0: the exact set (:690-731).  --exact-dedup / SYLPH_HIP_EXACT_DEDUP=1
+    // (not in the reference) force the exact set whatever --fpr says.  (--no-dedup never consults the filter: sketch.rs:744.)
+    const double pair_fpr = exact_dedup_accepted(args.exact_dedup) ? 0. : args.fpr;
 
     // Samples are independent (sketch.rs:313,371 runs them on the rayon pool, `-t`): a pool of `-t` worker threads, each with
     // its own GPU context (calls on one context are serialised) and its own page-locked batch, takes them in input order.
@@ -616,7 +620,7 @@ int sketch(Engine& e, const SketchArgs& args) {
         if (j < first_pairs.size()) {                                        // :311-367
             std::optional<std::string> sample_name;
             if (sample_names) sample_name = (*sample_names)[j];
-            auto sk = sketch_pair_sequences_impl(eng, first_pairs[j], second_pairs[j], args.c, args.k, sample_name, args.no_dedup, &pre);
+            auto sk = sketch_pair_sequences_impl(eng, first_pairs[j], second_pairs[j], args.c, args.k, sample_name, args.no_dedup, pair_fpr, &pre);
             if (!sk) return;
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
@@ -1050,7 +1054,8 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         std::atomic<bool> cancel{false};
         std::mutex gate_mu;
         std::condition_variable gate_cv;
-        bool warned_pairs = false;
+        // contain.rs:591: raw pairs are sketched with the default filter (DEFAULT_FPR) — unless the exact set is asked for (not in the reference)
+        const double raw_pair_fpr = exact_dedup_accepted(args.exact_dedup) ? 0. : DEFAULT_FPR;
         auto prepare = [&](Engine& eng, size_t j) {
             Prepared pr;
             try {
@@ -1063,7 +1068,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                     std::optional<IndexedInput> pre = ahead.get(j);
                     ahead.start(j + n_workers);
                     if (files.size() == 1) pr.meta = sketch_sequences_needle_impl(eng, files[0], args.c, args.k, std::nullopt, false, &pre, &pr.session);
-                    else pr.meta = sketch_pair_sequences_impl(eng, files[0], files[1], args.c, args.k, std::nullopt, false, &pre, &pr.session);
+                    else pr.meta = sketch_pair_sequences_impl(eng, files[0], files[1], args.c, args.k, std::nullopt, false, raw_pair_fpr, &pre, &pr.session);
                 }
             } catch (...) { pr.error = std::current_exception(); }
             promises[j].set_value(std::move(pr));
@@ -1087,15 +1092,6 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                 prepare(*eng, j);
             }
         };
-        for (const auto& r : read_files)
-            if (r.size() > 1 && !warned_pairs) {
-                warned_pairs = true;
-                // contain.rs:591 forces the cuckoo default (fpr 1e-4) for raw pairs; here there is only the exact set: refuse unless accepted
-                if (!exact_dedup_accepted(args.exact_dedup))
-                    throw Error{1, "raw paired reads: sylph deduplicates them with its approximate cuckoo filter (contain.rs:591), which this build "
-                                   "does not have. Pass --exact-dedup (or set SYLPH_HIP_EXACT_DEDUP=1) to accept the exact marker set: results then "
-                                   "equal `sylph sketch --fpr 0` followed by profile / query on the sketches"};
-            }
         sylph_pipeline* pipe = nullptr;
         sylph_pipeline_config cfg;
         memset(&cfg, 0, sizeof(cfg));

@@ -253,7 +253,7 @@ struct SketchArgs {   // cmdline.rs:28-86
     std::optional<std::vector<std::string>> sample_names;
     std::string db_out_name = "database", sample_output_dir = "./";
     bool individual = false, no_dedup = false, no_pseudotax = false;
-    bool exact_dedup = false;   // --exact-dedup (not in the reference): accept the exact marker set where the reference would use its cuckoo filter
+    bool exact_dedup = false;   // --exact-dedup (not in the reference): the exact marker set where the reference would use its cuckoo filter
     uint64_t k = 31, c = 200, min_spacing_kmer = 30, threads = 3;   // -t: samples in flight (cmdline.rs: default 3)
     double fpr = DEFAULT_FPR;
     std::optional<std::string> list_sequence, list_reads, list_genomes, list_first_pair, list_second_pair, list_sample_names;
@@ -265,9 +265,9 @@ struct ContainCmdArgs : ContainArgs {   // cmdline.rs:88-160
     bool individual = false;
     bool exact_dedup = false;   // --exact-dedup: raw pairs are deduplicated with the exact marker set (the reference forces its cuckoo filter, contain.rs:591)
 };
-// a10 stance: the approximate cuckoo-filter dedup of the reference is not built; paired input whose
-// reference semantics would be that filter is refused unless the caller asks for the exact set (--exact-dedup, --fpr 0 where the
-// command has it, or SYLPH_HIP_EXACT_DEDUP=1 in the environment)
+// a10: paired input is deduplicated as the reference does — behind its cuckoo filter for --fpr != 0
+// (the default; raw pairs in profile / query always: contain.rs:591) — unless the caller asks for the exact set: --exact-dedup,
+// SYLPH_HIP_EXACT_DEDUP=1 in the environment (neither is in the reference), or --fpr 0 where the command has it
 bool exact_dedup_accepted(bool flag);
 // --estimate-unknown (contain.rs:901-951, :377-408)
 std::optional<double> get_kmer_identity(const SequencesSketch& S, bool estimate_unknown);

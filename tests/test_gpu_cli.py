@@ -19,8 +19,8 @@ BIN = os.path.join(ROOT, "sylph_amd", "sylph-hip")
 
 
 def run(*args, check=True, accept_exact=True):
-    # the reference's own integration assertions use default flags on pairs: this build only has the exact marker set and refuses
-    # such runs unless that is accepted (--exact-dedup / SYLPH_HIP_EXACT_DEDUP=1; test_paired_default_fpr_is_refused... below)
+    # (most tests here compare with the oracle's EXACT pair set: SYLPH_HIP_EXACT_DEDUP=1 selects it whatever --fpr says; the
+    #  reference's default — the filter — is test_paired_reads_are_deduplicated_as_the_reference_does_by_default's subject)
     env = dict(os.environ)
     env.pop("SYLPH_HIP_EXACT_DEDUP", None)
     if accept_exact:
@@ -388,24 +388,45 @@ def test_estimate_unknown_columns_vs_independent_restatement(data):
     assert with_u != plain                                # the option changes the coverage and abundance columns
 
 
-def test_paired_default_fpr_is_refused_unless_exact_dedup_is_accepted(data):
-    """a10 (cuckoo-filter dedup, sketch.rs:733-769, default for pairs cmdline.rs:77, forced for raw pairs in profile contain.rs:591)
-    is not built: a run whose reference semantics would be that filter exits 1 with a message naming the ways to accept the exact
-    marker set; --exact-dedup, SYLPH_HIP_EXACT_DEDUP=1 and --fpr 0 all give the same bytes; --no-dedup never consults the filter."""
+def sylsp_table(path):
+    """(k-mers ascending, counts) of a .sylsp: the table leads the file (types.rs:145-155: u64 length, then (u64, u32) entries)"""
+    raw = open(path, "rb").read()
+    n = int.from_bytes(raw[:8], "little")
+    t = np.frombuffer(raw, dtype=np.dtype([("k", "<u8"), ("c", "<u4")]), count=n, offset=8)
+    o = np.argsort(t["k"])
+    return t["k"][o], t["c"][o]
+
+
+def test_paired_reads_are_deduplicated_as_the_reference_does_by_default(data):
+    """a10 (sketch.rs:733-769): with default flags the pair set lives behind a cuckoo filter of --fpr 1e-4 (cmdline.rs:77; raw
+    pairs in profile: contain.rs:591) — the sketch equals the oracle's model of that walk; --fpr 0, --exact-dedup and
+    SYLPH_HIP_EXACT_DEDUP=1 give the exact set (the same bytes, equal to the oracle's exact sketch); another --fpr is another
+    filter; --no-dedup never consults it."""
     d = data["dir"]
-    p = run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w1", check=False, accept_exact=False)
-    assert p.returncode == 1 and "EXACT marker set" in p.stderr and "--exact-dedup" in p.stderr and "--fpr 0" in p.stderr
-    assert not (d / "w1" / "s_1.fq.paired.sylsp").exists()
+    recs = [x for p in zip(data["m1"], data["m2"]) for x in p]
+    b, off = O.concat([bytes(r) for r in recs])
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w1", accept_exact=False)                    # the reference's default
     run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w2", "--fpr", "0", accept_exact=False)
     run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w3", "--exact-dedup", accept_exact=False)
-    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w4")                       # SYLPH_HIP_EXACT_DEDUP=1
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w4")                                        # SYLPH_HIP_EXACT_DEDUP=1
     run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w5", "--no-dedup", accept_exact=False)
+    run("sketch", "-1", d / "s_1.fq", "-2", d / "s_2.fq", "-d", d / "w6", "--fpr", "0.3", accept_exact=False)
+    tab = lambda w: sylsp_table(d / w / "s_1.fq.paired.sylsp")
+    for w, e in (("w1", O.sketch_reads_cuckoo_model(b, off, fpr=1e-4)), ("w2", O.sketch_reads(b, off, paired=True)),
+                 ("w5", O.sketch_reads(b, off, paired=True, no_dedup=True)), ("w6", O.sketch_reads_cuckoo_model(b, off, fpr=0.3))):
+        k, c = tab(w)
+        assert np.array_equal(k, e["kmers"]) and np.array_equal(c, e["counts"]), w
     ref = (d / "w2" / "s_1.fq.paired.sylsp").read_bytes()
     assert (d / "w3" / "s_1.fq.paired.sylsp").read_bytes() == ref and (d / "w4" / "s_1.fq.paired.sylsp").read_bytes() == ref
+    # (a sample this small leaves a filter of capacity 10^7 nearly empty: even at --fpr 0.3 hardly any test meets a false positive —
+    #  the filter's own effects are test_gpu_parity.py::test_read_sketch_paired_filter_dedup's subject)
+    # raw pairs in profile / query: the default filter (contain.rs:591), or the exact set on request — same rows as the sketches give
     g = data["genomes"]
-    q = run("profile", g["K12"][0], "-1", d / "s_1.fq", "-2", d / "s_2.fq", check=False, accept_exact=False)
-    assert q.returncode == 1 and "--exact-dedup" in q.stderr
-    run("profile", g["K12"][0], "-1", d / "s_1.fq", "-2", d / "s_2.fq", "--exact-dedup", accept_exact=False)
+    raw = run("profile", g["K12"][0], g["EC590"][0], "-1", d / "s_1.fq", "-2", d / "s_2.fq", accept_exact=False).stdout
+    pre = run("profile", g["K12"][0], g["EC590"][0], d / "w1" / "s_1.fq.paired.sylsp").stdout
+    assert raw == pre and len(raw.splitlines()) >= 2
+    raw0 = run("profile", g["K12"][0], g["EC590"][0], "-1", d / "s_1.fq", "-2", d / "s_2.fq", "--exact-dedup", accept_exact=False).stdout
+    assert raw0 == run("profile", g["K12"][0], g["EC590"][0], d / "w2" / "s_1.fq.paired.sylsp").stdout
 
 
 def test_parallel_feed_equals_sequential_feed(data):
