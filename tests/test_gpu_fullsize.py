@@ -172,3 +172,39 @@ def test_long_read_sample_in_two_pushes_at_c100_against_a_c200_database(ctx):
     assert np.array_equal(cc, ecc) and cc[:12].min() > 1000
     for gi in list(range(12)) + list(np.nonzero(ecc[12:])[0][:50] + 12):
         assert np.array_equal(covs[int(coff2[gi]):int(coff2[gi + 1])], np.sort(ecov[gi]))
+
+
+def test_filter_dedup_at_its_real_capacity_with_growth(ctx):
+    """a10 at full size: 1.5 Gbp of pairs = 12 M filter operations against the reference's own parameters (--fpr 1e-4, initial
+    capacity 10^7, sketch.rs:796-804): the first filter fills up and a second one opens in mid-sample.  csrc/a10.hip (two phases:
+    class table, count of the inserting operations, the cut, closed-filter lookups) against the oracle's walk of the same filter,
+    whole table and duplicate count; in one push and in three."""
+    import torch
+    import synth
+    dev = torch.device("cuda", 0)
+    c, k, n_pairs, read_len = 200, 31, 5_000_000, 150
+    genomes = synth.random_genomes(24, 2_000_000, dev, 3, mutated_frac=0.0)
+    bases, off = synth.paired_reads(genomes, n_pairs, seed=13)
+    torch.cuda.synchronize()
+    n_rec = 2 * n_pairs
+    n_bases = n_rec * read_len
+    hb = bases[:n_bases].cpu().numpy()
+    ho = off.cpu().numpy().astype(np.uint64)
+    e = O.sketch_reads_cuckoo_model(hb, ho, c=c, k=k, fpr=1e-4)
+    x = O.sketch_reads(hb, ho, c=c, k=k, paired=True)
+    assert int(e["counts"].sum()) + e["dup_removed"] > 5_100_000            # more than 10^7 operations: the filter had to grow
+    assert e["dup_removed"] >= x["dup_removed"]
+    for batches in (1, 3):
+        sk = S.ReadSketcher(ctx, c=c, k=k, paired=True, dedup_fpr=1e-4)
+        step = ((n_rec // batches + 1) // 2) * 2
+        keep = []
+        for a in range(0, n_rec, step):
+            z = min(n_rec, a + step)
+            o = (off[a:z + 1] - off[a]).contiguous()
+            keep.append(o)
+            torch.cuda.synchronize()
+            sk.push_device(bases.data_ptr() + a * read_len, o.data_ptr(), z - a, (z - a) * read_len)
+        g = sk.finish()
+        sk.close()
+        assert np.array_equal(g["kmers"], e["kmers"]) and np.array_equal(g["counts"], e["counts"]), batches
+        assert g["dup_removed"] == e["dup_removed"]

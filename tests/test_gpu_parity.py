@@ -421,6 +421,12 @@ def test_replay_configurations_by_kmer_depth(ctx, depth):
             assert e["dup_removed"] > 50 and (paired or e["counts"].max() >= depth // 2)
             for batches in (1, 3):
                 assert_same_sketch(_sketch_gpu_once(ctx, b, off, paired, False, S.SEED_AVX2_COMPAT, 7, 31, batches), e)
+        # the same buckets with the filter's answers in place of the marker comparisons (a10: every configuration reads the bit a10.hip
+        # left in the records, the device-wide path too); a small, leaky filter so that it grows and reports false positives
+        ef = O.sketch_reads_cuckoo_model(b, off, c=7, fpr=0.05, initial_capacity=2500)
+        assert ef["dup_removed"] != O.sketch_reads(b, off, c=7, paired=True)["dup_removed"]
+        for batches in (1, 3):
+            assert_same_sketch(_sketch_gpu_once(ctx, b, off, True, False, S.SEED_AVX2_COMPAT, 7, 31, batches, dedup_fpr=0.05, dedup_capacity=2500), ef)
     finally:
         ctx.set_option("finish", "auto")
     assert_same_sketch(sketch_gpu(ctx, b, off, paired=True, c=7), O.sketch_reads(b, off, c=7, paired=True))   # all three flavours agree

@@ -2,7 +2,7 @@
 """End-to-end host-feed measurement: synthetic paired FASTQ files on local disk -> `sylph-hip sketch` -> .sylsp,
 plain and gzip, wall clock of the whole command (process start, parsing, H2D, GPU, sketch file written)."""
 import os
-os.environ.setdefault("SYLPH_HIP_EXACT_DEDUP", "1")   # paired runs below use default flags: accept the exact marker set (a10 stance)
+os.environ.pop("SYLPH_HIP_EXACT_DEDUP", None)         # default flags, as a user runs them: pairs behind the cuckoo filter (--fpr 1e-4)
 import subprocess
 import sys
 import time
