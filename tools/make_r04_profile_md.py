@@ -130,6 +130,17 @@ if c5f and c5w:
             f"* SQ_INSTS_VALU {c5s.get('slots.SQ_INSTS_VALU', 0):.4g} per launch = {c5s.get('slots.SQ_INSTS_VALU', 0) / max(1, per_launch_kmers / 64):.1f} wave-instructions per hashed position; "
             f"VALU busy {100 * c5s.get('slots.SQ_ACTIVE_INST_VALU', 0) * 4 / max(1, 1024 * c5s.get('slots.GRBM_GUI_ACTIVE', 1) / 8):.0f} %; "
             f"{rf5.get('alone_on_gpu', {}).get('avg_launch_ms')} ms per launch alone ({c5.get('value')} Gbp/s for the whole step)."]
+fk = os.path.join(src, "kernel_stats_filter.csv")
+if os.path.exists(fk):
+    import csv
+    rows = [r for r in csv.DictReader(open(fk)) if "a10_" in r["Name"] or "fillBuffer" in r["Name"] or "compact_occ" in r["Name"]]
+    fl = b.get("c3", {}).get("default_pair_dedup", {})
+    out += ["", "### the filter dedup (csrc/a10.hip; rocprofv3 --stats of a run whose last leg sketches with `dedup_fpr` 1e-4, every kernel alone on the GPU)", "",
+            "| kernel | calls | average us |", "|---|---|---|"]
+    out += [f"| `{r['Name'].split('(')[0].replace('sylph::(anonymous namespace)::', '')[:60]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} |" for r in rows]
+    if fl and "pipelined" in fl:
+        out += ["", f"Bench line of the same tree: pipelined {fl['pipelined']['value']} Gbp/s ({fl['pipelined']['ms_per_sample']} ms per sample), one at a time "
+                    f"{fl['one_step_at_a_time']['ms_per_sample']} ms; the whole table of a 1 Gbp sample equal to the oracle's walk of the filter: {fl.get('verify', {}).get('table_equal')}."]
 open(os.path.join(dst, "r04_kernel_stats.md"), "w").write("\n".join(out) + "\n")
 json.dump({"hbm_bytes_per_launch": int(reads_fetch + reads_write), "kernel": "reads_kernel<31,1,0>", "valu_per_kmer": round(valu_per_kmer, 1),
            "valu_per_kmer_position_kernel": 38, "valu_busy": round(valu_busy, 3),

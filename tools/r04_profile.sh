@@ -12,17 +12,21 @@ done
 python bench.py --gpus 2 --workload small --steps 3 --warmup 1 --min-seconds 0.3 --no-cpu-baseline --no-h2d > $out/bench_small_2ranks.json 2> $out/bench_small_2ranks.err
 MASTER_PORT=29581 python bench.py --gpus 2 --workload small --db-mode genome --steps 3 --warmup 1 --min-seconds 0.3 --no-cpu-baseline --no-h2d > $out/bench_small_2ranks_genome.json 2> $out/bench_small_2ranks_genome.err
 # (a) the default (pipelined) command under the tracer: per-kernel durations as the bench line's HIP events see them
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_p -o c3 -- python bench.py --steps 4 --warmup 1 --min-seconds 0.3 --mode pipelined --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-packed-leg > $out/bench_prof.json 2> $out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_p -o c3 -- python bench.py --steps 4 --warmup 1 --min-seconds 0.3 --mode pipelined --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-packed-leg --no-filter-leg --no-files-leg > $out/bench_prof.json 2> $out/prof.err
 f=$(find $out/stats_p -name '*kernel_trace.csv' | head -1)
 python tools/step_timeline.py $f --steps 60 --anchor reads_kernel --summary-only > $out/kernels_pipelined.md
 rm -rf $out/stats_p
 # (b) one sample at a time: the dispatch sequence of a sample with its gaps, every kernel alone on the GPU
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o c3 -- python bench.py --steps 3 --warmup 1 --min-seconds 0.02 --mode sequential --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-packed-leg > $out/bench_prof_seq.json 2>> $out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o c3 -- python bench.py --steps 3 --warmup 1 --min-seconds 0.02 --mode sequential --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-packed-leg --no-filter-leg --no-files-leg > $out/bench_prof_seq.json 2>> $out/prof.err
 f=$(find $out/stats -name '*kernel_trace.csv' | head -1)
 python tools/step_timeline.py $f --steps 5 --anchor reads_kernel > $out/step_timeline.md
 find $out/stats -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 rm -rf $out/stats
-B="python bench.py --steps 3 --warmup 1 --min-seconds 0.02 --mode sequential --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-kernel-timers --no-packed-leg"
+# (c) the same with sylph's default pair dedup (the cuckoo filter, csrc/a10.hip): what the a10 kernels cost alone on the GPU
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_f -o c3 -- python bench.py --steps 2 --warmup 1 --min-seconds 0.02 --mode sequential --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-packed-leg --no-files-leg > $out/bench_prof_filter.json 2>> $out/prof.err
+find $out/stats_f -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats_filter.csv \;
+rm -rf $out/stats_f
+B="python bench.py --steps 3 --warmup 1 --min-seconds 0.02 --mode sequential --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-kernel-timers --no-packed-leg --no-filter-leg --no-files-leg"
 K='reads_kernel|probe_kernel|bucket_replay_kernel|hits_scatter_kernel|rows_sort_kernel|hits_count_kernel'
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-include-regex "$K" --output-format csv -d $out/pmc_$c -o s -- $B > /dev/null 2>&1
