@@ -135,9 +135,9 @@ if os.path.exists(fk):
     import csv
     rows = [r for r in csv.DictReader(open(fk)) if "a10_" in r["Name"] or "fillBuffer" in r["Name"] or "compact_occ" in r["Name"]]
     fl = b.get("c3", {}).get("default_pair_dedup", {})
-    out += ["", "### the filter dedup (csrc/a10.hip; rocprofv3 --stats of a run whose last leg sketches with `dedup_fpr` 1e-4, every kernel alone on the GPU)", "",
+    out += ["", "### the filter dedup (csrc/a10.hip; rocprofv3 --stats of a run whose last leg sketches with `dedup_fpr` 1e-4, averages over its pipelined and its one-at-a-time samples)", "",
             "| kernel | calls | average us |", "|---|---|---|"]
-    out += [f"| `{r['Name'].split('(')[0].replace('sylph::(anonymous namespace)::', '')[:60]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} |" for r in rows]
+    out += [f"| `{r['Name'].replace('sylph::(anonymous namespace)::', '').split('(')[0][:60]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} |" for r in rows]
     if fl and "pipelined" in fl:
         out += ["", f"Bench line of the same tree: pipelined {fl['pipelined']['value']} Gbp/s ({fl['pipelined']['ms_per_sample']} ms per sample), one at a time "
                     f"{fl['one_step_at_a_time']['ms_per_sample']} ms; the whole table of a 1 Gbp sample equal to the oracle's walk of the filter: {fl.get('verify', {}).get('table_equal')}."]
