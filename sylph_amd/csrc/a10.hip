@@ -103,12 +103,14 @@ __device__ __forceinline__ void table_enter(const Filter& d, uint64_t g, uint64_
     }
 }
 
-struct Occs { const uint64_t* hash; OccRec* recs; uint32_t n; };
+struct Occs { const uint64_t* hash; OccRec* recs; uint32_t n; const uint8_t* part; };   // part[i]: occurrence i takes part (a10_part_kernel)
 
 // Occurrence i takes part in the filter's bookkeeping iff it is valid, its pair has markers (sketch.rs:745) and it is not a
 // mate-2 occurrence of a k-mer that mate 1 of the same pair produced too (:852).  The dense arrays are in file order record by
 // record: the pair's mate-1 occurrences lie right before its mate-2 occurrences.
-__device__ __forceinline__ bool takes_part(const Occs& o, uint32_t i, uint64_t& km, uint64_t& rid, uint64_t& m0, uint64_t& m1) {
+// (The walk is linear in the pair's seeds in front of i — quadratic per pair, which only shows for pairs of long reads at c = 1: it
+//  is done ONCE per sample, by a10_part_kernel; every other kernel reads its verdict.)
+__device__ __forceinline__ bool walk_takes_part(const Occs& o, uint32_t i, uint64_t& km, uint64_t& rid, uint64_t& m0, uint64_t& m1) {
     // (every output is assigned before the walk below, whatever the verdict: with the assignments behind the loop hipcc 7.2 zeroed
     //  m0 for the lanes that had walked — seen in the ISA of the lookup kernels, and in half of the mate-2 lookups missing)
     const OccRec r = o.recs[i];
@@ -130,6 +132,20 @@ __device__ __forceinline__ bool takes_part(const Occs& o, uint32_t i, uint64_t& 
         }
     }
     return !mate1_has_it;
+}
+__global__ __launch_bounds__(A10_TPB) void a10_part_kernel(Occs o, uint8_t* __restrict__ part) {
+    const uint32_t i = blockIdx.x * A10_TPB + threadIdx.x;
+    if (i >= o.n) return;
+    uint64_t km, rid, m0, m1;
+    part[i] = walk_takes_part(o, i, km, rid, m0, m1) ? 1 : 0;
+}
+__device__ __forceinline__ bool takes_part(const Occs& o, uint32_t i, uint64_t& km, uint64_t& rid, uint64_t& m0, uint64_t& m1) {
+    const OccRec r = o.recs[i];
+    km = r.hash;
+    rid = r.rid;
+    m0 = r.m0;
+    m1 = r.m1;
+    return o.part[i] != 0;
 }
 // true: an earlier, closed filter holds the operation's reduced key
 __device__ __forceinline__ bool in_closed_filters(const Filters& F, uint64_t h) {
@@ -195,7 +211,8 @@ __global__ __launch_bounds__(A10_TPB) void a10_count_kernel(Occs o, Filters F, u
 // op_key): the workgroup finds the occurrence that holds inserting operation `rank` in ARRAY order; the operation wanted is in
 // the same record — the records before it hold the same inserting operations in either order — and one lane picks it among the
 // record's inserting operations by their keys.
-__global__ __launch_bounds__(A10_TPB) void a10_find_kernel(Occs o, Filters F, uint32_t tile, uint32_t rank, uint64_t* __restrict__ out_op) {
+__global__ __launch_bounds__(A10_TPB) void a10_find_kernel(Occs o, Filters F, uint32_t tile, uint32_t rank, unsigned long long* __restrict__ run_keys,
+                                                            uint32_t run_cap, uint64_t* __restrict__ out_op) {
     constexpr uint32_t PER = TILE_OCC / A10_TPB;
     __shared__ uint32_t s_cnt[A10_TPB];
     uint32_t mine = 0;
@@ -216,45 +233,47 @@ __global__ __launch_bounds__(A10_TPB) void a10_find_kernel(Occs o, Filters F, ui
     __syncthreads();
     uint32_t before = 0;
     for (uint32_t t = 0; t < threadIdx.x; t++) before += s_cnt[t];
-    if (!(rank >= before && rank < before + mine)) return;
-    uint32_t at = 0, r = before;                          // the occurrence that holds inserting operation `rank` in array order
-    for (uint32_t e = 0; e < PER; e++) {
-        if (rank < r + ins[e]) { at = tile * TILE_OCC + threadIdx.x * PER + e; break; }
-        r += ins[e];
+    // one lane holds inserting operation `rank` in array order: it names the occurrence and its record's run of occurrences
+    // [lo, hi) in the dense arrays (invalid entries in between belong to no record: skipped)
+    __shared__ uint32_t s_run[3];                         // at, lo, hi
+    __shared__ uint32_t s_t;                              // the record's inserting operations before number `rank` in array order
+    if (rank >= before && rank < before + mine) {
+        uint32_t at = 0, r = before;
+        for (uint32_t e = 0; e < PER; e++) {
+            if (rank < r + ins[e]) { at = tile * TILE_OCC + threadIdx.x * PER + e; break; }
+            r += ins[e];
+        }
+        const uint64_t rec = o.recs[at].rid & RID_MASK;
+        uint32_t lo = at, hi = at + 1;
+        while (lo > 0 && (o.hash[lo - 1] == INVALID_HASH || (o.recs[lo - 1].rid & RID_MASK) == rec)) lo--;
+        while (hi < o.n && (o.hash[hi] == INVALID_HASH || (o.recs[hi].rid & RID_MASK) == rec)) hi++;
+        s_run[0] = at; s_run[1] = lo; s_run[2] = hi;
+        s_t = rank - r;                                   // (those of `at` itself that come before number `rank`)
     }
-    // the record's run of occurrences [lo, hi) in the dense arrays (invalid entries in between belong to no record: skipped)
-    const uint64_t rec = o.recs[at].rid & RID_MASK;
-    uint32_t lo = at, hi = at + 1;
-    while (lo > 0 && (o.hash[lo - 1] == INVALID_HASH || (o.recs[lo - 1].rid & RID_MASK) == rec)) lo--;
-    while (hi < o.n && (o.hash[hi] == INVALID_HASH || (o.recs[hi].rid & RID_MASK) == rec)) hi++;
-    // inserting operations of the record before `at` in array order + those of `at` itself that come before number `rank`
-    uint32_t t = rank - r;
-    for (uint32_t i = lo; i < at; i++) {
+    __syncthreads();
+    const uint32_t at = s_run[0], lo = s_run[1], hi = s_run[2];
+    // The operation wanted is the record's inserting operation with exactly t of the record's inserting operations before it BY
+    // KEY, t = those before number `rank` in array order (the records in front hold the same inserting operations in either
+    // order).  The record's keys go to a scratch array (a record of a long read pair at c = 1 has thousands).
+    if (2 * (hi - lo) > run_cap) return;                  // (out_op stays unset: the host reports it)
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += A10_TPB) {
         uint64_t km, rid, m[2];
-        if (!takes_part(o, i, km, rid, m[0], m[1])) continue;
+        const bool part = takes_part(o, i, km, rid, m[0], m[1]);
         for (uint32_t w = 0; w < 2; w++) {
             const uint64_t op = op_key(rid, w);
-            if (op >= F.begin) t += (uint32_t)op_inserts(F, item_hash(km, m[w]), op);
+            const bool in = part && op >= F.begin && op_inserts(F, item_hash(km, m[w]), op);
+            run_keys[2 * (i - lo) + w] = in ? op : NO_OP;
+            if (in && i < at) atomicAdd(&s_t, 1u);
         }
     }
-    // the record's inserting operation with exactly t of the record's inserting operations before it BY KEY
-    for (uint32_t i = lo; i < hi; i++) {
-        uint64_t km, rid, m[2];
-        if (!takes_part(o, i, km, rid, m[0], m[1])) continue;
-        for (uint32_t w = 0; w < 2; w++) {
-            const uint64_t op = op_key(rid, w);
-            if (op < F.begin || !op_inserts(F, item_hash(km, m[w]), op)) continue;
-            uint32_t smaller = 0;
-            for (uint32_t i2 = lo; i2 < hi; i2++) {
-                uint64_t km2, rid2, m2[2];
-                if (!takes_part(o, i2, km2, rid2, m2[0], m2[1])) continue;
-                for (uint32_t w2 = 0; w2 < 2; w2++) {
-                    const uint64_t op2 = op_key(rid2, w2);
-                    if (op2 >= F.begin && op2 < op && op_inserts(F, item_hash(km2, m2[w2]), op2)) smaller++;
-                }
-            }
-            if (smaller == t) { *out_op = op; return; }
-        }
+    __syncthreads();                                      // (one workgroup: its own global writes are visible to it behind the barrier)
+    const uint32_t t = s_t, n_keys = 2 * (hi - lo);
+    for (uint32_t e = threadIdx.x; e < n_keys; e += A10_TPB) {
+        const unsigned long long key = run_keys[e];
+        if (key == NO_OP) continue;
+        uint32_t smaller = 0;
+        for (uint32_t q = 0; q < n_keys; q++) smaller += run_keys[q] < key ? 1u : 0u;
+        if (smaller == t) *out_op = key;
     }
 }
 
@@ -287,7 +306,14 @@ void a10_mark(sylph_sketch* sk) {
     if (!n) return;
     SY_REQUIRE(sk->dedup_capacity >= 1 && sk->dedup_capacity < (1ull << 31), "dedup_capacity out of range");
     HostPhase ph(ctx, "finish: a10 filter marks");
-    Occs o{sk->hash.as<uint64_t>(), sk->recs.as<OccRec>(), (uint32_t)n};
+    DevBuf b_part(ctx), b_run(ctx);
+    b_part.reserve(n);
+    Occs o{sk->hash.as<uint64_t>(), sk->recs.as<OccRec>(), (uint32_t)n, b_part.as<uint8_t>()};
+    {
+        ScopedKernelTimer t(ctx, "a10");
+        hipLaunchKernelGGL(a10_part_kernel, dim3((uint32_t)((n + A10_TPB - 1) / A10_TPB)), dim3(A10_TPB), 0, ctx->stream, o, b_part.as<uint8_t>());
+        SY_HIP(hipGetLastError());
+    }
     if (const char* dump = getenv("SYLPH_HIP_A10_DUMP")) {      // debug aid: the occurrence records the filter pass works on
         std::vector<OccRec> h(n);
         ctx->d2h(h.data(), o.recs, n * sizeof(OccRec));
@@ -365,7 +391,10 @@ void a10_mark(sylph_sketch* sk) {
             else {
                 uint64_t* d_cut = reinterpret_cast<uint64_t*>(b_tiles.as<uint32_t>() + ((n_tiles + 1) & ~1u));
                 SY_HIP(hipMemsetAsync(d_cut, 0xFF, 8, ctx->stream));
-                hipLaunchKernelGGL(a10_find_kernel, dim3(1), dim3(A10_TPB), 0, ctx->stream, o, F, tile, (uint32_t)(cap - seen), d_cut);
+                const uint32_t run_cap = (uint32_t)std::min<uint64_t>(2 * n, 1u << 22);     // operations of ONE record the cut can be looked for in
+                b_run.reserve((size_t)run_cap * 8);
+                hipLaunchKernelGGL(a10_find_kernel, dim3(1), dim3(A10_TPB), 0, ctx->stream, o, F, tile, (uint32_t)(cap - seen),
+                                   b_run.as<unsigned long long>(), run_cap, d_cut);
                 SY_HIP(hipGetLastError());
                 uint64_t cut = 0;
                 ctx->read_back(&cut, d_cut, 8);

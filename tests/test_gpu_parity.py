@@ -1081,6 +1081,14 @@ def test_read_shapes_fuzz(ctx, seed):
             e = O.sketch_reads(b, off, c=c, mode=om, paired=paired)
             g = sketch_gpu(ctx, b, off, paired=paired, seed_mode=gm, c=c, batches=int(rng.integers(1, 4)))
             assert_same_sketch(g, e)
+            if paired:       # the same shapes behind the filter (a10): a leaky one that has to grow, against the oracle's walk of it
+                cap = int(rng.choice([600, 2500, 40000]))
+                fpr = float(rng.choice([1e-4, 0.02, 0.3]))
+                ef = O.sketch_reads_cuckoo_model(b, off, c=c, mode=om, fpr=fpr, initial_capacity=cap)
+                n_ops = 2 * (int(ef["counts"].sum()) + ef["dup_removed"])
+                if n_ops <= cap * 255:                             # (a10.hip stops at 8 filters: c = 1 with the smallest capacity may need more)
+                    gf = sketch_gpu(ctx, b, off, paired=True, seed_mode=gm, c=c, batches=int(rng.integers(1, 4)), dedup_fpr=fpr, dedup_capacity=cap)
+                    assert_same_sketch(gf, ef)
 
 
 def test_short_reads_over_the_whole_byte_alphabet(ctx):
