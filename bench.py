@@ -185,13 +185,48 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     return db, int(n_total), community, stats, verify_set
 
 
+def effective_cpus():
+    """CPUs this process may really use: os.cpu_count() cut down to the affinity mask and to the cgroup's CPU quota (a container that
+    shows 256 hardware threads under `cpu.max` = 16 CPUs runs 256 threads for 6 ms of every 100 ms period and is frozen for the rest)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    q = None
+    dirs = ["/sys/fs/cgroup", "/sys/fs/cgroup/cpu"]
+    try:
+        for ln in open("/proc/self/cgroup"):
+            path = ln.strip().split(":")[-1]
+            if path.startswith("/") and path != "/":
+                dirs += ["/sys/fs/cgroup" + path, "/sys/fs/cgroup/cpu" + path]
+    except Exception:
+        pass
+    for d in dirs:
+        try:
+            a, per = open(d + "/cpu.max").read().split()[:2]
+            if a != "max":
+                q = min(q or 1e9, float(a) / float(per))
+        except Exception:
+            pass
+        try:
+            quota, per = int(open(d + "/cpu.cfs_quota_us").read()), int(open(d + "/cpu.cfs_period_us").read())
+            if quota > 0 and per > 0:
+                q = min(q or 1e9, quota / per)
+        except Exception:
+            pass
+    if q:
+        n = min(n, max(1, int(np.ceil(q))))
+    return n
+
+
 def cpu_baseline(bases, rec_off, n_pairs, read_len, c, k, db_host, whole):
     """Oracle (C++ restatement of the reference CPU path) on this box's host cores.  whole: the WHOLE sample (every read pair on one
     thread — the reference sketches one sample per thread, sketch.rs:313,371 — and every genome of the database on all threads,
     contain.rs:284): nothing extrapolated, and the results double as the full-size parity check (verify).  Otherwise a bounded
     sample, extrapolated (boxes without the host memory for the genome-major database)."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()                       # (threads beyond the container's CPU quota only get the whole process throttled)
     n_s = n_pairs if whole else min(n_pairs, 2_000_000)
     hb = bases[: n_s * 2 * read_len].cpu().numpy()
     ho = rec_off[: 2 * n_s + 1].cpu().numpy().astype(np.uint64)
@@ -250,7 +285,7 @@ def end_to_end_from_files(bases, n_pairs_total, read_len, n_pairs):
                 raise RuntimeError(p.stderr[-500:])
             per = [float(ln.split(" in ")[1].split(" s")[0]) for ln in p.stderr.split("\n") if "timing:" in ln]
             return dt, per
-        out = {"pairs_per_sample": n_pairs, "gbp_per_sample": round(gbp, 4), "host_threads": os.cpu_count(),
+        out = {"pairs_per_sample": n_pairs, "gbp_per_sample": round(gbp, 4), "host_threads": os.cpu_count(), "host_cpus_usable": effective_cpus(),
                "what": "`sylph-hip sketch` with default flags (pairs deduplicated behind the cuckoo filter, --fpr 1e-4) on FASTQ files in a temporary "
                        "directory: whole-command wall clock and the per-sample times it logs"}
         dt, per = run(["-1", *[f"{d}/p{i}_1.fq" for i in range(4)], "-2", *[f"{d}/p{i}_2.fq" for i in range(4)], "-t", "1"])
@@ -989,7 +1024,7 @@ def main():
             del dk_h
             cb = cpu_baseline(rs["bases"], rs["rec_off"], n_pairs, read_len, c, k, db_host, whole)
             t_cpu = n_bases / 1e9 / cb["sketch_gbp_per_s"] + n_total / cb["comparisons_per_s"]
-            out["cpu_baseline"] = {"value": round(n_bases / 1e9 / t_cpu, 4), "unit": "Gbp/s", "cores": cb["probe_cores"], "kind": "port",
+            out["cpu_baseline"] = {"value": round(n_bases / 1e9 / t_cpu, 4), "unit": "Gbp/s", "cores": cb["probe_cores"], "host_hardware_threads": os.cpu_count(), "kind": "port",
                                    "sample": cb["sample"], "sketch_gbp_per_s": round(cb["sketch_gbp_per_s"], 4),
                                    "sketch_cores": 1, "genome_comparisons_per_s": round(cb["comparisons_per_s"], 1),
                                    "sketch_s": round(cb["sketch_s"], 3), "probe_s": round(cb["probe_s"], 3), "extrapolated": not whole,

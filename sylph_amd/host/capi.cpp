@@ -192,8 +192,8 @@ int sylph_host_pgunzip(const char* path, unsigned threads, uint64_t* out_len, ui
     for (size_t r; (r = fread(buf, 1, sizeof(buf), f)) > 0;) gz.insert(gz.end(), buf, buf + r);
     fclose(f);
     uint8_t* o = nullptr;
-    size_t n = 0;
-    if (!sylph_host::parallel_gunzip(gz.data(), gz.size(), threads, &o, &n, 0)) return 0;
+    size_t n = 0, n_map = 0;
+    if (!sylph_host::parallel_gunzip(gz.data(), gz.size(), threads, &o, &n, &n_map, 0)) return 0;
     if (out_len) *out_len = n;
     if (out_crc) {
         uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
@@ -201,7 +201,7 @@ int sylph_host_pgunzip(const char* path, unsigned threads, uint64_t* out_len, ui
         *out_crc = c;
     }
     if (out && out_cap >= n) memcpy(out, o, n);
-    munmap(o, n);
+    sylph_host::inflated_release(o, n_map);
     return 1;
 }
 

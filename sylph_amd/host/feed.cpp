@@ -5,12 +5,14 @@
 // Record semantics are those of FastxReader (needletail 0.5.1: seq() without newlines, errors per record).
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -184,11 +186,55 @@ void PinnedBatch::add(sylph_sketch* sk, const uint8_t* a, uint32_t la, const uin
 // ---- block-parallel FASTQ indexing -------------------------------------------------------------------
 namespace { std::atomic<unsigned> g_parse_share{1}; }
 void set_parse_share(unsigned sample_threads) { g_parse_share = std::max(1u, sample_threads); }
+unsigned effective_cpus() {
+    static const unsigned n = [] {
+        unsigned cpus = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) cpus = std::min<unsigned>(cpus, (unsigned)CPU_COUNT(&set));
+        auto quota_of = [](const std::string& dir, double& q) {            // cgroup v2: "cpu.max" = "<quota|max> <period>"; v1: two files
+            if (FILE* f = fopen((dir + "/cpu.max").c_str(), "r")) {
+                char a[64] = {0};
+                long long period = 0;
+                const int got = fscanf(f, "%63s %lld", a, &period);
+                fclose(f);
+                if (got == 2 && strcmp(a, "max") != 0 && period > 0) { q = std::min(q, atof(a) / (double)period); return; }
+            }
+            long long quota = -1, period = 0;
+            if (FILE* f = fopen((dir + "/cpu.cfs_quota_us").c_str(), "r")) { if (fscanf(f, "%lld", &quota) != 1) quota = -1; fclose(f); }
+            if (FILE* f = fopen((dir + "/cpu.cfs_period_us").c_str(), "r")) { if (fscanf(f, "%lld", &period) != 1) period = 0; fclose(f); }
+            if (quota > 0 && period > 0) q = std::min(q, (double)quota / (double)period);
+        };
+        double q = 1e9;
+        quota_of("/sys/fs/cgroup", q);
+        quota_of("/sys/fs/cgroup/cpu", q);
+        if (FILE* f = fopen("/proc/self/cgroup", "r")) {                    // a nested group: "0::/path" (v2) or "N:cpu,cpuacct:/path" (v1)
+            char line[512];
+            while (fgets(line, sizeof(line), f)) {
+                std::string l(line);
+                while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+                const size_t c2 = l.rfind(':');
+                if (c2 == std::string::npos || c2 + 1 >= l.size() || l[c2 + 1] != '/') continue;
+                const std::string path = l.substr(c2 + 1);
+                if (path == "/") continue;
+                quota_of("/sys/fs/cgroup" + path, q);
+                quota_of("/sys/fs/cgroup/cpu" + path, q);
+            }
+            fclose(f);
+        }
+        if (q < 1e8) cpus = std::min<unsigned>(cpus, (unsigned)std::max(1.0, std::ceil(q)));
+        if (const char* e = getenv("SYLPH_HIP_CPUS")) cpus = (unsigned)std::max(1, atoi(e));
+        return cpus;
+    }();
+    return n;
+}
 unsigned parse_threads() {
     static const unsigned n = [] {
         if (const char* e = getenv("SYLPH_HIP_PARSE_THREADS")) return (unsigned)std::max(1, atoi(e));
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        return std::min(64u, std::max(std::min(hw, 8u), hw / 4));
+        // a quarter of the hardware threads (8..64) when the machine is the process's own; under a CPU quota as many as the quota allows
+        // (the feed's phases follow each other: each may use all of it)
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency()), cpus = effective_cpus();
+        return cpus < hw ? std::min(64u, std::max(2u, cpus)) : std::min(64u, std::max(std::min(hw, 8u), hw / 4));
     }();
     // `-t` sample threads index / gather / index-ahead at the same time, each with this many workers: they share the budget
     // (never below 2 per sample thread), so a large -t on a many-core box does not start thousands of transient threads
@@ -213,12 +259,70 @@ inline size_t next_line(const uint8_t* d, size_t n, size_t p) {   // start of th
 }
 }  // namespace
 
-FastqIndex::~FastqIndex() { if (data) munmap((void*)data, size); }
+FastqIndex::~FastqIndex() {
+    if (!data) return;
+    if (anonymous && map_bytes) inflated_release((void*)data, map_bytes);
+    else munmap((void*)data, size);
+}
+
+namespace {
+struct InflatedPool {
+    struct Map { void* p; size_t bytes; };
+    std::mutex mu;
+    std::vector<Map> idle;
+    size_t idle_bytes = 0;
+    size_t limit() const {
+        const size_t b = index_memory_budget();
+        return std::min<size_t>(b ? b / 4 : (size_t)8 << 30, (size_t)16 << 30);
+    }
+};
+InflatedPool& inflated_pool() { static InflatedPool p; return p; }
+}  // namespace
+void* inflated_acquire(size_t bytes, size_t* map_bytes) {
+    InflatedPool& pool = inflated_pool();
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        int best = -1;
+        for (size_t i = 0; i < pool.idle.size(); i++)
+            if (pool.idle[i].bytes >= bytes && pool.idle[i].bytes <= bytes + bytes / 2 + ((size_t)64 << 20) &&
+                (best < 0 || pool.idle[i].bytes < pool.idle[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0) {
+            const InflatedPool::Map m = pool.idle[(size_t)best];
+            pool.idle.erase(pool.idle.begin() + best);
+            pool.idle_bytes -= m.bytes;
+            *map_bytes = m.bytes;
+            return m.p;
+        }
+    }
+    const size_t want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void* buf = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (buf == MAP_FAILED) return nullptr;
+    (void)madvise(buf, want, MADV_HUGEPAGE);
+    *map_bytes = want;
+    return buf;
+}
+void inflated_release(void* p, size_t map_bytes) {
+    InflatedPool& pool = inflated_pool();
+    std::vector<InflatedPool::Map> drop;
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        pool.idle.push_back({p, map_bytes});
+        pool.idle_bytes += map_bytes;
+        while (pool.idle_bytes > pool.limit() && !pool.idle.empty()) {     // the oldest go first
+            drop.push_back(pool.idle.front());
+            pool.idle_bytes -= pool.idle.front().bytes;
+            pool.idle.erase(pool.idle.begin());
+        }
+    }
+    for (const auto& m : drop) munmap(m.p, m.bytes);
+}
 
 void FastqIndex::release_behind(size_t byte_offset) const {
     // only the inflated copy of a blocked-gzip file is real memory of this process (a mapped plain file is page cache the kernel
     // reclaims by itself): give the pages the feed has gathered from back, so that a large file never stays resident as a whole
     if (!anonymous || !data) return;
+    // (a buffer small enough to be recycled keeps its pages: the next file's inflate writes into them instead of faulting new ones in)
+    if (map_bytes && map_bytes <= inflated_pool().limit() / 2) return;
     const size_t page = 4096, upto = byte_offset / page * page;
     if (upto) (void)madvise((void*)data, upto, MADV_DONTNEED);
 }
@@ -368,12 +472,14 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
             // result (member CRC); otherwise the sequential reader (needletail does the same, one thread)
             uint8_t* buf = nullptr;
             size_t n_out = 0;
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const unsigned tz = getenv("SYLPH_HIP_PARSE_THREADS") ? threads : std::max(threads, std::min(64u, hw / 2));
-            if (!parallel_gunzip(data, size, tz, &buf, &n_out, index_memory_budget())) return;
+            const unsigned hw = effective_cpus();
+            const unsigned tz = getenv("SYLPH_HIP_PARSE_THREADS") ? threads : std::max(threads, std::min(64u, std::max(1u, hw / 2)));
+            size_t n_map = 0;
+            if (!parallel_gunzip(data, size, tz, &buf, &n_out, &n_map, index_memory_budget())) return;
             munmap((void*)data, size);
             data = buf;
             size = n_out;
+            map_bytes = n_map;
             anonymous = true;
             blocks.clear();
         }
@@ -382,15 +488,16 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
         // at once) beyond what the machine has ends in the OOM killer instead of in the sequential reader, which runs in
         // constant memory.  The drivers set the budget from MemAvailable and their concurrency.
         if (const size_t budget = index_memory_budget(); budget && total > budget) return;
-        void* buf = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (buf == MAP_FAILED) return;
-        (void)madvise(buf, total, MADV_HUGEPAGE);                                  // first touch by many threads: 2 MiB pages where the system allows
+        size_t n_map = 0;
+        void* buf = inflated_acquire(total, &n_map);                               // (a recycled buffer where there is one: no first touch)
+        if (!buf) return;
         // (inflating is pure compute per member: it takes more threads than the memory-bound index does)
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const bool inflated = bgzf_inflate(data, blocks, (uint8_t*)buf, getenv("SYLPH_HIP_PARSE_THREADS") ? threads : std::max(threads, std::min(64u, hw / 2)));
+        const unsigned hw = effective_cpus();
+        const bool inflated = bgzf_inflate(data, blocks, (uint8_t*)buf, getenv("SYLPH_HIP_PARSE_THREADS") ? threads : std::max(threads, std::min(64u, std::max(1u, hw / 2))));
         munmap((void*)data, size);
         data = (const uint8_t*)buf;
         size = total;
+        map_bytes = n_map;
         anonymous = true;
         if (!inflated) return;                                                     // (the sequential reader reports the damage)
         }

@@ -9,10 +9,13 @@
 //      end-of-block symbol, every literal a byte a FASTQ file may hold — and is FOLLOWED by another well-formed block header;
 //   2. inflate every stretch from its block start to the next stretch's block start with its own decoder, WITHOUT the 32 KiB that
 //      precede it: a copy that reaches back beyond the stretch's own output yields a symbol "byte w of the unknown window"
-//      (16-bit cells: 0..255 a byte, 256 + w a window reference), and symbols are copied around like bytes;
+//      (16-bit cells: 0..255 a byte, 256 + w a window reference), and symbols are copied around like bytes.  This pass keeps only
+//      the last 32 KiB of cells, in a ring that lives in the core's cache, and the stretch's length: writing all cells out (the
+//      first version: 2 B per inflated byte, 2 GB per file) made 94 decoders that take 14 ms each when alone take 110 ms each —
+//      page faults and memory traffic, not decoding (profiles/r04_feed*.txt, tools/gz_trace.sh);
 //   3. hand the windows down the chain — the last 32 KiB of stretch i, resolved with the window of stretch i-1, are the window of
-//      stretch i+1: 32 KiB of table look-ups per stretch, sequential but tiny — and resolve all stretches in parallel, straight
-//      into their place in the output;
+//      stretch i+1: 32 KiB of table look-ups per stretch, sequential but tiny — and decode every stretch a SECOND time, now as
+//      plain bytes with its window known, straight into its place in the output (the decoder is cheap next to the memory it saves);
 //   4. check the member's CRC-32 and length (per-stretch CRCs combined).  ANY doubt on the way — no block start found, a decoder
 //      that runs past the next stretch's start instead of landing on it, an invalid code, a CRC mismatch, a second member — makes
 //      the whole attempt return false, and the caller reads the file with the sequential reader as before: this path can make a
@@ -24,8 +27,11 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -221,10 +227,92 @@ struct Cells {   // 16-bit cells in anonymous memory with 2 MiB pages where the 
 
 enum class Stop { Error, AtStopBit, FinalBlock, OutOfLimit };
 
+// The three things a stretch is decoded INTO (the decoder below is a template over them):
+//   Cells    everything, as 16-bit cells, in memory of its own — the block-start search's scratch (a few MB per attempt);
+//   RingOut  pass 1 of a stretch: only the last WINDOW cells are kept, in a ring that stays in the core's cache — what pass 1 is
+//            for is the stretch's LENGTH and the symbolic image of its last 32 KiB (the next stretch's window);
+//   ByteOut  pass 2: plain bytes, straight into the stretch's place in the output, references in front of the stretch taken from
+//            its (by then known) window.
+// put(v): a literal;  copy(len, dist, have_window): a match, false = it reaches where nothing can be (error);  n: cells so far.
+struct CellsOut {
+    Cells& c;
+    size_t& n;
+    explicit CellsOut(Cells& cells) : c(cells), n(cells.n) {}
+    inline bool room(size_t extra) { return c.room(extra); }
+    inline void put(unsigned v) { c.v[c.n++] = (uint16_t)v; }
+    inline bool copy(unsigned len, unsigned dist, bool have_window) {
+        uint16_t* o = c.v + c.n;
+        if (dist <= c.n) {
+            const uint16_t* src = o - dist;
+            if (dist >= len) memcpy(o, src, (size_t)len * 2);
+            else for (unsigned i = 0; i < len; i++) o[i] = src[i];      // (overlapping copies run forward, byte order)
+        } else {
+            if (!have_window || dist - c.n > WINDOW) return false;        // bytes into the unknown window: 1 .. WINDOW
+            for (unsigned i = 0; i < len; i++) {
+                const long src = (long)c.n + (long)i - (long)dist;
+                o[i] = src >= 0 ? c.v[(size_t)src] : (uint16_t)(256 + WINDOW + src);
+            }
+        }
+        c.n += len;
+        return true;
+    }
+};
+struct RingOut {
+    uint16_t ring[WINDOW];
+    size_t n = 0;
+    inline bool room(size_t) { return true; }
+    inline void put(unsigned v) { ring[n++ & (WINDOW - 1)] = (uint16_t)v; }
+    inline bool copy(unsigned len, unsigned dist, bool have_window) {
+        if (dist > n && (!have_window || dist - n > WINDOW)) return false;
+        const size_t at = n & (WINDOW - 1);
+        if (dist <= n && dist >= len && at + len <= WINDOW) {             // the usual match: inside the stretch, no overlap, no wrap of
+            const size_t from = (n - dist) & (WINDOW - 1);                // either end in the ring
+            if (from + len <= WINDOW) { memcpy(ring + at, ring + from, (size_t)len * 2); n += len; return true; }
+        }
+        for (unsigned i = 0; i < len; i++, n++) {                         // (dist <= WINDOW: the source cell is still in the ring)
+            const long src = (long)n - (long)dist;
+            ring[n & (WINDOW - 1)] = src >= 0 ? ring[(size_t)src & (WINDOW - 1)] : (uint16_t)(256 + WINDOW + src);
+        }
+        return true;
+    }
+    // the last min(n, WINDOW) cells in stream order
+    void tail(std::vector<uint16_t>& t) const {
+        const size_t take = std::min<size_t>(n, WINDOW);
+        t.resize(take);
+        for (size_t i = 0; i < take; i++) t[i] = ring[(n - take + i) & (WINDOW - 1)];
+    }
+};
+struct ByteOut {
+    uint8_t* o;               // the stretch's place in the output
+    size_t cap;               // its length (known from pass 1): one byte more is an error
+    const uint8_t* win;       // the WINDOW bytes in front of it (nullptr: the stream's true start)
+    size_t n = 0;
+    inline bool room(size_t extra) { return n + extra <= cap + 258 + 8; }   // (checked exactly where bytes are written)
+    inline void put(unsigned v) { if (n < cap) o[n] = (uint8_t)v; n++; }
+    inline bool copy(unsigned len, unsigned dist, bool) {
+        if (n + len > cap) { n += len; return true; }                     // (longer than pass 1 found it: the caller sees n != cap)
+        uint8_t* d = o + n;
+        if (dist <= n) {
+            const uint8_t* src = d - dist;
+            if (dist >= len) memcpy(d, src, len);
+            else for (unsigned i = 0; i < len; i++) d[i] = src[i];
+        } else {
+            if (!win || dist - n > WINDOW) return false;
+            for (unsigned i = 0; i < len; i++) {
+                const long src = (long)n + (long)i - (long)dist;
+                d[i] = src >= 0 ? o[(size_t)src] : win[WINDOW + src];
+            }
+        }
+        n += len;
+        return true;
+    }
+};
+
 // Inflates blocks from b's position.  have_window = false: the stream's true start (a reference before the output is an error).
 // stop_bit: stop when a block ends exactly there (SIZE_MAX: run to the final block).  strict: FASTQ bytes only, stop after
 // `max_blocks` blocks (the block-start search); limit_cells bounds the output.
-Stop inflate_cells(Bits& b, Cells& out, bool have_window, size_t stop_bit, bool strict, unsigned max_blocks, size_t limit_cells) {
+template <class Out>
+Stop inflate_to(Bits& b, Out& out, bool have_window, size_t stop_bit, bool strict, unsigned max_blocks, size_t limit_cells) {
     BlockCodes dyn;
     for (unsigned blocks = 0;; blocks++) {
         if (b.bitpos() == stop_bit) return Stop::AtStopBit;
@@ -243,7 +331,7 @@ Stop inflate_cells(Bits& b, Cells& out, bool have_window, size_t stop_bit, bool 
                 b.refill();
                 const unsigned v = b.take(8);
                 if (b.overrun || (strict && !fastq_byte(v))) return Stop::Error;
-                out.v[out.n++] = (uint16_t)v;
+                out.put(v);
             }
         } else {
             const BlockCodes* c = &fixed_codes();
@@ -254,15 +342,15 @@ Stop inflate_cells(Bits& b, Cells& out, bool have_window, size_t stop_bit, bool 
                 int s = c->lit.decode(b);
                 if (s >= 0 && s < 256) {
                     if (strict && !fastq_byte((unsigned)s)) return Stop::Error;
-                    out.v[out.n++] = (uint16_t)s;
+                    out.put((unsigned)s);
                     s = c->lit.decode(b);
                     if (s >= 0 && s < 256) {
                         if (strict && !fastq_byte((unsigned)s)) return Stop::Error;
-                        out.v[out.n++] = (uint16_t)s;
+                        out.put((unsigned)s);
                         s = c->lit.decode(b);
                         if (s >= 0 && s < 256) {
                             if (strict && !fastq_byte((unsigned)s)) return Stop::Error;
-                            out.v[out.n++] = (uint16_t)s;
+                            out.put((unsigned)s);
                             continue;
                         }
                     }
@@ -277,27 +365,17 @@ Stop inflate_cells(Bits& b, Cells& out, bool have_window, size_t stop_bit, bool 
                 if (ds < 0 || ds >= 30) return Stop::Error;
                 const unsigned dist = DIST_BASE[ds] + b.take(DIST_EXTRA[ds]);
                 if (b.overrun) return Stop::Error;
-                uint16_t* o = out.v + out.n;
-                if (dist <= out.n) {
-                    const uint16_t* src = o - dist;
-                    if (dist >= len) memcpy(o, src, (size_t)len * 2);
-                    else for (unsigned i = 0; i < len; i++) o[i] = src[i];   // (overlapping copies run forward, byte order)
-                } else {
-                    if (!have_window) return Stop::Error;
-                    const size_t back = dist - out.n;                   // bytes into the unknown window: 1 .. WINDOW
-                    if (back > WINDOW) return Stop::Error;
-                    for (unsigned i = 0; i < len; i++) {
-                        const long src = (long)out.n + (long)i - (long)dist;
-                        o[i] = src >= 0 ? out.v[(size_t)src] : (uint16_t)(256 + WINDOW + src);
-                    }
-                }
-                out.n += len;
+                if (!out.copy(len, dist, have_window)) return Stop::Error;
                 if (out.n > limit_cells) return Stop::OutOfLimit;
             }
             if (b.overrun) return Stop::Error;
         }
         if (final_block) return Stop::FinalBlock;
     }
+}
+inline Stop inflate_cells(Bits& b, Cells& cells, bool have_window, size_t stop_bit, bool strict, unsigned max_blocks, size_t limit_cells) {
+    CellsOut out(cells);
+    return inflate_to(b, out, have_window, stop_bit, strict, max_blocks, limit_cells);
 }
 
 // first bit position >= from (and < to) where a plausible non-final dynamic block starts, followed by another valid block header
@@ -339,51 +417,70 @@ uint32_t crc32_of(const uint8_t* p, size_t n) {
     return x;
 }
 
-// The cell mappings are kept for the next file (a feed inflates two mate files per sample, sample after sample): pages that have been
-// touched once need no fault and no zeroing again — on the GPU box the first-touch cost of 2 GB of cells varied between 0.07 and
-// 0.85 s per file (2 MiB page allocation, compaction).  At most four mappings stay cached (mates x index-ahead); they are scratch, not state.
-struct CellPool {
-    struct Map { void* p; size_t bytes; bool busy; };
+// The decoders' threads live as long as the process: a file is three short parallel phases (tens of ms each), and creating and
+// joining 128 threads for each of them — a stack mapping, a malloc arena, their page faults, all under the process's one
+// address-space lock, while other threads of the feed are faulting pages in — made a fifth of the decoders start 60 ms late
+// (per-stretch times of 10 ms and 70 ms side by side in tools/gz_trace.sh's output; everybody waits for the last).
+class DecoderPool {
     std::mutex mu;
-    std::vector<Map> maps;
-    void* acquire(size_t bytes, size_t* got) {
-        std::lock_guard<std::mutex> lk(mu);
-        int best = -1;
-        for (size_t i = 0; i < maps.size(); i++)
-            if (!maps[i].busy && maps[i].bytes >= bytes && (best < 0 || maps[i].bytes < maps[(size_t)best].bytes)) best = (int)i;
-        if (best >= 0) { maps[(size_t)best].busy = true; *got = maps[(size_t)best].bytes; return maps[(size_t)best].p; }
-        for (size_t i = 0; i < maps.size(); i++)                              // none fits: an idle smaller one makes room
-            if (!maps[i].busy) { munmap(maps[i].p, maps[i].bytes); maps.erase(maps.begin() + (long)i); break; }
-        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (m == MAP_FAILED) return nullptr;
-        (void)madvise(m, bytes, MADV_HUGEPAGE);
-        maps.push_back(Map{m, bytes, true});
-        *got = bytes;
-        return m;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> workers;              // worker i runs index i + 1 (the caller is index 0)
+    const std::function<void(unsigned)>* job = nullptr;
+    unsigned want = 0, running = 0;
+    unsigned long gen = 0;
+    void loop(unsigned idx) {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)>* f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (idx >= want) continue;
+                f = job;
+            }
+            (*f)(idx);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--running == 0) cv_done.notify_one();
+            }
+        }
     }
-    void release(void* p) {
-        std::lock_guard<std::mutex> lk(mu);
-        size_t idle = 0;
-        for (auto& m : maps) { if (m.p == p) m.busy = false; idle += !m.busy; }
-        for (size_t i = 0; i < maps.size() && idle > 4;)                       // keep a few, give the rest back
-            if (!maps[i].busy && maps[i].p != p) { munmap(maps[i].p, maps[i].bytes); maps.erase(maps.begin() + (long)i); idle--; } else i++;
+   public:
+    // f(0) .. f(n - 1), f(0) on the calling thread; returns when all are done.  One caller at a time (parallel_gunzip's file lock).
+    void run(unsigned n, const std::function<void(unsigned)>& f) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (workers.size() + 1 < n) {
+                const unsigned idx = (unsigned)workers.size() + 1;
+                workers.emplace_back([this, idx] { loop(idx); });
+                workers.back().detach();                                  // (they end with the process)
+            }
+            job = &f;
+            want = n;
+            running = n - 1;
+            gen++;
+        }
+        cv_job.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return running == 0; });
     }
 };
-CellPool& cell_pool() { static CellPool p; return p; }
-
+DecoderPool& decoder_pool() { static DecoderPool* p = new DecoderPool(); return *p; }
 template <class F>
 void run_threads(unsigned n, F&& f) {
-    std::vector<std::thread> th;
-    for (unsigned w = 1; w < n; w++) th.emplace_back([&f, w] { f(w); });
-    f(0u);
-    for (auto& t : th) t.join();
+    if (n <= 1) { f(0u); return; }
+    const std::function<void(unsigned)> g = [&f](unsigned w) { f(w); };
+    decoder_pool().run(n, g);
 }
 
 }  // namespace
 
-bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** out, size_t* out_size, size_t memory_budget) {
+bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** out, size_t* out_size, size_t* out_map, size_t memory_budget) {
     *out = nullptr;
     *out_size = 0;
+    *out_map = 0;
     if (getenv("SYLPH_HIP_NO_PGUNZIP")) return false;
     // ---- member header (RFC 1952)
     if (n < 18 + 8 || gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xE0)) return false;
@@ -398,33 +495,46 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
     const uint8_t* tr = gz + n - 8;
     const uint32_t want_crc = tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
     const uint32_t want_len = tr[4] | (uint32_t)tr[5] << 8 | (uint32_t)tr[6] << 16 | (uint32_t)tr[7] << 24;
-    const size_t min_stretch = getenv("SYLPH_HIP_PGZ_STRETCH")   /* (tests lower it; read per call) */ ? (size_t)atol(getenv("SYLPH_HIP_PGZ_STRETCH")) : (2u << 20);
+    const size_t min_stretch = getenv("SYLPH_HIP_PGZ_STRETCH")   /* (tests lower it; read per call) */ ? (size_t)atol(getenv("SYLPH_HIP_PGZ_STRETCH")) : (1u << 20);
     const size_t body = body_end - body0;
     // One file at a time per process, on all the threads the host can spare: two mate files inflated side by side with 64 threads each
     // took 0.4-0.9 s apiece on the GPU box where one alone takes 0.1-0.2 s (tools/pgunzip_bench.py, profiles/r04_feed.txt) — the
     // decoders are compute-bound and interfere; queueing the files costs nothing and evens the times out.
     static std::mutex one_file_at_a_time;
     std::lock_guard<std::mutex> file_lock(one_file_at_a_time);
-    if (!getenv("SYLPH_HIP_PARSE_THREADS")) threads = std::max(threads, std::min(128u, std::max(1u, std::thread::hardware_concurrency()) / 2));
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, body / std::max<size_t>(min_stretch, 1024)));
+    // (as many as the process may really use — effective_cpus() knows about CPU quotas: decoders beyond the quota only burn it in a
+    //  burst and leave every thread of the process frozen for the rest of the scheduler's period)
+    if (!getenv("SYLPH_HIP_PARSE_THREADS")) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency()), cpus = effective_cpus();
+        threads = cpus < hw ? std::max(2u, cpus) : std::max(threads, std::min(128u, hw / 2));
+    }
+    // T stretches for NT threads, about three per thread: the threads take them off a counter, so that one that starts late or shares
+    // its core (the feed of the previous sample is still gathering and pushing meanwhile) holds the others up by a third of its share
+    // at most — with one stretch per thread a tenth of the decoders took three times as long as the rest, and everybody waited
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)threads * 3, body / std::max<size_t>(min_stretch, 1024)));
     if (T < 2) return false;                                               // nothing to gain: the sequential reader
-    // transient memory: 2 B per inflated byte for the cells + the output (estimate: the trailer's length, or 6x the file if that wrapped)
+    const unsigned NT = std::min(T, threads);
+    auto for_stretches = [&](auto&& f) {
+        std::atomic<unsigned> next{0};
+        run_threads(NT, [&](unsigned) { for (unsigned w = next++; w < T; w = next++) f(w); });
+    };
+    // memory: the output only (estimate: the trailer's length, or 3x the file if that wrapped)
     const size_t est = std::max<size_t>(want_len, body * 3);
-    if (memory_budget && est * 3 > memory_budget) return false;
+    if (memory_budget && est > memory_budget) return false;
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](const char* what) {
         if (!trace) return;
         const double t = now();
-        fprintf(stderr, "[sylph_hip pgunzip] %-24s %8.3f ms (%u threads)\n", what, (t - t_prev) * 1e3, T);
+        fprintf(stderr, "[sylph_hip pgunzip] %-24s %8.3f ms (%u stretches on %u threads)\n", what, (t - t_prev) * 1e3, T, NT);
         t_prev = t;
     };
     // ---- 1. block starts
     std::vector<size_t> start(T + 1, SIZE_MAX);
     start[0] = body0 * 8;
     std::atomic<bool> bad{false};
-    run_threads(T, [&](unsigned w) {
+    for_stretches([&](unsigned w) {
         if (w == 0) return;
         const size_t from = (body0 + body / T * w) * 8, to = std::min((body0 + body / T * (w + 1)) * 8, body_end * 8);
         start[w] = find_block_start(gz, body_end, from, to);
@@ -432,73 +542,141 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
     });
     if (bad) return false;
     lap("block starts");
-    // ---- 2. every stretch into cells: regions of one mapping, 12 cells per compressed byte each (address space, not memory: only what
-    // is written gets pages; FASTQ deflates 4-6x, a stretch beyond 12x gives the attempt up)
-    std::vector<Cells> cells(T);
-    std::vector<size_t> region(T + 1, 0);
-    for (unsigned w = 0; w < T; w++) {
-        const size_t in_bytes = ((w + 1 < T ? start[w + 1] : body_end * 8) - start[w]) / 8 + 16;
-        region[w + 1] = region[w] + ((in_bytes * 12 + (1u << 20)) & ~(size_t)((1u << 20) - 1));
-    }
-    size_t cell_map_bytes = 0;
-    void* cell_map = cell_pool().acquire(region[T] * 2, &cell_map_bytes);
-    if (!cell_map) return false;
-    struct MapGuard { void* p; ~MapGuard() { cell_pool().release(p); } } cell_guard{cell_map};
-    for (unsigned w = 0; w < T; w++) cells[w].carve((uint16_t*)cell_map + region[w], region[w + 1] - region[w]);
+    // Two ways from here, the same bytes either way.  The default: TWO passes, the first keeping nothing but a ring of cells in the
+    // core's cache, the second writing plain bytes.  The alternative (SYLPH_HIP_PGZ_PASSES=1; what this file did first): ONE decode into
+    // 16-bit cells for the whole stretch, then a translation — one decode less, but 2 B per inflated byte written to memory and read
+    // back.  Measured on the GPU box, four 1 Gbp .gz pairs in one command: 2.33 s with two passes, 3.70 s with one under the box's quota
+    // of 16 CPUs (decoding into cells runs at 330 MB/s per thread there, into the ring at 780); 2.9 s vs 3.2-3.8 s with 128 threads
+    // before the feed knew about the quota (profiles/r04_feed_gz_ab.txt).
+    const char* passes_env = getenv("SYLPH_HIP_PGZ_PASSES");
+    const bool single_pass = passes_env && atoi(passes_env) == 1;
+    std::vector<size_t> off(T + 1, 0);
+    std::vector<uint32_t> crc(T, 0);
+    size_t total = 0, map_bytes = 0;
+    void* buf = nullptr;
+    uint8_t* o = nullptr;
+    if (single_pass) {
+        // ---- 2'. every stretch into cells: regions of one mapping, 12 cells per compressed byte each (address space, not memory:
+        // only what is written gets pages; FASTQ deflates 4-6x, a stretch beyond 12x gives the attempt up)
+        std::vector<Cells> cells(T);
+        std::vector<size_t> region(T + 1, 0);
+        for (unsigned w = 0; w < T; w++) {
+            const size_t in_bytes = ((w + 1 < T ? start[w + 1] : body_end * 8) - start[w]) / 8 + 16;
+            region[w + 1] = region[w] + ((in_bytes * 12 + (1u << 20)) & ~(size_t)((1u << 20) - 1));
+        }
+        static void* cell_map = nullptr;                                    // (guarded by the file lock above)
+        static size_t cell_map_bytes = 0;
+        if (cell_map_bytes < region[T] * 2) {
+            if (cell_map) munmap(cell_map, cell_map_bytes);
+            cell_map_bytes = region[T] * 2 + region[T] / 2;
+            cell_map = mmap(nullptr, cell_map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (cell_map == MAP_FAILED) { cell_map = nullptr; cell_map_bytes = 0; return false; }
+            (void)madvise(cell_map, cell_map_bytes, MADV_HUGEPAGE);
+        }
+        for (unsigned w = 0; w < T; w++) cells[w].carve((uint16_t*)cell_map + region[w], region[w + 1] - region[w]);
+        std::vector<Stop> how(T, Stop::Error);
+        std::vector<size_t> end_bit(T, 0);
+        for_stretches([&](unsigned w) {
+            Bits b;
+            b.init(gz, body_end, start[w]);
+            how[w] = inflate_cells(b, cells[w], w != 0, w + 1 < T ? start[w + 1] : SIZE_MAX, false, 0, SIZE_MAX);
+            end_bit[w] = b.bitpos();
+        });
+        for (unsigned w = 0; w < T; w++)
+            if (how[w] != (w + 1 < T ? Stop::AtStopBit : Stop::FinalBlock)) return false;
+        if ((end_bit[T - 1] + 7) / 8 != body_end) return false;           // bytes behind the final block: another member, or garbage
+        lap("inflate to cells");
+        // ---- 3'. windows down the chain, then all stretches translated in parallel into the output
+        for (unsigned w = 0; w < T; w++) off[w + 1] = off[w] + cells[w].n;
+        total = off[T];
+        if ((uint32_t)total != want_len || total < 4) return false;
+        buf = inflated_acquire(total, &map_bytes);
+        if (!buf) return false;
+        o = (uint8_t*)buf;
+        std::vector<std::vector<uint8_t>> win(T);
+        win[0].assign(WINDOW, 0);
+        for (unsigned w = 0; w + 1 < T; w++) {
+            std::vector<uint8_t>& nx = win[w + 1];
+            nx.assign(WINDOW, 0);
+            const Cells& c = cells[w];
+            const size_t take = std::min<size_t>(c.n, WINDOW);
+            if (take < WINDOW) memcpy(nx.data(), win[w].data() + take, WINDOW - take);   // a short stretch: the rest is the older window
+            for (size_t i = 0; i < take; i++) {
+                const uint16_t v = c.v[c.n - take + i];
+                nx[WINDOW - take + i] = v < 256 ? (uint8_t)v : win[w][v - 256];
+            }
+        }
+        lap("windows");
+        for_stretches([&](unsigned w) {
+            const Cells& c = cells[w];
+            uint8_t* dst = o + off[w];
+            const uint8_t* wn = win[w].data();
+            for (size_t i = 0; i < c.n; i++) { const uint16_t v = c.v[i]; dst[i] = v < 256 ? (uint8_t)v : wn[v - 256]; }
+            crc[w] = crc32_of(dst, c.n);
+        });
+        lap("translate + crc");
+    } else {
+    // ---- 2. pass 1: every stretch decoded for its length and its last 32 KiB only (a ring of cells in the core's cache: nothing
+    // but the compressed bytes is read from memory, nothing is written to it)
+    std::vector<std::vector<uint16_t>> tails(T);
+    std::vector<size_t> n_out(T, 0);
     std::vector<Stop> how(T, Stop::Error);
     std::vector<size_t> end_bit(T, 0);
-    run_threads(T, [&](unsigned w) {
+    for_stretches([&](unsigned w) {
+        static thread_local std::unique_ptr<RingOut> ring_keep;           // (64 KiB per decoder thread, allocated once)
+        if (!ring_keep) ring_keep.reset(new RingOut());
+        RingOut* ring = ring_keep.get();
+        ring->n = 0;
         Bits b;
         b.init(gz, body_end, start[w]);
         const double t0 = trace ? now() : 0;
-        how[w] = inflate_cells(b, cells[w], w != 0, w + 1 < T ? start[w + 1] : SIZE_MAX, false, 0, SIZE_MAX);
+        how[w] = inflate_to(b, *ring, w != 0, w + 1 < T ? start[w + 1] : SIZE_MAX, false, 0, SIZE_MAX);
         end_bit[w] = b.bitpos();
-        if (trace) fprintf(stderr, "[sylph_hip pgunzip]   stretch %u: %zu compressed bytes -> %zu cells in %.2f ms\n", w, (end_bit[w] - start[w]) / 8, cells[w].n, (now() - t0) * 1e3);
+        n_out[w] = ring->n;
+        ring->tail(tails[w]);
+        if (trace) fprintf(stderr, "[sylph_hip pgunzip]   stretch %u: %zu compressed bytes -> %zu bytes, pass 1 in %.2f ms\n", w, (end_bit[w] - start[w]) / 8, n_out[w], (now() - t0) * 1e3);
     });
     for (unsigned w = 0; w < T; w++)
         if (how[w] != (w + 1 < T ? Stop::AtStopBit : Stop::FinalBlock)) return false;
     if ((end_bit[T - 1] + 7) / 8 != body_end) return false;               // bytes behind the final block: another member, or garbage
-    lap("inflate to cells");
-    // ---- 3. windows down the chain, then all stretches resolved in parallel into the output
-    std::vector<size_t> off(T + 1, 0);
-    for (unsigned w = 0; w < T; w++) off[w + 1] = off[w] + cells[w].n;
-    const size_t total = off[T];
+    lap("pass 1 (lengths, windows)");
+    // ---- 3. windows down the chain, then pass 2: every stretch decoded again, as bytes, straight into its place in the output
+    for (unsigned w = 0; w < T; w++) off[w + 1] = off[w] + n_out[w];
+    total = off[T];
     if ((uint32_t)total != want_len || total < 4) return false;
-    void* buf = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (buf == MAP_FAILED) return false;
-    (void)madvise(buf, total, MADV_HUGEPAGE);
-    uint8_t* o = (uint8_t*)buf;
+    buf = inflated_acquire(total, &map_bytes);                            // (a recycled buffer where there is one: no first touch)
+    if (!buf) return false;
+    o = (uint8_t*)buf;
     std::vector<std::vector<uint8_t>> win(T);                             // win[w]: the WINDOW bytes in front of stretch w
     win[0].assign(WINDOW, 0);
-    bool ok = true;
-    for (unsigned w = 0; w + 1 < T && ok; w++) {
+    for (unsigned w = 0; w + 1 < T; w++) {
         std::vector<uint8_t>& nx = win[w + 1];
         nx.assign(WINDOW, 0);
-        const Cells& c = cells[w];
-        const size_t take = std::min<size_t>(c.n, WINDOW);
+        const std::vector<uint16_t>& t = tails[w];
+        const size_t take = t.size();
         if (take < WINDOW) memcpy(nx.data(), win[w].data() + take, WINDOW - take);   // a short stretch: the rest is the older window
-        for (size_t i = 0; i < take; i++) {
-            const uint16_t v = c.v[c.n - take + i];
-            nx[WINDOW - take + i] = v < 256 ? (uint8_t)v : win[w][v - 256];
-        }
+        for (size_t i = 0; i < take; i++) nx[WINDOW - take + i] = t[i] < 256 ? (uint8_t)t[i] : win[w][t[i] - 256];
     }
     lap("windows");
-    std::vector<uint32_t> crc(T, 0);
-    run_threads(T, [&](unsigned w) {
-        const Cells& c = cells[w];
-        uint8_t* dst = o + off[w];
-        const uint8_t* wn = win[w].data();
-        for (size_t i = 0; i < c.n; i++) { const uint16_t v = c.v[i]; dst[i] = v < 256 ? (uint8_t)v : wn[v - 256]; }
-        crc[w] = crc32_of(dst, c.n);
-        // (the cells go back in one piece when the function returns)
+    std::atomic<bool> differs{false};
+    for_stretches([&](unsigned w) {
+        ByteOut out{o + off[w], n_out[w], w ? win[w].data() : nullptr};
+        Bits b;
+        b.init(gz, body_end, start[w]);
+        const Stop r = inflate_to(b, out, w != 0, w + 1 < T ? start[w + 1] : SIZE_MAX, false, 0, SIZE_MAX);
+        if (r != how[w] || b.bitpos() != end_bit[w] || out.n != n_out[w]) { differs = true; return; }   // (cannot happen: the same bits, the same decoder)
+        crc[w] = crc32_of(o + off[w], n_out[w]);
     });
-    lap("resolve + crc");
+    if (differs) { inflated_release(buf, map_bytes); return false; }
+    lap("pass 2 (bytes) + crc");
+    }
     // ---- 4. the member's CRC-32
     uint32_t all = crc[0];
     for (unsigned w = 1; w < T; w++) all = (uint32_t)crc32_combine(all, crc[w], (z_off_t)(off[w + 1] - off[w]));
-    if (all != want_crc) { munmap(buf, total); return false; }
+    if (all != want_crc) { inflated_release(buf, map_bytes); return false; }
     *out = o;
     *out_size = total;
+    *out_map = map_bytes;
     return true;
 }
 

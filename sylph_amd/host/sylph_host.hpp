@@ -116,7 +116,8 @@ struct FastqIndex {
     bool ok = false;
     const uint8_t* data = nullptr;   // the mapping (owned)
     size_t size = 0;
-    bool anonymous = false;          // `data` is the inflated copy of a blocked-gzip file (release_behind gives its pages back)
+    size_t map_bytes = 0;            // anonymous: what the mapping really spans (a recycled buffer may be larger than the file)
+    bool anonymous = false;          // `data` is the inflated copy of a gzip file: it goes back to the buffer pool (inflated_release)
     void release_behind(size_t byte_offset) const;   // the feed is done with everything before byte_offset
     std::vector<uint64_t> seq_off;   // byte offset of every record's sequence line
     std::vector<uint32_t> seq_len;
@@ -129,8 +130,19 @@ struct FastqIndex {
     size_t n_records() const { return seq_len.size(); }
 };
 // pgunzip.cpp: parallel inflate of a single-member gzip file (block-start search + window-free decoding + CRC check); false = not
-// done (any doubt at all): the caller reads the file sequentially.  *out: anonymous mapping of *out_size bytes (munmap).
-bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** out, size_t* out_size, size_t memory_budget);
+// done (any doubt at all): the caller reads the file sequentially.  *out: *out_size bytes in an anonymous mapping of *out_map bytes
+// from inflated_acquire (give it back with inflated_release).
+bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** out, size_t* out_size, size_t* out_map, size_t memory_budget);
+// Inflated copies of gzip files are GBs of anonymous memory each: a fresh mapping costs a page fault and a page of zeroes per 4 KiB
+// (90 ms per GB on the GPU box, as much as inflating it).  The buffers of files the feed is done with are kept (up to a quarter of
+// the index memory budget, at most 16 GB) and handed to the next file: its inflate writes into pages that are already there.
+void* inflated_acquire(size_t bytes, size_t* map_bytes);
+void inflated_release(void* p, size_t map_bytes);
+// CPUs this process may really use: the hardware threads, cut down to the cgroup's CPU quota (cpu.max / cfs_quota_us) and to the
+// affinity mask.  A container that shows 256 hardware threads under a quota of 16 CPUs runs 128 decoder threads for 12 ms of every
+// 100 ms period and is frozen for the other 88 (seen on the GPU box: per-stretch inflate times of 10 ms and 100 ms side by side):
+// every thread count of the feed starts from this number, not from hardware_concurrency().
+unsigned effective_cpus();
 unsigned parse_threads();   // worker threads of the parallel feed PER sample thread: SYLPH_HIP_PARSE_THREADS, else a quarter of the hardware threads (8..64), divided by set_parse_share
 void set_parse_share(unsigned sample_threads);   // the `-t` sample threads that run a feed each share the parse-thread budget
 constexpr size_t MAX_SAMPLE_THREADS = 16;        // each sample thread owns a GPU context + ~0.5 GB of page-locked batch buffers

@@ -77,7 +77,9 @@ def main():
     subprocess.run(["gzip", "-1", "-k", "-f", f"{d}/s_1.fq", f"{d}/s_2.fq"], check=True)
     bgzf_file(f"{d}/s_1.fq", f"{d}/b_1.fq.gz")
     bgzf_file(f"{d}/s_2.fq", f"{d}/b_2.fq.gz")
-    res = {"gbp": gbp, "fastq_bytes_per_file": b1, "host_threads": os.cpu_count()}
+    sys.path.insert(0, ROOT)
+    import bench as B
+    res = {"gbp": gbp, "fastq_bytes_per_file": b1, "host_threads": os.cpu_count(), "host_cpus_usable": B.effective_cpus()}
     for name, a in (("paired_plain", ["-1", f"{d}/s_1.fq", "-2", f"{d}/s_2.fq"]), ("paired_gz", ["-1", f"{d}/s_1.fq.gz", "-2", f"{d}/s_2.fq.gz"]),
                     ("paired_bgzf", ["-1", f"{d}/b_1.fq.gz", "-2", f"{d}/b_2.fq.gz"]),
                     ("single_plain", ["-r", f"{d}/s_1.fq"]), ("single_gz", ["-r", f"{d}/s_1.fq.gz"])):
