@@ -118,7 +118,8 @@ Engine::Engine(int dev) : device(dev) {
         try {
             hip_check(sylph_ctx_create(device, nullptr, &ctx_), "sylph_ctx_create");
             if (getenv("SYLPH_HIP_NO_WARMUP")) return;
-            batch.prealloc();
+            // (only the packed double buffers of the indexed feed: the 256 MB ASCII batch of the sequential reader is page-locked by
+            //  its first add() — most commands never need it, and pinning it was 50 ms of every bring-up)
             batch.prealloc_packed();
             // first use of a kernel loads its code object (~25 ms for the sketch kernels): do it here, with a few dummy pairs
             sylph_sketch* sk = nullptr;
