@@ -234,7 +234,9 @@ unsigned parse_threads() {
         // a quarter of the hardware threads (8..64) when the machine is the process's own; under a CPU quota as many as the quota allows
         // (the feed's phases follow each other: each may use all of it)
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency()), cpus = effective_cpus();
-        return cpus < hw ? std::min(64u, std::max(2u, cpus)) : std::min(64u, std::max(std::min(hw, 8u), hw / 4));
+        // (one and a half threads per usable CPU: the phases wait on page-cache faults and on each other — measured on the GPU box's 16 CPUs,
+        //  four plain 1 Gbp pairs in one command: 0.92 s with 16 threads, 0.73 with 24, 0.78 with 32, 0.81 with 64; tools/feed_threads_sweep.sh)
+        return cpus < hw ? std::min(64u, std::max(2u, cpus + cpus / 2)) : std::min(64u, std::max(std::min(hw, 8u), hw / 4));
     }();
     // `-t` sample threads index / gather / index-ahead at the same time, each with this many workers: they share the budget
     // (never below 2 per sample thread), so a large -t on a many-core box does not start thousands of transient threads
