@@ -205,4 +205,8 @@ int sylph_host_pgunzip(const char* path, unsigned threads, uint64_t* out_len, ui
     return 1;
 }
 
+// the CPUs the feed believes it may use (hardware threads cut down to the affinity mask and the cgroup CPU quota) and the parse
+// threads it derives from them: for the tests
+unsigned sylph_host_effective_cpus(void) { return sylph_host::effective_cpus(); }
+unsigned sylph_host_parse_threads(void) { return sylph_host::parse_threads(); }
 }  // extern "C"

@@ -646,3 +646,41 @@ def test_parallel_gunzip_of_single_member_gzip(host, tmp_path):
         assert run(tmp_path / "nonexistent.gz", 8, None) == -1
     finally:
         os.environ.pop("SYLPH_HIP_PGZ_STRETCH", None)
+
+
+def test_feed_thread_counts_follow_the_cpus_the_process_may_use():
+    """effective_cpus() (host/feed.cpp): hardware threads cut down to the affinity mask and the cgroup CPU quota — the GPU box's
+    container shows 256 hardware threads under a quota of 16 CPUs, and thread counts taken from the former got the whole process
+    frozen for most of every scheduler period.  Checked in child processes (the values are read once per process): the quota of this
+    very container, an affinity mask of two CPUs, and the SYLPH_HIP_CPUS override; the parse-thread count derived from them."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "sylph_amd", "libsylph_host.so")
+    code = ("import ctypes, os; L = ctypes.CDLL(%r); L.sylph_host_effective_cpus.restype = ctypes.c_uint; L.sylph_host_parse_threads.restype = ctypes.c_uint; "
+            "print(L.sylph_host_effective_cpus(), L.sylph_host_parse_threads())" % lib)
+
+    def ask(env=None, pre=""):
+        e = dict(os.environ)
+        for k in ("SYLPH_HIP_CPUS", "SYLPH_HIP_PARSE_THREADS"):
+            e.pop(k, None)
+        e.update(env or {})
+        out = subprocess.run([sys.executable, "-c", pre + code], capture_output=True, text=True, env=e, check=True).stdout.split()
+        return int(out[0]), int(out[1])
+
+    hw = os.cpu_count() or 1
+    expect = min(hw, len(os.sched_getaffinity(0)))
+    try:                                                           # this container's own quota, read the way the library reads it
+        a, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            expect = min(expect, max(1, -(-int(a) // int(per))))
+    except Exception:
+        pass
+    cpus, threads = ask()
+    assert cpus == expect and 1 <= cpus <= hw
+    assert threads == (min(64, max(2, cpus + cpus // 2)) if cpus < hw else min(64, max(min(hw, 8), hw // 4)))
+    if expect >= 2:
+        two = sorted(os.sched_getaffinity(0))[:2]
+        cpus2, threads2 = ask(pre="import os; os.sched_setaffinity(0, %r); " % (set(two),))
+        assert cpus2 == 2 and threads2 == (3 if hw > 2 else threads2)
+    assert ask({"SYLPH_HIP_CPUS": "5"})[0] == 5
+    assert ask({"SYLPH_HIP_PARSE_THREADS": "7"})[1] == 7
