@@ -14,17 +14,18 @@ for n_gen, glen in CASES:
     bases, off = synth.paired_reads(genomes, 3_333_334, seed=11)
     torch.cuda.synchronize()
     nb = int(off[-1].item())
-    for paired in (True, False):
+    fpr = float(os.environ.get("DEEP_DEDUP_FPR", "0"))        # > 0: the pairs behind the cuckoo filter (csrc/a10.hip) instead of the exact set
+    for paired in ((True,) if fpr else (True, False)):
         ts = []
         for rep in range(4):
             ctx.profile(True)
             torch.cuda.synchronize(); t = time.perf_counter()
-            sk = S.ReadSketcher(ctx, c=200, k=31, paired=paired)
+            sk = S.ReadSketcher(ctx, c=200, k=31, paired=paired, dedup_fpr=fpr if paired else 0.0)
             sk.push_device(bases.data_ptr(), off.data_ptr(), off.numel() - 1, nb)
             dk, dc, n, dup = sk.finish_device()
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-            st = {f: ctx.kernel_stats(f) for f in ("seeds", "compact", "sort", "replay", "replay_overflow")}
+            st = {f: ctx.kernel_stats(f) for f in ("seeds", "compact", "sort", "replay", "replay_overflow", "a10")}
             st = {k: (round(v[0], 3), v[1]) for k, v in st.items()}
             ctx.profile(False)
             sk.close()
-        print(f"{n_gen} genomes x {glen} ({nb/n_gen/glen:.0f}x coverage) paired={paired}: sketch {min(ts)*1e3:.2f} ms, table {n}, dup {dup}, kernels {st}", flush=True)
+        print(f"{n_gen} genomes x {glen} ({nb/n_gen/glen:.0f}x coverage) paired={paired}{' filter dedup fpr ' + str(fpr) if fpr and paired else ''}: sketch {min(ts)*1e3:.2f} ms, table {n}, dup {dup}, kernels {st}", flush=True)
