@@ -181,6 +181,109 @@ class _Dedup:
         self.counts[km] = c + 1
 
 
+# ---- a10: the DEFAULT pair dedup, dup_removal_lsh_full (sketch.rs:733-769) over a scalable cuckoo filter -----------------------
+# The crate (scalable_cuckoo_filter 0.2.4) is not in the reference tree.  What follows is the published structure (Fan, Andersen,
+# Kaminsky, Mitzenmacher: "Cuckoo Filter: Practically Better Than Bloom", 2014) with the crate's documented defaults — four
+# entries per bucket, fingerprints of ceil(log2(1/fpr) + 3) bits, a further filter of twice the capacity and 0.9x the rate when
+# one is full — and the same CHOICE of hash bits as the C++ model (FxHasher of the (u64, [u32; 2]) tuple, mixed; fingerprint from
+# the high word, bucket from the low bits, the partner bucket i ^ (fx(f) >> 11)).  Written from that description, not from the
+# C++: Python lists, and a DIFFERENT eviction policy (the victim is taken round-robin, the C++ model draws it from an LCG) —
+# which must not matter: an eviction moves a fingerprint between ITS two buckets only, so what `contains` answers depends on what
+# was inserted, not on where it ended up.  tests/test_pyref.py holds the two models against each other.
+_FX_K = 0x517cc1b727220a95
+_GOLD = 0x9E3779B97F4A7C15
+
+
+def _fx_add(h, w):
+    return ((((h << 5) | (h >> 59)) & M64) ^ w) * _FX_K & M64
+
+
+def _item_hash(km, half):
+    # FxHasher: the u64, then the two u32 of the marker pair, one write each
+    return _fx_add(_fx_add(_fx_add(0, km), half[0]), half[1]) * _GOLD & M64
+
+
+class _CuckooFilter:
+    def __init__(self, capacity, fpr):
+        self.capacity = capacity
+        self.fp_bits = min(31, int(math.ceil(math.log2(1.0 / fpr) + math.log2(8.0))))
+        nb = 1
+        while nb * 4 < capacity:
+            nb <<= 1
+        self.nb = nb
+        self.buckets = [[] for _ in range(nb)]
+        self.n_items = 0
+        self.victim = 0
+
+    def _where(self, h):
+        f = (h >> 32) & ((1 << self.fp_bits) - 1) or 1
+        i1 = h & (self.nb - 1)
+        return f, i1, (i1 ^ (_fx_add(0, f) >> 11)) & (self.nb - 1)
+
+    def contains(self, h):
+        f, i1, i2 = self._where(h)
+        return f in self.buckets[i1] or f in self.buckets[i2]
+
+    def insert(self, h):
+        f, i1, i2 = self._where(h)
+        for i in (i1, i2):
+            if len(self.buckets[i]) < 4:
+                self.buckets[i].append(f)
+                self.n_items += 1
+                return True
+        i = i1
+        for _ in range(512):
+            self.victim = (self.victim + 1) & 3
+            f, self.buckets[i][self.victim] = self.buckets[i][self.victim], f
+            i = (i ^ (_fx_add(0, f) >> 11)) & (self.nb - 1)
+            if len(self.buckets[i]) < 4:
+                self.buckets[i].append(f)
+                self.n_items += 1
+                return True
+        return False
+
+
+class _ScalableCuckoo:
+    def __init__(self, initial_capacity, fpr):
+        self.cap0, self.fpr = initial_capacity, fpr
+        self.filters = [_CuckooFilter(initial_capacity, fpr)]
+
+    def contains(self, h):
+        return any(f.contains(h) for f in self.filters)
+
+    def insert(self, h):
+        last = self.filters[-1]
+        if last.n_items >= last.capacity or not last.insert(h):
+            n = len(self.filters)
+            self.filters.append(_CuckooFilter(self.cap0 << n, self.fpr * 0.9 ** n))
+            self.filters[-1].insert(h)
+
+
+class _FilterDedup:
+    """dup_removal_lsh_full, sketch.rs:733-769: no cut-off; the set is the filter."""
+
+    def __init__(self, fpr, initial_capacity):
+        self.counts = {}
+        self.set = _ScalableCuckoo(initial_capacity, fpr)
+        self.removed = 0
+
+    def add(self, km, kmer_pair, no_dedup, _cutoff):
+        c = self.counts.setdefault(km, 0)                          # :743
+        if not no_dedup and kmer_pair is not None:                 # :744-745
+            ret = False
+            for half in kmer_pair:                                 # :747-760
+                h = _item_hash(km, half)
+                if self.set.contains(h):
+                    if c > 0:
+                        ret = True
+                else:
+                    self.set.insert(h)
+            if ret:                                                # :761-764
+                self.removed += 1
+                return
+        self.counts[km] = c + 1                                    # :767
+
+
 MAX_DEDUP_COUNT = 4   # constants.rs:14
 
 
@@ -197,9 +300,10 @@ def sketch_sequences_needle(records, c, k, no_dedup=False, avx2=True):
     return dict(kmer_counts=d.counts, dup_removed=d.removed, mean_read_length=mean)
 
 
-# sketch.rs:771-895 with dedup_fpr == 0 (exact set)
-def sketch_pair_sequences(records1, records2, c, k, no_dedup=False, avx2=True):
-    d = _Dedup()
+# sketch.rs:771-895: dedup_fpr == 0 the exact set (:829-838), else the filter with that false-positive probability (:796-804,
+# :839-848; initial capacity 10^7 in the reference, a parameter here so that small tests can make it grow)
+def sketch_pair_sequences(records1, records2, c, k, no_dedup=False, avx2=True, dedup_fpr=0.0, initial_capacity=10_000_000):
+    d = _FilterDedup(dedup_fpr, initial_capacity) if dedup_fpr != 0.0 else _Dedup()
     mean, counter = 0.0, 0.0
     for s1, s2 in zip(records1, records2):
         v1 = extract_markers(s1, c, k, avx2)

@@ -228,6 +228,24 @@ def test_fuzz_read_sketch_paired(recs_, c, no_dedup, avx2):
     assert g["mean_read_length"] == e["mean_read_length"]
 
 
+@SET
+@given(read_sets(), st.sampled_from([1, 3, 50]), st.booleans(), st.sampled_from([(1e-4, 10_000_000), (0.05, 2500), (0.3, 600), (0.3, 40)]))
+def test_fuzz_read_sketch_paired_behind_the_filter(recs_, c, avx2, filt):
+    """a10: the default pair dedup.  The C++ model of the filter (what csrc/a10.hip is held against) and this file's — written from the
+    same description, with another eviction policy — must agree on every count: what a cuckoo filter answers does not depend on
+    where an eviction left a fingerprint (the premise of a10.hip's formulation)."""
+    fpr, cap = filt
+    mode = O.MODE_AVX2_COMPAT if avx2 else O.MODE_SCALAR
+    if len(recs_) % 2:
+        recs_ = recs_[:-1]
+    b, off = O.concat(recs_)
+    e = O.sketch_reads_cuckoo_model(b, off, c=c, mode=mode, fpr=fpr, initial_capacity=cap)
+    g = P.sketch_pair_sequences(recs_[0::2], recs_[1::2], c, 31, avx2=avx2, dedup_fpr=fpr, initial_capacity=cap)
+    ks, cs = table(g["kmer_counts"])
+    assert ks.tolist() == e["kmers"].tolist() and cs.tolist() == e["counts"].tolist()
+    assert g["dup_removed"] == e["dup_removed"]
+
+
 @st.composite
 def genomes(draw):
     seed = draw(st.integers(0, 2**32 - 1))
