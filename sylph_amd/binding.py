@@ -616,7 +616,7 @@ class Pipeline:
         return int(load().sylph_pipeline_outstanding(self._h))
 
     def set_option(self, key, value):
-        _check(load().sylph_pipeline_set_option(self._h, key.encode(), value.encode()))
+        _check(load().sylph_pipeline_set_option(self._h, key.encode(), (repr(float(value)) if isinstance(value, float) else str(value)).encode()))
 
     def profile(self, enable=True):
         _check(load().sylph_pipeline_profile(self._h, int(enable)))

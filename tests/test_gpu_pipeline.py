@@ -79,6 +79,46 @@ def test_pipeline_matches_oracle_in_submission_order(ctx, workers, depth, max_ba
     db.close()
 
 
+def test_pipeline_with_the_default_pair_dedup(ctx):
+    """sylph_pipeline_set_option("dedup_fpr"): every session the pipeline opens from then on deduplicates its pairs behind the
+    cuckoo filter (sketch.rs:733-769; csrc/a10.hip) — the samples' tables, duplicate counts and containment rows must be the oracle's
+    model of that filter's; setting it back to 0 returns to the exact set.  Device batches (the deferred seeding verdict is
+    resolved by the filter pass) and host batches."""
+    import torch
+    rng, genomes, db_k, goff = small_world(11)
+    db = S.Database(ctx, db_k, goff)
+    fpr, cap = 0.05, 2500                                        # leaky and small: it grows and reports false positives
+    samples = []
+    for i in range(5):
+        b, off = sample_reads(rng, genomes, [i % 5], 500 + 100 * i)
+        samples.append((b, off, O.sketch_reads_cuckoo_model(b, off, c=50, fpr=fpr, initial_capacity=cap), O.sketch_reads(b, off, c=50, paired=True)))
+    assert any(f["dup_removed"] != x["dup_removed"] for _, _, f, x in samples)
+    dev = [(torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()) for b, off, _, _ in samples]
+    torch.cuda.synchronize()
+    p = S.Pipeline(db, c=50, paired=True, n_workers=2, depth=4, max_batch=4, want_table=True)
+    p.set_option("dedup_fpr", fpr)
+    p.set_option("dedup_capacity", cap)
+    for i, (b, off, _, _) in enumerate(samples):
+        if i % 2 == 0:
+            assert p.submit_device([(dev[i][0].data_ptr(), dev[i][1].data_ptr(), len(off) - 1, int(off[-1]))], tag=i)
+        else:
+            assert p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=i, mem=MEM_HOST)
+        if p.outstanding == 4 or i + 1 == len(samples):
+            while p.outstanding:
+                r = p.next()
+                e = samples[r["tag"]][2]
+                check_result(r, e, db_k, goff)
+                assert np.array_equal(r["kmers"], e["kmers"]) and np.array_equal(r["counts"], e["counts"])
+    p.set_option("dedup_fpr", 0)
+    b, off, _, x = samples[0]
+    assert p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=77, mem=MEM_HOST)
+    r = p.next()
+    check_result(r, x, db_k, goff)
+    assert np.array_equal(r["counts"], x["counts"])
+    p.close()
+    db.close()
+
+
 def test_pipeline_host_batches_sessions_and_errors(ctx):
     """Host-memory batches (several per sample), adopted sessions, and a sample that fails (odd number of records in a paired
     session) — the failure belongs to that sample only, the stream goes on."""
