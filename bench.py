@@ -366,7 +366,7 @@ def main():
     ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 3)")
     ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 5; sharded: two probe batches)")
     ap.add_argument("--no-files-leg", action="store_true", help="skip the leg that runs `sylph-hip sketch` on FASTQ files (plain, gzip)")
-    ap.add_argument("--files-leg-pairs", type=int, default=1_000_000, help="read pairs per sample of that leg (default 1 M = 0.3 Gbp)")
+    ap.add_argument("--files-leg-pairs", type=int, default=3_333_334, help="read pairs per sample of that leg (default: the workload's own sample, 1 Gbp)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")
     ap.add_argument("--no-filter-leg", action="store_true", help="skip the leg with sylph's default pair dedup (cuckoo filter, --fpr 1e-4)")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the leg of the mode `value` is NOT taken from")
