@@ -199,7 +199,8 @@ void sylph_sketch_destroy(sylph_sketch *sk);
  * until sylph_pipeline_next has returned the sample anyway).
  * "dedup_fpr" = "<f>" (paired sessions, before the first push; 0 = off, the default): the pair set of sketch_pair_sequences is kept
  * behind a scalable cuckoo filter of false-positive probability f, as the reference does for every --fpr != 0 — its default is 1e-4
- * (cmdline.rs:77; sketch.rs:796-804 builds the filter with initial capacity 10^7, "dedup_capacity" = "<n>" overrides that: tests).
+ * (cmdline.rs:77; sketch.rs:796-804 builds the filter with initial capacity 10^7, "dedup_capacity" = "<n>" overrides that: tests — a
+ * capacity that would fill its buckets beyond 80 % is refused, cuckoo insertions fail there and the answers turn order-dependent).
  * Same walk as sketch.rs:733-769 — test the filter, insert when absent, drop the seed when `*c > 0` — evaluated without walking: a
  * cuckoo filter reports an item iff an item with the same fingerprint and bucket pair went in before it (csrc/a10.hip).  The
  * filter's crate (scalable_cuckoo_filter 0.2.4) is not part of the reference tree: geometry and growth follow its documentation,

@@ -1039,6 +1039,14 @@ int sylph_sketch_set_option(sylph_sketch* sk, const char* key, const char* value
             } else {
                 const long long v = strtoll(value, nullptr, 10);
                 SY_REQUIRE(v >= 1 && v < (1ll << 31), "dedup_capacity must be in [1, 2^31) (got %s)", value);
+                // the filter has the next power of two above capacity / 4 buckets of four entries: a capacity that fills them beyond 80 %
+                // (8, 4096: 100 %) makes cuckoo insertions fail, and what a filter answers then depends on its eviction history — which
+                // a10.hip does not replay (the reference's 10^7 fills 59.6 %; every doubling keeps the ratio)
+                uint64_t nb = 1;
+                while (nb * 4 < (uint64_t)v) nb <<= 1;
+                SY_REQUIRE((double)v <= 0.8 * 4.0 * (double)nb, "dedup_capacity %lld would fill its %llu buckets to %.0f %%: insertions fail above ~80 %% and "
+                           "the result would depend on the eviction order; choose a capacity further from a power of two", v, (unsigned long long)nb,
+                           100.0 * (double)v / (4.0 * (double)nb));
                 sk->dedup_capacity = (uint64_t)v;
             }
         }
