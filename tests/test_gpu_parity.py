@@ -291,7 +291,7 @@ def test_read_sketch_paired_filter_dedup(ctx, fpr, capacity):
     if fpr >= 0.02:
         assert differs > 0          # the filter's false positives show in the result (else this test checks the exact path twice)
     # a capacity that would fill the filter's buckets to the brim is refused (insertions fail there; the answers turn order-dependent)
-    with pytest.raises(S.SylphError):
+    with pytest.raises(S.SylphHipError):
         S.ReadSketcher(ctx, c=200, paired=True, dedup_fpr=fpr, dedup_capacity=4096)
     # --no-dedup and single-end sessions ignore the option (sketch.rs:744, :897)
     g = sketch_gpu(ctx, b, off, paired=True, no_dedup=True, c=200, dedup_fpr=fpr, **cap)
