@@ -57,6 +57,8 @@ extern "C" {
     pub fn sylph_upload_finish(u: *mut SylphUpload, device_ptr: *mut *const c_void) -> c_int;
     pub fn sylph_upload_destroy(u: *mut SylphUpload);
     // "borrow_until_finish" = "1": device batches stay valid until finish -> one host round trip per sample instead of two
+    // "dedup_fpr" = "<f>" (pairs, before the first push): dup_removal_lsh_full (sketch.rs:733-769) over a cuckoo filter of that
+    // false-positive probability instead of the exact set — what sketch_pair_sequences does for every dedup_fpr != 0.
     pub fn sylph_sketch_set_option(sk: *mut SylphSketch, key: *const c_char, value: *const c_char) -> c_int;
     // replace the probe half of get_stats (contain.rs:601-656) for all genomes of a loaded database
     pub fn sylph_db_upload(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,
