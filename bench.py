@@ -826,6 +826,9 @@ def main():
         **({"resident_2bit": packed_leg} if packed_leg is not None else {}),
         **({"default_pair_dedup": filter_leg} if filter_leg is not None else {}),
     }
+    # what `sylph sketch -1 -2` / `profile -1 -2` do by DEFAULT is the filter rule (cmdline.rs:77, contain.rs:591): its rate beside `value`
+    if filter_leg is not None and "pipelined" in filter_leg:
+        out["value_default_flags"] = filter_leg["pipelined" if mode == "pipelined" else "one_step_at_a_time"]["value"]
     legs = {mode: (fam, rows)}
     if second is not None:
         o_mode, per2, e2, st2, g2, r2, f2 = second

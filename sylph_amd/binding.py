@@ -253,7 +253,7 @@ class ReadSketcher:
     exact pair set (--fpr 0, sketch.rs:690-731); > 0 (paired sessions): the reference's default, the set behind a scalable cuckoo
     filter of that false-positive probability (sketch.rs:733-769; csrc/a10.hip), dedup_capacity its initial capacity (10^7)."""
 
-    def __init__(self, ctx, c=200, k=31, paired=False, no_dedup=False, seed_mode=SEED_AVX2_COMPAT, dedup_fpr=0.0, dedup_capacity=None):
+    def __init__(self, ctx, c=200, k=31, paired=False, no_dedup=False, seed_mode=SEED_AVX2_COMPAT, dedup_fpr=0.0, dedup_capacity=None, a10=None):
         self.ctx = ctx
         self._h = C.c_void_p()
         _check(load().sylph_sketch_begin(ctx._h, c, k, READS_PAIRED if paired else READS_SINGLE, int(no_dedup), seed_mode,
@@ -262,9 +262,11 @@ class ReadSketcher:
             self.set_option("dedup_fpr", repr(float(dedup_fpr)))
         if dedup_capacity is not None:
             self.set_option("dedup_capacity", int(dedup_capacity))
+        if a10 is not None:            # "auto" | "walk" | "part": which pass marks the filter's answers (csrc/a10.hip; A/B and tests)
+            self.set_option("a10", a10)
 
     def set_option(self, key, value):
-        """sylph_sketch_set_option ("borrow_until_finish": device batches stay valid until finish; "dedup_fpr", "dedup_capacity")"""
+        """sylph_sketch_set_option ("borrow_until_finish": device batches stay valid until finish; "dedup_fpr", "dedup_capacity", "a10")"""
         _check(load().sylph_sketch_set_option(self._h, key.encode(), str(value).encode()))
 
     def push(self, bases, rec_off):

@@ -32,6 +32,7 @@
 #include "common.h"
 #include "device_common.h"
 #include "sketch_session.h"
+#include "partition.h"
 
 namespace sylph {
 namespace {
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(A10_TPB) void a10_part_kernel(Occs o, uint8_t* __re
     if (i >= o.n) return;
     uint64_t km, rid, m0, m1;
     part[i] = walk_takes_part(o, i, km, rid, m0, m1) ? 1 : 0;
+    if (rid & RID_A10_BIT) o.recs[i].rid = rid & ~RID_A10_BIT;     // a mark the partitioned pass left before it was found unfit (a10_verdict)
 }
 __device__ __forceinline__ bool takes_part(const Occs& o, uint32_t i, uint64_t& km, uint64_t& rid, uint64_t& m0, uint64_t& m1) {
     const OccRec r = o.recs[i];
@@ -295,16 +297,267 @@ __global__ __launch_bounds__(A10_TPB) void a10_debug_kernel(Occs o, Filters F, u
     }
 }
 
+
+// ---- the partitioned pass (round 5): one filter, no device-wide atomics -------------------------------------------------------
+// While the sample stays inside filter 0 (at most `capacity` operations: 1 Gbp of pairs has 8 M against the reference's 10^7),
+// "first operation of its class" needs no table at all: the operations are SORTED by class — the two-level partition that groups the
+// occurrences by k-mer hash for the replay (partition.h) moves one 8-byte word per operation, {upper 32 bits of the mixed class key |
+// operation id = 2 x slot + marker}, into ~128-operation buckets of equal class-hash ranges — and one workgroup per bucket finds the
+// words that share their upper half with another word (exact duplicates: 2-4 % of a sample; chance: 2^-16 per pair of a bucket).
+// Only those fetch their occurrence record, compute the exact class key and their place in the walk (op_key), and the ones that are
+// not the earliest of their class set RID_A10_BIT — an atomic OR on ~3 % of the records instead of two atomics and a load per
+// operation on a 256 MB table.  Skipped mate-2 occurrences (sketch.rs:852) take part here although the walk never sees them: their
+// items are those of the mate-1 occurrence of the same k-mer in the same pair, which precedes them — they are never the first of a
+// class, change no other operation's answer, and the replay drops them before it looks at the mark.
+// What the pass cannot do is tell by itself that one filter was enough: it leaves {buckets too full for the workgroup, operations
+// found} in two device words, the caller reads them with whatever it reads anyway (finish_bucketed's tail block), and a sample with
+// more operations than the capacity — or thousands of copies of one item in one bucket — is marked again by the phase walk above.
+constexpr int RES_CAP = 256, RES_TPB = 128;
+constexpr uint32_t OPS_BLK_PER_TILE = 8;           // two words per slot: half the blocks per partition tile
+
+struct OpsIn { const uint64_t* hash; const OccRec* recs; const uint32_t* blk_count; uint32_t n_dense, n_blk, slot_cap; int slotted; };
+
+__device__ __forceinline__ uint64_t op_word(const Filter& d, uint64_t km, uint64_t marker, uint32_t opid) {
+    return ((reduced_key(d, item_hash(km, marker)) * GOLD) & 0xFFFFFFFF00000000ull) | opid;
+}
+__device__ __forceinline__ ulonglong2 op_words(const Filter& d, const OccRec& r, bool valid, uint32_t slot) {
+    if (!valid || !(r.rid & RID_MARKER_BIT)) return make_ulonglong2(INVALID_HASH, INVALID_HASH);
+    return make_ulonglong2(op_word(d, r.hash, r.m0, 2u * slot), op_word(d, r.hash, r.m1, 2u * slot + 1u));
+}
+// ops[2 * slot + w] for every occurrence: slots of the session's one batch (one wavefront per block of the seeding kernel), or the dense arrays
+__global__ __launch_bounds__(64) void a10_ops_slots_kernel(OpsIn in, Filter d, ulonglong2* __restrict__ ops, uint32_t* __restrict__ tail) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) tail[threadIdx.x] = 0;
+    const uint32_t b = blockIdx.x, cnt = min(in.blk_count[b], in.slot_cap), g0 = b * in.slot_cap;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 64) ops[g0 + i] = op_words(d, in.recs[g0 + i], true, g0 + i);
+}
+__global__ __launch_bounds__(256) void a10_ops_dense_kernel(OpsIn in, Filter d, ulonglong2* __restrict__ ops, uint32_t* __restrict__ tail) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2) tail[i] = 0;
+    if (i >= in.n_dense) return;
+    ops[i] = op_words(d, in.recs[i], in.hash[i] != INVALID_HASH, i);
+}
+
+// One workgroup = one bucket of class hashes.  Sub-range counting sort as in the replay (the words are uniform over the bucket's
+// range: RES_CAP sub-ranges hold half a word each, equal upper halves share one); candidates = words with an equal upper half in
+// their sub-range; those resolve through their records.
+__global__ __launch_bounds__(RES_TPB) void a10_resolve_kernel(const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ boff, BucketMap bm,
+                                                              Filter d, OccRec* __restrict__ recs, uint32_t* __restrict__ tail) {
+    constexpr int ITEMS = RES_CAP / RES_TPB;
+    __shared__ uint64_t s_w[RES_CAP], s_g[RES_CAP], s_k[RES_CAP];
+    __shared__ uint32_t s_cnt[RES_CAP + 1];
+    __shared__ __attribute__((aligned(8))) uint16_t s_fill[RES_CAP];
+    __shared__ uint32_t s_wave[RES_TPB / 64];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    const uint32_t first = boff[b], n = boff[b + 1] - first;
+    if (b == 0 && tid == 0) tail[1] = boff[bm.B];             // operations found (every valid word of the layout)
+    if (n == 0) return;
+    if (n > (uint32_t)RES_CAP) { if (tid == 0) atomicAdd(&tail[0], 1u); return; }
+    const uint32_t lo_key = (uint32_t)((((uint64_t)b << 32) + bm.mult - 1u) / bm.mult);      // smallest 32-bit key of the bucket
+    const uint32_t sub_mult = bm.sub_mult[0];
+    uint64_t h[ITEMS];
+    uint32_t sub[ITEMS], place[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RES_TPB;
+        h[q] = i < n ? sorted[first + i] : 0ull;
+    }
+    for (uint32_t t = tid; t <= (uint32_t)RES_CAP; t += RES_TPB) s_cnt[t] = 0;
+    for (uint32_t t = tid; t < (uint32_t)RES_CAP; t += RES_TPB) s_fill[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RES_TPB;
+        sub[q] = 0;
+        if (i < n) {
+            const uint32_t res = (uint32_t)(h[q] >> 32) - lo_key;
+            sub[q] = sub_mult ? min(__umulhi(res, sub_mult), (uint32_t)RES_CAP - 1u) : min(res, (uint32_t)RES_CAP - 1u);
+            atomicAdd(&s_cnt[sub[q]], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t v[ITEMS], sum = 0;
+#pragma unroll
+        for (int e = 0; e < ITEMS; e++) { v[e] = s_cnt[tid * ITEMS + e]; sum += v[e]; }
+        uint32_t run = block_excl_sum<RES_TPB>(sum, s_wave, nullptr);
+#pragma unroll
+        for (int e = 0; e < ITEMS; e++) { s_cnt[tid * ITEMS + e] = run; run += v[e]; }
+        if (tid == RES_TPB - 1) s_cnt[RES_CAP] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RES_TPB;
+        place[q] = 0;
+        if (i < n) {
+            uint32_t* const w = reinterpret_cast<uint32_t*>(s_fill) + (sub[q] >> 1);
+            const uint32_t old = atomicAdd(w, (sub[q] & 1u) ? 65536u : 1u);
+            place[q] = s_cnt[sub[q]] + ((sub[q] & 1u) ? (old >> 16) : (old & 0xFFFFu));
+            s_w[place[q]] = h[q];
+        }
+    }
+    __syncthreads();
+    bool cand[ITEMS];
+    uint64_t g[ITEMS], key[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const uint32_t i = tid + q * RES_TPB;
+        cand[q] = false;
+        g[q] = ~0ull;
+        key[q] = 0;
+        if (i < n) {
+            const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1], up = (uint32_t)(h[q] >> 32);
+            for (uint32_t p = lo; p < hi; p++) cand[q] |= p != place[q] && (uint32_t)(s_w[p] >> 32) == up;
+            if (cand[q]) {
+                const uint32_t opid = (uint32_t)h[q];
+                const OccRec r = recs[opid >> 1];
+                g[q] = reduced_key(d, item_hash(r.hash, (opid & 1u) ? r.m1 : r.m0));      // < 2^63: never the ~0 of a word that is no candidate
+                key[q] = op_key(r.rid, opid & 1u);
+            }
+            s_g[place[q]] = g[q];
+            s_k[place[q]] = key[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        if (!cand[q]) continue;
+        const uint32_t lo = s_cnt[sub[q]], hi = s_cnt[sub[q] + 1];
+        bool contained = false;
+        for (uint32_t p = lo; p < hi; p++) contained |= s_g[p] == g[q] && s_k[p] < key[q];
+        // (the two operations of an occurrence may both be contained, from two workgroups: the OR commutes; readers of the rid in
+        //  this kernel look at its record and rank bits only)
+        if (contained) atomicOr(reinterpret_cast<uint32_t*>(&recs[(uint32_t)h[q] >> 1].rid) + 1, (uint32_t)(RID_A10_BIT >> 32));
+    }
+}
+
 }  // namespace
+
+static Filter filter_geometry(const sylph_sketch* sk, int j) {
+    // (as CuckooFilter::init / ScalableCuckoo::grow of the tests' CPU checker)
+    Filter f{};
+    const uint64_t cap = sk->dedup_capacity << j;
+    const double fpr = sk->dedup_fpr * std::pow(0.9, (double)j);
+    int fp_bits = (int)std::ceil(std::log2(1.0 / fpr) + std::log2(8.0));
+    fp_bits = std::min(31, std::max(1, fp_bits));
+    uint64_t n_buckets = 1;
+    while (n_buckets * 4 < cap) n_buckets <<= 1;
+    SY_REQUIRE(n_buckets <= (1ull << 31), "filter of %llu buckets", (unsigned long long)n_buckets);
+    f.fp_mask = (uint32_t)((1ull << fp_bits) - 1);
+    f.nb_mask = (uint32_t)(n_buckets - 1);
+    f.cut = NO_OP;
+    return f;
+}
+
+// The partitioned pass over the session's occurrences where they lie (slots of its one batch, or the dense arrays).
+static void a10_mark_partitioned(sylph_sketch* sk) {
+    sylph_ctx* ctx = sk->ctx;
+    const bool slotted = sk->pend.live;
+    const bool deferred = slotted && sk->pend.deferred;
+    const uint64_t n_slots = slotted ? (uint64_t)sk->pend.n_blk * sk->pend.slot_cap : sk->n_occ;
+    const uint64_t n_expect = deferred ? std::max<uint32_t>(1, sk->pend.n_expect) : (slotted ? sk->pend.n : sk->n_occ);
+    HostPhase ph(ctx, "finish: a10 filter marks (partitioned)");
+    sk->a10_tail.reserve(16);
+    uint32_t* tail = sk->a10_tail.as<uint32_t>();
+    DevBuf b_ops(ctx), b_pairs(ctx), b_sorted(ctx), b_hist(ctx), b_boff(ctx);
+    b_ops.reserve(n_slots * 16);
+    b_pairs.reserve(n_slots * 16);
+    b_sorted.reserve(n_slots * 16);
+    const Filter f0 = filter_geometry(sk, 0);
+    // buckets: equal ranges of the words' upper 32 bits, ~bucket_target operations each
+    const uint32_t B = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2 * n_expect / ctx->bucket_target), 1u << 24);
+    BucketMap bm{};
+    bm.sh = 32;
+    bm.mult = B;                                                   // (B << 32) / 2^32
+    bm.B = B;
+    bm.composite = 1;
+    const uint64_t range = (0x100000000ull + B - 1) / B + 1;       // widest bucket in key units
+    bm.range_hs = (uint32_t)std::min<uint64_t>(range, 0xFFFFFFFFull);
+    bm.sub_mult[0] = range > (uint64_t)RES_CAP ? (uint32_t)(((uint64_t)RES_CAP << 32) / range) : 0u;
+    const PartGeom geom = part_geometry(B);
+    OpsIn oin{};
+    PartIn in{};
+    in.key_sh = 32;
+    in.carry = 1;
+    uint32_t n_tiles;
+    if (slotted) {
+        const uint32_t* blk_count = sk->slot_meta.as<uint32_t>() + (sk->pend.n_blk + 1);      // (layout: reads.hip SlotMeta)
+        oin.recs = sk->slot_rec.as<OccRec>(); oin.blk_count = blk_count; oin.n_blk = sk->pend.n_blk; oin.slot_cap = sk->pend.slot_cap; oin.slotted = 1;
+        in.slotted = 2; in.blk_count = blk_count; in.n_blk = sk->pend.n_blk; in.slot_cap = sk->pend.slot_cap; in.blk_per_tile = OPS_BLK_PER_TILE;
+        n_tiles = (in.n_blk + OPS_BLK_PER_TILE - 1) / OPS_BLK_PER_TILE;
+    } else {
+        oin.hash = sk->hash.as<uint64_t>(); oin.recs = sk->recs.as<OccRec>(); oin.n_dense = (uint32_t)sk->n_occ;
+        in.slotted = 0; in.n_dense = (uint32_t)(2 * sk->n_occ);
+        in.tile_entries = (uint32_t)std::max<uint64_t>(4096, (2 * sk->n_occ + 65535) / 65536);
+        n_tiles = (uint32_t)((2 * sk->n_occ + in.tile_entries - 1) / in.tile_entries);
+    }
+    in.hash = b_ops.as<uint64_t>();
+    b_hist.reserve(part_hist_words(geom, n_tiles) * 4);
+    b_boff.reserve(((size_t)B + 2) * 4);
+    ScopedKernelTimer t(ctx, "a10");
+    if (slotted) hipLaunchKernelGGL(a10_ops_slots_kernel, dim3(oin.n_blk), dim3(64), 0, ctx->stream, oin, f0, b_ops.as<ulonglong2>(), tail);
+    else hipLaunchKernelGGL(a10_ops_dense_kernel, dim3((uint32_t)((sk->n_occ + 255) / 256)), dim3(256), 0, ctx->stream, oin, f0, b_ops.as<ulonglong2>(), tail);
+    launch_partition(ctx, in, bm, geom, n_tiles, 2 * n_expect, b_hist.as<uint32_t>(), b_pairs.as<uint2>(), b_boff.as<uint32_t>(), nullptr,
+                     b_sorted.as<uint64_t>(), nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(a10_resolve_kernel, dim3(B), dim3(RES_TPB), 0, ctx->stream, b_sorted.as<uint64_t>(), b_boff.as<uint32_t>(), bm, f0,
+                       const_cast<OccRec*>(oin.recs), tail);
+    SY_HIP(hipGetLastError());
+    sk->a10_state = 1;
+    if (ctx->profile) ctx->stats["a10_part"].launches++;              // (tests ask sylph_ctx_kernel_stats which pass ran)
+    // (the buffers go back to the pool here; stream order keeps them alive for the kernels queued above)
+}
+
+static void a10_mark_walk(sylph_sketch* sk);
+
+// Which pass: the partitioned one wherever the first filter is sure (the occurrence count is known) or expected (deferred
+// batches: the verdict words tell) to take every operation; the phase walk for samples that make the filter grow.
+void a10_mark(sylph_sketch* sk) {
+    if (!sk->filter_dedup() || sk->a10_state != 0) return;
+    SY_REQUIRE(sk->dedup_capacity >= 1 && sk->dedup_capacity < (1ull << 31), "dedup_capacity out of range");
+    static const int env_force = [] { const char* e = getenv("SYLPH_HIP_A10"); return !e ? 0 : !strcmp(e, "walk") ? 1 : !strcmp(e, "part") ? 2 : 0; }();
+    const int force = sk->a10_force ? sk->a10_force : env_force;
+    const bool slotted = sk->pend.live, deferred = slotted && sk->pend.deferred;
+    const uint64_t n_slots = slotted ? (uint64_t)sk->pend.n_blk * sk->pend.slot_cap : sk->n_occ;
+    const uint64_t n_ops = 2 * (deferred ? (uint64_t)sk->pend.n_expect + sk->pend.n_expect / 8 : (slotted ? sk->pend.n : sk->n_occ));
+    const bool fits = n_slots < (1ull << 31) && n_ops <= sk->dedup_capacity && sk->n_plain == 0;
+    if (n_slots == 0) { sk->a10_state = 2; return; }
+    if (force != 1 && fits) a10_mark_partitioned(sk);
+    else a10_mark_walk(sk);
+}
+
+// The verdict words of the partitioned pass, read by the caller together with its own tail: false = the marks were no good (a
+// bucket with more copies of one class than a workgroup takes; more operations than the first filter holds) and the phase walk
+// has marked the records again — on the dense arrays: whoever partitioned the slots starts over.
+bool a10_verdict(sylph_sketch* sk, const uint32_t words[2]) {
+    if (sk->a10_state != 1) return true;
+    if (words[0] == 0 && (uint64_t)words[1] <= sk->dedup_capacity) { sk->a10_state = 2; return true; }
+    if (sk->ctx->profile) sk->ctx->stats["a10_redo"].launches++;       // (tests ask sylph_ctx_kernel_stats whether this road was taken)
+    a10_mark_walk(sk);
+    return false;
+}
+
+void a10_settle(sylph_sketch* sk) {
+    if (!sk->filter_dedup()) return;
+    for (int round = 0; round < 4 && sk->a10_state != 2; round++) {
+        if (sk->a10_state == 0) { a10_mark(sk); continue; }
+        // the verdict of a deferred batch first: a batch that is redone loses its marks (redo_deferred_batch resets a10_state)
+        if (sk->pend.live && sk->pend.deferred) { resolve_deferred_slots(sk); if (sk->a10_state != 1) continue; }
+        uint32_t words[2] = {0, 0};
+        sk->ctx->read_back(words, sk->a10_tail.p, 8);
+        a10_verdict(sk, words);
+    }
+    SY_REQUIRE(sk->a10_state == 2, "internal: the filter marks did not settle");
+}
 
 // Marks (RID_A10_BIT) every occurrence of a paired session for which sketch.rs:747 / :754 would have found its (k-mer, markers)
 // in the filter.  Works on the dense file-order arrays: occurrences still in their slots are compacted first.
-void a10_mark(sylph_sketch* sk) {
+static void a10_mark_walk(sylph_sketch* sk) {
     sylph_ctx* ctx = sk->ctx;
     flush_pending_slots(sk);
+    sk->a10_state = 2;
     const uint64_t n = sk->n_occ;
     if (!n) return;
-    SY_REQUIRE(sk->dedup_capacity >= 1 && sk->dedup_capacity < (1ull << 31), "dedup_capacity out of range");
+    SY_REQUIRE(n < (1ull << 32), "more than 2^32-1 seed occurrences in one sample");
     HostPhase ph(ctx, "finish: a10 filter marks");
     DevBuf b_part(ctx), b_run(ctx);
     b_part.reserve(n);
@@ -330,14 +583,8 @@ void a10_mark(sylph_sketch* sk) {
     DevBuf b_tiles(ctx);
     for (int j = 0;; j++) {
         SY_REQUIRE(j < MAX_FILTERS, "the approximate dedup would need more than %d filters: raise dedup_capacity", MAX_FILTERS);
-        // the filter's geometry (as CuckooFilter::init / ScalableCuckoo::grow of the tests' CPU checker)
         const uint64_t cap = sk->dedup_capacity << j;
-        const double fpr = sk->dedup_fpr * std::pow(0.9, (double)j);
-        int fp_bits = (int)std::ceil(std::log2(1.0 / fpr) + std::log2(8.0));
-        fp_bits = std::min(31, std::max(1, fp_bits));
-        uint64_t n_buckets = 1;
-        while (n_buckets * 4 < cap) n_buckets <<= 1;
-        SY_REQUIRE(n_buckets <= (1ull << 31), "filter of %llu buckets", (unsigned long long)n_buckets);
+        const Filter geo = filter_geometry(sk, j);
         // the phase's table: every operation behind the cut may enter it
         const uint64_t remaining = n_ops - std::min(n_ops, ops_before);
         uint64_t slots = 1024;
@@ -348,8 +595,8 @@ void a10_mark(sylph_sketch* sk) {
         cur.tab = tables.back()->as<Ent>();
         cur.tab_mask = (uint32_t)(slots - 1);
         cur.tab_shift = (uint32_t)(64 - (bit_length(slots) - 1));
-        cur.fp_mask = (uint32_t)((1ull << fp_bits) - 1);
-        cur.nb_mask = (uint32_t)(n_buckets - 1);
+        cur.fp_mask = geo.fp_mask;
+        cur.nb_mask = geo.nb_mask;
         cur.cut = NO_OP;
         F.n = j + 1;
         F.end = NO_OP;
@@ -401,7 +648,7 @@ void a10_mark(sylph_sketch* sk) {
                 SY_REQUIRE(cut != NO_OP && cut > F.begin, "internal: the operation that opens filter %d was not found", j + 1);
                 if (getenv("SYLPH_HIP_A10_TRACE"))
                     fprintf(stderr, "[sylph_hip] a10 phase %d: capacity %llu, %d fingerprint bits, %llu buckets; the next filter opens at record %llu, seed %llu, marker %llu (tile %u, %llu inserting operations before the tile)\n",
-                            j, (unsigned long long)cap, fp_bits, (unsigned long long)n_buckets, (unsigned long long)(cut >> 21),
+                            j, (unsigned long long)cap, bit_length(geo.fp_mask), (unsigned long long)geo.nb_mask + 1, (unsigned long long)(cut >> 21),
                             (unsigned long long)((cut >> 1) & RID_RANK_MAX), (unsigned long long)(cut & 1), tile, (unsigned long long)seen);
                 cur.cut = cut;
                 F.end = cut;

@@ -281,6 +281,7 @@ int sylph_upload_begin(sylph_ctx* ctx, uint64_t bytes, uint64_t chunk_bytes, syl
         u->bytes = bytes;
         u->chunk_cap = std::max<uint64_t>(1u << 20, std::min<uint64_t>(chunk_bytes ? chunk_bytes : (128ull << 20), 1ull << 30));
         u->dev.alloc(bytes + 64);             // (plain hipMalloc: a buffer of this size does not belong in the context's pool)
+        ctx->refs++;                          // taken BEFORE anything that may throw: sylph_upload_destroy below gives it back
         try {
             SY_HIP(hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking));
             for (int i = 0; i < 2; i++) {
@@ -288,7 +289,6 @@ int sylph_upload_begin(sylph_ctx* ctx, uint64_t bytes, uint64_t chunk_bytes, syl
                 SY_HIP(hipEventCreateWithFlags(&u->ev[i], hipEventDisableTiming));
             }
         } catch (...) { sylph_upload_destroy(u.release()); throw; }
-        ctx->refs++;
         *out = u.release();
     });
 }

@@ -17,6 +17,7 @@
 // Results come back in submission order, so nothing the caller sees depends on the interleaving of the threads.
 // With a sharded database (cfg.comm) the batches must be the same on every rank: the profile thread then waits for exactly
 // `max_batch` samples (or sylph_pipeline_flush) and runs the exchange of shard.hip.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -88,7 +89,7 @@ struct sylph_pipeline {
     uint64_t flush_upto = 0;                     // sharded: jobs with seq < flush_upto may go in a partial batch
     bool stop = false;
     // tuning (sylph_pipeline_set_option): see the option table in include/sylph_hip.h
-    uint32_t serialize_seeding = 1;              // 1 (default, r04: +3 %, profiles/r04_ab_pipeline_sweep.txt): one worker at a time runs its seeding kernel —
+    std::atomic<uint32_t> serialize_seeding{1};  // 1 (default, r04: +3 %, profiles/r04_ab_pipeline_sweep.txt): one worker at a time runs its seeding kernel —
                                                  // two VALU-bound seeding kernels side by side only slow each other; the others are in their dedup/count tails
     std::string dedup_fpr, dedup_capacity;       // "dedup_fpr" / "dedup_capacity": handed to every session the pipeline opens (sylph_sketch_set_option; a10.hip)
     uint32_t min_batch = 2, batch_wait_us = 400; // the profile thread waits up to batch_wait_us for min_batch ready tables while more are being sketched (r04: +1.2 %)
@@ -124,12 +125,13 @@ struct sylph_pipeline {
             for (size_t i = 0; rc == SYLPH_OK && i < j->batches.size(); i++) {
                 const sylph_read_batch& b = j->batches[i];
                 std::unique_lock<std::mutex> seed_lock(seed_mu, std::defer_lock);
-                if (serialize_seeding) {
+                const bool serial = serialize_seeding.load() != 0;      // read ONCE per push: the option may change between the two uses below
+                if (serial) {
                     seed_lock.lock();
                     if (last_seed_ev && last_seed_ev != seed_ev[(size_t)w]) (void)hipStreamWaitEvent(wctx[w]->stream, last_seed_ev, 0);
                 }
                 rc = sylph_sketch_push_enc(j->sk, b.bases, b.rec_off, b.n_records, b.n_bases, j->mem, j->enc);
-                if (serialize_seeding && hipEventRecord(seed_ev[(size_t)w], wctx[w]->stream) == hipSuccess) last_seed_ev = seed_ev[(size_t)w];
+                if (serial && hipEventRecord(seed_ev[(size_t)w], wctx[w]->stream) == hipSuccess) last_seed_ev = seed_ev[(size_t)w];
             }
         }
         if (rc == SYLPH_OK) rc = sylph_sketch_finish_device(j->sk, &j->dev_k, &j->dev_c, &j->n_table, &j->dup_removed);
@@ -418,9 +420,9 @@ uint32_t sylph_pipeline_outstanding(sylph_pipeline* p) {
 int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* value) {
     if (!p || !key || !value) { set_error("null argument"); return SYLPH_ERR_INVALID; }
     {   // the pipeline's own knobs; everything else goes to the workers' contexts
-        uint32_t* dst = !strcmp(key, "serialize_seeding") ? &p->serialize_seeding : !strcmp(key, "min_batch") ? &p->min_batch
-                      : !strcmp(key, "batch_wait_us") ? &p->batch_wait_us : nullptr;
-        if (dst) {
+        if (!strcmp(key, "serialize_seeding")) { p->serialize_seeding.store((uint32_t)strtoul(value, nullptr, 10)); return SYLPH_OK; }
+        uint32_t* dst = !strcmp(key, "min_batch") ? &p->min_batch : !strcmp(key, "batch_wait_us") ? &p->batch_wait_us : nullptr;
+        if (dst) {                               // (the profile thread reads both with p->mu held)
             std::lock_guard<std::mutex> lk(p->mu);
             *dst = (uint32_t)strtoul(value, nullptr, 10);
             return SYLPH_OK;

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "device_common.h"
 #include "sketch_session.h"
+#include "partition.h"
 
 namespace sylph {
 namespace {
@@ -38,238 +39,6 @@ constexpr int IDX_BITS = 10;         // arrival index inside a bucket (< CAP_LAR
 // configuration, whose marker test is a hash table in LDS: linear in the bucket size.
 constexpr uint32_t SEG_LIMIT = 96;
 
-// Bucket of a hash: hs = hash >> sh (its 32 most significant bits below the threshold), b = (hs * mult) >> 32 — B
-// equal ranges for ANY B (not only powers of two), monotone in the hash.  Inverse used by the replay kernel: the
-// smallest hs of bucket b is ceil(b * 2^32 / mult).
-// range_hs = widest bucket in hs units; sub_mult[i] = floor(2^32 * CAP_i / range_hs) for the three replay configurations (the
-// sub-range of a hash inside its bucket, see replay_bucket), 0 when a bucket is narrower than CAP_i hs units.
-// rank_bits[i] > 0: (hash - lowest hash the sub-range can hold) << rank_bits | gather index fits in 64 bits for configuration
-// i — the key the occurrences of a sub-range are ranked by with ONE compare; sub_width[i] = floor(range_hs / CAP_i) hs units (a
-// lower bound of where sub-range s begins: s * sub_width).
-struct BucketMap { int sh; uint32_t mult; uint32_t B; int composite; uint32_t range_hs; uint32_t sub_mult[3]; uint32_t sub_width[3]; int rank_bits[3]; };
-
-__device__ __forceinline__ uint32_t bucket_of_key(uint32_t key, const BucketMap m) { return min(__umulhi(key, m.mult), m.B - 1u); }
-
-// ---- partition ------------------------------------------------------------------------------------------------------------
-// Where finish() reads the occurrences from: the dense arrays (hash[i], i < n_dense; INVALID_HASH entries are skipped) or the
-// slots of the session's one batch (slot_key[b * slot_cap + i], i < blk_count[b]; key = hash >> key_sh, written by the seeding
-// kernel).  The index an occurrence is known by — what the replay gathers its record with — is i, resp. b * slot_cap + i: both
-// grow with the file order.
-struct PartIn {
-    const uint64_t* hash;
-    const uint32_t* slot_key;
-    const uint32_t* blk_count;
-    uint32_t n_dense, n_blk, slot_cap, tile_entries;
-    int slotted, key_sh;
-    int carry;     // marker-less samples (dense only): the pairs ARE the 64-bit hashes — the partition sorts the hashes themselves by bucket
-};
-constexpr int PART_TPB = 256;
-constexpr uint32_t BLK_PER_TILE = 16;     // slotted: blocks of the seeding kernel per partition tile (~3,000 occurrences)
-constexpr uint32_t MAX_COARSE = 4096;     // coarse ranges (LDS counters of the histogram / scatter kernels)
-constexpr uint32_t MAX_FINE = 4096;       // buckets per coarse range (LDS counters of the fine kernel)
-constexpr uint32_t STAGE_PAIRS = 4096;    // pairs a scatter workgroup groups in LDS before writing them out in runs
-
-// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the tiles, so
-// that the runs two neighbouring tiles append to the same coarse range — adjacent in memory — meet in the same L2.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t n_tiles) {
-    const uint32_t per_xcd = (n_tiles + 7) / 8;
-    return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);      // may be >= n_tiles for the padding of the last XCD's range
-}
-
-// f(key, index, hash) for every occurrence of tile t (any order; all threads of the workgroup take part; hash = 0 from slots).  Slotted: eight groups of
-// 32 lanes walk eight blocks at a time (independent loads in flight instead of one block after the other).
-template <class F>
-__device__ __forceinline__ void for_tile_entries(const PartIn& in, uint32_t t, F&& f) {
-    if (in.slotted) {
-        const uint32_t grp = threadIdx.x >> 5, l = threadIdx.x & 31;
-        for (uint32_t bl = grp; bl < BLK_PER_TILE; bl += PART_TPB / 32) {
-            const uint32_t b = t * BLK_PER_TILE + bl;
-            if (b >= in.n_blk) break;
-            const uint32_t cnt = min(in.blk_count[b], in.slot_cap), g0 = b * in.slot_cap;
-            for (uint32_t i = l; i < cnt; i += 32) f(in.slot_key[g0 + i], g0 + i, 0ull);
-        }
-    } else {
-        const uint64_t i0 = (uint64_t)t * in.tile_entries;
-        for (uint32_t e = threadIdx.x; e < in.tile_entries; e += PART_TPB) {
-            const uint64_t i = i0 + e;
-            if (i >= in.n_dense) break;
-            const uint64_t h = in.hash[i];
-            if (h != INVALID_HASH) f((uint32_t)(h >> in.key_sh), (uint32_t)i, h);
-        }
-    }
-}
-
-// hist[c * n_tiles + t] = occurrences of tile t in coarse range c = bucket >> fine_bits
-// (also clears what the replay accumulates into — per-bucket counters, the list heads, the tail words — instead of memsets)
-__global__ __launch_bounds__(PART_TPB) void part_hist_kernel(PartIn in, BucketMap bm, int fine_bits, uint32_t C, uint32_t n_tiles,
-                                                             uint32_t* __restrict__ hist, uint32_t* __restrict__ zero, uint32_t n_zero,
-                                                             uint32_t* __restrict__ tail16, uint32_t* __restrict__ list_a,
-                                                             uint32_t* __restrict__ list_b, uint32_t* __restrict__ list_c) {
-    __shared__ uint32_t s_h[MAX_COARSE];
-    const uint32_t t = xcd_tile(n_tiles), gtid = blockIdx.x * PART_TPB + threadIdx.x;
-    for (uint32_t i = gtid; i < n_zero; i += gridDim.x * PART_TPB) zero[i] = 0;
-    if (gtid < 16) tail16[gtid] = 0;
-    if (gtid == 0) { *list_a = 0; *list_b = 0; *list_c = 0; }
-    if (t >= n_tiles) return;
-    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_h[c] = 0;
-    __syncthreads();
-    for_tile_entries(in, t, [&](uint32_t key, uint32_t, uint64_t) { atomicAdd(&s_h[bucket_of_key(key, bm) >> fine_bits], 1u); });
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) hist[(size_t)c * n_tiles + t] = s_h[c];
-}
-
-// exclusive prefix sum of one value per lane across the workgroup; total returned through *total
-template <int RTPB>
-__device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave, uint32_t* total);
-
-// one workgroup per coarse range: hist row -> exclusive offsets of the tiles inside the range; total[c] = size of the range
-__global__ __launch_bounds__(PART_TPB) void part_scan_kernel(uint32_t* __restrict__ hist, uint32_t n_tiles, uint32_t* __restrict__ total) {
-    __shared__ uint32_t s_wave[PART_TPB / 64];
-    uint32_t* row = hist + (size_t)blockIdx.x * n_tiles;
-    const uint32_t per = (n_tiles + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(n_tiles, a + per);
-    uint32_t sum = 0;
-    for (uint32_t i = a; i < b; i++) sum += row[i];
-    uint32_t tot = 0;
-    uint32_t run = block_excl_sum<PART_TPB>(sum, s_wave, &tot);
-    for (uint32_t i = a; i < b; i++) { const uint32_t v = row[i]; row[i] = run; run += v; }
-    if (threadIdx.x == 0) total[blockIdx.x] = tot;
-}
-
-// (bucket, index) pairs of tile t -> their coarse ranges.  The workgroup first groups its pairs by range in LDS (count, scan,
-// place with an LDS atomic), then writes them out position by position: neighbouring lanes write neighbouring pairs of one
-// run (cbase[c] + offset of the tile inside the range + place inside the run) instead of 64 scattered 8-byte words per
-// instruction.  The order inside a run is NOT the file order — the replay restores it from the indices.
-__global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, BucketMap bm, int fine_bits, uint32_t C, uint32_t n_tiles,
-                                                                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ total,
-                                                                uint32_t* __restrict__ cbase, uint2* __restrict__ out) {
-    extern __shared__ uint32_t s_dyn[];                  // [C] cursor (count -> start -> cursor) | [C] gb | STAGE_PAIRS pairs
-    uint32_t* const s_cur = s_dyn;
-    uint32_t* const s_gb = s_dyn + C;                    // global position of the range's run minus its start in the tile order
-    uint2* const s_stage = reinterpret_cast<uint2*>(s_dyn + 2 * (size_t)C + ((2 * C) & 1u));
-    __shared__ uint32_t s_wave[PART_TPB / 64];
-    const uint32_t t = xcd_tile(n_tiles);
-    if (t >= n_tiles) return;
-    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_cur[c] = 0;
-    __syncthreads();
-    for_tile_entries(in, t, [&](uint32_t key, uint32_t, uint64_t) { atomicAdd(&s_cur[bucket_of_key(key, bm) >> fine_bits], 1u); });
-    __syncthreads();
-    uint32_t n_tile = 0;
-    {   // tile order: start[c] = exclusive sum of the tile's counts; cbase = exclusive sum of the range sizes
-        const uint32_t per = (C + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(C, a + per);
-        uint32_t sum_t = 0, sum_g = 0;
-        for (uint32_t c = a; c < b; c++) { sum_t += s_cur[c]; sum_g += total[c]; }
-        uint32_t tot_g = 0;
-        uint32_t run_t = block_excl_sum<PART_TPB>(sum_t, s_wave, &n_tile);
-        uint32_t run_g = block_excl_sum<PART_TPB>(sum_g, s_wave, &tot_g);
-        for (uint32_t c = a; c < b; c++) {
-            const uint32_t cnt = s_cur[c];
-            if (t == 0) cbase[c] = run_g;
-            s_gb[c] = run_g + offs[(size_t)c * n_tiles + t] - run_t;
-            s_cur[c] = run_t;
-            run_t += cnt;
-            run_g += total[c];
-        }
-        if (t == 0 && threadIdx.x == 0) cbase[C] = tot_g;
-    }
-    __syncthreads();
-    for_tile_entries(in, t, [&](uint32_t key, uint32_t idx, uint64_t h) {
-        const uint32_t b = bucket_of_key(key, bm), c = b >> fine_bits;
-        const uint32_t p = atomicAdd(&s_cur[c], 1u);     // place in the tile order
-        const uint2 pr = in.carry ? make_uint2((uint32_t)h, (uint32_t)(h >> 32)) : make_uint2(b, idx);
-        if (p < STAGE_PAIRS) s_stage[p] = pr;
-        else out[s_gb[c] + p] = pr;                      // (a tile fuller than the stage: the rest goes out directly)
-    });
-    __syncthreads();
-    const uint32_t n_staged = min(n_tile, STAGE_PAIRS);
-    for (uint32_t p = threadIdx.x; p < n_staged; p += PART_TPB) {
-        const uint2 v = s_stage[p];
-        const uint32_t b = in.carry ? bucket_of_key((uint32_t)((((uint64_t)v.y << 32) | v.x) >> in.key_sh), bm) : v.x;
-        out[s_gb[b >> fine_bits] + p] = v;
-    }
-}
-
-// one workgroup per coarse range: counting sort of its pairs by bucket in LDS -> perm (occurrence indices grouped by bucket) and
-// boff[b] = first position of bucket b, boff[B] = number of valid occurrences
-template <int TPB>
-__global__ __launch_bounds__(TPB) void part_fine_kernel(const uint2* __restrict__ pairs,
-                                                             const uint32_t* __restrict__ cbase, int fine_bits, uint32_t C, uint32_t B,
-                                                             uint32_t* __restrict__ boff, uint32_t* __restrict__ perm, int carry, int key_sh,
-                                                             BucketMap bm, uint64_t* __restrict__ sorted_hash) {
-    __shared__ uint32_t s_cnt[MAX_FINE];
-    __shared__ uint32_t s_wave[TPB / 64];
-    const uint32_t c = blockIdx.x, F = 1u << fine_bits, b0 = c << fine_bits;
-    const uint32_t lo = cbase[c], hi = cbase[c + 1];
-    for (uint32_t f = threadIdx.x; f < F; f += TPB) s_cnt[f] = 0;
-    __syncthreads();
-    // (four independent loads in flight per lane: with one, a range of 10^5 pairs is a chain of load latencies)
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * TPB) {
-        uint32_t k[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            k[u] = 0xFFFFFFFFu;
-            if (e + u * TPB < hi) {
-                if (carry) { const uint2 v = pairs[e + u * TPB]; k[u] = bucket_of_key((uint32_t)((((uint64_t)v.y << 32) | v.x) >> key_sh), bm); }
-                else k[u] = pairs[e + u * TPB].x;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (k[u] != 0xFFFFFFFFu) atomicAdd(&s_cnt[k[u] - b0], 1u);
-    }
-    __syncthreads();
-    {
-        const uint32_t per = (F + TPB - 1) / TPB, a = threadIdx.x * per, b = min(F, a + per);
-        uint32_t sum = 0;
-        for (uint32_t f = a; f < b; f++) sum += s_cnt[f];
-        uint32_t run = lo + block_excl_sum<TPB>(sum, s_wave, nullptr);
-        for (uint32_t f = a; f < b; f++) {
-            const uint32_t v = s_cnt[f];
-            s_cnt[f] = run;                              // becomes the bucket's cursor
-            if (b0 + f < B) boff[b0 + f] = run;
-            run += v;
-        }
-    }
-    if (c + 1 == C && threadIdx.x == 0) boff[B] = hi;
-    __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * TPB) {
-        uint2 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = e + u * TPB < hi ? pairs[e + u * TPB] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (e + u * TPB >= hi) continue;
-            if (carry) {      // the sorted array holds the hashes themselves (marker-less samples: nothing else is ever looked at)
-                const uint64_t h = ((uint64_t)v[u].y << 32) | v[u].x;
-                sorted_hash[atomicAdd(&s_cnt[bucket_of_key((uint32_t)(h >> key_sh), bm) - b0], 1u)] = h;
-            } else
-                perm[atomicAdd(&s_cnt[v[u].x - b0], 1u)] = v[u].y;
-        }
-    }
-}
-
-// exclusive prefix sum of one value per lane across the workgroup (4 waves); total returned through *total
-template <int RTPB>
-__device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave, uint32_t* total) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    __syncthreads();
-    if (lane == 63) s_wave[wave] = x;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < RTPB / 64; w++) {
-        const uint32_t t = s_wave[w];
-        if ((uint32_t)w < wave) base += t;
-        tot += t;
-    }
-    if (total) *total = tot;
-    return base + x - v;
-}
 
 // One workgroup = one bucket.  SINGLE_CUTOFF = 4 for single-end (sketch.rs:937), 0 for pairs.
 //
@@ -601,6 +370,20 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             }
         }
     }
+    // DEDUP_FILTER: `*c > 0` (sketch.rs:749, :756) = an occurrence of the k-mer went through the dedup before this one.  The walk hands
+    // over a record's seeds in EMISSION order (the rank bits of the rid; lane-interleaved for the AVX2 routine), the segment lists them
+    // by position: the first of the walk is the lowest rank among the segment's leading occurrences of the head's record — the head
+    // itself unless the read repeats the k-mer (a tandem repeat inside one read).  (None of those is a skipped mate 2: the mate-1
+    // occurrence that would make it one belongs to an earlier record.)
+    auto walk_first = [&](uint32_t j) {
+        const uint32_t s0 = s_seg[j];
+        const uint64_t rec0 = s_rid[s0] & RID_MASK, rj = s_rid[j];
+        if ((rj & RID_MASK) != rec0) return false;
+        const uint64_t rank_j = (rj >> RID_RANK_SHIFT) & RID_RANK_MAX;
+        for (uint32_t q = s0; q < n && (uint32_t)s_seg[q] == s0 && (s_rid[q] & RID_MASK) == rec0; q++)
+            if (q != j && ((s_rid[q] >> RID_RANK_SHIFT) & RID_RANK_MAX) < rank_j) return false;
+        return true;
+    };
     // ---- mate-2 skip (sketch.rs:852) and duplicate flags ----------------------------------------------------------
     for (uint32_t t = 0; t < items; t++) {
         const uint32_t j = j0 + t;
@@ -665,9 +448,9 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             const uint32_t j = j0 + t;
             if (j >= n) break;
             uint8_t fl = s_fl[j];
-            if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT) && j != (uint32_t)s_seg[j]) {
-                if (filter) {      // sketch.rs:747-760: the filter's answers, `*c > 0` = not the head of the k-mer
-                    if (s_rid[j] & RID_A10_BIT) fl |= 2;
+            if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT) && (filter || j != (uint32_t)s_seg[j])) {
+                if (filter) {      // sketch.rs:747-760: the filter's answers, `*c > 0` = not the first of the k-mer in the walk
+                    if ((s_rid[j] & RID_A10_BIT) && !walk_first(j)) fl |= 2;
                 } else {
                     const bool hit = (s_tab[s_slot[2 * j]] & 0xFFFFu) < j || (s_tab[s_slot[2 * j + 1]] & 0xFFFFu) < j;
                     if (hit || s_m0[j] == s_m1[j]) fl |= 2;
@@ -683,8 +466,7 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             if (j >= n) break;
             uint8_t fl = s_fl[j];
             if (filter) {
-                // (the head of a k-mer is never a skipped mate 2, so "a processed occurrence precedes j" is "j is not the head")
-                if (!fl && (s_rid[j] & RID_MARKER_BIT) && j != (uint32_t)s_seg[j] && (s_rid[j] & RID_A10_BIT)) fl |= 2;
+                if (!fl && (s_rid[j] & RID_MARKER_BIT) && (s_rid[j] & RID_A10_BIT) && !walk_first(j)) fl |= 2;
             } else if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT)) {
                 const uint64_t a = s_m0[j], bb = s_m1[j];
                 bool any_prev = false, hit = false;
@@ -995,7 +777,7 @@ __global__ __launch_bounds__(SCAN_CHUNK) void table_scan_kernel(const uint32_t* 
     }
 }
 // out[rows before bucket b + i] = tmp[boff[b] + i] for i < n_distinct[b]; a workgroup walks buckets with its four wavefronts
-// (one bucket holds ~50 rows).  Also assembles the 36-byte tail block the host reads: {removed u64, overflow u32 (set by the
+// (one bucket holds ~50 rows).  Also assembles the 48-byte tail block the host reads: {removed u64, overflow u32 (set by the
 // replay), n_seg u32, n_ovf u32, n_mid u32, n_large u32, seeding verdict 2 x u32}.
 __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __restrict__ tmp_k, const uint32_t* __restrict__ tmp_c,
                                                             const uint32_t* __restrict__ boff, const uint32_t* __restrict__ d_loc,
@@ -1004,7 +786,8 @@ __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __re
                                                             uint64_t* __restrict__ out_k, uint32_t* __restrict__ out_c,
                                                             const uint32_t* __restrict__ ovf_list, const uint32_t* __restrict__ mid_list,
                                                             const uint32_t* __restrict__ large_list, int skip_if_listed,
-                                                            uint32_t* __restrict__ tail, const uint32_t* __restrict__ verdict) {
+                                                            uint32_t* __restrict__ tail, const uint32_t* __restrict__ verdict,
+                                                            const uint32_t* __restrict__ a10_words, const uint32_t* __restrict__ p_nv) {
     __shared__ uint32_t s_base[257];
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_rem[4];
@@ -1026,6 +809,9 @@ __global__ __launch_bounds__(256) void table_compact_kernel(const uint64_t* __re
                 tail[3] = tot; tail[4] = ovf_list[0]; tail[5] = mid_list[0]; tail[6] = large_list[0];
                 // deferred seeding verdict (reads.hip ReadsState: long_record, overflowing blocks) rides in the same block: one copy
                 tail[7] = verdict ? verdict[0] : 0u; tail[8] = verdict ? verdict[1] : 0u;
+                // ... and so do the verdict words of the filter dedup's partitioned pass (a10.hip)
+                tail[9] = a10_words ? a10_words[0] : 0u; tail[10] = a10_words ? a10_words[1] : 0u;
+                tail[11] = *p_nv;            // the occurrences the partition found: what a deferred batch's slots really hold
             }
         }
     }
@@ -1157,10 +943,7 @@ bool finish_bucketed(sylph_sketch* sk) {
         }
     }
     // partition geometry: F = 2^fine_bits buckets per coarse range (about 512 ranges), tiles of occurrences
-    int fine_bits = 6;
-    while ((1u << fine_bits) < MAX_FINE && ((B + (1u << fine_bits) - 1) >> fine_bits) > 512) fine_bits++;
-    const uint32_t C = (B + (1u << fine_bits) - 1) >> fine_bits;
-    SY_REQUIRE(C <= MAX_COARSE, "internal: %u coarse ranges", C);
+    const PartGeom geom = part_geometry(B);
     // marker-less sample (sketch_session.h): hashes only, counted without occurrence records; tiny samples whose bucket range does
     // not fit the sub-range arithmetic get their records written and take the usual kernels
     if (!slotted && sk->n_plain && !(sk->n_plain == sk->n_occ && bm.composite)) materialise_plain_records(sk);
@@ -1175,6 +958,7 @@ bool finish_bucketed(sylph_sketch* sk) {
         in.n_blk = sk->pend.n_blk;
         in.slot_cap = sk->pend.slot_cap;
         in.blk_count = sk->slot_meta.as<uint32_t>() + (sk->pend.n_blk + 1);   // (layout: reads.hip SlotMeta)
+        in.blk_per_tile = BLK_PER_TILE;
         n_tiles = (in.n_blk + BLK_PER_TILE - 1) / BLK_PER_TILE;
         recs = sk->slot_rec.as<OccRec>();
     } else {
@@ -1186,7 +970,7 @@ bool finish_bucketed(sylph_sketch* sk) {
     }
     DevBuf &b_hist = ctx->scratch[0], &b_pairs = ctx->scratch[1], &b_perm = ctx->scratch[2], &b_tmpk = ctx->scratch[3],
            &b_tmpc = ctx->scratch[4], &b_small = ctx->scratch[5], &b_bk = ctx->scratch[6];
-    b_hist.reserve(((size_t)C * n_tiles + 2 * (size_t)C + 2) * 4);      // hist (C x n_tiles) | total (C) | cbase (C + 1)
+    b_hist.reserve(part_hist_words(geom, n_tiles) * 4);
     b_pairs.reserve((size_t)n_cap * 8);                                 // (bucket, occurrence index) pairs grouped by coarse range
     if (!plain) b_perm.reserve((size_t)n_cap * 4);
     DevBuf& b_sorted = ctx->scratch[7];                                 // marker-less: the hashes sorted by bucket
@@ -1199,8 +983,6 @@ bool finish_bucketed(sylph_sketch* sk) {
     // boff | large_list | ovf_list | n_distinct | removed | d_off | mid_list (each B+2) | chunk_rows (264) | chunk_removed (264 u64)
     b_bk.reserve((size_t)(B + 2) * 4 * 7 + 264 * 4 + 264 * 8 + 16);
     uint32_t* hist = b_hist.as<uint32_t>();
-    uint32_t* ctotal = hist + (size_t)C * n_tiles;
-    uint32_t* cbase = ctotal + C;
     uint2* pairs = b_pairs.as<uint2>();
     uint32_t* boff = b_bk.as<uint32_t>();
     uint32_t* large_list = boff + (B + 2);      // [0] = number of buckets queued for the large configuration, [1..] = ids
@@ -1225,20 +1007,8 @@ bool finish_bucketed(sylph_sketch* sk) {
         HostPhase ph(ctx, "finish(bucket): partition + LDS replay + compact");
         {
             ScopedKernelTimer t(ctx, "sort");   // the partition: what the library's radix sort of (bucket, index) pairs used to do
-            const uint32_t tile_grid = ((n_tiles + 7) / 8) * 8;      // (padded: xcd_tile deals every XCD a contiguous eighth)
-            hipLaunchKernelGGL(part_hist_kernel, dim3(tile_grid), dim3(PART_TPB), 0, ctx->stream, in, bm, fine_bits, C, n_tiles, hist, n_distinct,
-                               n_zero, b_small.as<uint32_t>(), large_list, ovf_list, mid_list);
-            hipLaunchKernelGGL(part_scan_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, hist, n_tiles, ctotal);
-            hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)C + 2 * (size_t)STAGE_PAIRS) * 4, ctx->stream, in, bm,
-                               fine_bits, C, n_tiles, hist, ctotal, cbase, pairs);
-            // (a sample of tens of millions of occurrences — long reads at c = 100 — has ~10^5 pairs per coarse range: 1024
-            //  threads walk them instead of 256; c5: 1.27 -> see profiles)
-            if ((uint64_t)n_all / C > 32768)
-                hipLaunchKernelGGL((part_fine_kernel<1024>), dim3(C), dim3(1024), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
-                                   b_perm.as<uint32_t>(), in.carry, in.key_sh, bm, sorted_hash);
-            else
-                hipLaunchKernelGGL((part_fine_kernel<PART_TPB>), dim3(C), dim3(PART_TPB), 0, ctx->stream, pairs, cbase, fine_bits, C, B, boff,
-                                   b_perm.as<uint32_t>(), in.carry, in.key_sh, bm, sorted_hash);
+            launch_partition(ctx, in, bm, geom, n_tiles, n_all, hist, pairs, boff, b_perm.as<uint32_t>(), sorted_hash, n_distinct, n_zero,
+                             b_small.as<uint32_t>(), large_list, ovf_list, mid_list);
         }
         {
             ScopedKernelTimer t(ctx, "replay");
@@ -1264,16 +1034,21 @@ bool finish_bucketed(sylph_sketch* sk) {
                            b_tmpk.as<uint64_t>(), b_tmpc.as<uint32_t>(), boff, d_off, chunk_rows, chunk_removed, n_distinct, B, ipt,
                            sk->out_k.as<uint64_t>(), sk->out_c.as<uint32_t>(), ovf_list, mid_list, large_list, skip_if_listed,
                            b_small.as<uint32_t>(),
-                           deferred ? sk->slot_meta.as<uint32_t>() + (size_t)(sk->pend.n_blk + 1) * 4 : (const uint32_t*)nullptr);
+                           deferred ? sk->slot_meta.as<uint32_t>() + (size_t)(sk->pend.n_blk + 1) * 4 : (const uint32_t*)nullptr,
+                           sk->a10_state == 1 ? sk->a10_tail.as<uint32_t>() : (const uint32_t*)nullptr, d_nv);
         SY_HIP(hipGetLastError());
     };
     struct { unsigned long long removed; uint32_t overflow, n_seg, n_ovf, n_mid, n_large; } host{};
     uint32_t verdict[2] = {0, 0};                  // deferred: long_record flag, overflowing blocks of the seeding kernel
+    uint32_t a10_words[2] = {0, 0};                // filter dedup, partitioned pass: buckets it could not take, operations it found
+    uint32_t n_found = 0;                          // occurrences the partition found
     auto read_tail = [&] {
-        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 36, hipMemcpyDeviceToHost, ctx->stream));
+        SY_HIP(hipMemcpyAsync(ctx->pinned, d_removed, 48, hipMemcpyDeviceToHost, ctx->stream));
         SY_HIP(hipStreamSynchronize(ctx->stream));
         memcpy(&host, ctx->pinned, 28);
         if (deferred) memcpy(verdict, (const char*)ctx->pinned + 28, 8);   // (the two flag words of ReadsState, copied by table_compact_kernel)
+        memcpy(a10_words, (const char*)ctx->pinned + 36, 8);
+        memcpy(&n_found, (const char*)ctx->pinned + 44, 4);
         if (!ctx->pending.empty()) profile_collect(ctx);
     };
     close_table(1);
@@ -1281,10 +1056,14 @@ bool finish_bucketed(sylph_sketch* sk) {
     if (deferred) {
         if (verdict[0] || verdict[1]) {            // not a batch for the short-read kernel after all: the checked push, then from the top
             redo_deferred_batch(sk);
+            a10_mark(sk);                          // (filter dedup: the marks went with the slots)
             return finish_bucketed(sk);
         }
-        sk->pend.deferred = false;                 // the verdict is in: from here on an ordinary slotted sample
+        sk->pend.deferred = false;                 // the verdict is in: from here on an ordinary slotted sample ...
+        sk->pend.n = n_found;                      // ... whose occurrence count is known (whoever flushes the slots to the dense arrays needs it)
     }
+    // filter dedup: were the partitioned pass's marks good (a10.hip)?  If not the phase walk has marked the records again, dense: from the top
+    if (!a10_verdict(sk, a10_words)) return finish_bucketed(sk);
     if (host.overflow) return false;             // inconsistent bounds (defensive): the generic path redoes the sample
     if (plain && host.n_ovf) {
         // k-mers more than a thousand deep in a marker-less sample: write the occurrence records after all and take the usual

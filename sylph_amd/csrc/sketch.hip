@@ -323,7 +323,20 @@ __global__ __launch_bounds__(256) void dup_flags_kernel(const uint64_t* __restri
     uint8_t fl = skip ? skip[i] : 0;
     if (!fl && (rid_s[i] & RID_MARKER_BIT)) {
         const uint32_t s0 = seg_start[i];
-        const bool any_prev = skip ? (Eproc[i] != Eproc[s0]) : (i != s0);
+        bool any_prev = skip ? (Eproc[i] != Eproc[s0]) : (i != s0);
+        if (filter && hit[i]) {
+            // `*c > 0` (sketch.rs:749, :756) in the order of the WALK: a record's seeds go through the dedup in emission order (rank bits
+            // of the rid), the sorted segment lists them by position — the first of the walk is the lowest rank among the segment's
+            // leading occurrences of the head's record (replay_lds.hip walk_first)
+            const uint64_t rec0 = rid_s[s0] & RID_MASK, ri = rid_s[i];
+            any_prev = true;
+            if ((ri & RID_MASK) == rec0) {
+                any_prev = false;
+                const uint64_t rank_i = (ri >> RID_RANK_SHIFT) & RID_RANK_MAX;
+                for (uint32_t q = s0; q < n && seg_start[q] == s0 && (rid_s[q] & RID_MASK) == rec0; q++)
+                    if (q != i && ((rid_s[q] >> RID_RANK_SHIFT) & RID_RANK_MAX) < rank_i) { any_prev = true; break; }
+            }
+        }
         // (filter mode: equal markers are the filter's business too — its second test finds what the first inserted)
         if (any_prev && (hit[i] || (!filter && m0_s[i] == m1_s[i]))) fl |= 2;
     }
@@ -577,6 +590,7 @@ static void process_batch(sylph_sketch* sk, const uint8_t* d_bases, uint32_t pha
 void redo_deferred_batch(sylph_sketch* sk) {
     const PendingSlots d = sk->pend;
     sk->pend = PendingSlots{};
+    sk->a10_state = 0;                          // whatever the filter pass marked in the slots is gone with them (a10.hip)
     sk->rec_base -= d.n_records;
     if (sk->ctx->profile) sk->ctx->stats["deferred_redo"].launches++;
     const bool borrow = sk->borrow_until_finish;
@@ -843,14 +857,16 @@ static void sketch_finish_impl(sylph_sketch* sk) {
     DeviceGuard dg(ctx->device);
     HostPhase ph_total(ctx, "finish: total incl. readback");
     SY_REQUIRE(sk->n_occ + sk->pend.n < (1ull << 32) - 1, "more than 2^32-2 seed occurrences in one sample");
-    if (sk->filter_dedup()) a10_mark(sk);        // the reference's default dedup for pairs: the filter's answers go into the records first
+    a10_mark(sk);                                // the reference's default dedup for pairs (no-op otherwise): the filter's answers go into the records first
     // fast path: bucket partition + in-LDS replay (replay_lds.hip); falls through to the device-wide sort path
     // below when a bucket does not fit in LDS (some k-mer with thousands of occurrences)
     if (ctx->finish_mode != 1) {
         if (finish_bucketed(sk)) { sk->finished = true; return; }
         SY_REQUIRE(ctx->finish_mode != 2, "bucket finish overflowed and finish=bucket forbids the fallback");
     }
+    a10_settle(sk);            // (the partitioned filter pass's verdict, if finish_bucketed left before reading it)
     flush_pending_slots(sk);   // the device-wide path works on the dense file-order arrays ...
+    if (sk->filter_dedup() && sk->a10_state != 2) a10_settle(sk);   // (... and a deferred batch that was redone just now is marked again)
     materialise_plain_records(sk);   // ... and on occurrence records
     sk->n_out = 0;
     sk->dup_removed = 0;
@@ -1030,6 +1046,12 @@ int sylph_sketch_set_option(sylph_sketch* sk, const char* key, const char* value
         SY_REQUIRE(sk && key && value, "null argument");
         std::lock_guard<std::mutex> lock(sk->ctx->mu);
         if (!strcmp(key, "borrow_until_finish")) sk->borrow_until_finish = strtol(value, nullptr, 10) != 0;
+        else if (!strcmp(key, "a10")) {             // A/B and test knob: which pass marks the filter's answers (a10.hip)
+            if (!strcmp(value, "auto")) sk->a10_force = 0;
+            else if (!strcmp(value, "walk")) sk->a10_force = 1;
+            else if (!strcmp(value, "part")) sk->a10_force = 2;
+            else SY_REQUIRE(false, "a10 must be auto|walk|part");
+        }
         else if (!strcmp(key, "dedup_fpr") || !strcmp(key, "dedup_capacity")) {
             SY_REQUIRE_STATE(sk->rec_base == 0 && !sk->finished, "%s must be set before the first push", key);
             if (key[6] == 'f') {

@@ -30,7 +30,9 @@ inline int key_shift(uint32_t c) { return std::max(0, bit_length(UINT64_MAX / (u
 constexpr int DEDUP_EXACT = 0, DEDUP_NONE = 1, DEDUP_FILTER = 2;
 void generic_replay(sylph_ctx* ctx, const uint64_t* d_hash, const OccRec* d_recs, uint32_t n_all, bool paired, int dedup,
                     DevBuf& out_k, DevBuf& out_c, uint64_t& n_out, uint64_t& removed_out);   // sketch.hip
-void a10_mark(sylph_sketch* sk);              // a10.hip
+void a10_mark(sylph_sketch* sk);              // a10.hip: marks the records (partitioned pass where one filter suffices, else the phase walk)
+void a10_settle(sylph_sketch* sk);            // a10.hip: marks if not marked, reads the partitioned pass's verdict (synchronises), redoes with the walk if it was bad
+bool a10_verdict(sylph_sketch* sk, const uint32_t words[2]);   // a10.hip: the verdict words read by the caller (finish_bucketed's tail); false = redone with the walk: start over
 // A single-end session whose records carry no dedup markers so far (long reads: sketch.rs:922-927 passes no marker above 400
 // bases; --no-dedup) keeps only the hashes of its occurrences — nothing the replay looks at besides the hash exists for them
 // (no marker, no mate) — and finish() counts them without occurrence records.  The first batch that may carry markers (or a
@@ -71,6 +73,10 @@ struct sylph_sketch {
     bool borrow_until_finish = false;   // the caller keeps device batches valid until finish (sylph_sketch_set_option; see PendingSlots)
     double dedup_fpr = 0.;              // > 0 (paired sessions): the reference's default dedup over a cuckoo filter of this false-positive probability (a10.hip)
     uint64_t dedup_capacity = 10000000; // its initial capacity (sketch.rs:800)
+    // a10.hip: 0 = the records carry no marks (yet / any more: a batch was pushed or redone), 1 = marked by the partitioned pass, whose
+    // verdict words (a10_tail: buckets that overflowed, operations found) nobody has read yet, 2 = marked for good
+    int a10_state = 0;
+    int a10_force = 0;                  // session/test knob ("a10": 0 auto, 1 always the walk, 2 the partitioned pass wherever one filter suffices)
     bool filter_dedup() const { return paired && !no_dedup && dedup_fpr > 0.; }
     int dedup_mode() const { return no_dedup ? sylph::DEDUP_NONE : (filter_dedup() ? sylph::DEDUP_FILTER : sylph::DEDUP_EXACT); }
     uint64_t rec_base = 0;         // records pushed so far
@@ -85,8 +91,9 @@ struct sylph_sketch {
     sylph::DevBuf out_k, out_c;           // final table
     uint64_t n_out = 0, dup_removed = 0;
     sylph::DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
+    sylph::DevBuf a10_tail;               // a10.hip: verdict words of the partitioned pass (see a10_state)
     explicit sylph_sketch(sylph_ctx* cx)
         : ctx(cx), hash(cx), recs(cx), slot_bases{sylph::DevBuf(cx), sylph::DevBuf(cx)}, slot_off{sylph::DevBuf(cx), sylph::DevBuf(cx)},
-          slot_rec(cx), slot_key(cx), slot_meta(cx), batch_ascii(cx), out_k(cx), out_c(cx), counters(cx) {}
+          slot_rec(cx), slot_key(cx), slot_meta(cx), batch_ascii(cx), out_k(cx), out_c(cx), counters(cx), a10_tail(cx) {}
 };
 

@@ -267,7 +267,7 @@ struct RingOut {
         const size_t at = n & (WINDOW - 1);
         if (dist <= n && dist >= len && at + len <= WINDOW) {             // the usual match: inside the stretch, no overlap, no wrap of
             const size_t from = (n - dist) & (WINDOW - 1);                // either end in the ring
-            if (from + len <= WINDOW) { memcpy(ring + at, ring + from, (size_t)len * 2); n += len; return true; }
+            if (from + len <= WINDOW) { memmove(ring + at, ring + from, (size_t)len * 2); n += len; return true; }   // (dist near WINDOW: the two may overlap in the ring)
         }
         for (unsigned i = 0; i < len; i++, n++) {                         // (dist <= WINDOW: the source cell is still in the ring)
             const long src = (long)n - (long)dist;
@@ -428,6 +428,7 @@ class DecoderPool {
     const std::function<void(unsigned)>* job = nullptr;
     unsigned want = 0, running = 0;
     unsigned long gen = 0;
+    std::atomic<bool> failed{false};
     void loop(unsigned idx) {
         unsigned long seen = 0;
         for (;;) {
@@ -439,7 +440,7 @@ class DecoderPool {
                 if (idx >= want) continue;
                 f = job;
             }
-            (*f)(idx);
+            try { (*f)(idx); } catch (...) { failed.store(true); }      // (a bad_alloc in a decoder: the attempt is void, never std::terminate)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (--running == 0) cv_done.notify_one();
@@ -447,8 +448,9 @@ class DecoderPool {
         }
     }
    public:
-    // f(0) .. f(n - 1), f(0) on the calling thread; returns when all are done.  One caller at a time (parallel_gunzip's file lock).
-    void run(unsigned n, const std::function<void(unsigned)>& f) {
+    // f(0) .. f(n - 1), f(0) on the calling thread; returns when ALL are done (also when one of them threw: the workers hold a
+    // pointer to f) — false if any threw.  One caller at a time (parallel_gunzip's file lock).
+    bool run(unsigned n, const std::function<void(unsigned)>& f) {
         {
             std::lock_guard<std::mutex> lk(mu);
             while (workers.size() + 1 < n) {
@@ -459,20 +461,22 @@ class DecoderPool {
             job = &f;
             want = n;
             running = n - 1;
+            failed.store(false);
             gen++;
         }
         cv_job.notify_all();
-        f(0);
+        try { f(0); } catch (...) { failed.store(true); }
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return running == 0; });
+        return !failed.load();
     }
 };
 DecoderPool& decoder_pool() { static DecoderPool* p = new DecoderPool(); return *p; }
 template <class F>
-void run_threads(unsigned n, F&& f) {
-    if (n <= 1) { f(0u); return; }
+bool run_threads(unsigned n, F&& f) {
+    if (n <= 1) { try { f(0u); } catch (...) { return false; } return true; }
     const std::function<void(unsigned)> g = [&f](unsigned w) { f(w); };
-    decoder_pool().run(n, g);
+    return decoder_pool().run(n, g);
 }
 
 }  // namespace
@@ -514,9 +518,10 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)threads * 3, body / std::max<size_t>(min_stretch, 1024)));
     if (T < 2) return false;                                               // nothing to gain: the sequential reader
     const unsigned NT = std::min(T, threads);
+    std::atomic<bool> threw{false};                                        // a decoder thread ran out of memory: the attempt is void
     auto for_stretches = [&](auto&& f) {
         std::atomic<unsigned> next{0};
-        run_threads(NT, [&](unsigned) { for (unsigned w = next++; w < T; w = next++) f(w); });
+        if (!run_threads(NT, [&](unsigned) { for (unsigned w = next++; w < T; w = next++) f(w); })) threw = true;
     };
     // memory: the output only (estimate: the trailer's length, or 3x the file if that wrapped)
     const size_t est = std::max<size_t>(want_len, body * 3);
@@ -540,7 +545,7 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
         start[w] = find_block_start(gz, body_end, from, to);
         if (start[w] == SIZE_MAX) bad = true;
     });
-    if (bad) return false;
+    if (bad || threw) return false;
     lap("block starts");
     // Two ways from here, the same bytes either way.  The default: TWO passes, the first keeping nothing but a ring of cells in the
     // core's cache, the second writing plain bytes.  The alternative (SYLPH_HIP_PGZ_PASSES=1; what this file did first): ONE decode into
@@ -582,6 +587,7 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
             how[w] = inflate_cells(b, cells[w], w != 0, w + 1 < T ? start[w + 1] : SIZE_MAX, false, 0, SIZE_MAX);
             end_bit[w] = b.bitpos();
         });
+        if (threw) return false;
         for (unsigned w = 0; w < T; w++)
             if (how[w] != (w + 1 < T ? Stop::AtStopBit : Stop::FinalBlock)) return false;
         if ((end_bit[T - 1] + 7) / 8 != body_end) return false;           // bytes behind the final block: another member, or garbage
@@ -614,6 +620,7 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
             for (size_t i = 0; i < c.n; i++) { const uint16_t v = c.v[i]; dst[i] = v < 256 ? (uint8_t)v : wn[v - 256]; }
             crc[w] = crc32_of(dst, c.n);
         });
+        if (threw) { inflated_release(buf, map_bytes); return false; }
         lap("translate + crc");
     } else {
     // ---- 2. pass 1: every stretch decoded for its length and its last 32 KiB only (a ring of cells in the core's cache: nothing
@@ -636,6 +643,7 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
         ring->tail(tails[w]);
         if (trace) fprintf(stderr, "[sylph_hip pgunzip]   stretch %u: %zu compressed bytes -> %zu bytes, pass 1 in %.2f ms\n", w, (end_bit[w] - start[w]) / 8, n_out[w], (now() - t0) * 1e3);
     });
+    if (threw) return false;
     for (unsigned w = 0; w < T; w++)
         if (how[w] != (w + 1 < T ? Stop::AtStopBit : Stop::FinalBlock)) return false;
     if ((end_bit[T - 1] + 7) / 8 != body_end) return false;               // bytes behind the final block: another member, or garbage
@@ -667,7 +675,7 @@ bool parallel_gunzip(const uint8_t* gz, size_t n, unsigned threads, uint8_t** ou
         if (r != how[w] || b.bitpos() != end_bit[w] || out.n != n_out[w]) { differs = true; return; }   // (cannot happen: the same bits, the same decoder)
         crc[w] = crc32_of(o + off[w], n_out[w]);
     });
-    if (differs) { inflated_release(buf, map_bytes); return false; }
+    if (differs || threw) { inflated_release(buf, map_bytes); return false; }
     lap("pass 2 (bytes) + crc");
     }
     // ---- 4. the member's CRC-32

@@ -285,8 +285,9 @@ def test_read_sketch_paired_filter_dedup(ctx, fpr, capacity):
             x = O.sketch_reads(b, off, c=c, mode=om, paired=True)
             differs += int(e["dup_removed"] != x["dup_removed"])
             for batches in (1, 4):
-                g = sketch_gpu(ctx, b, off, paired=True, seed_mode=gm, c=c, batches=batches, dedup_fpr=fpr, **cap)
-                assert_same_sketch(g, e)
+                for a10 in ("walk", "part"):     # the phase walk over a class table / the partitioned pass (one filter only: else it IS the walk)
+                    g = sketch_gpu(ctx, b, off, paired=True, seed_mode=gm, c=c, batches=batches, dedup_fpr=fpr, a10=a10, **cap)
+                    assert_same_sketch(g, e)
             assert e["dup_removed"] > 0
     if fpr >= 0.02:
         assert differs > 0          # the filter's false positives show in the result (else this test checks the exact path twice)
@@ -296,6 +297,109 @@ def test_read_sketch_paired_filter_dedup(ctx, fpr, capacity):
     # --no-dedup and single-end sessions ignore the option (sketch.rs:744, :897)
     g = sketch_gpu(ctx, b, off, paired=True, no_dedup=True, c=200, dedup_fpr=fpr, **cap)
     assert_same_sketch(g, O.sketch_reads(b, off, c=200, paired=True, no_dedup=True))
+
+
+def test_filter_dedup_seeds_repeated_inside_one_read(ctx):
+    """The filter's answers depend on the ORDER of the walk (sketch.rs:806-867 hands a record's seeds over in the order
+    extract_markers emitted them: lane-interleaved for the AVX2 routine), and so does `*c > 0` (:749): reads cut from a tandem
+    repeat of period 40 carry the same k-mer two or three times, and the occurrence that comes first by position is often the one the
+    walk sees last.  Exact set and filter, both seed modes, both passes, both finish paths."""
+    rng = np.random.default_rng(4040)
+    unit = random_seq(rng, 40)
+    rep = np.tile(unit, 60)                                    # 2,400 bases of period 40
+    genome = np.concatenate([random_seq(rng, 3000), rep, random_seq(rng, 3000)])
+    recs = make_reads(rng, genome, 1500, 150, err=0.002, dup_frac=0.2, paired=True, insert=300, ragged=False)
+    b, off = concat(recs)
+    for c in (3, 11):
+        for gm, om in MODES:
+            e = O.sketch_reads_cuckoo_model(b, off, c=c, mode=om, fpr=1e-4)
+            x = O.sketch_reads(b, off, c=c, mode=om, paired=True)
+            assert e["counts"].max() > 20                       # the repeat's k-mers are deep, and repeated inside single reads
+            for a10 in ("walk", "part"):
+                assert_same_sketch(sketch_gpu(ctx, b, off, paired=True, seed_mode=gm, c=c, dedup_fpr=1e-4, a10=a10), e)
+            assert_same_sketch(sketch_gpu(ctx, b, off, paired=True, seed_mode=gm, c=c), x)
+
+
+def test_filter_dedup_partitioned_pass_and_its_verdict(ctx):
+    """Round 5: where ONE filter takes every operation of the sample the marks come from the partitioned pass (csrc/a10.hip: operations
+    sorted by class, no table), which cannot know by itself that one filter was enough: its verdict — a bucket with more copies of one
+    class than a workgroup takes, more operations than the capacity — is read with the finish's tail block, and a bad one sends the
+    sample through the phase walk.  Slots of a deferred device batch, slots of a checked push, dense arrays; every table against
+    the model, the road read from the context's counters."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(555)
+    genome = random_seq(rng, 400_000)
+
+    def pairs(n, L=150):
+        st = rng.integers(0, len(genome) - 500, size=n)
+        recs = []
+        for s in st:
+            recs.append(genome[s:s + L])
+            recs.append(revcomp(genome[s + 200:s + 200 + L]))
+        return recs
+
+    def run(recs_list, borrow=True, host=False, c=200, **dedup):
+        sk = S.ReadSketcher(ctx, c=c, k=31, paired=True, dedup_fpr=1e-4, **dedup)
+        if borrow:
+            sk.set_option("borrow_until_finish", 1)
+        keep = []
+        for recs in recs_list:
+            b, o = concat(recs)
+            if host:
+                sk.push(b, o)
+            else:
+                tb = torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).to(dev)
+                to = torch.from_numpy(o.astype(np.int64)).to(dev)
+                torch.cuda.synchronize()
+                keep.append((tb, to))
+                sk.push_device(tb.data_ptr(), to.data_ptr(), len(recs), int(o[-1]))
+        g = sk.finish()
+        sk.close()
+        b, o = concat([r for recs in recs_list for r in recs])
+        ocap = dict(initial_capacity=dedup["dedup_capacity"]) if "dedup_capacity" in dedup else {}
+        assert_same_sketch(g, O.sketch_reads_cuckoo_model(b, o, c=c, mode=O.MODE_AVX2_COMPAT, fpr=1e-4, **ocap))
+        return g
+
+    def roads(fn):
+        ctx.profile(True)
+        fn()
+        r = tuple(int(ctx.kernel_stats(f)[1]) for f in ("deferred", "deferred_redo", "a10_part", "a10_redo"))
+        ctx.profile(False)
+        return r
+
+    normal = pairs(6000) + pairs(50) * 3                                   # ~1.8 Mbp, some exact duplicate pairs
+    assert roads(lambda: run([normal])) == (1, 0, 1, 0)                    # deferred slots, partitioned pass, good verdict
+    assert roads(lambda: run([normal], a10="walk")) == (1, 0, 0, 0)
+    assert roads(lambda: run([normal], borrow=False)) == (0, 0, 1, 0)      # slots of a checked push
+    assert roads(lambda: run([normal], host=True)) == (0, 0, 1, 0)         # dense arrays
+    assert roads(lambda: run([normal, pairs(4000)])) == (1, 0, 1, 0)       # two batches: dense arrays by the time of the finish
+    long_rec = pairs(3000) + [genome[1000:1600], revcomp(genome[1200:1350])] + pairs(3000)
+    assert roads(lambda: run([long_rec])) == (1, 1, 2, 0)                  # the seeding verdict was bad: batch redone, marked again
+    one = None
+    for s in range(0, 5000, 7):                                            # a pair whose mate 1 carries >= 3 seeds at c = 200
+        if len(O.extract_markers(genome[s:s + 150], c=200, k=31)) >= 3:
+            one = [genome[s:s + 150], revcomp(genome[s + 200:s + 350])]
+            break
+    assert one is not None
+    # 700 copies of one pair spread among ordinary ones: each of its items fills a class bucket beyond what a workgroup takes -> the walk
+    spread = []
+    for _ in range(700):
+        spread += pairs(9) + one
+    assert roads(lambda: run([spread])) == (1, 0, 1, 1)
+    # capacities around the sample's number of operations: below the estimate the walk is chosen at once; between the estimate and
+    # the true count the partitioned pass runs and its verdict sends the sample to the walk (which then grows a second filter)
+    b, o = concat(normal)
+    n_ops = 2 * sum(len(O.extract_markers(b[int(o[i]):int(o[i + 1])], c=200, k=31)) for i in range(len(o) - 1))
+    seen = set()
+    for cap in sorted({int(n_ops * f) for f in (0.55, 0.8, 0.9, 0.95, 0.99, 1.05, 1.2)}):
+        nb = 1
+        while nb * 4 < cap:
+            nb *= 2
+        if cap > 0.8 * 4 * nb:
+            continue                                                       # (refused: would fill its buckets to the brim)
+        seen.add(roads(lambda: run([normal], dedup_capacity=cap))[2:])
+    assert (1, 0) in seen and ((1, 1) in seen or (0, 0) in seen)
 
 
 def test_read_sketch_deep_coverage_and_cutoff(ctx):
