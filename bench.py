@@ -370,11 +370,15 @@ def main():
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")
     ap.add_argument("--no-filter-leg", action="store_true", help="skip the leg with sylph's default pair dedup (cuckoo filter, --fpr 1e-4)")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the leg of the mode `value` is NOT taken from")
+    ap.add_argument("--main-dedup-fpr", type=float, default=0.0, help="profiling runs only: EVERY leg's sessions get sylph's default pair dedup (the cuckoo "
+                                                                      "filter of csrc/a10.hip) with this --fpr; switches the exact-set verify and the filter leg off")
     ap.add_argument("--seed", type=int, default=20250711)
     ap.add_argument("--sweep", default="", help="tuning runs only: JSON list of pipeline configurations ({name, workers, depth, max_batch, options{}, "
                                                 "pipe_options{}}) measured one after the other on the workload of this run, after the timed region; "
                                                 "results go into the line's `sweep` object (never into `value`)")
     args = ap.parse_args()
+    if args.main_dedup_fpr:
+        args.no_verify = args.no_filter_leg = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -504,6 +508,8 @@ def main():
                        comm=comm)
         for kv in ctx_options + pipe_options:
             p.set_option(*kv)
+        if args.main_dedup_fpr:
+            p.set_option("dedup_fpr", repr(args.main_dedup_fpr))
         return p
 
     pipe_box = [None]
@@ -528,7 +534,7 @@ def main():
                 t = r["t"]
                 rows.append((t[2] - t[1], t[4] - t[3], r["n_table"], r["dup_removed"], r["n_covs"], r["probe_batch"]))
 
-    filter_box = [False]                     # the filter leg: sessions get the reference's default pair dedup (dedup_fpr 1e-4)
+    filter_box = [bool(args.main_dedup_fpr)]    # the filter leg: sessions get the reference's default pair dedup (dedup_fpr 1e-4)
 
     def sketch_inline(rs):
         sk = S.ReadSketcher(ctx, c=c_reads, k=k, paired=not long_mode, dedup_fpr=1e-4 if filter_box[0] else 0.0)
@@ -807,7 +813,8 @@ def main():
                    "sketch_workers_per_gpu": n_workers if mode == "pipelined" else 0, "samples_in_flight": depth if mode == "pipelined" else 1,
                    **({"fallbacks": fallbacks} if fallbacks else {}), "reads_per_sample_gbp": round(n_bases / 1e9, 4),
                    "distinct_read_sets_rotated": n_sets, "genomes": n_total, "db_kmers_per_shard": dbstats["shard_kmers"],
-                   "dedup": "exact (--fpr 0 semantics)" if not long_mode else "none applies (reads > 400 bp, sketch.rs:922-927)",
+                   "dedup": ("none applies (reads > 400 bp, sketch.rs:922-927)" if long_mode else
+                             f"the pair set behind the model of sylph's cuckoo filter, --fpr {args.main_dedup_fpr} (profiling run)" if args.main_dedup_fpr else "exact (--fpr 0 semantics)"),
                    "seed_mode": "avx2_compat", "parallelism": parallelism,
                    "inputs": "reads + database resident in HBM before the timed region",
                    "rng": "splitmix64 counter streams (synth.py: every random number = one word of a stream addressed by its index, integer arithmetic "
