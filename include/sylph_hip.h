@@ -55,6 +55,9 @@ typedef struct sylph_sketch sylph_sketch;  /* a read-sketch session (one sample)
 typedef struct sylph_db sylph_db;          /* a genome database (shard) resident in HBM */
 
 int sylph_version(void);
+/* gfx950 devices this process sees (0: none, or the runtime failed): what `sylph-hip profile --gpus all` spreads its replicas over —
+ * the reference sizes its rayon pool from the machine the same way (contain.rs:136-139). */
+int sylph_device_count(void);
 const char *sylph_last_error(void);
 void sylph_free(void *p);
 /* Page-locked host memory for SYLPH_MEM_HOST_PINNED inputs (host feed); release with sylph_pinned_free(). */
@@ -216,6 +219,11 @@ int sylph_sketch_set_option(sylph_sketch *sk, const char *key, const char *value
  * by HBM only (the index is built in passes). */
 int sylph_db_upload(sylph_ctx *ctx, const uint64_t *kmers, const uint64_t *genome_off, uint64_t n_genomes, int mem,
                     sylph_db **out);
+/* A copy of an UNSHARDED database (kept index, tracked index of sylph_db_attach_tracked, genome lengths) on another context —
+ * normally another GPU of the node: the arrays travel device to device (hipMemcpyPeer, over xGMI), nothing is uploaded or indexed
+ * again.  What N GPUs share where the reference's rayon workers share one Vec<GenomeSketch> (contain.rs:252-295, :482-517).
+ * Attach the tracked k-mers to `src` BEFORE replicating if the replicas are to reassign.  Free with sylph_db_destroy. */
+int sylph_db_replicate(sylph_db *src, sylph_ctx *dst_ctx, sylph_db **out);
 uint64_t sylph_db_n_genomes(const sylph_db *db);
 uint64_t sylph_db_n_kmers(const sylph_db *db);
 
@@ -372,6 +380,19 @@ typedef struct sylph_pipeline_result {
     double t_submit, t_sketch_begin, t_sketch_end, t_profile_begin, t_done;   /* CLOCK_MONOTONIC seconds */
 } sylph_pipeline_result;
 int sylph_pipeline_create(sylph_db *db, const sylph_pipeline_config *cfg, sylph_pipeline **out);
+/* ONE sample loop over all GPUs of a node from one process (round 5).  The reference's loop uses the whole machine through its rayon
+ * pool (contain.rs:252-295 samples x genomes; sketch.rs:313,371 one file per worker); a database of 113k genomes is a 29 GB index,
+ * so on N GPUs the natural split is N replicas: dbs[i] = the copy on GPU i, made by sylph_db_replicate
+ * (device to device over xGMI, the database is uploaded and indexed ONCE).  Every replica gets a pipeline of its own with `cfg`
+ * (workers, depth, max_batch: per replica; cfg.comm must be NULL); the returned object takes every sylph_pipeline_* call:
+ * submit sends a sample to the replica on the device its memory is on (device batches: hipPointerGetAttributes; sessions: their
+ * context's device) or, for host memory, to the replica with the fewest samples outstanding; next returns the samples in
+ * SUBMISSION order whichever GPU had them (sylph_pipeline_replica_of_last: which one — the device its dev_kmers live on, for
+ * sylph_db_reassign_view on dbs[replica]); a result's pointers stay valid until the next sylph_pipeline_next that lands on the
+ * same replica.  Two replicas may share a device (that is how the one-GPU tests run it). */
+int sylph_pipeline_create_multi(sylph_db *const *dbs, uint32_t n_dbs, const sylph_pipeline_config *cfg, sylph_pipeline **out);
+/* Index into dbs[] of the sample the last successful sylph_pipeline_next returned (0 for a single-database pipeline; -1: null). */
+int sylph_pipeline_replica_of_last(sylph_pipeline *p);
 /* SYLPH_ERR_STATE when `depth` samples are outstanding already (take one with sylph_pipeline_next first). */
 int sylph_pipeline_submit(sylph_pipeline *p, const sylph_read_batch *batches, uint32_t n_batches, int mem, int enc, uint64_t tag);
 int sylph_pipeline_submit_session(sylph_pipeline *p, sylph_sketch *sk, uint64_t tag);

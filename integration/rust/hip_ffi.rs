@@ -131,6 +131,12 @@ extern "C" {
     // ---- round 3: the sample loop of `sylph profile` (contain.rs:267-289 over sketch.rs:313,371) as a pipeline inside the
     // library: sketch workers + one profile thread; submit samples, take results in submission order
     pub fn sylph_pipeline_create(db: *mut SylphDb, cfg: *const SylphPipelineConfig, out: *mut *mut SylphPipeline) -> c_int;
+    // round 5: one sample loop over all GPUs of the node — dbs[i] = the replica on GPU i (sylph_db_replicate: the index copied over
+    // xGMI); the returned pipeline takes every sylph_pipeline_* call and hands the samples back in submission order
+    pub fn sylph_device_count() -> c_int;
+    pub fn sylph_db_replicate(src: *mut SylphDb, dst_ctx: *mut SylphCtx, out: *mut *mut SylphDb) -> c_int;
+    pub fn sylph_pipeline_create_multi(dbs: *const *mut SylphDb, n_dbs: u32, cfg: *const SylphPipelineConfig, out: *mut *mut SylphPipeline) -> c_int;
+    pub fn sylph_pipeline_replica_of_last(p: *mut SylphPipeline) -> c_int;
     pub fn sylph_pipeline_submit(p: *mut SylphPipeline, batches: *const SylphReadBatch, n_batches: u32, mem: c_int, enc: c_int,
                                  tag: u64) -> c_int;
     pub fn sylph_pipeline_submit_session(p: *mut SylphPipeline, sk: *mut SylphSketch, tag: u64) -> c_int;

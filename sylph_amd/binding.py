@@ -33,7 +33,8 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_pipeline_create", "sylph_pipeline_submit", "sylph_pipeline_submit_session", "sylph_pipeline_flush", "sylph_pipeline_next",
            "sylph_pipeline_outstanding", "sylph_pipeline_set_option", "sylph_pipeline_profile", "sylph_pipeline_kernel_stats",
            "sylph_pipeline_destroy", "sylph_db_exchange_stats", "sylph_sketch_set_option",
-           "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_destroy"]
+           "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_destroy",
+           "sylph_db_replicate", "sylph_pipeline_create_multi", "sylph_pipeline_replica_of_last", "sylph_device_count"]
 
 
 def load():
@@ -110,6 +111,10 @@ def load():
     L.sylph_pipeline_kernel_stats.argtypes = [vp, C.c_char_p, P(dbl), P(u64)]
     L.sylph_pipeline_destroy.argtypes = [vp]
     L.sylph_pipeline_destroy.restype = None
+    L.sylph_db_replicate.argtypes = [vp, vp, P(vp)]
+    L.sylph_pipeline_create_multi.argtypes = [vp, u32, vp, P(vp)]
+    L.sylph_pipeline_replica_of_last.argtypes = [vp]
+    L.sylph_device_count.restype = i32
     _LIB = L
     return L
 
@@ -406,6 +411,17 @@ class Database:
         self.n_genomes = int(load().sylph_db_n_genomes(self._h))
         self.n_kmers = int(load().sylph_db_n_kmers(self._h))
 
+    def replicate(self, ctx):
+        """sylph_db_replicate: a copy of this (unsharded) database on another context — another GPU of the node; the index travels device
+        to device (xGMI), nothing is uploaded or built again."""
+        other = Database.__new__(Database)
+        other.ctx = ctx
+        other._h = C.c_void_p()
+        _check(load().sylph_db_replicate(self._h, ctx._h, C.byref(other._h)))
+        other.n_genomes = int(load().sylph_db_n_genomes(other._h))
+        other.n_kmers = int(load().sylph_db_n_kmers(other._h))
+        return other
+
     def contain(self, sample_kmers, sample_counts, min_number_kmers=50.0, device_ptrs=False, n=None):
         """-> (contain_count[G] uint32, cov_off[G+1] uint64, covs uint32 sorted ascending per genome)."""
         G = self.n_genomes
@@ -553,11 +569,18 @@ class Pipeline:
 
     def __init__(self, db, c=200, k=31, paired=True, no_dedup=False, seed_mode=SEED_AVX2_COMPAT, n_workers=0, depth=0, max_batch=0,
                  want_table=False, min_number_kmers=50.0, comm=None):
-        self.db = db
+        # db: one Database, or a list of replicas of one (Database.replicate: one per GPU) -> sylph_pipeline_create_multi: one sample
+        # loop over all of them, results in submission order
+        self.dbs = list(db) if isinstance(db, (list, tuple)) else None
+        self.db = self.dbs[0] if self.dbs else db
         self._h = C.c_void_p()
         cfg = PipelineConfig(C.sizeof(PipelineConfig), n_workers, depth, max_batch, c, k, READS_PAIRED if paired else READS_SINGLE,
                              int(no_dedup), seed_mode, int(want_table), float(min_number_kmers), comm._h if comm is not None else None)
-        _check(load().sylph_pipeline_create(db._h, C.byref(cfg), C.byref(self._h)))
+        if self.dbs:
+            arr = (C.c_void_p * len(self.dbs))(*[d._h for d in self.dbs])
+            _check(load().sylph_pipeline_create_multi(arr, len(self.dbs), C.byref(cfg), C.byref(self._h)))
+        else:
+            _check(load().sylph_pipeline_create(db._h, C.byref(cfg), C.byref(self._h)))
         self._res = PipelineResult()
         self._want_table = bool(want_table)
 
@@ -592,6 +615,7 @@ class Pipeline:
         if r.status != 0:
             raise SylphHipError(r.status, (r.error or b"").decode("utf-8", "replace"))
         out = dict(tag=int(r.tag), n_table=int(r.n_table), dup_removed=int(r.dup_removed), dev_kmers=r.dev_kmers or 0,
+                   replica=int(load().sylph_pipeline_replica_of_last(self._h)),
                    dev_counts=r.dev_counts or 0, n_covs=int(r.n_covs), probe_batch=int(r.probe_batch),
                    t=(r.t_submit, r.t_sketch_begin, r.t_sketch_end, r.t_profile_begin, r.t_done))
         if views:

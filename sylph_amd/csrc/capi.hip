@@ -170,6 +170,11 @@ void sylph_ctx::h2d(void* dev_dst, const void* src, size_t bytes) {
 extern "C" {
 
 int sylph_version(void) { return 100; }   // 0.1.0
+int sylph_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 
 const char* sylph_last_error(void) { return g_err; }
 

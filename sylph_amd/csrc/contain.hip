@@ -1068,6 +1068,50 @@ int sylph_db_attach_tracked(sylph_db* db, const uint64_t* tracked_kmers, const u
     });
 }
 
+// A copy of an unsharded database on another context (normally: another GPU of the node).  The line index, the overflow runs, the
+// tracked index and the genome lengths travel device to device — hipMemcpyPeer, i.e. over xGMI between two GPUs — instead of being
+// uploaded from the host and built again per GPU: the counterpart of the reference's one `Vec<GenomeSketch>` shared by all rayon
+// workers (contain.rs:252-295), for N GPUs behind one sample loop (sylph_pipeline_create_multi).
+int sylph_db_replicate(sylph_db* src, sylph_ctx* dst_ctx, sylph_db** out) {
+    return guarded([&] {
+        SY_REQUIRE(src && dst_ctx && out, "null argument");
+        SY_REQUIRE(src->world == 1 && src->bounds.empty(), "only an unsharded database can be replicated");
+        sylph_ctx* sctx = src->ctx;
+        // (two context locks, always in address order: two threads replicating in opposite directions cannot deadlock)
+        std::unique_lock<std::mutex> l1(sctx < dst_ctx ? sctx->mu : dst_ctx->mu, std::defer_lock), l2(sctx < dst_ctx ? dst_ctx->mu : sctx->mu, std::defer_lock);
+        l1.lock();
+        if (sctx != dst_ctx) l2.lock();
+        {   // everything queued on the source's stream (the index build) must have landed
+            DeviceGuard dg(sctx->device);
+            SY_HIP(hipStreamSynchronize(sctx->stream));
+        }
+        DeviceGuard dg(dst_ctx->device);
+        std::unique_ptr<sylph_db> db(new sylph_db(dst_ctx));
+        db->n_genomes = src->n_genomes;
+        db->n_kmers = src->n_kmers;
+        db->min_glen = src->min_glen;
+        db->counter.reserve(64);
+        auto copy = [&](DevBuf& d, const DevBuf& s_, size_t bytes) {
+            if (!bytes) return;
+            d.reserve(bytes);
+            if (sctx->device == dst_ctx->device) SY_HIP(hipMemcpyAsync(d.p, s_.p, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream));
+            else SY_HIP(hipMemcpyPeerAsync(d.p, dst_ctx->device, s_.p, sctx->device, bytes, dst_ctx->stream));
+        };
+        auto copy_index = [&](LineIndex& d, const LineIndex& s_) {
+            d.base = s_.base; d.div = s_.div; d.magic = s_.magic; d.n_postings = s_.n_postings; d.n_ovf = s_.n_ovf;
+            d.n_buckets = s_.n_buckets; d.gshift = s_.gshift;
+            copy(d.lines, s_.lines, (size_t)s_.n_buckets * LINE_SLOTS * 8);
+            copy(d.ovf, s_.ovf, s_.ovf.p ? std::min<size_t>(s_.ovf.cap, ((size_t)s_.n_ovf + 64) * 8) : 0);   // (+64: the wavefront-wide walk of a long run reads 64 entries at a time)
+        };
+        copy_index(db->kept, src->kept);
+        copy_index(db->tracked, src->tracked);
+        copy(db->glen, src->glen, std::max<uint64_t>(1, src->n_genomes) * 4);
+        SY_HIP(hipStreamSynchronize(dst_ctx->stream));
+        dst_ctx->refs++;
+        *out = db.release();
+    });
+}
+
 uint64_t sylph_db_n_genomes(const sylph_db* db) { return db ? db->n_genomes : 0; }
 uint64_t sylph_db_n_kmers(const sylph_db* db) { return db ? db->n_kmers : 0; }
 uint64_t sylph_db_index_bytes(const sylph_db* db) {

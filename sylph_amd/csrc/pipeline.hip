@@ -99,6 +99,12 @@ struct sylph_pipeline {
     // behind its seeding kernel instead (hosts never block on it)
     std::vector<hipEvent_t> seed_ev;             // one per worker
     hipEvent_t last_seed_ev = nullptr;           // guarded by seed_mu
+    // A pipeline over several replicas of one database (sylph_pipeline_create_multi: one per GPU of the node) is only a router:
+    // `children` are ordinary pipelines, one per replica; `route` holds the replica of every outstanding sample in submission
+    // order, so that sylph_pipeline_next returns the samples in the order they were submitted whichever GPU had them.
+    std::vector<sylph_pipeline*> children;
+    std::deque<uint32_t> route;                  // guarded by mu
+    uint32_t last_replica = 0;                   // replica of the sample sylph_pipeline_next returned last
 
     Block* take_block() {                        // mu held
         for (auto& b : blocks)
@@ -343,8 +349,95 @@ int sylph_pipeline_create(sylph_db* db, const sylph_pipeline_config* cfg, sylph_
     });
 }
 
+// One sample loop over the GPUs of a node, in ONE process (the reference's sample loop uses the whole machine through its rayon
+// pool: contain.rs:252-295, sketch.rs:313,371).  dbs[i]: the database's replica on GPU i (sylph_db_replicate: the index copied over
+// xGMI, not uploaded N times).  Every replica gets a pipeline of its own (cfg: per replica); a sample goes to the replica on the
+// device its memory lives on (device batches, sessions) or to the least busy one (host batches), and comes back in submission order.
+int sylph_pipeline_create_multi(sylph_db* const* dbs, uint32_t n_dbs, const sylph_pipeline_config* cfg, sylph_pipeline** out) {
+    return guarded([&] {
+        SY_REQUIRE(dbs && cfg && out && n_dbs >= 1 && n_dbs <= 64, "null argument, or not 1..64 replicas");
+        SY_REQUIRE(cfg->struct_size == sizeof(sylph_pipeline_config), "sylph_pipeline_config.struct_size is %u, this library expects %zu",
+                   cfg->struct_size, sizeof(sylph_pipeline_config));
+        SY_REQUIRE(!cfg->comm, "replicas take no communicator (a sharded database runs one pipeline per rank)");
+        for (uint32_t i = 0; i < n_dbs; i++) {
+            SY_REQUIRE(dbs[i] && dbs[i]->world == 1 && dbs[i]->bounds.empty(), "replica %u is null or a shard", i);
+            SY_REQUIRE(dbs[i]->n_genomes == dbs[0]->n_genomes && dbs[i]->n_kmers == dbs[0]->n_kmers, "replica %u is not a copy of replica 0", i);
+        }
+        std::unique_ptr<sylph_pipeline> p(new sylph_pipeline());
+        p->db = dbs[0];
+        p->n_workers = 0;
+        try {
+            for (uint32_t i = 0; i < n_dbs; i++) {
+                sylph_pipeline* c = nullptr;
+                if (sylph_pipeline_create(dbs[i], cfg, &c) != SYLPH_OK) throw ArgError{sylph_last_error()};
+                p->children.push_back(c);
+            }
+        } catch (...) {
+            for (sylph_pipeline* c : p->children) sylph_pipeline_destroy(c);
+            throw;
+        }
+        p->depth = p->children[0]->depth * n_dbs;
+        p->max_batch = p->children[0]->max_batch;
+        *out = p.release();
+    });
+}
+
+}  // extern "C"
+
+namespace {
+
+// multi: the replica a sample goes to — among those on `device` (-1: any) the one with the fewest samples outstanding
+int pick_replica(sylph_pipeline* p, int device) {
+    int best = -1;
+    uint32_t best_out = 0;
+    for (size_t i = 0; i < p->children.size(); i++) {
+        sylph_pipeline* c = p->children[i];
+        if (device >= 0 && c->db->ctx->device != device) continue;
+        const uint32_t o = sylph_pipeline_outstanding(c);
+        if (o >= c->depth) continue;
+        if (best < 0 || o < best_out) { best = (int)i; best_out = o; }
+    }
+    return best;
+}
+// submits through `send` (a call on the chosen child) and records the route; mu orders submissions against each other
+template <class Send>
+int route_submit(sylph_pipeline* p, int device, const char* what, Send&& send) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    const int r = pick_replica(p, device);
+    if (r < 0) {
+        bool any = false;
+        for (sylph_pipeline* c : p->children) any |= device < 0 || c->db->ctx->device == device;
+        if (!any) { set_error("%s: no replica of the database lives on device %d, where the sample's memory is", what, device); return SYLPH_ERR_INVALID; }
+        set_error("%s: every replica%s has its `depth` samples outstanding: call sylph_pipeline_next first", what, device >= 0 ? " on the sample's device" : "");
+        return SYLPH_ERR_STATE;
+    }
+    const int rc = send(p->children[(size_t)r]);
+    if (rc == SYLPH_OK) p->route.push_back((uint32_t)r);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sylph_pipeline_replica_of_last(sylph_pipeline* p) {
+    if (!p) return -1;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return p->children.empty() ? 0 : (int)p->last_replica;
+}
+
 int sylph_pipeline_submit(sylph_pipeline* p, const sylph_read_batch* batches, uint32_t n_batches, int mem, int enc, uint64_t tag) {
     if (!p || (n_batches && !batches)) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (!p->children.empty()) {
+        int device = -1;
+        if (mem == SYLPH_MEM_DEVICE && n_batches) {
+            hipPointerAttribute_t at;
+            const void* ptr = batches[0].bases ? (const void*)batches[0].bases : (const void*)batches[0].rec_off;
+            if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); set_error("sylph_pipeline_submit: cannot tell the device of the batch's memory"); return SYLPH_ERR_INVALID; }
+            device = at.device;
+        }
+        return route_submit(p, device, "sylph_pipeline_submit", [&](sylph_pipeline* c) { return sylph_pipeline_submit(c, batches, n_batches, mem, enc, tag); });
+    }
     std::unique_ptr<Job> j(new Job());
     j->batches.assign(batches, batches + n_batches);
     j->mem = mem; j->enc = enc; j->tag = tag;
@@ -353,6 +446,8 @@ int sylph_pipeline_submit(sylph_pipeline* p, const sylph_read_batch* batches, ui
 
 int sylph_pipeline_submit_session(sylph_pipeline* p, sylph_sketch* sk, uint64_t tag) {
     if (!p || !sk) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (!p->children.empty())
+        return route_submit(p, sk->ctx->device, "sylph_pipeline_submit_session", [&](sylph_pipeline* c) { return sylph_pipeline_submit_session(c, sk, tag); });
     if (sk->ctx->device != p->db->ctx->device) { set_error("the session lives on another device than the database"); return SYLPH_ERR_INVALID; }
     std::unique_ptr<Job> j(new Job());
     j->sk = sk; j->adopted = true; j->tag = tag;
@@ -362,12 +457,25 @@ int sylph_pipeline_submit_session(sylph_pipeline* p, sylph_sketch* sk, uint64_t 
 int sylph_pipeline_flush(sylph_pipeline* p) {
     return guarded([&] {
         SY_REQUIRE(p, "null argument");
+        for (sylph_pipeline* c : p->children) (void)sylph_pipeline_flush(c);
         { std::lock_guard<std::mutex> lk(p->mu); p->flush_upto = p->next_seq; }
         p->cv_sketched.notify_all();
     });
 }
 
 int sylph_pipeline_next(sylph_pipeline* p, sylph_pipeline_result* out) {
+    if (p && out && !p->children.empty()) {
+        uint32_t r;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (p->route.empty()) { set_error("sylph_pipeline_next: nothing is outstanding"); return SYLPH_ERR_INVALID; }
+            r = p->route.front();
+        }
+        // (the replica's own pipeline hands its samples back in ITS submission order, which is the order they were routed in)
+        const int rc = sylph_pipeline_next(p->children[r], out);
+        if (rc == SYLPH_OK) { std::lock_guard<std::mutex> lk(p->mu); p->route.pop_front(); p->last_replica = r; }
+        return rc;
+    }
     return guarded([&] {
         SY_REQUIRE(p && out, "null argument");
         std::unique_lock<std::mutex> lk(p->mu);
@@ -414,11 +522,16 @@ int sylph_pipeline_next(sylph_pipeline* p, sylph_pipeline_result* out) {
 uint32_t sylph_pipeline_outstanding(sylph_pipeline* p) {
     if (!p) return 0;
     std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->children.empty()) return (uint32_t)p->route.size();
     return (uint32_t)p->order.size();
 }
 
 int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* value) {
     if (!p || !key || !value) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (!p->children.empty()) {
+        for (sylph_pipeline* c : p->children) { const int rc = sylph_pipeline_set_option(c, key, value); if (rc != SYLPH_OK) return rc; }
+        return SYLPH_OK;
+    }
     {   // the pipeline's own knobs; everything else goes to the workers' contexts
         if (!strcmp(key, "serialize_seeding")) { p->serialize_seeding.store((uint32_t)strtoul(value, nullptr, 10)); return SYLPH_OK; }
         uint32_t* dst = !strcmp(key, "min_batch") ? &p->min_batch : !strcmp(key, "batch_wait_us") ? &p->batch_wait_us : nullptr;
@@ -442,6 +555,10 @@ int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* va
 
 int sylph_pipeline_profile(sylph_pipeline* p, int enable) {
     if (!p) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (!p->children.empty()) {
+        for (sylph_pipeline* c : p->children) { const int rc = sylph_pipeline_profile(c, enable); if (rc != SYLPH_OK) return rc; }
+        return SYLPH_OK;
+    }
     for (sylph_ctx* cx : p->wctx) {
         const int rc = sylph_ctx_profile(cx, enable);
         if (rc != SYLPH_OK) return rc;
@@ -453,6 +570,19 @@ int sylph_pipeline_kernel_stats(sylph_pipeline* p, const char* family, double* t
     if (!p || !family) { set_error("null argument"); return SYLPH_ERR_INVALID; }
     double ms = 0;
     uint64_t n = 0;
+    if (!p->children.empty()) {
+        for (sylph_pipeline* c : p->children) {
+            double m = 0;
+            uint64_t l = 0;
+            const int rc = sylph_pipeline_kernel_stats(c, family, &m, &l);
+            if (rc != SYLPH_OK) return rc;
+            ms += m;
+            n += l;
+        }
+        if (total_ms) *total_ms = ms;
+        if (launches) *launches = n;
+        return SYLPH_OK;
+    }
     std::vector<sylph_ctx*> all(p->wctx);
     all.push_back(p->db->ctx);
     for (sylph_ctx* cx : all) {
@@ -470,6 +600,11 @@ int sylph_pipeline_kernel_stats(sylph_pipeline* p, const char* family, double* t
 
 void sylph_pipeline_destroy(sylph_pipeline* p) {
     if (!p) return;
+    if (!p->children.empty()) {                  // the router: its replicas' pipelines finish what they have and go
+        for (sylph_pipeline* c : p->children) sylph_pipeline_destroy(c);
+        delete p;
+        return;
+    }
     sylph_sketch* dead = nullptr;
     {
         std::unique_lock<std::mutex> lk(p->mu);

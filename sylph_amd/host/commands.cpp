@@ -952,7 +952,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
     // views (coverage values cov_width bytes each); the sample table is given where it lies (tk / tc / tn in tmem) for the
     // reassignment probe; S carries the metadata, and the counts on the host when -u needs them.
     auto report = [&](const SequencesSketch& S, const std::string& first_file, const uint32_t* cc, const uint64_t* coff, const void* covs,
-                      uint32_t cov_width, const uint64_t* tk, const uint32_t* tc, uint64_t tn, int tmem) {
+                      uint32_t cov_width, const uint64_t* tk, const uint32_t* tc, uint64_t tn, int tmem, sylph_db* rdb) {
         if (genome_k != S.k) throw Error{1, "k parameter for reads != k parameter for genome"};   // contain.rs:608-615
         const std::string seq_name = S.sample_name ? *S.sample_name : S.file_name;   // :775-781
         auto cov_vector = [&](const void* base, uint32_t width, uint64_t lo, uint64_t hi) {
@@ -992,7 +992,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             const uint32_t *cc2 = nullptr, *covs2 = nullptr, *lost2 = nullptr;
             const uint64_t* coff2 = nullptr;
             uint64_t ncov2 = 0;
-            hip_check(sylph_db_reassign_view(db, tk, tc, tn, tmem, pg.data(), pa.data(), (uint32_t)pg.size(), &cc2, &coff2, &covs2, &ncov2, &lost2),
+            hip_check(sylph_db_reassign_view(rdb, tk, tc, tn, tmem, pg.data(), pa.data(), (uint32_t)pg.size(), &cc2, &coff2, &covs2, &ncov2, &lost2),
                       "sylph_db_reassign_view");
             std::vector<AniResult> stats2;
             std::vector<std::optional<AniResult>> res2(stats.size());
@@ -1044,7 +1044,39 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         std::vector<std::promise<Prepared>> promises(n_raw);
         std::vector<std::future<Prepared>> futures;
         for (auto& p : promises) futures.push_back(p.get_future());
-        const size_t n_workers = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(args.threads, MAX_SAMPLE_THREADS), n_raw));
+        // --gpus N|all: the database replicated on N GPUs (index copied device to device), sample threads dealt to them in turn,
+        // one router pipeline over the replicas (sylph_pipeline_create_multi): the reference's sample loop spans the machine through
+        // its rayon pool (contain.rs:252-295), this is the same for the GPUs of a node.  One GPU: everything as before.
+        // (SYLPH_HIP_SHARE_GPUS=1: more replicas than devices — they wrap around; how the one-GPU test box runs `--gpus 2`)
+        int n_gpus = args.gpus < 0 ? sylph_device_count() : getenv("SYLPH_HIP_SHARE_GPUS") ? args.gpus : std::min(args.gpus, std::max(1, sylph_device_count()));
+        n_gpus = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_gpus), n_raw));
+        std::vector<std::unique_ptr<Engine>> replica_engines;            // (declared before the replicas: destroyed after them)
+        struct Replicas { std::vector<sylph_db*> v; ~Replicas() { for (size_t i = 1; i < v.size(); i++) sylph_db_destroy(v[i]); } } replicas;
+        std::vector<sylph_db*>& dbs = replicas.v;
+        dbs.push_back(db);
+        std::vector<int> replica_device{e.device};
+        {
+            int dev0 = e.device;
+            if (dev0 < 0) dev0 = 0;                                      // (Engine(-1) = the current device = 0 in a fresh process)
+            replica_device[0] = e.device;
+            const auto t_r0 = std::chrono::steady_clock::now();
+            for (int g = 1; g < n_gpus; g++) {
+                const int dev = (dev0 + g) % std::max(1, sylph_device_count());
+                replica_engines.emplace_back(new Engine(dev));
+                sylph_db* r = nullptr;
+                hip_check(sylph_db_replicate(db, replica_engines.back()->context(), &r), "sylph_db_replicate");
+                dbs.push_back(r);
+                replica_device.push_back(dev);
+            }
+            if (n_gpus > 1) {
+                char b[160];
+                snprintf(b, sizeof(b), "database replicated on %d GPUs (device to device) in %.3f s", n_gpus,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count());
+                info(b);
+            }
+        }
+        std::atomic<size_t> worker_no{0};
+        const size_t n_workers = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(std::min<size_t>(args.threads, MAX_SAMPLE_THREADS), (size_t)n_gpus), n_raw));
         set_parse_share((unsigned)n_workers);
         const size_t ahead_limit = n_workers + 2;                        // sessions that may wait, sketched, for the profile stage
         std::vector<IndexAhead::Files> job_files;
@@ -1079,7 +1111,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             // profile stage and the reassignment probes
             std::unique_ptr<Engine> own;
             Engine* eng = nullptr;
-            try { own.reset(new Engine(e.device)); eng = own.get(); }
+            try { own.reset(new Engine(replica_device[worker_no++ % replica_device.size()])); eng = own.get(); }
             catch (...) { eng = nullptr; }
             for (;;) {
                 const size_t j = next_job++;
@@ -1104,7 +1136,8 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         cfg.reads_mode = SYLPH_READS_PAIRED; cfg.seed_mode = SYLPH_SEED_AVX2_COMPAT;
         cfg.want_table = args.estimate_unknown ? 1 : 0;                 // -u walks the counts on the host
         cfg.min_number_kmers = args.min_number_kmers;
-        hip_check(sylph_pipeline_create(db, &cfg, &pipe), "sylph_pipeline_create");
+        if (n_gpus > 1) hip_check(sylph_pipeline_create_multi(dbs.data(), (uint32_t)dbs.size(), &cfg, &pipe), "sylph_pipeline_create_multi");
+        else hip_check(sylph_pipeline_create(db, &cfg, &pipe), "sylph_pipeline_create");
         struct PipeGuard { sylph_pipeline* p; ~PipeGuard() { sylph_pipeline_destroy(p); } } pipe_guard{pipe};
         std::vector<std::thread> pool;
         size_t submitted = 0;
@@ -1152,7 +1185,8 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                 if (r.status != SYLPH_OK) throw Error{1, std::string("sample ") + read_files[j][0] + ": " + (r.error ? r.error : "GPU stage failed")};
                 SequencesSketch& S = *metas[j];
                 if (args.estimate_unknown && r.counts) S.counts.assign(r.counts, r.counts + r.n_table);
-                report(S, read_files[j][0], r.contain_count, r.cov_off, r.covs, r.cov_width, r.dev_kmers, r.dev_counts, r.n_table, SYLPH_MEM_DEVICE);
+                report(S, read_files[j][0], r.contain_count, r.cov_off, r.covs, r.cov_width, r.dev_kmers, r.dev_counts, r.n_table, SYLPH_MEM_DEVICE,
+                       dbs[(size_t)std::max(0, sylph_pipeline_replica_of_last(pipe))]);
             }
             finished(read_files[j]);
             metas[j].reset();
@@ -1177,7 +1211,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
             const uint32_t* cc = nullptr; const uint64_t* coff = nullptr; const uint32_t* covs = nullptr; uint64_t ncov = 0;
             hip_check(sylph_db_contain_view(db, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST,
                                             args.min_number_kmers, &cc, &coff, &covs, &ncov), "sylph_db_contain_view");
-            report(S, files[0], cc, coff, covs, 4, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST);
+            report(S, files[0], cc, coff, covs, 4, S.kmers.data(), S.counts.data(), S.kmers.size(), SYLPH_MEM_HOST, db);
         }
         finished(files);
     }

@@ -90,6 +90,7 @@ int run_contain(Argv a, bool profile) {
         else if (t == "--mean-coverage") { c.mean_coverage = true; a.i++; }
         else if (t == "--debug-f64") { c.debug_f64 = true; a.i++; }
         else if (t == "--exact-dedup") { c.exact_dedup = true; a.i++; }
+        else if (t == "--gpus") { const std::string v = a.one(); c.gpus = v == "all" ? -1 : std::max(1, atoi(v.c_str())); }
         else if (t == "--debug" || t == "--trace" || t == "--log-reassignments") a.i++;
         else if (t[0] == '-' && t.size() > 1) throw Error{2, "unknown option " + t};
         else { c.files.push_back(t); a.i++; }

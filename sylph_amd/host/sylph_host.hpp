@@ -276,6 +276,7 @@ struct ContainCmdArgs : ContainArgs {   // cmdline.rs:88-160
     uint64_t k = 31, c = 200, min_spacing_kmer = 30;
     bool individual = false;
     bool exact_dedup = false;   // --exact-dedup: raw pairs are deduplicated with the exact marker set (the reference forces its cuckoo filter, contain.rs:591)
+    int gpus = 1;               // --gpus N|all (-1): raw samples are spread over N GPUs, each with a replica of the database (not in the reference: its rayon pool spans the machine by itself)
 };
 // a10: paired input is deduplicated as the reference does — behind its cuckoo filter for --fpr != 0
 // (the default; raw pairs in profile / query always: contain.rs:591) — unless the caller asks for the exact set: --exact-dedup,

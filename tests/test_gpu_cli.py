@@ -18,13 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "sylph_amd", "sylph-hip")
 
 
-def run(*args, check=True, accept_exact=True):
+def run(*args, check=True, accept_exact=True, env_extra=None):
     # (most tests here compare with the oracle's EXACT pair set: SYLPH_HIP_EXACT_DEDUP=1 selects it whatever --fpr says; the
     #  reference's default — the filter — is test_paired_reads_are_deduplicated_as_the_reference_does_by_default's subject)
     env = dict(os.environ)
     env.pop("SYLPH_HIP_EXACT_DEDUP", None)
     if accept_exact:
         env["SYLPH_HIP_EXACT_DEDUP"] = "1"
+    env.update(env_extra or {})
     p = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
     if check:
         assert p.returncode == 0, p.stderr[-3000:]
@@ -501,3 +502,20 @@ def test_database_views_equal_copied_database(data):
             assert p.returncode == 0, p.stderr[-2000:]
             assert p.stdout == ref[cmd], (cmd, threads)
             assert "uploaded and indexed in" in p.stderr
+
+
+def test_profile_over_several_gpus_equals_one_gpu(data):
+    """Round 5: `--gpus N|all` — the database replicated (index copied device to device), sample threads dealt to the GPUs in turn, ONE
+    router pipeline (sylph_pipeline_create_multi) handing the samples back in input order: the TSV must be the one-GPU TSV, byte for
+    byte, for query and profile.  On the one-GPU box SYLPH_HIP_SHARE_GPUS=1 lets three replicas share device 0."""
+    d = data["dir"]
+    g = data["genomes"]
+    order = ["EC590", "K12", "O157", "rand"]
+    gen = [g[n][0] for n in order]
+    raw = ["-1", d / "s_1.fq", d / "s_1.fq", d / "s_1.fq", "-2", d / "s_2.fq", d / "s_2.fq", d / "s_2.fq", "-r", d / "single.fastq.gz", d / "single.fastq.gz"]
+    for cmd in ("profile", "query"):
+        one = run(cmd, *gen, *raw, "-t", "3")
+        many = run(cmd, *gen, *raw, "-t", "3", "--gpus", "3", env_extra={"SYLPH_HIP_SHARE_GPUS": "1"})
+        assert "replicated on 3 GPUs" in many.stderr
+        assert one.stdout == many.stdout and len(one.stdout.strip().split("\n")) >= 6
+        assert run(cmd, *gen, *raw, "--gpus", "all").stdout == one.stdout

@@ -237,3 +237,64 @@ def test_bench_two_ranks_genome_sharded_arm():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["mode"] == "sequential"
     assert d["verify"]["mismatches"] == 0 and d["verify"]["genomes_checked"] > 0 and d["verify"]["genomes_with_hits"] > 0
     assert "sharded by GENOME" in d["config"]["parallelism"]
+
+
+def test_one_sample_loop_over_several_replicas_of_the_database(ctx):
+    """Round 5: sylph_db_replicate + sylph_pipeline_create_multi — ONE submit / next queue over N replicas of the database (one per GPU
+    of a node; here, on the one-GPU box, two contexts of device 0).  Device batches and sessions go to a replica on their device, host
+    batches to the least busy one; the results come back in SUBMISSION order whichever replica had them, each equal to the oracle's;
+    the replicas answer a direct probe like the original (kept + tracked index copied device to device)."""
+    import torch
+    rng, genomes, db_k, goff = small_world(23)
+    db = S.Database(ctx, db_k, goff)
+    ctx2, ctx3 = S.Context(0), S.Context(0)
+    reps = [db, db.replicate(ctx2), db.replicate(ctx3)]
+    assert all(r.n_genomes == db.n_genomes and r.n_kmers == db.n_kmers for r in reps)
+    samples = []
+    for i in range(13):
+        b, off = sample_reads(rng, genomes, [i % 5, (i * 3 + 1) % 5][: 1 + i % 2], 300 + 120 * (i % 4))
+        samples.append((b, off, O.sketch_reads(b, off, c=50, paired=True)))
+    # a replica probed directly gives what the original gives
+    e0 = samples[0][2]
+    for r in reps[1:]:
+        cc, coff, covs = r.contain(e0["kmers"], e0["counts"])
+        cc0, coff0, covs0 = db.contain(e0["kmers"], e0["counts"])
+        assert np.array_equal(cc, cc0) and np.array_equal(coff, coff0) and np.array_equal(covs, covs0)
+    dev = [(torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()) for b, off, _ in samples]
+    torch.cuda.synchronize()
+    p = S.Pipeline(reps, c=50, paired=True, n_workers=2, depth=3, max_batch=4, want_table=True)
+    used = set()
+    submitted = done = 0
+    while done < len(samples):
+        while submitted < len(samples) and p.outstanding < 3 * len(reps):
+            b, off, _ = samples[submitted]
+            if submitted % 3 == 0:          # host memory: the least busy replica
+                ok = p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=submitted, mem=MEM_HOST)
+            elif submitted % 3 == 1:        # device memory: a replica on that device
+                ok = p.submit_device([(dev[submitted][0].data_ptr(), dev[submitted][1].data_ptr(), len(off) - 1, int(off[-1]))], tag=submitted)
+            else:                           # a session the caller pushed into (on a context of its own, device 0)
+                sk = S.ReadSketcher([ctx, ctx2, ctx3][submitted % 2], c=50, paired=True)
+                sk.push(b, off)
+                ok = p.submit_session(sk, tag=submitted)
+            assert ok
+            submitted += 1
+        r = p.next()
+        assert r["tag"] == done
+        used.add(r["replica"])
+        e = samples[done][2]
+        check_result(r, e, db_k, goff)
+        assert np.array_equal(r["kmers"], e["kmers"]) and np.array_equal(r["counts"], e["counts"])
+        done += 1
+    assert len(used) >= 2 and used <= {0, 1, 2}
+    with pytest.raises(S.SylphHipError):
+        p.next()
+    # every replica full: refused, not blocked
+    for i in range(3 * len(reps)):
+        b, off, _ = samples[i]
+        assert p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=i, mem=MEM_HOST)
+    b, off, _ = samples[0]
+    assert p.submit_device([(b.ctypes.data, off.ctypes.data, len(off) - 1, int(off[-1]))], tag=99, mem=MEM_HOST) is False
+    p.close()                               # (finishes what is outstanding)
+    for r in reps[1:]:
+        r.close()
+    db.close(); ctx2.close(); ctx3.close()
