@@ -113,14 +113,24 @@ struct Session {   // RAII
 
 }  // namespace
 
+// SYLPH_HIP_FEED_TRACE: "[sylph_hip t+123.4 ms] what" — milliseconds since this library was loaded (just behind the dynamic linker)
+static const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
+void trace_mark(const char* what) {
+    static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[sylph_hip t+%.1f ms] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count() * 1e3, what);
+}
+
 Engine::Engine(int dev) : device(dev) {
     init_ = std::thread([this] {
         try {
+            trace_mark("engine: bring-up begins");
             hip_check(sylph_ctx_create(device, nullptr, &ctx_), "sylph_ctx_create");
+            trace_mark("engine: context created (runtime initialised, stream, pinned page)");
             if (getenv("SYLPH_HIP_NO_WARMUP")) return;
             // (only the packed double buffers of the indexed feed: the 256 MB ASCII batch of the sequential reader is page-locked by
             //  its first add() — most commands never need it, and pinning it was 50 ms of every bring-up)
             batch.prealloc_packed();
+            trace_mark("engine: packed double buffers page-locked");
             // first use of a kernel loads its code object (~25 ms for the sketch kernels): do it here, with a few dummy pairs
             sylph_sketch* sk = nullptr;
             hip_check(sylph_sketch_begin(ctx_, 200, 31, SYLPH_READS_PAIRED, 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
@@ -134,6 +144,7 @@ Engine::Engine(int dev) : device(dev) {
             sylph_free(k); sylph_free(c);
             sylph_sketch_destroy(sk);
             if (rc) hip_check(rc, "warm-up");
+            trace_mark("engine: sketch kernels loaded (warm-up sample done)");
         } catch (const Error& e) { init_error_ = e.msg; init_code_ = e.code ? e.code : 1; }
     });
 }
@@ -607,6 +618,7 @@ int sketch(Engine& e, const SketchArgs& args) {
     set_feed_budget(4 * n_workers);            // two files per sample, the current and the next sample of every worker
     auto run_job = [&](Engine& eng, size_t j) {
         std::optional<IndexedInput> pre = ahead.get(j);
+        trace_mark("sketch: the sample's files are indexed (or not indexable)");
         ahead.start(j + n_workers);
         const auto t_job = std::chrono::steady_clock::now();
         auto timing = [&](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
@@ -625,7 +637,9 @@ int sketch(Engine& e, const SketchArgs& args) {
             if (!sk) return;
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
+            trace_mark("sketch: the pair is sketched (table on the host)");
             write_sylsp(path, *sk);
+            trace_mark("sketch: .sylsp written");
             info("Sketching " + path + " complete.");
             timing(*sk, first_pairs[j]);
         } else {                                                             // :369-420

@@ -127,6 +127,7 @@ int run_inspect(Argv a) {   // cmdline.rs:166-173; no GPU involved
 }  // namespace
 
 int main(int argc, char** argv) {
+    trace_mark("main()");
     if (argc < 2) { fprintf(stderr, "usage: sylph-hip <sketch|profile|query|inspect> ...\n"); return 2; }
     try {
         const std::string cmd = argv[1];

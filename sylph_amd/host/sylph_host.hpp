@@ -204,6 +204,7 @@ bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109
 
 // ---- sketching (GPU through the C ABI) ----
+void trace_mark(const char* what);   // SYLPH_HIP_FEED_TRACE: a line with the milliseconds since the host library was loaded
 struct Engine {   // one GPU context shared by the drivers
     int device = -1;
     PinnedBatch batch;   // reused by every sample sketched through this engine
