@@ -220,30 +220,36 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(bases, rec_off, n_pairs, read_len, c, k, db_host, whole):
-    """Oracle (C++ restatement of the reference CPU path) on this box's host cores.  whole: the WHOLE sample (every read pair on one
+def cpu_baseline(bases, rec_off, n_records, paired, c, k, db_host, whole):
+    """Oracle (C++ restatement of the reference CPU path) on this box's host cores.  whole: the WHOLE sample (every read on one
     thread — the reference sketches one sample per thread, sketch.rs:313,371 — and every genome of the database on all threads,
     contain.rs:284): nothing extrapolated, and the results double as the full-size parity check (verify).  Otherwise a bounded
-    sample, extrapolated (boxes without the host memory for the genome-major database)."""
+    sample, extrapolated (boxes without the host memory for the genome-major database).  Reads of any shape: `bases` / `rec_off` are
+    the sample's device arrays (pairs interleaved mate 1, mate 2; long reads single-end)."""
     from oracle import oracle as O
     cores = effective_cpus()                       # (threads beyond the container's CPU quota only get the whole process throttled)
-    n_s = n_pairs if whole else min(n_pairs, 2_000_000)
-    hb = bases[: n_s * 2 * read_len].cpu().numpy()
-    ho = rec_off[: 2 * n_s + 1].cpu().numpy().astype(np.uint64)
+    n_s = n_records
+    if not whole:                                  # about 600 Mbp from the front of the sample (whole pairs)
+        n_s = int(torch.searchsorted(rec_off, torch.tensor([600_000_000], dtype=rec_off.dtype, device=rec_off.device)).item())
+        n_s = max(2, min(n_records, n_s)) & ~1
+    ho = rec_off[: n_s + 1].cpu().numpy().astype(np.uint64)
+    nb = int(ho[-1])
+    hb = bases[:nb].cpu().numpy()
     mode = O.MODE_AVX2_FAST if O.lib().orc_has_avx2() else O.MODE_SCALAR
     t = time.perf_counter()
-    sk = O.sketch_reads(hb, ho, c=c, k=k, mode=mode, paired=True)
+    sk = O.sketch_reads(hb, ho, c=c, k=k, mode=mode, paired=paired)
     t_sketch = time.perf_counter() - t
-    sketch_gbps = n_s * 2 * read_len / t_sketch / 1e9          # one sample = one thread in the reference (sketch.rs:313,371)
+    sketch_gbps = nb / t_sketch / 1e9                           # one sample = one thread in the reference (sketch.rs:313,371)
     dbk, dbo = db_host
     ls = O.LoadedSample(sk["kmers"], sk["counts"])
     cc, cov, t_probe = ls.probe(dbk, dbo, n_threads=cores)      # genomes in parallel on all cores (contain.rs:284)
     ls.close()
     G = len(dbo) - 1
-    what = (f"the WHOLE sample: {n_s} read pairs ({n_s * 2 * read_len / 1e6:.0f} Mbp) sketched on 1 thread in {t_sketch:.2f} s "
+    shape = f"{n_s // 2} read pairs" if paired else f"{n_s} reads"
+    what = (f"the WHOLE sample: {shape} ({nb / 1e6:.0f} Mbp) sketched on 1 thread in {t_sketch:.2f} s "
             f"({'AVX2 intrinsics' if mode == O.MODE_AVX2_FAST else 'scalar'}), its {len(sk['kmers'])}-entry table probed against all {G} genomes "
             f"({len(dbk) / 1e6:.0f} M k-mers) on {cores} threads in {t_probe:.2f} s; nothing extrapolated") if whole else (
-            f"sketch: first {n_s} read pairs ({n_s * 2 * read_len / 1e6:.0f} Mbp of the sample) on 1 thread "
+            f"sketch: first {shape} ({nb / 1e6:.0f} Mbp of the sample) on 1 thread "
             f"({'AVX2 intrinsics' if mode == O.MODE_AVX2_FAST else 'scalar'}); probe: {G} of the genomes ({len(dbk) / 1e6:.0f} M k-mers) on {cores} "
             f"threads vs the {len(sk['kmers'])}-entry sample table; both rates EXTRAPOLATED linearly to the full workload")
     return dict(sketch_gbp_per_s=sketch_gbps, comparisons_per_s=G / t_probe, sketch_cores=1, probe_cores=cores, sample=what,
@@ -1006,7 +1012,7 @@ def main():
                 p_.close()
         except Exception as e:
             out["value_h2d_inclusive"] = {"error": str(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not long_mode and wl != "c3r":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import oracle as O  # noqa: F401  (cpu_baseline leg only)
             rs = read_sets[0]
@@ -1032,7 +1038,7 @@ def main():
             else:
                 db_host = (dk_h, doff_h)
             del dk_h
-            cb = cpu_baseline(rs["bases"], rs["rec_off"], n_pairs, read_len, c, k, db_host, whole)
+            cb = cpu_baseline(rs["bases"], rs["rec_off"], rs["n_records"], not long_mode, c_reads, k, db_host, whole)
             t_cpu = n_bases / 1e9 / cb["sketch_gbp_per_s"] + n_total / cb["comparisons_per_s"]
             out["cpu_baseline"] = {"value": round(n_bases / 1e9 / t_cpu, 4), "unit": "Gbp/s", "cores": cb["probe_cores"], "host_hardware_threads": os.cpu_count(), "kind": "port",
                                    "sample": cb["sample"], "sketch_gbp_per_s": round(cb["sketch_gbp_per_s"], 4),
@@ -1063,7 +1069,7 @@ def main():
                 out["verify"] = {"genomes_checked": int(n_total), "genomes_with_hits": int(len(hit_g)), "hits_checked": int(ecc.sum()),
                                  "mismatches": int(bad), "sample_table_entries": int(nt_g), "sample_table_equal": table_ok,
                                  "what": "the whole sample at full size: the GPU's (k-mer, count) table and duplicate count vs the oracle's sketch of the "
-                                         "same 1 Gbp read set; contain_count of EVERY genome of the database and the sorted coverage vector of every "
+                                         f"same {n_bases / 1e9:.0f} Gbp read set; contain_count of EVERY genome of the database and the sorted coverage vector of every "
                                          "genome with hits vs the oracle's probe of that table"}
                 if not table_ok:
                     out["verify"]["mismatches"] = int(bad) + 1

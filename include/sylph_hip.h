@@ -105,8 +105,10 @@ void sylph_upload_destroy(sylph_upload *u);
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);
 
 /* Per-kernel timing (hipEvent pairs on the ctx stream around every launch of the named kernel family) for
- * bench.py's roofline object.  enable=1 starts collecting and clears the totals. Families: "seeds", "compact",
- * "annotate", "sort", "replay", "probe", "db_index". */
+ * bench.py's roofline object.  enable=1 starts collecting and clears the totals.  Families (time + launches): "seeds", "compact",
+ * "annotate", "sort" (the bucket partition), "replay", "a10" (the filter dedup's passes), "probe", "assemble" (hits -> result rows),
+ * "exchange", "db_index", "genome_filter", "seeds_spill", "replay_overflow"; counters only (launches = how often that road was
+ * taken; the tests read them): "deferred", "deferred_redo", "a10_part", "a10_redo". */
 int sylph_ctx_profile(sylph_ctx *ctx, int enable);
 int sylph_ctx_kernel_stats(sylph_ctx *ctx, const char *family, double *total_ms, uint64_t *launches);
 

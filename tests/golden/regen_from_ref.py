@@ -88,6 +88,24 @@ def run(args, cwd):
     return p.stdout
 
 
+def copy_crate_sources():
+    """The source of the cuckoo filter crate cargo fetched for the build (~/.cargo/registry/src/*/scalable_cuckoo_filter-0.2.4) ->
+    oracle/_ref/crate_src/ (git-ignored like the rest of oracle/_ref: reference material for the checker, never product source).
+    tests/test_ref_binary.py::test_filter_model_against_crate_source reads it: fingerprint width, bucket count, hash derivation and —
+    the one assumption of the model that changes results for samples above ~1.3 Gbp — WHEN a filter is declared full."""
+    import glob
+    import shutil
+    home = os.environ.get("CARGO_HOME", os.path.join(os.path.expanduser("~"), ".cargo"))
+    hits = sorted(glob.glob(os.path.join(home, "registry", "src", "*", "scalable_cuckoo_filter-0.2.4")))
+    if not hits:
+        print("crate sources not found under " + home + " (vendored build?): the model stays unchecked against them", file=sys.stderr)
+        return
+    dst = os.path.join(ROOT, "oracle", "_ref", "crate_src", "scalable_cuckoo_filter-0.2.4")
+    shutil.rmtree(dst, ignore_errors=True)
+    shutil.copytree(os.path.join(hits[-1], "src"), dst)
+    print(f"copied {hits[-1]}/src -> {dst}")
+
+
 def main():
     if not os.path.exists(BIN):
         print(f"{BIN} does not exist: run oracle/ref_build.sh on a box with cargo first", file=sys.stderr)
@@ -101,6 +119,13 @@ def main():
         run(["sketch", "-r", os.path.join(tf, "k12_R1.fq"), "-d", os.path.join(d, "se"), "-c", "200", "-k", "31"], d)
         pe = read_sylsp(os.path.join(d, "pe", "k12_R1.fq.paired.sylsp"))
         se = read_sylsp(os.path.join(d, "se", "k12_R1.fq.sylsp"))
+        # round 5: the reference's DEFAULT for pairs — dup_removal_lsh_full behind scalable_cuckoo_filter 0.2.4 (sketch.rs:733-769, :796-804) —
+        # at its default --fpr and at a leaky one (false positives that show).  The oracle's model of that crate has its own hash bits
+        # (the crate is not in the reference tree): these vectors say how far the model is from the real filter, they pin nothing yet.
+        pe_def = {}
+        for tag, extra in (("fpr_default", []), ("fpr_0.02", ["--fpr", "0.02"])):
+            run(["sketch", "-1", os.path.join(tf, "k12_R1.fq"), "-2", os.path.join(tf, "k12_R2.fq"), "-d", os.path.join(d, tag), "-c", "200", "-k", "31"] + extra, d)
+            pe_def[tag] = read_sylsp(os.path.join(d, tag, "k12_R1.fq.paired.sylsp"))
         prof = run(["profile", os.path.join(d, "db.syldb"), os.path.join(d, "pe", "k12_R1.fq.paired.sylsp"), os.path.join(d, "se", "k12_R1.fq.sylsp"), "-t", "2"], d)
         query = run(["query", os.path.join(d, "db.syldb"), os.path.join(d, "pe", "k12_R1.fq.paired.sylsp"), "-t", "2"], d)
     arrays = {"version": np.array(subprocess.run([BIN, "--version"], stdout=subprocess.PIPE, text=True).stdout.strip()),
@@ -113,7 +138,10 @@ def main():
     for name, s in (("pe", pe), ("se", se)):
         arrays[f"{name}_kmers"], arrays[f"{name}_counts"] = s["kmers"], s["counts"]
         arrays[f"{name}_mean_read_length"] = np.array(s["mean_read_length"])
+    for tag, s in pe_def.items():
+        arrays[f"pe_{tag}_kmers"], arrays[f"pe_{tag}_counts"] = s["kmers"], s["counts"]
     np.savez_compressed(OUT, **arrays)
+    copy_crate_sources()
     print(f"wrote {OUT}: {len(db)} genome sketches, {len(pe['kmers'])} / {len(se['kmers'])} read-sketch entries")
     return 0
 

@@ -55,3 +55,55 @@ def test_oracle_equals_reference_binary_vectors():
     se = O.sketch_reads(b, o, c=200, k=31, paired=False)
     assert np.array_equal(se["kmers"], v["se_kmers"]) and np.array_equal(se["counts"], v["se_counts"])
     assert abs(se["mean_read_length"] - float(v["se_mean_read_length"])) < 1e-9
+
+
+def test_default_flag_pair_sketches_vs_the_filter_model():
+    """The reference's default pair dedup runs behind scalable_cuckoo_filter 0.2.4; the oracle models that crate with hash bits of its
+    own.  With the reference's vectors at hand this says how far apart they are: the tables must hold the same k-mers (the filter only
+    decides counts), and the duplicate totals may differ by the false positives only — an EXACT match is expected only once the model's
+    hash derivation has been aligned with the crate's (test_filter_model_against_crate_source names what to look at)."""
+    if not os.path.exists(VEC):
+        pytest.skip("tests/golden/ref_binary_vectors.npz does not exist")
+    v = np.load(VEC)
+    if "pe_fpr_default_kmers" not in v:
+        pytest.skip("vectors from before round 5: no default-flag pair sketches in them")
+    if not os.path.isdir(os.path.join(REF, "test_files")):
+        pytest.skip("the reference's test_files are not on this box")
+    from oracle import oracle as O
+    tf = os.path.join(REF, "test_files")
+    seqs = lambda rs: [r[1] if isinstance(r, tuple) else r for r in rs]   # noqa: E731
+    inter = [x for pair in zip(seqs(O.read_fastx(os.path.join(tf, "k12_R1.fq"))), seqs(O.read_fastx(os.path.join(tf, "k12_R2.fq")))) for x in pair]
+    b, o = O.concat(inter)
+    for tag, fpr in (("fpr_default", 1e-4), ("fpr_0.02", 0.02)):
+        m = O.sketch_reads_cuckoo_model(b, o, c=200, k=31, fpr=fpr)
+        assert np.array_equal(m["kmers"], v[f"pe_{tag}_kmers"]), tag                     # which k-mers: independent of the filter
+        diff = int(np.abs(m["counts"].astype(np.int64) - v[f"pe_{tag}_counts"].astype(np.int64)).sum())
+        total = int(v[f"pe_{tag}_counts"].astype(np.int64).sum())
+        assert diff <= max(4, int(4 * fpr * 2 * total)), (tag, diff, total)            # a few false positives either way, not a different rule
+
+
+def test_filter_model_against_crate_source():
+    """The model's free choices, checked against the crate's source when regen_from_ref.py could copy it (oracle/_ref/crate_src/).
+    Each assertion names the line of the model (oracle/sylph_oracle.cpp ScalableCuckoo / CuckooFilter; csrc/a10.hip filter_geometry) to
+    change when it fails.  The growth trigger is the one that matters for results: the model opens the next filter when a filter holds
+    `capacity` items; if the crate instead grows when an insertion was kicked out (near ~95 % load of its 4-entry buckets), paired samples
+    above ~1.3 Gbp open their second filter at different operations."""
+    import glob
+    import re
+    src_dir = os.path.join(ROOT, "oracle", "_ref", "crate_src", "scalable_cuckoo_filter-0.2.4")
+    files = sorted(glob.glob(os.path.join(src_dir, "**", "*.rs"), recursive=True))
+    if not files:
+        pytest.skip("no crate sources under oracle/_ref/crate_src (needs cargo + tests/golden/regen_from_ref.py)")
+    src = "\n".join(open(f, errors="replace").read() for f in files)
+    # 4 entries per bucket, fingerprint width = ceil(log2(1 / fpr) + log2(2 x entries per bucket)) = ceil(log2(1 / fpr) + 3)
+    assert re.search(r"entries_per_bucket\s*[:=]\s*4|DEFAULT_ENTRIES_PER_BUCKET\s*:\s*usize\s*=\s*4", src), "entries per bucket: CuckooFilter::init"
+    assert re.search(r"log2\(\)", src) and re.search(r"ceil\(\)", src), "fingerprint width: filter_geometry / CuckooFilter::init"
+    # a further filter of twice the capacity and 0.9 x the rate
+    assert re.search(r"0\.9", src), "tightening ratio of the false-positive probability: ScalableCuckoo::grow"
+    assert re.search(r"next_power_of_two", src), "bucket count = next power of two: CuckooFilter::init"
+    # the growth trigger
+    by_count = re.search(r"len\(\)\s*>=\s*self\.capacity|item_count\s*>=\s*self\.capacity|is_full", src) is not None
+    by_kick = re.search(r"is_nearly_full|kicked_out|exceptional", src) is not None
+    assert by_count and not by_kick, ("the crate declares a filter full " + ("when an insertion was kicked out" if by_kick else "by a rule this test does not recognise") +
+                                      ": align ScalableCuckoo::insert (oracle/sylph_oracle.cpp) and the phase cut of csrc/a10.hip with it")
+
