@@ -295,6 +295,17 @@ int sylph_shard_bounds(uint64_t max_kmer, uint32_t world, uint64_t *bounds);
 int sylph_db_upload_shard(sylph_ctx *ctx, const uint64_t *kmers, const uint64_t *genome_off, uint64_t n_genomes, int mem,
                           const uint64_t *bounds, uint32_t world, uint32_t rank, sylph_db **out);
 
+/* The other way to cut a database (round 5) — north_star's own wording: "sharded by genome", the reference's unit of parallelism
+ * (contain.rs:284 runs get_stats per genome on the rayon pool).  Rank r indexes ALL k-mers of the genomes [g_bounds[r], g_bounds[r+1])
+ * under their global ids (sylph_genome_shard_bounds: contiguous ranges holding ~1/world of the k-mers each; genome_off is a HOST array
+ * there).  sylph_db_contain_batch_sharded and the pipeline take such a database exactly like a k-mer-range one; inside, the table
+ * "slices" are whole tables (every rank probes every sample in full — the all-to-all of step 2 delivers what an all-gather of the
+ * tables would), the hits travel to their samples' owners as before.  Per-rank probe work grows with `world` here, which is why the
+ * k-mer-range cut is the default; both, and plain replicas (sylph_db_replicate), are there to be measured against each other. */
+int sylph_genome_shard_bounds(const uint64_t *genome_off, uint64_t n_genomes, uint32_t world, uint64_t *g_bounds);
+int sylph_db_upload_genome_shard(sylph_ctx *ctx, const uint64_t *kmers, const uint64_t *genome_off, uint64_t n_genomes, int mem,
+                                 const uint64_t *g_bounds, uint32_t world, uint32_t rank, sylph_db **out);
+
 /* Communicator = the collectives the exchange needs, on device buffers, enqueued on `stream` (a hipStream_t).
  * sylph_comm_create_rccl: RCCL (librccl.so resolved at run time: the copy already mapped into the process — e.g. PyTorch's
  * — or the ROCm one); `id` is the 128-byte ncclUniqueId made by sylph_comm_rccl_unique_id on rank 0 and handed to every rank

@@ -118,6 +118,10 @@ extern "C" {
     pub fn sylph_shard_bounds(max_kmer: u64, world: u32, bounds: *mut u64) -> c_int;
     pub fn sylph_db_upload_shard(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,
                                  bounds: *const u64, world: u32, rank: u32, out: *mut *mut SylphDb) -> c_int;
+    // round 5: the cut north_star words — whole genomes per rank (contain.rs:284's unit); same collective call, same pipeline
+    pub fn sylph_genome_shard_bounds(genome_off: *const u64, n_genomes: u64, world: u32, g_bounds: *mut u64) -> c_int;
+    pub fn sylph_db_upload_genome_shard(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,
+                                        g_bounds: *const u64, world: u32, rank: u32, out: *mut *mut SylphDb) -> c_int;
     pub fn sylph_comm_rccl_unique_id(id: *mut u8) -> c_int;                       // 128 bytes, made on rank 0
     pub fn sylph_comm_create_rccl(ctx: *mut SylphCtx, rank: u32, world: u32, id: *const u8, out: *mut *mut SylphComm) -> c_int;
     pub fn sylph_comm_create(rank: u32, world: u32, ops: *const SylphCommOps, user: *mut c_void, out: *mut *mut SylphComm) -> c_int;

@@ -34,7 +34,8 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_pipeline_outstanding", "sylph_pipeline_set_option", "sylph_pipeline_profile", "sylph_pipeline_kernel_stats",
            "sylph_pipeline_destroy", "sylph_db_exchange_stats", "sylph_sketch_set_option",
            "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_destroy",
-           "sylph_db_replicate", "sylph_pipeline_create_multi", "sylph_pipeline_replica_of_last", "sylph_device_count"]
+           "sylph_db_replicate", "sylph_pipeline_create_multi", "sylph_pipeline_replica_of_last", "sylph_device_count",
+           "sylph_genome_shard_bounds", "sylph_db_upload_genome_shard"]
 
 
 def load():
@@ -115,6 +116,8 @@ def load():
     L.sylph_pipeline_create_multi.argtypes = [vp, u32, vp, P(vp)]
     L.sylph_pipeline_replica_of_last.argtypes = [vp]
     L.sylph_device_count.restype = i32
+    L.sylph_genome_shard_bounds.argtypes = [vp, u64, u32, vp]
+    L.sylph_db_upload_genome_shard.argtypes = [vp, vp, vp, u64, i32, vp, u32, u32, P(vp)]
     _LIB = L
     return L
 
@@ -393,8 +396,9 @@ class Comm:
 class Database:
     """genome_kmers of many GenomeSketch resident in HBM + postings index; probe half of get_stats (contain.rs:601-656)."""
 
-    def __init__(self, ctx, kmers, genome_off, device_ptrs=False, n_genomes=None, shard=None):
-        """shard = (bounds[world + 1], world, rank): keep only the k-mers of this rank's range (sylph_db_upload_shard)."""
+    def __init__(self, ctx, kmers, genome_off, device_ptrs=False, n_genomes=None, shard=None, genome_shard=None):
+        """shard = (bounds[world + 1], world, rank): keep only the k-mers of this rank's range (sylph_db_upload_shard);
+        genome_shard = (g_bounds[world + 1], world, rank): keep the genomes [g_bounds[rank], g_bounds[rank + 1]) (sylph_db_upload_genome_shard)."""
         self.ctx = ctx
         self._h = C.c_void_p()
         if device_ptrs:
@@ -402,7 +406,11 @@ class Database:
         else:
             k, off = _np(kmers, np.uint64), _np(genome_off, np.uint64)
             kp, op, G, mem = (_ptr(k) if len(k) else None), _ptr(off), len(off) - 1, MEM_HOST
-        if shard is None:
+        if genome_shard is not None:
+            gb = _np(genome_shard[0], np.uint64)
+            assert len(gb) == genome_shard[1] + 1
+            _check(load().sylph_db_upload_genome_shard(ctx._h, kp, op, G, mem, _ptr(gb), genome_shard[1], genome_shard[2], C.byref(self._h)))
+        elif shard is None:
             _check(load().sylph_db_upload(ctx._h, kp, op, G, mem, C.byref(self._h)))
         else:
             b = _np(shard[0], np.uint64)

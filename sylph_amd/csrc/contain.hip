@@ -26,6 +26,7 @@
 #include <memory>
 
 #include "contain_index.h"
+#include "shard_plan.h"
 #include "device_common.h"
 
 namespace sylph {
@@ -874,8 +875,16 @@ static void index_genome_major(sylph_ctx* ctx, const uint64_t* d_kmers, const ui
     SY_HIP(hipStreamSynchronize(ctx->stream));
 }
 
+// off3[g] = clamp(off[g], a, b) - a: the offsets of the genome range whose k-mers lie in [a, b) of the genome-major array, every
+// other genome empty, ids unchanged
+__global__ __launch_bounds__(256) void clamp_offsets_kernel(const uint64_t* __restrict__ off, uint64_t n_entries, uint64_t a, uint64_t b,
+                                                            uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_entries) out[i] = min(max(off[i], a), b) - a;
+}
+
 static void db_upload_impl(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
-                           const uint64_t* bounds, uint32_t world, uint32_t rank, sylph_db** out) {
+                           const uint64_t* bounds, uint32_t world, uint32_t rank, sylph_db** out, const uint64_t* g_bounds = nullptr) {
     SY_REQUIRE(ctx && out, "null argument");
     SY_REQUIRE(mem == SYLPH_MEM_HOST || mem == SYLPH_MEM_DEVICE, "bad mem kind %d", mem);
     SY_REQUIRE(n_genomes < (1ull << 30), "at most 2^30-1 genomes per shard");
@@ -907,6 +916,31 @@ static void db_upload_impl(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t
         ctx->read_back(&min_len, d_min, 4);
     }
     db->min_glen = min_len;
+    if (g_bounds) {
+        // shard by GENOME: all k-mers of the genomes [g0, g1), global genome ids, the lengths of ALL genomes (contain.rs:627 looks at
+        // the whole genome); the exchange treats every table as one slice for every shard (shard_plan.h Meta::whole)
+        db->by_genome = true;
+        db->g_bounds.assign(g_bounds, g_bounds + world + 1);
+        SY_REQUIRE(db->g_bounds[0] == 0 && db->g_bounds[world] == n_genomes, "genome bounds must run from 0 to n_genomes");
+        for (uint32_t r = 0; r < world; r++) SY_REQUIRE(db->g_bounds[r] <= db->g_bounds[r + 1], "genome bounds must be non-decreasing");
+        db->bounds.assign((size_t)world + 1, UINT64_MAX);
+        db->bounds[0] = 0;
+        const uint64_t g0 = db->g_bounds[rank], g1 = db->g_bounds[rank + 1];
+        uint64_t ab[2] = {0, 0};
+        if (n_genomes) { ctx->read_back(&ab[0], d_off + g0, 8); ctx->read_back(&ab[1], d_off + g1, 8); }
+        if (ab[1] > ab[0]) {
+            DevBuf d_off3(ctx);
+            d_off3.reserve((n_genomes + 1) * 8);
+            hipLaunchKernelGGL(clamp_offsets_kernel, dim3(grid_for64(n_genomes + 1)), dim3(256), 0, ctx->stream, d_off, n_genomes + 1, ab[0], ab[1],
+                               d_off3.as<uint64_t>());
+            SY_HIP(hipGetLastError());
+            index_genome_major(ctx, d_kmers_in + ab[0], d_off3.as<uint64_t>(), n_genomes, ab[1] - ab[0], 0, 0, db->kept);
+        }
+        db->n_kmers = db->kept.n_postings;
+        ctx->refs++;
+        *out = db.release();
+        return;
+    }
     const uint64_t lo = bounds ? db->bounds[rank] : 0, hi = bounds ? db->bounds[rank + 1] : 0;
     const bool last = !bounds || rank + 1 == world;   // the last shard is open-ended (hi == 0 means "no upper bound" in the build)
     if (last || hi > lo) index_genome_major(ctx, d_kmers_in, d_off, n_genomes, n, lo, last ? 0 : hi, db->kept);
@@ -1049,6 +1083,21 @@ int sylph_db_upload_shard(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t*
     return guarded([&] {
         SY_REQUIRE(bounds, "null bounds");
         db_upload_impl(ctx, kmers, genome_off, n_genomes, mem, bounds, world, rank, out);
+    });
+}
+
+int sylph_genome_shard_bounds(const uint64_t* genome_off, uint64_t n_genomes, uint32_t world, uint64_t* g_bounds) {
+    return guarded([&] {
+        SY_REQUIRE(genome_off && g_bounds && world >= 1, "bad argument");
+        shardplan::genome_bounds(genome_off, n_genomes, world, g_bounds);
+    });
+}
+
+int sylph_db_upload_genome_shard(sylph_ctx* ctx, const uint64_t* kmers, const uint64_t* genome_off, uint64_t n_genomes, int mem,
+                                 const uint64_t* g_bounds, uint32_t world, uint32_t rank, sylph_db** out) {
+    return guarded([&] {
+        SY_REQUIRE(g_bounds, "null genome bounds");
+        db_upload_impl(ctx, kmers, genome_off, n_genomes, mem, nullptr, world, rank, out, g_bounds);
     });
 }
 

@@ -183,6 +183,10 @@ struct sylph_db {
     // k-mer-range sharding (sylph_db_upload_shard): this shard holds k-mers in [bounds[rank], bounds[rank + 1])
     std::vector<uint64_t> bounds;
     uint32_t world = 1, rank = 0;
+    // genome sharding (sylph_db_upload_genome_shard): this shard indexes ALL k-mers of the genomes [g_bounds[rank], g_bounds[rank + 1])
+    // under their global ids; `bounds` is then {0, ~0, .., ~0} — a table's slice for any shard is the whole table (shard_plan.h)
+    bool by_genome = false;
+    std::vector<uint64_t> g_bounds;
     uint64_t shard_hit_cap = 1ull << 20;     // hits per rank in the all-gathered block; doubles identically on every rank
     uint64_t x_batches = 0, x_table_bytes = 0, x_hit_bytes = 0;   // exchange totals (sylph_db_exchange_stats): batches, bytes sent to OTHER ranks
     sylph::DevBuf rank_of, ani, lost;        // reassign pass: rank[g] in the passing list (or ~0), ANI per rank, kmers_lost[g]

@@ -278,7 +278,7 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         SY_REQUIRE(n_local <= MAX_LOCAL, "at most %u samples per rank and batch", MAX_LOCAL);
         SY_REQUIRE(db->world == comm->world && db->rank == comm->rank, "database shard %u/%u does not match communicator rank %u/%u", db->rank,
                    db->world, comm->rank, comm->world);
-        SY_REQUIRE(db->bounds.size() == (size_t)db->world + 1, "database was not uploaded with sylph_db_upload_shard");
+        SY_REQUIRE(db->bounds.size() == (size_t)db->world + 1, "database was not uploaded with sylph_db_upload_shard / sylph_db_upload_genome_shard");
         SY_REQUIRE(comm->world <= MAX_WORLD, "at most %u ranks", MAX_WORLD);
         sylph_ctx* ctx = db->ctx;
         std::lock_guard<std::mutex> lock(ctx->mu);
@@ -342,9 +342,8 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         std::vector<uint64_t> meta((size_t)W * meta_words);
         ctx->d2h(meta.data(), d_gather, meta.size() * 8);
         // every offset below comes from shard_plan.h (the same arithmetic on every rank, from the same gathered block)
-        const shardplan::Meta pm{meta.data(), W};
+        const shardplan::Meta pm{meta.data(), W, db->by_genome ? 1 : 0};
         auto n_loc = [&](uint32_t r) { return pm.n_loc(r); };
-        auto split = [&](uint32_t r, uint32_t s, uint32_t j) { return pm.split(r, s, j); };
         const shardplan::SlicePlan sp = shardplan::plan_slices(pm, me, G);
         SY_REQUIRE(sp.error.empty(), "%s", sp.error.c_str());
         const std::vector<uint64_t>& prefix = sp.prefix;
@@ -363,7 +362,7 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
                 for (uint32_t s = 0; s < n_local; s++) {
                     const shardplan::SliceAt at = shardplan::slice_in_block(pm, me, s, d);
                     if (!at.len) continue;
-                    const uint64_t a = split(me, s, d);
+                    const uint64_t a = pm.slice_begin(me, s, d);
                     segs.push_back(Seg{reinterpret_cast<const uint32_t*>(mine[s].k + a), reinterpret_cast<uint32_t*>(blk + at.k_off), at.len * 2});
                     segs.push_back(Seg{mine[s].c + a, reinterpret_cast<uint32_t*>(blk + at.c_off), at.len});
                     max_words = std::max(max_words, at.len * 2);

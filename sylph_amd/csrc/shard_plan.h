@@ -41,13 +41,32 @@ SY_PLAN_HD uint32_t owner_of_sample(uint64_t s, const uint64_t* prefix, uint32_t
 // The all-gathered meta blocks: per rank [n_local | split[MAX_LOCAL][W + 1]] (u64), split[s][j] = first entry of the rank's sample s
 // whose k-mer is >= bounds[j].
 inline uint64_t meta_words(uint32_t W) { return 1 + (uint64_t)MAX_LOCAL * (W + 1); }
+// whole = 1: a database sharded by GENOME (sylph_db_upload_genome_shard; north_star's wording) — every rank probes every sample in
+// full, so the "slice" of a table for any destination is the whole table [split[0], split[W]) = [0, n): the all-to-all of the slices
+// then IS the all-gather of the tables, and everything downstream (probe, owners, hits, assembly) is the k-mer-range path's.
 struct Meta {
     const uint64_t* words;   // W blocks of meta_words(W)
     uint32_t W;
+    int whole = 0;
     uint32_t n_loc(uint32_t r) const { return (uint32_t)words[(size_t)r * meta_words(W)]; }
     uint64_t split(uint32_t r, uint32_t s, uint32_t j) const { return words[(size_t)r * meta_words(W) + 1 + (size_t)s * (W + 1) + j]; }
-    uint64_t slice_len(uint32_t r, uint32_t s, uint32_t d) const { return split(r, s, d + 1) - split(r, s, d); }   // entries of (rank r, sample s) for shard d
+    uint64_t slice_begin(uint32_t r, uint32_t s, uint32_t d) const { return split(r, s, whole ? 0 : d); }          // first entry of (rank r, sample s) that goes to shard d
+    uint64_t slice_len(uint32_t r, uint32_t s, uint32_t d) const { return whole ? split(r, s, W) - split(r, s, 0) : split(r, s, d + 1) - split(r, s, d); }   // entries of (rank r, sample s) for shard d
 };
+
+// Genome shards: contiguous genome ranges [g_bounds[r], g_bounds[r + 1]) holding about 1 / W of the database's k-mers each
+// (off: the genome-major offsets, G + 1 entries) — genomes are the reference's unit of parallelism (contain.rs:284).
+inline void genome_bounds(const uint64_t* off, uint64_t G, uint32_t W, uint64_t* g_bounds) {
+    const uint64_t total = off[G] - off[0];
+    g_bounds[0] = 0;
+    for (uint32_t r = 1; r < W; r++) {
+        const uint64_t target = off[0] + (uint64_t)((unsigned __int128)total * r / W);
+        uint64_t lo = 0, hi = G;                       // first genome whose start offset is >= target
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (off[mid] < target) lo = mid + 1; else hi = mid; }
+        g_bounds[r] = lo < g_bounds[r - 1] ? g_bounds[r - 1] : lo;
+    }
+    g_bounds[W] = G;
+}
 
 // Step 2: the all-to-all of the table slices.  Block (src -> dst) = [k-mers of slice (s, dst), s = 0.. | counts of the same slices | pad to 8].
 struct SlicePlan {

@@ -171,6 +171,16 @@ def model_contain_batch_sharded(dist, bounds, n_genomes, samples, probe_fn):
 # 8-GPU node (bench.py --db-mode genome); it is composed from the unsharded entry points + torch.distributed collectives (RCCL on
 # device tensors), not a second exchange inside the library.
 
+def genome_shard_bounds(genome_off, world):
+    """sylph_genome_shard_bounds: the library's own cut (csrc/shard_plan.h) -> world + 1 genome indices (uint64)."""
+    import ctypes as C
+    from .binding import _check, _np, _ptr, load
+    off = _np(genome_off, np.uint64)
+    out = np.zeros(world + 1, dtype=np.uint64)
+    _check(load().sylph_genome_shard_bounds(_ptr(off), len(off) - 1, world, _ptr(out)))
+    return out
+
+
 def genome_shard_ranges(genome_off, world):
     """Contiguous genome ranges [g0, g1) per rank, balanced by the number of k-mers: world + 1 boundaries."""
     off = np.asarray(genome_off, dtype=np.uint64)

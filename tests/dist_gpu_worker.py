@@ -36,9 +36,14 @@ def main():
     goff[1:] = np.cumsum([len(g) for g in genomes])
     G = len(genomes)
     ctx = S.Context(0)
-    bounds = S.shard_bounds(int(full.max()), world)
-    db = S.Database(ctx, full, goff, shard=(bounds, world, rank))
-    assert 0 < db.n_kmers < len(full)
+    if os.environ.get("SYLPH_TEST_SHARD_BY", "kmer") == "genome":       # round 5: the cut by genome (north_star's wording), same exchange
+        gb = SH.genome_shard_bounds(goff, world)
+        db = S.Database(ctx, full, goff, genome_shard=(gb, world, rank))
+        assert db.n_kmers == int(goff[int(gb[rank + 1])] - goff[int(gb[rank])]) and 0 < db.n_kmers < len(full)
+    else:
+        bounds = S.shard_bounds(int(full.max()), world)
+        db = S.Database(ctx, full, goff, shard=(bounds, world, rank))
+        assert 0 < db.n_kmers < len(full)
     comm = SH.torch_callback_comm(dist, dev)
     r2 = np.random.default_rng(100 + rank)
     for step in range(3):

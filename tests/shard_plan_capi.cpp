@@ -16,9 +16,13 @@ uint32_t sp_size_words(uint32_t W) { return size_words(W); }
 uint64_t sp_lower_bound(const uint64_t* k, uint64_t n, uint64_t key) { return lower_bound_u64(k, n, key); }
 uint32_t sp_owner(uint64_t s, const uint64_t* prefix, uint32_t W) { return owner_of_sample(s, prefix, W); }
 uint64_t sp_rebase(uint64_t hit, uint64_t first, uint64_t G) { return rebase_hit(hit, first, G); }
+static int g_whole = 0;                       // 1: genome shards (every slice is the whole table)
+void sp_set_whole(int whole) { g_whole = whole; }
+uint64_t sp_slice_begin(const uint64_t* meta, uint32_t W, uint32_t r, uint32_t s, uint32_t d) { return Meta{meta, W, g_whole}.slice_begin(r, s, d); }
+void sp_genome_bounds(const uint64_t* off, uint64_t G, uint32_t W, uint64_t* out) { genome_bounds(off, G, W, out); }
 int sp_plan_slices(const uint64_t* meta, uint32_t W, uint32_t me, uint64_t G, uint64_t* prefix, uint64_t* send_off, uint64_t* recv_off,
                    uint64_t* S_total, char* err, size_t errn) {
-    const SlicePlan p = plan_slices(Meta{meta, W}, me, G);
+    const SlicePlan p = plan_slices(Meta{meta, W, g_whole}, me, G);
     if (!p.error.empty()) { put_err(p.error, err, errn); return 1; }
     memcpy(prefix, p.prefix.data(), (W + 1) * 8);
     memcpy(send_off, p.send_off.data(), (W + 1) * 8);
@@ -27,7 +31,7 @@ int sp_plan_slices(const uint64_t* meta, uint32_t W, uint32_t me, uint64_t G, ui
     return 0;
 }
 void sp_slice_in_block(const uint64_t* meta, uint32_t W, uint32_t src, uint32_t s, uint32_t dst, uint64_t out[3]) {
-    const SliceAt a = slice_in_block(Meta{meta, W}, src, s, dst);
+    const SliceAt a = slice_in_block(Meta{meta, W, g_whole}, src, s, dst);
     out[0] = a.k_off; out[1] = a.c_off; out[2] = a.len;
 }
 int sp_plan_hits(const uint32_t* sizes, uint32_t W, uint32_t me, uint64_t* send_off, uint64_t* recv_off, uint32_t* start, uint32_t* max_mine,

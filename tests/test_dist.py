@@ -129,6 +129,10 @@ def _plan_lib():
     L.sp_plan_slices.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u64p, u64p, u64p, C.c_char_p, C.c_size_t]
     L.sp_slice_in_block.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p]
     L.sp_plan_hits.argtypes = [u32p, C.c_uint32, C.c_uint32, u64p, u64p, u32p, u32p, u64p, u32p, u32p, C.c_char_p, C.c_size_t]
+    L.sp_set_whole.argtypes = [C.c_int]
+    L.sp_slice_begin.restype = C.c_uint64
+    L.sp_slice_begin.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.sp_genome_bounds.argtypes = [u64p, C.c_uint64, C.c_uint32, u64p]
     return L
 
 
@@ -172,7 +176,7 @@ def library_plan_exchange(dist, L, bounds, G, samples, probe_fn, fail=False):
         for s, (k, c) in enumerate(samples):
             L.sp_slice_in_block(_p64(meta), W, me, s, d, _p64(at))
             ko, co, ln = int(at[0]), int(at[1]), int(at[2])
-            a = int(meta[me * mw + 1 + s * (W + 1) + d])
+            a = int(L.sp_slice_begin(_p64(meta), W, me, s, d))      # (k-mer ranges: split[s][d]; genome shards: 0 — the whole table)
             base = int(send_off[d])
             send[base + ko:base + ko + 8 * ln] = np.ascontiguousarray(k[a:a + ln], dtype=np.uint64).view(np.uint8)
             send[base + co:base + co + 4 * ln] = np.ascontiguousarray(c[a:a + ln], dtype=np.uint32).view(np.uint8)
@@ -279,6 +283,58 @@ def test_library_exchange_bookkeeping_gloo(world):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_plan_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert [ret.get(r) for r in range(world)] == [True] * world
+
+
+def genome_shard_probe(genomes, g0, g1, min_number_kmers=50.0):
+    """CPU stand-in for a GENOME shard (sylph_db_upload_genome_shard): all k-mers of the genomes [g0, g1), global ids."""
+    inner = shard_probe([g if g0 <= i < g1 else g[:0] for i, g in enumerate(genomes)], 0, 0, 0.0)
+    full_len = [len(g) for g in genomes]
+    return lambda k, c: [(g, x) for g, x in inner(k, c) if full_len[g] >= min_number_kmers]
+
+
+def _genome_plan_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = _plan_lib()
+        L.sp_set_whole(1)
+        pool, genomes = make_db()
+        G = len(genomes)
+        db = np.concatenate(genomes)
+        goff = np.zeros(G + 1, dtype=np.uint64)
+        goff[1:] = np.cumsum([len(g) for g in genomes])
+        gb = np.zeros(world + 1, dtype=np.uint64)
+        L.sp_genome_bounds(_p64(goff), G, world, _p64(gb))
+        ok = int(gb[0]) == 0 and int(gb[world]) == G and all(gb[i] <= gb[i + 1] for i in range(world))
+        per = [int(goff[int(gb[i + 1])] - goff[int(gb[i])]) for i in range(world)]
+        ok = ok and max(per) - min(per) <= 2 * 900                          # within a genome or two of each other
+        probe = genome_shard_probe(genomes, int(gb[rank]), int(gb[rank + 1]))
+        bounds = np.full(world + 1, np.iinfo(np.uint64).max, dtype=np.uint64)   # what the library sets for a genome shard: {0, ~0, ..}
+        bounds[0] = 0
+        for step, sizes in enumerate(([2, 3, 0], [0, 1, 4], [1, 1, 1])):
+            samples = make_samples(pool, rank + 3 * step, sizes[rank]) if step else make_samples(pool, rank, sizes[rank])
+            cc, covs = library_plan_exchange(dist, L, bounds, G, samples, probe)
+            ok = ok and cc.shape == (len(samples), G)
+            for s, (k, c) in enumerate(samples):
+                ecc, ecov, _ = O.contain(k, c, db, goff)
+                ok = ok and np.array_equal(cc[s], ecc) and all(np.array_equal(covs[s][g], np.sort(ecov[g])) for g in range(G))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_genome_shards_bookkeeping_gloo(world):
+    """Round 5: the database cut by GENOME inside the library (sylph_db_upload_genome_shard; north_star's wording) — the same exchange
+    with every table travelling whole to every shard (shard_plan.h Meta::whole) and the genome ranges of sylph_genome_shard_bounds: the
+    header's arithmetic rank against rank over gloo, every rank's own samples against the single-process oracle."""
+    _plan_lib()
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_genome_plan_worker, args=(world, port, ret), nprocs=world, join=True)
     assert [ret.get(r) for r in range(world)] == [True] * world
 
 

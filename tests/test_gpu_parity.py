@@ -858,6 +858,18 @@ def test_sharded_database_one_rank_over_rccl(ctx):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
     with pytest.raises(S.SylphHipError):
         d0.contain_batch_sharded(comm, samples)            # not a shard
+    # round 5: the one-rank "genome shard" (every genome) through the same call, the same RCCL communicator
+    from sylph_amd import shard as SH
+    gb = SH.genome_shard_bounds(goff, 1)
+    assert list(gb) == [0, len(goff) - 1]
+    d2 = S.Database(ctx, db, goff, genome_shard=(gb, 1, 0))
+    for subset in (samples, samples[1:]):
+        a = [x.copy() for x in d2.contain_batch_sharded(comm, subset)]
+        assert all(np.array_equal(x, y) for x, y in zip(a, d0.contain_batch(subset)))
+    gb3 = SH.genome_shard_bounds(goff, 3)
+    per = [int(goff[int(gb3[i + 1])] - goff[int(gb3[i])]) for i in range(3)]
+    assert gb3[0] == 0 and gb3[3] == len(goff) - 1 and max(per) - min(per) <= 2 * int(np.diff(goff.astype(np.int64)).max())
+    d2.close()
     d1.close(); d0.close(); comm.close()
 
 
@@ -1021,16 +1033,18 @@ def test_packed_input_and_chunked_host_pipeline(ctx):
         ctx.set_option("push_chunk_bytes", str(64 << 20))
 
 
-def test_sharded_containment_two_ranks_one_gpu():
-    """Two ranks (gloo rendezvous, both on cuda:0) run the library's k-mer-range sharded exchange (csrc/shard.hip) with the
-    collectives routed through torch.distributed callbacks, each with its own shard resident on the GPU, and check their own
-    samples against the oracle over the whole database."""
+@pytest.mark.parametrize("shard_by", ["kmer", "genome"])
+def test_sharded_containment_two_ranks_one_gpu(shard_by):
+    """Two ranks (gloo rendezvous, both on cuda:0) run the library's sharded exchange (csrc/shard.hip) with the collectives routed
+    through torch.distributed callbacks, each with its own shard resident on the GPU — cut by k-mer range, or (round 5) by genome:
+    sylph_db_upload_genome_shard, every table probed whole by every rank — and check their own samples against the oracle over the
+    whole database; a rank that fails between the collectives takes every rank out of the call."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "tests", "dist_gpu_worker.py")]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+           "--master-port", "29533" if shard_by == "kmer" else "29537", os.path.join(root, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, SYLPH_TEST_SHARD_BY=shard_by))
     assert out.returncode == 0 and "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
