@@ -21,15 +21,17 @@ decides before the timed region, all ranks agree):
   sequential  one sample at a time on one context: step latency, and every kernel alone on the GPU (`one_step_at_a_time`).
 
 Workloads (--workload): c3 = BASELINE configs[2], the configuration the metric is quoted on (default at N = 1: database on the
-one GPU); c4 = configs[3] (default at N > 1: 8 samples per GPU per probe batch, database sharded by k-mer range over the N GPUs,
-RCCL exchange inside sylph_db_contain_batch_sharded); c2 / c5 = configs[1] / [4]; c3r = c3 with ragged 35-151 bp reads and
-0.1 % N (reported beside c3, not instead of it).
+one GPU); c4 = configs[3] (default at N > 1: 8 samples per GPU per probe batch); c2 / c5 = configs[1] / [4]; c3r = c3 with ragged
+35-151 bp reads and 0.1 % N (reported beside c3, not instead of it).
 
-Multi-GPU: samples are independent units (no collective in the sketch stage).  --db-mode shard (default for
-N > 1, what north_star describes): every rank holds the postings of one k-mer range; per probe batch the library all-gathers the
-slice boundaries, sends every rank its 1/N slice of every table (all-to-all), probes, and sends every hit to the rank that
-owns its sample (a second all-to-all); --db-mode replicate: every rank holds the whole index (22-38 GB of 288 GB) and no data-path collective
-is needed at all.  scaling = weak (per-GPU work fixed).
+Multi-GPU: samples are independent units (the reference deals them to its rayon workers).  --db-mode replicate (default
+since round 5): every rank holds the whole index (29 GB of 288 GB), sketches and profiles its own samples, no data-path collective at
+all; --db-mode shard: every rank holds the postings of one k-mer range — per probe batch the library all-gathers the slice
+boundaries, sends every rank its 1/N slice of every table (all-to-all), probes, and sends every hit to the rank that owns its sample
+(a second all-to-all); --db-mode genome: north_star's wording — whole genomes per rank (sylph_db_upload_genome_shard), the same
+exchange with whole tables as slices (per-rank probe work grows with N: for the A/B).  scaling = weak (per-GPU work fixed).
+A single PROCESS over several GPUs (sylph_pipeline_create_multi, what `sylph-hip profile --gpus N` runs) is measured by
+tools/multi_gpu_pipeline_bench.py.
 
 After the timed region (untimed): --verify compares the containment results of one more sample, for the sequence-backed genomes
 + a sample of the decoys, against the CPU oracle on the same table; the CPU baseline leg (rank 0, N = 1) times the oracle — the
@@ -153,7 +155,11 @@ def build_database(ctx, device, wl, c, k, seed, rank, world, db_mode):
     if db_mode == "shard":      # every rank generated the same database and keeps the postings of its k-mer range
         bounds = S.shard_bounds((2**64 - 1) // c - 1, world)
         db = S.Database(ctx, kmers.data_ptr(), goff.data_ptr(), device_ptrs=True, n_genomes=n_total, shard=(bounds, world, rank))
-    elif db_mode == "genome":   # north_star's wording: whole genomes per rank (contiguous ranges balanced by k-mer count), an unsharded index each
+    elif db_mode == "genome":   # north_star's wording, inside the library (round 5): whole genomes per rank, global ids, the library's exchange
+        gb = SH.genome_shard_bounds(goff.cpu().numpy().astype(np.uint64), world)
+        genome_ranges = gb
+        db = S.Database(ctx, kmers.data_ptr(), goff.data_ptr(), device_ptrs=True, n_genomes=n_total, genome_shard=(gb, world, rank))
+    elif db_mode == "genome-py":   # the same cut composed OUTSIDE the library (round 4: unsharded index per rank + torch.distributed all-gathers)
         genome_ranges = SH.genome_shard_ranges(goff.cpu().numpy(), world)
         g0, g1 = int(genome_ranges[rank]), int(genome_ranges[rank + 1])
         k0 = int(goff[g0].item())
@@ -357,7 +363,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SYLPH_BENCH_WORKLOAD", "auto"), choices=["auto"] + sorted(WORKLOADS))
-    ap.add_argument("--db-mode", default=os.environ.get("SYLPH_BENCH_DB_MODE", "auto"), choices=["auto", "replicate", "shard", "genome"])
+    ap.add_argument("--db-mode", default=os.environ.get("SYLPH_BENCH_DB_MODE", "auto"), choices=["auto", "replicate", "shard", "genome", "genome-py"])
     ap.add_argument("--mode", default=os.environ.get("SYLPH_BENCH_MODE", "auto"), choices=["auto", "pipelined", "sequential"],
                     help="which way of running the samples `value` is taken from (auto: the faster one of the untimed calibration)")
     ap.add_argument("--min-seconds", type=float, default=float(os.environ.get("SYLPH_BENCH_MIN_SECONDS", "2.0")),
@@ -435,7 +441,10 @@ def main():
     for kv in ctx_options:
         ctx.set_option(*kv)
 
-    db_mode = args.db_mode if args.db_mode != "auto" else ("shard" if world > 1 else "replicate")
+    # auto = replicas (round 5): the samples are the independent units (the reference deals them to its rayon workers: contain.rs:252-295,
+    # sketch.rs:313,371), the 29 GB index fits every GPU, and no data-path collective is needed — `--db-mode shard` (k-mer ranges) and
+    # `--db-mode genome` (north_star's wording) run the library's exchange instead, for databases that do not fit and for the A/B
+    db_mode = args.db_mode if args.db_mode != "auto" else "replicate"
     log(f"[bench] building workload {wl} on {world} GPU(s), db {db_mode} ...")
     db, n_total, community, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
     comm, comm_kind, fallbacks = None, None, []
@@ -443,7 +452,7 @@ def main():
     def agreed_failure(failed):            # a rank that failed takes every rank down the same fallback
         return bool(agree(1 if failed else 0))
 
-    if db_mode == "shard":
+    if db_mode in ("shard", "genome"):
         if world == 1:      # the sharded code path with a one-rank RCCL communicator: the exchange's own cost, nothing on the wire
             comm, comm_kind = S.Comm(0, 1, ctx=ctx, rccl_id=S.Comm.rccl_unique_id()), "RCCL (one rank)"
         elif shared_gpu or dist.get_backend() != "nccl":
@@ -564,7 +573,7 @@ def main():
             refs = [(dk, dc, nt) for _, (dk, dc, nt, _) in sess]
             if comm is not None:
                 res = db.contain_batch_sharded(comm, refs, device_ptrs=True)
-            elif db_mode == "genome":
+            elif db_mode == "genome-py":
                 res = SH.contain_batch_genome_sharded(dist, db, np.array(dbstats["genome_ranges"]), refs, device)
             else:
                 res = db.contain_batch(refs, device_ptrs=True)      # borrowed pinned views
@@ -609,7 +618,7 @@ def main():
             db, n_total, _, dbstats, verify_set = build_database(ctx, device, wl, c, k, args.seed, rank, world, db_mode)
             pipe_box[0] = make_pipeline()
     run_sequential(2 * spb)
-    if db_mode != "genome":
+    if db_mode != "genome-py":
         run_pipelined(max(2 * depth, 2 * spb))
     torch.cuda.synchronize()
 
@@ -628,11 +637,11 @@ def main():
     n_cal = spb * int(min(400, max(2, round(0.25 / max(t_batch, 1e-6)))))
     cal = {"samples_per_mode": n_cal}
     for mode in ("pipelined", "sequential"):
-        if db_mode == "genome" and mode == "pipelined":
+        if db_mode == "genome-py" and mode == "pipelined":
             continue
         if args.mode in ("auto", mode) or not args.no_second_leg:
             cal[mode + "_ms_per_sample"] = round(measure(mode, n_cal) * 1e3, 4)
-    if db_mode == "genome":
+    if db_mode == "genome-py":
         mode = "sequential"          # the genome-sharded arm is a step-at-a-time composition (sylph_amd/shard.py), not a pipeline
     elif args.mode != "auto":
         mode = args.mode
@@ -681,7 +690,7 @@ def main():
         runners[mode](sps)
     elapsed, step_s, gaps, rows, fam = timed(mode, args.steps, sps)
     second = None
-    if not args.no_second_leg and db_mode != "genome":               # the same samples the other way, ~0.6 s of them
+    if not args.no_second_leg and db_mode != "genome-py":               # the same samples the other way, ~0.6 s of them
         n2 = max(spb, int(0.6 / max(cal.get(other + "_ms_per_sample", 1.5) * 1e-3, 1e-6) / spb) * spb)
         steps2 = max(1, min(args.steps, 4))
         per2 = max(spb, n2 // steps2 // spb * spb)
@@ -720,7 +729,7 @@ def main():
     # quarter of the bytes, no ASCII -> 2-bit conversion in the seeding kernel).  Reported beside `value`, never instead of it:
     # SURVEY 8d's 1.085 B/base is the ASCII input.
     packed_leg = None
-    if not args.no_packed_leg and not long_mode and wl != "c3r" and comm is None and db_mode != "genome":
+    if not args.no_packed_leg and not long_mode and wl != "c3r" and comm is None and db_mode != "genome-py":
         try:
             packed_sets = []
             for rs in read_sets:
@@ -762,7 +771,7 @@ def main():
     # `value` stays on the exact set (sylph's --fpr 0): the filter's hash bits are this repository's model of a crate that is not in
     # the reference tree, so only the exact set is pinned to the reference's own arithmetic.  Reported beside it.
     filter_leg = None
-    if not args.no_filter_leg and not long_mode and comm is None and db_mode != "genome":
+    if not args.no_filter_leg and not long_mode and comm is None and db_mode != "genome-py":
         try:
             def with_filter(on):
                 pipe_box[0].set_option("dedup_fpr", "1e-4" if on else "0")
@@ -806,9 +815,11 @@ def main():
                    ("sharded by GENOME over the GPUs (contiguous ranges balanced by k-mer count, an unsharded index each): every table all-gathered to "
                     "every rank and probed there, ONE all-gather of contain_count[S, G/W] + one of the coverage values (torch.distributed on "
                     f"{'device tensors (RCCL)' if (dist is not None and dist.get_backend() == 'nccl') else 'host copies'}; sylph_amd/shard.py)"
-                    if db_mode == "genome" else
-                    f"sharded by k-mer range over {world} GPUs (per probe batch: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
-                    f"{comm_kind})"
+                    if db_mode == "genome-py" else
+                    (f"sharded by GENOME over {world} GPUs inside the library (sylph_db_upload_genome_shard: contiguous genome ranges balanced by k-mer count, global ids; per probe "
+                     f"batch every table travels whole to every shard, hits all-to-all to the owners, two tiny all-gathers of sizes; {comm_kind})" if db_mode == "genome" else
+                     f"sharded by k-mer range over {world} GPUs (per probe batch: table slices all-to-all, hits all-to-all to the owners, two tiny all-gathers of sizes; "
+                     f"{comm_kind})")
                     if comm is not None else ("replicated on every GPU (no data-path collective)" if world > 1 else "on the one GPU")))
     out = {
         "metric": "read Gbp/s sketched + genome-comparisons/s profiled, 1 Gbp vs GTDB-R220",

@@ -1,6 +1,7 @@
 // commands.cpp — minimal restatement of the sketch / contain command drivers (sketch.rs:276-479, contain.rs:115-351)
 // around the GPU engine: parse records on the host, push batches through the C ABI, keep the sequential f64
 // bookkeeping here, run the statistics on the containment results, print the reference's TSV rows.
+#include <functional>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -115,43 +116,64 @@ struct Session {   // RAII
 
 // SYLPH_HIP_FEED_TRACE: "[sylph_hip t+123.4 ms] what" — milliseconds since this library was loaded (just behind the dynamic linker)
 static const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
+bool fast_exit() { static const bool f = getenv("SYLPH_HIP_CLEAN_EXIT") == nullptr; return f; }
 void trace_mark(const char* what) {
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[sylph_hip t+%.1f ms] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count() * 1e3, what);
 }
 
-Engine::Engine(int dev) : device(dev) {
+struct Engine::Gate { std::mutex mu; std::condition_variable cv; bool ready = false; };
+
+Engine::Engine(int dev) : device(dev), gate_(new Gate()) {
     init_ = std::thread([this] {
+        auto open_gate = [this] { { std::lock_guard<std::mutex> lk(gate_->mu); gate_->ready = true; } gate_->cv.notify_all(); };
         try {
             trace_mark("engine: bring-up begins");
             hip_check(sylph_ctx_create(device, nullptr, &ctx_), "sylph_ctx_create");
             trace_mark("engine: context created (runtime initialised, stream, pinned page)");
-            if (getenv("SYLPH_HIP_NO_WARMUP")) return;
-            // (only the packed double buffers of the indexed feed: the 256 MB ASCII batch of the sequential reader is page-locked by
-            //  its first add() — most commands never need it, and pinning it was 50 ms of every bring-up)
-            batch.prealloc_packed();
-            trace_mark("engine: packed double buffers page-locked");
-            // first use of a kernel loads its code object (~25 ms for the sketch kernels): do it here, with a few dummy pairs
+            if (getenv("SYLPH_HIP_NO_WARMUP")) { open_gate(); return; }
+            // first use of a kernel loads its code object (~25 ms for the sketch kernels, the filter dedup's included): do it here, with
+            // a few dummy pairs at a small c (so that the pairs really carry seeds and every kernel of a finish runs)
             sylph_sketch* sk = nullptr;
-            hip_check(sylph_sketch_begin(ctx_, 200, 31, SYLPH_READS_PAIRED, 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
+            hip_check(sylph_sketch_begin(ctx_, 5, 31, SYLPH_READS_PAIRED, 0, SYLPH_SEED_AVX2_COMPAT, &sk), "sylph_sketch_begin");
+            int rc = sylph_sketch_set_option(sk, "dedup_fpr", "0.0001");
             std::vector<uint8_t> b(8 * 150, 'A');
             for (size_t i = 0; i < b.size(); i++) b[i] = "ACGT"[(i * 2654435761u >> 7) & 3];
             std::vector<uint64_t> off(9);
             for (size_t i = 0; i < off.size(); i++) off[i] = i * 150;
             uint64_t* k = nullptr; uint32_t* c = nullptr; uint64_t n = 0, dup = 0;
-            const int rc = sylph_sketch_push(sk, b.data(), off.data(), 8, SYLPH_MEM_HOST) ||
-                           sylph_sketch_finish(sk, &k, &c, &n, &dup);
+            rc = rc || sylph_sketch_push(sk, b.data(), off.data(), 8, SYLPH_MEM_HOST) || sylph_sketch_finish(sk, &k, &c, &n, &dup);
             sylph_free(k); sylph_free(c);
             sylph_sketch_destroy(sk);
             if (rc) hip_check(rc, "warm-up");
             trace_mark("engine: sketch kernels loaded (warm-up sample done)");
-        } catch (const Error& e) { init_error_ = e.msg; init_code_ = e.code ? e.code : 1; }
+            open_gate();             // sessions may be opened from here on ...
+            // ... while the packed double buffers of the indexed feed are page-locked (~27 ms; round 5: BEHIND the gate — the first
+            // sample of a process travels from pageable memory it was gathered into during the bring-up: PinnedBatch::gather_packed_early).
+            // (Only these: the 256 MB ASCII batch of the sequential reader is page-locked by its first add() — most commands never need it.)
+            batch.prealloc_packed();
+            trace_mark("engine: packed double buffers page-locked");
+        } catch (const Error& e) { init_error_ = e.msg; init_code_ = e.code ? e.code : 1; open_gate(); }
     });
 }
+bool Engine::ready() const {
+    std::lock_guard<std::mutex> lk(gate_->mu);
+    return gate_->ready;
+}
 sylph_ctx* Engine::context() {
-    if (init_.joinable()) init_.join();
+    {
+        std::unique_lock<std::mutex> lk(gate_->mu);
+        gate_->cv.wait(lk, [&] { return gate_->ready; });
+    }
     if (init_code_) throw Error{init_code_, init_error_};
     return ctx_;
+}
+void Engine::wait_pinned() {
+    (void)context();
+    static std::mutex join_mu;                       // (sample threads share the command's first engine only through run_job: one joiner)
+    std::lock_guard<std::mutex> lk(join_mu);
+    if (init_.joinable()) init_.join();
+    if (init_code_) throw Error{init_code_, init_error_};
 }
 Engine::~Engine() {
     if (init_.joinable()) init_.join();
@@ -203,7 +225,10 @@ std::vector<std::pair<size_t, size_t>> cut_batches(size_t n, bool paired, const 
     }
     return out;
 }
-void sketch_indexed(Engine& e, sylph_sketch* sk, const IndexedInput& in, double& mean_read_length) {
+// open_session: creates the sample's session — it waits for the engine's context, so it is called as late as possible: whatever
+// batches can be gathered and packed before the context is up (the first sample of a process: ~0.15 s of idle parse threads otherwise)
+// are gathered into pageable memory first (round 5)
+void sketch_indexed(Engine& e, const std::function<sylph_sketch*()>& open_session, const IndexedInput& in, double& mean_read_length) {
     const unsigned T = parse_threads();
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -225,13 +250,32 @@ void sketch_indexed(Engine& e, sylph_sketch* sk, const IndexedInput& in, double&
     double mean = 0.;
     std::thread tm([&] { double counter = 0.; for (size_t i = 0; i < n; i++) { counter += 1.; mean = mean + ((double)a.seq_len[i] - mean) / counter; } });
     ThreadJoiner jm{tm};
+    const auto batches = cut_batches(n, b != nullptr, ca, cb);
+    size_t early = 0;
+    constexpr size_t MAX_EARLY = 16;                                     // 4 Gbp = 1 GB of packed bases in pageable memory at most
+    while (!e.ready() && early < batches.size() && early < MAX_EARLY) {
+        e.batch.gather_packed_early(a, b, ca, b ? &cb : nullptr, batches[early].first, batches[early].second, T);
+        early++;
+    }
+    if (early) lap("early batches: gather + pack (context still coming up)");
+    sylph_sketch* const sk = open_session();
     e.batch.flush(sk);
+    if (early) {
+        e.batch.push_early(sk);
+        if (early < batches.size()) {
+            a.release_behind(a.seq_off[batches[early].first]);
+            if (b) b->release_behind(b->seq_off[batches[early].first]);
+        }
+        lap("early batches: pushed");
+    }
     // Batches are gathered AND packed to 2 bits per base by the parse threads into one of two page-locked slots while the other
     // slot is on its way to the device: the push of batch i (PCIe + kernels) hides behind the gather of batch i + 1.
-    const auto batches = cut_batches(n, b != nullptr, ca, cb);
-    if (!batches.empty()) e.batch.gather_packed(0, a, b, ca, b ? &cb : nullptr, batches[0].first, batches[0].second, T);
-    lap("batch 0: gather + pack");
-    for (size_t bi = 0; bi < batches.size(); bi++) {
+    if (early < batches.size()) {
+        e.wait_pinned();
+        e.batch.gather_packed((int)(early & 1), a, b, ca, b ? &cb : nullptr, batches[early].first, batches[early].second, T);
+        lap("batch: gather + pack");
+    }
+    for (size_t bi = early; bi < batches.size(); bi++) {
         std::exception_ptr err;
         std::thread tg;
         ThreadJoiner jg{tg};
@@ -329,9 +373,10 @@ std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std
     std::optional<IndexedInput> own;
     if (!pre) { own = index_inputs(read_file, nullptr); pre = &own; }
     if (auto& in = *pre) {   // uncompressed 4-line FASTQ: block-parallel feed
-        Session s(e, c, k, false, no_dedup);
+        std::optional<Session> so;
         double mean = 0.;
-        sketch_indexed(e, s.sk, *in, mean);
+        sketch_indexed(e, [&] { so.emplace(e, c, k, false, no_dedup); return so->sk; }, *in, mean);
+        Session& s = *so;
         {
             SequencesSketch out;
             s.finish_or_keep(out, keep);
@@ -381,9 +426,10 @@ std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::
     std::optional<IndexedInput> own;
     if (!pre) { own = index_inputs(read_file1, &read_file2); pre = &own; }
     if (auto& in = *pre) {
-        Session s(e, c, k, true, no_dedup, dedup_fpr);
+        std::optional<Session> so;
         double mean = 0.;
-        sketch_indexed(e, s.sk, *in, mean);
+        sketch_indexed(e, [&] { so.emplace(e, c, k, true, no_dedup, dedup_fpr); return so->sk; }, *in, mean);
+        Session& s = *so;
         {
             SequencesSketch out;
             s.finish_or_keep(out, keep);
@@ -932,7 +978,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         hip_check(sylph_upload_finish(uo, &d_off), "sylph_upload_finish");
         hip_check(sylph_db_upload(e.context(), d_k, (const uint64_t*)d_off, genome_sketches.size(), SYLPH_MEM_DEVICE, &db), "sylph_db_upload");
     }
-    struct DbGuard { sylph_db* d; ~DbGuard() { sylph_db_destroy(d); } } guard{db};
+    struct DbGuard { sylph_db* d; ~DbGuard() { if (!fast_exit()) sylph_db_destroy(d); } } guard{db};   // (a 29 GB index is not freed block by block on the way to _exit)
     if (args.pseudotax) {   // the winner table also ranges over pseudotax_tracked_nonused_kmers (contain.rs:421-428)
         UploadGuard ug, og;
         std::vector<uint64_t> toff;
@@ -1065,7 +1111,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         int n_gpus = args.gpus < 0 ? sylph_device_count() : getenv("SYLPH_HIP_SHARE_GPUS") ? args.gpus : std::min(args.gpus, std::max(1, sylph_device_count()));
         n_gpus = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_gpus), n_raw));
         std::vector<std::unique_ptr<Engine>> replica_engines;            // (declared before the replicas: destroyed after them)
-        struct Replicas { std::vector<sylph_db*> v; ~Replicas() { for (size_t i = 1; i < v.size(); i++) sylph_db_destroy(v[i]); } } replicas;
+        struct Replicas { std::vector<sylph_db*> v; ~Replicas() { if (!fast_exit()) for (size_t i = 1; i < v.size(); i++) sylph_db_destroy(v[i]); } } replicas;
         std::vector<sylph_db*>& dbs = replicas.v;
         dbs.push_back(db);
         std::vector<int> replica_device{e.device};

@@ -114,25 +114,39 @@ ChunkStream::Kind ChunkStream::next(const uint8_t*& seq, uint32_t& len) {
 
 // ---- page-locked batch ---------------------------------------------------------------------------------------------
 PinnedBatch::PinnedBatch() {}
+void PinnedBatch::free_packed(Packed& p) {
+    if (p.pageable) { free(p.bytes); free(p.off); }
+    else { sylph_pinned_free(p.bytes); sylph_pinned_free(p.off); }
+    p = Packed{};
+}
 PinnedBatch::~PinnedBatch() {
     sylph_pinned_free(bases_);
     sylph_pinned_free(off_);
-    for (auto& p : pk_) { sylph_pinned_free(p.bytes); sylph_pinned_free(p.off); }
+    for (auto& p : pk_) free_packed(p);
+    for (auto& p : early_) free_packed(p);
 }
 
+// page-locked (the double-buffered slots: needs the GPU runtime) or pageable (the early batches of a process's first sample)
 void PinnedBatch::reserve_packed(Packed& p, size_t bytes, size_t recs) {
+    auto take = [&](size_t n) -> void* {
+        void* q = nullptr;
+        if (p.pageable) { if (posix_memalign(&q, 4096, (n + 4095) & ~(size_t)4095) != 0) throw Error{1, "out of host memory for a read batch"}; }
+        else if (sylph_pinned_alloc(n, &q) != SYLPH_OK) throw Error{1, std::string("sylph_pinned_alloc: ") + sylph_last_error()};
+        return q;
+    };
+    auto drop = [&](void* q) { if (p.pageable) free(q); else sylph_pinned_free(q); };
     if (bytes > p.cap_bytes) {
-        sylph_pinned_free(p.bytes);
+        drop(p.bytes);
         p.bytes = nullptr;
         p.cap_bytes = 0;
-        if (sylph_pinned_alloc(bytes, (void**)&p.bytes) != SYLPH_OK) throw Error{1, std::string("sylph_pinned_alloc: ") + sylph_last_error()};
+        p.bytes = (uint8_t*)take(bytes);
         p.cap_bytes = bytes;
     }
     if (recs > p.cap_recs) {
-        sylph_pinned_free(p.off);
+        drop(p.off);
         p.off = nullptr;
         p.cap_recs = 0;
-        if (sylph_pinned_alloc((recs + 1) * 8, (void**)&p.off) != SYLPH_OK) throw Error{1, std::string("sylph_pinned_alloc: ") + sylph_last_error()};
+        p.off = (uint64_t*)take((recs + 1) * 8);
         p.cap_recs = recs;
     }
 }
@@ -599,7 +613,27 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
 
 void PinnedBatch::gather_packed(int slot, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
                                 const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads) {
-    Packed& p = pk_[slot & 1];
+    gather_into(pk_[slot & 1], a, b, cum_a, cum_b, i0, i1, threads);
+}
+// The same into PAGEABLE memory, a batch of its own each time: nothing here needs the GPU runtime, so the first sample of a process is
+// gathered and packed while its context is still coming up (~0.2 s of runtime initialisation, during which the parse threads idled).
+void PinnedBatch::gather_packed_early(const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
+                                      const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads) {
+    early_.emplace_back();
+    early_.back().pageable = true;
+    gather_into(early_.back(), a, b, cum_a, cum_b, i0, i1, threads);
+}
+// the early batches go through the library's own staging buffers (SYLPH_MEM_HOST), in order, and are freed
+void PinnedBatch::push_early(sylph_sketch* sk) {
+    for (auto& p : early_) {
+        if (p.n_recs && sylph_sketch_push_enc(sk, p.bytes, p.off, p.n_recs, p.n_bases, SYLPH_MEM_HOST, SYLPH_ENC_2BIT) != SYLPH_OK)
+            throw Error{1, std::string("sylph_sketch_push: ") + sylph_last_error()};
+        free_packed(p);
+    }
+    early_.clear();
+}
+void PinnedBatch::gather_into(Packed& p, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a,
+                              const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads) {
     p.n_recs = p.n_bases = 0;
     if (i1 <= i0) return;
     const size_t n_items = i1 - i0, nrec = b ? 2 * n_items : n_items;

@@ -191,19 +191,29 @@ class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinne
                        const std::vector<uint64_t>* cum_b, size_t i0, size_t i1, unsigned threads);
     void push_packed(sylph_sketch* sk, int slot);
     void prealloc_packed();
+    // round 5: batches gathered + packed into PAGEABLE memory (no GPU runtime involved) while the context of a process's first sample
+    // is still coming up; push_early hands them over in order (SYLPH_MEM_HOST: the library's staging buffers) once there is a session
+    void gather_packed_early(const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a, const std::vector<uint64_t>* cum_b,
+                             size_t i0, size_t i1, unsigned threads);
+    void push_early(sylph_sketch* sk);
    private:
     void reserve(size_t bases_cap, size_t recs_cap);
     uint8_t* bases_ = nullptr;
     uint64_t* off_ = nullptr;
     size_t cap_bases_ = 0, cap_recs_ = 0, n_bases_ = 0, n_recs_ = 0;
-    struct Packed { uint8_t* bytes = nullptr; uint64_t* off = nullptr; size_t cap_bytes = 0, cap_recs = 0, n_bases = 0, n_recs = 0; };
+    struct Packed { uint8_t* bytes = nullptr; uint64_t* off = nullptr; size_t cap_bytes = 0, cap_recs = 0, n_bases = 0, n_recs = 0; bool pageable = false; };
     Packed pk_[2];
+    std::vector<Packed> early_;
     void reserve_packed(Packed& p, size_t bytes, size_t recs);
+    void free_packed(Packed& p);
+    void gather_into(Packed& p, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a, const std::vector<uint64_t>* cum_b,
+                     size_t i0, size_t i1, unsigned threads);
 };
 bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109
 
 // ---- sketching (GPU through the C ABI) ----
+bool fast_exit();                    // the command leaves through _exit once its outputs are written (not with SYLPH_HIP_CLEAN_EXIT=1): big device objects are not torn down first
 void trace_mark(const char* what);   // SYLPH_HIP_FEED_TRACE: a line with the milliseconds since the host library was loaded
 struct Engine {   // one GPU context shared by the drivers
     int device = -1;
@@ -213,12 +223,16 @@ struct Engine {   // one GPU context shared by the drivers
     // first input file; context() waits for it (and rethrows its error).
     explicit Engine(int device = -1);
     ~Engine();
-    sylph_ctx* context();
+    sylph_ctx* context();          // waits until the context exists and the sketch kernels are loaded
+    bool ready() const;            // context() would not block
+    void wait_pinned();            // ... and until the page-locked double buffers of `batch` are there (allocated behind `ready`)
    private:
     sylph_ctx* ctx_ = nullptr;
     std::thread init_;
     std::string init_error_;
     int init_code_ = 0;
+    struct Gate;                   // ready flag + condition variable
+    std::unique_ptr<Gate> gate_;
 };
 // sketch.rs:897 / :771 / :550 / :481 — return nullopt where the reference returns None (warn + skip).
 std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
