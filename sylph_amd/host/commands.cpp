@@ -662,9 +662,14 @@ int sketch(Engine& e, const SketchArgs& args) {
     for (const auto& r : read_inputs) job_files.push_back({r, std::nullopt});
     IndexAhead ahead(job_files);
     set_feed_budget(4 * n_workers);            // two files per sample, the current and the next sample of every worker
+    std::atomic<size_t> indexes_obtained{0};
+    set_no_more_inflates(false);
     auto run_job = [&](Engine& eng, size_t j) {
         std::optional<IndexedInput> pre = ahead.get(j);
         trace_mark("sketch: the sample's files are indexed (or not indexable)");
+        if (++indexes_obtained == n_jobs) set_no_more_inflates(true);   // nobody will want a recycled inflate buffer any more
+        // the index goes (2 x 1 GB of mappings to unmap / inflated copies to hand back: 30-60 ms per sample) on a thread of its own, behind the sample
+        struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) std::thread([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }).detach(); } } later{pre};
         ahead.start(j + n_workers);
         const auto t_job = std::chrono::steady_clock::now();
         auto timing = [&](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
@@ -1143,7 +1148,8 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         for (const auto& r : read_files) job_files.push_back({r[0], r.size() > 1 ? std::optional<std::string>(r[1]) : std::nullopt});
         IndexAhead ahead(job_files);
         set_feed_budget(4 * n_workers);
-        std::atomic<size_t> next_job{0}, released{0};
+        std::atomic<size_t> next_job{0}, released{0}, indexes_obtained{0};
+        set_no_more_inflates(false);
         std::atomic<bool> cancel{false};
         std::mutex gate_mu;
         std::condition_variable gate_cv;
@@ -1159,6 +1165,8 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                     fprintf(stderr, "ERROR [sylph_hip] %s -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.k, (unsigned long long)genome_k);
                 } else {
                     std::optional<IndexedInput> pre = ahead.get(j);
+                    if (++indexes_obtained == n_raw) set_no_more_inflates(true);
+                    struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) std::thread([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }).detach(); } } later{pre};
                     ahead.start(j + n_workers);
                     if (files.size() == 1) pr.meta = sketch_sequences_needle_impl(eng, files[0], args.c, args.k, std::nullopt, false, &pre, &pr.session);
                     else pr.meta = sketch_pair_sequences_impl(eng, files[0], files[1], args.c, args.k, std::nullopt, false, raw_pair_fpr, &pre, &pr.session);

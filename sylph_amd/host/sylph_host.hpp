@@ -119,6 +119,8 @@ struct FastqIndex {
     size_t map_bytes = 0;            // anonymous: what the mapping really spans (a recycled buffer may be larger than the file)
     bool anonymous = false;          // `data` is the inflated copy of a gzip file: it goes back to the buffer pool (inflated_release)
     void release_behind(size_t byte_offset) const;   // the feed is done with everything before byte_offset
+    mutable size_t released_ = 0;                    // bytes of an inflated copy already given back
+    mutable std::vector<std::thread> releasers_;     // ... by these threads (page freeing off the feed's critical path)
     std::vector<uint64_t> seq_off;   // byte offset of every record's sequence line
     std::vector<uint32_t> seq_len;
     std::vector<uint64_t> cum;       // cum[i] = sequence bases of records [0, i) (n_records + 1 entries)
@@ -150,6 +152,7 @@ constexpr size_t MAX_SAMPLE_THREADS = 16;        // each sample thread owns a GP
 // from MemAvailable and the number of files they index at the same time: beyond it the file goes to the sequential reader,
 // which runs in constant memory.
 void set_index_memory_budget(size_t bytes);
+void set_no_more_inflates(bool v);               // no further input file of the command will be inflated: inflated copies give their pages back as they are consumed
 size_t index_memory_budget();
 
 // BYTE_TO_SEQ + 2-bit packing into one part of a shared stream (pack2bit.cpp)
