@@ -30,7 +30,13 @@ namespace {
 // slower).  Larger buckets, and buckets that hold a deep k-mer (SEG_LIMIT), are queued for the CAP_MID / CAP_LARGE
 // configurations, which replace the scan over a k-mer's earlier occurrences by a hash table in LDS and are launched only
 // when something was queued; only beyond CAP_LARGE does a bucket take the device-wide path.
-constexpr int CAP_SMALL = 256, RTPB_SMALL = 128;
+#ifndef SYLPH_REPLAY_TPB
+#define SYLPH_REPLAY_TPB 128
+#endif
+#ifndef SYLPH_REPLAY_TAGS
+#define SYLPH_REPLAY_TAGS 1
+#endif
+constexpr int CAP_SMALL = 256, RTPB_SMALL = SYLPH_REPLAY_TPB;
 constexpr int CAP_MID = 512, RTPB_MID = 256;       // hashed marker test, ~31 KiB of LDS: 5 workgroups per CU
 constexpr int CAP_LARGE = 1024, RTPB_LARGE = 256;   // hashed marker test, ~59 KiB of LDS: 2 workgroups per CU
 constexpr int IDX_BITS = 10;         // arrival index inside a bucket (< CAP_LARGE)
@@ -39,6 +45,9 @@ constexpr int IDX_BITS = 10;         // arrival index inside a bucket (< CAP_LAR
 // configuration, whose marker test is a hash table in LDS: linear in the bucket size.
 constexpr uint32_t SEG_LIMIT = 96;
 
+
+// 15-bit tag of a dedup marker, never 0 (bit 0 set): what the scan over a k-mer's earlier occurrences compares first
+__device__ __forceinline__ uint32_t marker_tag(uint64_t m) { return (uint32_t)((m * 0x9E3779B97F4A7C15ull) >> 49) | 1u; }
 
 // One workgroup = one bucket.  SINGLE_CUTOFF = 4 for single-end (sketch.rs:937), 0 for pairs.
 //
@@ -70,7 +79,9 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
     __shared__ uint64_t s_hash[CAP], s_rid[CAP], s_m0[CAP], s_m1[CAP];
     __shared__ __attribute__((aligned(8))) uint16_t s_seg[CAP];   // first sorted position of the k-mer each sorted position belongs to
     __shared__ uint8_t s_fl[CAP];         // bit0 skip, bit1 would-be-dropped
-    __shared__ uint16_t s_a[CAP + 2], s_b[CAP + 2];   // exclusive counts <= CAP
+    __shared__ __attribute__((aligned(8))) uint16_t s_ab[2 * (CAP + 2)];   // exclusive counts <= CAP (s_a | s_b); before them: the marker tags
+    uint16_t* const s_a = s_ab;
+    uint16_t* const s_b = s_ab + (CAP + 2);
     __shared__ uint32_t s_wave[RTPB / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t nv = *p_nv;
@@ -384,6 +395,8 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             if (q != j && ((s_rid[q] >> RID_RANK_SHIFT) & RID_RANK_MAX) < rank_j) return false;
         return true;
     };
+    uint32_t* const s_tag = reinterpret_cast<uint32_t*>(s_ab);           // CAP words: fits the 2 x (CAP + 2) halfwords of s_a | s_b, which are written later
+    (void)s_tag;
     // ---- mate-2 skip (sketch.rs:852) and duplicate flags ----------------------------------------------------------
     for (uint32_t t = 0; t < items; t++) {
         const uint32_t j = j0 + t;
@@ -402,6 +415,10 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
             }
         }
         s_fl[j] = fl;
+#if SYLPH_REPLAY_TAGS
+        if constexpr (CAP == CAP_SMALL)
+            s_tag[j] = (!fl && (s_rid[j] & RID_MARKER_BIT)) ? (marker_tag(s_m0[j]) | (marker_tag(s_m1[j]) << 16)) : 0u;
+#endif
     }
     __syncthreads();
     uint32_t my_u = 0;
@@ -469,7 +486,25 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
                 if (!fl && (s_rid[j] & RID_MARKER_BIT) && (s_rid[j] & RID_A10_BIT) && !walk_first(j)) fl |= 2;
             } else if (!fl && !no_dedup && (s_rid[j] & RID_MARKER_BIT)) {
                 const uint64_t a = s_m0[j], bb = s_m1[j];
-                bool any_prev = false, hit = false;
+                bool hit = false;
+#if SYLPH_REPLAY_TAGS
+                // Round 5: the scan over the k-mer's earlier occurrences reads ONE 32-bit word per occurrence — two 15-bit tags of its
+                // markers, 0 for an occurrence that put nothing into the set (skipped mate 2, no markers) — and looks at the 16 bytes of
+                // markers only where a tag matches (a real duplicate, or 4 x 2^-15 by chance).  Before: flag byte + record id + both
+                // markers (25 bytes of LDS, four 64-bit compares) per earlier occurrence: the loop was a third of this kernel for a
+                // community with 30x genomes in it.  ("A processed occurrence precedes j" is "j is not the head": the head of a
+                // segment is never a skipped mate 2.)
+                const uint32_t ta = marker_tag(a) * 0x00010001u, tb = marker_tag(bb) * 0x00010001u;
+                for (uint32_t q = s_seg[j]; q < j; q++) {
+                    const uint32_t w = s_tag[q], za = w ^ ta, zb = w ^ tb;
+                    if ((((za - 0x00010001u) & ~za) | ((zb - 0x00010001u) & ~zb)) & 0x80008000u) {     // a zero halfword in either
+                        const uint64_t x = s_m0[q], y = s_m1[q];
+                        if (w && (x == a || y == a || x == bb || y == bb)) { hit = true; break; }
+                    }
+                }
+                if (j != (uint32_t)s_seg[j] && (hit || a == bb)) fl |= 2;
+#else
+                bool any_prev = false;
                 for (uint32_t q = s_seg[j]; q < j; q++) {
                     if (s_fl[q] & 1) continue;
                     any_prev = true;
@@ -479,6 +514,7 @@ __device__ __forceinline__ void replay_bucket(const uint32_t b, const OccRec* __
                     }
                 }
                 if (any_prev && (hit || a == bb)) fl |= 2;
+#endif
             }
             const bool u = !(fl & 1) && (no_dedup || !(fl & 2));
             if (u) { my_u++; ubits |= (uint8_t)(1u << t); }

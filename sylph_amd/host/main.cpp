@@ -2,6 +2,9 @@
 // defaults from cmdline.rs:28-173; hidden estimators and logging flags are not carried).
 #include <cstdlib>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/wait.h>
+#include <cerrno>
 #include <cstring>
 #include <functional>
 
@@ -132,7 +135,34 @@ int run_inspect(Argv a) {   // cmdline.rs:166-173; no GPU involved
 
 }  // namespace
 
+// The work runs in a CHILD process (forked before anything touches the GPU runtime); the process the user started waits for one word
+// from it — the exit status, sent when every output is written and the standard streams are flushed — and leaves at once.  What the
+// child still has to do then is give its address space back: GBs of file mappings, inflated copies and index arrays, which the kernel
+// frees page by page (0.15-0.2 s after a four-sample or a .gz command, measured in round 5: profiles/r05_cli_first_sample_trace.txt) —
+// it does that as an orphan, with its standard streams closed (so that a caller reading our pipes sees end-of-file when WE exit).
+// SYLPH_HIP_NO_FORK=1 / SYLPH_HIP_CLEAN_EXIT=1 keep everything in one process.
+static int g_report_fd = -1;
+static int run_in_child(int argc, char** argv) {
+    if (!fast_exit() || getenv("SYLPH_HIP_NO_FORK") || (argc >= 2 && !strcmp(argv[1], "inspect"))) return -1;
+    int fds[2];
+    if (pipe(fds) != 0) return -1;
+    fflush(stdout);
+    fflush(stderr);
+    const pid_t pid = fork();
+    if (pid < 0) { close(fds[0]); close(fds[1]); return -1; }
+    if (pid == 0) { close(fds[0]); g_report_fd = fds[1]; return -1; }        // the child: does the work, reports through g_report_fd
+    close(fds[1]);
+    int rc = 0;
+    ssize_t got;
+    do { got = read(fds[0], &rc, sizeof(rc)); } while (got < 0 && errno == EINTR);
+    if (got == (ssize_t)sizeof(rc)) _exit(rc);                                // outputs complete: leave, the child cleans up alone
+    int st = 0;                                                               // the child died without a word: its status is ours
+    while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+    _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0));
+}
+
 int main(int argc, char** argv) {
+    (void)run_in_child(argc, argv);          // (the parent never returns from here)
     trace_mark("main()");
     if (argc < 2) { fprintf(stderr, "usage: sylph-hip <sketch|profile|query|inspect> ...\n"); return 2; }
     int rc = 2;
@@ -155,6 +185,13 @@ int main(int argc, char** argv) {
     // (leak checkers).
     fflush(stdout);
     fflush(stderr);
+    if (g_report_fd >= 0) {                  // tell the process the user is waiting on, then let go of the streams it shares with us
+        const ssize_t w = write(g_report_fd, &rc, sizeof(rc));
+        (void)w;
+        close(g_report_fd);
+        const int devnull = open("/dev/null", O_RDWR);
+        if (devnull >= 0) { dup2(devnull, 0); dup2(devnull, 1); dup2(devnull, 2); }
+    }
     if (fast_exit()) _exit(rc);
     return rc;
 }
