@@ -871,7 +871,7 @@ def main():
     except Exception:
         pass
     meta_ok = meta.get("csrc_sha") == fp     # PMC figures measured on exactly these kernel sources
-    tsrc = f"profiles/seeds_traffic.json@{meta.get('head', '?')[:12]} (rocprofv3 --pmc passes of tools/r04_profile.sh; csrc {meta.get('csrc_sha', '?')})"
+    tsrc = f"profiles/seeds_traffic.json@{meta.get('head', '?')[:12]} (rocprofv3 --pmc passes of tools/r05_profile.sh; csrc {meta.get('csrc_sha', '?')})"
     seeds_ms, seeds_launches = fam["seeds"]
     if seeds_launches:
         n_rec = float(np.mean([r["n_records"] for r in read_sets]))

@@ -194,41 +194,48 @@ def test_pipeline_sharded_one_rank(ctx):
     p.close(); db.close(); comm.close()
 
 
-def test_bench_two_ranks_on_one_gpu_small_workload():
-    """`bench.py --gpus 2` end to end on whatever the box has (one GPU: the two ranks share it and the collectives of the sharded
-    exchange run through torch.distributed callbacks): the N > 1 code path of the bench — self-launch, sharded database, the
-    pipeline's fixed probe batches with flush, agreement on mode and step size across ranks — prints ONE line with n_gpus = 2
-    whose verify leg matches the oracle, and reports the exchange's time and bytes."""
+@pytest.mark.parametrize("db_mode", ["default", "shard", "genome"])
+def test_bench_two_ranks_on_one_gpu_small_workload(db_mode):
+    """`bench.py --gpus 2` end to end on whatever the box has (one GPU: the two ranks share it): the N > 1 code path of the bench —
+    self-launch, agreement on mode and step size across ranks, ONE line with n_gpus = 2 whose verify leg matches the oracle — in its
+    three database modes: the default (round 5: every rank a replica of the whole index, no data-path collective), `--db-mode shard`
+    (k-mer ranges) and `--db-mode genome` (north_star's cut, inside the library since round 5), the last two with the library's
+    exchange through torch.distributed callbacks, the pipeline's fixed probe batches with flush, and the exchange's time and bytes in
+    the line."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_PORT="29577")
+    env = dict(os.environ, MASTER_PORT={"default": "29577", "shard": "29578", "genome": "29579"}[db_mode])
+    extra = [] if db_mode == "default" else ["--db-mode", db_mode]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "3", "--warmup", "1",
-                        "--min-seconds", "0.3", "--no-cpu-baseline", "--no-h2d"], capture_output=True, text=True, timeout=900, env=env)
+                        "--min-seconds", "0.3", "--no-cpu-baseline", "--no-h2d"] + extra, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["verify"]["mismatches"] == 0 and d["verify"]["genomes_checked"] > 0
-    assert "sharded by k-mer range over 2 GPUs" in d["config"]["parallelism"]
+    par = d["config"]["parallelism"]
+    if db_mode == "default":
+        assert "replicated on every GPU (no data-path collective)" in par and "exchange" not in d
+        return
+    assert ("sharded by k-mer range over 2 GPUs" if db_mode == "shard" else "sharded by GENOME over 2 GPUs inside the library") in par
     legs = [d] + [d[k] for k in ("pipelined", "one_step_at_a_time") if k in d and "exchange" in d[k]]
     assert any("exchange" in leg and leg["exchange"]["probe_batches"] > 0 and leg["exchange"]["hit_bytes_sent_per_batch"] > 0 for leg in legs)
 
 
-def test_bench_two_ranks_genome_sharded_arm():
-    """`bench.py --gpus 2 --db-mode genome`: north_star's wording of the multi-GPU path (whole genomes per rank, one all-gather of the
-    containment counts) as the A/B arm of sylph_amd/shard.py — two ranks on whatever the box has, torch.distributed over gloo on host
-    copies; the verify leg compares a sample's assembled result (genomes of both shards, global order) with the oracle."""
+def test_bench_two_ranks_genome_sharded_arm_composed_outside_the_library():
+    """`bench.py --gpus 2 --db-mode genome-py`: round 4's composition of the cut by genome (sylph_amd/shard.py: unsharded index per rank,
+    torch.distributed all-gathers of tables, counts and coverage values) — kept beside the library mode for the A/B."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_PORT="29579")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small", "--db-mode", "genome", "--steps", "2",
+    env = dict(os.environ, MASTER_PORT="29580")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small", "--db-mode", "genome-py", "--steps", "2",
                         "--warmup", "1", "--min-seconds", "0.2", "--no-cpu-baseline", "--no-h2d"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]

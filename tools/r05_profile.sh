@@ -88,4 +88,4 @@ DEEP_CASES=extreme python tools/deep_coverage_check.py 2> /dev/null >> $out/stre
 DEEP_DEDUP_FPR=1e-4 python tools/deep_coverage_check.py 2> /dev/null > $out/stress_deep_coverage_filter_dedup.txt
 DEEP_DEDUP_FPR=1e-4 DEEP_CASES=extreme python tools/deep_coverage_check.py 2> /dev/null >> $out/stress_deep_coverage_filter_dedup.txt
 python tools/deep_long_reads_check.py 2> /dev/null > $out/stress_deep_long_reads.txt
-tail -3 $out/feed.txt $out/stress_shared_kmers.txt $out/stress_deep_coverage_filter_dedup.txt
+tail -n 3 $out/feed.txt; tail -n 3 $out/stress_deep_coverage_filter_dedup.txt
