@@ -983,7 +983,9 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         hip_check(sylph_upload_finish(uo, &d_off), "sylph_upload_finish");
         hip_check(sylph_db_upload(e.context(), d_k, (const uint64_t*)d_off, genome_sketches.size(), SYLPH_MEM_DEVICE, &db), "sylph_db_upload");
     }
-    struct DbGuard { sylph_db* d; ~DbGuard() { if (!fast_exit()) sylph_db_destroy(d); } } guard{db};   // (a 29 GB index is not freed block by block on the way to _exit)
+    // (destroyed even on the fast way out: a 29 GB index left to the driver's own clean-up at process exit is released BEHIND the
+    //  process — the next command's database load then took 2.7 s instead of 0.7: profiles/r05_db_load_with_forked_profile.txt)
+    struct DbGuard { sylph_db* d; ~DbGuard() { sylph_db_destroy(d); } } guard{db};
     if (args.pseudotax) {   // the winner table also ranges over pseudotax_tracked_nonused_kmers (contain.rs:421-428)
         UploadGuard ug, og;
         std::vector<uint64_t> toff;
@@ -1116,7 +1118,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         int n_gpus = args.gpus < 0 ? sylph_device_count() : getenv("SYLPH_HIP_SHARE_GPUS") ? args.gpus : std::min(args.gpus, std::max(1, sylph_device_count()));
         n_gpus = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_gpus), n_raw));
         std::vector<std::unique_ptr<Engine>> replica_engines;            // (declared before the replicas: destroyed after them)
-        struct Replicas { std::vector<sylph_db*> v; ~Replicas() { if (!fast_exit()) for (size_t i = 1; i < v.size(); i++) sylph_db_destroy(v[i]); } } replicas;
+        struct Replicas { std::vector<sylph_db*> v; ~Replicas() { for (size_t i = 1; i < v.size(); i++) sylph_db_destroy(v[i]); } } replicas;
         std::vector<sylph_db*>& dbs = replicas.v;
         dbs.push_back(db);
         std::vector<int> replica_device{e.device};

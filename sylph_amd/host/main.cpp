@@ -108,10 +108,11 @@ int run_contain(Argv a, bool profile) {
         out = fopen(c.out_file_name->c_str(), "w");
         if (!out) throw Error{1, "could not create " + *c.out_file_name};
     }
+    // (profile / query give their device memory back themselves, context included: see DbGuard in commands.cpp)
     Engine* e = new Engine();
     const int rc = contain(*e, c, profile, out);
     if (out != stdout) fclose(out);
-    if (!fast_exit()) delete e;
+    delete e;
     return rc;
 }
 

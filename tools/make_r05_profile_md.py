@@ -152,7 +152,9 @@ try:
         if not mine or name == "part_scan_kernel" and len(grids[name]) > 1 and int(grid) != max(grids[name]):
             continue
         f_b, w_b = v.get("FETCH_SIZE", 0) * 1024 * 2, v.get("WRITE_SIZE", 0) * 1024
-        share = 0.5 if (name.startswith("part_") and len(grids[name]) == 1) else 1.0      # one (kernel, grid) serving both partitions: half each
+        # one (kernel, grid) serves BOTH partitions of a sample (the operations' 8.0 M words and the replay's 4.0 M pairs: same number of
+        # coarse ranges): the mean over its dispatches is the mean of the two, the operations' share of it 2 x 8 / (8 + 4)
+        share = 4.0 / 3.0 if (name.startswith("part_") and len(grids[name]) == 1) else 1.0
         tot_f += f_b * share; tot_w += w_b * share; tot_valu += v.get("SQ_INSTS_VALU", 0) * share
         rows_a.append(f"| `{name}` | {grid} | {f_b * share:.3e} | {w_b * share:.3e} | {v.get('SQ_INSTS_VALU', 0) * share:.3g} | {v.get('SQ_INSTS_SALU', 0) * share:.3g} | {v.get('SQ_LDS_BANK_CONFLICT', 0) * share:.3g} |")
     a10_traffic = tot_f + tot_w
