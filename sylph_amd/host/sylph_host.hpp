@@ -216,7 +216,7 @@ bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109
 
 // ---- sketching (GPU through the C ABI) ----
-bool fast_exit();                    // the command leaves through _exit once its outputs are written (not with SYLPH_HIP_CLEAN_EXIT=1): big device objects are not torn down first
+bool fast_exit();                    // `sylph-hip sketch` leaves through _exit once its outputs are written (not with SYLPH_HIP_CLEAN_EXIT=1)
 void trace_mark(const char* what);   // SYLPH_HIP_FEED_TRACE: a line with the milliseconds since the host library was loaded
 struct Engine {   // one GPU context shared by the drivers
     int device = -1;
