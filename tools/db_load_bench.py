@@ -60,7 +60,14 @@ def main():
     del k
     res = {"genomes": n_genomes, "syldb_bytes": size, "write_s": round(time.time() - t0, 1), "host_threads": os.cpu_count()}
     for cmd in ("query", "profile"):
-        for label, env in (("views", {}), ("views_again", {}), ("copy_load", {"SYLPH_HIP_DB_COPY_LOAD": "1"})):
+        variants = [("views", {}), ("views_again", {}), ("copy_load", {"SYLPH_HIP_DB_COPY_LOAD": "1"})]
+        if os.environ.get("DBLOAD_DIAG"):       # back-to-back runs scatter: which knob, if any, matters
+            variants += [("views_3", {}), ("views_nowarm", {"SYLPH_HIP_NO_WARMUP": "1"}), ("views_nowarm_again", {"SYLPH_HIP_NO_WARMUP": "1"}),
+                         ("views_clean_exit", {"SYLPH_HIP_CLEAN_EXIT": "1"}), ("views_after_clean", {}), ("views_after_sleep", {"_SLEEP": "3"})]
+        for label, env in variants:
+            if env.get("_SLEEP"):
+                time.sleep(float(env["_SLEEP"]))
+                env = {}
             t = time.perf_counter()
             p = subprocess.run([BIN, cmd, path, f"{d}/sample.sylsp"], capture_output=True, text=True, env=dict(os.environ, SYLPH_HIP_DEBUG="1", **env))
             dt = time.perf_counter() - t
