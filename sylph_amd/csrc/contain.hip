@@ -162,10 +162,9 @@ __global__ __launch_bounds__(256) void write_lines_kernel(const uint64_t* __rest
         *o = SLOT_EMPTY;
     }
     uint4* lp = reinterpret_cast<uint4*>(lines + b * LINE_SLOTS);
-    lp[0] = make_uint4((uint32_t)s[0], (uint32_t)(s[0] >> 32), (uint32_t)s[1], (uint32_t)(s[1] >> 32));
-    lp[1] = make_uint4((uint32_t)s[2], (uint32_t)(s[2] >> 32), (uint32_t)s[3], (uint32_t)(s[3] >> 32));
-    lp[2] = make_uint4((uint32_t)s[4], (uint32_t)(s[4] >> 32), (uint32_t)s[5], (uint32_t)(s[5] >> 32));
-    lp[3] = make_uint4((uint32_t)s[6], (uint32_t)(s[6] >> 32), (uint32_t)s[7], (uint32_t)(s[7] >> 32));
+#pragma unroll
+    for (int t = 0; t < LINE_QUADS; t++)
+        lp[t] = make_uint4((uint32_t)s[2 * t], (uint32_t)(s[2 * t] >> 32), (uint32_t)s[2 * t + 1], (uint32_t)(s[2 * t + 1] >> 32));
 }
 
 // ---- probe -----------------------------------------------------------------------------------------------------------
@@ -532,7 +531,7 @@ void build_line_index(sylph_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d
     ix.gshift = gb + 1;
     const uint64_t div_cap = (1ull << (63 - gb)) - 1;                       // remainder < div keeps the all-ones pattern free
     const uint64_t span = max_key - kmer_lo + 1;                            // bucket 0 starts at kmer_lo     (span >= 1)
-    const uint64_t want_buckets = std::max<uint64_t>(1, m_total / std::max<uint32_t>(1, ctx->index_lambda));
+    const uint64_t want_buckets = std::max<uint64_t>(1, m_total / (ctx->index_lambda ? ctx->index_lambda : DEFAULT_INDEX_LAMBDA));
     uint64_t div = span / want_buckets + (span % want_buckets ? 1 : 0);
     if (span == 0) div = div_cap;                                           // (max_key - kmer_lo + 1 wrapped: the full 2^64 range)
     div = std::min(std::max<uint64_t>(div, 1), div_cap);

@@ -5,7 +5,16 @@
 
 namespace sylph {
 
-constexpr int LINE_SLOTS = 8;                 // 8 x 8 B = one 64-byte line per bucket
+// Slots per bucket line: 8 (a 64-byte line, lambda = 4 postings aimed at per line) or 4 (round 5: a 32-byte half-line, lambda = 2 —
+// the same index bytes, twice the buckets; random 32 B reads come back at 1.8x the rate of random 64 B reads on this chip,
+// profiles/r05_random_line_rates.txt).  A compile-time choice: the probe's loads and the slot scan are unrolled over it.
+#ifndef SYLPH_LINE_SLOTS
+#define SYLPH_LINE_SLOTS 8
+#endif
+constexpr int LINE_SLOTS = SYLPH_LINE_SLOTS;   // x 8 B per bucket line
+static_assert(LINE_SLOTS == 8 || LINE_SLOTS == 4, "a bucket line is 64 or 32 bytes");
+constexpr int LINE_QUADS = LINE_SLOTS / 2;     // 16-byte loads per line
+constexpr uint32_t DEFAULT_INDEX_LAMBDA = LINE_SLOTS / 2;
 constexpr uint64_t SLOT_EMPTY = ~0ull;
 
 // What the kernels need to probe an index (POD, passed by value).
@@ -64,10 +73,12 @@ __device__ __forceinline__ void for_each_posting(const LineView& v, uint64_t km,
     }
     if (q >= v.n_buckets) return;
     const uint4* lp = reinterpret_cast<const uint4*>(v.lines + q * LINE_SLOTS);
-    const uint4 a = lp[0], b = lp[1], c = lp[2], d = lp[3];
-    const uint64_t s[LINE_SLOTS] = {((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, ((uint64_t)b.y << 32) | b.x,
-                                    ((uint64_t)b.w << 32) | b.z, ((uint64_t)c.y << 32) | c.x, ((uint64_t)c.w << 32) | c.z,
-                                    ((uint64_t)d.y << 32) | d.x, ((uint64_t)d.w << 32) | d.z};
+    uint4 qd[LINE_QUADS];
+#pragma unroll
+    for (int t = 0; t < LINE_QUADS; t++) qd[t] = lp[t];
+    uint64_t s[LINE_SLOTS];
+#pragma unroll
+    for (int t = 0; t < LINE_QUADS; t++) { s[2 * t] = ((uint64_t)qd[t].y << 32) | qd[t].x; s[2 * t + 1] = ((uint64_t)qd[t].w << 32) | qd[t].z; }
     const uint64_t flag = 1ull << (v.gshift - 1), gmask = flag - 1;
 #pragma unroll
     for (int j = 0; j < LINE_SLOTS; j++)
@@ -89,7 +100,7 @@ __device__ __forceinline__ void for_each_posting(const LineView& v, uint64_t km,
 // probe is latency-bound: random 64 B reads): line_fetch computes the bucket and issues the four loads, line_scan walks the
 // slots (and the short overflow run) exactly as for_each_posting does.
 struct LineFetch {
-    uint4 a, b, c, d;
+    uint4 v[LINE_QUADS];
     uint64_t rem;
     bool live;
 };
@@ -97,7 +108,8 @@ __device__ __forceinline__ LineFetch line_fetch(const LineView& v, uint64_t km, 
     LineFetch f;
     f.live = false;
     f.rem = 0;
-    f.a = f.b = f.c = f.d = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+    for (int t = 0; t < LINE_QUADS; t++) f.v[t] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     if (!wanted || km < v.base) return f;
     const uint64_t x = km - v.base;
     uint64_t q, rem;
@@ -109,7 +121,8 @@ __device__ __forceinline__ LineFetch line_fetch(const LineView& v, uint64_t km, 
     }
     if (q >= v.n_buckets) return f;
     const uint4* lp = reinterpret_cast<const uint4*>(v.lines + q * LINE_SLOTS);
-    f.a = lp[0]; f.b = lp[1]; f.c = lp[2]; f.d = lp[3];
+#pragma unroll
+    for (int t = 0; t < LINE_QUADS; t++) f.v[t] = lp[t];
     f.rem = rem;
     f.live = true;
     return f;
@@ -119,9 +132,9 @@ __device__ __forceinline__ void line_scan(const LineView& v, const LineFetch& l,
     *long_start = ~0ull;
     if (!l.live) return;
     const uint64_t rem = l.rem;
-    const uint64_t s[LINE_SLOTS] = {((uint64_t)l.a.y << 32) | l.a.x, ((uint64_t)l.a.w << 32) | l.a.z, ((uint64_t)l.b.y << 32) | l.b.x,
-                                    ((uint64_t)l.b.w << 32) | l.b.z, ((uint64_t)l.c.y << 32) | l.c.x, ((uint64_t)l.c.w << 32) | l.c.z,
-                                    ((uint64_t)l.d.y << 32) | l.d.x, ((uint64_t)l.d.w << 32) | l.d.z};
+    uint64_t s[LINE_SLOTS];
+#pragma unroll
+    for (int t = 0; t < LINE_QUADS; t++) { s[2 * t] = ((uint64_t)l.v[t].y << 32) | l.v[t].x; s[2 * t + 1] = ((uint64_t)l.v[t].w << 32) | l.v[t].z; }
     const uint64_t flag = 1ull << (v.gshift - 1), gmask = flag - 1;
 #pragma unroll
     for (int j = 0; j < LINE_SLOTS; j++)
