@@ -210,7 +210,11 @@ void sylph_sketch_destroy(sylph_sketch *sk);
  * cuckoo filter reports an item iff an item with the same fingerprint and bucket pair went in before it (csrc/a10.hip).  The
  * filter's crate (scalable_cuckoo_filter 0.2.4) is not part of the reference tree: geometry and growth follow its documentation,
  * the hash bits are this library's, so WHICH pairs collide differs from a run of the reference (how many do — about f of the
- * tests once a filter is full — does not).  Bit-exact against the model of the same filter in the tests' CPU checker. */
+ * tests once a filter is full — does not).  Bit-exact against the model of the same filter in the tests' CPU checker.
+ * Round 5: where ONE filter holds the sample (every sample up to ~1.2 Gbp of pairs at the reference's capacity) the answers come from a
+ * sort of the operations by class (two-level partition + in-LDS resolution: no table, no device-wide atomics; 0.25 ms per Gbp
+ * instead of 0.92); larger samples, and samples with hundreds of copies of one pair, take round 4's walk over a class table.
+ * "a10" = "auto" | "walk" | "part" chooses the pass (A/B and tests; "part" still falls back where one filter does not suffice). */
 int sylph_sketch_set_option(sylph_sketch *sk, const char *key, const char *value);
 
 /* ---- containment (sample vs every genome of a resident DB shard) ----------------------------------------- */

@@ -117,6 +117,21 @@ struct Session {   // RAII
 // SYLPH_HIP_FEED_TRACE: "[sylph_hip t+123.4 ms] what" — milliseconds since this library was loaded (just behind the dynamic linker)
 static const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
 bool fast_exit() { static const bool f = getenv("SYLPH_HIP_CLEAN_EXIT") == nullptr; return f; }
+// Work that nobody waits for (unmapping a sample's files, handing inflated copies back) runs on threads of its own; a command that
+// leaves through exit() joins them first (they use function-local statics that exit() destroys), one that leaves through _exit does not.
+namespace {
+std::mutex g_bg_mu;
+std::vector<std::thread> g_bg;
+void background(std::function<void()> f) {
+    std::lock_guard<std::mutex> lk(g_bg_mu);
+    g_bg.emplace_back(std::move(f));
+}
+}  // namespace
+void join_background() {
+    std::vector<std::thread> v;
+    { std::lock_guard<std::mutex> lk(g_bg_mu); v.swap(g_bg); }
+    for (auto& t : v) if (t.joinable()) t.join();
+}
 void trace_mark(const char* what) {
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[sylph_hip t+%.1f ms] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count() * 1e3, what);
@@ -669,7 +684,7 @@ int sketch(Engine& e, const SketchArgs& args) {
         trace_mark("sketch: the sample's files are indexed (or not indexable)");
         if (++indexes_obtained == n_jobs) set_no_more_inflates(true);   // nobody will want a recycled inflate buffer any more
         // the index goes (2 x 1 GB of mappings to unmap / inflated copies to hand back: 30-60 ms per sample) on a thread of its own, behind the sample
-        struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) std::thread([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }).detach(); } } later{pre};
+        struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) background([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }); } } later{pre};
         ahead.start(j + n_workers);
         const auto t_job = std::chrono::steady_clock::now();
         auto timing = [&](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
@@ -739,6 +754,7 @@ int sketch(Engine& e, const SketchArgs& args) {
         if (all.empty()) warn("No valid genomes to sketch; " + path + " is not output");
         else { write_syldb(path, all); info("Wrote all genome sketches to " + path); }
     }
+    if (!fast_exit()) join_background();
     info("Finished.");
     return 0;
 }
@@ -1168,7 +1184,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                 } else {
                     std::optional<IndexedInput> pre = ahead.get(j);
                     if (++indexes_obtained == n_raw) set_no_more_inflates(true);
-                    struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) std::thread([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }).detach(); } } later{pre};
+                    struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) background([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }); } } later{pre};
                     ahead.start(j + n_workers);
                     if (files.size() == 1) pr.meta = sketch_sequences_needle_impl(eng, files[0], args.c, args.k, std::nullopt, false, &pre, &pr.session);
                     else pr.meta = sketch_pair_sequences_impl(eng, files[0], files[1], args.c, args.k, std::nullopt, false, raw_pair_fpr, &pre, &pr.session);
@@ -1286,6 +1302,7 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
         finished(files);
     }
     fflush(out);
+    join_background();
     info("sylph finished.");
     return 0;
 }

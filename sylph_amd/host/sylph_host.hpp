@@ -217,6 +217,7 @@ bool is_fasta(const std::string& f);   // sketch.rs:109
 
 // ---- sketching (GPU through the C ABI) ----
 bool fast_exit();                    // `sylph-hip sketch` leaves through _exit once its outputs are written (not with SYLPH_HIP_CLEAN_EXIT=1)
+void join_background();              // waits for the host side's fire-and-forget threads (unmapping behind a sample)
 void trace_mark(const char* what);   // SYLPH_HIP_FEED_TRACE: a line with the milliseconds since the host library was loaded
 struct Engine {   // one GPU context shared by the drivers
     int device = -1;
