@@ -1,6 +1,6 @@
 """The pin of the oracle against the REAL reference binary — runs only where the reference could be built (a Rust toolchain:
 oracle/ref_build.sh) or where somebody committed the vectors it produced (tests/golden/ref_binary_vectors.npz, written by
-tests/golden/regen_from_ref.py).  Neither exists in rounds 1-4 (no cargo in the image or on the GPU boxes): both tests skip, and
+tests/golden/regen_from_ref.py).  Neither exists in rounds 1-5 (no cargo in the image or on the GPU boxes): all four tests skip, and
 DESIGN.md keeps saying "parity unpinned".  Nothing here needs a GPU."""
 import os
 import shutil
