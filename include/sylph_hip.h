@@ -95,6 +95,10 @@ void sylph_upload_destroy(sylph_upload *u);
  * of the index build (tests lower it to force several passes), "push_chunk_bytes" = bytes of bases per chunk of a host batch
  * (default 64 MiB), "reads_wg_per_cu" = workgroups of the read-per-lane kernel per CU, each looping over blocks of reads
  * ("0".."64"; default 0 = one workgroup per block, measured 10 % faster than 8 looping workgroups per CU).
+ * "reads_hash" = "0" | "1" | "2" | "-1": how the read-per-lane kernel spells the hash and the threshold test in its k-mer loop —
+ * the compiler's own lowering, the hand-scheduled 64-bit one, or the last hash step and the test on the high word only (a superset of
+ * the seeds; the kernel's second pass, which hashes every candidate exactly anyway, prunes it); same tables all three, "-1" = the
+ * build's default.  "reads_slack" = n (tests only): widens that superset by n high-word values so that the pruning road is common.
  * "plain_records" = "1" (default) / "0": single-end batches whose records carry no dedup marker (reads above 400 bases, or a
  * --no-dedup session) keep only the hashes of their seed occurrences and are counted without occurrence records; "0" writes
  * the records for every batch (A/B and tests: the tables are identical).

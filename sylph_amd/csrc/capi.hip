@@ -383,6 +383,12 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 0 && v <= 64, "reads_wg_per_cu must be in [0, 64]");
             ctx->reads_wg_per_cu = (uint32_t)v;
+        } else if (!strcmp(key, "reads_hash")) {
+            const long v = strtol(value, nullptr, 10);
+            SY_REQUIRE(v >= -1 && v <= 2, "reads_hash must be -1 (default), 0, 1 or 2");
+            ctx->reads_hash = (int)v;
+        } else if (!strcmp(key, "reads_slack")) {
+            ctx->reads_slack = (uint32_t)strtoul(value, nullptr, 0);
         } else if (!strcmp(key, "index_lambda")) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 1 && v <= 8, "index_lambda must be in [1, 8]");

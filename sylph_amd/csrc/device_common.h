@@ -46,6 +46,25 @@ __device__ __forceinline__ uint64_t mm_hash64_gfx950(uint64_t key) {
     t = lshl_add_u64<0>(t << 31, t);                              // + (t << 31)
     return t;
 }
+// The same hash up to its last step, then only what `h < T` looks at first: u = hi(t) + bits 1..32 of t + 1 (mod 2^32).  With the
+// carry out of the low word's sum, hi(h) = u - 1 + carry: h < T implies u <= hi(T) + 1 (u = 0, the wrapped case, included), so
+// { u <= hi(T) + 1 } is a superset of { h < T } that is wrong for about 3 in 2^32 keys (hi(h) in {hi(T), hi(T) + 1, 2^32 - 1}).
+// v_alignbit + v_add3 + a 32-bit compare where the exact test takes v_lshlrev_b64 + v_lshl_add_u64 + a 64-bit compare.
+__device__ __forceinline__ uint32_t mm_hash64_gfx950_hi1(uint64_t key) {
+    uint64_t t = lshl_add_u64<0>(key << 21, key);
+    {
+        uint64_t sh;
+        asm("v_lshrrev_b64 %0, 24, %1" : "=v"(sh) : "v"(t));
+        uint32_t hi;
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(hi) : "v"((uint32_t)(t >> 32)), "v"((uint32_t)(sh >> 32)), "s"(0xFFFFFF00u));
+        t = ((uint64_t)hi << 32) | ((uint32_t)t ^ (uint32_t)sh);
+    }
+    t = lshl_add_u64<0>(t << 8, lshl_add_u64<3>(t, t));
+    t = t ^ (t >> 14);
+    t = lshl_add_u64<4>(t, lshl_add_u64<2>(t, t));
+    t = t ^ (t >> 28);
+    return (uint32_t)(t >> 32) + __builtin_amdgcn_alignbit((uint32_t)(t >> 32), (uint32_t)t, 1) + 1u;
+}
 
 // types.rs:50-59 BYTE_TO_SEQ for one byte, computed instead of looked up:
 // A/a=0 C/c=1 G/g=2 T/t/U/u=3; raw bytes 1,2,3 -> 1,2,3; everything else (N, IUPAC, gaps, ...) -> 0.

@@ -92,8 +92,14 @@ __device__ __forceinline__ void kmer_step(uint32_t A0, uint32_t A1, uint32_t A2,
     else { rlo = __builtin_amdgcn_alignbit(B1, B0, OFF); rhi = __builtin_amdgcn_alignbit(B2, B1, OFF); }
     const uint64_t f = ((uint64_t)fhi << 32) | flo, rc = ((uint64_t)rhi << 32) | rlo;
     const uint64_t canon = (f < rc ? f : rc) >> D;                                      // seeding.rs:134-139
-    const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
-    asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(h), "s"(thr) : "vcc");
+    if constexpr (HV == 2) {
+        // candidate test on the HIGH word: u = hi(h) + 1 - (the low word's carry), `thr` holds hi(T) + 1 here (reads_kernel)
+        const uint32_t u = mm_hash64_gfx950_hi1(canon);
+        asm("v_cmp_ge_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(u), "s"((uint32_t)thr) : "vcc");
+    } else {
+        const uint64_t h = HV ? mm_hash64_gfx950(canon) : mm_hash64(canon);
+        asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(h), "s"(thr) : "vcc");
+    }
 }
 template <int K, int T0, int HV>
 __device__ __forceinline__ void kmer_steps8(uint32_t A0, uint32_t A1, uint32_t A2, uint32_t Bm, uint32_t B0, uint32_t B1, uint32_t B2,
@@ -126,6 +132,9 @@ __global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __re
     blk_rec[b] = (uint32_t)lo;
 }
 
+#ifndef SYLPH_READS_HASH_DEFAULT
+#define SYLPH_READS_HASH_DEFAULT 1
+#endif
 #ifndef SYLPH_READS_WAVES
 #define SYLPH_READS_WAVES 5
 #endif
@@ -133,7 +142,7 @@ template <int K, int HV, int ENC>
 __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READS_WAVES, SYLPH_READS_WAVES))) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
                                                      const uint64_t* __restrict__ off, uint64_t n_rec,
                                                      const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
-                                                     int avx2_compat, int paired, int want_markers, uint64_t rec_base,
+                                                     uint32_t cand_slack, int avx2_compat, int paired, int want_markers, uint64_t rec_base,
                                                      uint32_t slot_cap, OccRec* __restrict__ slot_rec,
                                                      uint32_t* __restrict__ slot_key, int key_sh,
                                                      uint32_t* __restrict__ blk_count,
@@ -153,6 +162,12 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
     __shared__ uint32_t s_first[RTPB + 1], s_rel[RTPB];
     __shared__ uint16_t s_perm[RTPB], s_nh[RTPB];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // HV == 2: the loop tests hi(h) only (kmer_step) and yields a SUPERSET of the k-mers below the threshold — about 3 in 2^32 k-mers
+    // too many; the survivors' pass, which hashes every candidate exactly anyway, strikes those from the hit masks and the pass's
+    // bookkeeping is redone once (s_redo).  cand_slack widens the superset on purpose: the tests' way of making that road common.
+    __shared__ uint32_t s_redo;
+    const uint64_t thr_loop = HV == 2 ? (uint64_t)((uint32_t)(thr >> 32) + 1u + cand_slack) : thr;
+    if (tid == 0) s_redo = 0;                                        // (ordered before its first reader by the barriers below)
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the
     // blocks, so that the halo a block shares with its neighbour is found in the same L2.  (Outputs are indexed by block,
     // so the order of the results does not depend on this mapping.)
@@ -274,19 +289,21 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                 // extra register moves per k-mer)
                 for (uint32_t g = 0; g < n_grp; g++) {
                     uint32_t mask = 0;
-                    kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
-                    kmer_steps8<K, 8, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+                    kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr_loop, mask);
+                    kmer_steps8<K, 8, HV>(A0, A1, A2, Bm, B0, B1, B2, thr_loop, mask);
                     A0 = A1; A1 = A2; A2 = next_word(g + 3);
                     Bm = B0; B0 = B1; B1 = B2; B2 = rcword(A2);
                     mask_half[((g >> 1) * RTPB * 2) + ((g & 1u) ^ 1u)] = (uint16_t)mask;
                 }
                 if (n_half & 1u) {                                                   // a last half-group: its 8 k-mers are the top byte
                     uint32_t mask = 0;
-                    kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr, mask);
+                    kmer_steps8<K, 0, HV>(A0, A1, A2, Bm, B0, B1, B2, thr_loop, mask);
                     mask_half[((n_grp >> 1) * RTPB * 2) + ((n_grp & 1u) ^ 1u)] = (uint16_t)(mask << 8);
                 }
             }
             if (dealt) __syncthreads();                                 // masks were written by other lanes
+            uint32_t total = 0;
+            for (;;) {                                                  // (once; HV == 2: again after a candidate failed the exact test)
             // count the real hits of this lane's own record (bit 31 - (i & 31) of word i >> 5 <-> k-mer i < nh)
             uint32_t cnt = 0;
             const uint32_t nw = (nh + 31) >> 5;
@@ -306,7 +323,8 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
             __syncthreads();
             if (lane == 63) s_wave[wave] = x;
             __syncthreads();
-            uint32_t before = 0, total = 0;
+            uint32_t before = 0;
+            total = 0;
 #pragma unroll
             for (int w = 0; w < RTPB / 64; w++) {
                 const uint32_t t = s_wave[w];
@@ -395,6 +413,13 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                     const uint64_t ft = win64(sF, s_rel[lo] + i);
                     const uint64_t fk = ft >> (64 - 2 * K), rk = revcomp_top<K>(ft);
                     const uint64_t h = mm_hash64(fk < rk ? fk : rk);
+                    if constexpr (HV == 2) {
+                        if (h >= thr) {                                          // not a hit after all: out of its record's mask
+                            atomicAnd(&s_mask[i >> 5][lo], ~(0x80000000u >> (i & 31u)));
+                            s_redo = 1u;
+                            continue;
+                        }
+                    }
                     uint64_t rid = rec_base + pass + lo;
                     if (f >> 31) {
                         rid |= RID_MARKER_BIT;
@@ -404,8 +429,15 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                     if (slot_key) slot_key[out0 + o] = (uint32_t)(h >> key_sh);   // what finish() partitions by (replay_lds.hip)
                 }
             }
-            base_prev += total;
             __syncthreads();   // s_wave and s_mask are reused by the next pass
+            if constexpr (HV != 2) break;
+            else {
+                if (!s_redo) break;                                     // (uniform: read behind the barrier)
+                __syncthreads();
+                if (tid == 0) s_redo = 0;                               // the next writer is several barriers away
+            }
+            }
+            base_prev += total;
         }
         if (tid == 0) {
             if (blk_list) {
@@ -550,18 +582,25 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
                   "long_record and spill.n_tiles are the first two words");
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
+    // the k-mer loop's hash / threshold spelling: 0 the compiler's own, 1 mm_hash64_gfx950 + exact 64-bit test, 2 the last hash step and
+    // the test on the high word only (a superset the survivors' pass prunes).  Same results all three (tests run each).
+    static const int hv_env = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : SYLPH_READS_HASH_DEFAULT;
+    const int hv_want = ctx->reads_hash >= 0 ? ctx->reads_hash : hv_env;
+    // hi(T) + 1 + slack has to stay a 32-bit number (c = 1: every k-mer passes, T = 2^64 - 1)
+    const uint32_t slack = ctx->reads_slack;
+    const int hv = (hv_want == 2 && ((thr >> 32) + 1ull + slack) > 0xFFFFFFFFull) ? 1 : hv_want;
     const int key_sh = key_shift(sk->c);
     auto launch = [&](uint32_t n_it, uint32_t cap, OccRec* sr, uint32_t* skey, const uint32_t* list) {
         const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * ctx->reads_wg_per_cu) : n_it;
 #define SY_LAUNCH_READS(KK, HH, EE)                                                                                                   \
     hipLaunchKernelGGL((reads_kernel<KK, HH, EE>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
-                       m.blk_rec, n_it, rt, thr, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr, skey, key_sh,   \
+                       m.blk_rec, n_it, rt, thr, slack, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr, skey, key_sh,   \
                        m.blk_count, m.state, list, m.spill_slot)
         if (enc == SYLPH_ENC_2BIT) {
-            if (sk->k == 31) SY_LAUNCH_READS(31, 1, 1); else SY_LAUNCH_READS(21, 1, 1);
-        } else if (sk->k == 31) { if (hv) SY_LAUNCH_READS(31, 1, 0); else SY_LAUNCH_READS(31, 0, 0); }
-        else { if (hv) SY_LAUNCH_READS(21, 1, 0); else SY_LAUNCH_READS(21, 0, 0); }
+            if (sk->k == 31) { if (hv == 2) SY_LAUNCH_READS(31, 2, 1); else SY_LAUNCH_READS(31, 1, 1); }
+            else { if (hv == 2) SY_LAUNCH_READS(21, 2, 1); else SY_LAUNCH_READS(21, 1, 1); }
+        } else if (sk->k == 31) { if (hv == 2) SY_LAUNCH_READS(31, 2, 0); else if (hv) SY_LAUNCH_READS(31, 1, 0); else SY_LAUNCH_READS(31, 0, 0); }
+        else { if (hv == 2) SY_LAUNCH_READS(21, 2, 0); else if (hv) SY_LAUNCH_READS(21, 1, 0); else SY_LAUNCH_READS(21, 0, 0); }
 #undef SY_LAUNCH_READS
         SY_HIP(hipGetLastError());
     };

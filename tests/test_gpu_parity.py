@@ -180,10 +180,10 @@ def _sketch_gpu_once(ctx, bases, off, paired, no_dedup, seed_mode, c, k, batches
     return r
 
 
-def assert_same_sketch(g, e):
-    assert np.array_equal(g["kmers"], e["kmers"])
-    assert np.array_equal(g["counts"], e["counts"])
-    assert g["dup_removed"] == e["dup_removed"]
+def assert_same_sketch(g, e, tag=None):
+    assert np.array_equal(g["kmers"], e["kmers"]), tag
+    assert np.array_equal(g["counts"], e["counts"]), tag
+    assert g["dup_removed"] == e["dup_removed"], tag
 
 
 def test_golden_read_sketches(ctx, golden_dir):
@@ -1260,6 +1260,77 @@ def test_tiny_reads_many_records_per_block(ctx):
             e = O.sketch_reads(b, off, c=c, paired=paired)
             assert len(e["kmers"]) > 50
             assert_same_sketch(sketch_gpu(ctx, b, off, paired=paired, c=c), e)
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_reads_kernel_hash_spellings_and_the_pruning_road(ctx, k):
+    """The read-per-lane kernel's k-mer loop in its three spellings (ctx option "reads_hash": 0 the compiler's lowering, 1 the
+    hand-scheduled 64-bit hash + exact test, 2 the last hash step and the test on the HIGH word only).  Spelling 2 marks a superset of
+    the seeds — about 3 k-mers in 2^32 too many — which the survivors' pass strikes from the hit masks before it redoes its bookkeeping:
+    "reads_slack" widens the superset (by a third, and to five times the seeds, where the slots and the survivors' list overflow while
+    the wrong candidates are still in) so that this road is taken in nearly every pass.  Ragged pairs, tiny reads (several passes per
+    block), odd bytes, packed 2-bit input, c from 2 (c = 1 cannot use spelling 2: falls back to 1) to 1000; same tables as the oracle."""
+    from sylph_amd.binding import ENC_2BIT, MEM_HOST
+    rng = np.random.default_rng(9100 + k)
+    genome = random_seq(rng, 60000)
+    ragged = make_reads(rng, genome, 3000, 150, paired=True, dup_frac=0.2, ragged=True)
+    for r in ragged[::13]:
+        if len(r) > 5:
+            r[int(rng.integers(0, len(r)))] = ord("N")
+    tiny = [genome[s:s + int(rng.integers(0, 60))].copy() for s in rng.integers(0, 50000, size=8000)]
+    equal = make_reads(rng, genome, 2500, 150, paired=True, dup_frac=0.1, ragged=False)
+    cases = [(ragged, True), (tiny, False), (tiny, True), (equal, True), (equal, False)]
+    try:
+        for c in (1, 2, 3, 20, 200, 1000):
+            th = (0xFFFFFFFFFFFFFFFF // c) >> 32
+            slacks = [0] if c == 1 else [0, th // 3, min(4 * th, 0xFFFFFFFE - th - 1)]
+            for recs, paired in cases:
+                b, off = concat(recs)
+                e = O.sketch_reads(b, off, c=c, k=k, paired=paired)
+                packed = S.pack_2bit(b)
+                for hv, slack in [(0, 0), (1, 0)] + [(2, s_) for s_ in slacks]:
+                    ctx.set_option("reads_hash", str(hv))
+                    ctx.set_option("reads_slack", str(slack))
+                    tag = (c, paired, hv, slack)
+                    g = sketch_gpu(ctx, b, off, paired=paired, c=c, k=k, batches=1 + (hv + c) % 2)
+                    assert_same_sketch(g, e, tag)
+                    if hv == 2:
+                        sk = S.ReadSketcher(ctx, c=c, k=k, paired=paired)
+                        sk.push_enc(packed, off, int(off[-1]), MEM_HOST, ENC_2BIT)
+                        g = sk.finish()
+                        sk.close()
+                        assert_same_sketch(g, e, tag)
+                        if paired and c >= 2:        # the pruned slots behind the default pair dedup (deferred verdict, partitioned pass)
+                            ef = O.sketch_reads_cuckoo_model(b, off, c=c, k=k, fpr=1e-4)
+                            assert_same_sketch(sketch_gpu(ctx, b, off, paired=True, c=c, k=k, dedup_fpr=1e-4), ef, tag)
+        # a device batch with a deferred verdict (what the pipeline pushes): the pruned slots are partitioned where they lie
+        import torch
+        big = make_reads(rng, genome, 12000, 150, paired=True, dup_frac=0.1, ragged=False)
+        b, off = concat(big)
+        tb = torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).cuda()
+        to = torch.from_numpy(off.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        for c in (20, 200):
+            th = (0xFFFFFFFFFFFFFFFF // c) >> 32
+            e = O.sketch_reads(b, off, c=c, k=k, paired=True)
+            ef = O.sketch_reads_cuckoo_model(b, off, c=c, k=k, fpr=1e-4)
+            for slack in (0, th // 3, 4 * th):
+                ctx.set_option("reads_hash", "2")
+                ctx.set_option("reads_slack", str(slack))
+                for fpr, want in ((None, e), (1e-4, ef)):
+                    ctx.profile(True)
+                    sk = S.ReadSketcher(ctx, c=c, k=k, paired=True, **({} if fpr is None else {"dedup_fpr": fpr}))
+                    sk.set_option("borrow_until_finish", 1)
+                    sk.push_device(tb.data_ptr(), to.data_ptr(), len(off) - 1, int(off[-1]))
+                    g = sk.finish()
+                    sk.close()
+                    deferred = ctx.kernel_stats("deferred")[1]
+                    ctx.profile(False)
+                    assert_same_sketch(g, want, ("deferred", c, slack, fpr))
+                    assert deferred == 1, (c, slack, fpr)
+    finally:
+        ctx.set_option("reads_hash", "-1")
+        ctx.set_option("reads_slack", "0")
 
 
 def _sketch_in_batches(ctx, batches, c, no_dedup=False, plain="1"):
