@@ -375,6 +375,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
+    ap.add_argument("--all-kernel-timers", action="store_true", help="time every kernel family inside the timed region too (rounds 1-4 did; costs ~1 %% pipelined, ~4 %% one at a time)")
     ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 3)")
     ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 5; sharded: two probe batches)")
     ap.add_argument("--no-files-leg", action="store_true", help="skip the leg that runs `sylph-hip sketch` on FASTQ files (plain, gzip)")
@@ -656,10 +657,15 @@ def main():
         sps = int(agree(max(1, int(np.ceil(args.min_seconds * 1.1 / max(1, args.steps) / est / spb))) * spb))
     log(f"[bench] calibration {cal}: value from the {mode} mode, {sps} sample(s) per step")
 
-    def timed(mode, n_steps, per_step):
-        """-> elapsed seconds (max over ranks), per-step seconds, per-sample completion stamps, rows, kernel families"""
+    def timed(mode, n_steps, per_step, only=None):
+        """-> elapsed seconds (max over ranks), per-step seconds, per-sample completion stamps, rows, kernel families.
+        `only`: the kernel families the library times with HIP events in this region (None: all of them).  Every timed family costs two
+        event records per launch group on its stream — all of them together 1 % of a pipelined sample and 4 % of a sample run alone
+        (profiles/r05_ab_timers.txt) — so the regions a rate is quoted on time the dominant kernel only; the other families' durations come
+        from a pass of their own ("kernel_ms_pass")."""
         profiled = [pipe_box[0]] if mode == "pipelined" else [ctx]
         for o in profiled:
+            o.set_option("profile_only", "all" if (only is None or args.all_kernel_timers) else only)
             o.profile(not args.no_kernel_timers)
         if comm is not None:
             db.exchange_stats(reset=True)
@@ -684,17 +690,25 @@ def main():
             fam["_exchange_totals"] = db.exchange_stats()
         for o in profiled:
             o.profile(False)
+            o.set_option("profile_only", "all")
         return elapsed, list(np.diff(bounds)), list(np.diff([t_start] + stamps)), rows, fam
 
     for _ in range(args.warmup):
         runners[mode](sps)
-    elapsed, step_s, gaps, rows, fam = timed(mode, args.steps, sps)
+    elapsed, step_s, gaps, rows, fam = timed(mode, args.steps, sps, only="seeds,exchange" if comm is not None else "seeds")
+    # the other kernel families in the same mix: a shorter pass of the same mode with every family timed (never the quoted rate)
+    fam_pass = None
+    if not args.no_kernel_timers and not args.all_kernel_timers and not args.no_second_leg:
+        st_k = max(1, min(args.steps, 3))
+        per_k = max(spb, int(0.4 / max(est, 1e-6) / st_k / spb) * spb)
+        e_k, _, _, r_k, f_k = timed(mode, st_k, per_k)
+        fam_pass = {"fam": f_k, "rows": r_k, "ms_per_sample": round(e_k / (st_k * per_k) * 1e3, 4), "samples": st_k * per_k}
     second = None
     if not args.no_second_leg and db_mode != "genome-py":               # the same samples the other way, ~0.6 s of them
         n2 = max(spb, int(0.6 / max(cal.get(other + "_ms_per_sample", 1.5) * 1e-3, 1e-6) / spb) * spb)
         steps2 = max(1, min(args.steps, 4))
         per2 = max(spb, n2 // steps2 // spb * spb)
-        second = (other, per2) + timed(other, steps2, per2)
+        second = (other, per2) + timed(other, steps2, per2, only="seeds,probe")
 
     last = {}
     run_sequential(spb, keep_last=last)      # untimed: seed occurrences for the roofline's algorithmic bytes, results for --verify
@@ -725,6 +739,10 @@ def main():
         return d
 
     main_leg = leg_summary(mode, sps, args.steps, elapsed, step_s, gaps, rows, fam)
+    if fam_pass is not None:
+        main_leg["kernel_ms_pass"] = {"what": "every kernel family timed (HIP event pairs), a separate shorter pass of the same mode: the rate it cost",
+                                      "samples": fam_pass["samples"], "ms_per_sample": fam_pass["ms_per_sample"],
+                                      "kernel_ms": {f: (round(v[0] / max(1, v[1]), 4), int(v[1])) for f, v in fam_pass["fam"].items() if not f.startswith("_") and v[1]}}
     # ---- the same samples with the reads resident as the packed 2-bit stream (SYLPH_ENC_2BIT: what the CLI's feed pushes; a
     # quarter of the bytes, no ASCII -> 2-bit conversion in the seeding kernel).  Reported beside `value`, never instead of it:
     # SURVEY 8d's 1.085 B/base is the ASCII input.
@@ -746,7 +764,7 @@ def main():
             active_sets[0] = packed_sets
             runners["pipelined"](2 * depth)
             n_p = max(spb, int(0.5 / max(cal.get("pipelined_ms_per_sample", 1.0) * 1e-3, 1e-6)))
-            e_p, st_p, g_p, r_p, f_p = timed("pipelined", 2, max(1, n_p // 2))
+            e_p, st_p, g_p, r_p, f_p = timed("pipelined", 2, max(1, n_p // 2), only="seeds")
             leg_p = leg_summary("pipelined", max(1, n_p // 2), 2, e_p, st_p, g_p, r_p, f_p)
             n_q = max(spb, int(0.2 / max(cal.get("sequential_ms_per_sample", 1.5) * 1e-3, 1e-6)))
             e_q, st_q, g_q, r_q, f_q = timed("sequential", 1, n_q)
@@ -779,7 +797,7 @@ def main():
             with_filter(True)
             runners["pipelined"](2 * depth)
             n_p = max(spb, int(0.5 / max(cal.get("pipelined_ms_per_sample", 1.0) * 1e-3, 1e-6)))
-            e_p, st_p, g_p, r_p, f_p = timed("pipelined", 2, max(1, n_p // 2))
+            e_p, st_p, g_p, r_p, f_p = timed("pipelined", 2, max(1, n_p // 2), only="seeds")
             leg_p = leg_summary("pipelined", max(1, n_p // 2), 2, e_p, st_p, g_p, r_p, f_p)
             n_q = max(spb, int(0.2 / max(cal.get("sequential_ms_per_sample", 1.5) * 1e-3, 1e-6)))
             e_q, st_q, g_q, r_q, f_q = timed("sequential", 1, n_q)
@@ -844,7 +862,11 @@ def main():
         "genome_comparisons_per_s_whole_step": round(comparisons / (elapsed / (sps * args.steps)), 1),
         "sketch_ms": main_leg["sketch_ms"], "profile_ms": main_leg["profile_ms"], "probe_batch_mean": main_leg["probe_batch_mean"],
         "sample_table_entries": int(np.mean([r[2] for r in rows])), "dup_removed": int(np.mean([r[3] for r in rows])),
-        "kernel_ms": main_leg["kernel_ms"],
+        # per family: (average ms per launch group, launch groups).  The timed region times the dominant kernel only; the other families
+        # are from `kernel_ms_pass` (every family timed, a separate shorter pass of the same mode)
+        "kernel_ms": {**(main_leg["kernel_ms_pass"]["kernel_ms"] if "kernel_ms_pass" in main_leg else {}), **main_leg["kernel_ms"]},
+        "timers_in_timed_region": "every family" if args.all_kernel_timers else ("none" if args.no_kernel_timers else "the dominant kernel's family (seeds) only"),
+        **({"kernel_ms_pass": main_leg["kernel_ms_pass"]} if "kernel_ms_pass" in main_leg else {}),
         **({"exchange": main_leg["exchange"]} if "exchange" in main_leg else {}),
         "setup": dbstats,
         **({"resident_2bit": packed_leg} if packed_leg is not None else {}),
@@ -860,7 +882,7 @@ def main():
         leg2 = leg_summary(o_mode, per2, steps2, e2, st2, g2, r2, f2)
         out["one_step_at_a_time" if o_mode == "sequential" else "pipelined"] = leg2
         legs[o_mode] = (f2, r2)
-    out["one_step_at_a_time" if mode == "sequential" else "pipelined"] = {k_: main_leg[k_] for k_ in main_leg if k_ not in ("kernel_ms",)} | {"same_as": "the top-level fields"}
+    out["one_step_at_a_time" if mode == "sequential" else "pipelined"] = {k_: main_leg[k_] for k_ in main_leg if k_ not in ("kernel_ms", "kernel_ms_pass")} | {"same_as": "the top-level fields"}
 
     # roofline of the dominant kernel (seeds): algorithmic bytes per launch = 1 B/base + 8 B/record offset + 8 B/seed
     # occurrence out, over the HIP-event duration of that launch.
@@ -922,7 +944,8 @@ def main():
                                        "table (round 4: 0.92 ms): the traffic is several times the algorithmic bytes by construction, all of it coalesced"}
     # roofline of the profile half: probe_kernel, one launch per probe batch over all tables it probes.  Inverted-index formulation
     # (SURVEY 8d): B = N_s * (8 + 4 table in + 64 one index line per probe) + 8 * hits out.
-    probe_ms, probe_launches = fam["probe"]
+    fam_mix, rows_mix = (fam_pass["fam"], fam_pass["rows"]) if fam_pass is not None else (fam, rows)
+    probe_ms, probe_launches = fam_mix["probe"]
     if probe_launches:
         def probe_roof(fm, rws):
             pms, pl = fm["probe"]
@@ -942,7 +965,7 @@ def main():
                     "line_granule": {"bytes_per_launch": int(granule), "achieved": round(granule / (avg * 1e-3) / 1e9, 1),
                                      "frac": round(granule / (avg * 1e-3) / 1e9 / 8000.0, 4), "over_algorithmic": round(granule / alg, 2),
                                      "what": "one 64 B index line + 12 B table entry per probe, 8 B per hit written"}}
-        pr = probe_roof(fam, rows)
+        pr = probe_roof(fam_mix, rows_mix)
         per_probe = meta.get("probe_hbm_bytes_per_probe") if (meta_ok and wl in ("c3", "c4", "c3r")) else None
         out["roofline_profile"] = {"bound": "hbm", "kernel": "probe_kernel", "peak": 8000.0, "unit": "GB/s", **pr,
                                    "traffic": int(per_probe * pr["probes_per_launch"]) if per_probe else None,

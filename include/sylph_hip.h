@@ -95,6 +95,9 @@ void sylph_upload_destroy(sylph_upload *u);
  * of the index build (tests lower it to force several passes), "push_chunk_bytes" = bytes of bases per chunk of a host batch
  * (default 64 MiB), "reads_wg_per_cu" = workgroups of the read-per-lane kernel per CU, each looping over blocks of reads
  * ("0".."64"; default 0 = one workgroup per block, measured 10 % faster than 8 looping workgroups per CU).
+ * "profile_only" = "seeds" | "seeds,probe" | ... | "all": the kernel families sylph_ctx_profile times from now on (default all).  A timed
+ * family costs two event records per launch group on its stream — 1 % of a pipelined sample, 4 % of a sample run alone, with all of
+ * them on (profiles/r05_ab_timers.txt): bench.py times only the dominant kernel inside its timed region.
  * "reads_hash" = "0" | "1" | "2" | "-1": how the read-per-lane kernel spells the hash and the threshold test in its k-mer loop —
  * the compiler's own lowering, the hand-scheduled 64-bit one, or the last hash step and the test on the high word only (a superset of
  * the seeds; the kernel's second pass, which hashes every candidate exactly anyway, prunes it); same tables all three, "-1" = the

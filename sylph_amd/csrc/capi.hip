@@ -17,6 +17,16 @@ void set_error(const char* fmt, ...) {
 
 ScopedKernelTimer::ScopedKernelTimer(sylph_ctx* c, const char* family) : ctx(c), fam(family) {
     if (!ctx->profile) return;
+    if (!ctx->profile_only.empty()) {            // ",a,b," holds ",family,"?
+        const size_t n = strlen(family);
+        size_t at = 0;
+        bool found = false;
+        while ((at = ctx->profile_only.find(family, at)) != std::string::npos) {
+            if (ctx->profile_only[at - 1] == ',' && ctx->profile_only[at + n] == ',') { found = true; break; }
+            at += n;
+        }
+        if (!found) return;
+    }
     auto get = [&]() {
         hipEvent_t e;
         if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
@@ -383,6 +393,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= 0 && v <= 64, "reads_wg_per_cu must be in [0, 64]");
             ctx->reads_wg_per_cu = (uint32_t)v;
+        } else if (!strcmp(key, "profile_only")) {
+            // the families sylph_ctx_profile times from now on: "seeds" or "seeds,probe"; "" or "all" = every family.  (Every timed family
+            // costs two event records per launch group on the stream: bench.py keeps only the dominant kernel's in its timed region.)
+            ctx->profile_only = (!value[0] || !strcmp(value, "all")) ? std::string() : "," + std::string(value) + ",";
         } else if (!strcmp(key, "reads_hash")) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= -1 && v <= 2, "reads_hash must be -1 (default), 0, 1 or 2");

@@ -143,6 +143,7 @@ struct sylph_ctx {
     uint32_t fail_next_shard_probe = 0;     // fault injection for the tests ("fail_next_shard_probe"): the next sharded probe on this context throws
     uint32_t index_lambda = 0;              // 0 = the default for the line size (contain_index.h DEFAULT_INDEX_LAMBDA: 4 per 64-byte line); postings per bucket line of a database index aimed for ("index_lambda"; r04: 3 -> 4, 38.5 -> 29.1 GB at GTDB scale for +3 % probe time alone)
     uint64_t index_pass_max = 1ull << 30;   // postings sorted per pass of the index build ("index_pass_max"; tests lower it)
+    std::string profile_only;                 // "profile_only": comma-separated families the kernel timers are limited to ("" = all of them)
     int reads_hash = -1;                      // "reads_hash": the read kernel's hash / threshold spelling, -1 = the build's default (reads.hip)
     uint32_t reads_slack = 0;                 // "reads_slack": tests only — widens the high-word candidate test of reads_hash = 2
     uint32_t reads_wg_per_cu = 0;             // "reads_wg_per_cu": 0 = one workgroup per block of reads (measured best: 0.75 ms vs 0.84 ms with 8 looping workgroups per CU), n = n looping workgroups per CU

@@ -550,6 +550,7 @@ int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* va
         const int rc = sylph_ctx_set_option(cx, key, value);
         if (rc != SYLPH_OK) return rc;
     }
+    if (!strcmp(key, "profile_only")) return sylph_ctx_set_option(p->db->ctx, key, value);   // the profile thread's timers live there
     return SYLPH_OK;
 }
 
