@@ -143,6 +143,13 @@ struct sylph_ctx {
     uint32_t fail_next_shard_probe = 0;     // fault injection for the tests ("fail_next_shard_probe"): the next sharded probe on this context throws
     uint32_t index_lambda = 0;              // 0 = the default for the line size (contain_index.h DEFAULT_INDEX_LAMBDA: 4 per 64-byte line); postings per bucket line of a database index aimed for ("index_lambda"; r04: 3 -> 4, 38.5 -> 29.1 GB at GTDB scale for +3 % probe time alone)
     uint64_t index_pass_max = 1ull << 30;   // postings sorted per pass of the index build ("index_pass_max"; tests lower it)
+    // "One seeding kernel at a time" among the contexts of a pipeline (pipeline.hip arms this before a push, under its seed_mu): the
+    // stream waits for `gate` — the event behind the previous sample's seeding kernel — immediately before ITS seeding kernel, not before
+    // the bookkeeping kernels in front of it, and records `done` immediately behind it: what lies between two samples' seeding kernels
+    // on the GPU is one event and one wait (r05: it was the record-lookup kernel and three more event packets, 50-60 us per sample).
+    struct SeedTurn { hipEvent_t gate = nullptr, done = nullptr; bool recorded = false; } turn;
+    void seed_gate() { if (turn.gate) { (void)hipStreamWaitEvent(stream, turn.gate, 0); turn.gate = nullptr; } }
+    void seed_done() { if (turn.done && !turn.recorded && hipEventRecord(turn.done, stream) == hipSuccess) turn.recorded = true; }
     std::string profile_only;                 // "profile_only": comma-separated families the kernel timers are limited to ("" = all of them)
     int reads_hash = -1;                      // "reads_hash": the read kernel's hash / threshold spelling, -1 = the build's default (reads.hip)
     uint32_t reads_slack = 0;                 // "reads_slack": tests only — widens the high-word candidate test of reads_hash = 2

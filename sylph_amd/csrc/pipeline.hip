@@ -89,6 +89,7 @@ struct sylph_pipeline {
     uint64_t flush_upto = 0;                     // sharded: jobs with seq < flush_upto may go in a partial batch
     bool stop = false;
     // tuning (sylph_pipeline_set_option): see the option table in include/sylph_hip.h
+    std::atomic<uint32_t> serial_outside{0};     // "serialize_outside" = 1: the r01-r04 placement of that wait (A/B; profiles/r05_ab_seed_turn.txt)
     std::atomic<uint32_t> serialize_seeding{1};  // 1 (default, r04: +3 %, profiles/r04_ab_pipeline_sweep.txt): one worker at a time runs its seeding kernel —
                                                  // two VALU-bound seeding kernels side by side only slow each other; the others are in their dedup/count tails
     std::string dedup_fpr, dedup_capacity;       // "dedup_fpr" / "dedup_capacity": handed to every session the pipeline opens (sylph_sketch_set_option; a10.hip)
@@ -132,12 +133,25 @@ struct sylph_pipeline {
                 const sylph_read_batch& b = j->batches[i];
                 std::unique_lock<std::mutex> seed_lock(seed_mu, std::defer_lock);
                 const bool serial = serialize_seeding.load() != 0;      // read ONCE per push: the option may change between the two uses below
+                sylph_ctx* cx = wctx[w];
                 if (serial) {
                     seed_lock.lock();
-                    if (last_seed_ev && last_seed_ev != seed_ev[(size_t)w]) (void)hipStreamWaitEvent(wctx[w]->stream, last_seed_ev, 0);
+                    // the library waits and records around the seeding kernel itself (common.h SeedTurn), not around the whole push
+                    hipEvent_t prev = (last_seed_ev && last_seed_ev != seed_ev[(size_t)w]) ? last_seed_ev : nullptr;
+                    if (serial_outside.load()) {            // A/B knob: rounds 1-4 waited in front of the whole push and recorded behind it
+                        if (prev) (void)hipStreamWaitEvent(cx->stream, prev, 0);
+                    } else {
+                        cx->turn.gate = prev;
+                        cx->turn.done = seed_ev[(size_t)w];
+                        cx->turn.recorded = false;
+                    }
                 }
                 rc = sylph_sketch_push_enc(j->sk, b.bases, b.rec_off, b.n_records, b.n_bases, j->mem, j->enc);
-                if (serial && hipEventRecord(seed_ev[(size_t)w], wctx[w]->stream) == hipSuccess) last_seed_ev = seed_ev[(size_t)w];
+                if (serial) {
+                    // (a push that launched no seeding kernel: nothing to order; one whose kernel did not record: behind the whole push)
+                    if (cx->turn.recorded || hipEventRecord(seed_ev[(size_t)w], cx->stream) == hipSuccess) last_seed_ev = seed_ev[(size_t)w];
+                    cx->turn = sylph_ctx::SeedTurn{};
+                }
             }
         }
         if (rc == SYLPH_OK) rc = sylph_sketch_finish_device(j->sk, &j->dev_k, &j->dev_c, &j->n_table, &j->dup_removed);
@@ -534,6 +548,7 @@ int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* va
     }
     {   // the pipeline's own knobs; everything else goes to the workers' contexts
         if (!strcmp(key, "serialize_seeding")) { p->serialize_seeding.store((uint32_t)strtoul(value, nullptr, 10)); return SYLPH_OK; }
+        if (!strcmp(key, "serialize_outside")) { p->serial_outside.store((uint32_t)strtoul(value, nullptr, 10)); return SYLPH_OK; }
         uint32_t* dst = !strcmp(key, "min_batch") ? &p->min_batch : !strcmp(key, "batch_wait_us") ? &p->batch_wait_us : nullptr;
         if (dst) {                               // (the profile thread reads both with p->mu held)
             std::lock_guard<std::mutex> lk(p->mu);

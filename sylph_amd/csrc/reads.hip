@@ -611,9 +611,11 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
             hipLaunchKernelGGL(block_records_kernel, dim3(grid_for(n_blk + 1)), dim3(256), 0, ctx->stream, d_off, n_records, bias, rt,
                                n_blk + 1, m.blk_rec, m.blk_count + n_blk, reinterpret_cast<uint32_t*>(m.state));
         }
+        ctx->seed_gate();
         {
             ScopedKernelTimer t(ctx, "seeds");
             launch(n_blk, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
+            ctx->seed_done();
         }
         // deferred verdict (sketch_session.h PendingSlots): the caller keeps the batch valid until finish, this is the session's first
         // batch and nothing forces the dense arrays — no block total, no read-back, no wait; finish reads the flags with its own tail

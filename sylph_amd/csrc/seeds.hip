@@ -337,6 +337,7 @@ void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * 8);   // looping workgroups: the staging area is flushed with one global atomic per flush
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
+    ctx->seed_gate();
     ScopedKernelTimer t(ctx, "seeds");
 #define SY_LAUNCH_SEEDS(KK, HH)                                                                                         \
     hipLaunchKernelGGL((seeds_kernel<KK, HH>), dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles, \
@@ -346,6 +347,7 @@ void launch_seeds(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases, uint
     else throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
 #undef SY_LAUNCH_SEEDS
     SY_HIP(hipGetLastError());
+    ctx->seed_done();
 }
 
 
@@ -368,6 +370,7 @@ void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)cus * ctx->reads_wg_per_cu) : n_tiles;
     static const int hv = getenv("SYLPH_HIP_HASH_VARIANT") ? atoi(getenv("SYLPH_HIP_HASH_VARIANT")) : 1;   // tuning knob
+    ctx->seed_gate();
     ScopedKernelTimer t(ctx, "seeds");
 #define SY_LAUNCH_SLOTS(KK, HH)                                                                                              \
     hipLaunchKernelGGL((seeds_slots_kernel<KK, HH>), dim3(grid), dim3(TPB), 0, ctx->stream, d_bases, n_bases, thr, n_tiles, \
@@ -377,6 +380,7 @@ void launch_seeds_slots(sylph_ctx* ctx, const uint8_t* d_bases, uint32_t n_bases
     else throw ArgError{"k must be 21 or 31 (avx2_seeding.rs:46-52)"};
 #undef SY_LAUNCH_SLOTS
     SY_HIP(hipGetLastError());
+    if (!d_tile_list) ctx->seed_done();
 }
 uint32_t seeds_tile_bases() { return TILE_BASES; }
 
