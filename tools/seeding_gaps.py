@@ -37,7 +37,7 @@ def main():
         for s, e, n, q in ev:
             if e <= g0 or s >= g1 or a.kernel in n:
                 continue
-            nm = n.split("(")[0].replace("void ", "").replace("sylph::(anonymous namespace)::", "").replace("sylph::", "")[:40]
+            nm = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("sylph::", "").split("(")[0][:40]
             inside[nm] = inside.get(nm, 0.0) + (min(e, g1) - max(s, g0)) / 1e3
     tot_gap = gaps[gaps > 0].sum()
     print(f"kernel time overlapping the gaps ({tot_gap:.0f} us of gaps in all):")
