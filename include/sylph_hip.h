@@ -98,6 +98,8 @@ void sylph_upload_destroy(sylph_upload *u);
  * "profile_only" = "seeds" | "seeds,probe" | ... | "all": the kernel families sylph_ctx_profile times from now on (default all).  A timed
  * family costs two event records per launch group on its stream — 1 % of a pipelined sample, 4 % of a sample run alone, with all of
  * them on (profiles/r05_ab_timers.txt): bench.py times only the dominant kernel inside its timed region.
+ * "reads_tail_pct" = "0".."50": inside a pipeline's seeding turn (one seeding kernel at a time), the share of a sample's blocks of reads
+ * that is launched separately BEHIND the turn's event, so that the next sample's seeding kernel starts while they run ("0" = one launch).
  * "reads_hash" = "0" | "1" | "2" | "-1": how the read-per-lane kernel spells the hash and the threshold test in its k-mer loop —
  * the compiler's own lowering, the hand-scheduled 64-bit one, or the last hash step and the test on the high word only (a superset of
  * the seeds; the kernel's second pass, which hashes every candidate exactly anyway, prunes it); same tables all three, "-1" = the

@@ -397,6 +397,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             // the families sylph_ctx_profile times from now on: "seeds" or "seeds,probe"; "" or "all" = every family.  (Every timed family
             // costs two event records per launch group on the stream: bench.py keeps only the dominant kernel's in its timed region.)
             ctx->profile_only = (!value[0] || !strcmp(value, "all")) ? std::string() : "," + std::string(value) + ",";
+        } else if (!strcmp(key, "reads_tail_pct")) {
+            const long v = strtol(value, nullptr, 10);
+            SY_REQUIRE(v >= 0 && v <= 50, "reads_tail_pct must be in [0, 50]");
+            ctx->reads_tail_pct = (uint32_t)v;
         } else if (!strcmp(key, "reads_hash")) {
             const long v = strtol(value, nullptr, 10);
             SY_REQUIRE(v >= -1 && v <= 2, "reads_hash must be -1 (default), 0, 1 or 2");

@@ -132,6 +132,9 @@ struct KernelStat { double ms = 0; uint64_t launches = 0; };
 
 }  // namespace sylph
 
+#ifndef SYLPH_READS_TAIL_PCT
+#define SYLPH_READS_TAIL_PCT 0
+#endif
 struct sylph_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -151,6 +154,7 @@ struct sylph_ctx {
     void seed_gate() { if (turn.gate) { (void)hipStreamWaitEvent(stream, turn.gate, 0); turn.gate = nullptr; } }
     void seed_done() { if (turn.done && !turn.recorded && hipEventRecord(turn.done, stream) == hipSuccess) turn.recorded = true; }
     std::string profile_only;                 // "profile_only": comma-separated families the kernel timers are limited to ("" = all of them)
+    uint32_t reads_tail_pct = SYLPH_READS_TAIL_PCT;   // "reads_tail_pct": share of a sample's blocks launched behind its turn's event (pipelines only; 0 = one launch)
     int reads_hash = -1;                      // "reads_hash": the read kernel's hash / threshold spelling, -1 = the build's default (reads.hip)
     uint32_t reads_slack = 0;                 // "reads_slack": tests only — widens the high-word candidate test of reads_hash = 2
     uint32_t reads_wg_per_cu = 0;             // "reads_wg_per_cu": 0 = one workgroup per block of reads (measured best: 0.75 ms vs 0.84 ms with 8 looping workgroups per CU), n = n looping workgroups per CU

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __re
 template <int K, int HV, int ENC>
 __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READS_WAVES, SYLPH_READS_WAVES))) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
                                                      const uint64_t* __restrict__ off, uint64_t n_rec,
-                                                     const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t rt, uint64_t thr,
+                                                     const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t it_begin, uint32_t it_end,
+                                                     uint32_t rt, uint64_t thr,
                                                      uint32_t cand_slack, int avx2_compat, int paired, int want_markers, uint64_t rec_base,
                                                      uint32_t slot_cap, OccRec* __restrict__ slot_rec,
                                                      uint32_t* __restrict__ slot_key, int key_sh,
@@ -171,8 +172,10 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the
     // blocks, so that the halo a block shares with its neighbour is found in the same L2.  (Outputs are indexed by block,
     // so the order of the results does not depend on this mapping.)
-    const uint32_t per_xcd = (n_blk + 7) / 8, n_round = blk_list ? n_blk : per_xcd * 8;
-    for (uint32_t it0 = blockIdx.x; it0 < n_round; it0 += gridDim.x) {
+    // (a launch covers the positions [it_begin, it_end) of that dealing: the pipeline launches a sample's last positions separately, see
+    //  push_short_reads)
+    const uint32_t per_xcd = (n_blk + 7) / 8;
+    for (uint32_t it0 = it_begin + blockIdx.x; it0 < it_end; it0 += gridDim.x) {
         const uint32_t it = blk_list ? it0 : (it0 & 7u) * per_xcd + (it0 >> 3);
         if (it >= n_blk) continue;                                   // padding of the last XCD's range (uniform per workgroup)
         const uint32_t blk = blk_list ? blk_list[it] : it;
@@ -590,11 +593,13 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
     const uint32_t slack = ctx->reads_slack;
     const int hv = (hv_want == 2 && ((thr >> 32) + 1ull + slack) > 0xFFFFFFFFull) ? 1 : hv_want;
     const int key_sh = key_shift(sk->c);
-    auto launch = [&](uint32_t n_it, uint32_t cap, OccRec* sr, uint32_t* skey, const uint32_t* list) {
-        const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(n_it, (uint64_t)cus * ctx->reads_wg_per_cu) : n_it;
+    // positions [it_b, it_e) of the dealing of n_it blocks (reads_kernel)
+    auto launch = [&](uint32_t n_it, uint32_t it_b, uint32_t it_e, uint32_t cap, OccRec* sr, uint32_t* skey, const uint32_t* list) {
+        if (it_e <= it_b) return;
+        const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(it_e - it_b, (uint64_t)cus * ctx->reads_wg_per_cu) : it_e - it_b;
 #define SY_LAUNCH_READS(KK, HH, EE)                                                                                                   \
     hipLaunchKernelGGL((reads_kernel<KK, HH, EE>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
-                       m.blk_rec, n_it, rt, thr, slack, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr, skey, key_sh,   \
+                       m.blk_rec, n_it, it_b, it_e, rt, thr, slack, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr, skey, key_sh,   \
                        m.blk_count, m.state, list, m.spill_slot)
         if (enc == SYLPH_ENC_2BIT) {
             if (sk->k == 31) { if (hv == 2) SY_LAUNCH_READS(31, 2, 1); else SY_LAUNCH_READS(31, 1, 1); }
@@ -614,8 +619,16 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         ctx->seed_gate();
         {
             ScopedKernelTimer t(ctx, "seeds");
-            launch(n_blk, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
+            // In a pipeline's turn the sample's last positions are a launch of their own and the turn's event sits in front of it: the next
+            // sample's kernel starts while this one's last workgroups drain (two seeding kernels share the chip for those few per cent of
+            // one — the work is the same, the event-to-wait latency and the drain of a 26,000-workgroup grid are not paid between them).
+            const uint32_t n_round = ((n_blk + 7) / 8) * 8;
+            uint32_t cut = n_round;
+            if (ctx->turn.done && !ctx->turn.recorded && ctx->reads_tail_pct && n_round >= 64)
+                cut = (uint32_t)((uint64_t)n_round * (100 - ctx->reads_tail_pct) / 100) & ~7u;
+            launch(n_blk, 0, cut, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
             ctx->seed_done();
+            launch(n_blk, cut, n_round, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
         }
         // deferred verdict (sketch_session.h PendingSlots): the caller keeps the batch valid until finish, this is the session's first
         // batch and nothing forces the dense arrays — no block total, no read-back, no wait; finish reads the flags with its own tail
@@ -661,7 +674,7 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         OccRec* xr = b_x.as<OccRec>();
         ScopedKernelTimer ts(ctx, "seeds_spill");
         ScopedKernelTimer t(ctx, "seeds");
-        launch(res[2], spill_cap, xr, nullptr, m.state->spill.tiles);
+        launch(res[2], 0, res[2], spill_cap, xr, nullptr, m.state->spill.tiles);
         sp_r = xr;
     }
     compact_region(sk, n_blk, slot_cap, n, spill_cap, sp_r);

@@ -79,6 +79,40 @@ def test_pipeline_matches_oracle_in_submission_order(ctx, workers, depth, max_ba
     db.close()
 
 
+@pytest.mark.parametrize("tail_pct", [0, 10, 50])
+def test_pipeline_seeding_turns_and_the_tail_launch(ctx, tail_pct):
+    """One seeding kernel at a time (common.h SeedTurn): a worker's stream waits for the previous sample's seeding kernel right in front
+    of its own, and with "reads_tail_pct" the last share of a sample's blocks is a launch of its own behind the turn's event (the next
+    sample's kernel starts while it runs).  Samples of ~100 blocks of reads through three workers, exact set and default pair dedup,
+    the old placement of the wait too ("serialize_outside"): every table and result equal to the oracle's, in submission order."""
+    import torch
+    rng, genomes, db_k, goff = small_world(11)
+    db = S.Database(ctx, db_k, goff)
+    samples = []
+    for i in range(6):
+        b, off = sample_reads(rng, genomes, [i % 5, (i + 2) % 5], 6000 + 500 * (i % 3))
+        samples.append((b, off))
+    dev = [(torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()) for b, off in samples]
+    torch.cuda.synchronize()
+    for fpr, outside in ((None, 0), (1e-4, 0), (None, 1)):
+        exp = [O.sketch_reads(b, off, c=50, paired=True) if fpr is None else O.sketch_reads_cuckoo_model(b, off, c=50, fpr=fpr) for b, off in samples]
+        p = S.Pipeline(db, c=50, paired=True, n_workers=3, depth=6, max_batch=4, want_table=True)
+        p.set_option("reads_tail_pct", tail_pct)
+        p.set_option("serialize_outside", outside)
+        if fpr is not None:
+            p.set_option("dedup_fpr", fpr)
+        for rnd in range(2):
+            for i, (tb, toff) in enumerate(dev):
+                assert p.submit_device([(tb.data_ptr(), toff.data_ptr(), len(samples[i][1]) - 1, int(samples[i][1][-1]))], tag=i)
+            for i in range(len(dev)):
+                r = p.next()
+                assert r["tag"] == i
+                check_result(r, exp[i], db_k, goff)
+                assert np.array_equal(r["kmers"], exp[i]["kmers"]) and np.array_equal(r["counts"], exp[i]["counts"])
+        p.close()
+    db.close()
+
+
 def test_pipeline_with_the_default_pair_dedup(ctx):
     """sylph_pipeline_set_option("dedup_fpr"): every session the pipeline opens from then on deduplicates its pairs behind the
     cuckoo filter (sketch.rs:733-769; csrc/a10.hip) — the samples' tables, duplicate counts and containment rows must be the oracle's
