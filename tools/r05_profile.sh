@@ -64,6 +64,7 @@ python tools/multi_gpu_pipeline_bench.py --gpus 2 --share > $out/multi_pipeline_
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_p -o c3 -- python bench.py --steps 4 --warmup 1 --min-seconds 0.3 --mode pipelined --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-packed-leg --no-filter-leg --no-files-leg > $out/bench_prof.json 2> $out/prof.err
 f=$(find $out/stats_p -name '*kernel_trace.csv' | head -1)
 python tools/step_timeline.py $f --steps 60 --anchor reads_kernel --summary-only > $out/kernels_pipelined.md
+{ echo; echo "## how the seeding kernels of consecutive samples follow each other (tools/seeding_gaps.py over the same trace)"; echo; python tools/seeding_gaps.py $f --last 200 | sed 's/^/    /'; } >> $out/kernels_pipelined.md
 rm -rf $out/stats_p
 # (b) one sample at a time: the dispatch sequence of a sample with its gaps, every kernel alone on the GPU
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o c3 -- python bench.py --steps 3 --warmup 1 --min-seconds 0.02 --mode sequential --no-second-leg --no-cpu-baseline --no-h2d --no-verify --no-packed-leg --no-filter-leg --no-files-leg > $out/bench_prof_seq.json 2>> $out/prof.err
@@ -77,6 +78,10 @@ f=$(find $out/stats_f -name '*kernel_trace.csv' | head -1)
 python tools/step_timeline.py $f --steps 5 --anchor reads_kernel > $out/step_timeline_filter.md
 find $out/stats_f -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats_filter.csv \;
 rm -rf $out/stats_f
+# a 30-second run of the sample loop (35,000 samples): no drift, no growth
+python bench.py --steps 40 --warmup 2 --min-seconds 30 --no-cpu-baseline --no-h2d --no-packed-leg --no-filter-leg --no-files-leg --no-second-leg --no-verify > $out/bench_long_run.json 2> $out/bench_long_run.err
+# R05_SKIP_HOST=1 (the refresh at the round's last kernel sources): the host-side legs below did not change, their outputs stay
+[ -n "$R05_SKIP_HOST" ] && exit 0
 python tools/feed_bench.py 3333334 > $out/feed.txt 2> $out/feed.err
 d=/tmp/feed_bench
 ( for rep in 1 2; do echo "== plain pair, run $rep"; ( time env SYLPH_HIP_FEED_TRACE=1 sylph_amd/sylph-hip sketch -1 $d/s_1.fq -2 $d/s_2.fq -d $d/out ) 2>&1 | grep -v "pgunzip\]" | head -60; done
