@@ -34,6 +34,7 @@ extern "C" {
 #define SYLPH_ERR_HIP (-2)       /* HIP runtime error */
 #define SYLPH_ERR_NOMEM (-3)
 #define SYLPH_ERR_STATE (-4)     /* call made in the wrong session state */
+#define SYLPH_ERR_FORMAT (-5)    /* the input is not what this entry point parses (sylph_fastq_index): read it with the host reader */
 
 /* Which k-mers of a sequence are hashed.
  * SYLPH_SEED_SCALAR      = seeding.rs:86-146 fmh_seeds (every k-mer).
@@ -194,6 +195,26 @@ int sylph_sketch_push_n(sylph_sketch *sk, const uint8_t *bases, const uint64_t *
 int sylph_sketch_push_enc(sylph_sketch *sk, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_records, uint64_t n_bases,
                           int mem, int enc);
 int sylph_pack_2bit(const uint8_t *ascii, uint64_t n, uint8_t *out);
+
+/* ---- plain four-line FASTQ text, parsed on the device (csrc/fastq.hip) ------------------------------------------------------
+ * Replaces the record loop of sketch.rs:775-815 / :897-921 (needletail parse_fastx_file + next()) for uncompressed FASTQ: the TEXT
+ * goes to the device (`mem` says where it lies now; host text is copied by the call, SYLPH_MEM_DEVICE text is borrowed until
+ * sylph_fastq_destroy and must be readable from 16 bytes below `text` rounded down to 16 up to 16 bytes past its end, like a device
+ * batch of sylph_sketch_push), the library finds the records — lines 4r .. 4r+3 = '@' line, sequence, '+' line, quality of the
+ * sequence's length; a '\r' in front of a newline is not part of its line; blank space behind the last record is ignored — and
+ * sylph_sketch_push_fastq gathers the sequences of records [first, first + n_items) into a batch of the session and sketches it
+ * (a paired session takes the two mates' texts: item i = record i of `a`, then record i of `b`; the caller pushes min(n_a, n_b)
+ * items, sketch.rs:813-815).  At most 2^32 - 65 bases and 2^31 - 1 records per push.  Returns SYLPH_ERR_FORMAT — and nothing
+ * else happens — when the text is not exactly that (multi-line FASTQ, FASTA, a damaged record, no text): the caller then reads the
+ * file with its own reader, whose record and error semantics are the reference's.  sylph_fastq_lengths copies the sequence
+ * lengths of records [first, first + n) to the host: the reference's running mean of the read lengths (sketch.rs:941-943,
+ * :825-826) is sequential f64 arithmetic in file order and stays there. */
+typedef struct sylph_fastq sylph_fastq;
+int sylph_fastq_index(sylph_ctx *ctx, const void *text, uint64_t n_bytes, int mem, sylph_fastq **out);
+int sylph_fastq_counts(const sylph_fastq *f, uint64_t *n_records, uint64_t *n_bases);
+int sylph_fastq_lengths(sylph_fastq *f, uint64_t first, uint64_t n, uint32_t *out);
+int sylph_sketch_push_fastq(sylph_sketch *sk, sylph_fastq *a, sylph_fastq *b, uint64_t first, uint64_t n_items);
+void sylph_fastq_destroy(sylph_fastq *f);
 
 /* Finish the sample: (k-mer, count) table in ascending k-mer order == SequencesSketch.kmer_counts
  * (types.rs:145-155) as a keyed multiset, and the number of occurrences removed as duplicates

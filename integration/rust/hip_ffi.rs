@@ -5,6 +5,7 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct SylphSketch { _p: [u8; 0] }
 #[repr(C)] pub struct SylphDb { _p: [u8; 0] }
 #[repr(C)] pub struct SylphComm { _p: [u8; 0] }
+#[repr(C)] pub struct SylphFastq { _p: [u8; 0] }
 #[repr(C)] pub struct SylphUpload { _p: [u8; 0] }
 #[repr(C)] pub struct SylphSampleRef { pub kmers: *const u64, pub counts: *const u32, pub n: u64 }   // one sorted (k-mer, count) table
 #[repr(C)] pub struct SylphCommOps {   // caller-supplied collectives on device buffers (stream = hipStream_t); 0 = success
@@ -114,6 +115,13 @@ extern "C" {
     pub fn sylph_sketch_push_enc(sk: *mut SylphSketch, bases: *const u8, rec_off: *const u64, n_records: u64, n_bases: u64,
                                  mem: c_int, enc: c_int) -> c_int;
     pub fn sylph_pack_2bit(ascii: *const u8, n: u64, out: *mut u8) -> c_int;
+    // plain four-line FASTQ text parsed on the device (needletail's record loop, sketch.rs:775-815 / :897-921, for uncompressed FASTQ):
+    // index the text (ERR_FORMAT = -5: not that, keep the needletail loop), read the lengths back for the running mean, push records
+    pub fn sylph_fastq_index(ctx: *mut SylphCtx, text: *const c_void, n_bytes: u64, mem: c_int, out: *mut *mut SylphFastq) -> c_int;
+    pub fn sylph_fastq_counts(f: *const SylphFastq, n_records: *mut u64, n_bases: *mut u64) -> c_int;
+    pub fn sylph_fastq_lengths(f: *mut SylphFastq, first: u64, n: u64, out: *mut u32) -> c_int;
+    pub fn sylph_sketch_push_fastq(sk: *mut SylphSketch, a: *mut SylphFastq, b: *mut SylphFastq, first: u64, n_items: u64) -> c_int;
+    pub fn sylph_fastq_destroy(f: *mut SylphFastq);
     // k-mer-range shards: bounds for `world` GPUs, upload of this rank's range, communicator, the collective batch call
     pub fn sylph_shard_bounds(max_kmer: u64, world: u32, bounds: *mut u64) -> c_int;
     pub fn sylph_db_upload_shard(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,

@@ -35,7 +35,8 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_pipeline_destroy", "sylph_db_exchange_stats", "sylph_sketch_set_option",
            "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_destroy",
            "sylph_db_replicate", "sylph_pipeline_create_multi", "sylph_pipeline_replica_of_last", "sylph_device_count",
-           "sylph_genome_shard_bounds", "sylph_db_upload_genome_shard"]
+           "sylph_genome_shard_bounds", "sylph_db_upload_genome_shard",
+           "sylph_fastq_index", "sylph_fastq_counts", "sylph_fastq_lengths", "sylph_sketch_push_fastq", "sylph_fastq_destroy"]
 
 
 def load():
@@ -71,6 +72,12 @@ def load():
     L.sylph_sketch_push.argtypes = [vp, vp, vp, u64, i32]
     L.sylph_sketch_push_n.argtypes = [vp, vp, vp, u64, u64, i32]
     L.sylph_sketch_push_enc.argtypes = [vp, vp, vp, u64, u64, i32, i32]
+    L.sylph_fastq_index.argtypes = [vp, vp, u64, i32, P(vp)]
+    L.sylph_fastq_counts.argtypes = [vp, P(u64), P(u64)]
+    L.sylph_fastq_lengths.argtypes = [vp, u64, u64, vp]
+    L.sylph_sketch_push_fastq.argtypes = [vp, vp, vp, u64, u64]
+    L.sylph_fastq_destroy.argtypes = [vp]
+    L.sylph_fastq_destroy.restype = None
     L.sylph_pack_2bit.argtypes = [vp, u64, vp]
     L.sylph_sketch_finish.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
     L.sylph_sketch_finish_device.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
@@ -125,6 +132,9 @@ def load():
 def _check(rc):
     if rc != 0:
         raise SylphHipError(rc, load().sylph_last_error().decode("utf-8", "replace"))
+
+
+ERR_FORMAT = -5
 
 
 def _np(a, dtype):
@@ -256,6 +266,43 @@ class PinnedBuffer:
             pass
 
 
+class FastqText:
+    """sylph_fastq_*: plain four-line FASTQ text whose records the DEVICE finds (csrc/fastq.hip).  `text`: bytes / a uint8 array
+    (MEM_HOST), or an integer address with n_bytes (MEM_HOST_PINNED / MEM_DEVICE; device text is borrowed until close()).
+    Raises SylphHipError with code ERR_FORMAT when the text is not exactly that: parse it on the host then."""
+
+    def __init__(self, ctx, text, mem=MEM_HOST, n_bytes=None):
+        self._h = None
+        h = C.c_void_p()
+        if mem == MEM_HOST:
+            self._keep = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else _np(text, np.uint8)
+            _check(load().sylph_fastq_index(ctx._h, _ptr(self._keep) if len(self._keep) else None, len(self._keep), mem, C.byref(h)))
+            self._keep = None
+        else:
+            _check(load().sylph_fastq_index(ctx._h, C.c_void_p(int(text)), int(n_bytes), mem, C.byref(h)))
+        self._h = h
+        nr, nb = C.c_uint64(0), C.c_uint64(0)
+        _check(load().sylph_fastq_counts(self._h, C.byref(nr), C.byref(nb)))
+        self.n_records, self.n_bases = int(nr.value), int(nb.value)
+
+    def lengths(self, first=0, n=None):
+        n = self.n_records - first if n is None else n
+        out = np.zeros(n, dtype=np.uint32)
+        _check(load().sylph_fastq_lengths(self._h, int(first), int(n), _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            load().sylph_fastq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ReadSketcher:
     """Session for one sample: sketch_sequences_needle (sketch.rs:897) / sketch_pair_sequences (sketch.rs:771).  dedup_fpr = 0: the
     exact pair set (--fpr 0, sketch.rs:690-731); > 0 (paired sessions): the reference's default, the set behind a scalable cuckoo
@@ -304,6 +351,12 @@ class ReadSketcher:
             _check(load().sylph_sketch_push_enc(self._h, _ptr(a) if len(a) else None, _ptr(off), len(off) - 1, int(n_bases), mem, enc))
         else:
             _check(load().sylph_sketch_push_enc(self._h, C.c_void_p(int(bases)), C.c_void_p(int(rec_off)), int(n_records), int(n_bases), mem, enc))
+
+    def push_fastq(self, a, b=None, first=0, n_items=None):
+        """sylph_sketch_push_fastq: records [first, first + n_items) of the FastqText `a` (and of `b`, the mates, in a paired session)."""
+        if n_items is None:
+            n_items = (min(a.n_records, b.n_records) if b is not None else a.n_records) - first
+        _check(load().sylph_sketch_push_fastq(self._h, a._h, b._h if b is not None else None, int(first), int(n_items)))
 
     def finish(self):
         ok, oc, n, d = C.c_void_p(), C.c_void_p(), C.c_uint64(0), C.c_uint64(0)

@@ -88,12 +88,13 @@ struct sylph_sketch {
     sylph::DevBuf slot_rec, slot_key, slot_meta;   // reads.hip: per-block occurrence slots (OccRec | 32-bit bucket key) and block tables
     sylph::PendingSlots pend;
     sylph::DevBuf batch_ascii;            // a packed batch expanded to ASCII for the position-kernel path
+    sylph::DevBuf fq_bases, fq_off;       // fastq.hip: the batch sylph_sketch_push_fastq gathered from FASTQ text (valid until the next such push)
     sylph::DevBuf out_k, out_c;           // final table
     uint64_t n_out = 0, dup_removed = 0;
     sylph::DevBuf counters;               // [0] survivors (u32 @0), [1] n_valid (u64 @8), [2] removed (u64 @16)
     sylph::DevBuf a10_tail;               // a10.hip: verdict words of the partitioned pass (see a10_state)
     explicit sylph_sketch(sylph_ctx* cx)
         : ctx(cx), hash(cx), recs(cx), slot_bases{sylph::DevBuf(cx), sylph::DevBuf(cx)}, slot_off{sylph::DevBuf(cx), sylph::DevBuf(cx)},
-          slot_rec(cx), slot_key(cx), slot_meta(cx), batch_ascii(cx), out_k(cx), out_c(cx), counters(cx), a10_tail(cx) {}
+          slot_rec(cx), slot_key(cx), slot_meta(cx), batch_ascii(cx), fq_bases(cx), fq_off(cx), out_k(cx), out_c(cx), counters(cx), a10_tail(cx) {}
 };
 
