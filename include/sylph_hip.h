@@ -84,6 +84,9 @@ int sylph_upload_begin(sylph_ctx *ctx, uint64_t bytes, uint64_t chunk_bytes, syl
 int sylph_upload_chunk(sylph_upload *u, void **chunk, uint64_t *cap);
 int sylph_upload_commit(sylph_upload *u, uint64_t n);
 int sylph_upload_finish(sylph_upload *u, const void **device_ptr);
+/* The same uploader for another `bytes` bytes (a feed that sends one sample's text after the other): chunks, stream and — where it
+ * is large enough — the device buffer are kept; the pointer sylph_upload_finish returned before is no longer valid. */
+int sylph_upload_restart(sylph_upload *u, uint64_t bytes);
 void sylph_upload_destroy(sylph_upload *u);
 
 /* Tuning / test knobs (not needed for normal use).  "finish" = "auto" (default: bucket partition + in-LDS replay,

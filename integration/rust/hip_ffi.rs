@@ -56,6 +56,7 @@ extern "C" {
     pub fn sylph_upload_chunk(u: *mut SylphUpload, chunk: *mut *mut c_void, cap: *mut u64) -> c_int;
     pub fn sylph_upload_commit(u: *mut SylphUpload, n: u64) -> c_int;
     pub fn sylph_upload_finish(u: *mut SylphUpload, device_ptr: *mut *const c_void) -> c_int;
+    pub fn sylph_upload_restart(u: *mut SylphUpload, bytes: u64) -> c_int;   // the same chunks / stream / buffer for the next text
     pub fn sylph_upload_destroy(u: *mut SylphUpload);
     // "borrow_until_finish" = "1": device batches stay valid until finish -> one host round trip per sample instead of two
     // "dedup_fpr" = "<f>" (pairs, before the first push): dup_removal_lsh_full (sketch.rs:733-769) over a cuckoo filter of that

@@ -33,7 +33,7 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_pipeline_create", "sylph_pipeline_submit", "sylph_pipeline_submit_session", "sylph_pipeline_flush", "sylph_pipeline_next",
            "sylph_pipeline_outstanding", "sylph_pipeline_set_option", "sylph_pipeline_profile", "sylph_pipeline_kernel_stats",
            "sylph_pipeline_destroy", "sylph_db_exchange_stats", "sylph_sketch_set_option",
-           "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_destroy",
+           "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_restart", "sylph_upload_destroy",
            "sylph_db_replicate", "sylph_pipeline_create_multi", "sylph_pipeline_replica_of_last", "sylph_device_count",
            "sylph_genome_shard_bounds", "sylph_db_upload_genome_shard",
            "sylph_fastq_index", "sylph_fastq_counts", "sylph_fastq_lengths", "sylph_sketch_push_fastq", "sylph_fastq_destroy"]

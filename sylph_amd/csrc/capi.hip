@@ -349,6 +349,26 @@ int sylph_upload_finish(sylph_upload* u, const void** device_ptr) {
     });
 }
 
+// the same uploader once more (a feed that sends one sample's text after the other): the page-locked chunks, the stream and — where
+// it is large enough — the device buffer stay; what the previous round uploaded is no longer valid
+int sylph_upload_restart(sylph_upload* u, uint64_t bytes) {
+    return guarded([&] {
+        SY_REQUIRE(u, "null argument");
+        SY_REQUIRE_STATE(u->cur < 0, "sylph_upload_restart: a chunk is still out");
+        DeviceGuard dg(u->ctx->device);
+        SY_HIP(hipStreamSynchronize(u->stream));
+        if (bytes + 64 > u->dev.cap) {
+            SY_HIP(hipStreamSynchronize(u->ctx->stream));      // kernels of the context may still read the old buffer
+            u->dev.release();
+            u->dev.alloc(bytes + bytes / 8 + 64);
+        }
+        u->bytes = bytes;
+        u->at = 0;
+        u->used[0] = u->used[1] = false;
+        u->next = 0;
+    });
+}
+
 void sylph_upload_destroy(sylph_upload* u) {
     if (!u) return;
     (void)hipSetDevice(u->ctx->device);

@@ -195,6 +195,9 @@ Engine::~Engine() {
     if (ctx_) sylph_ctx_destroy(ctx_);
 }
 
+#ifndef SYLPH_HOST_FEED_DEVICE_DEFAULT
+#define SYLPH_HOST_FEED_DEVICE_DEFAULT 0
+#endif
 namespace {
 // Uncompressed 4-line FASTQ (the common case): the files are indexed by parse_threads() workers, whole batches are gathered
 // into page-locked memory in parallel and pushed; the record loop of the reference shrinks to its one sequential piece, the
@@ -314,6 +317,78 @@ void sketch_indexed(Engine& e, const std::function<sylph_sketch*()>& open_sessio
     lap("running mean (joined)");
 }
 
+// Round 5, the device-side route for plain FASTQ (csrc/fastq.hip): the files' TEXT goes to the device through the engine's uploader and
+// the library finds the records there; the host keeps the one sequential piece (the running mean of the mate-1 read lengths, from the
+// lengths the device hands back).  Taken for every sample whose engine is already up — a process's FIRST sample is indexed and gathered
+// on the host while the GPU runtime initialises, which no device can do — unless SYLPH_HIP_FEED_DEVICE=0.  Returns false, having pushed
+// nothing, when the files are not plain four-line FASTQ (SYLPH_ERR_FORMAT, gzip, FASTA): the caller takes the host route, whose
+// record and error semantics are needletail's.
+bool device_feed_enabled() {
+    static const bool on = [] { const char* e = getenv("SYLPH_HIP_FEED_DEVICE"); return e ? atoi(e) != 0 : SYLPH_HOST_FEED_DEVICE_DEFAULT != 0; }();
+    return on && !getenv("SYLPH_HIP_SEQUENTIAL_FEED");
+}
+bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& open_session, const std::string& f1, const std::string* f2,
+                            double& mean_read_length) {
+    if (!device_feed_enabled() || !e.ready()) return false;
+    static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const double t = now();
+        fprintf(stderr, "[sylph_hip feed] %-28s %8.3f ms\n", what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
+    sylph_ctx* ctx = e.context();
+    std::vector<std::string> files{f1};
+    if (f2) files.push_back(*f2);
+    std::vector<TextUploader::Text> texts;
+    if (!e.text.send(ctx, files, parse_threads(), texts)) return false;
+    lap("device route: text uploaded");
+    struct Fq { sylph_fastq* f = nullptr; ~Fq() { sylph_fastq_destroy(f); } } fa, fb;
+    auto index = [&](const TextUploader::Text& t, Fq& out) {
+        const int rc = sylph_fastq_index(ctx, t.dev, t.bytes, SYLPH_MEM_DEVICE, &out.f);
+        if (rc == SYLPH_ERR_FORMAT) return false;
+        hip_check(rc, "sylph_fastq_index");
+        return true;
+    };
+    if (!index(texts[0], fa) || (f2 && !index(texts[1], fb))) return false;
+    uint64_t na = 0, nb = 0, bases_a = 0, bases_b = 0;
+    hip_check(sylph_fastq_counts(fa.f, &na, &bases_a), "sylph_fastq_counts");
+    if (f2) hip_check(sylph_fastq_counts(fb.f, &nb, &bases_b), "sylph_fastq_counts");
+    const uint64_t n = f2 ? std::min(na, nb) : na;                         // lock-step readers: sketch.rs:813-815
+    lap("device route: records found");
+    std::vector<uint32_t> la(n), lb;
+    hip_check(sylph_fastq_lengths(fa.f, 0, n, la.data()), "sylph_fastq_lengths");
+    // the one sequential piece of the reference's record loop (f64, file order: sketch.rs:941-943, :825-826), on its own thread
+    double mean = 0.;
+    std::thread tm([&] { double counter = 0.; for (uint64_t i = 0; i < n; i++) { counter += 1.; mean = mean + ((double)la[i] - mean) / counter; } });
+    ThreadJoiner jm{tm};
+    // pushes of whole records (pairs) below 2^31 bases and 2^30 items: one for anything up to ~2 Gbp
+    std::vector<std::pair<uint64_t, uint64_t>> pushes;
+    if (bases_a + bases_b < (1ull << 31) && n < (1ull << 30)) {
+        if (n) pushes.emplace_back(0, n);
+    } else {
+        if (f2) { lb.resize(n); hip_check(sylph_fastq_lengths(fb.f, 0, n, lb.data()), "sylph_fastq_lengths"); }
+        uint64_t i0 = 0, sum = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t l = (uint64_t)la[i] + (f2 ? lb[i] : 0);
+            if (i > i0 && (sum + l >= (1ull << 31) || i - i0 >= (1ull << 30))) { pushes.emplace_back(i0, i - i0); i0 = i; sum = 0; }
+            sum += l;
+        }
+        if (n > i0) pushes.emplace_back(i0, n - i0);
+    }
+    sylph_sketch* const sk = open_session();
+    e.batch.flush(sk);
+    // one push: the batch is the session's own buffer, valid until finish — the seeding verdict may wait for it (one host round trip less)
+    if (pushes.size() == 1) hip_check(sylph_sketch_set_option(sk, "borrow_until_finish", "1"), "sylph_sketch_set_option");
+    for (const auto& p : pushes) hip_check(sylph_sketch_push_fastq(sk, fa.f, f2 ? fb.f : nullptr, p.first, p.second), "sylph_sketch_push_fastq");
+    lap("device route: pushed");
+    tm.join();
+    mean_read_length = mean;
+    return true;
+}
+
 // The index of the NEXT sample's files is built on a background thread while the current sample is gathered and pushed
 // (the files of a sample are independent of everything before them).  get(j) hands over what start(j) began — or builds it
 // now; at most `ahead` samples are in flight, so the memory of their mappings and index arrays stays bounded.
@@ -369,11 +444,11 @@ namespace {
 // the block-parallel feed)
 std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
                                                             std::optional<std::string> sample_name, bool no_dedup,
-                                                            std::optional<IndexedInput>* pre, sylph_sketch** keep = nullptr);
+                                                            std::optional<IndexedInput>* pre, sylph_sketch** keep = nullptr, bool try_device = false);
 std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                           uint64_t c, uint64_t k, std::optional<std::string> sample_name,
                                                           bool no_dedup, double dedup_fpr, std::optional<IndexedInput>* pre,
-                                                          sylph_sketch** keep = nullptr);
+                                                          sylph_sketch** keep = nullptr, bool try_device = false);
 }  // namespace
 
 // sketch.rs:897-959
@@ -384,7 +459,19 @@ std::optional<SequencesSketch> sketch_sequences_needle(Engine& e, const std::str
 namespace {
 std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
                                                             std::optional<std::string> sample_name, bool no_dedup,
-                                                            std::optional<IndexedInput>* pre, sylph_sketch** keep) {
+                                                            std::optional<IndexedInput>* pre, sylph_sketch** keep, bool try_device) {
+    if (try_device) {
+        std::optional<Session> so;
+        double mean = 0.;
+        if (sketch_fastq_on_device(e, [&] { so.emplace(e, c, k, false, no_dedup); return so->sk; }, read_file, nullptr, mean)) {
+            SequencesSketch out;
+            so->finish_or_keep(out, keep);
+            out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
+            out.sample_name = std::move(sample_name);
+            out.mean_read_length = mean;
+            return out;
+        }
+    }
     std::optional<IndexedInput> own;
     if (!pre) { own = index_inputs(read_file, nullptr); pre = &own; }
     if (auto& in = *pre) {   // uncompressed 4-line FASTQ: block-parallel feed
@@ -437,7 +524,19 @@ namespace {
 std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::string& read_file1, const std::string& read_file2,
                                                           uint64_t c, uint64_t k, std::optional<std::string> sample_name,
                                                           bool no_dedup, double dedup_fpr, std::optional<IndexedInput>* pre,
-                                                          sylph_sketch** keep) {
+                                                          sylph_sketch** keep, bool try_device) {
+    if (try_device) {
+        std::optional<Session> so;
+        double mean = 0.;
+        if (sketch_fastq_on_device(e, [&] { so.emplace(e, c, k, true, no_dedup, dedup_fpr); return so->sk; }, read_file1, &read_file2, mean)) {
+            SequencesSketch out;
+            so->finish_or_keep(out, keep);
+            out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;
+            out.sample_name = std::move(sample_name);
+            out.mean_read_length = mean;
+            return out;
+        }
+    }
     std::optional<IndexedInput> own;
     if (!pre) { own = index_inputs(read_file1, &read_file2); pre = &own; }
     if (auto& in = *pre) {
@@ -680,12 +779,16 @@ int sketch(Engine& e, const SketchArgs& args) {
     std::atomic<size_t> indexes_obtained{0};
     set_no_more_inflates(false);
     auto run_job = [&](Engine& eng, size_t j) {
-        std::optional<IndexedInput> pre = ahead.get(j);
-        trace_mark("sketch: the sample's files are indexed (or not indexable)");
+        // an engine that is up takes plain FASTQ by the device route (no host index at all); its first sample, whose index is built while
+        // the GPU runtime initialises, and everything the device route declines go the host way
+        const bool dev = device_feed_enabled() && eng.ready();
+        std::optional<IndexedInput> pre;
+        if (!dev) pre = ahead.get(j);
+        trace_mark(dev ? "sketch: the sample goes the device route" : "sketch: the sample's files are indexed (or not indexable)");
         if (++indexes_obtained == n_jobs) set_no_more_inflates(true);   // nobody will want a recycled inflate buffer any more
         // the index goes (2 x 1 GB of mappings to unmap / inflated copies to hand back: 30-60 ms per sample) on a thread of its own, behind the sample
         struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) background([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }); } } later{pre};
-        ahead.start(j + n_workers);
+        if (!device_feed_enabled()) ahead.start(j + n_workers);
         const auto t_job = std::chrono::steady_clock::now();
         auto timing = [&](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_job).count();
@@ -699,7 +802,7 @@ int sketch(Engine& e, const SketchArgs& args) {
         if (j < first_pairs.size()) {                                        // :311-367
             std::optional<std::string> sample_name;
             if (sample_names) sample_name = (*sample_names)[j];
-            auto sk = sketch_pair_sequences_impl(eng, first_pairs[j], second_pairs[j], args.c, args.k, sample_name, args.no_dedup, pair_fpr, &pre);
+            auto sk = sketch_pair_sequences_impl(eng, first_pairs[j], second_pairs[j], args.c, args.k, sample_name, args.no_dedup, pair_fpr, dev ? nullptr : &pre, nullptr, dev);
             if (!sk) return;
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
@@ -712,7 +815,7 @@ int sketch(Engine& e, const SketchArgs& args) {
             const size_t i = j - first_pairs.size();
             std::optional<std::string> sample_name;
             if (sample_names) sample_name = (*sample_names)[j];
-            auto sk = sketch_sequences_needle_impl(eng, read_inputs[i], args.c, args.k, sample_name, args.no_dedup, &pre);
+            auto sk = sketch_sequences_needle_impl(eng, read_inputs[i], args.c, args.k, sample_name, args.no_dedup, dev ? nullptr : &pre, nullptr, dev);
             if (!sk) return;
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + SAMPLE_FILE_SUFFIX;
@@ -1182,12 +1285,14 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                 } else if (genome_k != args.k) {
                     fprintf(stderr, "ERROR [sylph_hip] %s -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.k, (unsigned long long)genome_k);
                 } else {
-                    std::optional<IndexedInput> pre = ahead.get(j);
+                    const bool dev = device_feed_enabled() && eng.ready();      // (see sketch(): the device route for plain FASTQ)
+                    std::optional<IndexedInput> pre;
+                    if (!dev) pre = ahead.get(j);
                     if (++indexes_obtained == n_raw) set_no_more_inflates(true);
                     struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) background([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }); } } later{pre};
-                    ahead.start(j + n_workers);
-                    if (files.size() == 1) pr.meta = sketch_sequences_needle_impl(eng, files[0], args.c, args.k, std::nullopt, false, &pre, &pr.session);
-                    else pr.meta = sketch_pair_sequences_impl(eng, files[0], files[1], args.c, args.k, std::nullopt, false, raw_pair_fpr, &pre, &pr.session);
+                    if (!device_feed_enabled()) ahead.start(j + n_workers);
+                    if (files.size() == 1) pr.meta = sketch_sequences_needle_impl(eng, files[0], args.c, args.k, std::nullopt, false, dev ? nullptr : &pre, &pr.session, dev);
+                    else pr.meta = sketch_pair_sequences_impl(eng, files[0], files[1], args.c, args.k, std::nullopt, false, raw_pair_fpr, dev ? nullptr : &pre, &pr.session, dev);
                 }
             } catch (...) { pr.error = std::current_exception(); }
             promises[j].set_value(std::move(pr));

@@ -681,6 +681,62 @@ void PinnedBatch::gather_into(Packed& p, const FastqIndex& a, const FastqIndex* 
     p.n_bases = total;
 }
 
+TextUploader::~TextUploader() { sylph_upload_destroy(up_); }
+bool TextUploader::send(sylph_ctx* ctx, const std::vector<std::string>& files, unsigned threads, std::vector<Text>& out) {
+    struct Fd { int fd = -1; ~Fd() { if (fd >= 0) close(fd); } };
+    std::vector<Fd> fds(files.size());
+    std::vector<uint64_t> size(files.size()), at(files.size() + 1, 0);
+    for (size_t i = 0; i < files.size(); i++) {
+        fds[i].fd = open(files[i].c_str(), O_RDONLY);
+        struct stat st;
+        if (fds[i].fd < 0 || fstat(fds[i].fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 4) return false;
+        uint8_t head[2];
+        if (pread(fds[i].fd, head, 2, 0) != 2 || head[0] != '@') return false;      // (gzip: 0x1f 0x8b; FASTA: '>')
+        size[i] = (uint64_t)st.st_size;
+        at[i + 1] = (at[i] + size[i] + 15) & ~15ull;
+    }
+    const uint64_t total = at[files.size()];
+    auto check = [](int rc, const char* what) { if (rc != SYLPH_OK) throw Error{1, std::string(what) + ": " + sylph_last_error()}; };
+    if (!up_) check(sylph_upload_begin(ctx, total, 64ull << 20, &up_), "sylph_upload_begin");
+    else check(sylph_upload_restart(up_, total), "sylph_upload_restart");
+    uint64_t g = 0;                                                                  // bytes of the side-by-side layout sent so far
+    while (g < total) {
+        void* chunk = nullptr;
+        uint64_t cap = 0;
+        check(sylph_upload_chunk(up_, &chunk, &cap), "sylph_upload_chunk");
+        const uint64_t n = std::min<uint64_t>(cap, total - g);
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n / (4u << 20) + 1));
+        std::atomic<bool> good{true};
+        run_workers(T, [&](unsigned w) {
+            uint64_t p = g + n * w / T;
+            const uint64_t end = g + n * (w + 1) / T;
+            while (p < end) {
+                size_t i = 0;
+                while (at[i + 1] <= p) i++;                                           // the file (or the padding behind it) p lies in
+                uint8_t* dst = (uint8_t*)chunk + (p - g);
+                if (p >= at[i] + size[i]) {                                           // padding up to the next 16-byte boundary
+                    const uint64_t m = std::min(end, at[i + 1]) - p;
+                    memset(dst, '\n', m);
+                    p += m;
+                    continue;
+                }
+                const uint64_t m = std::min(end, at[i] + size[i]) - p;
+                const ssize_t r = pread(fds[i].fd, dst, std::min<uint64_t>(m, 8u << 20), (off_t)(p - at[i]));
+                if (r <= 0) { good = false; return; }
+                p += (uint64_t)r;
+            }
+        });
+        if (!good) { check(sylph_upload_commit(up_, 0), "sylph_upload_commit"); throw Error{1, "could not read " + files[0]}; }
+        check(sylph_upload_commit(up_, n), "sylph_upload_commit");
+        g += n;
+    }
+    const void* dev = nullptr;
+    check(sylph_upload_finish(up_, &dev), "sylph_upload_finish");
+    out.clear();
+    for (size_t i = 0; i < files.size(); i++) out.push_back(Text{(const uint8_t*)dev + at[i], size[i]});
+    return true;
+}
+
 void PinnedBatch::push_packed(sylph_sketch* sk, int slot) {
     Packed& p = pk_[slot & 1];
     if (!p.n_recs) return;

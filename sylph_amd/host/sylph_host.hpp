@@ -212,6 +212,18 @@ class PinnedBatch {   // flat bases + offsets in page-locked memory (sylph_pinne
     void gather_into(Packed& p, const FastqIndex& a, const FastqIndex* b, const std::vector<uint64_t>& cum_a, const std::vector<uint64_t>* cum_b,
                      size_t i0, size_t i1, unsigned threads);
 };
+// Round 5: the TEXT of plain FASTQ files sent to the device, where the library finds the records (sylph_fastq_index): one reusable
+// uploader per engine (two page-locked chunks the parse threads fill with pread while the other travels), the files of a sample laid
+// side by side at 16-byte boundaries in one device buffer.
+class TextUploader {
+   public:
+    struct Text { const uint8_t* dev = nullptr; uint64_t bytes = 0; };
+    ~TextUploader();
+    // false: some file is not a candidate (not a regular file, empty, gzip magic, does not begin with '@') — nothing was sent
+    bool send(sylph_ctx* ctx, const std::vector<std::string>& files, unsigned threads, std::vector<Text>& out);
+   private:
+    sylph_upload* up_ = nullptr;
+};
 bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109
 
@@ -222,6 +234,7 @@ void trace_mark(const char* what);   // SYLPH_HIP_FEED_TRACE: a line with the mi
 struct Engine {   // one GPU context shared by the drivers
     int device = -1;
     PinnedBatch batch;   // reused by every sample sketched through this engine
+    TextUploader text;   // ... and the uploader of the device-side FASTQ route (commands.cpp sketch_fastq_on_device)
     // GPU bring-up (runtime initialisation, context, page-locked batch, first-use loading of the sketch kernels: ~0.3 s) runs on a
     // background thread from the moment the engine exists, so that it overlaps with argument handling and the indexing of the
     // first input file; context() waits for it (and rethrows its error).

@@ -457,6 +457,49 @@ def test_parallel_feed_equals_sequential_feed(data):
     assert n_tab > 1000 and a[:n_tab] == b[:n_tab] and a[n_tab:n_tab + 16] == b[n_tab:n_tab + 16]   # + c, k; the file names differ
 
 
+def test_device_fastq_route_equals_the_host_feed(data):
+    """SYLPH_HIP_FEED_DEVICE=1: every plain-FASTQ sample whose engine is already up sends its TEXT to the device, where the library finds
+    the records (csrc/fastq.hip; host/commands.cpp sketch_fastq_on_device); a process's first sample, gzip input and anything that is
+    not plain four-line FASTQ go the host way.  Six samples through one engine — plain pairs, a CRLF copy, a pair whose mate 2 is
+    longer, a single-end file, a blocked-gzip pair, a pair with a damaged record in the middle — must give byte-identical sketches
+    and the same exit code either way, and `profile` on raw pairs the same rows."""
+    d = data["dir"]
+    t1, t2 = (d / "s_1.fq").read_bytes(), (d / "s_2.fq").read_bytes()
+    for m, t in (("1", t1), ("2", t2)):
+        (d / f"da_{m}.fq").write_bytes(t)
+        (d / f"db_{m}.fq").write_bytes(t.replace(b"\n", b"\r\n"))
+        (d / f"dd_{m}.fq.gz").write_bytes(bgzf_compress(t, block=4000))
+    (d / "dc_1.fq").write_bytes(t1)
+    (d / "dc_2.fq").write_bytes(t2 + b"@extra\nACGTACGTAC\n+\nIIIIIIIIII\n\n\n")
+    lines = t2.split(b"\n")
+    lines[4 * 57 + 2] = b"-"                                                     # record 57 of mate 2 loses its '+' line
+    (d / "de_1.fq").write_bytes(t1)
+    (d / "de_2.fq").write_bytes(b"\n".join(lines))
+    firsts = [d / f"d{x}_1.fq" for x in "abc"] + [d / "dd_1.fq.gz", d / "de_1.fq"]
+    seconds = [d / f"d{x}_2.fq" for x in "abc"] + [d / "dd_2.fq.gz", d / "de_2.fq"]
+    got = {}
+    for dev in ("0", "1"):
+        o = d / f"devroute_{dev}"
+        p = run("sketch", "-t", "1", "-1", *firsts, "-2", *seconds, "-r", d / "da_1.fq", "-d", o, accept_exact=False, check=False,
+                env_extra={"SYLPH_HIP_FEED_DEVICE": dev, "SYLPH_HIP_FEED_TRACE": "1"})
+        got[dev] = (p.returncode, {f.name: f.read_bytes() for f in sorted(o.iterdir())})
+        if dev == "1":
+            assert "device route: pushed" in p.stderr, p.stderr[-3000:]
+        else:
+            assert "device route" not in p.stderr
+    assert got["0"][0] == got["1"][0] == 0
+    assert sorted(got["0"][1]) == sorted(got["1"][1]) and len(got["0"][1]) >= 5
+    for name in got["0"][1]:
+        assert got["0"][1][name] == got["1"][1][name], name
+    gen = [data["genomes"][n][0] for n in ("EC590", "K12", "O157", "rand")]
+    rows = {}
+    for dev in ("0", "1"):
+        p = run("profile", *gen, "-t", "1", "-1", d / "da_1.fq", d / "db_1.fq", d / "dc_1.fq", "-2", d / "da_2.fq", d / "db_2.fq", d / "dc_2.fq",
+                accept_exact=False, env_extra={"SYLPH_HIP_FEED_DEVICE": dev})
+        rows[dev] = p.stdout
+    assert rows["0"] == rows["1"] and rows["0"].count("\n") >= 4
+
+
 def test_database_does_not_depend_on_threads(data):
     """Genome files are parsed and inflated on the -t threads and appended in file order: the .syldb must be the same bytes for
     every -t, with plain and gzip files, a file that is not FASTA in the middle of the list (warned about, skipped), `-i`."""
