@@ -32,3 +32,12 @@ def ctx():
     c = sylph_amd.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_runtime_first(request):
+    """When GPU tests are selected, THIS process brings its GPU runtime up before any test runs: several tests start child processes
+    on the device (the CLI, two ranks on one GPU), and a process that initialises HIP for the first time right behind them has been seen
+    to find no device (gpurun call 23: `pytest tests/test_gpu_cli.py tests/test_gpu_fastq.py`, HIP error 100 at the first context)."""
+    if any(item.get_closest_marker("gpu") for item in request.session.items):
+        request.getfixturevalue("ctx")
