@@ -168,6 +168,7 @@ Engine::Engine(int dev) : device(dev), gate_(new Gate()) {
             // (Only these: the 256 MB ASCII batch of the sequential reader is page-locked by its first add() — most commands never need it.)
             batch.prealloc_packed();
             trace_mark("engine: packed double buffers page-locked");
+            if (device_feed_enabled()) { text.prepare(ctx_); trace_mark("engine: text uploader's chunks page-locked"); }
         } catch (const Error& e) { init_error_ = e.msg; init_code_ = e.code ? e.code : 1; open_gate(); }
     });
 }
@@ -195,9 +196,6 @@ Engine::~Engine() {
     if (ctx_) sylph_ctx_destroy(ctx_);
 }
 
-#ifndef SYLPH_HOST_FEED_DEVICE_DEFAULT
-#define SYLPH_HOST_FEED_DEVICE_DEFAULT 0
-#endif
 namespace {
 // Uncompressed 4-line FASTQ (the common case): the files are indexed by parse_threads() workers, whole batches are gathered
 // into page-locked memory in parallel and pushed; the record loop of the reference shrinks to its one sequential piece, the
@@ -320,13 +318,10 @@ void sketch_indexed(Engine& e, const std::function<sylph_sketch*()>& open_sessio
 // Round 5, the device-side route for plain FASTQ (csrc/fastq.hip): the files' TEXT goes to the device through the engine's uploader and
 // the library finds the records there; the host keeps the one sequential piece (the running mean of the mate-1 read lengths, from the
 // lengths the device hands back).  Taken for every sample whose engine is already up — a process's FIRST sample is indexed and gathered
-// on the host while the GPU runtime initialises, which no device can do — unless SYLPH_HIP_FEED_DEVICE=0.  Returns false, having pushed
+// on the host while the GPU runtime initialises, which no device can do — when device_feed_enabled() (feed.cpp: SYLPH_HIP_FEED_DEVICE, else
+// by the number of CPUs this process may use).  Returns false, having pushed
 // nothing, when the files are not plain four-line FASTQ (SYLPH_ERR_FORMAT, gzip, FASTA): the caller takes the host route, whose
 // record and error semantics are needletail's.
-bool device_feed_enabled() {
-    static const bool on = [] { const char* e = getenv("SYLPH_HIP_FEED_DEVICE"); return e ? atoi(e) != 0 : SYLPH_HOST_FEED_DEVICE_DEFAULT != 0; }();
-    return on && !getenv("SYLPH_HIP_SEQUENTIAL_FEED");
-}
 bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& open_session, const std::string& f1, const std::string* f2,
                             double& mean_read_length) {
     if (!device_feed_enabled() || !e.ready()) return false;

@@ -681,8 +681,21 @@ void PinnedBatch::gather_into(Packed& p, const FastqIndex& a, const FastqIndex* 
     p.n_bases = total;
 }
 
+bool device_feed_enabled() {
+    static const bool on = [] {
+        if (getenv("SYLPH_HIP_SEQUENTIAL_FEED")) return false;
+        if (const char* e = getenv("SYLPH_HIP_FEED_DEVICE")) return atoi(e) != 0;
+        return effective_cpus() <= 8;
+    }();
+    return on;
+}
 TextUploader::~TextUploader() { sylph_upload_destroy(up_); }
+void TextUploader::prepare(sylph_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!up_ && sylph_upload_begin(ctx, 1u << 20, 64ull << 20, &up_) != SYLPH_OK) up_ = nullptr;   // (send tries again and reports)
+}
 bool TextUploader::send(sylph_ctx* ctx, const std::vector<std::string>& files, unsigned threads, std::vector<Text>& out) {
+    std::lock_guard<std::mutex> lk(mu_);
     struct Fd { int fd = -1; ~Fd() { if (fd >= 0) close(fd); } };
     std::vector<Fd> fds(files.size());
     std::vector<uint64_t> size(files.size()), at(files.size() + 1, 0);

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <string>
 #include <thread>
@@ -219,11 +220,17 @@ class TextUploader {
    public:
     struct Text { const uint8_t* dev = nullptr; uint64_t bytes = 0; };
     ~TextUploader();
+    void prepare(sylph_ctx* ctx);   // page-locks the two chunks ahead of the first send (the engine's background bring-up)
     // false: some file is not a candidate (not a regular file, empty, gzip magic, does not begin with '@') — nothing was sent
     bool send(sylph_ctx* ctx, const std::vector<std::string>& files, unsigned threads, std::vector<Text>& out);
    private:
+    std::mutex mu_;
     sylph_upload* up_ = nullptr;
 };
+// The device-side route for plain FASTQ (TextUploader + sylph_fastq_*): SYLPH_HIP_FEED_DEVICE=1 / 0, else by the CPUs this process may
+// use — the host feed's index + gather + pack scale with them (35-90 ms per Gbp pair on 16, measured), the text's trip over PCIe does
+// not (41 ms per Gbp pair): on by default at 8 CPUs or fewer.
+bool device_feed_enabled();
 bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109
 
