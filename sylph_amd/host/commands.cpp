@@ -318,8 +318,8 @@ void sketch_indexed(Engine& e, const std::function<sylph_sketch*()>& open_sessio
 // Round 5, the device-side route for plain FASTQ (csrc/fastq.hip): the files' TEXT goes to the device through the engine's uploader and
 // the library finds the records there; the host keeps the one sequential piece (the running mean of the mate-1 read lengths, from the
 // lengths the device hands back).  Taken for every sample whose engine is already up — a process's FIRST sample is indexed and gathered
-// on the host while the GPU runtime initialises, which no device can do — when device_feed_enabled() (feed.cpp: SYLPH_HIP_FEED_DEVICE, else
-// by the number of CPUs this process may use).  Returns false, having pushed
+// on the host while the GPU runtime initialises, which no device can do — unless SYLPH_HIP_FEED_DEVICE=0 (feed.cpp device_feed_enabled).
+// Returns false, having pushed
 // nothing, when the files are not plain four-line FASTQ (SYLPH_ERR_FORMAT, gzip, FASTA): the caller takes the host route, whose
 // record and error semantics are needletail's.
 bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& open_session, const std::string& f1, const std::string* f2,

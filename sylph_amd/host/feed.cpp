@@ -685,7 +685,7 @@ bool device_feed_enabled() {
     static const bool on = [] {
         if (getenv("SYLPH_HIP_SEQUENTIAL_FEED")) return false;
         if (const char* e = getenv("SYLPH_HIP_FEED_DEVICE")) return atoi(e) != 0;
-        return effective_cpus() <= 8;
+        return true;
     }();
     return on;
 }
@@ -709,6 +709,10 @@ bool TextUploader::send(sylph_ctx* ctx, const std::vector<std::string>& files, u
         at[i + 1] = (at[i] + size[i] + 15) & ~15ull;
     }
     const uint64_t total = at[files.size()];
+    // the whole text of the sample lies in device memory at once (plus its line index and the gathered bases): beyond this the host feed,
+    // which works through a sample in batches, takes it
+    static const uint64_t max_text = (uint64_t)((getenv("SYLPH_HIP_FEED_DEVICE_MAX_GB") ? atof(getenv("SYLPH_HIP_FEED_DEVICE_MAX_GB")) : 16.) * (1ull << 30));
+    if (total > max_text) return false;
     auto check = [](int rc, const char* what) { if (rc != SYLPH_OK) throw Error{1, std::string(what) + ": " + sylph_last_error()}; };
     if (!up_) check(sylph_upload_begin(ctx, total, 64ull << 20, &up_), "sylph_upload_begin");
     else check(sylph_upload_restart(up_, total), "sylph_upload_restart");

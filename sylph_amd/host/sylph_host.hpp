@@ -227,9 +227,10 @@ class TextUploader {
     std::mutex mu_;
     sylph_upload* up_ = nullptr;
 };
-// The device-side route for plain FASTQ (TextUploader + sylph_fastq_*): SYLPH_HIP_FEED_DEVICE=1 / 0, else by the CPUs this process may
-// use — the host feed's index + gather + pack scale with them (35-90 ms per Gbp pair on 16, measured), the text's trip over PCIe does
-// not (41 ms per Gbp pair): on by default at 8 CPUs or fewer.
+// The device-side route for plain FASTQ (TextUploader + sylph_fastq_*), taken by every sample whose engine is already up unless
+// SYLPH_HIP_FEED_DEVICE=0: the host feed's index + gather + pack scale with the CPUs the process may use (73-125 ms per warm 1 Gbp pair
+// on 16, 104-206 on 4), the text's trip over PCIe does not (58-65 ms per pair all in; profiles/r05_feed_device_route.txt).  Samples
+// whose text exceeds SYLPH_HIP_FEED_DEVICE_MAX_GB (default 16) stay with the host feed, which works through a sample in batches.
 bool device_feed_enabled();
 bool is_fastq(const std::string& f);   // sketch.rs:95
 bool is_fasta(const std::string& f);   // sketch.rs:109
