@@ -40,8 +40,9 @@ constexpr int FQ_TPB = 256, FQ_TILE = FQ_TPB * 16;       // one 16-byte load per
 constexpr uint32_t FQ_MAX_TRAILING = 1u << 16;
 
 // what the kernels leave for the host: [0] bytes of text without its trailing blank space, [1] first bad record (~0: none),
-// [2] bases of the text, [3] flags (1: more than FQ_MAX_TRAILING blank bytes behind the text)
-struct FqWords { unsigned long long n_eff, bad_rec, n_bases, flags; };
+// [2] bases of the text, [3] flags (1: more than FQ_MAX_TRAILING blank bytes behind the text), [4] newlines, counted in 64 bits (the
+// tiles' line numbers are a 32-bit scan: a text with 2^32 lines or more is refused, not mis-numbered)
+struct FqWords { unsigned long long n_eff, bad_rec, n_bases, flags, n_nl; };
 
 __global__ void fq_trim_kernel(const uint8_t* __restrict__ t, uint64_t n, FqWords* __restrict__ w) {
     uint64_t e = n;
@@ -50,6 +51,7 @@ __global__ void fq_trim_kernel(const uint8_t* __restrict__ t, uint64_t n, FqWord
     w->n_eff = e;
     w->bad_rec = ~0ull;
     w->n_bases = 0;
+    w->n_nl = 0;
     w->flags = (e > 0 && (t[e - 1] == '\n' || t[e - 1] == '\r')) ? 1ull : 0ull;
 }
 
@@ -80,7 +82,7 @@ __device__ __forceinline__ void lane_flags(const uint8_t* __restrict__ al, uint3
     }
 }
 
-__global__ __launch_bounds__(FQ_TPB) void fq_count_kernel(const uint8_t* __restrict__ al, uint32_t bias, const FqWords* __restrict__ w,
+__global__ __launch_bounds__(FQ_TPB) void fq_count_kernel(const uint8_t* __restrict__ al, uint32_t bias, FqWords* __restrict__ w,
                                                           uint32_t* __restrict__ tile_cnt) {
     __shared__ uint32_t s_wave[FQ_TPB / 64];
     uint32_t f[4];
@@ -89,7 +91,10 @@ __global__ __launch_bounds__(FQ_TPB) void fq_count_kernel(const uint8_t* __restr
     const uint32_t c = __popc(f[0]) + __popc(f[1]) + __popc(f[2]) + __popc(f[3]);
     uint32_t tot = 0;
     (void)block_excl_sum<FQ_TPB>(c, s_wave, &tot);
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        tile_cnt[blockIdx.x] = tot;
+        if (tot) atomicAdd(&w->n_nl, (unsigned long long)tot);
+    }
 }
 
 __global__ __launch_bounds__(FQ_TPB) void fq_lines_kernel(const uint8_t* __restrict__ al, uint32_t bias, const FqWords* __restrict__ w,
@@ -211,6 +216,7 @@ void fastq_index_impl(sylph_fastq* f, const void* text, uint64_t n_bytes, int me
     if (hw.flags & 1ull) throw FormatError{"more than 64 KiB of blank space behind the last line"};
     f->n = hw.n_eff;
     if (f->n == 0) throw FormatError{"no text"};
+    if (hw.n_nl != (unsigned long long)n_nl) throw FormatError{std::to_string(hw.n_nl) + " lines: at most 2^32 - 1 per index"};
     const uint64_t n_lines = (uint64_t)n_nl + 1;                   // the last line is unterminated (its newline was trimmed)
     if (n_lines % 4) throw FormatError{"the number of lines (" + std::to_string(n_lines) + ") is not a multiple of four"};
     f->n_rec = n_lines / 4;
