@@ -208,7 +208,9 @@ struct ThreadJoiner {   // joins on every way out of a scope (an Error thrown pa
     std::thread& t;
     ~ThreadJoiner() { if (t.joinable()) t.join(); }
 };
-std::optional<IndexedInput> index_inputs(const std::string& f1, const std::string* f2) {
+// build = false: the files are mapped / inflated, not indexed — what the device-side route needs of a gzip file (finish_index does
+// the rest on the host when that route is not taken after all)
+std::optional<IndexedInput> index_inputs(const std::string& f1, const std::string* f2, bool build = true) {
     if (getenv("SYLPH_HIP_SEQUENTIAL_FEED")) return std::nullopt;
     const unsigned T = parse_threads();
     IndexedInput in;
@@ -216,13 +218,32 @@ std::optional<IndexedInput> index_inputs(const std::string& f1, const std::strin
     std::thread tb;
     ThreadJoiner jb{tb};
     if (f2) tb = std::thread([&] {                        // the two mate files are indexed concurrently
-        try { in.b.reset(new FastqIndex(*f2, T)); } catch (...) { err_b = std::current_exception(); }
+        try { in.b.reset(new FastqIndex(*f2, T, build)); } catch (...) { err_b = std::current_exception(); }
     });
-    in.a.reset(new FastqIndex(f1, T));
+    in.a.reset(new FastqIndex(f1, T, build));
     if (tb.joinable()) tb.join();
     if (err_b) std::rethrow_exception(err_b);
-    if (!in.a->ok || (f2 && !in.b->ok)) return std::nullopt;
+    if (build ? (!in.a->ok || (f2 && !in.b->ok)) : (!in.a->text_ready || (f2 && !in.b->text_ready))) return std::nullopt;
     return in;
+}
+bool finish_index(IndexedInput& in) {
+    const unsigned T = parse_threads();
+    std::exception_ptr err_b;
+    std::thread tb;
+    ThreadJoiner jb{tb};
+    if (in.b) tb = std::thread([&] { try { in.b->build_index(T); } catch (...) { err_b = std::current_exception(); } });
+    in.a->build_index(T);
+    if (tb.joinable()) tb.join();
+    if (err_b) std::rethrow_exception(err_b);
+    return in.a->ok && (!in.b || in.b->ok);
+}
+bool is_gzip_file(const std::string& f) {
+    FILE* fp = fopen(f.c_str(), "rb");
+    if (!fp) return false;
+    unsigned char h[2] = {0, 0};
+    const size_t n = fread(h, 1, 2, fp);
+    fclose(fp);
+    return n == 2 && h[0] == 0x1f && h[1] == 0x8b;
 }
 // Batches of whole records (pairs) of at most BATCH_BASES bases / BATCH_RECS records
 std::vector<std::pair<size_t, size_t>> cut_batches(size_t n, bool paired, const std::vector<uint64_t>& ca, const std::vector<uint64_t>& cb) {
@@ -322,8 +343,9 @@ void sketch_indexed(Engine& e, const std::function<sylph_sketch*()>& open_sessio
 // Returns false, having pushed
 // nothing, when the files are not plain four-line FASTQ (SYLPH_ERR_FORMAT, gzip, FASTA): the caller takes the host route, whose
 // record and error semantics are needletail's.
+// `text`: the files' text where it lies in host memory already (the inflated copies of gzip files) instead of the files themselves
 bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& open_session, const std::string& f1, const std::string* f2,
-                            double& mean_read_length) {
+                            double& mean_read_length, const IndexedInput* text = nullptr) {
     if (!device_feed_enabled() || !e.ready()) return false;
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -338,7 +360,11 @@ bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& ope
     std::vector<std::string> files{f1};
     if (f2) files.push_back(*f2);
     std::vector<TextUploader::Text> texts;
-    if (!e.text.send(ctx, files, parse_threads(), texts)) return false;
+    if (text) {
+        std::vector<TextUploader::Mem> mem{{text->a->data, text->a->size}};
+        if (f2) mem.push_back({text->b->data, text->b->size});
+        if (!e.text.send(ctx, mem, parse_threads(), texts)) return false;
+    } else if (!e.text.send(ctx, files, parse_threads(), texts)) return false;
     lap("device route: text uploaded");
     struct Fq { sylph_fastq* f = nullptr; ~Fq() { sylph_fastq_destroy(f); } } fa, fb;
     auto index = [&](const TextUploader::Text& t, Fq& out) {
@@ -455,10 +481,13 @@ namespace {
 std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std::string& read_file, uint64_t c, uint64_t k,
                                                             std::optional<std::string> sample_name, bool no_dedup,
                                                             std::optional<IndexedInput>* pre, sylph_sketch** keep, bool try_device) {
-    if (try_device) {
+    // (pre holds un-indexed text — an inflated gzip file — when its index says neither ok nor failed: the device route takes the text
+    //  from memory; if it declines, the index is finished on the host)
+    const bool text_only = pre && *pre && !(*pre)->a->ok;
+    if (try_device || text_only) {
         std::optional<Session> so;
         double mean = 0.;
-        if (sketch_fastq_on_device(e, [&] { so.emplace(e, c, k, false, no_dedup); return so->sk; }, read_file, nullptr, mean)) {
+        if (sketch_fastq_on_device(e, [&] { so.emplace(e, c, k, false, no_dedup); return so->sk; }, read_file, nullptr, mean, text_only ? &**pre : nullptr)) {
             SequencesSketch out;
             so->finish_or_keep(out, keep);
             out.file_name = read_file; out.c = c; out.k = k; out.paired = false;
@@ -466,6 +495,7 @@ std::optional<SequencesSketch> sketch_sequences_needle_impl(Engine& e, const std
             out.mean_read_length = mean;
             return out;
         }
+        if (text_only && !finish_index(**pre)) pre->reset();
     }
     std::optional<IndexedInput> own;
     if (!pre) { own = index_inputs(read_file, nullptr); pre = &own; }
@@ -520,10 +550,11 @@ std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::
                                                           uint64_t c, uint64_t k, std::optional<std::string> sample_name,
                                                           bool no_dedup, double dedup_fpr, std::optional<IndexedInput>* pre,
                                                           sylph_sketch** keep, bool try_device) {
-    if (try_device) {
+    const bool text_only = pre && *pre && !(*pre)->a->ok;
+    if (try_device || text_only) {
         std::optional<Session> so;
         double mean = 0.;
-        if (sketch_fastq_on_device(e, [&] { so.emplace(e, c, k, true, no_dedup, dedup_fpr); return so->sk; }, read_file1, &read_file2, mean)) {
+        if (sketch_fastq_on_device(e, [&] { so.emplace(e, c, k, true, no_dedup, dedup_fpr); return so->sk; }, read_file1, &read_file2, mean, text_only ? &**pre : nullptr)) {
             SequencesSketch out;
             so->finish_or_keep(out, keep);
             out.file_name = read_file1; out.c = c; out.k = k; out.paired = true;
@@ -531,6 +562,7 @@ std::optional<SequencesSketch> sketch_pair_sequences_impl(Engine& e, const std::
             out.mean_read_length = mean;
             return out;
         }
+        if (text_only && !finish_index(**pre)) pre->reset();
     }
     std::optional<IndexedInput> own;
     if (!pre) { own = index_inputs(read_file1, &read_file2); pre = &own; }
@@ -776,9 +808,12 @@ int sketch(Engine& e, const SketchArgs& args) {
     auto run_job = [&](Engine& eng, size_t j) {
         // an engine that is up takes plain FASTQ by the device route (no host index at all); its first sample, whose index is built while
         // the GPU runtime initialises, and everything the device route declines go the host way
-        const bool dev = device_feed_enabled() && eng.ready();
+        const auto& jf = job_files[j];
+        const bool gz = device_feed_enabled() && is_gzip_file(jf.first);         // inflated on the host, its text then sent as it is
+        const bool dev = device_feed_enabled() && eng.ready() && !gz;
         std::optional<IndexedInput> pre;
-        if (!dev) pre = ahead.get(j);
+        if (gz) pre = index_inputs(jf.first, jf.second ? &*jf.second : nullptr, false);
+        else if (!dev) pre = ahead.get(j);
         trace_mark(dev ? "sketch: the sample goes the device route" : "sketch: the sample's files are indexed (or not indexable)");
         if (++indexes_obtained == n_jobs) set_no_more_inflates(true);   // nobody will want a recycled inflate buffer any more
         // the index goes (2 x 1 GB of mappings to unmap / inflated copies to hand back: 30-60 ms per sample) on a thread of its own, behind the sample
@@ -1280,9 +1315,11 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                 } else if (genome_k != args.k) {
                     fprintf(stderr, "ERROR [sylph_hip] %s -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.k, (unsigned long long)genome_k);
                 } else {
-                    const bool dev = device_feed_enabled() && eng.ready();      // (see sketch(): the device route for plain FASTQ)
+                    const bool gz = device_feed_enabled() && is_gzip_file(files[0]);   // (see sketch(): the device route)
+                    const bool dev = device_feed_enabled() && eng.ready() && !gz;
                     std::optional<IndexedInput> pre;
-                    if (!dev) pre = ahead.get(j);
+                    if (gz) pre = index_inputs(files[0], files.size() > 1 ? &files[1] : nullptr, false);
+                    else if (!dev) pre = ahead.get(j);
                     if (++indexes_obtained == n_raw) set_no_more_inflates(true);
                     struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) background([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }); } } later{pre};
                     if (!device_feed_enabled()) ahead.start(j + n_workers);

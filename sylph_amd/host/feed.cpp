@@ -445,7 +445,7 @@ bool bgzf_inflate(const uint8_t* d, const std::vector<BgzfBlock>& blocks, uint8_
 }
 }  // namespace
 
-FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
+FastqIndex::FastqIndex(const std::string& path, unsigned threads, bool build) : path_(path) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return;
     struct stat st;
@@ -529,9 +529,16 @@ FastqIndex::FastqIndex(const std::string& path, unsigned threads) {
         if (!inflated) return;                                                     // (the sequential reader reports the damage)
         }
     }
+    if (data[0] != '@') return;                                   // not FASTQ: sequential reader
+    text_ready = true;
+    if (build) build_index(threads);
+}
+
+void FastqIndex::build_index(unsigned threads) {
+    if (!text_ready || ok) return;
+    const std::string& path = path_;
     const uint8_t* d = data;
     const size_t n = size;
-    if (d[0] != '@') return;                                      // not FASTQ: sequential reader
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     const auto t_ix0 = std::chrono::steady_clock::now();
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / (1u << 20)));
@@ -695,20 +702,32 @@ void TextUploader::prepare(sylph_ctx* ctx) {
     if (!up_ && sylph_upload_begin(ctx, 1u << 20, 64ull << 20, &up_) != SYLPH_OK) up_ = nullptr;   // (send tries again and reports)
 }
 bool TextUploader::send(sylph_ctx* ctx, const std::vector<std::string>& files, unsigned threads, std::vector<Text>& out) {
-    std::lock_guard<std::mutex> lk(mu_);
     struct Fd { int fd = -1; ~Fd() { if (fd >= 0) close(fd); } };
     std::vector<Fd> fds(files.size());
-    std::vector<uint64_t> size(files.size()), at(files.size() + 1, 0);
+    std::vector<Src> src;
     for (size_t i = 0; i < files.size(); i++) {
         fds[i].fd = open(files[i].c_str(), O_RDONLY);
         struct stat st;
         if (fds[i].fd < 0 || fstat(fds[i].fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 4) return false;
         uint8_t head[2];
         if (pread(fds[i].fd, head, 2, 0) != 2 || head[0] != '@') return false;      // (gzip: 0x1f 0x8b; FASTA: '>')
-        size[i] = (uint64_t)st.st_size;
-        at[i + 1] = (at[i] + size[i] + 15) & ~15ull;
+        src.push_back(Src{fds[i].fd, nullptr, (uint64_t)st.st_size});
     }
-    const uint64_t total = at[files.size()];
+    return send_sources(ctx, src, threads, out);
+}
+bool TextUploader::send(sylph_ctx* ctx, const std::vector<Mem>& texts, unsigned threads, std::vector<Text>& out) {
+    std::vector<Src> src;
+    for (const Mem& m : texts) {
+        if (!m.p || m.bytes < 4 || m.p[0] != '@') return false;
+        src.push_back(Src{-1, m.p, m.bytes});
+    }
+    return send_sources(ctx, src, threads, out);
+}
+bool TextUploader::send_sources(sylph_ctx* ctx, const std::vector<Src>& src, unsigned threads, std::vector<Text>& out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    std::vector<uint64_t> at(src.size() + 1, 0);
+    for (size_t i = 0; i < src.size(); i++) at[i + 1] = (at[i] + src[i].size + 15) & ~15ull;
+    const uint64_t total = at[src.size()];
     // the whole text of the sample lies in device memory at once (plus its line index and the gathered bases): beyond this the host feed,
     // which works through a sample in batches, takes it
     static const uint64_t max_text = (uint64_t)((getenv("SYLPH_HIP_FEED_DEVICE_MAX_GB") ? atof(getenv("SYLPH_HIP_FEED_DEVICE_MAX_GB")) : 16.) * (1ull << 30));
@@ -729,28 +748,29 @@ bool TextUploader::send(sylph_ctx* ctx, const std::vector<std::string>& files, u
             const uint64_t end = g + n * (w + 1) / T;
             while (p < end) {
                 size_t i = 0;
-                while (at[i + 1] <= p) i++;                                           // the file (or the padding behind it) p lies in
+                while (at[i + 1] <= p) i++;                                           // the text (or the padding behind it) p lies in
                 uint8_t* dst = (uint8_t*)chunk + (p - g);
-                if (p >= at[i] + size[i]) {                                           // padding up to the next 16-byte boundary
+                if (p >= at[i] + src[i].size) {                                       // padding up to the next 16-byte boundary
                     const uint64_t m = std::min(end, at[i + 1]) - p;
                     memset(dst, '\n', m);
                     p += m;
                     continue;
                 }
-                const uint64_t m = std::min(end, at[i] + size[i]) - p;
-                const ssize_t r = pread(fds[i].fd, dst, std::min<uint64_t>(m, 8u << 20), (off_t)(p - at[i]));
+                const uint64_t m = std::min(end, at[i] + src[i].size) - p;
+                if (src[i].mem) { memcpy(dst, src[i].mem + (p - at[i]), m); p += m; continue; }
+                const ssize_t r = pread(src[i].fd, dst, std::min<uint64_t>(m, 8u << 20), (off_t)(p - at[i]));
                 if (r <= 0) { good = false; return; }
                 p += (uint64_t)r;
             }
         });
-        if (!good) { check(sylph_upload_commit(up_, 0), "sylph_upload_commit"); throw Error{1, "could not read " + files[0]}; }
+        if (!good) { check(sylph_upload_commit(up_, 0), "sylph_upload_commit"); throw Error{1, "could not read the sample's text"}; }
         check(sylph_upload_commit(up_, n), "sylph_upload_commit");
         g += n;
     }
     const void* dev = nullptr;
     check(sylph_upload_finish(up_, &dev), "sylph_upload_finish");
     out.clear();
-    for (size_t i = 0; i < files.size(); i++) out.push_back(Text{(const uint8_t*)dev + at[i], size[i]});
+    for (size_t i = 0; i < src.size(); i++) out.push_back(Text{(const uint8_t*)dev + at[i], src[i].size});
     return true;
 }
 

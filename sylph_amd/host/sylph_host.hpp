@@ -125,8 +125,13 @@ struct FastqIndex {
     std::vector<uint64_t> seq_off;   // byte offset of every record's sequence line
     std::vector<uint32_t> seq_len;
     std::vector<uint64_t> cum;       // cum[i] = sequence bases of records [0, i) (n_records + 1 entries)
+    bool text_ready = false;         // data[0, size) is the file's complete plain text (the mapping, or the inflated copy of a gzip file) and begins with '@'
+    std::string path_;
     FastqIndex() = default;
-    FastqIndex(const std::string& path, unsigned threads);
+    // build = false: stop behind the mapping / the inflate (text_ready says whether there is text) — the device-side route sends the text
+    // as it is; build_index() finishes the job on the host when that route is not taken
+    FastqIndex(const std::string& path, unsigned threads, bool build = true);
+    void build_index(unsigned threads);
     ~FastqIndex();
     FastqIndex(const FastqIndex&) = delete;
     FastqIndex& operator=(const FastqIndex&) = delete;
@@ -223,7 +228,12 @@ class TextUploader {
     void prepare(sylph_ctx* ctx);   // page-locks the two chunks ahead of the first send (the engine's background bring-up)
     // false: some file is not a candidate (not a regular file, empty, gzip magic, does not begin with '@') — nothing was sent
     bool send(sylph_ctx* ctx, const std::vector<std::string>& files, unsigned threads, std::vector<Text>& out);
+    // the same for texts that lie in host memory already (the inflated copies of gzip files)
+    struct Mem { const uint8_t* p; uint64_t bytes; };
+    bool send(sylph_ctx* ctx, const std::vector<Mem>& texts, unsigned threads, std::vector<Text>& out);
    private:
+    struct Src { int fd; const uint8_t* mem; uint64_t size; };
+    bool send_sources(sylph_ctx* ctx, const std::vector<Src>& src, unsigned threads, std::vector<Text>& out);
     std::mutex mu_;
     sylph_upload* up_ = nullptr;
 };

@@ -460,23 +460,25 @@ def test_parallel_feed_equals_sequential_feed(data):
 def test_device_fastq_route_equals_the_host_feed(data):
     """SYLPH_HIP_FEED_DEVICE=1: every plain-FASTQ sample whose engine is already up sends its TEXT to the device, where the library finds
     the records (csrc/fastq.hip; host/commands.cpp sketch_fastq_on_device); a process's first sample, gzip input and anything that is
-    not plain four-line FASTQ go the host way.  Six samples through one engine — plain pairs, a CRLF copy, a pair whose mate 2 is
-    longer, a single-end file, a blocked-gzip pair, a pair with a damaged record in the middle — must give byte-identical sketches
-    and the same exit code either way, and `profile` on raw pairs the same rows."""
+    not plain four-line FASTQ go the host way — gzip files are inflated on the host and their TEXT then takes the same route.  Seven
+    samples through one engine — a single-member gzip pair first, plain pairs, a CRLF copy, a pair whose mate 2 is longer, a blocked-gzip
+    pair, a pair with a damaged record in the middle, a single-end file — must give byte-identical sketches and the same exit code
+    either way, and `profile` on raw pairs (gzip ones too) the same rows."""
     d = data["dir"]
     t1, t2 = (d / "s_1.fq").read_bytes(), (d / "s_2.fq").read_bytes()
     for m, t in (("1", t1), ("2", t2)):
         (d / f"da_{m}.fq").write_bytes(t)
         (d / f"db_{m}.fq").write_bytes(t.replace(b"\n", b"\r\n"))
         (d / f"dd_{m}.fq.gz").write_bytes(bgzf_compress(t, block=4000))
+        (d / f"df_{m}.fq.gz").write_bytes(gzip.compress(t, 1))                  # an ordinary single-member gzip file
     (d / "dc_1.fq").write_bytes(t1)
     (d / "dc_2.fq").write_bytes(t2 + b"@extra\nACGTACGTAC\n+\nIIIIIIIIII\n\n\n")
     lines = t2.split(b"\n")
     lines[4 * 57 + 2] = b"-"                                                     # record 57 of mate 2 loses its '+' line
     (d / "de_1.fq").write_bytes(t1)
     (d / "de_2.fq").write_bytes(b"\n".join(lines))
-    firsts = [d / f"d{x}_1.fq" for x in "abc"] + [d / "dd_1.fq.gz", d / "de_1.fq"]
-    seconds = [d / f"d{x}_2.fq" for x in "abc"] + [d / "dd_2.fq.gz", d / "de_2.fq"]
+    firsts = [d / "df_1.fq.gz"] + [d / f"d{x}_1.fq" for x in "abc"] + [d / "dd_1.fq.gz", d / "de_1.fq"]
+    seconds = [d / "df_2.fq.gz"] + [d / f"d{x}_2.fq" for x in "abc"] + [d / "dd_2.fq.gz", d / "de_2.fq"]
     got = {}
     for dev in ("0", "1"):
         o = d / f"devroute_{dev}"
@@ -494,7 +496,7 @@ def test_device_fastq_route_equals_the_host_feed(data):
     gen = [data["genomes"][n][0] for n in ("EC590", "K12", "O157", "rand")]
     rows = {}
     for dev in ("0", "1"):
-        p = run("profile", *gen, "-t", "1", "-1", d / "da_1.fq", d / "db_1.fq", d / "dc_1.fq", "-2", d / "da_2.fq", d / "db_2.fq", d / "dc_2.fq",
+        p = run("profile", *gen, "-t", "1", "-1", d / "df_1.fq.gz", d / "da_1.fq", d / "db_1.fq", d / "dc_1.fq", "-2", d / "df_2.fq.gz", d / "da_2.fq", d / "db_2.fq", d / "dc_2.fq",
                 accept_exact=False, env_extra={"SYLPH_HIP_FEED_DEVICE": dev})
         rows[dev] = p.stdout
     assert rows["0"] == rows["1"] and rows["0"].count("\n") >= 4
