@@ -771,6 +771,7 @@ bool TextUploader::send_sources(sylph_ctx* ctx, const std::vector<Src>& src, uns
     check(sylph_upload_finish(up_, &dev), "sylph_upload_finish");
     out.clear();
     for (size_t i = 0; i < src.size(); i++) out.push_back(Text{(const uint8_t*)dev + at[i], src[i].size});
+    sent_ = true;
     return true;
 }
 

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -226,6 +227,7 @@ class TextUploader {
     struct Text { const uint8_t* dev = nullptr; uint64_t bytes = 0; };
     ~TextUploader();
     void prepare(sylph_ctx* ctx);   // page-locks the two chunks ahead of the first send (the engine's background bring-up)
+    bool warm() const { return sent_.load(); }   // a text has travelled before: the device-side buffers of the route exist
     // false: some file is not a candidate (not a regular file, empty, gzip magic, does not begin with '@') — nothing was sent
     bool send(sylph_ctx* ctx, const std::vector<std::string>& files, unsigned threads, std::vector<Text>& out);
     // the same for texts that lie in host memory already (the inflated copies of gzip files)
@@ -236,6 +238,7 @@ class TextUploader {
     bool send_sources(sylph_ctx* ctx, const std::vector<Src>& src, unsigned threads, std::vector<Text>& out);
     std::mutex mu_;
     sylph_upload* up_ = nullptr;
+    std::atomic<bool> sent_{false};
 };
 // The device-side route for plain FASTQ (TextUploader + sylph_fastq_*), taken by every sample whose engine is already up unless
 // SYLPH_HIP_FEED_DEVICE=0: the host feed's index + gather + pack scale with the CPUs the process may use (73-125 ms per warm 1 Gbp pair
