@@ -238,6 +238,8 @@ bool finish_index(IndexedInput& in) {
     return in.a->ok && (!in.b || in.b->ok);
 }
 bool is_gzip_file(const std::string& f) {
+    struct stat st;
+    if (stat(f.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;   // (never read from a pipe here: the bytes would be gone for its reader)
     FILE* fp = fopen(f.c_str(), "rb");
     if (!fp) return false;
     unsigned char h[2] = {0, 0};

@@ -502,6 +502,32 @@ def test_device_fastq_route_equals_the_host_feed(data):
     assert rows["0"] == rows["1"] and rows["0"].count("\n") >= 4
 
 
+def test_reads_from_a_named_pipe(data):
+    """A sample that is not a regular file (`mkfifo`, process substitution) can be read once, front to back: nothing may peek at it
+    (the gzip test of the device-side route stats before it reads), and it goes through the sequential reader like in the reference."""
+    import threading
+    d = data["dir"]
+    fifo = d / "pipe_1.fq"
+    if fifo.exists():
+        fifo.unlink()
+    os.mkfifo(fifo)
+    text = (d / "s_1.fq").read_bytes()
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(text)
+    t = threading.Thread(target=feed, daemon=True)
+    t.start()
+    o = d / "pipe_out"
+    p = run("sketch", "-r", fifo, "-d", o, check=False)
+    t.join(timeout=60)
+    assert p.returncode == 0, p.stderr[-2000:]
+    run("sketch", "-r", d / "s_1.fq", "-d", o)
+    a, b = (o / "pipe_1.fq.sylsp").read_bytes(), (o / "s_1.fq.sylsp").read_bytes()
+    n_tab = 8 + 12 * int.from_bytes(b[:8], "little")
+    assert n_tab > 1000 and a[:n_tab] == b[:n_tab]
+
+
 def test_database_does_not_depend_on_threads(data):
     """Genome files are parsed and inflated on the -t threads and appended in file order: the .syldb must be the same bytes for
     every -t, with plain and gzip files, a file that is not FASTA in the middle of the list (warned about, skipped), `-i`."""
