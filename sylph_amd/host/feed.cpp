@@ -446,9 +446,11 @@ bool bgzf_inflate(const uint8_t* d, const std::vector<BgzfBlock>& blocks, uint8_
 }  // namespace
 
 FastqIndex::FastqIndex(const std::string& path, unsigned threads, bool build) : path_(path) {
+    struct stat st;
+    // a pipe (mkfifo, process substitution) is opened ONCE, by the sequential reader: opening and closing it here would end its writer
+    if (stat(path.c_str(), &st) != 0 || st.st_size < 4 || !S_ISREG(st.st_mode)) return;
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return;
-    struct stat st;
     if (fstat(fd, &st) != 0 || st.st_size < 4 || !S_ISREG(st.st_mode)) { close(fd); return; }
     size = (size_t)st.st_size;
     void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -706,8 +708,9 @@ bool TextUploader::send(sylph_ctx* ctx, const std::vector<std::string>& files, u
     std::vector<Fd> fds(files.size());
     std::vector<Src> src;
     for (size_t i = 0; i < files.size(); i++) {
-        fds[i].fd = open(files[i].c_str(), O_RDONLY);
         struct stat st;
+        if (stat(files[i].c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 4) return false;   // (a pipe is never opened here)
+        fds[i].fd = open(files[i].c_str(), O_RDONLY);
         if (fds[i].fd < 0 || fstat(fds[i].fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 4) return false;
         uint8_t head[2];
         if (pread(fds[i].fd, head, 2, 0) != 2 || head[0] != '@') return false;      // (gzip: 0x1f 0x8b; FASTA: '>')
