@@ -162,7 +162,15 @@ int sylph_host_fastx_digest(const char* path, int threaded, uint64_t* n_records,
 int sylph_host_fastq_index_digest(const char* path, unsigned threads, int* ok, uint64_t* n_records, uint64_t* n_bases, uint64_t* digest) {
     uint64_t h = 1469598103934665603ull, nb = 0;
     auto mix = [&](const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } };
-    FastqIndex ix(path, threads);
+    // threads with bit 31 set: the two steps of the device-side route's gzip handling — the text first (mapping / inflate, no index:
+    // text_ready), the index afterwards (build_index) — which must end where the one-step constructor ends
+    const bool two_steps = (threads & 0x80000000u) != 0;
+    threads &= 0x7FFFFFFFu;
+    FastqIndex ix(path, threads, !two_steps);
+    if (two_steps) {
+        if (ix.ok) return 1;                           // nothing may have been indexed yet
+        if (ix.text_ready) ix.build_index(threads);
+    }
     *ok = ix.ok ? 1 : 0;
     if (!ix.ok) return 0;
     for (size_t i = 0; i < ix.n_records(); i++) {

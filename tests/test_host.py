@@ -463,7 +463,7 @@ def test_block_parallel_fastq_index_matches_the_sequential_reader(host, tmp_path
         v = [C.c_uint64(0) for _ in range(4)]
         assert host.sylph_host_fastx_digest(str(path).encode(), 0, *[C.byref(x) for x in v]) == 0
         assert v[1].value == 0
-        for threads in (1, 3, 16):
+        for threads in (1, 3, 16, 3 | 0x80000000):     # (bit 31: text first, index afterwards — the two steps of the device route's gzip handling)
             ok = C.c_int(0)
             w = [C.c_uint64(0) for _ in range(3)]
             assert host.sylph_host_fastq_index_digest(str(path).encode(), threads, C.byref(ok), *[C.byref(x) for x in w]) == 0
@@ -477,7 +477,7 @@ def test_block_parallel_fastq_index_matches_the_sequential_reader(host, tmp_path
     for name, text in bad.items():
         path = tmp_path / name
         path.write_bytes(text)
-        for threads in (1, 4):
+        for threads in (1, 4, 4 | 0x80000000):
             ok = C.c_int(1)
             w = [C.c_uint64(0) for _ in range(3)]
             assert host.sylph_host_fastq_index_digest(str(path).encode(), threads, C.byref(ok), *[C.byref(x) for x in w]) == 0
@@ -511,7 +511,7 @@ def test_blocked_gzip_is_inflated_in_parallel_and_indexed(host, tmp_path, monkey
         w = [C.c_uint64(0) for _ in range(3)]
         assert host.sylph_host_fastq_index_digest(str(path).encode(), threads, C.byref(ok), *[C.byref(x) for x in w]) == 0
         return ok.value, (w[0].value, w[1].value, w[2].value)
-    for threads in (1, 5, 16):
+    for threads in (1, 5, 16, 5 | 0x80000000):
         assert index(bg, threads) == (1, (v[0].value, v[2].value, v[3].value))
     # a flipped byte inside one member's deflate data: CRC / inflate failure -> declined
     bad = bytearray(z)
