@@ -211,7 +211,10 @@ int sylph_pack_2bit(const uint8_t *ascii, uint64_t n, uint8_t *out);
  * else happens — when the text is not exactly that (multi-line FASTQ, FASTA, a damaged record, no text): the caller then reads the
  * file with its own reader, whose record and error semantics are the reference's.  sylph_fastq_lengths copies the sequence
  * lengths of records [first, first + n) to the host: the reference's running mean of the read lengths (sketch.rs:941-943,
- * :825-826) is sequential f64 arithmetic in file order and stays there. */
+ * :825-826) is sequential f64 arithmetic in file order and stays there.  An index belongs to its context (sessions of the same
+ * context push from it; calls are serialised like every call on a context), holds at most 2^32 - 1 lines, and must be destroyed
+ * before its context; the gathered batch is the session's own buffer, so "borrow_until_finish" may be set on a session that is
+ * fed by ONE sylph_sketch_push_fastq (the seeding verdict then waits for finish). */
 typedef struct sylph_fastq sylph_fastq;
 int sylph_fastq_index(sylph_ctx *ctx, const void *text, uint64_t n_bytes, int mem, sylph_fastq **out);
 int sylph_fastq_counts(const sylph_fastq *f, uint64_t *n_records, uint64_t *n_bases);
