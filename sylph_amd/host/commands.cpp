@@ -376,7 +376,7 @@ bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& ope
     struct Fq { sylph_fastq* f = nullptr; ~Fq() { sylph_fastq_destroy(f); } } fa, fb;
     auto index = [&](const TextUploader::Text& t, Fq& out) {
         const int rc = sylph_fastq_index(ctx, t.dev, t.bytes, SYLPH_MEM_DEVICE, &out.f);
-        if (rc == SYLPH_ERR_FORMAT) return false;
+        if (rc == SYLPH_ERR_FORMAT || rc == SYLPH_ERR_NOMEM) return false;   // not for this route / no room for it: the host feed
         hip_check(rc, "sylph_fastq_index");
         return true;
     };

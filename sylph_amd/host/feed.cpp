@@ -736,8 +736,9 @@ bool TextUploader::send_sources(sylph_ctx* ctx, const std::vector<Src>& src, uns
     static const uint64_t max_text = (uint64_t)((getenv("SYLPH_HIP_FEED_DEVICE_MAX_GB") ? atof(getenv("SYLPH_HIP_FEED_DEVICE_MAX_GB")) : 16.) * (1ull << 30));
     if (total > max_text) return false;
     auto check = [](int rc, const char* what) { if (rc != SYLPH_OK) throw Error{1, std::string(what) + ": " + sylph_last_error()}; };
-    if (!up_) check(sylph_upload_begin(ctx, total, 64ull << 20, &up_), "sylph_upload_begin");
-    else check(sylph_upload_restart(up_, total), "sylph_upload_restart");
+    // (no room for the text on the device: not an error — the host feed takes the sample)
+    if (!up_) { const int rc = sylph_upload_begin(ctx, total, 64ull << 20, &up_); if (rc == SYLPH_ERR_NOMEM) { up_ = nullptr; return false; } check(rc, "sylph_upload_begin"); }
+    else { const int rc = sylph_upload_restart(up_, total); if (rc == SYLPH_ERR_NOMEM) return false; check(rc, "sylph_upload_restart"); }
     uint64_t g = 0;                                                                  // bytes of the side-by-side layout sent so far
     while (g < total) {
         void* chunk = nullptr;
