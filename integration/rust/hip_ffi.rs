@@ -6,6 +6,7 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct SylphDb { _p: [u8; 0] }
 #[repr(C)] pub struct SylphComm { _p: [u8; 0] }
 #[repr(C)] pub struct SylphFastq { _p: [u8; 0] }
+#[repr(C)] pub struct SylphInflated { _p: [u8; 0] }
 #[repr(C)] pub struct SylphUpload { _p: [u8; 0] }
 #[repr(C)] pub struct SylphSampleRef { pub kmers: *const u64, pub counts: *const u32, pub n: u64 }   // one sorted (k-mer, count) table
 #[repr(C)] pub struct SylphCommOps {   // caller-supplied collectives on device buffers (stream = hipStream_t); 0 = success
@@ -123,6 +124,14 @@ extern "C" {
     pub fn sylph_fastq_lengths(f: *mut SylphFastq, first: u64, n: u64, out: *mut u32) -> c_int;
     pub fn sylph_sketch_push_fastq(sk: *mut SylphSketch, a: *mut SylphFastq, b: *mut SylphFastq, first: u64, n_items: u64) -> c_int;
     pub fn sylph_fastq_destroy(f: *mut SylphFastq);
+    // round 6: gzip inflated on the device (what flate2 does inside parse_fastx_file, sketch.rs:780-781 / :906): compressed bytes in,
+    // text in HBM out (hand the pointer to sylph_fastq_index with MEM_DEVICE); ERR_FORMAT = -5: keep the flate2 reader for this file
+    pub fn sylph_inflate(ctx: *mut SylphCtx, gz: *const c_void, n_bytes: u64, mem: c_int, out: *mut *mut SylphInflated) -> c_int;
+    pub fn sylph_inflated_text(t: *const SylphInflated, dev_text: *mut *const c_void, n_bytes: *mut u64) -> c_int;
+    pub fn sylph_inflated_info(t: *const SylphInflated, n_members: *mut u64, n_blocks: *mut u64, n_candidates: *mut u64,
+                               n_host_members: *mut u64) -> c_int;
+    pub fn sylph_inflated_read(t: *mut SylphInflated, first: u64, n: u64, host_out: *mut c_void) -> c_int;
+    pub fn sylph_inflated_destroy(t: *mut SylphInflated);
     // k-mer-range shards: bounds for `world` GPUs, upload of this rank's range, communicator, the collective batch call
     pub fn sylph_shard_bounds(max_kmer: u64, world: u32, bounds: *mut u64) -> c_int;
     pub fn sylph_db_upload_shard(ctx: *mut SylphCtx, kmers: *const u64, genome_off: *const u64, n_genomes: u64, mem: c_int,

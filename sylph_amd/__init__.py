@@ -4,8 +4,8 @@ The product is the shared library `libsylph_hip.so` (hand-written gfx950 HIP ker
 package is the thin Python binding used by tests/ and bench.py; it fails loudly when the library is missing — there
 is no CPU fallback.
 """
-from .binding import (Comm, Context, Database, FastqText, PinnedBuffer, Pipeline, ReadSketcher, SylphHipError, SEED_AVX2_COMPAT, SEED_SCALAR, READS_PAIRED,
+from .binding import (Comm, Context, Database, FastqText, Inflated, PinnedBuffer, Pipeline, ReadSketcher, SylphHipError, SEED_AVX2_COMPAT, SEED_SCALAR, READS_PAIRED,
                       READS_SINGLE, lib_path, load, pack_2bit, shard_bounds)
 
-__all__ = ["Pipeline", "pack_2bit", "Comm", "shard_bounds", "Context", "Database", "FastqText", "PinnedBuffer", "ReadSketcher", "SylphHipError", "SEED_AVX2_COMPAT", "SEED_SCALAR", "READS_PAIRED",
+__all__ = ["Pipeline", "pack_2bit", "Comm", "shard_bounds", "Context", "Database", "FastqText", "Inflated", "PinnedBuffer", "ReadSketcher", "SylphHipError", "SEED_AVX2_COMPAT", "SEED_SCALAR", "READS_PAIRED",
            "READS_SINGLE", "lib_path", "load"]

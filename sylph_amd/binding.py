@@ -36,7 +36,8 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_upload_begin", "sylph_upload_chunk", "sylph_upload_commit", "sylph_upload_finish", "sylph_upload_restart", "sylph_upload_destroy",
            "sylph_db_replicate", "sylph_pipeline_create_multi", "sylph_pipeline_replica_of_last", "sylph_device_count",
            "sylph_genome_shard_bounds", "sylph_db_upload_genome_shard",
-           "sylph_fastq_index", "sylph_fastq_counts", "sylph_fastq_lengths", "sylph_sketch_push_fastq", "sylph_fastq_destroy"]
+           "sylph_fastq_index", "sylph_fastq_counts", "sylph_fastq_lengths", "sylph_sketch_push_fastq", "sylph_fastq_destroy",
+           "sylph_inflate", "sylph_inflated_text", "sylph_inflated_info", "sylph_inflated_read", "sylph_inflated_destroy"]
 
 
 def load():
@@ -78,6 +79,12 @@ def load():
     L.sylph_sketch_push_fastq.argtypes = [vp, vp, vp, u64, u64]
     L.sylph_fastq_destroy.argtypes = [vp]
     L.sylph_fastq_destroy.restype = None
+    L.sylph_inflate.argtypes = [vp, vp, u64, i32, P(vp)]
+    L.sylph_inflated_text.argtypes = [vp, P(vp), P(u64)]
+    L.sylph_inflated_info.argtypes = [vp, P(u64), P(u64), P(u64), P(u64)]
+    L.sylph_inflated_read.argtypes = [vp, u64, u64, vp]
+    L.sylph_inflated_destroy.argtypes = [vp]
+    L.sylph_inflated_destroy.restype = None
     L.sylph_pack_2bit.argtypes = [vp, u64, vp]
     L.sylph_sketch_finish.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
     L.sylph_sketch_finish_device.argtypes = [vp, P(vp), P(vp), P(u64), P(u64)]
@@ -258,6 +265,42 @@ class PinnedBuffer:
             self.array = None
             load().sylph_pinned_free(C.c_void_p(self.ptr))
             self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Inflated:
+    """sylph_inflate: the bytes of one gzip file (bytes / uint8 array, host memory) inflated on the device (csrc/inflate.hip).  The text
+    stays in HBM: .dev_ptr / .n_bytes go to FastqText(ctx, ptr, MEM_DEVICE, n_bytes); read() copies a range back.  Raises SylphHipError
+    with code ERR_FORMAT when the library declines the stream (not gzip, damaged, ...): inflate on the host then."""
+
+    def __init__(self, ctx, gz):
+        self._h = None
+        keep = np.frombuffer(gz, dtype=np.uint8) if isinstance(gz, (bytes, bytearray, memoryview)) else _np(gz, np.uint8)
+        h = C.c_void_p()
+        _check(load().sylph_inflate(ctx._h, _ptr(keep) if len(keep) else None, len(keep), MEM_HOST, C.byref(h)))
+        self._h = h
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _check(load().sylph_inflated_text(self._h, C.byref(p), C.byref(n)))
+        self.dev_ptr, self.n_bytes = int(p.value or 0), int(n.value)
+        a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(load().sylph_inflated_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        self.n_members, self.n_blocks, self.n_candidates, self.n_host_members = int(a.value), int(b.value), int(c.value), int(d.value)
+
+    def read(self, first=0, n=None):
+        n = self.n_bytes - first if n is None else n
+        out = np.zeros(n, dtype=np.uint8)
+        _check(load().sylph_inflated_read(self._h, int(first), int(n), _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            load().sylph_inflated_destroy(self._h)
+            self._h = None
 
     def __del__(self):
         try:

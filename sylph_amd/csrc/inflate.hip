@@ -1,0 +1,933 @@
+// inflate.hip — gzip (.fastq.gz / .fasta.gz, single-member, multi-member and BGZF) inflated ON THE DEVICE.
+//
+// The reference reads its normal input — gzip files (README.md:51; sketch.rs:780-781, :906 through needletail -> flate2) — with one
+// thread per file: ~0.4 Gbp/s.  Rounds 4-5 inflated on the host with all parse threads (host/pgunzip.cpp): 1.6-2.0 Gbp/s per
+// command on the GPU box, the slowest road of the feed although compressed bytes (0.4 B per base) are the cheapest thing to move
+// over PCIe.  Here the COMPRESSED bytes travel and the device does the rest (bookkeeping and the proof of it: inflate_plan.h):
+//
+//   scan1_kernel      every bit position of the file: "BTYPE = dynamic, HLIT/HDIST in range, the code-length code is complete"
+//                     (one 17-bit test + a Kraft sum over the 3-bit lengths from a 512-entry LDS table) -> ~0.1 % survive
+//   scan2_kernel      one lane per survivor: the header's 258-316 code lengths decoded through a per-lane 7-bit table; both codes
+//                     complete (or zlib's single-code exception), an end-of-block code -> the CANDIDATES (true block starts + ~0)
+//   decode_kernel     one WAVEFRONT per candidate: the block's Huffman tables built in LDS by the 64 lanes (canonical arithmetic,
+//                     10-bit / 8-bit roots, codes beyond the root decoded by first-code comparison — no second-level tables:
+//                     3.4 KB of LDS per wave), symbols decoded wave-uniformly (bit buffer and state live in SGPRs), literals
+//                     collected 64 at a time in a VGPR and stored with one coalesced store, matches copied by all lanes.  Output:
+//                     16-bit cells — a byte, or 256 + w = "byte w of the 32 KiB in front of this block", which nobody knows yet.
+//                     The wave runs on through stored / fixed blocks and stops in front of the next dynamic header or behind
+//                     a final block, and reports where.
+//   (host)            chain_walk: which candidates are the stream, where their bytes go, the members' trailers
+//   winfn_kernel      per group of ~sqrt(K) chain blocks, sequentially inside the group: block k's window as a FUNCTION of the
+//                     group's first window (32 Ki cells: a byte or a reference into that window), both in LDS (128 KB of the 160)
+//   winchain_kernel   the groups' first windows, one after the other (one workgroup, 32 KiB look-ups per group)
+//   translate_kernel  all blocks side by side: the block's real window composed in LDS, cells -> bytes in their place in the text
+//   crc_kernel        CRC-32 of the text in 1 KiB pieces (slicing-by-4 tables in LDS), each shifted to its place in its member
+//                     by polynomial arithmetic and XORed into the member's word; the host compares with the trailers
+//
+// Any doubt — a chain that breaks, an output that does not fit its region, a CRC or ISIZE that differs, no room on the device —
+// returns SYLPH_ERR_FORMAT / SYLPH_ERR_NOMEM and nothing else happens: the caller inflates with zlib as before.
+#include <zlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "inflate_plan.h"
+
+struct sylph_inflated {
+    sylph_ctx* ctx = nullptr;
+    void* buf = nullptr;                  // hipMalloc'ed: 256 bytes of zero padding, the text, 256 bytes of zero padding
+    uint64_t n = 0;
+    uint64_t n_members = 0, n_blocks = 0, n_candidates = 0, n_host_members = 0;
+    const uint8_t* text() const { return (const uint8_t*)buf + 256; }
+};
+
+namespace sylph {
+namespace {
+
+using namespace inflate_plan;
+
+struct FormatDecline { std::string msg; };
+
+constexpr int LIT_ROOT = 10, DIST_ROOT = 8, PRE_ROOT = 7;
+constexpr uint32_t T_LONG = 0xFFFFu;
+constexpr uint32_t REGION_RATIO = 16;       // cells a candidate may write per compressed byte up to the next candidate ...
+constexpr uint32_t REGION_SLACK = 1024;     // ... plus this
+constexpr uint64_t GZ_PAD_WORDS = 1024;     // zero words behind the compressed bytes (a header parsed at the very end reads < 600 bytes on)
+
+// =================================================================================================================================
+// scan, stage 1: the cheap test at every bit position
+// =================================================================================================================================
+constexpr int SCAN_TPB = 256;
+constexpr uint32_t SCAN_STAGE = 4096;       // staged hits per workgroup before a flush (>= SCAN_TPB * 8 + what a flush leaves)
+
+__global__ __launch_bounds__(SCAN_TPB) void scan1_kernel(const uint32_t* __restrict__ gzw, uint64_t byte_lo, uint64_t byte_hi, uint64_t* __restrict__ out,
+                                                         unsigned long long* __restrict__ n_out, uint64_t cap) {
+    __shared__ uint8_t kraft[512];
+    __shared__ uint64_t stage[SCAN_STAGE];
+    __shared__ uint32_t stage_n;
+    __shared__ unsigned long long gbase;
+    for (uint32_t i = threadIdx.x; i < 512; i += SCAN_TPB) {
+        uint32_t s = 0;
+        for (int f = 0; f < 3; f++) { const uint32_t v = (i >> (3 * f)) & 7; if (v) s += 128u >> v; }
+        kraft[i] = (uint8_t)s;                                                // <= 192
+    }
+    if (threadIdx.x == 0) stage_n = 0;
+    __syncthreads();
+    const uint64_t span = byte_hi - byte_lo;
+    for (uint64_t base = (uint64_t)blockIdx.x * SCAN_TPB; base < span; base += (uint64_t)gridDim.x * SCAN_TPB) {
+        const uint64_t b = byte_lo + base + threadIdx.x;
+        if (b < byte_hi) {
+            const uint64_t wi = b >> 2;
+            const uint32_t d0 = gzw[wi], d1 = gzw[wi + 1], d2 = gzw[wi + 2], d3 = gzw[wi + 3];
+            const uint32_t s0 = (uint32_t)(b & 3) * 8;
+#pragma unroll
+            for (uint32_t sh = 0; sh < 8; sh++) {
+                const uint32_t s = s0 + sh;                                   // 0 .. 31
+                const uint32_t h0 = __builtin_amdgcn_alignbit(d1, d0, s);
+                // BTYPE == 2 (bits 1-2 = 0,1), HLIT <= 29, HDIST <= 29
+                if (((h0 >> 1) & 3) != 2 || ((h0 >> 3) & 31) > 29 || ((h0 >> 8) & 31) > 29) continue;
+                const uint32_t h1 = __builtin_amdgcn_alignbit(d2, d1, s), h2 = __builtin_amdgcn_alignbit(d3, d2, s);
+                const uint32_t hclen = ((h0 >> 13) & 15) + 4;
+                uint64_t c = ((((uint64_t)h1 << 32) | h0) >> 17) | ((uint64_t)h2 << 47);
+                c &= (1ull << (3 * hclen)) - 1;
+                uint32_t sum = 0;
+#pragma unroll
+                for (int j = 0; j < 7; j++) sum += kraft[(uint32_t)(c >> (9 * j)) & 511];
+                if (sum != 128) continue;
+                const uint32_t at = atomicAdd(&stage_n, 1u);
+                stage[at] = b * 8 + sh;
+            }
+        }
+        __syncthreads();
+        const uint32_t m = stage_n;                                           // (uniform: everybody reads the same word between two barriers)
+        __syncthreads();
+        if (m > SCAN_STAGE - SCAN_TPB * 8) {
+            if (threadIdx.x == 0) { gbase = atomicAdd(n_out, (unsigned long long)m); stage_n = 0; }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < m; i += SCAN_TPB)
+                if (gbase + i < cap) out[gbase + i] = stage[i];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const uint32_t m = stage_n;
+    if (threadIdx.x == 0 && m) gbase = atomicAdd(n_out, (unsigned long long)m);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += SCAN_TPB)
+        if (gbase + i < cap) out[gbase + i] = stage[i];
+}
+
+// =================================================================================================================================
+// scan, stage 2: one lane per survivor, the whole header
+// =================================================================================================================================
+struct LaneBits {                                  // per-lane bit reader over the dword stream
+    const uint32_t* w;
+    uint64_t acc, wpos;
+    uint32_t cnt;
+    __device__ __forceinline__ void init(const uint32_t* words, uint64_t bitpos) {
+        w = words;
+        wpos = bitpos >> 5;
+        const uint32_t s = (uint32_t)bitpos & 31;
+        acc = (uint64_t)(w[wpos++] >> s);
+        cnt = 32 - s;
+        refill();
+    }
+    __device__ __forceinline__ void refill() { if (cnt <= 32) { acc |= (uint64_t)w[wpos++] << cnt; cnt += 32; } }
+    __device__ __forceinline__ uint32_t take(uint32_t k) { const uint32_t v = (uint32_t)acc & ((1u << k) - 1); acc >>= k; cnt -= k; return v; }
+    __device__ __forceinline__ uint64_t bitpos() const { return wpos * 32 - cnt; }
+};
+
+__device__ __constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+constexpr int SCAN2_TPB = 128;
+__global__ __launch_bounds__(SCAN2_TPB) void scan2_kernel(const uint32_t* __restrict__ gzw, uint64_t n_bits, const uint64_t* __restrict__ in,
+                                                          const unsigned long long* __restrict__ n_in_p, uint64_t in_cap, uint64_t* __restrict__ out,
+                                                          unsigned long long* __restrict__ n_out, uint64_t cap) {
+    __shared__ uint8_t pre[SCAN2_TPB][128 + 4];    // (+4: the lanes' tables start in different banks)
+    const uint64_t n_in = (uint64_t)min((unsigned long long)*n_in_p, (unsigned long long)in_cap);
+    const uint64_t i = (uint64_t)blockIdx.x * SCAN2_TPB + threadIdx.x;
+    if (i >= n_in) return;
+    const uint64_t p = in[i];
+    LaneBits b;
+    b.init(gzw, p);
+    b.take(3);
+    const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
+    uint64_t clp = 0;                               // the 19 code lengths of the code-length code, 3 bits each, by symbol
+    for (uint32_t j = 0; j < hclen; j++) { b.refill(); clp |= (uint64_t)b.take(3) << (3 * CL_ORDER[j]); }
+    // canonical codes of the code-length code (complete: stage 1 checked the Kraft sum) into the lane's 128-entry table
+    uint8_t* tab = pre[threadIdx.x];
+    {
+        uint32_t code = 0;
+        for (uint32_t l = 1; l <= 7; l++) {
+            for (uint32_t s = 0; s < 19; s++) {
+                if (((clp >> (3 * s)) & 7) != l) continue;
+                const uint32_t rev = __brev(code) >> (32 - l);
+                for (uint32_t k = rev; k < 128; k += 1u << l) tab[k] = (uint8_t)(s << 3 | l);
+                code++;
+            }
+            code <<= 1;
+        }
+    }
+    const uint32_t total = hlit + hdist;
+    uint32_t idx = 0, prev = 0, kl = 0, kd = 0, nzl = 0, nzd = 0, l1 = 0, d1 = 0, eob = 0;
+    bool ok = true;
+    while (idx < total) {
+        b.refill();
+        const uint32_t e = tab[(uint32_t)b.acc & 127];
+        b.take(e & 7);
+        const uint32_t sym = e >> 3;
+        uint32_t val, rep;
+        if (sym < 16) { val = sym; rep = 1; }
+        else if (sym == 16) { if (idx == 0) { ok = false; break; } val = prev; rep = 3 + b.take(2); }
+        else if (sym == 17) { val = 0; rep = 3 + b.take(3); }
+        else { val = 0; rep = 11 + b.take(7); }
+        if (idx + rep > total) { ok = false; break; }
+        if (val) {
+            const uint32_t nl = idx >= hlit ? 0 : min(rep, hlit - idx), nd = rep - nl;
+            kl += nl << (15 - val); nzl += nl; if (val == 1) l1 += nl;
+            kd += nd << (15 - val); nzd += nd; if (val == 1) d1 += nd;
+            if (idx <= 256 && 256 < idx + rep) eob = val;
+        }
+        prev = val;
+        idx += rep;
+    }
+    if (!ok || b.bitpos() > n_bits || eob == 0) return;
+    if (kl > 32768 || (kl < 32768 && !(nzl == 1 && l1 == 1))) return;          // zlib inflate_table: incomplete only for a single 1-bit code
+    if (nzd && (kd > 32768 || (kd < 32768 && !(nzd == 1 && d1 == 1)))) return;
+    const unsigned long long at = atomicAdd(n_out, 1ull);
+    if (at < cap) out[at] = p;
+}
+
+// =================================================================================================================================
+// decode: one wavefront per candidate
+// =================================================================================================================================
+struct WaveTables {
+    uint16_t lit[1 << LIT_ROOT];          // sym << 4 | len;  0 = no code;  T_LONG = longer than the root
+    uint16_t dist[1 << DIST_ROOT];        // (the code-length code is built here first, 7-bit root)
+    uint16_t lit_sorted[288];
+    uint16_t dist_sorted[32];
+    uint16_t lit_first[16], lit_count[16], lit_off[16];
+    uint16_t dist_first[16], dist_count[16], dist_off[16];
+    uint8_t lens[320];
+    uint8_t plens[20];
+    uint32_t lit_maxlen, dist_maxlen;
+};
+
+struct WaveBits {                                  // the same reader, but everything in it is wave-uniform (SGPRs)
+    const uint32_t* w;
+    uint64_t acc, wpos, wlimit;
+    uint32_t cnt;
+    bool over;
+    __device__ __forceinline__ void init(const uint32_t* words, uint64_t bitpos, uint64_t limit_words) {
+        w = words;
+        wlimit = limit_words;
+        over = false;
+        wpos = bitpos >> 5;
+        const uint32_t s = (uint32_t)bitpos & 31;
+        acc = (uint64_t)(w[wpos++] >> s);
+        cnt = 32 - s;
+        refill();
+    }
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32) {
+            if (wpos >= wlimit) over = true;
+            else acc |= (uint64_t)w[wpos] << cnt;
+            wpos++;
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t k) const { return (uint32_t)acc & ((1u << k) - 1); }
+    __device__ __forceinline__ void drop(uint32_t k) { acc >>= k; cnt -= k; }
+    __device__ __forceinline__ uint32_t take(uint32_t k) { const uint32_t v = peek(k); drop(k); return v; }
+    __device__ __forceinline__ uint64_t bitpos() const { return wpos * 32 - cnt; }
+};
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1; }
+
+// Canonical code from lens[0, nsym): sorted symbols, first code / count / offset per length, the root table.  kind: 0 = the
+// code-length code (must be complete), 1 = literal/length, 2 = distance (zlib inflate_table: an incomplete code is fine only when
+// it is a single 1-bit code; a distance code with no code at all is fine).  Wave-uniform result.
+__device__ bool build_code(const uint8_t* lens, uint32_t nsym, uint32_t root, uint16_t* tab, uint16_t* sorted, uint16_t* first, uint16_t* count,
+                           uint16_t* off, uint32_t* maxlen_out, int kind) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t used = 0;
+    for (uint32_t s = lane; s < nsym; s += 64) used |= 1u << lens[s];
+    used = wave_or(used) & ~1u;
+    uint32_t run = 0, code = 0, prev_count = 0, maxlen = 0;
+    int left = 1;
+    bool over = false;
+    for (uint32_t L = 1; L <= 15; L++) {
+        const uint32_t off_l = run;
+        if (used >> L & 1) {
+            for (uint32_t base = 0; base < nsym; base += 64) {
+                const uint32_t s = base + lane;
+                const bool hit = s < nsym && lens[s] == L;
+                const uint64_t mask = __ballot(hit);
+                if (hit) sorted[run + __popcll(mask & lanemask_lt())] = (uint16_t)s;
+                run += __popcll(mask);
+            }
+            maxlen = L;
+        }
+        const uint32_t c = run - off_l;
+        code = (code + prev_count) << 1;
+        prev_count = c;
+        left = (left << 1) - (int)c;
+        if (left < 0) over = true;
+        if (lane == 0) { first[L] = (uint16_t)code; count[L] = (uint16_t)c; off[L] = (uint16_t)off_l; }
+    }
+    *maxlen_out = maxlen;
+    __syncthreads();
+    if (over) return false;
+    if (run == 0) { if (kind != 2) return false; }
+    else if (left > 0 && (kind == 0 || maxlen != 1)) return false;
+    const uint32_t top = min(root, maxlen);
+    for (uint32_t idx = lane; idx < (1u << root); idx += 64) {
+        const uint32_t r = __brev(idx) >> (32 - root);
+        uint32_t e = maxlen > root ? T_LONG : 0;
+        for (uint32_t L = 1; L <= top; L++) {
+            const uint32_t d = (r >> (root - L)) - first[L];
+            if (d < count[L]) { e = (uint32_t)sorted[off[L] + d] << 4 | L; break; }
+        }
+        tab[idx] = (uint16_t)e;
+    }
+    __syncthreads();
+    return true;
+}
+
+// a code longer than the root: first-code comparison, lengths root+1 .. maxlen.  -> sym << 4 | len, or 0
+__device__ __forceinline__ uint32_t decode_long(uint32_t bits, uint32_t root, uint32_t maxlen, const uint16_t* sorted, const uint16_t* first,
+                                                const uint16_t* count, const uint16_t* off) {
+    const uint32_t r = __brev(bits);
+    for (uint32_t L = root + 1; L <= maxlen; L++) {
+        const uint32_t d = (r >> (32 - L)) - first[L];
+        if (d < count[L]) return (uint32_t)sorted[off[L] + d] << 4 | L;
+    }
+    return 0;
+}
+
+struct DecodeOut {                       // the wave's output state (n, m, cap wave-uniform; pend per lane)
+    uint16_t* out;
+    uint32_t n, m, cap;
+    uint32_t pend;
+    bool overflow;
+    __device__ __forceinline__ void flush() {
+        if (m) {
+            if (n + m > cap) { overflow = true; m = 0; return; }
+            if ((threadIdx.x & 63) < m) out[n + (threadIdx.x & 63)] = (uint16_t)pend;
+            n += m;
+            m = 0;
+        }
+    }
+    __device__ __forceinline__ void literal(uint32_t v) {
+        if ((threadIdx.x & 63) == m) pend = v;
+        if (++m == 64) flush();
+    }
+};
+
+__global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__ gzw, uint64_t n_words, const uint64_t* __restrict__ cand, uint32_t n_cand,
+                                                    uint64_t byte0, uint64_t byte_end, uint16_t* __restrict__ cells, BlockResult* __restrict__ res) {
+    __shared__ WaveTables T;
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    const uint64_t start = cand[k];
+    const uint64_t next_byte = k + 1 < n_cand ? cand[k + 1] >> 3 : byte_end;
+    const uint64_t region = ((start >> 3) - byte0) * REGION_RATIO + (uint64_t)k * REGION_SLACK;
+    DecodeOut o;
+    o.out = cells + region;
+    o.n = 0; o.m = 0; o.pend = 0; o.overflow = false;
+    o.cap = (uint32_t)min((uint64_t)0xFFFFFF00u, (next_byte - (start >> 3)) * REGION_RATIO + REGION_SLACK);
+    const bool have_window = k != 0;
+    WaveBits b;
+    b.init(gzw, start, n_words);
+    uint32_t status = ST_NONE, flags = 0;
+    uint64_t end_bit = 0;
+    bool first_block = true;
+    while (status == ST_NONE) {
+        b.refill();
+        const uint64_t header_at = b.bitpos();
+        const uint32_t bfinal = b.peek(1), btype = (b.peek(3) >> 1);
+        if (!first_block && btype == 2) { status = ST_NEXT_DYNAMIC; end_bit = header_at; break; }
+        first_block = false;
+        b.drop(3);
+        if (btype == 3) { status = ST_ERR_CODE; break; }
+        if (btype == 0) {
+            b.drop(b.cnt & 7);                                                 // to the byte boundary
+            b.refill();
+            const uint32_t len = b.take(16);
+            b.refill();
+            const uint32_t nlen = b.take(16);
+            if (b.over || (len ^ 0xFFFFu) != nlen) { status = ST_ERR_STORED; break; }
+            const uint64_t from = b.bitpos() >> 3;
+            if (from + len > n_words * 4) { status = ST_ERR_OVERRUN; break; }
+            o.flush();
+            if (o.overflow || o.n + len > o.cap) { status = ST_OVERFLOW; break; }
+            const uint8_t* gzb = reinterpret_cast<const uint8_t*>(gzw);
+            for (uint32_t i = lane; i < len; i += 64) o.out[o.n + i] = gzb[from + i];
+            o.n += len;
+            b.init(gzw, (from + len) * 8, n_words);
+        } else {
+            if (btype == 2) {
+                b.refill();
+                const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
+                if (hlit > 286 || hdist > 30) { status = ST_ERR_CODE; break; }
+                if (lane < 19) T.plens[lane] = 0;
+                __syncthreads();
+                for (uint32_t i = 0; i < hclen; i++) {
+                    b.refill();
+                    const uint32_t v = b.take(3);
+                    if (lane == 0) T.plens[CL_ORDER[i]] = (uint8_t)v;
+                }
+                __syncthreads();
+                uint32_t pre_max;
+                if (b.over || !build_code(T.plens, 19, PRE_ROOT, T.dist, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off, &pre_max, 0)) {
+                    status = b.over ? ST_ERR_OVERRUN : ST_ERR_CODE;
+                    break;
+                }
+                const uint32_t total = hlit + hdist;
+                uint32_t i = 0, prev = 0;
+                bool bad = false;
+                while (i < total) {
+                    b.refill();
+                    const uint32_t e = T.dist[b.peek(PRE_ROOT)];
+                    if (e == 0) { bad = true; break; }
+                    b.drop(e & 15);
+                    const uint32_t sym = e >> 4;
+                    uint32_t val, rep;
+                    if (sym < 16) { val = sym; rep = 1; }
+                    else if (sym == 16) { if (i == 0) { bad = true; break; } val = prev; rep = 3 + b.take(2); }
+                    else if (sym == 17) { val = 0; rep = 3 + b.take(3); }
+                    else { val = 0; rep = 11 + b.take(7); }
+                    if (i + rep > total) { bad = true; break; }
+                    for (uint32_t j = lane; j < rep; j += 64) T.lens[i + j] = (uint8_t)val;
+                    prev = val;
+                    i += rep;
+                }
+                __syncthreads();
+                if (bad || b.over || T.lens[256] == 0) { status = b.over ? ST_ERR_OVERRUN : ST_ERR_CODE; break; }
+                if (!build_code(T.lens, hlit, LIT_ROOT, T.lit, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off, &T.lit_maxlen, 1) ||
+                    !build_code(T.lens + hlit, hdist, DIST_ROOT, T.dist, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off, &T.dist_maxlen, 2)) {
+                    status = ST_ERR_CODE;
+                    break;
+                }
+            } else {
+                for (uint32_t s = lane; s < 288; s += 64) T.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                if (lane < 32) T.lens[288 + lane] = 5;
+                __syncthreads();
+                build_code(T.lens, 288, LIT_ROOT, T.lit, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off, &T.lit_maxlen, 1);
+                build_code(T.lens + 288, 32, DIST_ROOT, T.dist, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off, &T.dist_maxlen, 2);
+            }
+            const uint32_t lit_max = T.lit_maxlen, dist_max = T.dist_maxlen;
+            // ---- the block's symbols
+            for (;;) {
+                b.refill();
+                uint32_t e = T.lit[b.peek(LIT_ROOT)];
+                if (e == T_LONG) e = decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off);
+                e = __builtin_amdgcn_readfirstlane(e);
+                if (e == 0) { status = ST_ERR_CODE; break; }
+                b.drop(e & 15);
+                uint32_t sym = e >> 4;
+                if (sym < 256) {
+                    o.literal(sym);
+                    // (>= 33 bits were there: a second and a third code of <= 15 bits fit without a refill)
+                    e = T.lit[b.peek(LIT_ROOT)];
+                    if (e == T_LONG) e = decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off);
+                    e = __builtin_amdgcn_readfirstlane(e);
+                    if (e == 0) { status = ST_ERR_CODE; break; }
+                    b.drop(e & 15);
+                    sym = e >> 4;
+                    if (sym < 256) { o.literal(sym); continue; }
+                    b.refill();
+                }
+                if (sym == 256) break;
+                const uint32_t s = sym - 257;
+                if (s >= 29) { status = ST_ERR_CODE; break; }
+                uint32_t len;
+                if (s < 8) len = 3 + s;
+                else if (s == 28) len = 258;
+                else { const uint32_t eb = (s - 4) >> 2; len = 3 + ((4 + (s & 3)) << eb) + b.take(eb); }
+                b.refill();
+                uint32_t de = T.dist[b.peek(DIST_ROOT)];
+                if (de == T_LONG) de = decode_long((uint32_t)b.acc, DIST_ROOT, dist_max, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off);
+                de = __builtin_amdgcn_readfirstlane(de);
+                if (de == 0) { status = ST_ERR_CODE; break; }
+                b.drop(de & 15);
+                const uint32_t ds = de >> 4;
+                if (ds >= 30) { status = ST_ERR_CODE; break; }
+                uint32_t dist;
+                if (ds < 4) dist = 1 + ds;
+                else { const uint32_t eb = (ds - 2) >> 1; dist = 1 + ((2 + (ds & 1)) << eb) + b.take(eb); }
+                if (b.over) { status = ST_ERR_OVERRUN; break; }
+                o.flush();
+                if (dist > o.n) {
+                    if (!have_window || dist - o.n > WINDOW) { status = ST_ERR_DISTANCE; break; }
+                    flags |= 1;
+                }
+                if (o.overflow || o.n + len > o.cap) { status = ST_OVERFLOW; break; }
+                const long long src0 = (long long)o.n - (long long)dist;
+                if (dist >= len) {
+                    for (uint32_t i = lane; i < len; i += 64) {
+                        const long long src = src0 + i;
+                        o.out[o.n + i] = src >= 0 ? o.out[src] : (uint16_t)(256 + WINDOW + src);
+                    }
+                } else if (dist == 1) {
+                    const uint16_t v = src0 >= 0 ? o.out[src0] : (uint16_t)(256 + WINDOW + src0);
+                    for (uint32_t i = lane; i < len; i += 64) o.out[o.n + i] = v;
+                } else {
+                    for (uint32_t i = lane; i < len; i += 64) {
+                        const long long src = src0 + (i % dist);
+                        o.out[o.n + i] = src >= 0 ? o.out[src] : (uint16_t)(256 + WINDOW + src);
+                    }
+                }
+                o.n += len;
+            }
+            if (status != ST_NONE) break;
+            if (b.over) { status = ST_ERR_OVERRUN; break; }
+        }
+        if (bfinal) { status = ST_FINAL; end_bit = b.bitpos(); }
+    }
+    o.flush();
+    if (o.overflow && status < ST_ERR_CODE) status = ST_OVERFLOW;
+    if (lane == 0) {
+        BlockResult r;
+        r.end_bit = end_bit;
+        r.n_out = o.n;
+        r.status = status;
+        r.flags = flags;
+        r.pad = 0;
+        res[k] = r;
+    }
+}
+
+// =================================================================================================================================
+// windows
+// =================================================================================================================================
+struct PlanBlock {                      // one chain block, as the device needs it
+    unsigned long long cells;           // offset of its region in the cells
+    unsigned long long out_off;
+    uint32_t n_out;
+    uint32_t flags;
+};
+
+constexpr int WIN_TPB = 1024;
+// group g = chain blocks [g * G, min(K, (g + 1) * G)).  S (in LDS, 2 x 32 Ki cells): the window in front of the current block as a
+// function of the window in front of the group's first block.  sfn[k] receives the S of block k, ffn[g] the one behind the group.
+__global__ __launch_bounds__(WIN_TPB) void winfn_kernel(const PlanBlock* __restrict__ plan, uint32_t K, uint32_t G, const uint16_t* __restrict__ cells,
+                                                        uint16_t* __restrict__ sfn, uint16_t* __restrict__ ffn) {
+    extern __shared__ uint16_t S[];     // [2][WINDOW]
+    const uint32_t g = blockIdx.x, k0 = g * G, k1 = min(K, k0 + G);
+    uint16_t* cur = S;
+    uint16_t* nxt = S + WINDOW;
+    for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) cur[j] = (uint16_t)(256 + j);
+    __syncthreads();
+    for (uint32_t k = k0; k < k1; k++) {
+        uint16_t* dst = sfn + (uint64_t)k * WINDOW;
+        for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) dst[j] = cur[j];
+        const uint32_t t = plan[k].n_out;
+        const uint16_t* c = cells + plan[k].cells;
+        if (t >= WINDOW) {
+            const uint16_t* tail = c + (t - WINDOW);
+            for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) {
+                const uint16_t v = tail[j];
+                nxt[j] = v < 256 ? v : cur[v - 256];
+            }
+        } else {
+            const uint32_t keep = WINDOW - t;                                   // the older window, moved down
+            for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) {
+                if (j < keep) nxt[j] = cur[j + t];
+                else { const uint16_t v = c[j - keep]; nxt[j] = v < 256 ? v : cur[v - 256]; }
+            }
+        }
+        __syncthreads();
+        uint16_t* sw = cur; cur = nxt; nxt = sw;
+    }
+    uint16_t* dst = ffn + (uint64_t)g * WINDOW;
+    for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) dst[j] = cur[j];
+}
+
+// the real window in front of every group, one group after the other
+__global__ __launch_bounds__(WIN_TPB) void winchain_kernel(const uint16_t* __restrict__ ffn, uint32_t n_groups, uint8_t* __restrict__ rwin) {
+    __shared__ uint8_t R[2][WINDOW];
+    uint8_t* cur = R[0];
+    uint8_t* nxt = R[1];
+    for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) cur[j] = 0;
+    __syncthreads();
+    for (uint32_t g = 0; g < n_groups; g++) {
+        uint8_t* dst = rwin + (uint64_t)g * WINDOW;
+        const uint16_t* f = ffn + (uint64_t)g * WINDOW;
+        for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) {
+            dst[j] = cur[j];
+            const uint16_t v = f[j];
+            nxt[j] = v < 256 ? (uint8_t)v : cur[v - 256];
+        }
+        __syncthreads();
+        uint8_t* sw = cur; cur = nxt; nxt = sw;
+    }
+}
+
+// =================================================================================================================================
+// cells -> bytes
+// =================================================================================================================================
+constexpr int TR_TPB = 256;
+__global__ __launch_bounds__(TR_TPB) void translate_kernel(const PlanBlock* __restrict__ plan, uint32_t G, const uint16_t* __restrict__ cells,
+                                                           const uint16_t* __restrict__ sfn, const uint8_t* __restrict__ rwin, uint8_t* __restrict__ text) {
+    __shared__ uint8_t W[WINDOW];
+    const uint32_t k = blockIdx.x;
+    const PlanBlock pb = plan[k];
+    if (pb.flags & 1) {
+        const uint16_t* s = sfn + (uint64_t)k * WINDOW;
+        const uint8_t* r = rwin + (uint64_t)(k / G) * WINDOW;
+        for (uint32_t j = threadIdx.x; j < WINDOW; j += TR_TPB) { const uint16_t v = s[j]; W[j] = v < 256 ? (uint8_t)v : r[v - 256]; }
+        __syncthreads();
+    }
+    const uint16_t* c = cells + pb.cells;
+    uint8_t* o = text + pb.out_off;
+    const uint32_t n = pb.n_out;
+    // byte-wise up to the first 4-byte boundary of the text, then four cells -> one dword per lane
+    const uint32_t head = min(n, (uint32_t)((4 - (pb.out_off & 3)) & 3));
+    if (threadIdx.x < head) { const uint16_t v = c[threadIdx.x]; o[threadIdx.x] = v < 256 ? (uint8_t)v : W[v - 256]; }
+    const uint32_t quads = (n - head) / 4;
+    for (uint32_t q = threadIdx.x; q < quads; q += TR_TPB) {
+        const uint16_t* cq = c + head + 4 * q;
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint16_t v = cq[j]; w |= (uint32_t)(v < 256 ? (uint8_t)v : W[v - 256]) << (8 * j); }
+        *reinterpret_cast<uint32_t*>(o + head + 4 * q) = w;
+    }
+    const uint32_t done = head + 4 * quads;
+    if (threadIdx.x < n - done) { const uint16_t v = c[done + threadIdx.x]; o[done + threadIdx.x] = v < 256 ? (uint8_t)v : W[v - 256]; }
+}
+
+// =================================================================================================================================
+// CRC-32
+// =================================================================================================================================
+constexpr int CRC_TPB = 256;
+constexpr uint32_t CRC_PIECE = 1024;
+// member_end[m]: ascending end offsets of the members in the text.  raw[m] ^= (register of the piece, started at 0) shifted by the
+// bytes between the piece's end and the member's end.
+__global__ __launch_bounds__(CRC_TPB) void crc_kernel(const uint8_t* __restrict__ text, uint64_t total, const unsigned long long* __restrict__ member_end,
+                                                      uint32_t n_members, const uint32_t* __restrict__ x2n_g, uint32_t* __restrict__ raw) {
+    __shared__ uint32_t T[4][256];
+    __shared__ uint32_t x2n[64];
+    for (uint32_t i = threadIdx.x; i < 256; i += CRC_TPB) {
+        uint32_t c = i;
+        for (int b = 0; b < 8; b++) c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        T[0][i] = c;
+    }
+    if (threadIdx.x < 64) x2n[threadIdx.x] = x2n_g[threadIdx.x];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += CRC_TPB) {
+        const uint32_t c1 = (T[0][i] >> 8) ^ T[0][T[0][i] & 0xFF];
+        const uint32_t c2 = (c1 >> 8) ^ T[0][c1 & 0xFF];
+        const uint32_t c3 = (c2 >> 8) ^ T[0][c2 & 0xFF];
+        T[1][i] = c1; T[2][i] = c2; T[3][i] = c3;
+    }
+    __syncthreads();
+    const uint64_t piece = (uint64_t)blockIdx.x * CRC_TPB + threadIdx.x;
+    uint64_t pos = piece * CRC_PIECE;
+    if (pos >= total) return;
+    const uint64_t end = min(total, pos + CRC_PIECE);
+    // the member that holds `pos`: the first whose end lies behind it
+    uint32_t lo = 0, hi = n_members - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (member_end[mid] > pos) hi = mid; else lo = mid + 1; }
+    uint32_t m = lo;
+    while (pos < end) {
+        while (member_end[m] <= pos) m++;                                    // (empty members)
+        const uint64_t m_end = member_end[m];
+        const uint64_t stop = min(end, m_end);
+        uint32_t reg = 0;
+        uint64_t p = pos;
+        while (p < stop && (p & 3)) { reg = T[0][(reg ^ text[p]) & 0xFF] ^ (reg >> 8); p++; }
+        for (; p + 4 <= stop; p += 4) {
+            reg ^= *reinterpret_cast<const uint32_t*>(text + p);
+            reg = T[3][reg & 0xFF] ^ T[2][(reg >> 8) & 0xFF] ^ T[1][(reg >> 16) & 0xFF] ^ T[0][reg >> 24];
+        }
+        while (p < stop) { reg = T[0][(reg ^ text[p]) & 0xFF] ^ (reg >> 8); p++; }
+        atomicXor(&raw[m], crc_shift(x2n, reg, m_end - stop));
+        pos = stop;
+    }
+}
+
+// =================================================================================================================================
+// host
+// =================================================================================================================================
+struct Raw {                            // plain hipMalloc / hipFree: GBs of scratch per call must not stay in the context's pool
+    void* p = nullptr;
+    ~Raw() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    void alloc(size_t bytes) {
+        const hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 256));
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); throw HipError{e, "hipMalloc (inflate scratch)", __FILE__, __LINE__}; }
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// a small member through zlib (gzip wrapper: zlib checks CRC and ISIZE itself)
+bool zlib_member(const uint8_t* gz, size_t n, size_t p, size_t* end, std::vector<uint8_t>& out) {
+    constexpr size_t MAX_OUT = 1u << 20, MAX_IN = 1u << 18;
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;
+    out.resize(MAX_OUT);
+    zs.next_in = const_cast<Bytef*>(gz + p);
+    zs.avail_in = (uInt)std::min<size_t>(n - p, MAX_IN);
+    zs.next_out = out.data();
+    zs.avail_out = (uInt)MAX_OUT;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END;
+    if (ok) { *end = p + zs.total_in; out.resize(zs.total_out); }
+    inflateEnd(&zs);
+    return ok;
+}
+
+void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
+    sylph_ctx* ctx = t->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard dg(ctx->device);
+    hipStream_t s = ctx->stream;
+    const size_t body0 = member_body(gz, n, 0);
+    if (!body0) throw FormatDecline{"not a gzip file"};
+    if (n >= (3ull << 30)) throw FormatDecline{"gzip file of 3 GiB or more: the host reader takes it"};
+    const uint64_t byte_end = n;                    // (trailers and later headers are scanned too: no harm, and members end anywhere)
+    // ---- the compressed bytes, padded with zero words
+    const uint64_t n_words = (n + 3) / 4;
+    Raw d_gz;
+    d_gz.alloc((n_words + GZ_PAD_WORDS) * 4);
+    {
+        HostPhase hp(ctx, "inflate: upload");
+        SY_HIP(hipMemsetAsync(d_gz.as<uint8_t>() + (n & ~(uint64_t)3), 0, (n_words + GZ_PAD_WORDS) * 4 - (n & ~(uint64_t)3), s));
+        ctx->h2d(d_gz.p, gz, n);
+    }
+    // ---- candidates
+    const uint64_t cap1 = n / 8 + 4096, cap2 = n / 64 + 4096;
+    Raw d_c1, d_c2, d_cnt;
+    d_c1.alloc(cap1 * 8);
+    d_c2.alloc(cap2 * 8);
+    d_cnt.alloc(64);
+    SY_HIP(hipMemsetAsync(d_cnt.p, 0, 64, s));
+    unsigned long long* cnt = d_cnt.as<unsigned long long>();
+    unsigned long long n1 = 0, n2 = 0;
+    {
+        ScopedKernelTimer kt(ctx, "inflate_scan");
+        HostPhase hp(ctx, "inflate: scan");
+        const uint64_t span = byte_end - body0;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((span + SCAN_TPB - 1) / SCAN_TPB, 256 * 16);
+        hipLaunchKernelGGL(scan1_kernel, dim3(std::max(grid, 1u)), dim3(SCAN_TPB), 0, s, d_gz.as<uint32_t>(), (uint64_t)body0, byte_end, d_c1.as<uint64_t>(), cnt, cap1);
+        SY_HIP(hipGetLastError());
+        ctx->read_back(&n1, cnt, 8);
+        if (n1 > cap1) throw FormatDecline{"more header-like bit positions than the scan has room for"};
+        if (n1) {
+            hipLaunchKernelGGL(scan2_kernel, dim3((uint32_t)((n1 + SCAN2_TPB - 1) / SCAN2_TPB)), dim3(SCAN2_TPB), 0, s, d_gz.as<uint32_t>(), n * 8, d_c1.as<uint64_t>(),
+                               cnt, cap1, d_c2.as<uint64_t>(), cnt + 1, cap2);
+            SY_HIP(hipGetLastError());
+        }
+        ctx->read_back(&n2, cnt + 1, 8);
+        if (n2 > cap2) throw FormatDecline{"more block-start candidates than the scan has room for"};
+    }
+    std::vector<uint64_t> cand(n2 + 1);
+    if (n2) ctx->d2h(cand.data(), d_c2.p, n2 * 8);
+    cand[n2] = (uint64_t)body0 * 8;                 // the stream's first block, whatever its type
+    std::sort(cand.begin(), cand.end());
+    cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    const uint32_t K = (uint32_t)cand.size();
+    if (cand.size() >= (1ull << 31)) throw FormatDecline{"too many candidates"};
+    t->n_candidates = K;
+    d_c1.release();
+    // ---- decode every candidate
+    const uint64_t n_cells = (byte_end - body0) * REGION_RATIO + (uint64_t)K * REGION_SLACK + 64;
+    Raw d_cells, d_res, d_cand;
+    d_cells.alloc(n_cells * 2);
+    d_res.alloc((size_t)K * sizeof(BlockResult));
+    d_cand.alloc((size_t)K * 8);
+    std::vector<BlockResult> res(K);
+    {
+        ScopedKernelTimer kt(ctx, "inflate_decode");
+        HostPhase hp(ctx, "inflate: decode");
+        ctx->h2d(d_cand.p, cand.data(), (size_t)K * 8);
+        hipLaunchKernelGGL(decode_kernel, dim3(K), dim3(64), 0, s, d_gz.as<uint32_t>(), n_words, d_cand.as<uint64_t>(), K, (uint64_t)body0, byte_end, d_cells.as<uint16_t>(),
+                           d_res.as<BlockResult>());
+        SY_HIP(hipGetLastError());
+    }
+    ctx->d2h(res.data(), d_res.p, (size_t)K * sizeof(BlockResult));
+    // ---- the chain
+    std::vector<std::vector<uint8_t>> host_bytes;
+    Chain chain = chain_walk(gz, (size_t)n, cand, res.data(), [&](size_t p, size_t* end, uint64_t* n_out) {
+        std::vector<uint8_t> o;
+        if (!zlib_member(gz, (size_t)n, p, end, o)) return false;
+        *n_out = o.size();
+        if (!o.empty()) host_bytes.push_back(std::move(o));
+        return true;
+    });
+    if (!chain.why.empty()) throw FormatDecline{chain.why};
+    const uint32_t KB = (uint32_t)chain.blocks.size();
+    const uint32_t NM = (uint32_t)chain.members.size();
+    t->n_blocks = KB;
+    t->n_members = NM;
+    t->n_host_members = 0;
+    for (const Member& m : chain.members) t->n_host_members += m.on_host;
+    t->n = chain.total;
+    // ---- the text
+    {
+        const hipError_t e = hipMalloc(&t->buf, chain.total + 512);
+        if (e != hipSuccess) { t->buf = nullptr; (void)hipGetLastError(); throw HipError{e, "hipMalloc (inflated text)", __FILE__, __LINE__}; }
+    }
+    uint8_t* text = (uint8_t*)t->buf + 256;
+    SY_HIP(hipMemsetAsync(t->buf, 0, 256, s));
+    SY_HIP(hipMemsetAsync(text + chain.total, 0, 256, s));
+    for (size_t i = 0; i < chain.host.size(); i++) ctx->h2d(text + chain.host[i].out_off, host_bytes[i].data(), host_bytes[i].size());
+    if (KB) {
+        std::vector<PlanBlock> plan(KB);
+        bool any_window = false;
+        for (uint32_t i = 0; i < KB; i++) {
+            const ChainBlock& cb = chain.blocks[i];
+            plan[i].cells = ((cand[cb.cand] >> 3) - body0) * REGION_RATIO + (uint64_t)cb.cand * REGION_SLACK;
+            plan[i].out_off = cb.out_off;
+            plan[i].n_out = cb.n_out;
+            plan[i].flags = cb.flags;
+            any_window |= (cb.flags & 1) != 0;
+        }
+        Raw d_plan, d_sfn, d_ffn, d_rwin;
+        d_plan.alloc((size_t)KB * sizeof(PlanBlock));
+        ctx->h2d(d_plan.p, plan.data(), (size_t)KB * sizeof(PlanBlock));
+        uint32_t G = 1;
+        while ((uint64_t)G * G < KB) G++;
+        G = std::max(G, 8u);
+        const uint32_t NG = (KB + G - 1) / G;
+        if (any_window) {
+            ScopedKernelTimer kt(ctx, "inflate_windows");
+            HostPhase hp(ctx, "inflate: windows");
+            d_sfn.alloc((size_t)KB * WINDOW * 2);
+            d_ffn.alloc((size_t)NG * WINDOW * 2);
+            d_rwin.alloc((size_t)NG * WINDOW);
+            static std::once_flag once;
+            std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winfn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW * 4); });
+            hipLaunchKernelGGL(winfn_kernel, dim3(NG), dim3(WIN_TPB), WINDOW * 4, s, d_plan.as<PlanBlock>(), KB, G, d_cells.as<uint16_t>(), d_sfn.as<uint16_t>(),
+                               d_ffn.as<uint16_t>());
+            SY_HIP(hipGetLastError());
+            hipLaunchKernelGGL(winchain_kernel, dim3(1), dim3(WIN_TPB), 0, s, d_ffn.as<uint16_t>(), NG, d_rwin.as<uint8_t>());
+            SY_HIP(hipGetLastError());
+        }
+        {
+            ScopedKernelTimer kt(ctx, "inflate_translate");
+            HostPhase hp(ctx, "inflate: translate");
+            hipLaunchKernelGGL(translate_kernel, dim3(KB), dim3(TR_TPB), 0, s, d_plan.as<PlanBlock>(), G, d_cells.as<uint16_t>(), d_sfn.as<uint16_t>(), d_rwin.as<uint8_t>(), text);
+            SY_HIP(hipGetLastError());
+        }
+        // ---- CRC-32 of every member
+        std::vector<unsigned long long> m_end(NM);
+        for (uint32_t i = 0; i < NM; i++) m_end[i] = chain.members[i].out_end;
+        uint32_t x2n[64];
+        crc_x2n_table(x2n);
+        Raw d_mend, d_x2n, d_raw;
+        d_mend.alloc((size_t)NM * 8);
+        d_x2n.alloc(256);
+        d_raw.alloc((size_t)NM * 4);
+        std::vector<uint32_t> raw(NM);
+        {
+            ScopedKernelTimer kt(ctx, "inflate_crc");
+            HostPhase hp(ctx, "inflate: crc");
+            ctx->h2d(d_mend.p, m_end.data(), (size_t)NM * 8);
+            ctx->h2d(d_x2n.p, x2n, 256);
+            SY_HIP(hipMemsetAsync(d_raw.p, 0, (size_t)NM * 4, s));
+            if (chain.total) {
+                const uint64_t pieces = (chain.total + CRC_PIECE - 1) / CRC_PIECE;
+                hipLaunchKernelGGL(crc_kernel, dim3((uint32_t)((pieces + CRC_TPB - 1) / CRC_TPB)), dim3(CRC_TPB), 0, s, text, chain.total, d_mend.as<unsigned long long>(), NM,
+                                   d_x2n.as<uint32_t>(), d_raw.as<uint32_t>());
+                SY_HIP(hipGetLastError());
+            }
+        }
+        ctx->d2h(raw.data(), d_raw.p, (size_t)NM * 4);
+        for (uint32_t i = 0; i < NM; i++) {
+            const Member& m = chain.members[i];
+            if (m.on_host) continue;
+            const uint32_t got = crc_finish(x2n, raw[i], m.out_end - m.out_begin);
+            if (got != m.crc) {
+                char msg[128];
+                snprintf(msg, sizeof(msg), "member %u: CRC-32 %08x, the trailer says %08x", i, got, m.crc);
+                throw FormatDecline{msg};
+            }
+        }
+    }
+    SY_HIP(hipStreamSynchronize(s));      // the scratch is freed on the way out
+}
+
+}  // namespace
+}  // namespace sylph
+
+using namespace sylph;
+
+extern "C" {
+
+int sylph_inflate(sylph_ctx* ctx, const void* gz, uint64_t n_bytes, int mem, sylph_inflated** out) {
+    if (!ctx || !out || !gz) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (mem != SYLPH_MEM_HOST && mem != SYLPH_MEM_HOST_PINNED) { set_error("sylph_inflate: the compressed bytes must lie in host memory (mem kind %d)", mem); return SYLPH_ERR_INVALID; }
+    *out = nullptr;
+    ctx->refs.fetch_add(1);
+    sylph_inflated* t = nullptr;
+    int format = 0;
+    const int rc = guarded([&] {
+        t = new sylph_inflated();
+        t->ctx = ctx;
+        try { inflate_impl(t, (const uint8_t*)gz, n_bytes); }
+        catch (const FormatDecline& e) { set_error("sylph_inflate: declined: %s", e.msg.c_str()); format = 1; }
+    });
+    if (rc != SYLPH_OK || format) {
+        if (t) {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            DeviceGuard dg(ctx->device);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (t->buf) (void)hipFree(t->buf);
+            delete t;
+        }
+        ctx_unref(ctx);
+        return rc != SYLPH_OK ? rc : SYLPH_ERR_FORMAT;
+    }
+    *out = t;
+    return SYLPH_OK;
+}
+
+int sylph_inflated_text(const sylph_inflated* t, const void** dev_text, uint64_t* n_bytes) {
+    if (!t) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (dev_text) *dev_text = t->text();
+    if (n_bytes) *n_bytes = t->n;
+    return SYLPH_OK;
+}
+
+int sylph_inflated_info(const sylph_inflated* t, uint64_t* n_members, uint64_t* n_blocks, uint64_t* n_candidates, uint64_t* n_host_members) {
+    if (!t) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    if (n_members) *n_members = t->n_members;
+    if (n_blocks) *n_blocks = t->n_blocks;
+    if (n_candidates) *n_candidates = t->n_candidates;
+    if (n_host_members) *n_host_members = t->n_host_members;
+    return SYLPH_OK;
+}
+
+int sylph_inflated_read(sylph_inflated* t, uint64_t first, uint64_t n, void* host_out) {
+    return guarded([&] {
+        SY_REQUIRE(t && (host_out || n == 0), "null argument");
+        SY_REQUIRE(first <= t->n && n <= t->n - first, "sylph_inflated_read: bytes [%llu, +%llu) of %llu", (unsigned long long)first, (unsigned long long)n,
+                   (unsigned long long)t->n);
+        if (!n) return;
+        std::lock_guard<std::mutex> lock(t->ctx->mu);
+        DeviceGuard dg(t->ctx->device);
+        t->ctx->d2h(host_out, t->text() + first, n);
+    });
+}
+
+void sylph_inflated_destroy(sylph_inflated* t) {
+    if (!t) return;
+    sylph_ctx* ctx = t->ctx;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard dg(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);       // kernels that read the text may still be queued
+        if (t->buf) (void)hipFree(t->buf);
+        delete t;
+    }
+    ctx_unref(ctx);
+}
+
+}  // extern "C"
