@@ -11,8 +11,9 @@
 //                     complete (or zlib's single-code exception), an end-of-block code -> the CANDIDATES (true block starts + ~0)
 //   decode_kernel     one WAVEFRONT per candidate: the block's Huffman tables built in LDS by the 64 lanes (canonical arithmetic,
 //                     10-bit / 8-bit roots, codes beyond the root decoded by first-code comparison — no second-level tables:
-//                     3.4 KB of LDS per wave), symbols decoded wave-uniformly (bit buffer and state live in SGPRs), literals
-//                     collected 64 at a time in a VGPR and stored with one coalesced store, matches copied by all lanes.  Output:
+//                     3.4 KB of LDS per wave), symbols decoded wave-uniformly (bit buffer and state live in SGPRs; the compressed
+//                     words in two VGPRs read with v_readlane; one VGPR as a 64-entry table of 1-3 literal runs), output through
+//                     an LDS ring of the last 4 Ki cells: matches are copied by all lanes, from the ring where they reach.  Output:
 //                     16-bit cells — a byte, or 256 + w = "byte w of the 32 KiB in front of this block", which nobody knows yet.
 //                     The wave runs on through stored / fixed blocks and stops in front of the next dynamic header or behind
 //                     a final block, and reports where.
@@ -21,8 +22,9 @@
 //                     group's first window (32 Ki cells: a byte or a reference into that window), both in LDS (128 KB of the 160)
 //   winchain_kernel   the groups' first windows, one after the other (one workgroup, 32 KiB look-ups per group)
 //   translate_kernel  all blocks side by side: the block's real window composed in LDS, cells -> bytes in their place in the text
-//   crc_kernel        CRC-32 of the text in 1 KiB pieces (slicing-by-4 tables in LDS), each shifted to its place in its member
-//                     by polynomial arithmetic and XORed into the member's word; the host compares with the trailers
+//   crc_kernel        CRC-32 of the text: 64 bytes per lane through slicing-by-4 tables in LDS, the lanes' registers shifted to their
+//                     place by polynomial arithmetic (crc32 is linear over GF(2)) and XORed into the member's word; the host
+//                     compares with the trailers
 //
 // Any doubt — a chain that breaks, an output that does not fit its region, a CRC or ISIZE that differs, no room on the device —
 // returns SYLPH_ERR_FORMAT / SYLPH_ERR_NOMEM and nothing else happens: the caller inflates with zlib as before.
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(SCAN2_TPB) void scan2_kernel(const uint32_t* __rest
 // =================================================================================================================================
 // decode: one wavefront per candidate
 // =================================================================================================================================
+constexpr uint32_t RING = 4096, RING_MASK = RING - 1, FLUSH = 1024;   // cells of a block kept in LDS / leaving for global memory at a time (DecodeOut)
 struct WaveTables {
     uint16_t lit[1 << LIT_ROOT];          // sym << 4 | len;  0 = no code;  T_LONG = longer than the root
     uint16_t dist[1 << DIST_ROOT];        // (the code-length code is built here first, 7-bit root)
@@ -211,28 +214,51 @@ struct WaveTables {
     uint8_t lens[320];
     uint8_t plens[20];
     uint32_t lit_maxlen, dist_maxlen;
+    alignas(16) uint16_t ring[RING];
 };
+
+// Everything the decoding wavefront keeps — bit buffer, positions, counts, the symbol just decoded — is the same in all 64 lanes, and it
+// has to live in SGPRs for the loop to run on the scalar unit: a value that came out of LDS or global memory is "divergent" to the
+// compiler until it has been through v_readfirstlane, and one divergent value in a loop condition drags the whole state into VGPRs
+// behind exec masks (the first build of this file: 7,900 lines of s_and_saveexec).
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 struct WaveBits {                                  // the same reader, but everything in it is wave-uniform (SGPRs)
     const uint32_t* w;
-    uint64_t acc, wpos, wlimit;
+    uint64_t acc, wpos, wlimit, cbase;
     uint32_t cnt;
     bool over;
+    // The stream itself sits in two VGPRs: lane i of `cur` holds word cbase + i, `nxt` the 64 words behind — one coalesced load per
+    // 256 compressed bytes, issued 256 bytes ahead of its use — and a refill is a v_readlane.  (A scalar load per refill put a trip to
+    // memory, ~1-2 thousand cycles with nothing else to do, into the chain of every ten literals.)
+    uint32_t cur, nxt;
     __device__ __forceinline__ void init(const uint32_t* words, uint64_t bitpos, uint64_t limit_words) {
         w = words;
         wlimit = limit_words;
         over = false;
         wpos = bitpos >> 5;
+        cbase = wpos & ~(uint64_t)63;
+        cur = w[cbase + (threadIdx.x & 63)];
+        nxt = w[cbase + 64 + (threadIdx.x & 63)];
         const uint32_t s = (uint32_t)bitpos & 31;
-        acc = (uint64_t)(w[wpos++] >> s);
+        acc = (uint64_t)(word() >> s);
         cnt = 32 - s;
         refill();
     }
+    __device__ __forceinline__ uint32_t word() {                          // the stream's word wpos; wpos moves on
+        const uint32_t v = __builtin_amdgcn_readlane(cur, (uint32_t)(wpos - cbase));
+        wpos++;
+        if (wpos - cbase == 64) {
+            cur = nxt;
+            cbase += 64;
+            nxt = w[cbase + 64 + (threadIdx.x & 63)];
+        }
+        return v;
+    }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32) {
-            if (wpos >= wlimit) over = true;
-            else acc |= (uint64_t)w[wpos] << cnt;
-            wpos++;
+            if (wpos >= wlimit) { over = true; wpos++; }
+            else acc |= (uint64_t)word() << cnt;
             cnt += 32;
         }
     }
@@ -240,6 +266,12 @@ struct WaveBits {                                  // the same reader, but every
     __device__ __forceinline__ void drop(uint32_t k) { acc >>= k; cnt -= k; }
     __device__ __forceinline__ uint32_t take(uint32_t k) { const uint32_t v = peek(k); drop(k); return v; }
     __device__ __forceinline__ uint64_t bitpos() const { return wpos * 32 - cnt; }
+    __device__ __forceinline__ void pin() {                                  // at the head of a loop: whatever the analysis thought, this IS uniform
+        acc = (uint64_t)uni((uint32_t)acc) | (uint64_t)uni((uint32_t)(acc >> 32)) << 32;
+        wpos = (uint64_t)uni((uint32_t)wpos) | (uint64_t)uni((uint32_t)(wpos >> 32)) << 32;
+        cbase = (uint64_t)uni((uint32_t)cbase) | (uint64_t)uni((uint32_t)(cbase >> 32)) << 32;
+        cnt = uni(cnt);
+    }
 };
 
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
@@ -257,7 +289,7 @@ __device__ bool build_code(const uint8_t* lens, uint32_t nsym, uint32_t root, ui
     const uint32_t lane = threadIdx.x & 63;
     uint32_t used = 0;
     for (uint32_t s = lane; s < nsym; s += 64) used |= 1u << lens[s];
-    used = wave_or(used) & ~1u;
+    used = uni(wave_or(used)) & ~1u;
     uint32_t run = 0, code = 0, prev_count = 0, maxlen = 0;
     int left = 1;
     bool over = false;
@@ -304,28 +336,38 @@ __device__ __forceinline__ uint32_t decode_long(uint32_t bits, uint32_t root, ui
                                                 const uint16_t* count, const uint16_t* off) {
     const uint32_t r = __brev(bits);
     for (uint32_t L = root + 1; L <= maxlen; L++) {
-        const uint32_t d = (r >> (32 - L)) - first[L];
-        if (d < count[L]) return (uint32_t)sorted[off[L] + d] << 4 | L;
+        const uint32_t d = (r >> (32 - L)) - uni(first[L]);
+        if (d < uni(count[L])) return uni(sorted[uni(off[L]) + d]) << 4 | L;
     }
     return 0;
 }
 
-struct DecodeOut {                       // the wave's output state (n, m, cap wave-uniform; pend per lane)
+// Where a block's cells go: the last RING of them live in an LDS ring, and whole chunks of FLUSH cells leave for the candidate's
+// region in global memory behind the wave (two 16-byte stores per lane).  A copy whose source lies inside the ring — distance +
+// length <= RING — is LDS reads and writes, ~100 cycles; only a copy from further back loads from global memory (its source left
+// the ring at least a chunk ago, so the stores are issued; the same wave's loads see them).  The first version kept nothing on the
+// chip and every match waited for the acknowledgement of all earlier stores and for its own load — vmcnt counts both —, ~5,000
+// cycles per match: 35 ms for a block of 16 K matches, whatever the literals cost.
+struct DecodeOut {                       // n, flushed, cap: wave-uniform
     uint16_t* out;
-    uint32_t n, m, cap;
-    uint32_t pend;
-    bool overflow;
-    __device__ __forceinline__ void flush() {
-        if (m) {
-            if (n + m > cap) { overflow = true; m = 0; return; }
-            if ((threadIdx.x & 63) < m) out[n + (threadIdx.x & 63)] = (uint16_t)pend;
-            n += m;
-            m = 0;
-        }
+    uint16_t* ring;
+    uint32_t n, flushed, cap;
+    __device__ __forceinline__ void flush_chunk() {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint4* src = reinterpret_cast<const uint4*>(ring + ((flushed + lane * 16) & RING_MASK));
+        uint4* dst = reinterpret_cast<uint4*>(out + flushed + lane * 16);
+        const uint4 a = src[0], b = src[1];
+        dst[0] = a;
+        dst[1] = b;
+        flushed += FLUSH;
     }
-    __device__ __forceinline__ void literal(uint32_t v) {
-        if ((threadIdx.x & 63) == m) pend = v;
-        if (++m == 64) flush();
+    __device__ __forceinline__ void advance(uint32_t k) {
+        n += k;
+        while (n - flushed >= FLUSH) flush_chunk();
+    }
+    __device__ __forceinline__ void finish() {
+        for (uint32_t i = flushed + (threadIdx.x & 63); i < n; i += 64) out[i] = ring[i & RING_MASK];
+        flushed = n;
     }
 };
 
@@ -338,7 +380,8 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
     const uint64_t region = ((start >> 3) - byte0) * REGION_RATIO + (uint64_t)k * REGION_SLACK;
     DecodeOut o;
     o.out = cells + region;
-    o.n = 0; o.m = 0; o.pend = 0; o.overflow = false;
+    o.ring = T.ring;
+    o.n = 0; o.flushed = 0;
     o.cap = (uint32_t)min((uint64_t)0xFFFFFF00u, (next_byte - (start >> 3)) * REGION_RATIO + REGION_SLACK);
     const bool have_window = k != 0;
     WaveBits b;
@@ -346,6 +389,9 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
     uint32_t status = ST_NONE, flags = 0;
     uint64_t end_bit = 0;
     bool first_block = true;
+    uint32_t n_sym = 0, n_far = 0;
+    uint64_t t_build = 0;
+    const uint64_t t_start = __builtin_readcyclecounter();
     while (status == ST_NONE) {
         b.refill();
         const uint64_t header_at = b.bitpos();
@@ -363,13 +409,15 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
             if (b.over || (len ^ 0xFFFFu) != nlen) { status = ST_ERR_STORED; break; }
             const uint64_t from = b.bitpos() >> 3;
             if (from + len > n_words * 4) { status = ST_ERR_OVERRUN; break; }
-            o.flush();
-            if (o.overflow || o.n + len > o.cap) { status = ST_OVERFLOW; break; }
+            if (o.n + len > o.cap) { status = ST_OVERFLOW; break; }
             const uint8_t* gzb = reinterpret_cast<const uint8_t*>(gzw);
-            for (uint32_t i = lane; i < len; i += 64) o.out[o.n + i] = gzb[from + i];
-            o.n += len;
+            for (uint32_t base = 0; base < len; base += 64) {
+                if (base + lane < len) o.ring[(o.n + lane) & RING_MASK] = gzb[from + base + lane];
+                o.advance(min(64u, len - base));
+            }
             b.init(gzw, (from + len) * 8, n_words);
         } else {
+            const uint64_t t_b0 = __builtin_readcyclecounter();
             if (btype == 2) {
                 b.refill();
                 const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
@@ -391,8 +439,9 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 uint32_t i = 0, prev = 0;
                 bool bad = false;
                 while (i < total) {
+                    b.pin();
                     b.refill();
-                    const uint32_t e = T.dist[b.peek(PRE_ROOT)];
+                    const uint32_t e = uni(T.dist[b.peek(PRE_ROOT)]);
                     if (e == 0) { bad = true; break; }
                     b.drop(e & 15);
                     const uint32_t sym = e >> 4;
@@ -407,7 +456,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     i += rep;
                 }
                 __syncthreads();
-                if (bad || b.over || T.lens[256] == 0) { status = b.over ? ST_ERR_OVERRUN : ST_ERR_CODE; break; }
+                if (bad || b.over || uni(T.lens[256]) == 0) { status = b.over ? ST_ERR_OVERRUN : ST_ERR_CODE; break; }
                 if (!build_code(T.lens, hlit, LIT_ROOT, T.lit, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off, &T.lit_maxlen, 1) ||
                     !build_code(T.lens + hlit, hdist, DIST_ROOT, T.dist, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off, &T.dist_maxlen, 2)) {
                     status = ST_ERR_CODE;
@@ -420,27 +469,48 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 build_code(T.lens, 288, LIT_ROOT, T.lit, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off, &T.lit_maxlen, 1);
                 build_code(T.lens + 288, 32, DIST_ROOT, T.dist, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off, &T.dist_maxlen, 2);
             }
-            const uint32_t lit_max = T.lit_maxlen, dist_max = T.dist_maxlen;
+            const uint32_t lit_max = uni(T.lit_maxlen), dist_max = uni(T.dist_maxlen);
+            // One VGPR as a 64-entry table over the next SIX bits: lane i holds what the bits i decode to when that is one, two or three
+            // literals — bits used | count << 4 | the bytes — and 0 when the first code is longer, or no literal.  A look-up is a
+            // v_readlane: no trip to the LDS for the symbols a FASTQ file is mostly made of (bases at 2-3 bits, binned qualities).
+            uint32_t t0 = 0;
+            {
+                uint32_t idx = lane, left = 6, used = 0, cnt = 0, syms = 0;
+                for (int j = 0; j < 3; j++) {
+                    const uint32_t e = T.lit[idx];
+                    const uint32_t l = e & 15, sy = e >> 4;
+                    if (e == T_LONG || l == 0 || l > left || sy >= 256) break;
+                    syms |= sy << (8 * j);
+                    cnt++; used += l; left -= l; idx >>= l;
+                }
+                if (cnt) t0 = used | cnt << 4 | syms << 8;
+            }
+            t_build += __builtin_readcyclecounter() - t_b0;
             // ---- the block's symbols
             for (;;) {
+                n_sym++;
+                b.pin();
+                o.n = uni(o.n); o.flushed = uni(o.flushed);
                 b.refill();
-                uint32_t e = T.lit[b.peek(LIT_ROOT)];
+                const uint32_t e0 = __builtin_amdgcn_readlane(t0, b.peek(6));
+                if (e0) {
+                    const uint32_t c = (e0 >> 4) & 3;
+                    if (o.n + c > o.cap) { status = ST_OVERFLOW; break; }
+                    if (lane < c) o.ring[(o.n + lane) & RING_MASK] = (uint16_t)((e0 >> (8 + 8 * lane)) & 0xFF);
+                    o.advance(c);
+                    b.drop(e0 & 15);
+                    continue;
+                }
+                uint32_t e = uni(T.lit[b.peek(LIT_ROOT)]);
                 if (e == T_LONG) e = decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off);
-                e = __builtin_amdgcn_readfirstlane(e);
                 if (e == 0) { status = ST_ERR_CODE; break; }
                 b.drop(e & 15);
-                uint32_t sym = e >> 4;
+                const uint32_t sym = e >> 4;
                 if (sym < 256) {
-                    o.literal(sym);
-                    // (>= 33 bits were there: a second and a third code of <= 15 bits fit without a refill)
-                    e = T.lit[b.peek(LIT_ROOT)];
-                    if (e == T_LONG) e = decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off);
-                    e = __builtin_amdgcn_readfirstlane(e);
-                    if (e == 0) { status = ST_ERR_CODE; break; }
-                    b.drop(e & 15);
-                    sym = e >> 4;
-                    if (sym < 256) { o.literal(sym); continue; }
-                    b.refill();
+                    if (o.n + 1 > o.cap) { status = ST_OVERFLOW; break; }
+                    if (lane == 0) o.ring[o.n & RING_MASK] = (uint16_t)sym;
+                    o.advance(1);
+                    continue;
                 }
                 if (sym == 256) break;
                 const uint32_t s = sym - 257;
@@ -450,9 +520,8 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 else if (s == 28) len = 258;
                 else { const uint32_t eb = (s - 4) >> 2; len = 3 + ((4 + (s & 3)) << eb) + b.take(eb); }
                 b.refill();
-                uint32_t de = T.dist[b.peek(DIST_ROOT)];
+                uint32_t de = uni(T.dist[b.peek(DIST_ROOT)]);
                 if (de == T_LONG) de = decode_long((uint32_t)b.acc, DIST_ROOT, dist_max, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off);
-                de = __builtin_amdgcn_readfirstlane(de);
                 if (de == 0) { status = ST_ERR_CODE; break; }
                 b.drop(de & 15);
                 const uint32_t ds = de >> 4;
@@ -461,36 +530,34 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 if (ds < 4) dist = 1 + ds;
                 else { const uint32_t eb = (ds - 2) >> 1; dist = 1 + ((2 + (ds & 1)) << eb) + b.take(eb); }
                 if (b.over) { status = ST_ERR_OVERRUN; break; }
-                o.flush();
                 if (dist > o.n) {
                     if (!have_window || dist - o.n > WINDOW) { status = ST_ERR_DISTANCE; break; }
                     flags |= 1;
                 }
-                if (o.overflow || o.n + len > o.cap) { status = ST_OVERFLOW; break; }
-                const long long src0 = (long long)o.n - (long long)dist;
-                if (dist >= len) {
-                    for (uint32_t i = lane; i < len; i += 64) {
-                        const long long src = src0 + i;
-                        o.out[o.n + i] = src >= 0 ? o.out[src] : (uint16_t)(256 + WINDOW + src);
-                    }
-                } else if (dist == 1) {
-                    const uint16_t v = src0 >= 0 ? o.out[src0] : (uint16_t)(256 + WINDOW + src0);
-                    for (uint32_t i = lane; i < len; i += 64) o.out[o.n + i] = v;
-                } else {
-                    for (uint32_t i = lane; i < len; i += 64) {
-                        const long long src = src0 + (i % dist);
-                        o.out[o.n + i] = src >= 0 ? o.out[src] : (uint16_t)(256 + WINDOW + src);
+                if (o.n + len > o.cap) { status = ST_OVERFLOW; break; }
+                // sources: cell n - dist + (i mod dist) for i < len — all of them in front of n, whatever the overlap
+                const int src0 = (int)o.n - (int)dist;
+                const bool near = dist + len <= RING;
+                n_far += near ? 0u : 1u;
+                for (uint32_t base = 0; base < len; base += 64) {
+                    const uint32_t i = base + lane;
+                    if (i < len) {
+                        const int src = src0 + (int)(dist >= len ? i : dist == 1 ? 0u : i % dist);
+                        uint16_t v;
+                        if (src < 0) v = (uint16_t)(256 + WINDOW + src);
+                        else if (near) v = o.ring[src & RING_MASK];
+                        else v = o.out[src];
+                        o.ring[(o.n + i) & RING_MASK] = v;
                     }
                 }
-                o.n += len;
+                o.advance(len);
             }
             if (status != ST_NONE) break;
             if (b.over) { status = ST_ERR_OVERRUN; break; }
         }
         if (bfinal) { status = ST_FINAL; end_bit = b.bitpos(); }
     }
-    o.flush();
-    if (o.overflow && status < ST_ERR_CODE) status = ST_OVERFLOW;
+    o.finish();
     if (lane == 0) {
         BlockResult r;
         r.end_bit = end_bit;
@@ -498,6 +565,10 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
         r.status = status;
         r.flags = flags;
         r.pad = 0;
+        r.stats[0] = n_sym;
+        r.stats[1] = n_far;
+        r.stats[2] = (uint32_t)(t_build >> 10);
+        r.stats[3] = (uint32_t)((__builtin_readcyclecounter() - t_start) >> 10);
         res[k] = r;
     }
 }
@@ -605,13 +676,20 @@ __global__ __launch_bounds__(TR_TPB) void translate_kernel(const PlanBlock* __re
 // CRC-32
 // =================================================================================================================================
 constexpr int CRC_TPB = 256;
-constexpr uint32_t CRC_PIECE = 1024;
-// member_end[m]: ascending end offsets of the members in the text.  raw[m] ^= (register of the piece, started at 0) shifted by the
-// bytes between the piece's end and the member's end.
+constexpr uint32_t CRC_LANE = 64;                       // bytes per lane and step
+constexpr uint32_t CRC_STEP = 64 * CRC_LANE;            // bytes per wavefront and step: 4 KiB
+constexpr uint32_t CRC_SPAN = 16 * CRC_STEP;            // bytes per wavefront: 64 KiB
+// member_end[m]: ascending end offsets of the members in the text.  raw[m] ^= (register of a piece, started at 0) shifted by the
+// bytes between the piece's end and the member's end.  A wavefront walks 64 KiB in steps of 4 KiB: every lane takes the register
+// of its 64 bytes through the slicing tables and multiplies it by x^(8 * bytes behind it in the step) — a constant per lane —, the
+// 64 products are XORed across the wave, and the step joins the wave's running register (one more multiplication by a constant);
+// the expensive shift by an arbitrary distance (crc_shift: ~30 multiplications) happens once per span, or where a member ends.
+// Steps that hold a member boundary (one in sixteen for BGZF) or the text's ragged end go lane by lane.
 __global__ __launch_bounds__(CRC_TPB) void crc_kernel(const uint8_t* __restrict__ text, uint64_t total, const unsigned long long* __restrict__ member_end,
                                                       uint32_t n_members, const uint32_t* __restrict__ x2n_g, uint32_t* __restrict__ raw) {
     __shared__ uint32_t T[4][256];
     __shared__ uint32_t x2n[64];
+    __shared__ uint32_t lane_k[64];                     // x^(8 * 64 * (63 - lane))
     for (uint32_t i = threadIdx.x; i < 256; i += CRC_TPB) {
         uint32_t c = i;
         for (int b = 0; b < 8; b++) c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
@@ -625,30 +703,67 @@ __global__ __launch_bounds__(CRC_TPB) void crc_kernel(const uint8_t* __restrict_
         const uint32_t c3 = (c2 >> 8) ^ T[0][c2 & 0xFF];
         T[1][i] = c1; T[2][i] = c2; T[3][i] = c3;
     }
+    if (threadIdx.x < 64) lane_k[threadIdx.x] = crc_x8n(x2n, (uint64_t)CRC_LANE * (63 - threadIdx.x));
     __syncthreads();
-    const uint64_t piece = (uint64_t)blockIdx.x * CRC_TPB + threadIdx.x;
-    uint64_t pos = piece * CRC_PIECE;
-    if (pos >= total) return;
-    const uint64_t end = min(total, pos + CRC_PIECE);
-    // the member that holds `pos`: the first whose end lies behind it
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (CRC_TPB / 64) + (threadIdx.x >> 6);
+    const uint64_t span0 = wave * CRC_SPAN;
+    if (span0 >= total) return;
+    const uint64_t span1 = min(total, span0 + CRC_SPAN);
+    const uint32_t k_step = crc_x8n(x2n, CRC_STEP), k_mine = lane_k[lane];
+    // the member that holds span0: the first whose end lies behind it
     uint32_t lo = 0, hi = n_members - 1;
-    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (member_end[mid] > pos) hi = mid; else lo = mid + 1; }
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (member_end[mid] > span0) hi = mid; else lo = mid + 1; }
     uint32_t m = lo;
-    while (pos < end) {
-        while (member_end[m] <= pos) m++;                                    // (empty members)
+    uint32_t acc = 0;                                   // the wave's running register over [acc_from, pos), all of it inside member m
+    bool have = false;
+    for (uint64_t pos = span0; pos < span1; pos += CRC_STEP) {
+        while (member_end[m] <= pos) m++;
         const uint64_t m_end = member_end[m];
-        const uint64_t stop = min(end, m_end);
-        uint32_t reg = 0;
-        uint64_t p = pos;
-        while (p < stop && (p & 3)) { reg = T[0][(reg ^ text[p]) & 0xFF] ^ (reg >> 8); p++; }
-        for (; p + 4 <= stop; p += 4) {
-            reg ^= *reinterpret_cast<const uint32_t*>(text + p);
-            reg = T[3][reg & 0xFF] ^ T[2][(reg >> 8) & 0xFF] ^ T[1][(reg >> 16) & 0xFF] ^ T[0][reg >> 24];
+        if (pos + CRC_STEP <= span1 && pos + CRC_STEP <= m_end) {
+            const uint4* p = reinterpret_cast<const uint4*>(text + pos + (uint64_t)lane * CRC_LANE);
+            uint32_t reg = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = p[q];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    reg ^= w[j];
+                    reg = T[3][reg & 0xFF] ^ T[2][(reg >> 8) & 0xFF] ^ T[1][(reg >> 16) & 0xFF] ^ T[0][reg >> 24];
+                }
+            }
+            uint32_t x = crc_multmodp(k_mine, reg);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) x ^= __shfl_xor(x, o);
+            acc = (have ? crc_multmodp(k_step, acc) : 0) ^ x;
+            have = true;
+            if (pos + CRC_STEP == m_end) {              // the member ends with this step: its word takes what the wave holds, unshifted
+                if (lane == 0) atomicXor(&raw[m], acc);
+                have = false;
+                acc = 0;
+            }
+            continue;
         }
-        while (p < stop) { reg = T[0][(reg ^ text[p]) & 0xFF] ^ (reg >> 8); p++; }
-        atomicXor(&raw[m], crc_shift(x2n, reg, m_end - stop));
-        pos = stop;
+        // a member ends inside this step, or the text does: first what the wave holds, then lane by lane
+        if (have) {
+            if (lane == 0) atomicXor(&raw[m], crc_shift(x2n, acc, m_end - pos));
+            have = false;
+            acc = 0;
+        }
+        uint64_t q = pos + (uint64_t)lane * CRC_LANE;
+        const uint64_t q_end = min(span1, q + CRC_LANE);
+        uint32_t mm = m;
+        while (q < q_end) {
+            while (member_end[mm] <= q) mm++;
+            const uint64_t e = member_end[mm];
+            const uint64_t stop = min(q_end, e);
+            uint32_t reg = 0;
+            for (; q < stop; q++) reg = T[0][(reg ^ text[q]) & 0xFF] ^ (reg >> 8);
+            atomicXor(&raw[mm], crc_shift(x2n, reg, e - stop));
+        }
     }
+    if (have && lane == 0) atomicXor(&raw[m], crc_shift(x2n, acc, member_end[m] - span1));
 }
 
 // =================================================================================================================================
@@ -752,6 +867,12 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
         SY_HIP(hipGetLastError());
     }
     ctx->d2h(res.data(), d_res.p, (size_t)K * sizeof(BlockResult));
+    if (getenv("SYLPH_HIP_INFLATE_STATS")) {
+        uint64_t sym = 0, far = 0, tb = 0, tt = 0, tmax = 0, cells_out = 0;
+        for (const BlockResult& r : res) { sym += r.stats[0]; far += r.stats[1]; tb += r.stats[2]; tt += r.stats[3]; tmax = std::max<uint64_t>(tmax, r.stats[3]); cells_out += r.n_out; }
+        fprintf(stderr, "[sylph_hip inflate] %u candidates: %llu symbol-loop turns, %llu copies from global memory, %llu cells; per wave: %.0f k-cycles mean (%.0f on headers + tables), %llu max\n",
+                K, (unsigned long long)sym, (unsigned long long)far, (unsigned long long)cells_out, (double)tt / K, (double)tb / K, (unsigned long long)tmax);
+    }
     // ---- the chain
     std::vector<std::vector<uint8_t>> host_bytes;
     Chain chain = chain_walk(gz, (size_t)n, cand, res.data(), [&](size_t p, size_t* end, uint64_t* n_out) {
@@ -833,8 +954,8 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
             ctx->h2d(d_x2n.p, x2n, 256);
             SY_HIP(hipMemsetAsync(d_raw.p, 0, (size_t)NM * 4, s));
             if (chain.total) {
-                const uint64_t pieces = (chain.total + CRC_PIECE - 1) / CRC_PIECE;
-                hipLaunchKernelGGL(crc_kernel, dim3((uint32_t)((pieces + CRC_TPB - 1) / CRC_TPB)), dim3(CRC_TPB), 0, s, text, chain.total, d_mend.as<unsigned long long>(), NM,
+                const uint64_t waves = (chain.total + CRC_SPAN - 1) / CRC_SPAN;
+                hipLaunchKernelGGL(crc_kernel, dim3((uint32_t)((waves + CRC_TPB / 64 - 1) / (CRC_TPB / 64))), dim3(CRC_TPB), 0, s, text, chain.total, d_mend.as<unsigned long long>(), NM,
                                    d_x2n.as<uint32_t>(), d_raw.as<uint32_t>());
                 SY_HIP(hipGetLastError());
             }

@@ -52,6 +52,8 @@ struct BlockResult {
     uint32_t status;
     uint32_t flags;        // bit 0: the output holds window references
     uint32_t pad;
+    uint32_t stats[4];     // diagnostics (SYLPH_HIP_INFLATE_STATS=1): symbols decoded, copies served from global memory, shader
+                           // kilo-cycles spent on headers + tables, kilo-cycles in all
 };
 
 // ---- CRC-32 (reflected, polynomial 0xEDB88320) as polynomial arithmetic over GF(2) ----------------------------------------------

@@ -3,6 +3,9 @@
 // bookkeeping here, run the statistics on the containment results, print the reference's TSV rows.
 #include <functional>
 #include <sys/stat.h>
+#include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -346,9 +349,44 @@ void sketch_indexed(Engine& e, const std::function<sylph_sketch*()>& open_sessio
 // nothing, when the files are not plain four-line FASTQ (SYLPH_ERR_FORMAT, gzip, FASTA): the caller takes the host route, whose
 // record and error semantics are needletail's.
 // `text`: the files' text where it lies in host memory already (the inflated copies of gzip files) instead of the files themselves
+// Round 6, gzip on the device (csrc/inflate.hip): a sample whose files are gzip sends their COMPRESSED bytes (0.4 B per base instead of
+// 2.1) and the library inflates them there — sylph_inflate; SYLPH_HIP_INFLATE_DEVICE=0 keeps the host's inflate.  What the library
+// declines (SYLPH_ERR_FORMAT: damaged, not gzip after all, a stream it does not take; SYLPH_ERR_NOMEM) goes the host way, whose
+// error semantics are needletail's.
+bool device_inflate_enabled() {
+    static const bool on = [] {
+        if (!device_feed_enabled()) return false;
+        if (const char* e = getenv("SYLPH_HIP_INFLATE_DEVICE")) return atoi(e) != 0;
+        return true;
+    }();
+    return on;
+}
+namespace {
+struct MappedFile {                       // the compressed bytes of one file (read-only mapping of the page cache)
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    explicit MappedFile(const std::string& path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void* p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (p != MAP_FAILED) { data = (const uint8_t*)p; size = (size_t)st.st_size; }
+        }
+        close(fd);
+    }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+    ~MappedFile() { if (data) munmap(const_cast<uint8_t*>(data), size); }
+};
+struct InflatedText { sylph_inflated* h = nullptr; ~InflatedText() { sylph_inflated_destroy(h); } };
+}  // namespace
+
 bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& open_session, const std::string& f1, const std::string* f2,
                             double& mean_read_length, const IndexedInput* text = nullptr) {
-    if (!device_feed_enabled() || !e.ready()) return false;
+    if (!device_feed_enabled()) return false;
+    const bool gz = !text && device_inflate_enabled() && is_gzip_file(f1) && (!f2 || is_gzip_file(*f2));
+    if (!gz && !e.ready()) return false;             // (a gzip sample waits for the engine: nothing on the host side is faster than that)
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
@@ -362,7 +400,25 @@ bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& ope
     std::vector<std::string> files{f1};
     if (f2) files.push_back(*f2);
     std::vector<TextUploader::Text> texts;
-    if (text) {
+    InflatedText inflated[2];                        // (destroyed behind the indexes that borrow their text: declared before them)
+    if (gz) {
+        for (size_t i = 0; i < files.size(); i++) {
+            MappedFile m(files[i]);
+            if (!m.data) return false;
+            const int rc = sylph_inflate(ctx, m.data, m.size, SYLPH_MEM_HOST, &inflated[i].h);
+            if (rc == SYLPH_ERR_FORMAT || rc == SYLPH_ERR_NOMEM) {
+                if (trace) fprintf(stderr, "[sylph_hip feed] device inflate declined %s: %s\n", files[i].c_str(), sylph_last_error());
+                return false;
+            }
+            hip_check(rc, "sylph_inflate");
+            const void* dev = nullptr;
+            uint64_t bytes = 0;
+            hip_check(sylph_inflated_text(inflated[i].h, &dev, &bytes), "sylph_inflated_text");
+            if (!bytes) return false;
+            texts.push_back(TextUploader::Text{(const uint8_t*)dev, bytes});
+        }
+        lap("device route: gzip inflated on the device");
+    } else if (text) {
         // The first text an engine sends pays for the route's device buffers (~40-90 ms of allocations, once); skipping the host's index
         // and gather of an inflated copy buys that back only for a sample of some size: 0.45 against 0.53 s for a 1 Gbp gzip pair, 0.34
         // against 0.30 s for its first mate alone (profiles/r05_feed_device_route.txt)
@@ -372,7 +428,7 @@ bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& ope
         if (f2) mem.push_back({text->b->data, text->b->size});
         if (!e.text.send(ctx, mem, parse_threads(), texts)) return false;
     } else if (!e.text.send(ctx, files, parse_threads(), texts)) return false;
-    lap("device route: text uploaded");
+    if (!gz) lap("device route: text uploaded");
     struct Fq { sylph_fastq* f = nullptr; ~Fq() { sylph_fastq_destroy(f); } } fa, fb;
     auto index = [&](const TextUploader::Text& t, Fq& out) {
         const int rc = sylph_fastq_index(ctx, t.dev, t.bytes, SYLPH_MEM_DEVICE, &out.f);
@@ -816,10 +872,11 @@ int sketch(Engine& e, const SketchArgs& args) {
         // an engine that is up takes plain FASTQ by the device route (no host index at all); its first sample, whose index is built while
         // the GPU runtime initialises, and everything the device route declines go the host way
         const auto& jf = job_files[j];
-        const bool gz = device_feed_enabled() && is_gzip_file(jf.first);         // inflated on the host, its text then sent as it is
-        const bool dev = device_feed_enabled() && eng.ready() && !gz;
+        const bool gz = device_feed_enabled() && is_gzip_file(jf.first);
+        const bool gz_dev = gz && device_inflate_enabled();                      // round 6: the compressed bytes travel, the device inflates
+        const bool dev = device_feed_enabled() && (gz_dev || (eng.ready() && !gz));
         std::optional<IndexedInput> pre;
-        if (gz) pre = index_inputs(jf.first, jf.second ? &*jf.second : nullptr, false);
+        if (gz && !gz_dev) pre = index_inputs(jf.first, jf.second ? &*jf.second : nullptr, false);   // inflated on the host, its text then sent as it is
         else if (!dev) pre = ahead.get(j);
         trace_mark(dev ? "sketch: the sample goes the device route" : "sketch: the sample's files are indexed (or not indexable)");
         if (++indexes_obtained == n_jobs) set_no_more_inflates(true);   // nobody will want a recycled inflate buffer any more
@@ -1323,9 +1380,10 @@ int contain(Engine& e, ContainCmdArgs args, bool pseudotax_in, FILE* out) {
                     fprintf(stderr, "ERROR [sylph_hip] %s -k %llu is not equal to -k %llu found in sketches. Continuing without sketching.\n", files[0].c_str(), (unsigned long long)args.k, (unsigned long long)genome_k);
                 } else {
                     const bool gz = device_feed_enabled() && is_gzip_file(files[0]);   // (see sketch(): the device route)
-                    const bool dev = device_feed_enabled() && eng.ready() && !gz;
+                    const bool gz_dev = gz && device_inflate_enabled();
+                    const bool dev = device_feed_enabled() && (gz_dev || (eng.ready() && !gz));
                     std::optional<IndexedInput> pre;
-                    if (gz) pre = index_inputs(files[0], files.size() > 1 ? &files[1] : nullptr, false);
+                    if (gz && !gz_dev) pre = index_inputs(files[0], files.size() > 1 ? &files[1] : nullptr, false);
                     else if (!dev) pre = ahead.get(j);
                     if (++indexes_obtained == n_raw) set_no_more_inflates(true);
                     struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) background([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }); } } later{pre};

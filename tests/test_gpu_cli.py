@@ -487,8 +487,16 @@ def test_device_fastq_route_equals_the_host_feed(data):
         got[dev] = (p.returncode, {f.name: f.read_bytes() for f in sorted(o.iterdir())})
         if dev == "1":
             assert "device route: pushed" in p.stderr, p.stderr[-3000:]
+            # round 6: the two gzip pairs (single-member, blocked) send their COMPRESSED bytes; the device inflates (csrc/inflate.hip)
+            assert p.stderr.count("device route: gzip inflated on the device") == 2, p.stderr[-3000:]
         else:
             assert "device route" not in p.stderr
+    # ... and with the device's inflate switched off the host inflates and the TEXT travels, as in round 5: the same files
+    o = d / "devroute_hostinflate"
+    p = run("sketch", "-t", "1", "-1", *firsts, "-2", *seconds, "-r", d / "da_1.fq", "-d", o, accept_exact=False, check=False,
+            env_extra={"SYLPH_HIP_FEED_DEVICE": "1", "SYLPH_HIP_INFLATE_DEVICE": "0", "SYLPH_HIP_FEED_TRACE": "1"})
+    assert p.returncode == 0 and "gzip inflated on the device" not in p.stderr and "device route: pushed" in p.stderr
+    assert {f.name: f.read_bytes() for f in sorted(o.iterdir())} == got["1"][1]
     assert got["0"][0] == got["1"][0] == 0
     assert sorted(got["0"][1]) == sorted(got["1"][1]) and len(got["0"][1]) >= 5
     for name in got["0"][1]:
@@ -500,6 +508,26 @@ def test_device_fastq_route_equals_the_host_feed(data):
                 accept_exact=False, env_extra={"SYLPH_HIP_FEED_DEVICE": dev})
         rows[dev] = p.stdout
     assert rows["0"] == rows["1"] and rows["0"].count("\n") >= 4
+
+
+def test_damaged_gzip_goes_the_host_way(data):
+    """A truncated .fastq.gz: the device's inflate declines it (SYLPH_ERR_FORMAT: the chain of deflate blocks ends before a final block)
+    and the host reader takes the file, with the reference's behaviour for it — the same exit code, messages and sketch (if any) as with
+    the device's inflate switched off."""
+    d = data["dir"]
+    t1 = (d / "s_1.fq").read_bytes()
+    gz = gzip.compress(t1, 6)
+    (d / "trunc.fq.gz").write_bytes(gz[: len(gz) * 2 // 3])
+    (d / "flipped.fq.gz").write_bytes(gz[:5000] + bytes([gz[5000] ^ 0x40]) + gz[5001:])
+    res = {}
+    for inf in ("1", "0"):
+        o = d / f"damaged_{inf}"
+        p = run("sketch", "-t", "1", "-r", d / "da_1.fq", d / "trunc.fq.gz", d / "flipped.fq.gz", d / "single.fastq.gz", "-d", o, check=False,
+                env_extra={"SYLPH_HIP_INFLATE_DEVICE": inf, "SYLPH_HIP_FEED_TRACE": "1"})
+        res[inf] = (p.returncode, {f.name: f.read_bytes() for f in sorted(o.iterdir())}, sorted(ln for ln in p.stderr.split("\n") if "WARN" in ln or "ERROR" in ln))
+        if inf == "1":
+            assert p.stderr.count("device inflate declined") == 2 and p.stderr.count("gzip inflated on the device") == 1, p.stderr[-3000:]
+    assert res["1"] == res["0"] and "single.fastq.gz.sylsp" in res["1"][1]
 
 
 def test_reads_from_a_named_pipe(data):
