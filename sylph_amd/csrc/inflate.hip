@@ -211,10 +211,10 @@ struct WaveTables {
     uint16_t dist_sorted[32];
     uint16_t lit_first[16], lit_count[16], lit_off[16];
     uint16_t dist_first[16], dist_count[16], dist_off[16];
-    uint8_t lens[320];
-    uint8_t plens[20];
+    uint8_t lens[320 + 64];
+    uint8_t plens[20 + 64];
     uint32_t lit_maxlen, dist_maxlen;
-    alignas(16) uint16_t ring[RING];
+    alignas(16) uint16_t ring[RING + 64];   // (+64: where the lanes that have nothing to write write — see DUMMY below)
 };
 
 // Everything the decoding wavefront keeps — bit buffer, positions, counts, the symbol just decoded — is the same in all 64 lanes, and it
@@ -266,12 +266,6 @@ struct WaveBits {                                  // the same reader, but every
     __device__ __forceinline__ void drop(uint32_t k) { acc >>= k; cnt -= k; }
     __device__ __forceinline__ uint32_t take(uint32_t k) { const uint32_t v = peek(k); drop(k); return v; }
     __device__ __forceinline__ uint64_t bitpos() const { return wpos * 32 - cnt; }
-    __device__ __forceinline__ void pin() {                                  // at the head of a loop: whatever the analysis thought, this IS uniform
-        acc = (uint64_t)uni((uint32_t)acc) | (uint64_t)uni((uint32_t)(acc >> 32)) << 32;
-        wpos = (uint64_t)uni((uint32_t)wpos) | (uint64_t)uni((uint32_t)(wpos >> 32)) << 32;
-        cbase = (uint64_t)uni((uint32_t)cbase) | (uint64_t)uni((uint32_t)(cbase >> 32)) << 32;
-        cnt = uni(cnt);
-    }
 };
 
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
@@ -284,11 +278,14 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 // Canonical code from lens[0, nsym): sorted symbols, first code / count / offset per length, the root table.  kind: 0 = the
 // code-length code (must be complete), 1 = literal/length, 2 = distance (zlib inflate_table: an incomplete code is fine only when
 // it is a single 1-bit code; a distance code with no code at all is fine).  Wave-uniform result.
-__device__ bool build_code(const uint8_t* lens, uint32_t nsym, uint32_t root, uint16_t* tab, uint16_t* sorted, uint16_t* first, uint16_t* count,
+__device__ bool build_code_raw(const uint8_t* lens, uint32_t nsym, uint32_t root, uint16_t* tab, uint16_t* sorted, uint16_t* first, uint16_t* count,
                            uint16_t* off, uint32_t* maxlen_out, int kind) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t used = 0;
-    for (uint32_t s = lane; s < nsym; s += 64) used |= 1u << lens[s];
+    // (every loop of this kernel counts in wave-uniform steps and tests the lane inside: a loop whose induction variable depends on the
+    //  lane has, for the compiler, an exit that lanes may take at different times — and everything behind it stops being uniform)
+    for (uint32_t base = 0; base < nsym; base += 64)
+        if (base + lane < nsym) used |= 1u << lens[base + lane];
     used = uni(wave_or(used)) & ~1u;
     uint32_t run = 0, code = 0, prev_count = 0, maxlen = 0;
     int left = 1;
@@ -318,7 +315,8 @@ __device__ bool build_code(const uint8_t* lens, uint32_t nsym, uint32_t root, ui
     if (run == 0) { if (kind != 2) return false; }
     else if (left > 0 && (kind == 0 || maxlen != 1)) return false;
     const uint32_t top = min(root, maxlen);
-    for (uint32_t idx = lane; idx < (1u << root); idx += 64) {
+    for (uint32_t base = 0; base < (1u << root); base += 64) {
+        const uint32_t idx = base + lane;
         const uint32_t r = __brev(idx) >> (32 - root);
         uint32_t e = maxlen > root ? T_LONG : 0;
         for (uint32_t L = 1; L <= top; L++) {
@@ -329,6 +327,12 @@ __device__ bool build_code(const uint8_t* lens, uint32_t nsym, uint32_t root, ui
     }
     __syncthreads();
     return true;
+}
+
+// (the value a call returns is divergent to the compiler, whatever the callee computes: one v_readfirstlane says what it is)
+__device__ __forceinline__ bool build_code(const uint8_t* lens, uint32_t nsym, uint32_t root, uint16_t* tab, uint16_t* sorted, uint16_t* first, uint16_t* count,
+                                           uint16_t* off, uint32_t* maxlen_out, int kind) {
+    return uni(build_code_raw(lens, nsym, root, tab, sorted, first, count, off, maxlen_out, kind) ? 1u : 0u) != 0;
 }
 
 // a code longer than the root: first-code comparison, lengths root+1 .. maxlen.  -> sym << 4 | len, or 0
@@ -342,6 +346,10 @@ __device__ __forceinline__ uint32_t decode_long(uint32_t bits, uint32_t root, ui
     return 0;
 }
 
+// DUMMY: a store that only some lanes make is written as a store every lane makes, the idle ones into a pad behind the array — an
+// `if (lane < c)` is a divergent branch, and LLVM's uniformity analysis marks every phi of the block where its two sides meet as
+// divergent; when that block is also where a loop's `continue` / `break` paths meet, the loop's exit stops being uniform and all of its
+// state moves into VGPRs behind exec masks (found with opt -passes='print<uniformity>').
 // Where a block's cells go: the last RING of them live in an LDS ring, and whole chunks of FLUSH cells leave for the candidate's
 // region in global memory behind the wave (two 16-byte stores per lane).  A copy whose source lies inside the ring — distance +
 // length <= RING — is LDS reads and writes, ~100 cycles; only a copy from further back loads from global memory (its source left
@@ -366,7 +374,10 @@ struct DecodeOut {                       // n, flushed, cap: wave-uniform
         while (n - flushed >= FLUSH) flush_chunk();
     }
     __device__ __forceinline__ void finish() {
-        for (uint32_t i = flushed + (threadIdx.x & 63); i < n; i += 64) out[i] = ring[i & RING_MASK];
+        for (uint32_t base = flushed; base < n; base += 64) {
+            const uint32_t i = base + (threadIdx.x & 63);
+            if (i < n) out[i] = ring[i & RING_MASK];
+        }
         flushed = n;
     }
 };
@@ -391,8 +402,10 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
     bool first_block = true;
     uint32_t n_sym = 0, n_far = 0;
     uint64_t t_build = 0;
+
     const uint64_t t_start = __builtin_readcyclecounter();
-    while (status == ST_NONE) {
+    for (;;) {
+        if (status != ST_NONE) break;
         b.refill();
         const uint64_t header_at = b.bitpos();
         const uint32_t bfinal = b.peek(1), btype = (b.peek(3) >> 1);
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
             if (o.n + len > o.cap) { status = ST_OVERFLOW; break; }
             const uint8_t* gzb = reinterpret_cast<const uint8_t*>(gzw);
             for (uint32_t base = 0; base < len; base += 64) {
-                if (base + lane < len) o.ring[(o.n + lane) & RING_MASK] = gzb[from + base + lane];
+                o.ring[base + lane < len ? (o.n + lane) & RING_MASK : RING + lane] = gzb[from + min(base + lane, len - 1)];
                 o.advance(min(64u, len - base));
             }
             b.init(gzw, (from + len) * 8, n_words);
@@ -422,12 +435,12 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 b.refill();
                 const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
                 if (hlit > 286 || hdist > 30) { status = ST_ERR_CODE; break; }
-                if (lane < 19) T.plens[lane] = 0;
+                T.plens[lane < 19 ? lane : 20 + lane] = 0;   // (no branch on the lane: DUMMY)
                 __syncthreads();
                 for (uint32_t i = 0; i < hclen; i++) {
                     b.refill();
                     const uint32_t v = b.take(3);
-                    if (lane == 0) T.plens[CL_ORDER[i]] = (uint8_t)v;
+                    T.plens[lane == 0 ? (uint32_t)CL_ORDER[i] : 20 + lane] = (uint8_t)v;
                 }
                 __syncthreads();
                 uint32_t pre_max;
@@ -439,7 +452,6 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 uint32_t i = 0, prev = 0;
                 bool bad = false;
                 while (i < total) {
-                    b.pin();
                     b.refill();
                     const uint32_t e = uni(T.dist[b.peek(PRE_ROOT)]);
                     if (e == 0) { bad = true; break; }
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     else if (sym == 17) { val = 0; rep = 3 + b.take(3); }
                     else { val = 0; rep = 11 + b.take(7); }
                     if (i + rep > total) { bad = true; break; }
-                    for (uint32_t j = lane; j < rep; j += 64) T.lens[i + j] = (uint8_t)val;
+                    for (uint32_t jb = 0; jb < rep; jb += 64) T.lens[jb + lane < rep ? i + jb + lane : 320 + lane] = (uint8_t)val;
                     prev = val;
                     i += rep;
                 }
@@ -463,7 +475,10 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     break;
                 }
             } else {
-                for (uint32_t s = lane; s < 288; s += 64) T.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                for (uint32_t sb = 0; sb < 288; sb += 64) {
+                    const uint32_t s = sb + lane;
+                    if (s < 288) T.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                }
                 if (lane < 32) T.lens[288 + lane] = 5;
                 __syncthreads();
                 build_code(T.lens, 288, LIT_ROOT, T.lit, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off, &T.lit_maxlen, 1);
@@ -489,26 +504,24 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
             // ---- the block's symbols
             for (;;) {
                 n_sym++;
-                b.pin();
-                o.n = uni(o.n); o.flushed = uni(o.flushed);
                 b.refill();
                 const uint32_t e0 = __builtin_amdgcn_readlane(t0, b.peek(6));
                 if (e0) {
                     const uint32_t c = (e0 >> 4) & 3;
                     if (o.n + c > o.cap) { status = ST_OVERFLOW; break; }
-                    if (lane < c) o.ring[(o.n + lane) & RING_MASK] = (uint16_t)((e0 >> (8 + 8 * lane)) & 0xFF);
+                    o.ring[lane < c ? (o.n + lane) & RING_MASK : RING + lane] = (uint16_t)((e0 >> (8 + 8 * (lane & 3))) & 0xFF);
                     o.advance(c);
                     b.drop(e0 & 15);
                     continue;
                 }
                 uint32_t e = uni(T.lit[b.peek(LIT_ROOT)]);
-                if (e == T_LONG) e = decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off);
+                if (e == T_LONG) e = uni(decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off));
                 if (e == 0) { status = ST_ERR_CODE; break; }
                 b.drop(e & 15);
                 const uint32_t sym = e >> 4;
                 if (sym < 256) {
                     if (o.n + 1 > o.cap) { status = ST_OVERFLOW; break; }
-                    if (lane == 0) o.ring[o.n & RING_MASK] = (uint16_t)sym;
+                    o.ring[lane == 0 ? o.n & RING_MASK : RING + lane] = (uint16_t)sym;
                     o.advance(1);
                     continue;
                 }
@@ -521,7 +534,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 else { const uint32_t eb = (s - 4) >> 2; len = 3 + ((4 + (s & 3)) << eb) + b.take(eb); }
                 b.refill();
                 uint32_t de = uni(T.dist[b.peek(DIST_ROOT)]);
-                if (de == T_LONG) de = decode_long((uint32_t)b.acc, DIST_ROOT, dist_max, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off);
+                if (de == T_LONG) de = uni(decode_long((uint32_t)b.acc, DIST_ROOT, dist_max, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off));
                 if (de == 0) { status = ST_ERR_CODE; break; }
                 b.drop(de & 15);
                 const uint32_t ds = de >> 4;
@@ -540,15 +553,11 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 const bool near = dist + len <= RING;
                 n_far += near ? 0u : 1u;
                 for (uint32_t base = 0; base < len; base += 64) {
-                    const uint32_t i = base + lane;
-                    if (i < len) {
-                        const int src = src0 + (int)(dist >= len ? i : dist == 1 ? 0u : i % dist);
-                        uint16_t v;
-                        if (src < 0) v = (uint16_t)(256 + WINDOW + src);
-                        else if (near) v = o.ring[src & RING_MASK];
-                        else v = o.out[src];
-                        o.ring[(o.n + i) & RING_MASK] = v;
-                    }
+                    const uint32_t i = min(base + lane, len - 1);
+                    const int src = src0 + (int)(dist >= len ? i : dist == 1 ? 0u : i % dist);
+                    const uint32_t at = (uint32_t)max(src, 0);
+                    const uint16_t got = near ? o.ring[at & RING_MASK] : o.out[at];
+                    o.ring[base + lane < len ? (o.n + i) & RING_MASK : RING + lane] = src < 0 ? (uint16_t)(256 + WINDOW + src) : got;
                 }
                 o.advance(len);
             }

@@ -123,18 +123,48 @@ bool fast_exit() { static const bool f = getenv("SYLPH_HIP_CLEAN_EXIT") == nullp
 // Work that nobody waits for (unmapping a sample's files, handing inflated copies back) runs on threads of its own; a command that
 // leaves through exit() joins them first (they use function-local statics that exit() destroys), one that leaves through _exit does not.
 namespace {
-std::mutex g_bg_mu;
-std::vector<std::thread> g_bg;
-void background(std::function<void()> f) {
-    std::lock_guard<std::mutex> lk(g_bg_mu);
-    g_bg.emplace_back(std::move(f));
-}
+// ONE long-lived reaper thread and a queue (round 6): a thread per task, joined only at the end of the command, left a
+// finished-but-unjoined thread (its stack mapping) behind every gzip sample — tens of thousands of samples in one command run into
+// vm.max_map_count or the thread limit, and std::thread's constructor then throws inside a destructor.  A task that cannot be queued
+// (no memory for the node, no thread) runs inline.
+struct Reaper {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::vector<std::function<void()>> queue;
+    bool running = false, started = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return !queue.empty(); });
+            std::vector<std::function<void()>> todo;
+            todo.swap(queue);
+            running = true;
+            lk.unlock();
+            for (auto& f : todo) { try { f(); } catch (...) {} }
+            todo.clear();
+            lk.lock();
+            running = false;
+            if (queue.empty()) cv_idle.notify_all();
+        }
+    }
+    void add(std::function<void()> f) {
+        try {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!started) { std::thread([this] { loop(); }).detach(); started = true; }   // (it ends with the process)
+            queue.push_back(std::move(f));
+            lk.unlock();
+            cv_work.notify_one();
+        } catch (...) { try { f(); } catch (...) {} }
+    }
+    void drain() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_idle.wait(lk, [&] { return queue.empty() && !running; });
+    }
+};
+Reaper& reaper() { static Reaper* r = new Reaper(); return *r; }
+void background(std::function<void()> f) { reaper().add(std::move(f)); }
 }  // namespace
-void join_background() {
-    std::vector<std::thread> v;
-    { std::lock_guard<std::mutex> lk(g_bg_mu); v.swap(g_bg); }
-    for (auto& t : v) if (t.joinable()) t.join();
-}
+void join_background() { reaper().drain(); }
 void trace_mark(const char* what) {
     static const bool trace = getenv("SYLPH_HIP_FEED_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[sylph_hip t+%.1f ms] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count() * 1e3, what);

@@ -141,12 +141,16 @@ int run_inspect(Argv a) {   // cmdline.rs:166-173; no GPU involved
 // child still has to do then is give its address space back: GBs of file mappings, inflated copies and index arrays, which the kernel
 // frees page by page (0.15-0.2 s after a four-sample or a .gz command, measured in round 5: profiles/r05_cli_first_sample_trace.txt) —
 // it does that as an orphan, with its standard streams closed (so that a caller reading our pipes sees end-of-file when WE exit).
-// `sylph-hip sketch` only (see run_in_child); SYLPH_HIP_NO_FORK=1 / SYLPH_HIP_CLEAN_EXIT=1 keep everything in one process.
+// `sylph-hip sketch` only (see run_in_child), and OPT-IN since round 6 (SYLPH_HIP_FORK=1): the process the user started must be the
+// one that does the work — a signal sent to it has to stop the work, `time` / getrusage / a scheduler's accounting have to see its
+// CPU and memory, and the next command must not find the previous one's HBM and RAM still being torn down by an orphan.
+// By default everything runs in one process, whose wall clock includes its own teardown, as the reference's does.
 static int g_report_fd = -1;
 static int run_in_child(int argc, char** argv) {
     // `sketch` only: what a `profile` / `query` leaves behind is a 29 GB index in HBM and a 14 GB mapping — with those still being torn
     // down by an orphan, the NEXT command's database load took 3-5 s instead of 1.3 (profiles/r05_db_load.txt, first version of this)
-    if (!fast_exit() || getenv("SYLPH_HIP_NO_FORK") || argc < 2 || strcmp(argv[1], "sketch") != 0) return -1;
+    const char* want = getenv("SYLPH_HIP_FORK");
+    if (!want || atoi(want) == 0 || !fast_exit() || getenv("SYLPH_HIP_NO_FORK") || argc < 2 || strcmp(argv[1], "sketch") != 0) return -1;
     int fds[2];
     if (pipe(fds) != 0) return -1;
     fflush(stdout);
