@@ -177,6 +177,30 @@ def sketch_reads(bases, off, c=200, k=31, mode=MODE_AVX2_COMPAT, paired=False, n
         lib().orc_sketch_free(h)
 
 
+def sketch_files(first, second=None, c=200, k=31, mode=None, fpr=0.0, threads=1):
+    """The reference's `sylph sketch` from FILES as the CPU runs it (sketch.rs:313 / :371: one worker per sample; needletail + flate2 on
+    that thread): every sample's file(s) read through zlib, cut into records and sketched on ONE thread, `threads` samples at a time.
+    -> dict(seconds=[per sample], table_sizes=[...], n_bases=[...], wall_seconds)."""
+    import ctypes as C
+    import time
+    n = len(first)
+    a1 = (C.c_char_p * n)(*[str(f).encode() for f in first])
+    a2 = (C.c_char_p * n)(*[str(f).encode() for f in second]) if second is not None else None
+    sec = (C.c_double * n)()
+    tab = (C.c_uint64 * n)()
+    nb = (C.c_uint64 * n)()
+    L = lib()
+    L.orc_sketch_files.restype = C.c_int
+    L.orc_sketch_files.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_int,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    t = time.perf_counter()
+    rc = L.orc_sketch_files(a1, a2, n, c, k, MODE_AVX2_FAST if mode is None else mode, float(fpr), int(threads), sec, tab, nb)
+    wall = time.perf_counter() - t
+    if rc:
+        raise ValueError(f"oracle could not read sample {rc - 1}")
+    return dict(seconds=list(sec), table_sizes=list(tab), n_bases=list(nb), wall_seconds=wall)
+
+
 def sketch_reads_cuckoo_model(bases, off, c=200, k=31, mode=MODE_AVX2_COMPAT, fpr=1e-4, initial_capacity=10_000_000):
     """sketch_pair_sequences with the DEFAULT dedup (sketch.rs:733-769 over a scalable cuckoo filter; --fpr 1e-4, capacity 10^7
     at :796-804), the filter restated from the paper — a model of the third-party crate, not its bits (see sylph_oracle.cpp)."""

@@ -17,12 +17,15 @@
 // Build: see oracle/Makefile  (g++ -O3 -mavx2 -fopenmp -shared -fPIC).
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -32,6 +35,7 @@
 #endif
 #if defined(_OPENMP)
 #include <omp.h>
+#include <zlib.h>
 #endif
 
 namespace {
@@ -686,6 +690,91 @@ void* orc_sketch_reads_cuckoo(const uint8_t* bases, const uint64_t* off, uint64_
     sk->finalize();
     return sk;
 }
+// ---- the reference's `sylph sketch` FROM FILES, as the CPU runs it (bench.py's cpu_baseline_from_files; round 6) --------------------
+// sketch.rs:313 / :371 hand every sample to ONE rayon worker, which reads its file(s) record by record through needletail — flate2
+// inflating gzip input on the same thread — and sketches as it goes.  Here: one thread per sample reads the file(s) through zlib's
+// gzread (plain text passes through it unchanged), cuts the four-line records, and sketches the sample with the fast seeding variant
+// and the paired dedup the flags select (fpr = 0: exact set; else the filter model).  seconds[s]: wall clock of sample s alone, from
+// opening its files to its finished table.  Returns 0, or the 1-based index of the first sample that could not be read.
+static bool read_fastq_records(const char* path, std::vector<uint8_t>& bases, std::vector<uint64_t>& lens) {
+    gzFile f = gzopen(path, "rb");
+    if (!f) return false;
+    gzbuffer(f, 1u << 20);
+    std::vector<uint8_t> buf(8u << 20);
+    std::vector<uint8_t> carry;
+    int line = 0;
+    uint64_t cur = 0;
+    for (;;) {
+        const int got = gzread(f, buf.data(), (unsigned)buf.size());
+        if (got < 0) { gzclose(f); return false; }
+        if (got == 0) break;
+        const uint8_t* p = buf.data();
+        const uint8_t* end = p + got;
+        while (p < end) {
+            const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+            const uint8_t* stop = nl ? nl : end;
+            if ((line & 3) == 1) { bases.insert(bases.end(), p, stop); cur += (uint64_t)(stop - p); }
+            if (!nl) break;
+            if ((line & 3) == 1) {
+                if (cur && bases.back() == '\r') { bases.pop_back(); cur--; }
+                lens.push_back(cur);
+                cur = 0;
+            }
+            line++;
+            p = nl + 1;
+        }
+    }
+    gzclose(f);
+    return true;
+}
+int orc_sketch_files(const char* const* f1, const char* const* f2, uint64_t n_samples, uint64_t c, uint64_t k, int mode, double fpr, int threads,
+                     double* seconds, uint64_t* table_sizes, uint64_t* n_bases_out) {
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&] {
+        for (uint64_t s = next++; s < n_samples; s = next++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<uint8_t> b1, b2;
+            std::vector<uint64_t> l1, l2;
+            if (!read_fastq_records(f1[s], b1, l1) || (f2 && !read_fastq_records(f2[s], b2, l2))) { int z = 0; failed.compare_exchange_strong(z, (int)s + 1); continue; }
+            ReadSketch sk;
+            uint64_t nb = b1.size() + b2.size();
+            if (f2) {
+                // interleave the mates' records the way orc_sketch_reads takes pairs (the reference's lock-step readers, sketch.rs:813-815)
+                const uint64_t n = std::min(l1.size(), l2.size());
+                std::vector<uint8_t> bases;
+                bases.reserve(nb + 64);
+                std::vector<uint64_t> off(2 * n + 1, 0);
+                uint64_t a = 0, b = 0;
+                for (uint64_t i = 0; i < n; i++) {
+                    bases.insert(bases.end(), b1.begin() + a, b1.begin() + a + l1[i]); a += l1[i];
+                    off[2 * i + 1] = bases.size();
+                    bases.insert(bases.end(), b2.begin() + b, b2.begin() + b + l2[i]); b += l2[i];
+                    off[2 * i + 2] = bases.size();
+                }
+                bases.resize(bases.size() + 64, 'A');
+                if (fpr == 0.) sketch_paired(sk, bases.data(), off.data(), n, c, k, mode, false);
+                else sketch_paired_cuckoo(sk, bases.data(), off.data(), n, c, k, mode, fpr, 10000000);
+            } else {
+                std::vector<uint64_t> off(l1.size() + 1, 0);
+                for (size_t i = 0; i < l1.size(); i++) off[i + 1] = off[i] + l1[i];
+                b1.resize(b1.size() + 64, 'A');
+                sketch_single(sk, b1.data(), off.data(), l1.size(), c, k, mode, false);
+            }
+            sk.finalize();
+            seconds[s] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (table_sizes) table_sizes[s] = sk.sorted_keys.size();
+            if (n_bases_out) n_bases_out[s] = nb;
+        }
+    };
+    std::vector<std::thread> pool;
+    const int T = std::max(1, std::min<int>(threads, (int)n_samples));
+    for (int t = 1; t < T; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    return failed.load();
+}
+
 // The filter alone, walked as sketch.rs:747-760 walks it — test, insert when absent — over a stream of (k-mer, markers) items:
 // contained[i] = what `contains` answered for item i; returns the number of filters at the end.  (The checker of the
 // data-parallel formulation in sylph_amd/csrc/a10.hip: tests/test_oracle.py restates that formulation in numpy against this walk.)

@@ -215,6 +215,7 @@ struct WaveTables {
     uint8_t plens[20 + 64];
     uint32_t lit_maxlen, dist_maxlen;
     alignas(16) uint16_t ring[RING + 64];   // (+64: where the lanes that have nothing to write write — see DUMMY below)
+    uint32_t stream[256];
 };
 
 // Everything the decoding wavefront keeps — bit buffer, positions, counts, the symbol just decoded — is the same in all 64 lanes, and it
@@ -228,32 +229,47 @@ struct WaveBits {                                  // the same reader, but every
     uint64_t acc, wpos, wlimit, cbase;
     uint32_t cnt;
     bool over;
-    // The stream itself sits in two VGPRs: lane i of `cur` holds word cbase + i, `nxt` the 64 words behind — one coalesced load per
-    // 256 compressed bytes, issued 256 bytes ahead of its use — and a refill is a v_readlane.  (A scalar load per refill put a trip to
-    // memory, ~1-2 thousand cycles with nothing else to do, into the chain of every ten literals.)
-    uint32_t cur, nxt;
+    // The stream's words [cbase - 64, cbase + 128) lie in an LDS buffer of 256 words (word i at [i & 255]); the 64 words behind them wait
+    // in a VGPR, loaded one chunk — 256 compressed bytes, one coalesced load — ahead of their use.  Both readers take their words there:
+    // this one a word per refill (a scalar load per refill put a trip to memory, ~1-2 thousand cycles with nothing else to do, into the
+    // chain of every ten literals), the window step three words per lane.
+    uint32_t nxt;
+    uint32_t* stream;
     __device__ __forceinline__ void init(const uint32_t* words, uint64_t bitpos, uint64_t limit_words) {
+        const uint32_t lane = threadIdx.x & 63;
         w = words;
         wlimit = limit_words;
         over = false;
         wpos = bitpos >> 5;
         cbase = wpos & ~(uint64_t)63;
-        cur = w[cbase + (threadIdx.x & 63)];
-        nxt = w[cbase + 64 + (threadIdx.x & 63)];
+        stream[(cbase + lane) & 255] = w[cbase + lane];
+        stream[(cbase + 64 + lane) & 255] = w[cbase + 64 + lane];
+        nxt = w[cbase + 128 + lane];
         const uint32_t s = (uint32_t)bitpos & 31;
         acc = (uint64_t)(word() >> s);
         cnt = 32 - s;
         refill();
     }
+    __device__ __forceinline__ void next_chunk() {
+        const uint32_t lane = threadIdx.x & 63;
+        stream[(cbase + 128 + lane) & 255] = nxt;
+        cbase += 64;
+        nxt = w[cbase + 128 + lane];
+    }
     __device__ __forceinline__ uint32_t word() {                          // the stream's word wpos; wpos moves on
-        const uint32_t v = __builtin_amdgcn_readlane(cur, (uint32_t)(wpos - cbase));
+        const uint32_t v = uni(stream[wpos & 255]);
         wpos++;
-        if (wpos - cbase == 64) {
-            cur = nxt;
-            cbase += 64;
-            nxt = w[cbase + 64 + (threadIdx.x & 63)];
-        }
+        if ((long long)(wpos - cbase) >= 64) next_chunk();
         return v;
+    }
+    // continue at another bit position: at most two words behind the words already taken, less than a chunk ahead of them
+    __device__ __forceinline__ void seek(uint64_t bitpos) {
+        wpos = bitpos >> 5;
+        if ((long long)(wpos - cbase) >= 64) next_chunk();
+        const uint32_t s = (uint32_t)bitpos & 31;
+        acc = (uint64_t)(word() >> s);
+        cnt = 32 - s;
+        refill();
     }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32) {
@@ -396,6 +412,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
     o.cap = (uint32_t)min((uint64_t)0xFFFFFF00u, (next_byte - (start >> 3)) * REGION_RATIO + REGION_SLACK);
     const bool have_window = k != 0;
     WaveBits b;
+    b.stream = T.stream;
     b.init(gzw, start, n_words);
     uint32_t status = ST_NONE, flags = 0;
     uint64_t end_bit = 0;
@@ -485,35 +502,97 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 build_code(T.lens + 288, 32, DIST_ROOT, T.dist, T.dist_sorted, T.dist_first, T.dist_count, T.dist_off, &T.dist_maxlen, 2);
             }
             const uint32_t lit_max = uni(T.lit_maxlen), dist_max = uni(T.dist_maxlen);
-            // One VGPR as a 64-entry table over the next SIX bits: lane i holds what the bits i decode to when that is one, two or three
-            // literals — bits used | count << 4 | the bytes — and 0 when the first code is longer, or no literal.  A look-up is a
-            // v_readlane: no trip to the LDS for the symbols a FASTQ file is mostly made of (bases at 2-3 bits, binned qualities).
-            uint32_t t0 = 0;
-            {
-                uint32_t idx = lane, left = 6, used = 0, cnt = 0, syms = 0;
-                for (int j = 0; j < 3; j++) {
-                    const uint32_t e = T.lit[idx];
-                    const uint32_t l = e & 15, sy = e >> 4;
-                    if (e == T_LONG || l == 0 || l > left || sy >= 256) break;
-                    syms |= sy << (8 * j);
-                    cnt++; used += l; left -= l; idx >>= l;
-                }
-                if (cnt) t0 = used | cnt << 4 | syms << 8;
-            }
             t_build += __builtin_readcyclecounter() - t_b0;
             // ---- the block's symbols
-            for (;;) {
+            // THE WINDOW STEP.  A wavefront that decodes one symbol at a time spends 300 cycles on a literal and 1,500 on a match, whatever
+            // the instruction count: every turn is a chain of dependent scalar instructions, taken branches and trips to the LDS, each
+            // waited for with nothing else to do (profiles/r06_inflate_steps.txt).  So the 64 lanes decode the 64 BIT POSITIONS behind the
+            // stream's position at once — lane j: "if a symbol started j bits from here, which one, how long, how many bits" (its own three
+            // words of the stream, one look-up in each table) — and the wave then walks the chain of true starts with v_readlane (bits used
+            // by the symbol at 0 lead to the next start, ...), four scalar instructions per symbol.  The cells the walked symbols produce
+            // (at most 64 per step) are dealt to the lanes, literals written, copies resolved in rounds — a round gives every cell whose
+            // source lies in front of the first unresolved one its value: one round unless a copy reads what this step wrote.  What the
+            // step cannot take — a code longer than the table's root, a copy of more than 64 cells, the last bits of the stream — is left
+            // to the one-symbol path behind it, which also reports the errors.
+            bool eob = false;
+            const uint64_t limit_bits = n_words * 32;
+            while (!eob && status == ST_NONE) {
                 n_sym++;
-                b.refill();
-                const uint32_t e0 = __builtin_amdgcn_readlane(t0, b.peek(6));
-                if (e0) {
-                    const uint32_t c = (e0 >> 4) & 3;
-                    if (o.n + c > o.cap) { status = ST_OVERFLOW; break; }
-                    o.ring[lane < c ? (o.n + lane) & RING_MASK : RING + lane] = (uint16_t)((e0 >> (8 + 8 * (lane & 3))) & 0xFF);
-                    o.advance(c);
-                    b.drop(e0 & 15);
-                    continue;
+                uint32_t taken = 0;
+                const uint64_t p = b.bitpos();
+                if (p + 192 <= limit_bits) {
+                    // lane j: 64 bits of the stream from bit p + j
+                    const uint64_t pj = p + lane;
+                    const uint32_t wj = (uint32_t)(pj >> 5), sj = (uint32_t)pj & 31;
+                    const uint32_t d0 = T.stream[wj & 255], d1 = T.stream[(wj + 1) & 255], d2 = T.stream[(wj + 2) & 255];
+                    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sj), x1 = __builtin_amdgcn_alignbit(d2, d1, sj);
+                    const uint32_t e1 = T.lit[x0 & ((1u << LIT_ROOT) - 1)];
+                    const uint32_t l1 = e1 & 15, sy = e1 >> 4;
+                    const bool is_lit = sy < 256, is_eob = sy == 256, is_len = sy > 256;
+                    // (a length code's extra bits and distance: computed by every lane, kept by the lanes that saw one — no branch on the lane)
+                    const uint32_t ls = is_len ? sy - 257 : 0;
+                    const uint32_t leb = ls < 8 || ls >= 28 ? 0u : (ls - 4) >> 2;
+                    const uint32_t lbase = ls < 8 ? 3 + ls : ls >= 28 ? 258u : 3 + ((4 + (ls & 3)) << leb);
+                    const uint64_t x = ((uint64_t)x1 << 32 | x0) >> l1;
+                    const uint32_t len = lbase + ((uint32_t)x & ((1u << leb) - 1));
+                    const uint32_t y = (uint32_t)(x >> leb);
+                    const uint32_t e2 = T.dist[y & ((1u << DIST_ROOT) - 1)];
+                    const uint32_t l2 = e2 & 15, dsy = e2 >> 4;
+                    const uint32_t deb = dsy < 4 ? 0u : min((dsy - 2) >> 1, 13u);
+                    const uint32_t dbase = dsy < 4 ? 1 + dsy : 1 + ((2 + (dsy & 1)) << deb);
+                    const bool bad = e1 == T_LONG || e1 == 0 || sy > 285 || (is_len && (e2 == T_LONG || e2 == 0 || dsy >= 30 || len > 64));
+                    const uint32_t bits = is_len ? l1 + leb + l2 + deb : l1;
+                    const uint32_t cells = is_len ? len : is_lit ? 1u : 0u;
+                    // what a cell needs of its symbol, in one word: first cell (7 bits, filled in by the walk) | cells << 7 | literal << 14 |
+                    // (the literal's byte, or the distance) << 15
+                    const uint32_t about = cells << 7 | (is_lit ? 1u << 14 : 0u) | (is_lit ? sy : dbase + ((y >> l2) & ((1u << deb) - 1))) << 15;
+                    // the chain of symbol starts, from lane 0; owner of cell c = the last walked symbol whose first cell is <= c
+                    uint32_t pos = 0, total = 0, owner = 0, first_cell = 0;
+                    while (pos < 64) {
+                        if (__builtin_amdgcn_readlane(bad ? 1u : 0u, pos)) break;
+                        const uint32_t c = __builtin_amdgcn_readlane(cells, pos);
+                        if (total + c > 64) break;
+                        owner = lane >= total ? pos : owner;
+                        first_cell = lane == pos ? total : first_cell;
+                        total += c;
+                        taken++;
+                        const bool last = __builtin_amdgcn_readlane(is_eob ? 1u : 0u, pos) != 0;
+                        pos += __builtin_amdgcn_readlane(bits, pos);
+                        if (last) { eob = true; break; }
+                    }
+                    if (taken) {
+                        if (o.n + total > o.cap) { status = ST_OVERFLOW; break; }
+                        const uint32_t mine_about = __shfl(about | first_cell, owner);
+                        const uint32_t my_first = mine_about & 127, my_len = (mine_about >> 7) & 127, my_val = mine_about >> 15;
+                        const bool mine = lane < total, my_lit = (mine_about >> 14 & 1) != 0;
+                        const uint32_t i = lane - my_first;                  // my cell's index in its symbol; my_val: its distance
+                        const int src = (int)(o.n + my_first) - (int)my_val + (int)(my_val >= my_len ? i : my_val == 1 ? 0u : i % max(my_val, 1u));
+                        const bool is_copy = mine && !my_lit;
+                        if (__ballot(is_copy && src < 0)) {
+                            if (!have_window || __ballot(is_copy && src < -(int)WINDOW)) { status = ST_ERR_DISTANCE; break; }
+                            flags |= 1;
+                        }
+                        const bool far = is_copy && src >= 0 && (int)(o.n + lane) - src > (int)(RING - 128);
+                        n_far += __ballot(far) ? 1u : 0u;
+                        // literals now; copies in rounds
+                        o.ring[mine && my_lit ? (o.n + lane) & RING_MASK : RING + lane] = (uint16_t)my_val;
+                        uint64_t pending = __ballot(is_copy);
+                        while (pending) {
+                            const uint32_t frontier = o.n + (uint32_t)__builtin_ctzll(pending);   // every cell in front of it has its value
+                            const bool can = is_copy && (pending >> lane & 1) && src < (int)frontier;
+                            const uint32_t at = (uint32_t)max(src, 0);
+                            uint16_t v = o.ring[at & RING_MASK];
+                            if (__ballot(can && far)) { const uint16_t g = o.out[far ? at : 0u]; v = far ? g : v; }
+                            o.ring[can ? (o.n + lane) & RING_MASK : RING + lane] = src < 0 ? (uint16_t)(256 + WINDOW + src) : v;
+                            pending &= ~__ballot(can);
+                        }
+                        o.advance(total);
+                        b.seek(p + pos);
+                    }
                 }
+                if (taken || eob || status != ST_NONE) continue;
+                // ---- one symbol, the slow way
+                b.refill();
                 uint32_t e = uni(T.lit[b.peek(LIT_ROOT)]);
                 if (e == T_LONG) e = uni(decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off));
                 if (e == 0) { status = ST_ERR_CODE; break; }
@@ -525,7 +604,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     o.advance(1);
                     continue;
                 }
-                if (sym == 256) break;
+                if (sym == 256) { eob = true; continue; }
                 const uint32_t s = sym - 257;
                 if (s >= 29) { status = ST_ERR_CODE; break; }
                 uint32_t len;

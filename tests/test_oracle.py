@@ -8,7 +8,7 @@ import pytest
 
 from oracle import oracle as O
 
-from .helpers import hist, xor_sum
+from .helpers import concat, hist, random_seq, xor_sum
 
 
 @pytest.fixture(scope="module")
@@ -338,3 +338,35 @@ def test_a10_filter_walk_equals_first_of_reduced_key_class(fpr, cap0, n):
     assert (walked | ~exact).all()                                    # no false negatives
     if fpr >= 0.05:
         assert (walked & ~exact).sum() > 10                           # and the false positives this test is about do occur
+
+
+def test_sketch_files_equals_sketch_of_the_parsed_records(tmp_path):
+    """orc_sketch_files (bench.py's cpu_baseline_from_files: zlib reader + record cutting + sketch, one thread per sample) gives the table
+    sketch_reads gives for the same records — plain and gzip, single and paired, exact set and filter model."""
+    import gzip
+    rng = np.random.default_rng(5)
+    g = random_seq(rng, 60000)
+    recs = [g[s:s + int(rng.integers(40, 160))] for s in rng.integers(0, 59000, size=1500)]
+    recs += recs[:50]
+    def fq(rs, crlf=False):
+        nl = b"\r\n" if crlf else b"\n"
+        return b"".join(b"@r%d" % i + nl + r.tobytes() + nl + b"+" + nl + b"I" * len(r) + nl for i, r in enumerate(rs))
+    m1, m2 = recs[0::2], recs[1::2]
+    (tmp_path / "a_1.fq").write_bytes(fq(m1))
+    (tmp_path / "a_2.fq").write_bytes(fq(m2, crlf=True))
+    (tmp_path / "b_1.fq.gz").write_bytes(gzip.compress(fq(m1), 6))
+    (tmp_path / "b_2.fq.gz").write_bytes(gzip.compress(fq(m2), 1))
+    inter = [r for pair in zip(m1, m2) for r in pair]
+    bases, off = concat(inter)
+    want = O.sketch_reads(bases, off, c=20, paired=True)
+    r = O.sketch_files([tmp_path / "a_1.fq", tmp_path / "b_1.fq.gz"], [tmp_path / "a_2.fq", tmp_path / "b_2.fq.gz"], c=20, fpr=0.0, threads=2)
+    assert r["table_sizes"] == [len(want["kmers"])] * 2 and r["n_bases"] == [int(off[-1])] * 2 and min(r["seconds"]) > 0
+    want_f = O.sketch_reads_cuckoo_model(bases, off, c=20)
+    r = O.sketch_files([tmp_path / "b_1.fq.gz"], [tmp_path / "b_2.fq.gz"], c=20, fpr=1e-4)
+    assert r["table_sizes"] == [len(want_f["kmers"])]
+    b1, o1 = concat(m1)
+    want_s = O.sketch_reads(b1, o1, c=20)
+    r = O.sketch_files([tmp_path / "b_1.fq.gz", tmp_path / "a_1.fq"], None, c=20, threads=1)
+    assert r["table_sizes"] == [len(want_s["kmers"])] * 2
+    with pytest.raises(ValueError):
+        O.sketch_files([tmp_path / "missing.fq"], None)
