@@ -312,9 +312,50 @@ def end_to_end_from_files(bases, n_pairs_total, read_len, n_pairs):
         dt, per = run(["-1", f"{d}/s_1.fq.gz", "-2", f"{d}/s_2.fq.gz"])
         out["gz_one_sample"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(gbp / dt, 3),
                                 "sample_gbp_per_s": round(gbp / per[0], 2) if per else None,
-                                "what": "one ordinary (single-member) gzip -1 file per mate: inflated on the host's threads by host/pgunzip.cpp"}
+                                "what": "one ordinary (single-member) gzip -1 file per mate: the COMPRESSED bytes go to the device, which inflates them "
+                                        "(csrc/inflate.hip; round 6)"}
         dt, per = run(["-1", f"{d}/s_1.fq.gz", "-2", f"{d}/s_2.fq.gz"])
         out["gz_one_sample"]["second_run_command_gbp_per_s"] = round(gbp / dt, 3)
+        env["SYLPH_HIP_INFLATE_DEVICE"] = "0"
+        dt, per = run(["-1", f"{d}/s_1.fq.gz", "-2", f"{d}/s_2.fq.gz"])
+        env.pop("SYLPH_HIP_INFLATE_DEVICE")
+        out["gz_one_sample"]["inflated_on_the_host"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(gbp / dt, 3),
+                                                        "what": "the same command with SYLPH_HIP_INFLATE_DEVICE=0: host/pgunzip.cpp on the host's threads (round 5's road)"}
+        for i in range(4):
+            for m in (1, 2):
+                os.symlink(f"{d}/s_{m}.fq.gz", f"{d}/g{i}_{m}.fq.gz")
+        dt, per = run(["-1", *[f"{d}/g{i}_1.fq.gz" for i in range(4)], "-2", *[f"{d}/g{i}_2.fq.gz" for i in range(4)], "-t", "1"])
+        out["gz_four_samples_one_command"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(4 * gbp / dt, 3),
+                                              "sample_gbp_per_s_in_order": [round(gbp / x, 2) for x in per]}
+        # The same files through the CPU path as the reference runs it (sketch.rs:313, :371: one rayon worker per sample; needletail +
+        # flate2 on that thread): oracle/'s fast seeding + its model of the default pair dedup behind a zlib reader, ONE thread per
+        # sample, as many samples side by side as the box may use CPUs.  kind = "port": the oracle, timed, never the product.
+        try:
+            from oracle import oracle as O
+            cpus = effective_cpus()
+            cpu = {"kind": "port", "cores_usable": cpus, "threads_per_sample": 1,
+                   "what": "oracle/ (C++ restatement of the reference's CPU path: AVX2 seeding, filter-model dedup, zlib reader) on the SAME files, one thread per "
+                           "sample, min(samples, usable CPUs) samples at a time — the reference's own parallelism (sketch.rs:313, :371)"}
+            for kind, ext in (("plain", "fq"), ("gz", "fq.gz")):
+                for n in (1, 4, 16):
+                    try:
+                        avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+                    except Exception:
+                        avail = 0
+                    # (a sample is ~2.3 B per base in host memory while its two mates are interleaved: never risk the box for a baseline)
+                    if n > 1 and (n > 2 * cpus or min(n, cpus) * gbp * 2.6e9 > avail / 2):
+                        cpu[f"{kind}_{n}_samples"] = {"skipped": "not enough CPUs or host memory for that many samples side by side"}
+                        continue
+                    f1 = [f"{d}/s_1.{ext}"] * n
+                    f2 = [f"{d}/s_2.{ext}"] * n
+                    r = O.sketch_files(f1, f2, c=200, k=31, fpr=1e-4, threads=min(n, cpus))
+                    cpu[f"{kind}_{n}_samples"] = {"wall_seconds": round(r["wall_seconds"], 3), "gbp_per_s": round(n * gbp / r["wall_seconds"], 3),
+                                                  "threads": min(n, cpus), "seconds_per_sample_mean": round(float(np.mean(r["seconds"])), 3)}
+                    if n == 16 and r["wall_seconds"] > 40:
+                        break
+            out["cpu_baseline_from_files"] = cpu
+        except Exception as e:
+            out["cpu_baseline_from_files"] = {"error": str(e)[:300]}
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -1131,6 +1172,31 @@ def main():
             out["end_to_end_from_files"] = end_to_end_from_files(read_sets[0]["bases"], n_pairs, read_len, args.files_leg_pairs)
         except Exception as e:
             out["end_to_end_from_files"] = {"error": str(e)[:400]}
+    if rank == 0:
+        # every rate a reader needs to compare, side by side at the top level: GPU with the inputs resident (= `value`, and
+        # with the reference's default flags), fed over PCIe, from files through the product's own command; the CPU path on the same inputs
+        e2e = out.get("end_to_end_from_files", {}) if isinstance(out.get("end_to_end_from_files"), dict) else {}
+        cbf = e2e.get("cpu_baseline_from_files", {}) if isinstance(e2e.get("cpu_baseline_from_files"), dict) else {}
+        h2d = out.get("value_h2d_inclusive", {}) if isinstance(out.get("value_h2d_inclusive"), dict) else {}
+
+        def g(dct, *ks):
+            for k_ in ks:
+                dct = dct.get(k_) if isinstance(dct, dict) else None
+            return dct
+        out["rates_gbp_per_s"] = {
+            "gpu_inputs_resident_exact_dedup": out.get("value"), "gpu_inputs_resident_default_flags": out.get("value_default_flags"),
+            "gpu_fed_over_pcie_ascii": g(h2d, "ascii", "gbp_per_s"), "gpu_fed_over_pcie_2bit": g(h2d, "2bit", "gbp_per_s"),
+            "gpu_from_files_plain_1_sample_command": g(e2e, "plain_one_sample", "command_gbp_per_s"),
+            "gpu_from_files_plain_4_samples_command": g(e2e, "plain_four_samples_one_command", "command_gbp_per_s"),
+            "gpu_from_files_gz_1_sample_command": g(e2e, "gz_one_sample", "command_gbp_per_s"),
+            "gpu_from_files_gz_4_samples_command": g(e2e, "gz_four_samples_one_command", "command_gbp_per_s"),
+            "cpu_resident_whole_job": g(out, "cpu_baseline", "value"), "cpu_resident_sketch_one_thread": g(out, "cpu_baseline", "sketch_gbp_per_s"),
+            "cpu_from_files_plain": {k_: g(cbf, k_, "gbp_per_s") for k_ in ("plain_1_samples", "plain_4_samples", "plain_16_samples")},
+            "cpu_from_files_gz": {k_: g(cbf, k_, "gbp_per_s") for k_ in ("gz_1_samples", "gz_4_samples", "gz_16_samples")},
+            "cpu_cores_usable": cbf.get("cores_usable"),
+            "note": "command = whole `sylph-hip sketch` process (start-up, GPU bring-up, feed, kernels, .sylsp written); cpu_from_files = the oracle "
+                    "(kind: port) on the same files, one thread per sample as the reference runs samples; sketch stage only on both sides",
+        }
     sys.stdout.flush()
     try:                      # C stdio of the libraries (RCCL's banner) is still buffered: flush it while fd 1 is stderr
         import ctypes

@@ -229,16 +229,17 @@ void sylph_fastq_destroy(sylph_fastq *f);
  * blocks, decodes them side by side and checks every member's CRC-32 and ISIZE.  The text stays in HBM: sylph_inflated_text lends
  * the device pointer (readable 256 bytes either side, valid until sylph_inflated_destroy) — hand it to sylph_fastq_index with
  * SYLPH_MEM_DEVICE — and sylph_inflated_read copies a range to the host (FASTA genomes, tests).  Returns SYLPH_ERR_FORMAT — and
- * nothing else happens — when the bytes are not gzip, are damaged, or are a stream this road does not take (e.g. a block that
- * deflates more than 16:1, 3 GiB or more of compressed bytes), SYLPH_ERR_NOMEM when the device has no room: the caller then
+ * nothing else happens — when the bytes are not gzip, are damaged, or are a stream this road does not take (3 GiB or more of
+ * compressed bytes, a member that begins with a large stored or fixed-Huffman block), SYLPH_ERR_NOMEM when the device has no room: the caller then
  * inflates with its own reader (flate2 / zlib), whose error semantics are the reference's.  The result is byte-identical to zlib's
  * or the call fails; it belongs to its context and must be destroyed before it.  sylph_inflated_info: members, deflate blocks of
- * the stream, header-like bit positions that were decoded to find them, members small enough to have gone through zlib. */
+ * the stream, header-like bit positions that were decoded to find them, members small enough to have gone through zlib, blocks that
+ * were decoded a second time because their first region of memory was too small. */
 typedef struct sylph_inflated sylph_inflated;
 int sylph_inflate(sylph_ctx *ctx, const void *gz, uint64_t n_bytes, int mem, sylph_inflated **out);
 int sylph_inflated_text(const sylph_inflated *t, const void **dev_text, uint64_t *n_bytes);
 int sylph_inflated_info(const sylph_inflated *t, uint64_t *n_members, uint64_t *n_blocks, uint64_t *n_candidates,
-                        uint64_t *n_host_members);
+                        uint64_t *n_host_members, uint64_t *n_decoded_again);
 int sylph_inflated_read(sylph_inflated *t, uint64_t first, uint64_t n, void *host_out);
 void sylph_inflated_destroy(sylph_inflated *t);
 

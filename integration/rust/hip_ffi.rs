@@ -129,7 +129,7 @@ extern "C" {
     pub fn sylph_inflate(ctx: *mut SylphCtx, gz: *const c_void, n_bytes: u64, mem: c_int, out: *mut *mut SylphInflated) -> c_int;
     pub fn sylph_inflated_text(t: *const SylphInflated, dev_text: *mut *const c_void, n_bytes: *mut u64) -> c_int;
     pub fn sylph_inflated_info(t: *const SylphInflated, n_members: *mut u64, n_blocks: *mut u64, n_candidates: *mut u64,
-                               n_host_members: *mut u64) -> c_int;
+                               n_host_members: *mut u64, n_decoded_again: *mut u64) -> c_int;
     pub fn sylph_inflated_read(t: *mut SylphInflated, first: u64, n: u64, host_out: *mut c_void) -> c_int;
     pub fn sylph_inflated_destroy(t: *mut SylphInflated);
     // k-mer-range shards: bounds for `world` GPUs, upload of this rank's range, communicator, the collective batch call

@@ -753,6 +753,8 @@ int orc_sketch_files(const char* const* f1, const char* const* f2, uint64_t n_sa
                     off[2 * i + 2] = bases.size();
                 }
                 bases.resize(bases.size() + 64, 'A');
+                std::vector<uint8_t>().swap(b1);
+                std::vector<uint8_t>().swap(b2);
                 if (fpr == 0.) sketch_paired(sk, bases.data(), off.data(), n, c, k, mode, false);
                 else sketch_paired_cuckoo(sk, bases.data(), off.data(), n, c, k, mode, fpr, 10000000);
             } else {

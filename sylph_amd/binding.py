@@ -81,7 +81,7 @@ def load():
     L.sylph_fastq_destroy.restype = None
     L.sylph_inflate.argtypes = [vp, vp, u64, i32, P(vp)]
     L.sylph_inflated_text.argtypes = [vp, P(vp), P(u64)]
-    L.sylph_inflated_info.argtypes = [vp, P(u64), P(u64), P(u64), P(u64)]
+    L.sylph_inflated_info.argtypes = [vp, P(u64), P(u64), P(u64), P(u64), P(u64)]
     L.sylph_inflated_read.argtypes = [vp, u64, u64, vp]
     L.sylph_inflated_destroy.argtypes = [vp]
     L.sylph_inflated_destroy.restype = None
@@ -287,9 +287,9 @@ class Inflated:
         p, n = C.c_void_p(), C.c_uint64(0)
         _check(load().sylph_inflated_text(self._h, C.byref(p), C.byref(n)))
         self.dev_ptr, self.n_bytes = int(p.value or 0), int(n.value)
-        a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        _check(load().sylph_inflated_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        self.n_members, self.n_blocks, self.n_candidates, self.n_host_members = int(a.value), int(b.value), int(c.value), int(d.value)
+        a, b, c, d, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(load().sylph_inflated_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        self.n_members, self.n_blocks, self.n_candidates, self.n_host_members, self.n_decoded_again = (int(x.value) for x in (a, b, c, d, e))
 
     def read(self, first=0, n=None):
         n = self.n_bytes - first if n is None else n

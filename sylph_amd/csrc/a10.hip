@@ -279,6 +279,7 @@ __global__ __launch_bounds__(A10_TPB) void a10_find_kernel(Occs o, Filters F, ui
     }
 }
 
+#ifdef SYLPH_A10_DEBUG   // (not in the product build: `make CXXFLAGS+=-DSYLPH_A10_DEBUG` for tools/a10_debug.py / a10_dump.py)
 // debug aid (SYLPH_HIP_A10_TRACE): [0] occurrences taking part, [1] operations of the phase, [2] inserting, [3] first_op < op, [4] first_op > op
 __global__ __launch_bounds__(A10_TPB) void a10_debug_kernel(Occs o, Filters F, unsigned long long* __restrict__ out) {
     const uint32_t i = blockIdx.x * A10_TPB + threadIdx.x;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(A10_TPB) void a10_debug_kernel(Occs o, Filters F, u
         atomicAdd(&out[fo == op ? 2 : (fo < op ? 3 : 4)], 1ull);
     }
 }
+#endif
 
 
 // ---- the partitioned pass (round 5): one filter, no device-wide atomics -------------------------------------------------------
@@ -567,6 +569,7 @@ static void a10_mark_walk(sylph_sketch* sk) {
         hipLaunchKernelGGL(a10_part_kernel, dim3((uint32_t)((n + A10_TPB - 1) / A10_TPB)), dim3(A10_TPB), 0, ctx->stream, o, b_part.as<uint8_t>());
         SY_HIP(hipGetLastError());
     }
+#ifdef SYLPH_A10_DEBUG
     if (const char* dump = getenv("SYLPH_HIP_A10_DUMP")) {      // debug aid: the occurrence records the filter pass works on
         std::vector<OccRec> h(n);
         ctx->d2h(h.data(), o.recs, n * sizeof(OccRec));
@@ -574,6 +577,7 @@ static void a10_mark_walk(sylph_sketch* sk) {
         ctx->d2h(hh.data(), o.hash, n * 8);
         if (FILE* f = fopen(dump, "wb")) { fwrite(hh.data(), 8, n, f); fwrite(h.data(), sizeof(OccRec), n, f); fclose(f); }
     }
+#endif
     const uint64_t n_ops = 2 * n;                 // an upper bound of the operations (occurrences that take part x 2)
     uint64_t ops_before = 0;                      // ... and of those before the current phase: every closed filter took its capacity
     std::vector<std::unique_ptr<DevBuf>> tables;
@@ -603,6 +607,7 @@ static void a10_mark_walk(sylph_sketch* sk) {
         ScopedKernelTimer t(ctx, "a10");
         SY_HIP(hipMemsetAsync(tables.back()->p, 0, slots * sizeof(Ent), ctx->stream));
         hipLaunchKernelGGL(a10_enter_kernel, dim3(grid), dim3(A10_TPB), 0, ctx->stream, o, F);
+#ifdef SYLPH_A10_DEBUG
         if (const char* dump = getenv("SYLPH_HIP_A10_DUMP")) {
             if (j == 0) {
                 std::vector<Ent> h(slots);
@@ -621,6 +626,7 @@ static void a10_mark_walk(sylph_sketch* sk) {
             fprintf(stderr, "[sylph_hip] a10 phase %d: %llu occurrences take part, %llu operations, %llu inserting, %llu later than their class's first, %llu EARLIER than it\n",
                     j, hdbg[0], hdbg[1], hdbg[2], hdbg[3], hdbg[4]);
         }
+#endif
         bool last = remaining <= cap;            // not even every remaining operation inserting would fill the filter
         if (!last) {
             b_tiles.reserve(((size_t)n_tiles + 2) * 4 + 16);

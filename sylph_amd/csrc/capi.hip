@@ -236,6 +236,7 @@ void sylph::ctx_unref(sylph_ctx* ctx) {
     ctx->tmp_sort.release();
     ctx->counters.release();
     for (auto& b : ctx->scratch) b.release();
+    if (ctx->inflate_scratch && ctx->inflate_scratch_free) ctx->inflate_scratch_free(ctx->inflate_scratch);
     for (auto& b : ctx->pool_free) (void)hipFree(b.second);
     ctx->pool_free.clear();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -357,7 +358,11 @@ int sylph_upload_restart(sylph_upload* u, uint64_t bytes) {
         SY_REQUIRE_STATE(u->cur < 0, "sylph_upload_restart: a chunk is still out");
         DeviceGuard dg(u->ctx->device);
         SY_HIP(hipStreamSynchronize(u->stream));
-        if (bytes + 64 > u->dev.cap) {
+        // grows when it must, and SHRINKS behind an unusually large sample (round 6): a buffer that only grew stayed at the
+        // size of the largest text an engine ever sent — up to ~18 GB each, times the engines of a `profile`, beside a 29 GB index
+        const bool too_small = bytes + 64 > u->dev.cap;
+        const bool wasteful = u->dev.cap > (4ull << 30) && u->dev.cap / 4 > bytes + 64;
+        if (too_small || wasteful) {
             SY_HIP(hipStreamSynchronize(u->ctx->stream));      // kernels of the context may still read the old buffer
             u->dev.release();
             u->dev.alloc(bytes + bytes / 8 + 64);
@@ -403,6 +408,8 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             ctx->bucket_target = (uint32_t)v;
         } else if (!strcmp(key, "plain_records")) {
             ctx->plain_records = (uint32_t)strtol(value, nullptr, 10) ? 1u : 0u;   // A/B knob: 0 = occurrence records for every batch
+        } else if (!strcmp(key, "fail_next_peer_copy")) {
+            ctx->fail_next_peer_copy = (uint32_t)strtol(value, nullptr, 10);     // tests only: sylph_db_replicate into this context takes the host road
         } else if (!strcmp(key, "fail_next_shard_probe")) {
             ctx->fail_next_shard_probe = (uint32_t)strtol(value, nullptr, 10);   // tests only: one rank of a sharded batch fails between the collectives
         } else if (!strcmp(key, "push_chunk_bytes")) {

@@ -143,6 +143,7 @@ struct sylph_ctx {
     int finish_mode = 0;                    // 0 auto, 1 generic, 2 bucket-only (sylph_ctx_set_option "finish")
     uint32_t bucket_target = 128;           // mean occurrences per replay bucket aimed for ("bucket_target")
     uint32_t plain_records = 1;             // marker-less single-end batches keep no occurrence records ("plain_records" = 0: always write them)
+    uint32_t fail_next_peer_copy = 0;       // fault injection for the tests ("fail_next_peer_copy"): the next sylph_db_replicate INTO this context finds no device-to-device road
     uint32_t fail_next_shard_probe = 0;     // fault injection for the tests ("fail_next_shard_probe"): the next sharded probe on this context throws
     uint32_t index_lambda = 0;              // 0 = the default for the line size (contain_index.h DEFAULT_INDEX_LAMBDA: 4 per 64-byte line); postings per bucket line of a database index aimed for ("index_lambda"; r04: 3 -> 4, 38.5 -> 29.1 GB at GTDB scale for +3 % probe time alone)
     uint64_t index_pass_max = 1ull << 30;   // postings sorted per pass of the index build ("index_pass_max"; tests lower it)
@@ -174,6 +175,11 @@ struct sylph_ctx {
     sylph::DevBuf tmp_sort;                 // rocPRIM temporary storage
     sylph::DevBuf scratch[8];
     sylph::DevBuf counters;                 // small device words (survivor counters etc.)
+    // csrc/inflate.hip: the scratch of sylph_inflate (compressed bytes, cells, window functions: GBs) stays allocated between calls while
+    // an inflated text of this context is alive — the two mates of a pair share it — and is freed with the last of them (free_fn)
+    void* inflate_scratch = nullptr;
+    void (*inflate_scratch_free)(void*) = nullptr;
+    uint32_t inflate_live = 0;
     void* pinned = nullptr;                 // 4 KiB pinned host page for small read-backs
     // small synchronous device->host read through the pinned page (pageable D2H copies are staged and slow)
     void read_back(void* dst, const void* dev_src, size_t bytes);

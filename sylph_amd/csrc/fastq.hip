@@ -324,6 +324,15 @@ int sylph_sketch_push_fastq(sylph_sketch* sk, sylph_fastq* a, sylph_fastq* b, ui
         ctx->read_back(&total, b_tot.p, 8);
         SY_REQUIRE(total < (1ull << 32) - 64, "sylph_sketch_push_fastq: %llu bases in one push (at most 2^32 - 65: push fewer records at a time)", total);
         n_bases = total;
+        // no room for the gathered batch and its seeding?  Say so BEFORE anything of the session is touched (round 6): the caller
+        // pushes fewer records at a time, or takes its host feed, which works through a sample in 256 Mbp batches
+        if (n_bases + 64 > sk->fq_bases.cap) {
+            size_t free_b = 0, total_b = 0;
+            size_t pooled = 0;                                  // blocks the context's pool holds and hands out again
+            for (const auto& blk : ctx->pool_free) pooled += blk.first;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + pooled < n_bases + n_bases / 2 + (256u << 20))
+                throw HipError{hipErrorOutOfMemory, "sylph_sketch_push_fastq: no room for the batch", __FILE__, __LINE__};
+        }
         sk->fq_bases.reserve(n_bases + 64);
         sk->fq_off.reserve((n_rec_batch + 1) * 8);
         hipLaunchKernelGGL(fq_widen_kernel, dim3(grid1(n_rec_batch + 1, 256, 4096)), dim3(256), 0, ctx->stream, b_off.as<uint32_t>(), n_rec_batch + 1,

@@ -39,7 +39,7 @@ struct sylph_inflated {
     sylph_ctx* ctx = nullptr;
     void* buf = nullptr;                  // hipMalloc'ed: 256 bytes of zero padding, the text, 256 bytes of zero padding
     uint64_t n = 0;
-    uint64_t n_members = 0, n_blocks = 0, n_candidates = 0, n_host_members = 0;
+    uint64_t n_members = 0, n_blocks = 0, n_candidates = 0, n_host_members = 0, n_redone = 0;
     const uint8_t* text() const { return (const uint8_t*)buf + 256; }
 };
 
@@ -203,7 +203,9 @@ __global__ __launch_bounds__(SCAN2_TPB) void scan2_kernel(const uint32_t* __rest
 // =================================================================================================================================
 // decode: one wavefront per candidate
 // =================================================================================================================================
-constexpr uint32_t RING = 4096, RING_MASK = RING - 1, FLUSH = 1024;   // cells of a block kept in LDS / leaving for global memory at a time (DecodeOut)
+constexpr uint32_t FLUSH = 1024;     // cells of a block leaving the LDS ring for global memory at a time (DecodeOut)
+// RING: cells of a block kept in LDS — 4096, or 2048 when the file has more blocks than wavefronts fit beside each other with the larger ring
+template <uint32_t RING>
 struct WaveTables {
     uint16_t lit[1 << LIT_ROOT];          // sym << 4 | len;  0 = no code;  T_LONG = longer than the root
     uint16_t dist[1 << DIST_ROOT];        // (the code-length code is built here first, 7-bit root)
@@ -235,6 +237,15 @@ struct WaveBits {                                  // the same reader, but every
     // chain of every ten literals), the window step three words per lane.
     uint32_t nxt;
     uint32_t* stream;
+    uint64_t at;                                   // !synced: the position (acc / cnt / wpos are stale: the window step moves `at` alone)
+    bool synced;
+    __device__ __forceinline__ uint64_t position() const { return synced ? wpos * 32 - cnt : at; }
+    __device__ __forceinline__ void move_to(uint64_t bitpos) {            // (the window step: no word is fetched for the scalar reader)
+        at = bitpos;
+        synced = false;
+        if ((long long)((bitpos >> 5) - cbase) >= 64) next_chunk();
+    }
+    __device__ __forceinline__ void sync() { if (!synced) seek(at); }
     __device__ __forceinline__ void init(const uint32_t* words, uint64_t bitpos, uint64_t limit_words) {
         const uint32_t lane = threadIdx.x & 63;
         w = words;
@@ -248,6 +259,8 @@ struct WaveBits {                                  // the same reader, but every
         const uint32_t s = (uint32_t)bitpos & 31;
         acc = (uint64_t)(word() >> s);
         cnt = 32 - s;
+        synced = true;
+        at = 0;
         refill();
     }
     __device__ __forceinline__ void next_chunk() {
@@ -269,6 +282,7 @@ struct WaveBits {                                  // the same reader, but every
         const uint32_t s = (uint32_t)bitpos & 31;
         acc = (uint64_t)(word() >> s);
         cnt = 32 - s;
+        synced = true;
         refill();
     }
     __device__ __forceinline__ void refill() {
@@ -372,45 +386,94 @@ __device__ __forceinline__ uint32_t decode_long(uint32_t bits, uint32_t root, ui
 // the ring at least a chunk ago, so the stores are issued; the same wave's loads see them).  The first version kept nothing on the
 // chip and every match waited for the acknowledgement of all earlier stores and for its own load — vmcnt counts both —, ~5,000
 // cycles per match: 35 ms for a block of 16 K matches, whatever the literals cost.
+// one candidate for a wavefront: where its block starts, where its cells go (offset into the cells buffer) and how many fit
+struct DecodeJob { unsigned long long start_bit, region; uint32_t cap, have_window; };
+// the spill arena behind the candidates' regions: SPILL_SLOTS regions of SPILL_CELLS cells, handed out by an atomic counter (next)
+struct Spill { unsigned long long base; uint32_t slots; };
+constexpr uint32_t SPILL_CELLS = 1u << 20, SPILL_SLOTS = 96;
+
+template <uint32_t RING>
 struct DecodeOut {                       // n, flushed, cap: wave-uniform
+    static constexpr uint32_t RING_MASK = RING - 1;
     uint16_t* out;
     uint16_t* ring;
     uint32_t n, flushed, cap;
+    bool dry;                            // the region is full: the rest of the block is decoded for its length and its end only (room())
     __device__ __forceinline__ void flush_chunk() {
-        const uint32_t lane = threadIdx.x & 63;
-        const uint4* src = reinterpret_cast<const uint4*>(ring + ((flushed + lane * 16) & RING_MASK));
-        uint4* dst = reinterpret_cast<uint4*>(out + flushed + lane * 16);
-        const uint4 a = src[0], b = src[1];
-        dst[0] = a;
-        dst[1] = b;
+        if (!dry) {
+            const uint32_t lane = threadIdx.x & 63;
+            const uint4* src = reinterpret_cast<const uint4*>(ring + ((flushed + lane * 16) & RING_MASK));
+            uint4* dst = reinterpret_cast<uint4*>(out + region + flushed + lane * 16);
+            const uint4 a = src[0], b = src[1];
+            dst[0] = a;
+            dst[1] = b;
+        }
         flushed += FLUSH;
+    }
+    // k more cells: false = not even countable (a block of 4 Gi cells).  A block that outgrows its region — a header-like bit pattern
+    // inside it cut the region short (one in ~4,000 blocks of a FASTQ file), or it deflates better than REGION_RATIO — MOVES, once, to a
+    // region of SPILL_CELLS cells of the spill arena (what it has written so far goes with it: whole chunks, 16 bytes per lane and
+    // step); a block that outgrows that too, or finds the arena empty, goes on DRY: it still reports where it ends and how long it is,
+    // and the host has it decoded once more into a region of exactly that size.
+    uint32_t* spill_next;
+    unsigned long long spill_base;
+    uint32_t spill_slots;
+    bool moved;
+    unsigned long long region;
+    __device__ __forceinline__ bool room(uint32_t k) {
+        if (n + k > cap && !dry) {
+            uint32_t slot = ~0u;
+            if (!moved && n + k <= SPILL_CELLS) {
+                if ((threadIdx.x & 63) == 0) slot = atomicAdd(spill_next, 1u);
+                slot = uni(slot);
+            }
+            if (slot < spill_slots) {
+                const unsigned long long to = spill_base + (unsigned long long)slot * SPILL_CELLS;
+                for (uint32_t at = 0; at < flushed; at += 64 * 8) {
+                    const uint32_t i = at + (threadIdx.x & 63) * 8;
+                    if (i < flushed) *reinterpret_cast<uint4*>(out + to + i) = *reinterpret_cast<const uint4*>(out + region + i);
+                }
+                region = to;
+                cap = SPILL_CELLS;
+                moved = true;
+            } else dry = true;
+        }
+        return n + k <= 0xFFFFFF00u;
     }
     __device__ __forceinline__ void advance(uint32_t k) {
         n += k;
         while (n - flushed >= FLUSH) flush_chunk();
     }
     __device__ __forceinline__ void finish() {
-        for (uint32_t base = flushed; base < n; base += 64) {
+        for (uint32_t base = flushed; base < n && !dry; base += 64) {
             const uint32_t i = base + (threadIdx.x & 63);
-            if (i < n) out[i] = ring[i & RING_MASK];
+            if (i < n) out[region + i] = ring[i & RING_MASK];
         }
         flushed = n;
     }
 };
 
-__global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__ gzw, uint64_t n_words, const uint64_t* __restrict__ cand, uint32_t n_cand,
-                                                    uint64_t byte0, uint64_t byte_end, uint16_t* __restrict__ cells, BlockResult* __restrict__ res) {
-    __shared__ WaveTables T;
+template <uint32_t RING>
+__global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__ gzw, uint64_t n_words, const DecodeJob* __restrict__ jobs, uint16_t* __restrict__ cells,
+                                                    Spill spill, uint32_t* __restrict__ spill_next, BlockResult* __restrict__ res) {
+    constexpr uint32_t RING_MASK = RING - 1;
+    __shared__ WaveTables<RING> T;
     const uint32_t k = blockIdx.x, lane = threadIdx.x;
-    const uint64_t start = cand[k];
-    const uint64_t next_byte = k + 1 < n_cand ? cand[k + 1] >> 3 : byte_end;
-    const uint64_t region = ((start >> 3) - byte0) * REGION_RATIO + (uint64_t)k * REGION_SLACK;
-    DecodeOut o;
-    o.out = cells + region;
+    const DecodeJob job = jobs[k];
+    const uint64_t start = job.start_bit;
+    const uint64_t region = job.region;
+    DecodeOut<RING> o;
+    o.out = cells;                                  // (the whole buffer: a block's cells begin at o.region — which the block may change, room())
     o.ring = T.ring;
     o.n = 0; o.flushed = 0;
-    o.cap = (uint32_t)min((uint64_t)0xFFFFFF00u, (next_byte - (start >> 3)) * REGION_RATIO + REGION_SLACK);
-    const bool have_window = k != 0;
+    o.cap = job.cap;
+    o.dry = false;
+    o.spill_base = spill.base;
+    o.spill_slots = spill.slots;
+    o.spill_next = spill_next;
+    o.moved = false;
+    o.region = region;
+    const bool have_window = job.have_window != 0;
     WaveBits b;
     b.stream = T.stream;
     b.init(gzw, start, n_words);
@@ -439,7 +502,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
             if (b.over || (len ^ 0xFFFFu) != nlen) { status = ST_ERR_STORED; break; }
             const uint64_t from = b.bitpos() >> 3;
             if (from + len > n_words * 4) { status = ST_ERR_OVERRUN; break; }
-            if (o.n + len > o.cap) { status = ST_OVERFLOW; break; }
+            if (!o.room(len)) { status = ST_OVERFLOW; break; }
             const uint8_t* gzb = reinterpret_cast<const uint8_t*>(gzw);
             for (uint32_t base = 0; base < len; base += 64) {
                 o.ring[base + lane < len ? (o.n + lane) & RING_MASK : RING + lane] = gzb[from + min(base + lane, len - 1)];
@@ -519,7 +582,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
             while (!eob && status == ST_NONE) {
                 n_sym++;
                 uint32_t taken = 0;
-                const uint64_t p = b.bitpos();
+                const uint64_t p = b.position();
                 if (p + 192 <= limit_bits) {
                     // lane j: 64 bits of the stream from bit p + j
                     const uint64_t pj = p + lane;
@@ -547,21 +610,22 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     // (the literal's byte, or the distance) << 15
                     const uint32_t about = cells << 7 | (is_lit ? 1u << 14 : 0u) | (is_lit ? sy : dbase + ((y >> l2) & ((1u << deb) - 1))) << 15;
                     // the chain of symbol starts, from lane 0; owner of cell c = the last walked symbol whose first cell is <= c
+                    // (what the walk asks of a start, in one word per lane: bits | cells << 6 | end-of-block << 13 | not-for-this-step << 14)
+                    const uint32_t walk = bits | cells << 6 | (is_eob ? 1u << 13 : 0u) | (bad ? 1u << 14 : 0u);
                     uint32_t pos = 0, total = 0, owner = 0, first_cell = 0;
                     while (pos < 64) {
-                        if (__builtin_amdgcn_readlane(bad ? 1u : 0u, pos)) break;
-                        const uint32_t c = __builtin_amdgcn_readlane(cells, pos);
-                        if (total + c > 64) break;
+                        const uint32_t w1 = __builtin_amdgcn_readlane(walk, pos);
+                        const uint32_t c = (w1 >> 6) & 127;
+                        if ((w1 >> 14) || total + c > 64) break;
                         owner = lane >= total ? pos : owner;
                         first_cell = lane == pos ? total : first_cell;
                         total += c;
                         taken++;
-                        const bool last = __builtin_amdgcn_readlane(is_eob ? 1u : 0u, pos) != 0;
-                        pos += __builtin_amdgcn_readlane(bits, pos);
-                        if (last) { eob = true; break; }
+                        pos += w1 & 63;
+                        if (w1 >> 13 & 1) { eob = true; break; }
                     }
                     if (taken) {
-                        if (o.n + total > o.cap) { status = ST_OVERFLOW; break; }
+                        if (!o.room(total)) { status = ST_OVERFLOW; break; }
                         const uint32_t mine_about = __shfl(about | first_cell, owner);
                         const uint32_t my_first = mine_about & 127, my_len = (mine_about >> 7) & 127, my_val = mine_about >> 15;
                         const bool mine = lane < total, my_lit = (mine_about >> 14 & 1) != 0;
@@ -582,16 +646,17 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                             const bool can = is_copy && (pending >> lane & 1) && src < (int)frontier;
                             const uint32_t at = (uint32_t)max(src, 0);
                             uint16_t v = o.ring[at & RING_MASK];
-                            if (__ballot(can && far)) { const uint16_t g = o.out[far ? at : 0u]; v = far ? g : v; }
+                            if (__ballot(can && far) && !o.dry) { const uint16_t g = o.out[o.region + (far ? at : 0u)]; v = far ? g : v; }
                             o.ring[can ? (o.n + lane) & RING_MASK : RING + lane] = src < 0 ? (uint16_t)(256 + WINDOW + src) : v;
                             pending &= ~__ballot(can);
                         }
                         o.advance(total);
-                        b.seek(p + pos);
+                        b.move_to(p + pos);
                     }
                 }
                 if (taken || eob || status != ST_NONE) continue;
                 // ---- one symbol, the slow way
+                b.sync();
                 b.refill();
                 uint32_t e = uni(T.lit[b.peek(LIT_ROOT)]);
                 if (e == T_LONG) e = uni(decode_long((uint32_t)b.acc, LIT_ROOT, lit_max, T.lit_sorted, T.lit_first, T.lit_count, T.lit_off));
@@ -599,7 +664,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 b.drop(e & 15);
                 const uint32_t sym = e >> 4;
                 if (sym < 256) {
-                    if (o.n + 1 > o.cap) { status = ST_OVERFLOW; break; }
+                    if (!o.room(1)) { status = ST_OVERFLOW; break; }
                     o.ring[lane == 0 ? o.n & RING_MASK : RING + lane] = (uint16_t)sym;
                     o.advance(1);
                     continue;
@@ -626,7 +691,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     if (!have_window || dist - o.n > WINDOW) { status = ST_ERR_DISTANCE; break; }
                     flags |= 1;
                 }
-                if (o.n + len > o.cap) { status = ST_OVERFLOW; break; }
+                if (!o.room(len)) { status = ST_OVERFLOW; break; }
                 // sources: cell n - dist + (i mod dist) for i < len — all of them in front of n, whatever the overlap
                 const int src0 = (int)o.n - (int)dist;
                 const bool near = dist + len <= RING;
@@ -635,11 +700,17 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     const uint32_t i = min(base + lane, len - 1);
                     const int src = src0 + (int)(dist >= len ? i : dist == 1 ? 0u : i % dist);
                     const uint32_t at = (uint32_t)max(src, 0);
-                    const uint16_t got = near ? o.ring[at & RING_MASK] : o.out[at];
+                    // (two loads and a select of the VALUES: a select between an LDS and a global POINTER becomes a flat load whose
+                    //  aperture test hipcc 7.2 cannot select — "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+                    const bool from_ring = near || o.dry;
+                    const uint16_t in_ring = o.ring[at & RING_MASK];
+                    uint16_t got = in_ring;
+                    if (!from_ring) got = *const_cast<const volatile uint16_t*>(&o.out[o.region + at]);   // (volatile: not to be merged with the load above)
                     o.ring[base + lane < len ? (o.n + i) & RING_MASK : RING + lane] = src < 0 ? (uint16_t)(256 + WINDOW + src) : got;
                 }
                 o.advance(len);
             }
+            b.sync();
             if (status != ST_NONE) break;
             if (b.over) { status = ST_ERR_OVERRUN; break; }
         }
@@ -651,8 +722,9 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
         r.end_bit = end_bit;
         r.n_out = o.n;
         r.status = status;
-        r.flags = flags;
+        r.flags = flags | (o.dry ? 2u : 0u);
         r.pad = 0;
+        r.region = o.region;
         r.stats[0] = n_sym;
         r.stats[1] = n_far;
         r.stats[2] = (uint32_t)(t_build >> 10);
@@ -665,7 +737,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
 // windows
 // =================================================================================================================================
 struct PlanBlock {                      // one chain block, as the device needs it
-    unsigned long long cells;           // offset of its region in the cells
+    const uint16_t* cells;              // its region of cells (in the first pass's buffer, or in the buffer of the blocks decoded again)
     unsigned long long out_off;
     uint32_t n_out;
     uint32_t flags;
@@ -674,8 +746,8 @@ struct PlanBlock {                      // one chain block, as the device needs 
 constexpr int WIN_TPB = 1024;
 // group g = chain blocks [g * G, min(K, (g + 1) * G)).  S (in LDS, 2 x 32 Ki cells): the window in front of the current block as a
 // function of the window in front of the group's first block.  sfn[k] receives the S of block k, ffn[g] the one behind the group.
-__global__ __launch_bounds__(WIN_TPB) void winfn_kernel(const PlanBlock* __restrict__ plan, uint32_t K, uint32_t G, const uint16_t* __restrict__ cells,
-                                                        uint16_t* __restrict__ sfn, uint16_t* __restrict__ ffn) {
+__global__ __launch_bounds__(WIN_TPB) void winfn_kernel(const PlanBlock* __restrict__ plan, uint32_t K, uint32_t G, uint16_t* __restrict__ sfn,
+                                                        uint16_t* __restrict__ ffn) {
     extern __shared__ uint16_t S[];     // [2][WINDOW]
     const uint32_t g = blockIdx.x, k0 = g * G, k1 = min(K, k0 + G);
     uint16_t* cur = S;
@@ -686,7 +758,7 @@ __global__ __launch_bounds__(WIN_TPB) void winfn_kernel(const PlanBlock* __restr
         uint16_t* dst = sfn + (uint64_t)k * WINDOW;
         for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) dst[j] = cur[j];
         const uint32_t t = plan[k].n_out;
-        const uint16_t* c = cells + plan[k].cells;
+        const uint16_t* c = plan[k].cells;
         if (t >= WINDOW) {
             const uint16_t* tail = c + (t - WINDOW);
             for (uint32_t j = threadIdx.x; j < WINDOW; j += WIN_TPB) {
@@ -731,7 +803,7 @@ __global__ __launch_bounds__(WIN_TPB) void winchain_kernel(const uint16_t* __res
 // cells -> bytes
 // =================================================================================================================================
 constexpr int TR_TPB = 256;
-__global__ __launch_bounds__(TR_TPB) void translate_kernel(const PlanBlock* __restrict__ plan, uint32_t G, const uint16_t* __restrict__ cells,
+__global__ __launch_bounds__(TR_TPB) void translate_kernel(const PlanBlock* __restrict__ plan, uint32_t G,
                                                            const uint16_t* __restrict__ sfn, const uint8_t* __restrict__ rwin, uint8_t* __restrict__ text) {
     __shared__ uint8_t W[WINDOW];
     const uint32_t k = blockIdx.x;
@@ -742,7 +814,7 @@ __global__ __launch_bounds__(TR_TPB) void translate_kernel(const PlanBlock* __re
         for (uint32_t j = threadIdx.x; j < WINDOW; j += TR_TPB) { const uint16_t v = s[j]; W[j] = v < 256 ? (uint8_t)v : r[v - 256]; }
         __syncthreads();
     }
-    const uint16_t* c = cells + pb.cells;
+    const uint16_t* c = pb.cells;
     uint8_t* o = text + pb.out_off;
     const uint32_t n = pb.n_out;
     // byte-wise up to the first 4-byte boundary of the text, then four cells -> one dword per lane
@@ -859,14 +931,35 @@ __global__ __launch_bounds__(CRC_TPB) void crc_kernel(const uint8_t* __restrict_
 // =================================================================================================================================
 struct Raw {                            // plain hipMalloc / hipFree: GBs of scratch per call must not stay in the context's pool
     void* p = nullptr;
+    size_t cap = 0;
     ~Raw() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     void alloc(size_t bytes) {
-        const hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 256));
+        release();
+        bytes = std::max<size_t>(bytes, 256);
+        const hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); throw HipError{e, "hipMalloc (inflate scratch)", __FILE__, __LINE__}; }
+        cap = bytes;
     }
+    void reserve(size_t bytes) { if (bytes > cap) alloc(bytes + bytes / 8); }      // contents are not kept
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+// What a call needs beside the text it returns.  Kept by the context between calls while one of its inflated texts is alive (the two
+// mates of a pair, one call after the other: the second finds 7 GB of buffers in place), freed with the last of them.
+struct InflateScratch { Raw gz, c1, c2, cnt, cells, res, jobs, plan, sfn, ffn, rwin, mend, x2n, raw; };
+InflateScratch& scratch_of(sylph_ctx* ctx) {
+    if (!ctx->inflate_scratch) {
+        ctx->inflate_scratch = new InflateScratch();
+        ctx->inflate_scratch_free = [](void* p) { delete static_cast<InflateScratch*>(p); };
+    }
+    return *static_cast<InflateScratch*>(ctx->inflate_scratch);
+}
+void scratch_drop(sylph_ctx* ctx) {          // (under the context's lock, its stream idle)
+    if (ctx->inflate_scratch && ctx->inflate_live == 0) {
+        delete static_cast<InflateScratch*>(ctx->inflate_scratch);
+        ctx->inflate_scratch = nullptr;
+    }
+}
 
 // a small member through zlib (gzip wrapper: zlib checks CRC and ISIZE itself)
 bool zlib_member(const uint8_t* gz, size_t n, size_t p, size_t* end, std::vector<uint8_t>& out) {
@@ -897,8 +990,9 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
     const uint64_t byte_end = n;                    // (trailers and later headers are scanned too: no harm, and members end anywhere)
     // ---- the compressed bytes, padded with zero words
     const uint64_t n_words = (n + 3) / 4;
-    Raw d_gz;
-    d_gz.alloc((n_words + GZ_PAD_WORDS) * 4);
+    InflateScratch& S = scratch_of(ctx);
+    Raw& d_gz = S.gz;
+    d_gz.reserve((n_words + GZ_PAD_WORDS) * 4);
     {
         HostPhase hp(ctx, "inflate: upload");
         SY_HIP(hipMemsetAsync(d_gz.as<uint8_t>() + (n & ~(uint64_t)3), 0, (n_words + GZ_PAD_WORDS) * 4 - (n & ~(uint64_t)3), s));
@@ -906,10 +1000,10 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
     }
     // ---- candidates
     const uint64_t cap1 = n / 8 + 4096, cap2 = n / 64 + 4096;
-    Raw d_c1, d_c2, d_cnt;
-    d_c1.alloc(cap1 * 8);
-    d_c2.alloc(cap2 * 8);
-    d_cnt.alloc(64);
+    Raw &d_c1 = S.c1, &d_c2 = S.c2, &d_cnt = S.cnt;
+    d_c1.reserve(cap1 * 8);
+    d_c2.reserve(cap2 * 8);
+    d_cnt.reserve(64);
     SY_HIP(hipMemsetAsync(d_cnt.p, 0, 64, s));
     unsigned long long* cnt = d_cnt.as<unsigned long long>();
     unsigned long long n1 = 0, n2 = 0;
@@ -938,26 +1032,52 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
     const uint32_t K = (uint32_t)cand.size();
     if (cand.size() >= (1ull << 31)) throw FormatDecline{"too many candidates"};
     t->n_candidates = K;
-    d_c1.release();
     // ---- decode every candidate
-    const uint64_t n_cells = (byte_end - body0) * REGION_RATIO + (uint64_t)K * REGION_SLACK + 64;
-    Raw d_cells, d_res, d_cand;
-    d_cells.alloc(n_cells * 2);
-    d_res.alloc((size_t)K * sizeof(BlockResult));
-    d_cand.alloc((size_t)K * 8);
+    // (SYLPH_HIP_INFLATE_REGION_RATIO: the tests' way to make every block outgrow its region)
+    const char* rr_env = getenv("SYLPH_HIP_INFLATE_REGION_RATIO");
+    const uint64_t region_ratio = rr_env ? std::max(1, std::min(64, atoi(rr_env))) : REGION_RATIO;
+    const uint64_t n_cells = (byte_end - body0) * region_ratio + (uint64_t)K * REGION_SLACK + 64;
+    Raw &d_cells = S.cells, &d_res = S.res, &d_jobs = S.jobs;
+    const uint64_t spill_base = (n_cells + 63) & ~(uint64_t)63;
+    d_cells.reserve((spill_base + (uint64_t)SPILL_SLOTS * SPILL_CELLS + 64) * 2);
+    d_res.reserve((size_t)K * sizeof(BlockResult));
+    d_jobs.reserve((size_t)K * sizeof(DecodeJob));
+    SY_HIP(hipMemsetAsync(cnt + 2, 0, 8, s));                                 // the spill arena's counter
+    const Spill spill{spill_base, SPILL_SLOTS}, no_spill{0, 0};
+    uint32_t* const spill_next = reinterpret_cast<uint32_t*>(cnt + 2);
     std::vector<BlockResult> res(K);
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    auto launch_decode = [&](const DecodeJob* jobs, uint32_t n_jobs, uint16_t* cells, const Spill& sp, BlockResult* out) {
+        // the larger ring while all blocks' wavefronts fit on the chip beside each other with it (LDS: ~13 KB per wavefront -> 12 per CU)
+        if (n_jobs <= (uint32_t)n_cu * 12 && !getenv("SYLPH_HIP_INFLATE_SMALL_RING"))
+            hipLaunchKernelGGL(decode_kernel<4096>, dim3(n_jobs), dim3(64), 0, s, d_gz.as<uint32_t>(), n_words, jobs, cells, sp, spill_next, out);
+        else
+            hipLaunchKernelGGL(decode_kernel<2048>, dim3(n_jobs), dim3(64), 0, s, d_gz.as<uint32_t>(), n_words, jobs, cells, sp, spill_next, out);
+        SY_HIP(hipGetLastError());
+    };
     {
         ScopedKernelTimer kt(ctx, "inflate_decode");
         HostPhase hp(ctx, "inflate: decode");
-        ctx->h2d(d_cand.p, cand.data(), (size_t)K * 8);
-        hipLaunchKernelGGL(decode_kernel, dim3(K), dim3(64), 0, s, d_gz.as<uint32_t>(), n_words, d_cand.as<uint64_t>(), K, (uint64_t)body0, byte_end, d_cells.as<uint16_t>(),
-                           d_res.as<BlockResult>());
-        SY_HIP(hipGetLastError());
+        // a candidate's region: REGION_RATIO cells per compressed byte up to the next candidate, + REGION_SLACK
+        std::vector<DecodeJob> jobs(K);
+        for (uint32_t i = 0; i < K; i++) {
+            const uint64_t b0 = cand[i] >> 3, b1 = i + 1 < K ? cand[i + 1] >> 3 : byte_end;
+            jobs[i].start_bit = cand[i];
+            jobs[i].region = (b0 - body0) * region_ratio + (uint64_t)i * REGION_SLACK;
+            jobs[i].cap = (uint32_t)std::min<uint64_t>(0xFFFFFF00u, (b1 - b0) * region_ratio + REGION_SLACK);
+            jobs[i].have_window = i != 0;
+        }
+        ctx->h2d(d_jobs.p, jobs.data(), (size_t)K * sizeof(DecodeJob));
+        launch_decode(d_jobs.as<DecodeJob>(), K, d_cells.as<uint16_t>(), spill, d_res.as<BlockResult>());
     }
     ctx->d2h(res.data(), d_res.p, (size_t)K * sizeof(BlockResult));
     if (getenv("SYLPH_HIP_INFLATE_STATS")) {
         uint64_t sym = 0, far = 0, tb = 0, tt = 0, tmax = 0, cells_out = 0;
         for (const BlockResult& r : res) { sym += r.stats[0]; far += r.stats[1]; tb += r.stats[2]; tt += r.stats[3]; tmax = std::max<uint64_t>(tmax, r.stats[3]); cells_out += r.n_out; }
+        uint64_t moved_n = 0, dry_n = 0;
+        for (const BlockResult& r : res) { moved_n += r.region >= spill_base; dry_n += (r.flags & 2) != 0; }
+        fprintf(stderr, "[sylph_hip inflate] %llu candidates moved to the spill arena, %llu ran dry\n", (unsigned long long)moved_n, (unsigned long long)dry_n);
         fprintf(stderr, "[sylph_hip inflate] %u candidates: %llu symbol-loop turns, %llu copies from global memory, %llu cells; per wave: %.0f k-cycles mean (%.0f on headers + tables), %llu max\n",
                 K, (unsigned long long)sym, (unsigned long long)far, (unsigned long long)cells_out, (double)tt / K, (double)tb / K, (unsigned long long)tmax);
     }
@@ -978,6 +1098,47 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
     t->n_host_members = 0;
     for (const Member& m : chain.members) t->n_host_members += m.on_host;
     t->n = chain.total;
+    // ---- blocks of the chain that outgrew their region (BlockResult::flags bit 1): once more, each into a region of exactly its size
+    Raw d_cells2;
+    std::vector<uint64_t> redo_region(KB, ~0ull);
+    {
+        std::vector<DecodeJob> jobs;
+        std::vector<uint32_t> which;
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < KB; i++) {
+            const ChainBlock& cb = chain.blocks[i];
+            if (!(cb.flags & 2)) continue;
+            DecodeJob j;
+            j.start_bit = cand[cb.cand];
+            j.region = at;
+            j.cap = cb.n_out;
+            j.have_window = cb.cand != 0;
+            redo_region[i] = at;
+            at += ((uint64_t)cb.n_out + 63) & ~(uint64_t)63;       // (regions start 128-byte aligned: the ring leaves in 16-byte stores)
+            jobs.push_back(j);
+            which.push_back(i);
+        }
+        t->n_redone = jobs.size();
+        if (!jobs.empty()) {
+            ScopedKernelTimer kt(ctx, "inflate_decode");
+            HostPhase hp(ctx, "inflate: decode again");
+            Raw d_jobs2, d_res2;
+            d_cells2.alloc((at + 64) * 2);
+            d_jobs2.alloc(jobs.size() * sizeof(DecodeJob));
+            d_res2.alloc(jobs.size() * sizeof(BlockResult));
+            ctx->h2d(d_jobs2.p, jobs.data(), jobs.size() * sizeof(DecodeJob));
+            launch_decode(d_jobs2.as<DecodeJob>(), (uint32_t)jobs.size(), d_cells2.as<uint16_t>(), no_spill, d_res2.as<BlockResult>());
+            std::vector<BlockResult> res2(jobs.size());
+            ctx->d2h(res2.data(), d_res2.p, jobs.size() * sizeof(BlockResult));
+            for (size_t q = 0; q < jobs.size(); q++) {
+                const ChainBlock& cb = chain.blocks[which[q]];
+                const BlockResult& a = res[cb.cand];
+                const BlockResult& b2 = res2[q];
+                if (b2.status != a.status || b2.n_out != a.n_out || b2.end_bit != a.end_bit || (b2.flags & 2))
+                    throw FormatDecline{"a block decoded a second time came out differently"};
+            }
+        }
+    }
     // ---- the text
     {
         const hipError_t e = hipMalloc(&t->buf, chain.total + 512);
@@ -992,14 +1153,14 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
         bool any_window = false;
         for (uint32_t i = 0; i < KB; i++) {
             const ChainBlock& cb = chain.blocks[i];
-            plan[i].cells = ((cand[cb.cand] >> 3) - body0) * REGION_RATIO + (uint64_t)cb.cand * REGION_SLACK;
+            plan[i].cells = redo_region[i] != ~0ull ? d_cells2.as<uint16_t>() + redo_region[i] : d_cells.as<uint16_t>() + res[cb.cand].region;
             plan[i].out_off = cb.out_off;
             plan[i].n_out = cb.n_out;
             plan[i].flags = cb.flags;
             any_window |= (cb.flags & 1) != 0;
         }
-        Raw d_plan, d_sfn, d_ffn, d_rwin;
-        d_plan.alloc((size_t)KB * sizeof(PlanBlock));
+        Raw &d_plan = S.plan, &d_sfn = S.sfn, &d_ffn = S.ffn, &d_rwin = S.rwin;
+        d_plan.reserve((size_t)KB * sizeof(PlanBlock));
         ctx->h2d(d_plan.p, plan.data(), (size_t)KB * sizeof(PlanBlock));
         uint32_t G = 1;
         while ((uint64_t)G * G < KB) G++;
@@ -1008,13 +1169,12 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
         if (any_window) {
             ScopedKernelTimer kt(ctx, "inflate_windows");
             HostPhase hp(ctx, "inflate: windows");
-            d_sfn.alloc((size_t)KB * WINDOW * 2);
-            d_ffn.alloc((size_t)NG * WINDOW * 2);
-            d_rwin.alloc((size_t)NG * WINDOW);
+            d_sfn.reserve((size_t)KB * WINDOW * 2);
+            d_ffn.reserve((size_t)NG * WINDOW * 2);
+            d_rwin.reserve((size_t)NG * WINDOW);
             static std::once_flag once;
             std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winfn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW * 4); });
-            hipLaunchKernelGGL(winfn_kernel, dim3(NG), dim3(WIN_TPB), WINDOW * 4, s, d_plan.as<PlanBlock>(), KB, G, d_cells.as<uint16_t>(), d_sfn.as<uint16_t>(),
-                               d_ffn.as<uint16_t>());
+            hipLaunchKernelGGL(winfn_kernel, dim3(NG), dim3(WIN_TPB), WINDOW * 4, s, d_plan.as<PlanBlock>(), KB, G, d_sfn.as<uint16_t>(), d_ffn.as<uint16_t>());
             SY_HIP(hipGetLastError());
             hipLaunchKernelGGL(winchain_kernel, dim3(1), dim3(WIN_TPB), 0, s, d_ffn.as<uint16_t>(), NG, d_rwin.as<uint8_t>());
             SY_HIP(hipGetLastError());
@@ -1022,7 +1182,7 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
         {
             ScopedKernelTimer kt(ctx, "inflate_translate");
             HostPhase hp(ctx, "inflate: translate");
-            hipLaunchKernelGGL(translate_kernel, dim3(KB), dim3(TR_TPB), 0, s, d_plan.as<PlanBlock>(), G, d_cells.as<uint16_t>(), d_sfn.as<uint16_t>(), d_rwin.as<uint8_t>(), text);
+            hipLaunchKernelGGL(translate_kernel, dim3(KB), dim3(TR_TPB), 0, s, d_plan.as<PlanBlock>(), G, d_sfn.as<uint16_t>(), d_rwin.as<uint8_t>(), text);
             SY_HIP(hipGetLastError());
         }
         // ---- CRC-32 of every member
@@ -1030,10 +1190,10 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
         for (uint32_t i = 0; i < NM; i++) m_end[i] = chain.members[i].out_end;
         uint32_t x2n[64];
         crc_x2n_table(x2n);
-        Raw d_mend, d_x2n, d_raw;
-        d_mend.alloc((size_t)NM * 8);
-        d_x2n.alloc(256);
-        d_raw.alloc((size_t)NM * 4);
+        Raw &d_mend = S.mend, &d_x2n = S.x2n, &d_raw = S.raw;
+        d_mend.reserve((size_t)NM * 8);
+        d_x2n.reserve(256);
+        d_raw.reserve((size_t)NM * 4);
         std::vector<uint32_t> raw(NM);
         {
             ScopedKernelTimer kt(ctx, "inflate_crc");
@@ -1084,15 +1244,20 @@ int sylph_inflate(sylph_ctx* ctx, const void* gz, uint64_t n_bytes, int mem, syl
         catch (const FormatDecline& e) { set_error("sylph_inflate: declined: %s", e.msg.c_str()); format = 1; }
     });
     if (rc != SYLPH_OK || format) {
-        if (t) {
+        {
             std::lock_guard<std::mutex> lock(ctx->mu);
             DeviceGuard dg(ctx->device);
             (void)hipStreamSynchronize(ctx->stream);
-            if (t->buf) (void)hipFree(t->buf);
+            if (t && t->buf) (void)hipFree(t->buf);
             delete t;
+            scratch_drop(ctx);
         }
         ctx_unref(ctx);
         return rc != SYLPH_OK ? rc : SYLPH_ERR_FORMAT;
+    }
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        ctx->inflate_live++;
     }
     *out = t;
     return SYLPH_OK;
@@ -1105,12 +1270,14 @@ int sylph_inflated_text(const sylph_inflated* t, const void** dev_text, uint64_t
     return SYLPH_OK;
 }
 
-int sylph_inflated_info(const sylph_inflated* t, uint64_t* n_members, uint64_t* n_blocks, uint64_t* n_candidates, uint64_t* n_host_members) {
+int sylph_inflated_info(const sylph_inflated* t, uint64_t* n_members, uint64_t* n_blocks, uint64_t* n_candidates, uint64_t* n_host_members,
+                        uint64_t* n_decoded_again) {
     if (!t) { set_error("null argument"); return SYLPH_ERR_INVALID; }
     if (n_members) *n_members = t->n_members;
     if (n_blocks) *n_blocks = t->n_blocks;
     if (n_candidates) *n_candidates = t->n_candidates;
     if (n_host_members) *n_host_members = t->n_host_members;
+    if (n_decoded_again) *n_decoded_again = t->n_redone;
     return SYLPH_OK;
 }
 
@@ -1135,6 +1302,8 @@ void sylph_inflated_destroy(sylph_inflated* t) {
         (void)hipStreamSynchronize(ctx->stream);       // kernels that read the text may still be queued
         if (t->buf) (void)hipFree(t->buf);
         delete t;
+        if (ctx->inflate_live) ctx->inflate_live--;
+        scratch_drop(ctx);
     }
     ctx_unref(ctx);
 }

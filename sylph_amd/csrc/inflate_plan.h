@@ -44,14 +44,16 @@ enum : uint32_t {
     ST_ERR_DISTANCE = 17,  // a copy from further back than a window reaches (or from before the stream's start)
     ST_ERR_OVERRUN = 18,   // ran out of input
     ST_ERR_STORED = 19,    // stored block: LEN != ~NLEN
-    ST_OVERFLOW = 20,      // output did not fit the candidate's region of cells
+    ST_OVERFLOW = 20,      // more cells than a block may have here (2^32 - 256)
 };
 struct BlockResult {
     unsigned long long end_bit;
     uint32_t n_out;        // cells written
     uint32_t status;
-    uint32_t flags;        // bit 0: the output holds window references
+    uint32_t flags;        // bit 0: the output holds window references; bit 1: the region was too small — end_bit and n_out are right, the
+                           // cells are not all there: the block is decoded once more into a region of n_out cells
     uint32_t pad;
+    unsigned long long region;   // where the block's cells begin in the cells buffer (its own region, or the spill region it moved to)
     uint32_t stats[4];     // diagnostics (SYLPH_HIP_INFLATE_STATS=1): symbols decoded, copies served from global memory, shader
                            // kilo-cycles spent on headers + tables, kilo-cycles in all
 };

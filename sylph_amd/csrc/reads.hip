@@ -255,12 +255,7 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
             const uint32_t hg_max = bins_used ? 63u - (uint32_t)(__ffsll((unsigned long long)bins_used) - 1) : 0u;   // half-groups of 8 k-mers
             const uint32_t rows_used = min((uint32_t)MASKW, (hg_max * 8u + 31u) >> 5);
             if (dealt) {
-                uint32_t incl = hc;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(incl, d);
-                    if (lane >= (uint32_t)d) incl += y;
-                }
+                const uint32_t incl = wave_inclusive_sum(hc);
                 s_perm[(uint32_t)__shfl((int)(incl - hc), (int)bin) + arrival] = (uint16_t)tid;
                 __syncthreads();
             }
@@ -317,12 +312,7 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                 s_mask[nw - 1][tid] = m;
                 cnt += __popc(m);
             }
-            uint32_t x = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d);
-                if (lane >= (uint32_t)d) x += y;
-            }
+            const uint32_t x = wave_inclusive_sum(cnt);
             __syncthreads();
             if (lane == 63) s_wave[wave] = x;
             __syncthreads();

@@ -496,7 +496,17 @@ bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& ope
     e.batch.flush(sk);
     // one push: the batch is the session's own buffer, valid until finish — the seeding verdict may wait for it (one host round trip less)
     if (pushes.size() == 1) hip_check(sylph_sketch_set_option(sk, "borrow_until_finish", "1"), "sylph_sketch_set_option");
-    for (const auto& p : pushes) hip_check(sylph_sketch_push_fastq(sk, fa.f, f2 ? fb.f : nullptr, p.first, p.second), "sylph_sketch_push_fastq");
+    for (const auto& p : pushes) {
+        const int rc = sylph_sketch_push_fastq(sk, fa.f, f2 ? fb.f : nullptr, p.first, p.second);
+        if (rc == SYLPH_ERR_NOMEM) {
+            // no room on the device for this route's batch (the whole sample in one piece, up to 2 Gbp): not an error — the host feed, which
+            // works through a sample in 256 Mbp batches, takes the sample from its start; the caller opens a fresh session
+            if (trace) fprintf(stderr, "[sylph_hip feed] device route: no room for the batch (%s): the host feed takes the sample\n", sylph_last_error());
+            tm.join();
+            return false;
+        }
+        hip_check(rc, "sylph_sketch_push_fastq");
+    }
     lap("device route: pushed");
     tm.join();
     mean_read_length = mean;
@@ -888,7 +898,19 @@ int sketch(Engine& e, const SketchArgs& args) {
     // The parsing / inflating of different samples overlaps; the GPU work of one sample is ~2 ms per Gbp.
     create_dir_all(args.sample_output_dir);
     const size_t n_jobs = first_pairs.size() + read_inputs.size();
-    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(args.threads, MAX_SAMPLE_THREADS), n_jobs));
+    // --gpus N|all (round 6): the workers are dealt to the node's GPUs — worker w runs on device w mod N, with its own context, page-locked
+    // batch and uploader there; a sample never leaves its GPU, nothing is exchanged ("replicas only" for the sketch stage —
+    // what the reference's rayon pool does with the machine's cores, sketch.rs:313, :371).  At least one worker per GPU.
+    int n_gpus = 1;
+    if (args.gpus != 1) {
+        const int have = std::max(1, sylph_device_count());
+        n_gpus = args.gpus < 0 ? have : std::min(args.gpus, have);
+        if (args.gpus > have) warn("--gpus " + std::to_string(args.gpus) + ": this node has " + std::to_string(have) + " GPU(s); using them all");
+    }
+    // (tests on a one-GPU box: SYLPH_HIP_FAKE_GPUS=N deals the workers as for N GPUs and maps every one of them to device 0)
+    const char* fake = getenv("SYLPH_HIP_FAKE_GPUS");
+    const int n_deal = fake ? std::max(1, atoi(fake)) : n_gpus;
+    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(std::min<size_t>(args.threads, MAX_SAMPLE_THREADS), (size_t)(args.gpus != 1 || fake ? n_deal : 1)), n_jobs));
     set_parse_share((unsigned)n_workers);
     // the next sample of every worker is indexed while the current one is gathered and pushed
     std::vector<IndexAhead::Files> job_files;
@@ -954,10 +976,17 @@ int sketch(Engine& e, const SketchArgs& args) {
         std::atomic<size_t> next{0};
         std::mutex err_mu;
         std::optional<Error> first_error;
+        std::atomic<size_t> worker_no{1};
         auto worker = [&](Engine* eng) {
             try {
                 std::unique_ptr<Engine> own;
-                if (!eng) { own.reset(new Engine(e.device)); eng = own.get(); }
+                if (!eng) {
+                    const size_t w = worker_no++;
+                    const int dev = n_deal > 1 ? (fake ? e.device : (int)(w % (size_t)n_deal)) : e.device;
+                    if (n_deal > 1) info("sketch worker " + std::to_string(w) + " runs on GPU " + std::to_string(fake ? (int)(w % (size_t)n_deal) : dev) + (fake ? " (SYLPH_HIP_FAKE_GPUS: device 0)" : ""));
+                    own.reset(new Engine(dev));
+                    eng = own.get();
+                }
                 for (size_t j = next++; j < n_jobs; j = next++) run_job(*eng, j);
             } catch (const Error& er) {
                 std::lock_guard<std::mutex> lk(err_mu);

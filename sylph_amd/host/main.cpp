@@ -58,6 +58,7 @@ int run_sketch(Argv a) {
         else if (t == "--min-spacing") s.min_spacing_kmer = strtoull(a.one().c_str(), nullptr, 10);
         else if (t == "--fpr") s.fpr = atof(a.one().c_str());
         else if (t == "--exact-dedup") { s.exact_dedup = true; a.i++; }
+        else if (t == "--gpus") { const std::string v = a.one(); s.gpus = v == "all" ? -1 : std::max(1, atoi(v.c_str())); }
         else if (t == "-1" || t == "--first-pairs") append(s.first_pair, a.multi());
         else if (t == "-2" || t == "--second-pairs") append(s.second_pair, a.multi());
         else if (t == "--debug" || t == "--trace") a.i++;

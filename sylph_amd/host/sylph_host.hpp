@@ -321,6 +321,7 @@ struct SketchArgs {   // cmdline.rs:28-86
     bool exact_dedup = false;   // --exact-dedup (not in the reference): the exact marker set where the reference would use its cuckoo filter
     uint64_t k = 31, c = 200, min_spacing_kmer = 30, threads = 3;   // -t: samples in flight (cmdline.rs: default 3)
     double fpr = DEFAULT_FPR;
+    int gpus = 1;               // --gpus N|all (-1): the samples' workers are dealt to N GPUs (not in the reference: its rayon pool spans the machine, sketch.rs:313, :371)
     std::optional<std::string> list_sequence, list_reads, list_genomes, list_first_pair, list_second_pair, list_sample_names;
 };
 struct ContainCmdArgs : ContainArgs {   // cmdline.rs:88-160

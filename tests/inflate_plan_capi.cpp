@@ -93,12 +93,16 @@ const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 
 const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-// what one wavefront of decode_kernel does for one candidate
+// what one wavefront of decode_kernel does for one candidate.  A block that outgrows `cap` is decoded to its end all the same (the
+// cells past the region are not kept: flags bit 1) — the caller has it decoded again with room for n_out cells.
 BlockResult model_decode(const uint8_t* gz, size_t n, uint64_t start, bool have_window, size_t cap, std::vector<uint16_t>& out) {
     BitReader b{gz, (uint64_t)n * 8, start};
-    BlockResult r{0, 0, ST_NONE, 0, 0, {0, 0, 0, 0}};
+    BlockResult r{0, 0, ST_NONE, 0, 0, 0, {0, 0, 0, 0}};
     bool first = true;
     out.clear();
+    size_t count = 0;                                  // cells decoded (== out.size() until the region is full)
+    auto put = [&](uint16_t v) { if (count < cap) out.push_back(v); else r.flags |= 2; count++; };
+    auto get = [&](size_t i) { return i < out.size() ? out[i] : (uint16_t)0; };
     while (r.status == ST_NONE) {
         const uint64_t at = b.pos;
         const unsigned bfinal = b.bits(1), type = b.bits(2);
@@ -111,8 +115,7 @@ BlockResult model_decode(const uint8_t* gz, size_t n, uint64_t start, bool have_
             const unsigned len = b.bits(16), nlen = b.bits(16);
             if (b.over || (len ^ 0xFFFF) != nlen) { r.status = ST_ERR_STORED; break; }
             if (b.pos / 8 + len > n) { r.status = ST_ERR_OVERRUN; break; }
-            if (out.size() + len > cap) { r.status = ST_OVERFLOW; break; }
-            for (unsigned i = 0; i < len; i++) out.push_back(gz[b.pos / 8 + i]);
+            for (unsigned i = 0; i < len; i++) put(gz[b.pos / 8 + i]);
             b.pos += (uint64_t)len * 8;
         } else {
             Code lit, dist;
@@ -127,7 +130,7 @@ BlockResult model_decode(const uint8_t* gz, size_t n, uint64_t start, bool have_
             for (;;) {
                 int s = lit.decode(b);
                 if (s < 0) { r.status = b.over ? ST_ERR_OVERRUN : ST_ERR_CODE; break; }
-                if (s < 256) { if (out.size() + 1 > cap) { r.status = ST_OVERFLOW; break; } out.push_back((uint16_t)s); continue; }
+                if (s < 256) { put((uint16_t)s); continue; }
                 if (s == 256) break;
                 s -= 257;
                 if (s >= 29) { r.status = ST_ERR_CODE; break; }
@@ -136,21 +139,20 @@ BlockResult model_decode(const uint8_t* gz, size_t n, uint64_t start, bool have_
                 if (ds < 0 || ds >= 30) { r.status = b.over ? ST_ERR_OVERRUN : ST_ERR_CODE; break; }
                 const unsigned dd = DBASE[ds] + b.bits(DEXT[ds]);
                 if (b.over) { r.status = ST_ERR_OVERRUN; break; }
-                if (dd > out.size()) {
-                    if (!have_window || dd - out.size() > WINDOW) { r.status = ST_ERR_DISTANCE; break; }
+                if (dd > count) {
+                    if (!have_window || dd - count > WINDOW) { r.status = ST_ERR_DISTANCE; break; }
                     r.flags |= 1;
                 }
-                if (out.size() + len > cap) { r.status = ST_OVERFLOW; break; }
                 for (unsigned i = 0; i < len; i++) {
-                    const long src = (long)out.size() - (long)dd;
-                    out.push_back(src >= 0 ? out[(size_t)src] : (uint16_t)(256 + WINDOW + src));
+                    const long src = (long)count - (long)dd;
+                    put(src >= 0 ? get((size_t)src) : (uint16_t)(256 + WINDOW + src));
                 }
             }
             if (r.status != ST_NONE) break;
         }
         if (bfinal) { r.status = ST_FINAL; r.end_bit = b.pos; }
     }
-    r.n_out = (uint32_t)out.size();
+    r.n_out = (uint32_t)count;
     return r;
 }
 
@@ -230,6 +232,16 @@ long long ip_model_inflate(const uint8_t* gz, uint64_t n, uint8_t* out, uint64_t
     });
     if (!c.why.empty()) { put_err(c.why, err, errn); return -1; }
     if (c.total > out_cap) { put_err("output buffer too small", err, errn); return -1; }
+    uint64_t redone = 0;
+    for (const ChainBlock& b : c.blocks) {                 // blocks of the chain that outgrew their region: again, with room for all of it
+        if (!(b.flags & 2)) continue;
+        const BlockResult again = model_decode(gz, (size_t)n, cand[b.cand], b.cand != 0, b.n_out, cells[b.cand]);
+        if (again.status != res[b.cand].status || again.n_out != b.n_out || again.end_bit != res[b.cand].end_bit || (again.flags & 2)) {
+            put_err("a block decoded a second time came out differently", err, errn);
+            return -1;
+        }
+        redone++;
+    }
     for (size_t i = 0; i < c.host.size(); i++) memcpy(out + c.host[i].out_off, host_bytes[i].data(), host_bytes[i].size());
     std::vector<uint8_t> win(WINDOW, 0);
     for (const ChainBlock& b : c.blocks) {
@@ -249,7 +261,7 @@ long long ip_model_inflate(const uint8_t* gz, uint64_t n, uint8_t* out, uint64_t
         if (c.members[i].on_host) { on_host++; continue; }
         if (crc[i] != c.members[i].crc) { put_err("member " + std::to_string(i) + ": CRC-32 differs", err, errn); return -1; }
     }
-    if (info) { info[0] = c.members.size(); info[1] = c.blocks.size(); info[2] = cand.size(); info[3] = on_host; }
+    if (info) { info[0] = c.members.size(); info[1] = c.blocks.size(); info[2] = cand.size(); info[3] = on_host; info[4] = redone; }
     return (long long)c.total;
 }
 

@@ -448,13 +448,17 @@ def test_parallel_feed_equals_sequential_feed(data):
     # comparison is on the k-mer tables the query prints
     for m in ("1", "2"):
         (d / f"z_{m}.fq.gz").write_bytes(bgzf_compress((d / f"s_{m}.fq").read_bytes(), block=4000))
-    o = d / "feed_bgzf"
-    p = subprocess.run([BIN, "sketch", "-1", str(d / "z_1.fq.gz"), "-2", str(d / "z_2.fq.gz"), "--fpr", "0", "-d", str(o)],
-                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SYLPH_HIP_FEED_TRACE="1"))
-    assert p.returncode == 0 and "gather" in p.stderr, p.stderr[-2000:]          # (the trace line of the indexed path)
-    a, b = (o / "z_1.fq.gz.paired.sylsp").read_bytes(), outs[0][0]
+    # (round 6: by default a gzip sample's compressed bytes go to the device — SYLPH_HIP_INFLATE_DEVICE=0 keeps the host's inflate, which
+    #  is what this test is about; the default road gives the same table)
+    b = outs[0][0]
     n_tab = 8 + 12 * int.from_bytes(b[:8], "little")                               # the k-mer table leads the file (types.rs:145-155)
-    assert n_tab > 1000 and a[:n_tab] == b[:n_tab] and a[n_tab:n_tab + 16] == b[n_tab:n_tab + 16]   # + c, k; the file names differ
+    for inflate_device, marker in (("0", "gather"), ("1", "gzip inflated on the device")):
+        o = d / f"feed_bgzf_{inflate_device}"
+        p = subprocess.run([BIN, "sketch", "-1", str(d / "z_1.fq.gz"), "-2", str(d / "z_2.fq.gz"), "--fpr", "0", "-d", str(o)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, SYLPH_HIP_FEED_TRACE="1", SYLPH_HIP_INFLATE_DEVICE=inflate_device))
+        assert p.returncode == 0 and marker in p.stderr, p.stderr[-2000:]        # (the trace line of the indexed path / of the device's inflate)
+        a = (o / "z_1.fq.gz.paired.sylsp").read_bytes()
+        assert n_tab > 1000 and a[:n_tab] == b[:n_tab] and a[n_tab:n_tab + 16] == b[n_tab:n_tab + 16]   # + c, k; the file names differ
 
 
 def test_device_fastq_route_equals_the_host_feed(data):
@@ -618,3 +622,28 @@ def test_profile_over_several_gpus_equals_one_gpu(data):
         assert "replicated on 3 GPUs" in many.stderr
         assert one.stdout == many.stdout and len(one.stdout.strip().split("\n")) >= 6
         assert run(cmd, *gen, *raw, "--gpus", "all").stdout == one.stdout
+
+
+def test_sketch_over_several_gpus_equals_one_gpu(data):
+    """Round 6: `sylph-hip sketch --gpus N|all` — the samples' workers dealt to the GPUs (worker w on device w mod N, each with its own
+    context, page-locked batch and uploader; nothing exchanged: what the reference's rayon pool does with the machine's cores,
+    sketch.rs:313, :371).  The sketches must be the one-GPU sketches, byte for byte.  On the one-GPU box SYLPH_HIP_FAKE_GPUS=3 deals the
+    workers as for three GPUs and runs them all on device 0."""
+    d = data["dir"]
+    for i in range(5):
+        for m in ("1", "2"):
+            if not (d / f"mg{i}_{m}.fq").exists():
+                (d / f"mg{i}_{m}.fq").write_bytes((d / f"s_{m}.fq").read_bytes())
+    firsts = [d / f"mg{i}_1.fq" for i in range(5)]
+    seconds = [d / f"mg{i}_2.fq" for i in range(5)]
+    one = d / "mg_one"
+    run("sketch", "-1", *firsts, "-2", *seconds, "-r", d / "single.fastq.gz", "-t", "1", "-d", one)
+    many = d / "mg_many"
+    p = run("sketch", "-1", *firsts, "-2", *seconds, "-r", d / "single.fastq.gz", "-t", "2", "--gpus", "3", "-d", many, env_extra={"SYLPH_HIP_FAKE_GPUS": "3"})
+    assert "sketch worker 1 runs on GPU 1" in p.stderr and "sketch worker 2 runs on GPU 2" in p.stderr, p.stderr[-2000:]
+    a = {f.name: f.read_bytes() for f in sorted(one.iterdir())}
+    b = {f.name: f.read_bytes() for f in sorted(many.iterdir())}
+    assert a == b and len(a) == 6
+    allg = d / "mg_all"
+    run("sketch", "-1", *firsts, "-2", *seconds, "-r", d / "single.fastq.gz", "--gpus", "all", "-d", allg)
+    assert {f.name: f.read_bytes() for f in sorted(allg.iterdir())} == a

@@ -289,6 +289,9 @@ def test_one_sample_loop_over_several_replicas_of_the_database(ctx):
     rng, genomes, db_k, goff = small_world(23)
     db = S.Database(ctx, db_k, goff)
     ctx2, ctx3 = S.Context(0), S.Context(0)
+    # (the third replica by the long road: "fail_next_peer_copy" makes the copy into ctx3 find no device-to-device way — what two GPUs
+    #  without peer access would do — and the index travels through the library's page-locked chunk; round 6)
+    ctx3.set_option("fail_next_peer_copy", "1")
     reps = [db, db.replicate(ctx2), db.replicate(ctx3)]
     assert all(r.n_genomes == db.n_genomes and r.n_kmers == db.n_kmers for r in reps)
     samples = []

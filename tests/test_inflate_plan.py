@@ -39,12 +39,12 @@ def L():
 
 def model(L, gz, cap, ratio=16, slack=1024):
     out = C.create_string_buffer(max(cap, 1))
-    info = (C.c_uint64 * 4)()
+    info = (C.c_uint64 * 5)()
     err = C.create_string_buffer(256)
     n = L.ip_model_inflate(gz, len(gz), out, cap, info, ratio, slack, err, 256)
     if n < 0:
         return None, err.value.decode(), None
-    return out.raw[:n], "", dict(members=info[0], blocks=info[1], candidates=info[2], host_members=info[3])
+    return out.raw[:n], "", dict(members=info[0], blocks=info[1], candidates=info[2], host_members=info[3], redone=info[4])
 
 
 def gz_level(data, level, strategy=zlib.Z_DEFAULT_STRATEGY):
@@ -144,9 +144,11 @@ def test_model_road_declines_damage(L):
         bad = bytearray(gz)
         bad[at] ^= bit
         assert model(L, bytes(bad), cap)[0] is None, at
-    # a region too small for the block (here: a ratio no FASTQ block meets) is an overflow, and an overflow on the chain declines
-    got, why, _ = model(L, gz, cap, ratio=1, slack=0)
-    assert got is None and "status 20" in why
+    # a region too small for its block (here: a ratio no FASTQ block meets) is not damage: the block is decoded again with room for it
+    got, why, info = model(L, gz, cap, ratio=1, slack=0)
+    assert why == "" and got == text and info["redone"] == info["blocks"] >= 2
+    got, why, info = model(L, gz, cap)
+    assert got == text and info["redone"] == 0
 
 
 def test_reference_fasta_gz_through_the_model(L, golden_dir):
