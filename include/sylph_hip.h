@@ -237,6 +237,13 @@ void sylph_fastq_destroy(sylph_fastq *f);
  * were decoded a second time because their first region of memory was too small. */
 typedef struct sylph_inflated sylph_inflated;
 int sylph_inflate(sylph_ctx *ctx, const void *gz, uint64_t n_bytes, int mem, sylph_inflated **out);
+/* Several files in one call — the two mates of a pair (sketch.rs:771-782 opens both readers side by side): their bytes are taken as one
+ * stream of gzip members, decoded in one pass (the files share the latency of a deflate block's wavefront instead of paying it one after
+ * the other), and every file's text is a piece of the one text: sylph_inflated_file lends file i's pointer and length (each usable with
+ * sylph_fastq_index / SYLPH_MEM_DEVICE like sylph_inflated_text's).  All files or none: one that is declined declines the call. */
+int sylph_inflate_files(sylph_ctx *ctx, const void *const *gz, const uint64_t *n_bytes, uint32_t n_files, int mem,
+                        sylph_inflated **out);
+int sylph_inflated_file(const sylph_inflated *t, uint32_t i, const void **dev_text, uint64_t *n_bytes);
 int sylph_inflated_text(const sylph_inflated *t, const void **dev_text, uint64_t *n_bytes);
 int sylph_inflated_info(const sylph_inflated *t, uint64_t *n_members, uint64_t *n_blocks, uint64_t *n_candidates,
                         uint64_t *n_host_members, uint64_t *n_decoded_again);

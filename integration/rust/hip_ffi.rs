@@ -127,6 +127,9 @@ extern "C" {
     // round 6: gzip inflated on the device (what flate2 does inside parse_fastx_file, sketch.rs:780-781 / :906): compressed bytes in,
     // text in HBM out (hand the pointer to sylph_fastq_index with MEM_DEVICE); ERR_FORMAT = -5: keep the flate2 reader for this file
     pub fn sylph_inflate(ctx: *mut SylphCtx, gz: *const c_void, n_bytes: u64, mem: c_int, out: *mut *mut SylphInflated) -> c_int;
+    pub fn sylph_inflate_files(ctx: *mut SylphCtx, gz: *const *const c_void, n_bytes: *const u64, n_files: u32, mem: c_int,
+                               out: *mut *mut SylphInflated) -> c_int;   // the two mates of a pair in one pass
+    pub fn sylph_inflated_file(t: *const SylphInflated, i: u32, dev_text: *mut *const c_void, n_bytes: *mut u64) -> c_int;
     pub fn sylph_inflated_text(t: *const SylphInflated, dev_text: *mut *const c_void, n_bytes: *mut u64) -> c_int;
     pub fn sylph_inflated_info(t: *const SylphInflated, n_members: *mut u64, n_blocks: *mut u64, n_candidates: *mut u64,
                                n_host_members: *mut u64, n_decoded_again: *mut u64) -> c_int;

@@ -37,7 +37,7 @@ EXPORTS = ["sylph_version", "sylph_last_error", "sylph_free", "sylph_pinned_allo
            "sylph_db_replicate", "sylph_pipeline_create_multi", "sylph_pipeline_replica_of_last", "sylph_device_count",
            "sylph_genome_shard_bounds", "sylph_db_upload_genome_shard",
            "sylph_fastq_index", "sylph_fastq_counts", "sylph_fastq_lengths", "sylph_sketch_push_fastq", "sylph_fastq_destroy",
-           "sylph_inflate", "sylph_inflated_text", "sylph_inflated_info", "sylph_inflated_read", "sylph_inflated_destroy"]
+           "sylph_inflate", "sylph_inflate_files", "sylph_inflated_file", "sylph_inflated_text", "sylph_inflated_info", "sylph_inflated_read", "sylph_inflated_destroy"]
 
 
 def load():
@@ -81,6 +81,8 @@ def load():
     L.sylph_fastq_destroy.restype = None
     L.sylph_inflate.argtypes = [vp, vp, u64, i32, P(vp)]
     L.sylph_inflated_text.argtypes = [vp, P(vp), P(u64)]
+    L.sylph_inflate_files.argtypes = [vp, P(vp), P(u64), C.c_uint32, i32, P(vp)]
+    L.sylph_inflated_file.argtypes = [vp, C.c_uint32, P(vp), P(u64)]
     L.sylph_inflated_info.argtypes = [vp, P(u64), P(u64), P(u64), P(u64), P(u64)]
     L.sylph_inflated_read.argtypes = [vp, u64, u64, vp]
     L.sylph_inflated_destroy.argtypes = [vp]
@@ -279,11 +281,23 @@ class Inflated:
     with code ERR_FORMAT when the library declines the stream (not gzip, damaged, ...): inflate on the host then."""
 
     def __init__(self, ctx, gz):
+        """gz: the bytes of one file, or a list of them (sylph_inflate_files: one pass over all; .files[i] = (dev_ptr, n_bytes))"""
         self._h = None
-        keep = np.frombuffer(gz, dtype=np.uint8) if isinstance(gz, (bytes, bytearray, memoryview)) else _np(gz, np.uint8)
+        many = isinstance(gz, (list, tuple))
+        keeps = [np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray, memoryview)) else _np(g, np.uint8) for g in (gz if many else [gz])]
         h = C.c_void_p()
-        _check(load().sylph_inflate(ctx._h, _ptr(keep) if len(keep) else None, len(keep), MEM_HOST, C.byref(h)))
+        if many:
+            ptrs = (C.c_void_p * len(keeps))(*[k.ctypes.data for k in keeps])
+            lens = (C.c_uint64 * len(keeps))(*[len(k) for k in keeps])
+            _check(load().sylph_inflate_files(ctx._h, ptrs, lens, len(keeps), MEM_HOST, C.byref(h)))
+        else:
+            _check(load().sylph_inflate(ctx._h, _ptr(keeps[0]) if len(keeps[0]) else None, len(keeps[0]), MEM_HOST, C.byref(h)))
         self._h = h
+        self.files = []
+        for i in range(len(keeps)):
+            fp, fn = C.c_void_p(), C.c_uint64(0)
+            _check(load().sylph_inflated_file(self._h, i, C.byref(fp), C.byref(fn)))
+            self.files.append((int(fp.value or 0), int(fn.value)))
         p, n = C.c_void_p(), C.c_uint64(0)
         _check(load().sylph_inflated_text(self._h, C.byref(p), C.byref(n)))
         self.dev_ptr, self.n_bytes = int(p.value or 0), int(n.value)

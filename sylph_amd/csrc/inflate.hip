@@ -40,6 +40,7 @@ struct sylph_inflated {
     void* buf = nullptr;                  // hipMalloc'ed: 256 bytes of zero padding, the text, 256 bytes of zero padding
     uint64_t n = 0;
     uint64_t n_members = 0, n_blocks = 0, n_candidates = 0, n_host_members = 0, n_redone = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> files;   // [begin, end) of every file's text in the whole text
     const uint8_t* text() const { return (const uint8_t*)buf + 256; }
 };
 
@@ -979,14 +980,24 @@ bool zlib_member(const uint8_t* gz, size_t n, size_t p, size_t* end, std::vector
     return ok;
 }
 
-void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
+// Several files in one call are ONE stream of gzip members to everything below (`cat a.gz b.gz` is a gzip file): their bytes lie back
+// to back on the device, one scan, one decode launch, one chain — the two mates of a pair share the latency of a block's wavefront
+// (~15 ms whatever the file's size) instead of paying it one after the other.
+void inflate_impl(sylph_inflated* t, const void* const* gzs, const uint64_t* n_bytes, uint32_t n_files) {
     sylph_ctx* ctx = t->ctx;
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard dg(ctx->device);
     hipStream_t s = ctx->stream;
-    const size_t body0 = member_body(gz, n, 0);
-    if (!body0) throw FormatDecline{"not a gzip file"};
-    if (n >= (3ull << 30)) throw FormatDecline{"gzip file of 3 GiB or more: the host reader takes it"};
+    Segments segs;
+    segs.base.push_back(0);
+    for (uint32_t i = 0; i < n_files; i++) {
+        if (!member_body((const uint8_t*)gzs[i], (size_t)n_bytes[i], 0)) throw FormatDecline{"not a gzip file"};
+        segs.ptr.push_back((const uint8_t*)gzs[i]);
+        segs.base.push_back(segs.base.back() + (size_t)n_bytes[i]);
+    }
+    const uint64_t n = segs.total();
+    const size_t body0 = member_body(segs.ptr[0], (size_t)n_bytes[0], 0);
+    if (n >= (3ull << 30)) throw FormatDecline{"3 GiB of gzip bytes or more: the host reader takes them"};
     const uint64_t byte_end = n;                    // (trailers and later headers are scanned too: no harm, and members end anywhere)
     // ---- the compressed bytes, padded with zero words
     const uint64_t n_words = (n + 3) / 4;
@@ -996,7 +1007,7 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
     {
         HostPhase hp(ctx, "inflate: upload");
         SY_HIP(hipMemsetAsync(d_gz.as<uint8_t>() + (n & ~(uint64_t)3), 0, (n_words + GZ_PAD_WORDS) * 4 - (n & ~(uint64_t)3), s));
-        ctx->h2d(d_gz.p, gz, n);
+        for (uint32_t i = 0; i < n_files; i++) ctx->h2d(d_gz.as<uint8_t>() + segs.base[i], segs.ptr[i], (size_t)n_bytes[i]);
     }
     // ---- candidates
     const uint64_t cap1 = n / 8 + 4096, cap2 = n / 64 + 4096;
@@ -1083,9 +1094,11 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
     }
     // ---- the chain
     std::vector<std::vector<uint8_t>> host_bytes;
-    Chain chain = chain_walk(gz, (size_t)n, cand, res.data(), [&](size_t p, size_t* end, uint64_t* n_out) {
+    Chain chain = chain_walk(segs, cand, res.data(), [&](size_t p, size_t* end, uint64_t* n_out) {
         std::vector<uint8_t> o;
-        if (!zlib_member(gz, (size_t)n, p, end, o)) return false;
+        const size_t si = segs.find(p), gb = segs.base[si];
+        if (!zlib_member(segs.ptr[si], segs.base[si + 1] - gb, p - gb, end, o)) return false;
+        *end += gb;
         *n_out = o.size();
         if (!o.empty()) host_bytes.push_back(std::move(o));
         return true;
@@ -1098,6 +1111,13 @@ void inflate_impl(sylph_inflated* t, const uint8_t* gz, uint64_t n) {
     t->n_host_members = 0;
     for (const Member& m : chain.members) t->n_host_members += m.on_host;
     t->n = chain.total;
+    t->files.assign(n_files, {~0ull, 0});
+    for (const Member& m : chain.members) {                   // a file's text: from its first member's first byte to its last member's end
+        auto& f = t->files[m.file];
+        f.first = std::min<uint64_t>(f.first, m.out_begin);
+        f.second = std::max<uint64_t>(f.second, m.out_end);
+    }
+    for (auto& f : t->files) if (f.first == ~0ull) throw FormatDecline{"a file without a gzip member"};
     // ---- blocks of the chain that outgrew their region (BlockResult::flags bit 1): once more, each into a region of exactly its size
     Raw d_cells2;
     std::vector<uint64_t> redo_region(KB, ~0ull);
@@ -1230,8 +1250,9 @@ using namespace sylph;
 
 extern "C" {
 
-int sylph_inflate(sylph_ctx* ctx, const void* gz, uint64_t n_bytes, int mem, sylph_inflated** out) {
-    if (!ctx || !out || !gz) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+int sylph_inflate_files(sylph_ctx* ctx, const void* const* gz, const uint64_t* n_bytes, uint32_t n_files, int mem, sylph_inflated** out) {
+    if (!ctx || !out || !gz || !n_bytes || !n_files) { set_error("null argument"); return SYLPH_ERR_INVALID; }
+    for (uint32_t i = 0; i < n_files; i++) if (!gz[i]) { set_error("null argument"); return SYLPH_ERR_INVALID; }
     if (mem != SYLPH_MEM_HOST && mem != SYLPH_MEM_HOST_PINNED) { set_error("sylph_inflate: the compressed bytes must lie in host memory (mem kind %d)", mem); return SYLPH_ERR_INVALID; }
     *out = nullptr;
     ctx->refs.fetch_add(1);
@@ -1240,7 +1261,7 @@ int sylph_inflate(sylph_ctx* ctx, const void* gz, uint64_t n_bytes, int mem, syl
     const int rc = guarded([&] {
         t = new sylph_inflated();
         t->ctx = ctx;
-        try { inflate_impl(t, (const uint8_t*)gz, n_bytes); }
+        try { inflate_impl(t, gz, n_bytes, n_files); }
         catch (const FormatDecline& e) { set_error("sylph_inflate: declined: %s", e.msg.c_str()); format = 1; }
     });
     if (rc != SYLPH_OK || format) {
@@ -1260,6 +1281,17 @@ int sylph_inflate(sylph_ctx* ctx, const void* gz, uint64_t n_bytes, int mem, syl
         ctx->inflate_live++;
     }
     *out = t;
+    return SYLPH_OK;
+}
+
+int sylph_inflate(sylph_ctx* ctx, const void* gz, uint64_t n_bytes, int mem, sylph_inflated** out) {
+    return sylph_inflate_files(ctx, &gz, &n_bytes, 1, mem, out);
+}
+
+int sylph_inflated_file(const sylph_inflated* t, uint32_t i, const void** dev_text, uint64_t* n_bytes) {
+    if (!t || i >= t->files.size()) { set_error("sylph_inflated_file: no such file"); return SYLPH_ERR_INVALID; }
+    if (dev_text) *dev_text = t->text() + t->files[i].first;
+    if (n_bytes) *n_bytes = t->files[i].second - t->files[i].first;
     return SYLPH_OK;
 }
 

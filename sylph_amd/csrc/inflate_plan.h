@@ -143,6 +143,7 @@ struct Member {
     uint64_t out_begin, out_end;
     uint32_t crc, isize;      // from the trailer
     bool on_host;             // inflated and checked by zlib already: no device CRC needed
+    uint32_t file;            // which of the call's files it lies in
 };
 struct Chain {
     std::vector<ChainBlock> blocks;
@@ -152,19 +153,34 @@ struct Chain {
     std::string why;          // non-empty: the attempt is given up, and this is the reason
 };
 
+// The compressed bytes: one file, or several taken as ONE stream of gzip members (the two mates of a pair: a member never crosses from
+// one file into the next, so every header, trailer and small member is read inside one segment).
+struct Segments {
+    std::vector<const uint8_t*> ptr;
+    std::vector<size_t> base;                 // base[i] = offset of file i in the stream; base.back() = its total length
+    size_t total() const { return base.back(); }
+    size_t find(size_t pos) const { return (size_t)(std::upper_bound(base.begin(), base.end() - 1, pos) - base.begin()) - 1; }
+};
+inline Segments one_segment(const uint8_t* gz, size_t n) { return Segments{{gz}, {0, n}}; }
+
 // cand_bits: sorted, unique candidate start bits (the first member's first block is among them whatever its type);
-// res[i]: the report of candidate i;  region_cells[i]: what candidate i could write at most (n_out beyond it = ST_OVERFLOW anyway).
+// res[i]: the report of candidate i.
 // host_inflate(begin, &end, &n_out): inflate the member that starts at byte `begin` with the CPU (zlib), report where it ends
 // and how many bytes it gave; false = it cannot or will not (too large).  The caller keeps the bytes.
 template <class HostInflate>
-Chain chain_walk(const uint8_t* gz, size_t n, const std::vector<uint64_t>& cand_bits, const BlockResult* res, HostInflate&& host_inflate) {
+Chain chain_walk(const Segments& S, const std::vector<uint64_t>& cand_bits, const BlockResult* res, HostInflate&& host_inflate) {
     Chain c;
+    const size_t n = S.total();
     size_t p = 0;                                     // the current member starts at byte p
     while (true) {
-        const size_t body = member_body(gz, n, p);
-        if (!body) { c.why = "no gzip member header at byte " + std::to_string(p); return c; }
+        const size_t si = S.find(p);
+        const uint8_t* gz = S.ptr[si];
+        const size_t gb = S.base[si], gn = S.base[si + 1] - gb;
+        const size_t body_local = member_body(gz, gn, p - gb);
+        if (!body_local) { c.why = "no gzip member header at byte " + std::to_string(p); return c; }
+        const size_t body = body_local + gb;
         const uint32_t m = (uint32_t)c.members.size();
-        Member mem{c.total, c.total, 0, 0, false};
+        Member mem{c.total, c.total, 0, 0, false, (uint32_t)si};
         uint64_t bit = (uint64_t)body * 8;
         size_t trailer = 0;
         auto it = std::lower_bound(cand_bits.begin(), cand_bits.end(), bit);
@@ -194,8 +210,8 @@ Chain chain_walk(const uint8_t* gz, size_t n, const std::vector<uint64_t>& cand_
                 it = std::lower_bound(it, cand_bits.end(), bit);
                 if (it == cand_bits.end() || *it != bit) { c.why = "chain breaks at bit " + std::to_string(bit) + " (no candidate starts there)"; return c; }
             }
-            if (trailer + 8 > n) { c.why = "member trailer beyond the end of the file"; return c; }
-            const uint8_t* t = gz + trailer;
+            if (trailer + 8 > gb + gn) { c.why = "member trailer beyond the end of the file"; return c; }
+            const uint8_t* t = gz + (trailer - gb);
             mem.crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
             mem.isize = t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
             mem.out_end = c.total;
@@ -204,10 +220,10 @@ Chain chain_walk(const uint8_t* gz, size_t n, const std::vector<uint64_t>& cand_
             p = trailer + 8;
         }
         if (p == n) return c;
-        if (p > n) { c.why = "member runs past the end of the file"; return c; }
+        if (p > gb + gn) { c.why = "member runs past the end of the file"; return c; }
         // bytes behind a member that are no further member: zlib's gzread treats them as garbage to ignore only after at least one
         // member — needletail (flate2 MultiGzDecoder) errors; either way not this road's business
-        if (!member_body(gz, n, p)) { c.why = "trailing bytes behind the last member"; return c; }
+        if (p < gb + gn && !member_body(gz, gn, p - gb)) { c.why = "trailing bytes behind the last member"; return c; }
     }
 }
 

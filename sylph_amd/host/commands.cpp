@@ -430,20 +430,28 @@ bool sketch_fastq_on_device(Engine& e, const std::function<sylph_sketch*()>& ope
     std::vector<std::string> files{f1};
     if (f2) files.push_back(*f2);
     std::vector<TextUploader::Text> texts;
-    InflatedText inflated[2];                        // (destroyed behind the indexes that borrow their text: declared before them)
+    InflatedText inflated;                           // (destroyed behind the indexes that borrow its text: declared before them)
     if (gz) {
-        for (size_t i = 0; i < files.size(); i++) {
-            MappedFile m(files[i]);
-            if (!m.data) return false;
-            const int rc = sylph_inflate(ctx, m.data, m.size, SYLPH_MEM_HOST, &inflated[i].h);
-            if (rc == SYLPH_ERR_FORMAT || rc == SYLPH_ERR_NOMEM) {
-                if (trace) fprintf(stderr, "[sylph_hip feed] device inflate declined %s: %s\n", files[i].c_str(), sylph_last_error());
-                return false;
-            }
-            hip_check(rc, "sylph_inflate");
+        // both mates in ONE call (sylph_inflate_files): one scan, one decode launch, one chain — the mates share a block's latency
+        std::vector<std::unique_ptr<MappedFile>> maps;
+        std::vector<const void*> ptrs;
+        std::vector<uint64_t> lens;
+        for (const auto& f : files) {
+            maps.emplace_back(new MappedFile(f));
+            if (!maps.back()->data) return false;
+            ptrs.push_back(maps.back()->data);
+            lens.push_back(maps.back()->size);
+        }
+        const int rc = sylph_inflate_files(ctx, ptrs.data(), lens.data(), (uint32_t)ptrs.size(), SYLPH_MEM_HOST, &inflated.h);
+        if (rc == SYLPH_ERR_FORMAT || rc == SYLPH_ERR_NOMEM) {
+            if (trace) fprintf(stderr, "[sylph_hip feed] device inflate declined %s: %s\n", files[0].c_str(), sylph_last_error());
+            return false;
+        }
+        hip_check(rc, "sylph_inflate_files");
+        for (uint32_t i = 0; i < ptrs.size(); i++) {
             const void* dev = nullptr;
             uint64_t bytes = 0;
-            hip_check(sylph_inflated_text(inflated[i].h, &dev, &bytes), "sylph_inflated_text");
+            hip_check(sylph_inflated_file(inflated.h, i, &dev, &bytes), "sylph_inflated_file");
             if (!bytes) return false;
             texts.push_back(TextUploader::Text{(const uint8_t*)dev, bytes});
         }

@@ -216,7 +216,7 @@ long long ip_model_inflate(const uint8_t* gz, uint64_t n, uint8_t* out, uint64_t
         res[k] = model_decode(gz, (size_t)n, cand[k], k != 0, (size_t)((next_byte - (cand[k] >> 3)) * ratio + slack), cells[k]);
     }
     std::vector<std::vector<uint8_t>> host_bytes;
-    Chain c = chain_walk(gz, (size_t)n, cand, res.data(), [&](size_t p, size_t* end, uint64_t* n_out) {
+    Chain c = chain_walk(one_segment(gz, (size_t)n), cand, res.data(), [&](size_t p, size_t* end, uint64_t* n_out) {
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
         if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;

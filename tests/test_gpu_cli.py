@@ -492,7 +492,7 @@ def test_device_fastq_route_equals_the_host_feed(data):
         if dev == "1":
             assert "device route: pushed" in p.stderr, p.stderr[-3000:]
             # round 6: the two gzip pairs (single-member, blocked) send their COMPRESSED bytes; the device inflates (csrc/inflate.hip)
-            assert p.stderr.count("device route: gzip inflated on the device") == 2, p.stderr[-3000:]
+            assert p.stderr.count("device route: gzip inflated on the device") == 2, p.stderr[-3000:]   # (one line per sample: both mates in one call)
         else:
             assert "device route" not in p.stderr
     # ... and with the device's inflate switched off the host inflates and the TEXT travels, as in round 5: the same files

@@ -114,13 +114,16 @@ def test_blocks_that_outgrow_their_region_are_decoded_again(ctx, monkeypatch):
     """A header-like bit pattern INSIDE a block (one in ~4,000 blocks of bench.py's FASTQ file has one) cuts the block's region short; so
     does a block that deflates better than 16:1.  Such a block runs dry — decoded to its end for its length alone — and is decoded
     again into a region of exactly that size.  Here: every block, by giving the regions one cell per compressed byte."""
-    text = fastq_text(np.random.default_rng(23), 40000)
+    text = fastq_text(np.random.default_rng(23), 150000)
     gz = gz_level(text, 6)
     monkeypatch.setenv("SYLPH_HIP_INFLATE_REGION_RATIO", "1")
+    # (a block that outgrows its region first moves to one of the 96 regions of the spill arena; the blocks that find it empty run dry)
     info = check(ctx, gz, text)
-    assert info["again"] == info["blocks"] >= 10
+    assert info["blocks"] >= 130 and info["blocks"] - 97 <= info["again"] < info["blocks"]
     info = check(ctx, bgzf_compress(text), text)
-    assert info["again"] >= info["blocks"] // 2
+    assert info["blocks"] - 97 <= info["again"] < info["blocks"]
+    small = fastq_text(np.random.default_rng(24), 20000)
+    assert check(ctx, gz_level(small, 6), small)["again"] == 0      # few blocks: the arena takes them all
     monkeypatch.delenv("SYLPH_HIP_INFLATE_REGION_RATIO")
     assert check(ctx, gz, text)["again"] == 0
 
@@ -140,6 +143,26 @@ def test_members_and_bgzf(ctx):
     co = zlib.compressobj(6, zlib.DEFLATED, -15)
     body = co.compress(a) + co.flush()
     check(ctx, hdr + body + struct.pack("<II", zlib.crc32(a), len(a)), a)
+
+
+def test_several_files_in_one_call(ctx):
+    """sylph_inflate_files: the two mates of a pair (any files) taken as one stream of gzip members — one scan, one decode launch — and
+    every file's text a piece of the one text, each usable by the FASTQ index where it lies."""
+    rng = np.random.default_rng(29)
+    a, b, c = fastq_text(rng, 20000), fastq_text(rng, 21000, read_len=(50, 151)), fastq_text(rng, 300)
+    gzs = [gz_level(a, 6), gz_level(b, 1), bgzf_compress(c)]
+    t = S.Inflated(ctx, gzs)
+    assert t.n_bytes == len(a) + len(b) + len(c) and [n for _, n in t.files] == [len(a), len(b), len(c)]
+    assert t.read().tobytes() == a + b + c
+    assert t.files[1][0] == t.files[0][0] + len(a) and t.files[2][0] == t.files[1][0] + len(b)
+    for (ptr, n), text in zip(t.files, (a, b, c)):
+        fq, plain = S.FastqText(ctx, ptr, MEM_DEVICE, n), S.FastqText(ctx, text)
+        assert fq.n_records == plain.n_records and fq.n_bases == plain.n_bases and np.array_equal(fq.lengths(), plain.lengths())
+        fq.close(); plain.close()
+    t.close()
+    with pytest.raises(SylphHipError) as e:                         # all files or none
+        S.Inflated(ctx, [gzs[0], gzs[1][:-9]])
+    assert e.value.code == ERR_FORMAT
 
 
 def test_libdeflate_streams(ctx):
