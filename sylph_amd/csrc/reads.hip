@@ -166,7 +166,7 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
     // HV == 2: the loop tests hi(h) only (kmer_step) and yields a SUPERSET of the k-mers below the threshold — about 3 in 2^32 k-mers
     // too many; the survivors' pass, which hashes every candidate exactly anyway, strikes those from the hit masks and the pass's
     // bookkeeping is redone once (s_redo).  cand_slack widens the superset on purpose: the tests' way of making that road common.
-    __shared__ uint32_t s_redo;
+    __shared__ uint32_t s_redo, s_redo_deal;
     const uint64_t thr_loop = HV == 2 ? (uint64_t)((uint32_t)(thr >> 32) + 1u + cand_slack) : thr;
     if (tid == 0) s_redo = 0;                                        // (ordered before its first reader by the barriers below)
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the
@@ -243,16 +243,36 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
             if (tid < 64) s_hist[tid] = 0;
             s_rel[tid] = rel;
             s_nh[tid] = (uint16_t)nh;
+#ifndef SYLPH_READS_ALWAYS_DEAL
+            // Round 6 (VERDICT r05 #4a): whether the pass needs dealing at all is asked FIRST — one compare with the first record's count and
+            // one LDS word — and a pass of equally long records (every pass of an untrimmed 2 x 150 bp sample) skips the histogram: its 256
+            // atomic adds all went to ONE counter (the LDS serialises them), then a scan and a barrier, to find that nothing moves.
+            if (tid == 0) s_redo_deal = 0;
+            __syncthreads();
+            if (__ballot(nh != (uint32_t)s_nh[0]) && lane == 0) s_redo_deal = 1;
+            __syncthreads();
+            const bool dealt = s_redo_deal != 0;                       // uniform over the workgroup
+            const uint32_t bin = 63u - ((nh + 7) >> 3);              // nh <= RH - 20: at most 48 half-groups
+            uint32_t hg_max = (nh + 7) >> 3, arrival = 0, hc = 0;
+            if (dealt) {
+                arrival = atomicAdd(&s_hist[bin], 1u);
+                __syncthreads();
+                hc = s_hist[lane];
+                // the longest record of the pass (uniform over the workgroup: every wavefront reads the same histogram): its lowest
+                // non-empty bin; the mask rows above its words are free in this pass (see the survivors' list below)
+                const uint64_t bins_used = __ballot(hc != 0u);
+                hg_max = bins_used ? 63u - (uint32_t)(__ffsll((unsigned long long)bins_used) - 1) : 0u;   // half-groups of 8 k-mers
+            }
+#else
             __syncthreads();
             const uint32_t bin = 63u - ((nh + 7) >> 3);              // nh <= RH - 20: at most 48 half-groups
             const uint32_t arrival = atomicAdd(&s_hist[bin], 1u);
             __syncthreads();
             const uint32_t hc = s_hist[lane];
             const bool dealt = s_hist[bin] != (uint32_t)RTPB;         // uniform over the workgroup
-            // the longest record of the pass (uniform over the workgroup: every wavefront reads the same histogram): its lowest
-            // non-empty bin; the mask rows above its words are free in this pass (see the survivors' list below)
             const uint64_t bins_used = __ballot(hc != 0u);
             const uint32_t hg_max = bins_used ? 63u - (uint32_t)(__ffsll((unsigned long long)bins_used) - 1) : 0u;   // half-groups of 8 k-mers
+#endif
             const uint32_t rows_used = min((uint32_t)MASKW, (hg_max * 8u + 31u) >> 5);
             if (dealt) {
                 const uint32_t incl = wave_inclusive_sum(hc);
@@ -405,7 +425,11 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                 if (o < slot_cap) {
                     const uint64_t ft = win64(sF, s_rel[lo] + i);
                     const uint64_t fk = ft >> (64 - 2 * K), rk = revcomp_top<K>(ft);
+#ifndef SYLPH_READS_COOP_PLAIN_HASH
+                    const uint64_t h = mm_hash64_gfx950(fk < rk ? fk : rk);      // (round 6, VERDICT r05 #4d: the spelling the loop uses — v_lshl_add_u64, v_bitop3)
+#else
                     const uint64_t h = mm_hash64(fk < rk ? fk : rk);
+#endif
                     if constexpr (HV == 2) {
                         if (h >= thr) {                                          // not a hit after all: out of its record's mask
                             atomicAnd(&s_mask[i >> 5][lo], ~(0x80000000u >> (i & 31u)));
