@@ -405,6 +405,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SYLPH_BENCH_WORKLOAD", "auto"), choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--db-mode", default=os.environ.get("SYLPH_BENCH_DB_MODE", "auto"), choices=["auto", "replicate", "shard", "genome", "genome-py"])
+    ap.add_argument("--shard-reduce", default=os.environ.get("SYLPH_BENCH_SHARD_REDUCE", "alltoall"), choices=["alltoall", "allgather"],
+                    help="sharded databases (--db-mode shard | genome): how the hits reach the rank that owns the sample — all-to-all (default), or ONE all-gather "
+                         "of padded blocks (north_star's wording; csrc/shard_plan.h plan_hits_gather)")
     ap.add_argument("--mode", default=os.environ.get("SYLPH_BENCH_MODE", "auto"), choices=["auto", "pipelined", "sequential"],
                     help="which way of running the samples `value` is taken from (auto: the faster one of the untimed calibration)")
     ap.add_argument("--min-seconds", type=float, default=float(os.environ.get("SYLPH_BENCH_MIN_SECONDS", "2.0")),
@@ -479,6 +482,7 @@ def main():
     tstream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(tstream)
     ctx = S.Context(local, stream=tstream.cuda_stream)
+    ctx.set_option("shard_reduce", args.shard_reduce)
     ctx_options = [kv.split("=", 1) for kv in filter(None, os.environ.get("SYLPH_BENCH_CTX_OPTIONS", "").split(","))]   # tuning experiments only
     for kv in ctx_options:
         ctx.set_option(*kv)
@@ -892,6 +896,7 @@ def main():
                    "dedup": ("none applies (reads > 400 bp, sketch.rs:922-927)" if long_mode else
                              f"the pair set behind the model of sylph's cuckoo filter, --fpr {args.main_dedup_fpr} (profiling run)" if args.main_dedup_fpr else "exact (--fpr 0 semantics)"),
                    "seed_mode": "avx2_compat", "parallelism": parallelism,
+                   "db_mode": db_mode if world > 1 else "one GPU (whole index)", **({"shard_reduce": args.shard_reduce} if comm is not None else {}),
                    "inputs": "reads + database resident in HBM before the timed region",
                    "rng": "splitmix64 counter streams (synth.py: every random number = one word of a stream addressed by its index, integer arithmetic "
                           "only; host float tables for the abundances / decoy lengths), read set seed 20250711 + 1000003*(rank+1) + 7919*set"},

@@ -94,7 +94,10 @@ void sylph_upload_destroy(sylph_upload *u);
  * "bucket" (error instead of falling back).  "seeds" = "auto" (default: the read-per-lane kernel for short-read batches, the
  * position kernel with per-tile ordered slots otherwise), "slots" (always the position kernel with ordered slots) or
  * "unordered" (position kernel with LDS-staged atomics + radix sort by position).  "bucket_target" = mean number of
- * occurrences per replay bucket aimed for, "16".."256".  "index_lambda" = postings per 64-byte bucket line of a database
+ * occurrences per replay bucket aimed for, "16".."256".  "shard_reduce" = "alltoall" (default) or "allgather": how the hits of a
+ * sharded batch (sylph_db_contain_batch_sharded) reach the rank that owns the sample — one all-to-all of exactly the hits each rank
+ * needs, or ONE all-gather of every rank's whole hit buffer padded to the longest (W x the bytes, one collective; set on the database's
+ * context, or through sylph_pipeline_set_option).  "index_lambda" = postings per 64-byte bucket line of a database
  * index aimed for ("1".."8", default 4 — 29 GB at GTDB-R220 scale, 3 was 38.5 GB for 3 % less probe time; applies to databases uploaded afterwards), "index_pass_max" = postings sorted per pass
  * of the index build (tests lower it to force several passes), "push_chunk_bytes" = bytes of bases per chunk of a host batch
  * (default 64 MiB), "reads_wg_per_cu" = workgroups of the read-per-lane kernel per CU, each looping over blocks of reads

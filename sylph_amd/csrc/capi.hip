@@ -408,6 +408,10 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             ctx->bucket_target = (uint32_t)v;
         } else if (!strcmp(key, "plain_records")) {
             ctx->plain_records = (uint32_t)strtol(value, nullptr, 10) ? 1u : 0u;   // A/B knob: 0 = occurrence records for every batch
+        } else if (!strcmp(key, "shard_reduce")) {
+            if (!strcmp(value, "alltoall")) ctx->shard_reduce = 0;
+            else if (!strcmp(value, "allgather")) ctx->shard_reduce = 1;
+            else SY_REQUIRE(false, "shard_reduce must be alltoall|allgather");
         } else if (!strcmp(key, "fail_next_peer_copy")) {
             ctx->fail_next_peer_copy = (uint32_t)strtol(value, nullptr, 10);     // tests only: sylph_db_replicate into this context takes the host road
         } else if (!strcmp(key, "fail_next_shard_probe")) {

@@ -143,6 +143,7 @@ struct sylph_ctx {
     int finish_mode = 0;                    // 0 auto, 1 generic, 2 bucket-only (sylph_ctx_set_option "finish")
     uint32_t bucket_target = 128;           // mean occurrences per replay bucket aimed for ("bucket_target")
     uint32_t plain_records = 1;             // marker-less single-end batches keep no occurrence records ("plain_records" = 0: always write them)
+    uint32_t shard_reduce = 0;              // "shard_reduce": 0 = the sharded batch's hits travel by all-to-all (default), 1 = by ONE all-gather (north_star's wording; shard_plan.h plan_hits_gather)
     uint32_t fail_next_peer_copy = 0;       // fault injection for the tests ("fail_next_peer_copy"): the next sylph_db_replicate INTO this context finds no device-to-device road
     uint32_t fail_next_shard_probe = 0;     // fault injection for the tests ("fail_next_shard_probe"): the next sharded probe on this context throws
     uint32_t index_lambda = 0;              // 0 = the default for the line size (contain_index.h DEFAULT_INDEX_LAMBDA: 4 per 64-byte line); postings per bucket line of a database index aimed for ("index_lambda"; r04: 3 -> 4, 38.5 -> 29.1 GB at GTDB scale for +3 % probe time alone)

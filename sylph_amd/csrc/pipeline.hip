@@ -556,6 +556,7 @@ int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* va
             return SYLPH_OK;
         }
     }
+    if (!strcmp(key, "shard_reduce")) return sylph_ctx_set_option(p->db->ctx, key, value);      // (the database's context only: "alltoall" | "allgather")
     if (!strcmp(key, "dedup_fpr") || !strcmp(key, "dedup_capacity")) {      // for the sessions opened from now on (checked by the session)
         std::lock_guard<std::mutex> lk(p->mu);
         (key[6] == 'f' ? p->dedup_fpr : p->dedup_capacity) = value;
@@ -565,7 +566,7 @@ int sylph_pipeline_set_option(sylph_pipeline* p, const char* key, const char* va
         const int rc = sylph_ctx_set_option(cx, key, value);
         if (rc != SYLPH_OK) return rc;
     }
-    if (!strcmp(key, "profile_only")) return sylph_ctx_set_option(p->db->ctx, key, value);   // the profile thread's timers live there
+    if (!strcmp(key, "profile_only") || !strcmp(key, "shard_reduce")) return sylph_ctx_set_option(p->db->ctx, key, value);   // the profile thread's timers / the sharded batch's reduction live there
     return SYLPH_OK;
 }
 

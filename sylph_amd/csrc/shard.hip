@@ -452,11 +452,22 @@ uint32_t sylph::contain_batch_sharded_impl(sylph_db* db, sylph_comm* comm, const
         }
         const uint32_t n_mine = (uint32_t)(hr_off[W] / 8);
         db->hits.reserve((size_t)std::max<uint32_t>(n_mine, 1) * 8);      // (the scatter above has been queued: stream order keeps it safe)
-        {
+        if (ctx->shard_reduce == 0) {
             ScopedKernelTimer t(ctx, "exchange");
             comm->all_to_all(db->x_send.p, hs_off.data(), db->hits.p, hr_off.data(), st);
+            db->x_hit_bytes += hs_off[W] - (hs_off[me + 1] - hs_off[me]);
+        } else {
+            // "shard_reduce" = "allgather" (round 6): every rank's whole grouped buffer, padded to the longest, to every rank in ONE
+            // all-gather; this rank keeps its group from each (shard_plan.h plan_hits_gather: the all-to-all's receive layout)
+            ScopedKernelTimer t(ctx, "exchange");
+            const shardplan::GatherPlan gp = shardplan::plan_hits_gather(sizes.data(), W, me);
+            db->x_send.grow_keep(gp.pad_bytes + 64, hs_off[W], st);      // (the scatter filled hs_off[W] bytes: padded up, contents kept)
+            db->x_recv.reserve((size_t)W * gp.pad_bytes + 64);
+            if (gp.pad_bytes) comm->all_gather(db->x_send.p, db->x_recv.p, gp.pad_bytes, st);
+            for (uint32_t r = 0; r < W; r++)
+                if (gp.len[r]) SY_HIP(hipMemcpyAsync((char*)db->hits.p + hr_off[r], (const char*)db->x_recv.p + gp.src_off[r], gp.len[r], hipMemcpyDeviceToDevice, st));
+            db->x_hit_bytes += (uint64_t)(W - 1) * gp.pad_bytes;
         }
-        db->x_hit_bytes += hs_off[W] - (hs_off[me + 1] - hs_off[me]);
         ph.reset(); ph.reset(new HostPhase(ctx, "shard 6: sort + assemble + copy out"));
         // ---- 6. sort + assemble this rank's samples
         finish_hits(db, n_mine, max_mine, (uint64_t)n_local * G, cov_width, false, dst);

@@ -4,6 +4,7 @@
 // world sizes 2 and 3, so the arithmetic that has never met more than one physical GPU is at least exercised rank against rank.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -150,6 +151,27 @@ inline HitPlan plan_hits(const uint32_t* sizes, uint32_t W, uint32_t me) {
     }
     p.n_mine = p.recv_off[W] / 8;
     return p;
+}
+// Step 5 as ONE ALL-GATHER instead of an all-to-all (round 6; north_star's wording: "per-shard containment counts reduced by a single
+// RCCL all-gather"): every rank contributes its WHOLE grouped hit buffer, padded to the longest one (pad_bytes), every rank receives
+// all W of them and keeps the group meant for it from each: piece r lies at src_off[r] of the gathered buffer (block r + the groups for
+// the ranks in front of me), is len[r] bytes long and goes to recv_off[r] of the hit list — the layout the all-to-all would have
+// produced.  W x more bytes on the links than the all-to-all (every rank receives what was meant for the others too); one collective
+// call, no point-to-point schedule.  A/B-able: sylph_ctx_set_option(ctx, "shard_reduce", "allgather").
+struct GatherPlan { uint64_t pad_bytes = 0; std::vector<uint64_t> src_off, len; };
+inline GatherPlan plan_hits_gather(const uint32_t* sizes, uint32_t W, uint32_t me) {
+    GatherPlan g;
+    const uint32_t SZ = size_words(W);
+    for (uint32_t r = 0; r < W; r++) g.pad_bytes = std::max<uint64_t>(g.pad_bytes, (uint64_t)sizes[(size_t)r * SZ + W + 2] * 8);
+    g.src_off.assign(W, 0);
+    g.len.assign(W, 0);
+    for (uint32_t r = 0; r < W; r++) {
+        uint64_t before = 0;
+        for (uint32_t d = 0; d < me; d++) before += sizes[(size_t)r * SZ + d];
+        g.src_off[r] = (uint64_t)r * g.pad_bytes + before * 8;
+        g.len[r] = (uint64_t)sizes[(size_t)r * SZ + me] * 8;
+    }
+    return g;
 }
 // a hit (row << 32 | count) with row = global sample * n_genomes + genome, re-based to its owner's samples
 SY_PLAN_HD uint64_t rebase_hit(uint64_t hit, uint64_t owner_first_sample, uint64_t n_genomes) { return hit - ((owner_first_sample * n_genomes) << 32); }

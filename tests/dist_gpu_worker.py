@@ -36,6 +36,7 @@ def main():
     goff[1:] = np.cumsum([len(g) for g in genomes])
     G = len(genomes)
     ctx = S.Context(0)
+    ctx.set_option("shard_reduce", os.environ.get("SYLPH_TEST_SHARD_REDUCE", "alltoall"))   # round 6: the hits by all-to-all, or by ONE all-gather
     if os.environ.get("SYLPH_TEST_SHARD_BY", "kmer") == "genome":       # round 5: the cut by genome (north_star's wording), same exchange
         gb = SH.genome_shard_bounds(goff, world)
         db = S.Database(ctx, full, goff, genome_shard=(gb, world, rank))

@@ -48,4 +48,10 @@ int sp_plan_hits(const uint32_t* sizes, uint32_t W, uint32_t me, uint64_t* send_
     *n_mine = p.n_mine;
     return 0;
 }
+void sp_plan_hits_gather(const uint32_t* sizes, uint32_t W, uint32_t me, uint64_t* pad_bytes, uint64_t* src_off, uint64_t* len) {
+    const GatherPlan g = plan_hits_gather(sizes, W, me);
+    *pad_bytes = g.pad_bytes;
+    memcpy(src_off, g.src_off.data(), W * 8);
+    memcpy(len, g.len.data(), W * 8);
+}
 }

@@ -133,6 +133,8 @@ def _plan_lib():
     L.sp_slice_begin.restype = C.c_uint64
     L.sp_slice_begin.argtypes = [u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.sp_genome_bounds.argtypes = [u64p, C.c_uint64, C.c_uint32, u64p]
+    L.sp_plan_hits_gather.argtypes = [u32p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u64p, u64p]
+    L.sp_plan_hits_gather.restype = None
     return L
 
 
@@ -146,7 +148,7 @@ def _p32(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
-def library_plan_exchange(dist, L, bounds, G, samples, probe_fn, fail=False):
+def library_plan_exchange(dist, L, bounds, G, samples, probe_fn, fail=False, reduce="alltoall"):
     """sylph_db_contain_batch_sharded's steps on host arrays, EVERY offset, owner and size taken from csrc/shard_plan.h (through
     tests/shard_plan_capi.cpp) exactly as shard.hip takes them; byte buffers laid out as the device buffers are; the collectives are
     gloo's.  -> (contain_count[n_local, G], covs) or the (rank, class) of the agreed failure."""
@@ -225,10 +227,27 @@ def library_plan_exchange(dist, L, bounds, G, samples, probe_fn, fail=False):
     for h, r in zip(hits, owners):
         out[cur[r]] = L.sp_rebase(int(h), int(prefix[r]), G)
         cur[r] += 1
-    groups = [out[int(hs_off[r]) // 8:int(hs_off[r + 1]) // 8].tobytes() for r in range(W)]
-    allg = [None] * W
-    dist.all_gather_object(allg, groups)
-    mine = np.frombuffer(b"".join(allg[r][me] for r in range(W)), dtype=np.uint64)
+    if reduce == "alltoall":
+        groups = [out[int(hs_off[r]) // 8:int(hs_off[r + 1]) // 8].tobytes() for r in range(W)]
+        allg = [None] * W
+        dist.all_gather_object(allg, groups)
+        mine = np.frombuffer(b"".join(allg[r][me] for r in range(W)), dtype=np.uint64)
+    else:
+        # "shard_reduce" = "allgather": every rank's WHOLE grouped buffer, padded to the longest, to every rank in ONE all-gather of equal
+        # blocks (a real tensor collective here, as RCCL's would be); my group of each block where shard_plan.h's plan_hits_gather says
+        pad, src_off, ln = C.c_uint64(0), np.zeros(W, dtype=np.uint64), np.zeros(W, dtype=np.uint64)
+        L.sp_plan_hits_gather(_p32(allsizes), W, me, C.byref(pad), _p64(src_off), _p64(ln))
+        block = np.full(int(pad.value), 0xEE, dtype=np.uint8)                 # (the padding is never read)
+        block[:len(out) * 8] = out.view(np.uint8)
+        got = [torch.zeros(int(pad.value), dtype=torch.uint8) for _ in range(W)]
+        if pad.value:
+            dist.all_gather(got, torch.from_numpy(block))
+        gathered = np.concatenate([g.numpy() for g in got]) if pad.value else np.zeros(0, dtype=np.uint8)
+        mine_b = np.zeros(int(hr_off[W]), dtype=np.uint8)
+        for r in range(W):
+            mine_b[int(hr_off[r]):int(hr_off[r]) + int(ln[r])] = gathered[int(src_off[r]):int(src_off[r]) + int(ln[r])]
+            assert int(ln[r]) == int(hr_off[r + 1]) - int(hr_off[r])
+        mine = mine_b.view(np.uint64)
     assert len(mine) == int(n_mine.value) == int(hr_off[W]) // 8
     assert (int((mine & np.uint64(0xFFFFFFFF)).max()) if len(mine) else 0) <= int(max_mine.value)
     # 6. assemble
@@ -259,11 +278,12 @@ def _plan_worker(rank, world, port, ret):
         ok = True
         for step, sizes in enumerate(([2, 3, 0], [0, 1, 4], [1, 1, 1])):     # three batches of different shapes, an empty rank, an empty table
             samples = make_samples(pool, rank + 3 * step, sizes[rank]) if step else make_samples(pool, rank, sizes[rank])
-            cc, covs = library_plan_exchange(dist, L, bounds, G, samples, probe)
-            ok = ok and cc.shape == (len(samples), G)
-            for s, (k, c) in enumerate(samples):
-                ecc, ecov, _ = O.contain(k, c, db, goff)
-                ok = ok and np.array_equal(cc[s], ecc) and all(np.array_equal(covs[s][g], np.sort(ecov[g])) for g in range(G))
+            for reduce in ("alltoall", "allgather"):          # (round 6: the hits by all-to-all, and by ONE all-gather of padded blocks)
+                cc, covs = library_plan_exchange(dist, L, bounds, G, samples, probe, reduce=reduce)
+                ok = ok and cc.shape == (len(samples), G)
+                for s, (k, c) in enumerate(samples):
+                    ecc, ecov, _ = O.contain(k, c, db, goff)
+                    ok = ok and np.array_equal(cc[s], ecc) and all(np.array_equal(covs[s][g], np.sort(ecov[g])) for g in range(G))
         # a rank that fails between the collectives: every rank must come out with the same (rank, class)
         res = library_plan_exchange(dist, L, bounds, G, make_samples(pool, rank, 1), probe, fail=(rank == world - 1))
         ok = ok and res == ("failed", world - 1, 1)
@@ -315,11 +335,12 @@ def _genome_plan_worker(rank, world, port, ret):
         bounds[0] = 0
         for step, sizes in enumerate(([2, 3, 0], [0, 1, 4], [1, 1, 1])):
             samples = make_samples(pool, rank + 3 * step, sizes[rank]) if step else make_samples(pool, rank, sizes[rank])
-            cc, covs = library_plan_exchange(dist, L, bounds, G, samples, probe)
-            ok = ok and cc.shape == (len(samples), G)
-            for s, (k, c) in enumerate(samples):
-                ecc, ecov, _ = O.contain(k, c, db, goff)
-                ok = ok and np.array_equal(cc[s], ecc) and all(np.array_equal(covs[s][g], np.sort(ecov[g])) for g in range(G))
+            for reduce in ("alltoall", "allgather"):          # north_star's shape: whole genomes per rank AND one all-gather of the answers
+                cc, covs = library_plan_exchange(dist, L, bounds, G, samples, probe, reduce=reduce)
+                ok = ok and cc.shape == (len(samples), G)
+                for s, (k, c) in enumerate(samples):
+                    ecc, ecov, _ = O.contain(k, c, db, goff)
+                    ok = ok and np.array_equal(cc[s], ecc) and all(np.array_equal(covs[s][g], np.sort(ecov[g])) for g in range(G))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

@@ -1033,18 +1033,20 @@ def test_packed_input_and_chunked_host_pipeline(ctx):
         ctx.set_option("push_chunk_bytes", str(64 << 20))
 
 
-@pytest.mark.parametrize("shard_by", ["kmer", "genome"])
+@pytest.mark.parametrize("shard_by", ["kmer", "genome", "genome-allgather"])
 def test_sharded_containment_two_ranks_one_gpu(shard_by):
     """Two ranks (gloo rendezvous, both on cuda:0) run the library's sharded exchange (csrc/shard.hip) with the collectives routed
     through torch.distributed callbacks, each with its own shard resident on the GPU — cut by k-mer range, or (round 5) by genome:
     sylph_db_upload_genome_shard, every table probed whole by every rank — and check their own samples against the oracle over the
-    whole database; a rank that fails between the collectives takes every rank out of the call."""
+    whole database; a rank that fails between the collectives takes every rank out of the call.  "genome-allgather" (round 6): north_star's
+    literal shape — whole genomes per rank and the answers reduced by ONE all-gather (ctx option "shard_reduce" = "allgather")."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533" if shard_by == "kmer" else "29537", os.path.join(root, "tests", "dist_gpu_worker.py")]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, SYLPH_TEST_SHARD_BY=shard_by))
+           "--master-port", {"kmer": "29533", "genome": "29537"}.get(shard_by, "29541"), os.path.join(root, "tests", "dist_gpu_worker.py")]
+    env = dict(os.environ, SYLPH_TEST_SHARD_BY=shard_by.split("-")[0], SYLPH_TEST_SHARD_REDUCE="allgather" if shard_by.endswith("allgather") else "alltoall")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 

@@ -5,7 +5,8 @@
 # reader's.  What each mode exercises for the first time on real hardware:
 #   replicate   bench.py --db-mode replicate   one rank per GPU, every rank a whole index, no data-path collective (the default)
 #   shard       bench.py --db-mode shard       k-mer-range shards, RCCL all-to-all of table slices + all-to-all of hits (csrc/shard.hip)
-#   genome      bench.py --db-mode genome      north_star's cut: whole genomes per rank, sample tables all-gathered, hits to the owner
+#   genome      bench.py --db-mode genome      north_star's cut: whole genomes per rank, sample tables all-gathered, hits to the owner by all-to-all
+#   genome-allgather   + --shard-reduce allgather: the hits by ONE all-gather of padded blocks (north_star's literal wording) — the A/B of the two reductions
 #   router      tools/multi_gpu_pipeline_bench.py   ONE process, index copied device to device over xGMI (hipMemcpyPeer), one sample loop
 #   cli         sylph-hip sketch --gpus N / profile --gpus N on files (tools/feed_bench.py's shapes)
 # Usage: bash tools/first_node.sh [steps] [warmup]          (from the repository root; ~10 minutes on 8 GPUs)
@@ -21,12 +22,13 @@ python -m pytest tests -m gpu -x -q -k "dist or rccl or replicas or several_gpus
 PORT=29611
 for N in 1 2 4 8; do
   [ "$N" -le "$NGPU" ] || continue
-  for MODE in replicate shard genome; do
+  for MODE in replicate shard genome genome-allgather; do
     [ "$N" -eq 1 ] && [ "$MODE" != replicate ] && continue
     PORT=$((PORT + 1))
     if [ "$N" -eq 1 ]; then CMD="python bench.py --gpus 1"; else CMD="python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $N"; fi
     echo "[first_node] $MODE, $N GPU(s)"
-    timeout 1500 $CMD --steps "$STEPS" --warmup "$WARMUP" --db-mode "$MODE" --no-cpu-baseline --no-files-leg --no-h2d --no-packed-leg 2> "$OUT/bench_${MODE}_$N.err" | tail -1 >> "$OUT/SCALE_$MODE.jsonl" \
+    RED=alltoall; DBM=$MODE; [ "$MODE" = genome-allgather ] && { RED=allgather; DBM=genome; }
+    timeout 1500 $CMD --steps "$STEPS" --warmup "$WARMUP" --db-mode "$DBM" --shard-reduce "$RED" --no-cpu-baseline --no-files-leg --no-h2d --no-packed-leg 2> "$OUT/bench_${MODE}_$N.err" | tail -1 >> "$OUT/SCALE_$MODE.jsonl" \
       || echo "{\"n_gpus\": $N, \"mode\": \"$MODE\", \"error\": \"see bench_${MODE}_$N.err\"}" >> "$OUT/SCALE_$MODE.jsonl"
   done
   echo "[first_node] router (one process), $N GPU(s)"
