@@ -236,7 +236,6 @@ void sylph::ctx_unref(sylph_ctx* ctx) {
     ctx->tmp_sort.release();
     ctx->counters.release();
     for (auto& b : ctx->scratch) b.release();
-    if (ctx->inflate_scratch && ctx->inflate_scratch_free) ctx->inflate_scratch_free(ctx->inflate_scratch);
     for (auto& b : ctx->pool_free) (void)hipFree(b.second);
     ctx->pool_free.clear();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

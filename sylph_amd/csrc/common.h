@@ -176,11 +176,6 @@ struct sylph_ctx {
     sylph::DevBuf tmp_sort;                 // rocPRIM temporary storage
     sylph::DevBuf scratch[8];
     sylph::DevBuf counters;                 // small device words (survivor counters etc.)
-    // csrc/inflate.hip: the scratch of sylph_inflate (compressed bytes, cells, window functions: GBs) stays allocated between calls while
-    // an inflated text of this context is alive — the two mates of a pair share it — and is freed with the last of them (free_fn)
-    void* inflate_scratch = nullptr;
-    void (*inflate_scratch_free)(void*) = nullptr;
-    uint32_t inflate_live = 0;
     void* pinned = nullptr;                 // 4 KiB pinned host page for small read-backs
     // small synchronous device->host read through the pinned page (pageable D2H copies are staged and slow)
     void read_back(void* dst, const void* dev_src, size_t bytes);

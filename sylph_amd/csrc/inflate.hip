@@ -945,21 +945,22 @@ struct Raw {                            // plain hipMalloc / hipFree: GBs of scr
     void reserve(size_t bytes) { if (bytes > cap) alloc(bytes + bytes / 8); }      // contents are not kept
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
-// What a call needs beside the text it returns.  Kept by the context between calls while one of its inflated texts is alive (the two
-// mates of a pair, one call after the other: the second finds 7 GB of buffers in place), freed with the last of them.
-struct InflateScratch { Raw gz, c1, c2, cnt, cells, res, jobs, plan, sfn, ffn, rwin, mend, x2n, raw; };
-InflateScratch& scratch_of(sylph_ctx* ctx) {
-    if (!ctx->inflate_scratch) {
-        ctx->inflate_scratch = new InflateScratch();
-        ctx->inflate_scratch_free = [](void* p) { delete static_cast<InflateScratch*>(p); };
-    }
-    return *static_cast<InflateScratch*>(ctx->inflate_scratch);
-}
-void scratch_drop(sylph_ctx* ctx) {          // (under the context's lock, its stream idle)
-    if (ctx->inflate_scratch && ctx->inflate_live == 0) {
-        delete static_cast<InflateScratch*>(ctx->inflate_scratch);
-        ctx->inflate_scratch = nullptr;
-    }
+// What a call needs beside the text it returns: 16 x 2 B of cells per compressed byte and 64 KB per block — 13 GB for a 1 Gbp pair.
+// ONE set per device and PROCESS, whichever context calls (the calls of a device take turns: a decode launch fills the chip anyway), kept
+// between calls: allocating and freeing it per sample cost nothing on an idle box and, sporadically, a SECOND per sample beside another
+// process that holds HBM (bench.py's own situation: profiles/r06_gz_e2e_trace.txt, "hold") — and a set per context would multiply it by
+// the 16 engines of a `profile`.  A set that grew beyond SCRATCH_KEEP (an unusually large file) is freed behind its call.
+constexpr size_t SCRATCH_KEEP = 20ull << 30;
+struct InflateScratch {
+    Raw gz, c1, c2, cnt, cells, res, jobs, plan, sfn, ffn, rwin, mend, x2n, raw;
+    size_t bytes() const { return gz.cap + c1.cap + c2.cap + cnt.cap + cells.cap + res.cap + jobs.cap + plan.cap + sfn.cap + ffn.cap + rwin.cap + mend.cap + x2n.cap + raw.cap; }
+    void release() { for (Raw* r : {&gz, &c1, &c2, &cnt, &cells, &res, &jobs, &plan, &sfn, &ffn, &rwin, &mend, &x2n, &raw}) r->release(); }
+};
+constexpr int MAX_DEVICES = 64;
+struct DeviceScratch { std::mutex mu; InflateScratch s; };
+DeviceScratch& device_scratch(int device) {
+    static DeviceScratch* all = new DeviceScratch[MAX_DEVICES];      // (never destroyed: the process's HIP runtime may be gone by then)
+    return all[std::min(std::max(device, 0), MAX_DEVICES - 1)];
 }
 
 // a small member through zlib (gzip wrapper: zlib checks CRC and ISIZE itself)
@@ -1001,7 +1002,11 @@ void inflate_impl(sylph_inflated* t, const void* const* gzs, const uint64_t* n_b
     const uint64_t byte_end = n;                    // (trailers and later headers are scanned too: no harm, and members end anywhere)
     // ---- the compressed bytes, padded with zero words
     const uint64_t n_words = (n + 3) / 4;
-    InflateScratch& S = scratch_of(ctx);
+    DeviceScratch& DS = device_scratch(ctx->device);
+    std::lock_guard<std::mutex> turn(DS.mu);                       // one inflate per device at a time: they share the scratch
+    InflateScratch& S = DS.s;
+    // (on every way out — a decline included — the stream is idle before the next call may touch the scratch; destroyed before `turn`)
+    struct Done { InflateScratch& s; hipStream_t st; ~Done() { (void)hipStreamSynchronize(st); if (s.bytes() > SCRATCH_KEEP) s.release(); } } done{S, s};
     Raw& d_gz = S.gz;
     d_gz.reserve((n_words + GZ_PAD_WORDS) * 4);
     {
@@ -1271,14 +1276,9 @@ int sylph_inflate_files(sylph_ctx* ctx, const void* const* gz, const uint64_t* n
             (void)hipStreamSynchronize(ctx->stream);
             if (t && t->buf) (void)hipFree(t->buf);
             delete t;
-            scratch_drop(ctx);
         }
         ctx_unref(ctx);
         return rc != SYLPH_OK ? rc : SYLPH_ERR_FORMAT;
-    }
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        ctx->inflate_live++;
     }
     *out = t;
     return SYLPH_OK;
@@ -1334,8 +1334,6 @@ void sylph_inflated_destroy(sylph_inflated* t) {
         (void)hipStreamSynchronize(ctx->stream);       // kernels that read the text may still be queued
         if (t->buf) (void)hipFree(t->buf);
         delete t;
-        if (ctx->inflate_live) ctx->inflate_live--;
-        scratch_drop(ctx);
     }
     ctx_unref(ctx);
 }
