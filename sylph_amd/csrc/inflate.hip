@@ -1051,7 +1051,22 @@ void inflate_impl(sylph_inflated* t, const void* const* gzs, const uint64_t* n_b
     // ---- decode every candidate
     // (SYLPH_HIP_INFLATE_REGION_RATIO: the tests' way to make every block outgrow its region)
     const char* rr_env = getenv("SYLPH_HIP_INFLATE_REGION_RATIO");
-    const uint64_t region_ratio = rr_env ? std::max(1, std::min(64, atoi(rr_env))) : REGION_RATIO;
+    // A single-member file says how well it deflates (ISIZE in its trailer): its blocks get 1.5 x that + 1 cells per compressed byte instead
+    // of the flat REGION_RATIO (bench.py's mate file: 5.3 -> 9: 7 GB of cells for a 1 Gbp pair instead of 12.7) — less to allocate, and less
+    // for the process to hand back when it ends.  Several members (BGZF ends with an empty one), a wrapped ISIZE: the flat ratio.
+    uint64_t auto_ratio = REGION_RATIO;
+    {
+        double worst = 0;
+        bool known = true;
+        for (uint32_t i = 0; i < n_files && known; i++) {
+            const uint8_t* tr = segs.ptr[i] + n_bytes[i] - 4;
+            const double isize = (double)(tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24), r = isize / (double)n_bytes[i];
+            if (r < 1.5 || r > 40) known = false;
+            worst = std::max(worst, r);
+        }
+        if (known) auto_ratio = std::min<uint64_t>(REGION_RATIO, (uint64_t)(worst * 1.5) + 2);
+    }
+    const uint64_t region_ratio = rr_env ? std::max(1, std::min(64, atoi(rr_env))) : auto_ratio;
     const uint64_t n_cells = (byte_end - body0) * region_ratio + (uint64_t)K * REGION_SLACK + 64;
     Raw &d_cells = S.cells, &d_res = S.res, &d_jobs = S.jobs;
     const uint64_t spill_base = (n_cells + 63) & ~(uint64_t)63;
