@@ -2,6 +2,8 @@
 #include <algorithm>
 #include <memory>
 
+#include <thread>
+
 #include "common.h"
 
 namespace sylph {
@@ -156,6 +158,27 @@ void sylph_ctx::d2h(void* dst, const void* dev_src, size_t bytes) {
     if (!pending.empty()) sylph::profile_collect(this);
 }
 
+// A staging copy of 32 MiB on ONE thread runs at 10-20 GB/s out of the page cache — under what the link takes: four threads for the large ones
+// (round 6: the 400 MB of a gzip pair's compressed bytes travelled in 16-19 ms; the helpers are only started for chunks of 8 MiB and more).
+static void stage_copy(void* dst, const void* src, size_t n) {
+    constexpr int T = 4;
+    if (n < (8u << 20)) { memcpy(dst, src, n); return; }
+    const size_t per = ((n / T) + 4095) & ~(size_t)4095;
+    std::thread helpers[T - 1];
+    int started = 0;
+    try {
+        for (int t = 1; t < T; t++) {
+            const size_t a = (size_t)t * per;
+            if (a >= n) break;
+            helpers[started] = std::thread([=] { memcpy((char*)dst + a, (const char*)src + a, std::min(per, n - a)); });
+            started++;
+        }
+    } catch (...) {}                                            // (no thread to be had: the rest of the chunk on this one)
+    memcpy(dst, src, std::min(per, n));
+    for (int t = started + 1; t < T; t++) { const size_t a = (size_t)t * per; if (a < n) memcpy((char*)dst + a, (const char*)src + a, std::min(per, n - a)); }
+    for (int t = 0; t < started; t++) helpers[t].join();
+}
+
 void sylph_ctx::h2d(void* dev_dst, const void* src, size_t bytes) {
     if (!bytes) return;
     ensure_stage(this);
@@ -165,7 +188,7 @@ void sylph_ctx::h2d(void* dev_dst, const void* src, size_t bytes) {
     while (done < bytes) {
         const size_t n = std::min(STAGE_BYTES, bytes - done);
         if (used[slot]) SY_HIP(hipEventSynchronize(stage_ev[slot]));   // previous copy out of this buffer finished
-        memcpy(stage[slot], (const char*)src + done, n);
+        stage_copy(stage[slot], (const char*)src + done, n);
         SY_HIP(hipMemcpyAsync((char*)dev_dst + done, stage[slot], n, hipMemcpyHostToDevice, stream));
         SY_HIP(hipEventRecord(stage_ev[slot], stream));
         used[slot] = true;

@@ -584,42 +584,50 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                 n_sym++;
                 uint32_t taken = 0;
                 const uint64_t p = b.position();
-                if (p + 192 <= limit_bits) {
-                    // lane j: 64 bits of the stream from bit p + j
+                if (p + 256 <= limit_bits) {
+                    // lane j: the symbols that would start at bit p + j and at bit p + 64 + j (a window of 128 bit positions per step: the
+                    // LDS round trips of a step are what it costs, and both positions' look-ups travel together)
                     const uint64_t pj = p + lane;
                     const uint32_t wj = (uint32_t)(pj >> 5), sj = (uint32_t)pj & 31;
-                    const uint32_t d0 = T.stream[wj & 255], d1 = T.stream[(wj + 1) & 255], d2 = T.stream[(wj + 2) & 255];
-                    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sj), x1 = __builtin_amdgcn_alignbit(d2, d1, sj);
-                    const uint32_t e1 = T.lit[x0 & ((1u << LIT_ROOT) - 1)];
-                    const uint32_t l1 = e1 & 15, sy = e1 >> 4;
-                    const bool is_lit = sy < 256, is_eob = sy == 256, is_len = sy > 256;
-                    // (a length code's extra bits and distance: computed by every lane, kept by the lanes that saw one — no branch on the lane)
-                    const uint32_t ls = is_len ? sy - 257 : 0;
-                    const uint32_t leb = ls < 8 || ls >= 28 ? 0u : (ls - 4) >> 2;
-                    const uint32_t lbase = ls < 8 ? 3 + ls : ls >= 28 ? 258u : 3 + ((4 + (ls & 3)) << leb);
-                    const uint64_t x = ((uint64_t)x1 << 32 | x0) >> l1;
-                    const uint32_t len = lbase + ((uint32_t)x & ((1u << leb) - 1));
-                    const uint32_t y = (uint32_t)(x >> leb);
-                    const uint32_t e2 = T.dist[y & ((1u << DIST_ROOT) - 1)];
-                    const uint32_t l2 = e2 & 15, dsy = e2 >> 4;
-                    const uint32_t deb = dsy < 4 ? 0u : min((dsy - 2) >> 1, 13u);
-                    const uint32_t dbase = dsy < 4 ? 1 + dsy : 1 + ((2 + (dsy & 1)) << deb);
-                    const bool bad = e1 == T_LONG || e1 == 0 || sy > 285 || (is_len && (e2 == T_LONG || e2 == 0 || dsy >= 30 || len > 64));
-                    const uint32_t bits = is_len ? l1 + leb + l2 + deb : l1;
-                    const uint32_t cells = is_len ? len : is_lit ? 1u : 0u;
-                    // what a cell needs of its symbol, in one word: first cell (7 bits, filled in by the walk) | cells << 7 | literal << 14 |
-                    // (the literal's byte, or the distance) << 15
-                    const uint32_t about = cells << 7 | (is_lit ? 1u << 14 : 0u) | (is_lit ? sy : dbase + ((y >> l2) & ((1u << deb) - 1))) << 15;
-                    // the chain of symbol starts, from lane 0; owner of cell c = the last walked symbol whose first cell is <= c
-                    // (what the walk asks of a start, in one word per lane: bits | cells << 6 | end-of-block << 13 | not-for-this-step << 14)
-                    const uint32_t walk = bits | cells << 6 | (is_eob ? 1u << 13 : 0u) | (bad ? 1u << 14 : 0u);
-                    uint32_t pos = 0, total = 0, owner = 0, first_cell = 0;
-                    while (pos < 64) {
-                        const uint32_t w1 = __builtin_amdgcn_readlane(walk, pos);
+                    const uint32_t d0 = T.stream[wj & 255], d1 = T.stream[(wj + 1) & 255], d2 = T.stream[(wj + 2) & 255], d3 = T.stream[(wj + 3) & 255],
+                                   d4 = T.stream[(wj + 4) & 255];
+                    const uint32_t xa0 = __builtin_amdgcn_alignbit(d1, d0, sj), xa1 = __builtin_amdgcn_alignbit(d2, d1, sj);
+                    const uint32_t xb0 = __builtin_amdgcn_alignbit(d3, d2, sj), xb1 = __builtin_amdgcn_alignbit(d4, d3, sj);
+                    const uint32_t ea1 = T.lit[xa0 & ((1u << LIT_ROOT) - 1)], eb1 = T.lit[xb0 & ((1u << LIT_ROOT) - 1)];
+                    // -> walk word (bits | cells << 6 | end-of-block << 13 | not-for-this-step << 14) and what a cell needs of its symbol
+                    //    (cells << 7 | literal << 14 | (the literal's byte, or the distance) << 15; the first cell's 7 bits come from the walk)
+                    auto decode_at = [&](uint32_t x0, uint32_t x1, uint32_t e1, uint32_t& walk, uint32_t& about) {
+                        const uint32_t l1 = e1 & 15, sy = e1 >> 4;
+                        const bool is_lit = sy < 256, is_eob = sy == 256, is_len = sy > 256;
+                        // (a length code's extra bits and distance: computed by every lane, kept by the lanes that saw one — no branch on the lane)
+                        const uint32_t ls = is_len ? sy - 257 : 0;
+                        const uint32_t leb = ls < 8 || ls >= 28 ? 0u : (ls - 4) >> 2;
+                        const uint32_t lbase = ls < 8 ? 3 + ls : ls >= 28 ? 258u : 3 + ((4 + (ls & 3)) << leb);
+                        const uint64_t x = ((uint64_t)x1 << 32 | x0) >> l1;
+                        const uint32_t len = lbase + ((uint32_t)x & ((1u << leb) - 1));
+                        const uint32_t y = (uint32_t)(x >> leb);
+                        const uint32_t e2 = T.dist[y & ((1u << DIST_ROOT) - 1)];
+                        const uint32_t l2 = e2 & 15, dsy = e2 >> 4;
+                        const uint32_t deb = dsy < 4 ? 0u : min((dsy - 2) >> 1, 13u);
+                        const uint32_t dbase = dsy < 4 ? 1 + dsy : 1 + ((2 + (dsy & 1)) << deb);
+                        const bool bad = e1 == T_LONG || e1 == 0 || sy > 285 || (is_len && (e2 == T_LONG || e2 == 0 || dsy >= 30 || len > 64));
+                        const uint32_t bits = is_len ? l1 + leb + l2 + deb : l1;
+                        const uint32_t cells = is_len ? len : is_lit ? 1u : 0u;
+                        about = cells << 7 | (is_lit ? 1u << 14 : 0u) | (is_lit ? sy : dbase + ((y >> l2) & ((1u << deb) - 1))) << 15;
+                        walk = bits | cells << 6 | (is_eob ? 1u << 13 : 0u) | (bad ? 1u << 14 : 0u);
+                    };
+                    uint32_t walk_a, about_a, walk_b, about_b;
+                    decode_at(xa0, xa1, ea1, walk_a, about_a);
+                    decode_at(xb0, xb1, eb1, walk_b, about_b);
+                    // the chain of symbol starts, from position 0; owner of cell c = the last walked symbol whose first cell is <= c
+                    uint32_t pos = 0, total = 0, owner = 0, first_a = 0, first_b = 0;
+                    while (pos < 128) {
+                        const uint32_t w1 = pos < 64 ? __builtin_amdgcn_readlane(walk_a, pos) : __builtin_amdgcn_readlane(walk_b, pos - 64);
                         const uint32_t c = (w1 >> 6) & 127;
                         if ((w1 >> 14) || total + c > 64) break;
                         owner = lane >= total ? pos : owner;
-                        first_cell = lane == pos ? total : first_cell;
+                        first_a = lane == pos ? total : first_a;
+                        first_b = lane + 64 == pos ? total : first_b;
                         total += c;
                         taken++;
                         pos += w1 & 63;
@@ -627,7 +635,8 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t* __restrict__
                     }
                     if (taken) {
                         if (!o.room(total)) { status = ST_OVERFLOW; break; }
-                        const uint32_t mine_about = __shfl(about | first_cell, owner);
+                        const uint32_t from_a = __shfl(about_a | first_a, owner & 63), from_b = __shfl(about_b | first_b, owner & 63);
+                        const uint32_t mine_about = owner < 64 ? from_a : from_b;
                         const uint32_t my_first = mine_about & 127, my_len = (mine_about >> 7) & 127, my_val = mine_about >> 15;
                         const bool mine = lane < total, my_lit = (mine_about >> 14 & 1) != 0;
                         const uint32_t i = lane - my_first;                  // my cell's index in its symbol; my_val: its distance
