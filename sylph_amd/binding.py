@@ -20,6 +20,8 @@ class SylphHipError(RuntimeError):
 
 
 def lib_path():
+    if os.environ.get("SYLPH_HIP_LIBRARY"):           # A/B builds of the same ABI (tools/build_variant.sh)
+        return os.path.abspath(os.environ["SYLPH_HIP_LIBRARY"])
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsylph_hip.so")
 
 

@@ -433,6 +433,173 @@ __global__ __launch_bounds__(RES_TPB) void a10_resolve_kernel(const uint64_t* __
     }
 }
 
+// ---- one partition level (round 6) ------------------------------------------------------------------------------------------
+// The fine level above costs a read and a write of every word (part_fine) before the resolve kernel reads them a third time.
+// Here the words stay where part_scatter left them, grouped by coarse range (~8,000 words), and the words that share their upper half
+// with another one are found WITHOUT sorting them.  The upper halves are uniform over the range, so `(upper half - lowest of the
+// range) x slots / width` is a direct-mapped slot of a bit table in LDS:
+//   pass 1  every word sets its slot's bit; a word that finds it set is a SECOND ARRIVAL (every duplicate but one of each group, and by
+//           chance words / 2 slots = 1.5 % of the rest): its upper half goes into a small open-addressing set;
+//   pass 2  every word asks the set for its upper half: the ones found are the candidates (all words with an equal upper half — true
+//           duplicates and the filter's cross-item collisions — plus the chance arrivals), ~7 % of the words;
+//   then    candidates fetch their record, compute the exact class key and their place in the walk, and meet in a table of {class key,
+//           earliest place} that overlays the bit table (64-bit LDS compare-and-swap + minimum); the ones that are not the earliest
+//           of their class set RID_A10_BIT.
+// `split` workgroups share a range: each reads all of its words and keeps the ones whose slot falls into its part of the slot space
+// (2^17 slots per workgroup) — twice the reads, from L2, for half the LDS.  The footprint is what decides in the pipeline: the next
+// samples' seeding kernels keep every CU full (5 workgroups x ~30 KB of LDS), and a kernel of this pass gets a workgroup in only
+// where one of theirs retires.  Measured (profiles/r06_ab_a10.txt): 1024 threads + 68 KB per workgroup was 60 us faster than round 5's
+// two levels alone on the GPU and 2 % SLOWER in the pipeline; 256 threads + 48 KB 2 % faster; holding the words in registers between
+// the passes (112 VGPRs) slower again.
+// A workgroup with more second arrivals or candidates than its lists take (heavily duplicated samples) cuts its part into P slices,
+// resolved one after the other (equal classes share a slot); a slice that is still too full — ~a thousand copies of one item —
+// bumps the verdict word as the two-level pass does.
+constexpr uint32_t RNG_SLOT_BITS = 17, RNG_SLOTS = 1u << RNG_SLOT_BITS;     // per workgroup, one bit each: 16 KB
+constexpr uint32_t RNG_CAND = 512, RNG_TAB = 1024, RNG_TAB_BITS = 10;       // candidates per slice, table entries (both tables)
+constexpr uint32_t RNG_WORDS = 8192;                                       // words per range aimed for
+constexpr uint32_t RNG_FREE = 0xFFFFFFFFu;
+static_assert(RNG_TAB * 16 <= RNG_SLOTS / 8 && RNG_TAB == 1u << RNG_TAB_BITS, "the class table overlays the bits");
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void a10_range_kernel(const uint64_t* __restrict__ words, const uint32_t* __restrict__ cbase, uint32_t C, uint32_t mult,
+                                                        uint32_t slot_mult, uint32_t split, Filter d, OccRec* __restrict__ recs, uint32_t* __restrict__ tail) {
+    constexpr int Q = RNG_CAND / TPB, U = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[RNG_SLOTS / 32];
+    __shared__ uint32_t s_sec[RNG_CAND], s_up[RNG_TAB], s_list[RNG_CAND];
+    __shared__ uint32_t s_n[2];
+    const uint32_t tid = threadIdx.x, c = blockIdx.x / split, part = blockIdx.x % split, lane = tid & 63;
+    const uint32_t lo = cbase[c], hi = cbase[c + 1];
+    if (blockIdx.x == 0 && tid == 0) tail[1] = cbase[C];      // operations found
+    if (hi == lo) return;
+    const uint32_t lo_key = (uint32_t)((((uint64_t)c << 32) + mult - 1u) / mult);      // smallest upper half of the range
+    const uint32_t all_slots = split << RNG_SLOT_BITS;
+    unsigned long long* const t_key = reinterpret_cast<unsigned long long*>(s_bits);              // [RNG_TAB] class keys (~0: free)
+    unsigned long long* const t_min = reinterpret_cast<unsigned long long*>(s_bits) + RNG_TAB;    // [RNG_TAB] earliest place of the class
+    // appends v for the lanes with `take` to list[0 .. RNG_CAND) behind *counter (one LDS atomic per wavefront); every lane calls
+    auto append = [&](bool take, uint32_t v, uint32_t* list, uint32_t* counter) {
+        const uint64_t m = __ballot(take);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        if (take) {
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (at < RNG_CAND) list[at] = v;
+        }
+    };
+    // body(valid, word) for every word of the range, U loads in flight per lane; every lane calls body the same number of times (ballots)
+    auto for_words = [&](auto&& body) {
+        for (uint32_t e0 = lo; e0 < hi; e0 += U * TPB) {
+            uint64_t w[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const uint32_t e = e0 + u * TPB + tid; w[u] = e < hi ? words[e] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < U; u++) body(e0 + u * TPB + tid < hi, w[u]);
+        }
+    };
+    uint32_t P = 1;
+    // slot of a word in this workgroup's table, or RNG_FREE: another workgroup's (or another slice's) word
+    auto my_slot = [&](uint32_t res, uint32_t p) {
+        const uint32_t s = min(slot_mult ? __umulhi(res, slot_mult) : res, all_slots - 1u);
+        if ((s >> RNG_SLOT_BITS) != part) return RNG_FREE;
+        const uint32_t l = s & (RNG_SLOTS - 1u);
+        return (P == 1 || (uint32_t)(((uint64_t)l * P) >> RNG_SLOT_BITS) == p) ? l : RNG_FREE;
+    };
+    for (uint32_t p = 0; p < P; p++) {
+        for (uint32_t i = tid; i < RNG_SLOTS / 32; i += TPB) s_bits[i] = 0;
+        for (uint32_t i = tid; i < RNG_TAB; i += TPB) s_up[i] = RNG_FREE;
+        if (tid < 2) s_n[tid] = 0;
+        __syncthreads();
+        for_words([&](bool valid, uint64_t w) {
+            bool second = false;
+            const uint32_t res = min((uint32_t)(w >> 32) - lo_key, RNG_FREE - 1u);
+            if (valid) {
+                const uint32_t l = my_slot(res, p);
+                if (l != RNG_FREE) {
+                    const uint32_t bit = 1u << (l & 31u);
+                    second = atomicOr(&s_bits[l >> 5], bit) & bit;
+                }
+            }
+            append(second, res, s_sec, &s_n[0]);
+        });
+        __syncthreads();
+        const uint32_t n_sec = s_n[0];
+        bool over = n_sec > RNG_CAND;
+        uint32_t n_over = n_sec * 2u;
+        if (!over) {
+            for (uint32_t i = tid; i < n_sec; i += TPB) {
+                const uint32_t res = s_sec[i];
+                uint32_t at = (res * 0x9E3779B1u) >> (32 - RNG_TAB_BITS);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&s_up[at], RNG_FREE, res);
+                    if (old == RNG_FREE || old == res) break;
+                    at = (at + 1u) & (RNG_TAB - 1u);
+                }
+            }
+            __syncthreads();
+            for_words([&](bool valid, uint64_t w) {
+                bool cand = false;
+                if (valid) {
+                    const uint32_t res = min((uint32_t)(w >> 32) - lo_key, RNG_FREE - 1u);
+                    if (my_slot(res, p) != RNG_FREE) {
+                        uint32_t at = (res * 0x9E3779B1u) >> (32 - RNG_TAB_BITS);
+                        for (;;) {
+                            const uint32_t v = s_up[at];
+                            if (v == res) { cand = true; break; }
+                            if (v == RNG_FREE) break;
+                            at = (at + 1u) & (RNG_TAB - 1u);
+                        }
+                    }
+                }
+                append(cand, (uint32_t)w, s_list, &s_n[1]);
+            });
+            __syncthreads();
+            over = s_n[1] > RNG_CAND;
+            n_over = s_n[1];
+        }
+        if (over) {
+            if (P == 1) {                                                  // slices of about a quarter of the lists, from the top
+                P = min((n_over + RNG_CAND / 4 - 1) / (RNG_CAND / 4), 4096u);
+                p = ~0u;                                                   // (p++ makes it 0)
+                __syncthreads();
+                continue;
+            }
+            if (tid == 0) atomicAdd(&tail[0], 1u);                         // a slice fuller than the lists: the walk takes the sample
+            return;
+        }
+        const uint32_t nc = s_n[1];
+        for (uint32_t i = tid; i < RNG_TAB; i += TPB) { t_key[i] = ~0ull; t_min[i] = ~0ull; }
+        __syncthreads();
+        uint64_t key[Q];
+        uint32_t opid[Q], at[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const uint32_t i = tid + q * TPB;
+            key[q] = 0; opid[q] = 0; at[q] = 0;
+            if (i < nc) {
+                opid[q] = s_list[i];
+                const OccRec r = recs[opid[q] >> 1];
+                const uint64_t g = reduced_key(d, item_hash(r.hash, (opid[q] & 1u) ? r.m1 : r.m0));      // < 2^63: never the ~0 of a free entry
+                key[q] = op_key(r.rid, opid[q] & 1u);
+                at[q] = (uint32_t)((g * GOLD) >> 40) & (RNG_TAB - 1u);
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&t_key[at[q]], ~0ull, (unsigned long long)g);
+                    if (old == ~0ull || old == g) break;
+                    at[q] = (at[q] + 1u) & (RNG_TAB - 1u);
+                }
+                atomicMin(&t_min[at[q]], (unsigned long long)key[q]);
+            }
+        }
+        __syncthreads();
+        // (the two operations of an occurrence may both be contained, from two workgroups: the OR commutes; readers of the rid in
+        //  this kernel look at its record and rank bits only)
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            if (tid + q * TPB < nc && t_min[at[q]] < key[q])
+                atomicOr(reinterpret_cast<uint32_t*>(&recs[opid[q] >> 1].rid) + 1, (uint32_t)(RID_A10_BIT >> 32));
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 static Filter filter_geometry(const sylph_sketch* sk, int j) {
@@ -464,10 +631,12 @@ static void a10_mark_partitioned(sylph_sketch* sk) {
     DevBuf b_ops(ctx), b_pairs(ctx), b_sorted(ctx), b_hist(ctx), b_boff(ctx);
     b_ops.reserve(n_slots * 16);
     b_pairs.reserve(n_slots * 16);
-    b_sorted.reserve(n_slots * 16);
     const Filter f0 = filter_geometry(sk, 0);
     // buckets: equal ranges of the words' upper 32 bits, ~bucket_target operations each
-    const uint32_t B = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2 * n_expect / ctx->bucket_target), 1u << 24);
+    static const int env_levels = [] { const char* e = getenv("SYLPH_HIP_A10_LEVELS"); return e ? atoi(e) : 1; }();
+    const bool one_level = env_levels != 2;
+    const uint32_t B = one_level ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2 * n_expect / RNG_WORDS), MAX_COARSE)
+                                 : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2 * n_expect / ctx->bucket_target), 1u << 24);
     BucketMap bm{};
     bm.sh = 32;
     bm.mult = B;                                                   // (B << 32) / 2^32
@@ -476,7 +645,8 @@ static void a10_mark_partitioned(sylph_sketch* sk) {
     const uint64_t range = (0x100000000ull + B - 1) / B + 1;       // widest bucket in key units
     bm.range_hs = (uint32_t)std::min<uint64_t>(range, 0xFFFFFFFFull);
     bm.sub_mult[0] = range > (uint64_t)RES_CAP ? (uint32_t)(((uint64_t)RES_CAP << 32) / range) : 0u;
-    const PartGeom geom = part_geometry(B);
+    if (!one_level) b_sorted.reserve(n_slots * 16);
+    const PartGeom geom = one_level ? PartGeom{0, B} : part_geometry(B);
     OpsIn oin{};
     PartIn in{};
     in.key_sh = 32;
@@ -499,10 +669,22 @@ static void a10_mark_partitioned(sylph_sketch* sk) {
     ScopedKernelTimer t(ctx, "a10");
     if (slotted) hipLaunchKernelGGL(a10_ops_slots_kernel, dim3(oin.n_blk), dim3(64), 0, ctx->stream, oin, f0, b_ops.as<ulonglong2>(), tail);
     else hipLaunchKernelGGL(a10_ops_dense_kernel, dim3((uint32_t)((sk->n_occ + 255) / 256)), dim3(256), 0, ctx->stream, oin, f0, b_ops.as<ulonglong2>(), tail);
-    launch_partition(ctx, in, bm, geom, n_tiles, 2 * n_expect, b_hist.as<uint32_t>(), b_pairs.as<uint2>(), b_boff.as<uint32_t>(), nullptr,
-                     b_sorted.as<uint64_t>(), nullptr, 0, nullptr, nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL(a10_resolve_kernel, dim3(B), dim3(RES_TPB), 0, ctx->stream, b_sorted.as<uint64_t>(), b_boff.as<uint32_t>(), bm, f0,
-                       const_cast<OccRec*>(oin.recs), tail);
+    if (one_level) {
+        // words grouped by range where the scatter left them; slot of a word inside its range = (upper half - lowest of the range) x slots / width
+        launch_partition_coarse(ctx, in, bm, n_tiles, b_hist.as<uint32_t>(), b_pairs.as<uint2>());
+        static const int env_split = [] { const char* e = getenv("SYLPH_HIP_A10_RANGE_SPLIT"); return e ? std::max(1, std::min(8, atoi(e))) : 2; }();
+        static const int env_pad = [] { const char* e = getenv("SYLPH_HIP_A10_RANGE_LDS_PAD"); return e ? atoi(e) : 0; }();     // (A/B: LDS footprint)
+        const uint32_t split = (uint32_t)env_split;
+        const uint64_t all_slots = (uint64_t)split << RNG_SLOT_BITS;
+        const uint32_t slot_mult = range > all_slots ? (uint32_t)((all_slots << 32) / range) : 0u;
+        hipLaunchKernelGGL(a10_range_kernel<256>, dim3(B * split), dim3(256), (size_t)env_pad, ctx->stream, b_pairs.as<uint64_t>(),
+                           part_cbase(b_hist.as<uint32_t>(), B, n_tiles), B, bm.mult, slot_mult, split, f0, const_cast<OccRec*>(oin.recs), tail);
+    } else {
+        launch_partition(ctx, in, bm, geom, n_tiles, 2 * n_expect, b_hist.as<uint32_t>(), b_pairs.as<uint2>(), b_boff.as<uint32_t>(), nullptr,
+                         b_sorted.as<uint64_t>(), nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(a10_resolve_kernel, dim3(B), dim3(RES_TPB), 0, ctx->stream, b_sorted.as<uint64_t>(), b_boff.as<uint32_t>(), bm, f0,
+                           const_cast<OccRec*>(oin.recs), tail);
+    }
     SY_HIP(hipGetLastError());
     sk->a10_state = 1;
     if (ctx->profile) ctx->stats["a10_part"].launches++;              // (tests ask sylph_ctx_kernel_stats which pass ran)

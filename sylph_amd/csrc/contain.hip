@@ -172,7 +172,10 @@ __global__ __launch_bounds__(256) void write_lines_kernel(const uint64_t* __rest
 // (row << 32 | count), staged per workgroup in LDS and flushed with one global atomic per ~PROBE_FLUSH hits (one atomic per
 // chunk on a single word made the atomic unit 40 % of the kernel: ~88 single-address atomics/us on this chip).
 constexpr int PROBE_TPB = 256;
-constexpr int PROBE_STAGE = 4096;
+#ifndef SYLPH_PROBE_STAGE
+#define SYLPH_PROBE_STAGE 4096
+#endif
+constexpr int PROBE_STAGE = SYLPH_PROBE_STAGE;
 constexpr int PROBE_FLUSH = 2048;
 constexpr int PROBE_GRID = 1024;
 

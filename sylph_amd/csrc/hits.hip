@@ -50,8 +50,11 @@ __device__ __forceinline__ bool src_overflowed(const HitsSrc& s) { return s.d_cn
 
 // stretch hash: the hits of a workgroup's stretch of the list in an LDS table of HIT_SLOTS (row, count) entries (open addressing);
 // a stretch with more distinct rows than the table may hold sends the surplus hits straight to the global counters
-constexpr uint32_t HIT_SLOTS = 4096, HIT_SLOTS_FULL = HIT_SLOTS * 3 / 4, SLOT_EMPTY_ROW = 0xFFFFFFFFu, NO_SLOT = 0xFFFFFFFFu;
-__device__ __forceinline__ uint32_t hash_row(uint32_t row) { return (row * 2654435761u) >> 20; }   // top 12 bits
+#ifndef SYLPH_HIT_SLOTS_LOG2
+#define SYLPH_HIT_SLOTS_LOG2 12
+#endif
+constexpr uint32_t HIT_SLOTS = 1u << SYLPH_HIT_SLOTS_LOG2, HIT_SLOTS_FULL = HIT_SLOTS * 3 / 4, SLOT_EMPTY_ROW = 0xFFFFFFFFu, NO_SLOT = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t hash_row(uint32_t row) { return (row * 2654435761u) >> (32 - SYLPH_HIT_SLOTS_LOG2); }   // top bits
 // -> the row's slot, claiming a free one.  Whether the table still takes NEW rows is decided between rounds of 256 hits, for the
 // whole workgroup at once (`frozen`): a row then either owns a slot — and EVERY hit of it in the stretch goes through the slot —
 // or never gets one, and every hit of it goes straight to the global counter; a hit-by-hit decision could turn one hit of a row

@@ -38,7 +38,10 @@ constexpr int PART_TPB = 256;
 constexpr uint32_t BLK_PER_TILE = 16;     // slotted: blocks of the seeding kernel per partition tile (~3,000 occurrences)
 constexpr uint32_t MAX_COARSE = 4096;     // coarse ranges (LDS counters of the histogram / scatter kernels)
 constexpr uint32_t MAX_FINE = 4096;       // buckets per coarse range (LDS counters of the fine kernel)
-constexpr uint32_t STAGE_PAIRS = 4096;    // pairs a scatter workgroup groups in LDS before writing them out in runs
+#ifndef SYLPH_STAGE_PAIRS
+#define SYLPH_STAGE_PAIRS 4096
+#endif
+constexpr uint32_t STAGE_PAIRS = SYLPH_STAGE_PAIRS;    // pairs a scatter workgroup groups in LDS before writing them out in runs
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous eighth of the tiles, so
 // that the runs two neighbouring tiles append to the same coarse range — adjacent in memory — meet in the same L2.
@@ -287,6 +290,24 @@ inline void launch_partition(sylph_ctx* ctx, const PartIn& in, const BucketMap& 
     else
         hipLaunchKernelGGL((part_fine_kernel<PART_TPB>), dim3(g.C), dim3(PART_TPB), 0, ctx->stream, pairs, cbase, g.fine_bits, g.C, bm.B, boff, perm,
                            in.carry, in.key_sh, bm, sorted);
+    SY_HIP(hipGetLastError());
+}
+
+// One level only (round 6, a10.hip): the first three dispatches with every bucket a coarse range of its own — the 64-bit words end up
+// grouped by range in `pairs`, range c at [cbase[c], cbase[c + 1]) with cbase = part_cbase(hist, C, n_tiles); whoever reads the
+// ranges resolves the rest in LDS.  bm.B = C <= MAX_COARSE.
+inline const uint32_t* part_cbase(const uint32_t* hist, uint32_t C, uint32_t n_tiles) { return hist + (size_t)C * n_tiles + C; }
+inline void launch_partition_coarse(sylph_ctx* ctx, const PartIn& in, const BucketMap& bm, uint32_t n_tiles, uint32_t* hist, uint2* pairs) {
+    const uint32_t C = bm.B;
+    SY_REQUIRE(C >= 1 && C <= MAX_COARSE, "internal: %u ranges", C);
+    uint32_t* ctotal = hist + (size_t)C * n_tiles;
+    uint32_t* cbase = ctotal + C;
+    const uint32_t tile_grid = ((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(part_hist_kernel, dim3(tile_grid), dim3(PART_TPB), 0, ctx->stream, in, bm, 0, C, n_tiles, hist, (uint32_t*)nullptr, 0u,
+                       (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(part_scan_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, hist, n_tiles, ctotal);
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)C + 2 * (size_t)STAGE_PAIRS) * 4, ctx->stream, in, bm,
+                       0, C, n_tiles, hist, ctotal, cbase, pairs);
     SY_HIP(hipGetLastError());
 }
 

@@ -382,10 +382,17 @@ def test_filter_dedup_partitioned_pass_and_its_verdict(ctx):
             one = [genome[s:s + 150], revcomp(genome[s + 200:s + 350])]
             break
     assert one is not None
-    # 700 copies of one pair spread among ordinary ones: each of its items fills a class bucket beyond what a workgroup takes -> the walk
+    # 400 copies of one pair spread among ordinary ones: round 5's two-level pass (SYLPH_HIP_A10_LEVELS=2) finds a class bucket fuller than
+    # a workgroup takes -> the walk; round 6's one-level pass cuts the range into slices and resolves them in place.  3,000 copies of
+    # one item are more than a slice's lists take: the walk in both.
+    two_levels = os.environ.get("SYLPH_HIP_A10_LEVELS") == "2"
     spread = []
-    for _ in range(700):
+    for _ in range(400):
         spread += pairs(9) + one
+    assert roads(lambda: run([spread])) == ((1, 0, 1, 1) if two_levels else (1, 0, 1, 0))
+    spread = []
+    for _ in range(3000):
+        spread += pairs(2) + one
     assert roads(lambda: run([spread])) == (1, 0, 1, 1)
     # capacities around the sample's number of operations: below the estimate the walk is chosen at once; between the estimate and
     # the true count the partitioned pass runs and its verdict sends the sample to the walk (which then grows a second filter)
