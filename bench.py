@@ -479,7 +479,9 @@ def main():
     c_reads = 100 if long_mode else c        # reads may be sketched denser than the DB (contain.rs:562-568,616-623)
     # The main context launches on a torch-owned stream, so torch-side generation, the library's kernels on this context and the
     # timing events are stream-ordered without cross-queue synchronisation.
-    tstream = torch.cuda.Stream(device=device)
+    # (SYLPH_BENCH_STREAM_PRIORITY=high|low: the main — in the pipeline: the profile thread's — stream at another priority; A/B for VERDICT r05 #5)
+    prio = {"high": -1, "low": 0, "": 0}[os.environ.get("SYLPH_BENCH_STREAM_PRIORITY", "")]
+    tstream = torch.cuda.Stream(device=device, priority=prio)
     torch.cuda.set_stream(tstream)
     ctx = S.Context(local, stream=tstream.cuda_stream)
     ctx.set_option("shard_reduce", args.shard_reduce)
@@ -972,22 +974,23 @@ def main():
             out["roofline"]["alone_on_gpu"] = {"avg_launch_ms": round(a1, 4), "achieved": round(alg_bytes / (a1 * 1e-3) / 1e9, 1),
                                                "frac": round(alg_bytes / (a1 * 1e-3) / 1e9 / 8000.0, 4), "launches": int(f1["seeds"][1])}
     # roofline of the filter dedup (the reference's default for pairs; csrc/a10.hip): one "launch" = the six dispatches of the partitioned
-    # pass of one sample (operation words, two-level partition by class, in-LDS resolution), timed alone on the GPU by the library's
+    # pass of one sample (operation words, one partition level by class range, in-LDS resolution), timed alone on the GPU by the library's
     # HIP events.  Algorithmic bytes: the 32 B occurrence record of every seed occurrence in (k-mer, two markers, record id: what the
-    # filter's items are made of); the marks go back into ~3 % of the records in place.  `traffic`: the six kernels' PMC counters.
+    # filter's items are made of); the marks go back into ~3 % of the records in place.  `traffic`: the five kernels' PMC counters.
     if filter_leg is not None and filter_leg.get("one_step_at_a_time", {}).get("kernel_ms", {}).get("a10"):
         a_ms, a_n = filter_leg["one_step_at_a_time"]["kernel_ms"]["a10"]
         n_occ_f = float(np.mean(last["occ"])) if last.get("occ") else 0.0
         alg = 32.0 * n_occ_f
         a_traffic = meta.get("a10_hbm_bytes_per_sample") if meta_ok else None
-        out["roofline_a10"] = {"bound": "hbm", "kernel": "a10_ops_slots_kernel + part_hist/scan/scatter/fine (operations by class) + a10_resolve_kernel",
+        out["roofline_a10"] = {"bound": "hbm", "kernel": "a10_ops_slots_kernel + part_hist/scan/scatter (operations by class range) + a10_range_kernel",
                                "achieved": round(alg / (a_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / (a_ms * 1e-3) / 1e9 / 8000.0, 4),
                                "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": a_ms, "launches": int(a_n),
                                "traffic": a_traffic, "traffic_over_algorithmic": round(a_traffic / alg, 2) if (a_traffic and alg) else None,
                                "traffic_frac_of_peak": round(a_traffic / (a_ms * 1e-3) / 1e9 / 8000.0, 4) if a_traffic else None,
                                "traffic_source": tsrc if a_traffic else "none: no PMC figures for these kernel sources",
-                               "note": "a sort of 8 B operation words through two partition levels instead of 2 atomics + 1 load per operation on a 256 MB "
-                                       "table (round 4: 0.92 ms): the traffic is several times the algorithmic bytes by construction, all of it coalesced"}
+                               "note": "8 B operation words through ONE partition level (round 5: two), ranges of ~8,000 words resolved through an LDS bit table by "
+                                       "256-thread workgroups sized to fit beside the next samples' seeding kernels (profiles/r06_ab_a10.txt); round 4's table "
+                                       "of 2 atomics + 1 load per operation: 0.92 ms.  The traffic is several times the algorithmic bytes by construction, all of it coalesced"}
     # roofline of the profile half: probe_kernel, one launch per probe batch over all tables it probes.  Inverted-index formulation
     # (SURVEY 8d): B = N_s * (8 + 4 table in + 64 one index line per probe) + 8 * hits out.
     fam_mix, rows_mix = (fam_pass["fam"], fam_pass["rows"]) if fam_pass is not None else (fam, rows)

@@ -655,14 +655,17 @@ static void a10_mark_partitioned(sylph_sketch* sk) {
     if (slotted) {
         const uint32_t* blk_count = sk->slot_meta.as<uint32_t>() + (sk->pend.n_blk + 1);      // (layout: reads.hip SlotMeta)
         oin.recs = sk->slot_rec.as<OccRec>(); oin.blk_count = blk_count; oin.n_blk = sk->pend.n_blk; oin.slot_cap = sk->pend.slot_cap; oin.slotted = 1;
-        in.slotted = 2; in.blk_count = blk_count; in.n_blk = sk->pend.n_blk; in.slot_cap = sk->pend.slot_cap; in.blk_per_tile = OPS_BLK_PER_TILE;
-        n_tiles = (in.n_blk + OPS_BLK_PER_TILE - 1) / OPS_BLK_PER_TILE;
+        static const uint32_t env_bpt = [] { const char* e = getenv("SYLPH_HIP_A10_BLK_PER_TILE"); return e ? (uint32_t)std::max(1, std::min(32, atoi(e))) : OPS_BLK_PER_TILE; }();
+        in.slotted = 2; in.blk_count = blk_count; in.n_blk = sk->pend.n_blk; in.slot_cap = sk->pend.slot_cap; in.blk_per_tile = env_bpt;
+        n_tiles = (in.n_blk + env_bpt - 1) / env_bpt;
     } else {
         oin.hash = sk->hash.as<uint64_t>(); oin.recs = sk->recs.as<OccRec>(); oin.n_dense = (uint32_t)sk->n_occ;
         in.slotted = 0; in.n_dense = (uint32_t)(2 * sk->n_occ);
         in.tile_entries = (uint32_t)std::max<uint64_t>(4096, (2 * sk->n_occ + 65535) / 65536);
         n_tiles = (uint32_t)((2 * sk->n_occ + in.tile_entries - 1) / in.tile_entries);
     }
+    static const uint32_t env_stage = [] { const char* e = getenv("SYLPH_HIP_A10_STAGE_PAIRS"); return e ? (uint32_t)std::max(256, std::min(8192, atoi(e))) : 0u; }();
+    if (one_level) in.stage_pairs = env_stage;
     in.hash = b_ops.as<uint64_t>();
     b_hist.reserve(part_hist_words(geom, n_tiles) * 4);
     b_boff.reserve(((size_t)B + 2) * 4);

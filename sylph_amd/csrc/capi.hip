@@ -434,6 +434,22 @@ int sylph_ctx_set_option(sylph_ctx* ctx, const char* key, const char* value) {
             if (!strcmp(value, "alltoall")) ctx->shard_reduce = 0;
             else if (!strcmp(value, "allgather")) ctx->shard_reduce = 1;
             else SY_REQUIRE(false, "shard_reduce must be alltoall|allgather");
+        } else if (!strcmp(key, "stream_priority")) {
+            // The context's own stream is made again at another priority (hipStreamCreateWithPriority): "high" lets the small kernels of a
+            // profile context through where the sketch contexts' seeding kernels keep the chip full (pipeline.hip).
+            SY_REQUIRE(ctx->own_stream, "stream_priority: the context runs on the caller's stream");
+            int least = 0, greatest = 0;
+            DeviceGuard dg(ctx->device);
+            SY_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            int prio = 0;
+            if (!strcmp(value, "high")) prio = greatest;
+            else if (!strcmp(value, "low")) prio = least;
+            else SY_REQUIRE(!strcmp(value, "normal"), "stream_priority must be high|normal|low");
+            SY_HIP(hipStreamSynchronize(ctx->stream));
+            hipStream_t s = nullptr;
+            SY_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+            (void)hipStreamDestroy(ctx->stream);
+            ctx->stream = s;
         } else if (!strcmp(key, "fail_next_peer_copy")) {
             ctx->fail_next_peer_copy = (uint32_t)strtol(value, nullptr, 10);     // tests only: sylph_db_replicate into this context takes the host road
         } else if (!strcmp(key, "fail_next_shard_probe")) {

@@ -32,6 +32,7 @@ struct PartIn {
     uint32_t n_dense, n_blk, slot_cap, tile_entries;
     uint32_t blk_per_tile;   // slotted: blocks of the seeding kernel per partition tile (BLK_PER_TILE; fewer for the two-word layout)
     int slotted, key_sh;   // slotted: 0 dense, 1 slots (keys beside them), 2 pairs of 64-bit words in slot layout (carried)
+    uint32_t stage_pairs;   // pairs a scatter workgroup groups in LDS (0: STAGE_PAIRS)
     int carry;     // marker-less samples (dense only): the pairs ARE the 64-bit hashes — the partition sorts the hashes themselves by bucket
 };
 constexpr int PART_TPB = 256;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, Bucke
     uint32_t* const s_gb = s_dyn + C;                    // global position of the range's run minus its start in the tile order
     uint2* const s_stage = reinterpret_cast<uint2*>(s_dyn + 2 * (size_t)C + ((2 * C) & 1u));
     __shared__ uint32_t s_wave[PART_TPB / 64];
-    const uint32_t t = xcd_tile(n_tiles);
+    const uint32_t t = xcd_tile(n_tiles), stage = in.stage_pairs ? in.stage_pairs : STAGE_PAIRS;
     if (t >= n_tiles) return;
     for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_cur[c] = 0;
     __syncthreads();
@@ -162,11 +163,11 @@ __global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, Bucke
         const uint32_t b = bucket_of_key(key, bm), c = b >> fine_bits;
         const uint32_t p = atomicAdd(&s_cur[c], 1u);     // place in the tile order
         const uint2 pr = in.carry ? make_uint2((uint32_t)h, (uint32_t)(h >> 32)) : make_uint2(b, idx);
-        if (p < STAGE_PAIRS) s_stage[p] = pr;
+        if (p < stage) s_stage[p] = pr;
         else out[s_gb[c] + p] = pr;                      // (a tile fuller than the stage: the rest goes out directly)
     });
     __syncthreads();
-    const uint32_t n_staged = min(n_tile, STAGE_PAIRS);
+    const uint32_t n_staged = min(n_tile, stage);
     for (uint32_t p = threadIdx.x; p < n_staged; p += PART_TPB) {
         const uint2 v = s_stage[p];
         const uint32_t b = in.carry ? bucket_of_key((uint32_t)((((uint64_t)v.y << 32) | v.x) >> in.key_sh), bm) : v.x;
@@ -280,7 +281,7 @@ inline void launch_partition(sylph_ctx* ctx, const PartIn& in, const BucketMap& 
     hipLaunchKernelGGL(part_hist_kernel, dim3(tile_grid), dim3(PART_TPB), 0, ctx->stream, in, bm, g.fine_bits, g.C, n_tiles, hist, zero, n_zero,
                        tail16, list_a, list_b, list_c);
     hipLaunchKernelGGL(part_scan_kernel, dim3(g.C), dim3(PART_TPB), 0, ctx->stream, hist, n_tiles, ctotal);
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)g.C + 2 * (size_t)STAGE_PAIRS) * 4, ctx->stream, in, bm,
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)g.C + 2 * (size_t)(in.stage_pairs ? in.stage_pairs : STAGE_PAIRS)) * 4, ctx->stream, in, bm,
                        g.fine_bits, g.C, n_tiles, hist, ctotal, cbase, pairs);
     // (a sample of tens of millions of occurrences — long reads at c = 100 — has ~10^5 pairs per coarse range: 1024
     //  threads walk them instead of 256; c5: 1.27 -> see profiles)
@@ -306,7 +307,7 @@ inline void launch_partition_coarse(sylph_ctx* ctx, const PartIn& in, const Buck
     hipLaunchKernelGGL(part_hist_kernel, dim3(tile_grid), dim3(PART_TPB), 0, ctx->stream, in, bm, 0, C, n_tiles, hist, (uint32_t*)nullptr, 0u,
                        (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(part_scan_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, hist, n_tiles, ctotal);
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)C + 2 * (size_t)STAGE_PAIRS) * 4, ctx->stream, in, bm,
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)C + 2 * (size_t)(in.stage_pairs ? in.stage_pairs : STAGE_PAIRS)) * 4, ctx->stream, in, bm,
                        0, C, n_tiles, hist, ctotal, cbase, pairs);
     SY_HIP(hipGetLastError());
 }

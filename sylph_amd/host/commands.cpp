@@ -163,6 +163,9 @@ struct Reaper {
 };
 Reaper& reaper() { static Reaper* r = new Reaper(); return *r; }
 void background(std::function<void()> f) { reaper().add(std::move(f)); }
+// ... and one thread that writes finished sketches out, in the order they were finished, while their worker is at its next sample
+// (a 1 Gbp pair's .sylsp: 48 MB, 25-35 ms of a warm sample's ~120); always drained before the command returns
+Reaper& writers() { static Reaper* r = new Reaper(); return *r; }
 }  // namespace
 void join_background() { reaper().drain(); }
 void trace_mark(const char* what) {
@@ -199,6 +202,7 @@ Engine::Engine(int dev) : device(dev), gate_(new Gate()) {
             // ... while the packed double buffers of the indexed feed are page-locked (~27 ms; round 5: BEHIND the gate — the first
             // sample of a process travels from pageable memory it was gathered into during the bring-up: PinnedBatch::gather_packed_early).
             // (Only these: the 256 MB ASCII batch of the sequential reader is page-locked by its first add() — most commands never need it.)
+            if (defer_pinned.load()) { trace_mark("engine: page-locked feed buffers left to their first user"); return; }
             batch.prealloc_packed();
             trace_mark("engine: packed double buffers page-locked");
             if (device_feed_enabled()) { text.prepare(ctx_); trace_mark("engine: text uploader's chunks page-locked"); }
@@ -906,6 +910,10 @@ int sketch(Engine& e, const SketchArgs& args) {
     // The parsing / inflating of different samples overlaps; the GPU work of one sample is ~2 ms per Gbp.
     create_dir_all(args.sample_output_dir);
     const size_t n_jobs = first_pairs.size() + read_inputs.size();
+    // (a command's first sample is gathered into pageable memory while the GPU runtime comes up and the device route's uploader serves the
+    //  samples BEHIND it: with one sample nobody ever wants the page-locked feed buffers — ~80 ms of hipHostMalloc beside the sample's own
+    //  push, and as much again when the process is torn down)
+    if (n_jobs <= 1) e.defer_pinned.store(true);
     // --gpus N|all (round 6): the workers are dealt to the node's GPUs — worker w runs on device w mod N, with its own context, page-locked
     // batch and uploader there; a sample never leaves its GPU, nothing is exchanged ("replicas only" for the sketch stage —
     // what the reference's rayon pool does with the machine's cores, sketch.rs:313, :371).  At least one worker per GPU.
@@ -928,6 +936,25 @@ int sketch(Engine& e, const SketchArgs& args) {
     set_feed_budget(4 * n_workers);            // two files per sample, the current and the next sample of every worker
     std::atomic<size_t> indexes_obtained{0};
     set_no_more_inflates(false);
+    // a finished sketch is written by the writers' thread while its worker takes the next sample; the first error is rethrown by the command
+    std::mutex write_mu;
+    std::optional<Error> write_error;
+    auto write_out = [&](const std::string& path, SequencesSketch&& sk, const std::string& what, std::function<void(const SequencesSketch&, const std::string&)> timing) {
+        auto keep = std::make_shared<SequencesSketch>(std::move(sk));
+        auto task = [&write_mu, &write_error, keep, path, what, timing] {
+            try {
+                write_sylsp(path, *keep);
+                trace_mark("sketch: .sylsp written");
+                info("Sketching " + path + " complete.");
+                timing(*keep, what);
+            } catch (const Error& er) {
+                std::lock_guard<std::mutex> lk(write_mu);
+                if (!write_error) write_error = er;
+            }
+        };
+        if (n_jobs > 1) writers().add(task); else task();
+    };
+    struct DrainWriters { ~DrainWriters() { writers().drain(); } } drain_writers;     // (also on the way out of an exception: the tasks refer to this frame)
     auto run_job = [&](Engine& eng, size_t j) {
         // an engine that is up takes plain FASTQ by the device route (no host index at all); its first sample, whose index is built while
         // the GPU runtime initialises, and everything the device route declines go the host way
@@ -938,13 +965,16 @@ int sketch(Engine& e, const SketchArgs& args) {
         std::optional<IndexedInput> pre;
         if (gz && !gz_dev) pre = index_inputs(jf.first, jf.second ? &*jf.second : nullptr, false);   // inflated on the host, its text then sent as it is
         else if (!dev) pre = ahead.get(j);
+        // (a gzip sample on the device route needs none of the page-locked feed buffers: an engine still in its bring-up leaves them to
+        //  whoever wants them first — ~80 ms of hipHostMalloc that would run beside the sample's own allocations and copies)
+        if (gz_dev && !eng.ready()) eng.defer_pinned.store(true);
         trace_mark(dev ? "sketch: the sample goes the device route" : "sketch: the sample's files are indexed (or not indexable)");
         if (++indexes_obtained == n_jobs) set_no_more_inflates(true);   // nobody will want a recycled inflate buffer any more
         // the index goes (2 x 1 GB of mappings to unmap / inflated copies to hand back: 30-60 ms per sample) on a thread of its own, behind the sample
         struct Later { std::optional<IndexedInput>& p; ~Later() { if (p) background([x = std::make_shared<std::optional<IndexedInput>>(std::move(p))]() mutable { x.reset(); }); } } later{pre};
         if (!device_feed_enabled()) ahead.start(j + n_workers);
         const auto t_job = std::chrono::steady_clock::now();
-        auto timing = [&](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
+        auto timing = [t_job](const SequencesSketch& sk, const std::string& what) {   // (not a reference message: feed measurements)
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_job).count();
             uint64_t occ = 0;
             for (uint32_t c : sk.counts) occ += c;
@@ -961,10 +991,7 @@ int sketch(Engine& e, const SketchArgs& args) {
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + ".paired" + SAMPLE_FILE_SUFFIX;
             trace_mark("sketch: the pair is sketched (table on the host)");
-            write_sylsp(path, *sk);
-            trace_mark("sketch: .sylsp written");
-            info("Sketching " + path + " complete.");
-            timing(*sk, first_pairs[j]);
+            write_out(path, std::move(*sk), first_pairs[j], timing);
         } else {                                                             // :369-420
             const size_t i = j - first_pairs.size();
             std::optional<std::string> sample_name;
@@ -973,9 +1000,7 @@ int sketch(Engine& e, const SketchArgs& args) {
             if (!sk) return;
             const std::string& name = sample_name ? *sk->sample_name : sk->file_name;
             const std::string path = path_join(args.sample_output_dir, basename_of(name)) + SAMPLE_FILE_SUFFIX;
-            write_sylsp(path, *sk);
-            info("Sketching " + path + " complete.");
-            timing(*sk, read_inputs[i]);
+            write_out(path, std::move(*sk), read_inputs[i], timing);
         }
     };
     if (n_workers <= 1) {
@@ -1008,6 +1033,8 @@ int sketch(Engine& e, const SketchArgs& args) {
         for (auto& t : pool) t.join();
         if (first_error) throw *first_error;
     }
+    writers().drain();
+    if (write_error) throw *write_error;
     if (!genome_inputs.empty()) {                                            // :422-476
         const std::string path = args.db_out_name + QUERY_FILE_SUFFIX;
         create_dir_all(dirname_of(path));

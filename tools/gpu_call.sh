@@ -76,7 +76,7 @@ PY
       for cfg in "$@"; do
         envs=""; [ "$cfg" != "-" ] && envs=$(echo "$cfg" | tr ',' ' ')
         env $envs timeout 300 $BF > "$out/one.json" 2> "$out/one.err"
-        python -c "import json; o = json.load(open('$out/one.json')); print('round $r', '$cfg', 'Gbp/s', o['value'])" | tee -a "$out/ab.txt"
+        python -c "import json; o = json.load(open('$out/one.json')); print('round $r', '$cfg', 'Gbp/s', o['value'], 'interval_ms', o.get('sample_interval_ms'))" | tee -a "$out/ab.txt"
       done
     done
     python - "$out/ab.txt" <<'PY'

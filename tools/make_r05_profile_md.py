@@ -149,6 +149,8 @@ try:
     for key, v in sorted(a10.items()):
         name, grid = key.rsplit("@", 1)
         mine = name.startswith("a10_") or (name.startswith("part_") and (len(grids[name]) == 1 or int(grid) == max(grids[name])))
+        if name.startswith("part_fine") and any(k.startswith("a10_range_kernel") for k in a10):
+            mine = False                                     # round 6: one partition level — the fine level is the replay's alone
         if not mine or name == "part_scan_kernel" and len(grids[name]) > 1 and int(grid) != max(grids[name]):
             continue
         f_b, w_b = v.get("FETCH_SIZE", 0) * 1024 * 2, v.get("WRITE_SIZE", 0) * 1024
@@ -163,7 +165,7 @@ try:
             "FETCH_SIZE x 1024 x 2 (coalesced streaming reads: calibrated on part_hist_kernel, which reads the 8.0 M operation words = 64 MB and reports 32.0 MB), WRITE_SIZE x 1024:", "",
             "| kernel | grid | read bytes | written bytes | VALU wave-instr | SALU | LDS bank conflicts |", "|---|---|---|---|---|---|---|"] + rows_a
     out += ["", f"Per sample: **{a10_traffic:.4e} B of HBM traffic** for {ra.get('algorithmic_bytes_per_launch', 0):.4e} algorithmic bytes (the 32 B record of every occurrence) = "
-                f"{a10_traffic / max(1, ra.get('algorithmic_bytes_per_launch', 1)):.1f}x — a sort of 8-byte words through two partition levels, all of it coalesced — in {ra.get('avg_launch_ms')} ms alone on the GPU "
+                f"{a10_traffic / max(1, ra.get('algorithmic_bytes_per_launch', 1)):.1f}x — 8-byte operation words through one partition level (round 5: two) and an LDS bit table per range, all of it coalesced — in {ra.get('avg_launch_ms')} ms alone on the GPU "
                 f"= {a10_traffic / max(1e-9, ra.get('avg_launch_ms', 1) * 1e-3) / 1e12:.2f} TB/s; round 4's walk: 16 M device-wide atomics + 8 M agent-scope loads on a 256 MB table, 0.92 ms."]
     if os.path.exists(os.path.join(src, "step_timeline_filter.md")):
         out += ["", "One sample with the filter on, dispatch by dispatch (rocprofv3 --kernel-trace of the same sequential run):", "", open(os.path.join(src, "step_timeline_filter.md")).read()]
