@@ -110,15 +110,31 @@ template <int RTPB>
 __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* s_wave, uint32_t* total);
 
 // one workgroup per coarse range: hist row -> exclusive offsets of the tiles inside the range; total[c] = size of the range
+// (round 6: rows of up to SCAN_ROW_LDS tiles go through LDS — read and written with consecutive lanes on consecutive words; with every
+//  lane walking its own stretch of the row the 12.7 MB matrix of the filter pass's partition cost 44 MB of partial-line writes)
+constexpr uint32_t SCAN_ROW_LDS = 4096;
 __global__ __launch_bounds__(PART_TPB) void part_scan_kernel(uint32_t* __restrict__ hist, uint32_t n_tiles, uint32_t* __restrict__ total) {
     __shared__ uint32_t s_wave[PART_TPB / 64];
+    __shared__ uint32_t s_row[SCAN_ROW_LDS + SCAN_ROW_LDS / 32];      // (a pad word per 32: the lanes' stretches start 13+ words apart)
     uint32_t* row = hist + (size_t)blockIdx.x * n_tiles;
     const uint32_t per = (n_tiles + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(n_tiles, a + per);
+    const bool staged = n_tiles <= SCAN_ROW_LDS;
+    auto at = [](uint32_t i) { return i + (i >> 5); };
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i < n_tiles; i += PART_TPB) s_row[at(i)] = row[i];
+        __syncthreads();
+    }
     uint32_t sum = 0;
-    for (uint32_t i = a; i < b; i++) sum += row[i];
+    for (uint32_t i = a; i < b; i++) sum += staged ? s_row[at(i)] : row[i];
     uint32_t tot = 0;
     uint32_t run = block_excl_sum<PART_TPB>(sum, s_wave, &tot);
-    for (uint32_t i = a; i < b; i++) { const uint32_t v = row[i]; row[i] = run; run += v; }
+    if (staged) {
+        for (uint32_t i = a; i < b; i++) { const uint32_t v = s_row[at(i)]; s_row[at(i)] = run; run += v; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_tiles; i += PART_TPB) row[i] = s_row[at(i)];
+    } else {
+        for (uint32_t i = a; i < b; i++) { const uint32_t v = row[i]; row[i] = run; run += v; }
+    }
     if (threadIdx.x == 0) total[blockIdx.x] = tot;
 }
 

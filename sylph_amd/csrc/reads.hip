@@ -36,7 +36,8 @@ constexpr int RT_MIN = 4096, RT_MAX = 65536;
 constexpr int RH = 400;                            // halo = longest record taken (pair_kmer_single's upper limit, sketch.rs:923)
 constexpr int RPAD = 32;                           // lanes that idle behind the longest read of their wave read past the data
 constexpr int MASKW = 12;                          // 12 * 32 = 384 >= RH - 20 k-mers per record
-constexpr int OFFS = 600;                          // record offsets staged in LDS
+constexpr int OFFS_256 = 600;                      // record offsets staged in LDS (256-record blocks)
+constexpr int RTPB_RAGGED = 512;                   // lanes (= records per pass) of the kernel's variant for ragged input
 
 template <int K>
 struct KC {
@@ -138,8 +139,9 @@ __global__ __launch_bounds__(256) void block_records_kernel(const uint64_t* __re
 #ifndef SYLPH_READS_WAVES
 #define SYLPH_READS_WAVES 5
 #endif
-template <int K, int HV, int ENC>
-__global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READS_WAVES, SYLPH_READS_WAVES))) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
+template <int K, int HV, int ENC, int TPB>
+// (512 lanes are two wavefronts per SIMD and workgroup: three workgroups = six per SIMD — five would leave room for two)
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 256 ? SYLPH_READS_WAVES : 6, TPB == 256 ? SYLPH_READS_WAVES : 6))) void reads_kernel(const uint8_t* __restrict__ bases_al, uint32_t bias, uint64_t n_al,
                                                      const uint64_t* __restrict__ off, uint64_t n_rec,
                                                      const uint32_t* __restrict__ blk_rec, uint32_t n_blk, uint32_t it_begin, uint32_t it_end,
                                                      uint32_t rt, uint64_t thr,
@@ -149,6 +151,10 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                                                      uint32_t* __restrict__ blk_count,
                                                      ReadsState* __restrict__ state, const uint32_t* __restrict__ blk_list,
                                                      uint32_t* __restrict__ spill_slot_of_blk) {
+    // TPB = RTPB (256: one record per lane, a block of ~256 records) for equally long records; RTPB_RAGGED (512) for ragged input (round 6):
+    // the pass's records are dealt to the lanes by length, so a wavefront pays for the longest record of ITS share — a quarter of 256
+    // records, an eighth of 512: trimmed reads of 35..151 bp idle 11 % of their hash loop's lane-steps instead of 23 %
+    constexpr int RTPB = TPB, OFFS = TPB == 256 ? OFFS_256 : 2 * TPB + 80;
     extern __shared__ uint32_t sF[];                                 // (rt + 2 RH) / 16 + 3 stream words + RPAD
     __shared__ uint64_t s_off[OFFS + 4];
     const uint32_t n_words = (rt + 2 * RH) / 16 + 3;
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                     uint32_t m = s_mask[w][tid];
                     while (m) {
                         const uint32_t bpos = (uint32_t)__clz((int)m);
-                        s_owner[p++] = tid | ((w * 32 + bpos) << 8);
+                        s_owner[p++] = tid | ((w * 32 + bpos) << 10);
                         m &= ~(0x80000000u >> bpos);
                     }
                 }
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(RTPB) __attribute__((amdgpu_waves_per_eu(SYLPH_READ
                 uint32_t lo, i = 0, f;
                 if (listed) {
                     const uint32_t ow = s_owner[hix];
-                    lo = ow & 0xFFu;
-                    i = ow >> 8;
+                    lo = ow & 0x3FFu;
+                    i = ow >> 10;
                     f = s_first[lo];
                 } else {
                     lo = 0;
@@ -580,7 +586,12 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
     // Equally long records fill the RTPB lanes of every block exactly.  With ragged records the number that start inside a
     // block scatters around its mean (sigma ~ 6 for 35-151 bp reads) and every block above RTPB pays a whole second pass for a
     // handful of records: aim 7 % lower, so that such blocks are rare (c3r: 0.83 -> 0.70 ms per 0.62 Gbp; sweep 85-100 %).
-    const uint64_t target = (n_bases % n_records) ? (uint64_t)RTPB * 93 / 100 : (uint64_t)RTPB;
+    // Ragged input takes the kernel's 512-lane variant (see reads_kernel) where a block of that many records still fits the stream's LDS
+    // window; SYLPH_HIP_READS_RAGGED_TPB=256 keeps round 5's shape (A/B: profiles/r06_ab_ragged.txt).
+    static const int env_ragged_tpb = [] { const char* e = getenv("SYLPH_HIP_READS_RAGGED_TPB"); return e ? atoi(e) : RTPB_RAGGED; }();
+    const bool ragged = (n_bases % n_records) != 0;
+    const int tpb = (ragged && env_ragged_tpb == RTPB_RAGGED && (uint64_t)RTPB_RAGGED * 93 / 100 * n_bases / n_records <= (uint64_t)RT_MAX) ? RTPB_RAGGED : RTPB;
+    const uint64_t target = ragged ? (uint64_t)tpb * 93 / 100 : (uint64_t)tpb;
     uint32_t rt = (uint32_t)std::min<uint64_t>(RT_MAX, std::max<uint64_t>(RT_MIN, target * n_bases / n_records));
     rt = (rt + 15u) & ~15u;
     const uint32_t n_blk = (uint32_t)(n_al / rt) + 1;
@@ -611,15 +622,17 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
     auto launch = [&](uint32_t n_it, uint32_t it_b, uint32_t it_e, uint32_t cap, OccRec* sr, uint32_t* skey, const uint32_t* list) {
         if (it_e <= it_b) return;
         const uint32_t grid = ctx->reads_wg_per_cu ? (uint32_t)std::min<uint64_t>(it_e - it_b, (uint64_t)cus * ctx->reads_wg_per_cu) : it_e - it_b;
-#define SY_LAUNCH_READS(KK, HH, EE)                                                                                                   \
-    hipLaunchKernelGGL((reads_kernel<KK, HH, EE>), dim3(grid), dim3(RTPB), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
+#define SY_LAUNCH_READS_T(KK, HH, EE, TT)                                                                                             \
+    hipLaunchKernelGGL((reads_kernel<KK, HH, EE, TT>), dim3(grid), dim3(TT), lds_bytes, ctx->stream, bases_al, bias, n_al, d_off, n_records, \
                        m.blk_rec, n_it, it_b, it_e, rt, thr, slack, sk->avx2_compat, sk->paired, sk->no_dedup ? 0 : 1, sk->rec_base, cap, sr, skey, key_sh,   \
                        m.blk_count, m.state, list, m.spill_slot)
+#define SY_LAUNCH_READS(KK, HH, EE) do { if (tpb == RTPB_RAGGED) SY_LAUNCH_READS_T(KK, HH, EE, RTPB_RAGGED); else SY_LAUNCH_READS_T(KK, HH, EE, RTPB); } while (0)
         if (enc == SYLPH_ENC_2BIT) {
             if (sk->k == 31) { if (hv == 2) SY_LAUNCH_READS(31, 2, 1); else SY_LAUNCH_READS(31, 1, 1); }
             else { if (hv == 2) SY_LAUNCH_READS(21, 2, 1); else SY_LAUNCH_READS(21, 1, 1); }
         } else if (sk->k == 31) { if (hv == 2) SY_LAUNCH_READS(31, 2, 0); else if (hv) SY_LAUNCH_READS(31, 1, 0); else SY_LAUNCH_READS(31, 0, 0); }
         else { if (hv == 2) SY_LAUNCH_READS(21, 2, 0); else if (hv) SY_LAUNCH_READS(21, 1, 0); else SY_LAUNCH_READS(21, 0, 0); }
+#undef SY_LAUNCH_READS_T
 #undef SY_LAUNCH_READS
         SY_HIP(hipGetLastError());
     };

@@ -202,6 +202,8 @@ Engine::Engine(int dev) : device(dev), gate_(new Gate()) {
             // ... while the packed double buffers of the indexed feed are page-locked (~27 ms; round 5: BEHIND the gate — the first
             // sample of a process travels from pageable memory it was gathered into during the bring-up: PinnedBatch::gather_packed_early).
             // (Only these: the 256 MB ASCII batch of the sequential reader is page-locked by its first add() — most commands never need it.)
+            // (using the device FASTQ route's kernels once from here, on a second context, so that their first launches are not the first
+            //  sample's was tried: it takes 100-330 ms beside the sample's own work and doubled the sample's inflate — profiles/r06_gz_e2e_trace_final.txt)
             if (defer_pinned.load()) { trace_mark("engine: page-locked feed buffers left to their first user"); return; }
             batch.prealloc_packed();
             trace_mark("engine: packed double buffers page-locked");

@@ -64,13 +64,14 @@ with open(sys.argv[1] + "/kernel_stats.txt", "w") as o:
 PY
     if [ "${1:-}" != "--no-pmc" ]; then
       for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-include-regex 'a10_|part_' --output-format csv -d $out/pmca_$c -o s -- $BF > /dev/null 2>&1; done
-      python tools/pmc_by_kernel.py $out/pmca_FETCH_SIZE $out/pmca_WRITE_SIZE > $out/pmc_a10.json; rm -rf $out/pmca_FETCH_SIZE $out/pmca_WRITE_SIZE $out/trace
+      rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-include-regex 'a10_|part_|reads_kernel' --output-format csv -d $out/pmca_SQ -o s -- $BF > /dev/null 2>&1
+      python tools/pmc_by_kernel.py $out/pmca_FETCH_SIZE $out/pmca_WRITE_SIZE $out/pmca_SQ > $out/pmc_a10.json; rm -rf $out/pmca_FETCH_SIZE $out/pmca_WRITE_SIZE $out/pmca_SQ $out/trace
       python -c "import json; d = json.load(open('$out/pmc_a10.json')); print(json.dumps(d, indent=1)[:3000])"
     fi ;;
   ab-env)
     # A/B of environment knobs on the pipelined default-flag rate (every session behind sylph's default filter): AB_ROUNDS rounds over the
     # configurations given as arguments ("-" = no variable; "A=1,B=2" = two), alternating, one short bench process each
-    BF="python bench.py --main-dedup-fpr ${AB_FPR:-1e-4} --no-filter-leg --no-second-leg --no-verify --no-files-leg --no-packed-leg --no-h2d --no-cpu-baseline --min-seconds ${AB_SECONDS:-3}"
+    BF="python bench.py --main-dedup-fpr ${AB_FPR:-1e-4} --no-filter-leg --no-second-leg --no-verify --no-files-leg --no-packed-leg --no-h2d --no-cpu-baseline --min-seconds ${AB_SECONDS:-3} ${AB_EXTRA:-}"
     : > "$out/ab.txt"
     for r in $(seq 1 ${AB_ROUNDS:-4}); do
       for cfg in "$@"; do
