@@ -151,9 +151,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 256 
                                                      uint32_t* __restrict__ blk_count,
                                                      ReadsState* __restrict__ state, const uint32_t* __restrict__ blk_list,
                                                      uint32_t* __restrict__ spill_slot_of_blk) {
-    // TPB = RTPB (256: one record per lane, a block of ~256 records) for equally long records; RTPB_RAGGED (512) for ragged input (round 6):
-    // the pass's records are dealt to the lanes by length, so a wavefront pays for the longest record of ITS share — a quarter of 256
-    // records, an eighth of 512: trimmed reads of 35..151 bp idle 11 % of their hash loop's lane-steps instead of 23 %
+    // TPB = RTPB (256: one record per lane, a block of ~256 records); RTPB_RAGGED (512) is an A/B variant for ragged input (round 6): the
+    // pass's records are dealt to the lanes by length, so a wavefront pays for the longest record of ITS share — a quarter of 256 records,
+    // an eighth of 512: trimmed reads of 35..151 bp would idle 11 % of their hash loop's lane-steps instead of 23 %.  Measured slower (see
+    // push_short_reads): not the default.
     constexpr int RTPB = TPB, OFFS = TPB == 256 ? OFFS_256 : 2 * TPB + 80;
     extern __shared__ uint32_t sF[];                                 // (rt + 2 RH) / 16 + 3 stream words + RPAD
     __shared__ uint64_t s_off[OFFS + 4];
@@ -586,9 +587,11 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
     // Equally long records fill the RTPB lanes of every block exactly.  With ragged records the number that start inside a
     // block scatters around its mean (sigma ~ 6 for 35-151 bp reads) and every block above RTPB pays a whole second pass for a
     // handful of records: aim 7 % lower, so that such blocks are rare (c3r: 0.83 -> 0.70 ms per 0.62 Gbp; sweep 85-100 %).
-    // Ragged input takes the kernel's 512-lane variant (see reads_kernel) where a block of that many records still fits the stream's LDS
-    // window; SYLPH_HIP_READS_RAGGED_TPB=256 keeps round 5's shape (A/B: profiles/r06_ab_ragged.txt).
-    static const int env_ragged_tpb = [] { const char* e = getenv("SYLPH_HIP_READS_RAGGED_TPB"); return e ? atoi(e) : RTPB_RAGGED; }();
+    // Ragged input CAN take the kernel's 512-lane variant (see reads_kernel; SYLPH_HIP_READS_RAGGED_TPB=512) where a block of that many
+    // records still fits the stream's LDS window.  It is not the default: measured 8 % SLOWER on c3r (profiles/r06_ab_ragged.txt: 804 against
+    // 878 Gbp/s; 754 at five wavefronts per SIMD) — the lane-steps it saves in the hash loop are less than what eight wavefronts waiting
+    // for each other at the pass's barriers cost.
+    static const int env_ragged_tpb = [] { const char* e = getenv("SYLPH_HIP_READS_RAGGED_TPB"); return e ? atoi(e) : RTPB; }();
     const bool ragged = (n_bases % n_records) != 0;
     const int tpb = (ragged && env_ragged_tpb == RTPB_RAGGED && (uint64_t)RTPB_RAGGED * 93 / 100 * n_bases / n_records <= (uint64_t)RT_MAX) ? RTPB_RAGGED : RTPB;
     const uint64_t target = ragged ? (uint64_t)tpb * 93 / 100 : (uint64_t)tpb;
