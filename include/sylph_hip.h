@@ -116,6 +116,9 @@ void sylph_upload_destroy(sylph_upload *u);
  * the records for every batch (A/B and tests: the tables are identical).
  * "cu_mask" = "lo:hi" / "all": the context's OWN stream is recreated on the compute units [lo, hi) of the device's CU-mask numbering
  * (A/B knob; restricting the sketch workers' streams lost 25-40 % in r04: profiles/r04_ab_pipeline_sweep.txt).
+ * "stream_priority" = "high" | "normal" | "low": the context's OWN stream is recreated at that priority (an error on a context that
+ * runs on the caller's stream: create that stream at the priority wanted); no measurable effect on a pipeline's rate or its
+ * completion intervals (profiles/r06_ab_stream_priority.txt).
  * "fail_next_shard_probe" = "1": fault injection for the tests — the next sylph_db_contain_batch_sharded on this context fails
  * in its probe, between the collectives (every rank of the batch must then return the same error, nobody may hang). */
 int sylph_ctx_set_option(sylph_ctx *ctx, const char *key, const char *value);

@@ -514,6 +514,37 @@ def test_device_fastq_route_equals_the_host_feed(data):
     assert rows["0"] == rows["1"] and rows["0"].count("\n") >= 4
 
 
+def test_kernel_variants_behind_environment_knobs_give_the_same_sketches(data):
+    """Round 6's A/B knobs select other kernels for the same work: the read kernel's 512-lane variant for ragged input
+    (SYLPH_HIP_READS_RAGGED_TPB=512, csrc/reads.hip), round 5's two-level filter pass (SYLPH_HIP_A10_LEVELS=2) and one / four workgroups
+    per range of the one-level pass (SYLPH_HIP_A10_RANGE_SPLIT, csrc/a10.hip).  Ragged pairs (trimmed to 35..151 bases, some with N),
+    through the host feed and through the device route, with sylph's default filter dedup: byte-identical .sylsp files."""
+    d = data["dir"]
+    rng = np.random.default_rng(77)
+    t = [(d / "s_1.fq").read_bytes().split(b"\n"), (d / "s_2.fq").read_bytes().split(b"\n")]
+    n = min(len(t[0]), len(t[1])) // 4
+    for m in (0, 1):
+        out = []
+        for r in range(n):
+            seq = bytearray(t[m][4 * r + 1])
+            keep = int(rng.integers(35, max(36, len(seq) + 1)))
+            seq = seq[:keep]
+            if r % 17 == 0 and keep > 40:
+                seq[int(rng.integers(0, keep))] = ord("N")
+            out += [t[m][4 * r], bytes(seq), b"+", b"I" * len(seq)]
+        (d / f"rg_{m + 1}.fq").write_bytes(b"\n".join(out) + b"\n")
+    got = {}
+    for name, env in (("default", {}), ("tpb512", {"SYLPH_HIP_READS_RAGGED_TPB": "512"}), ("two_levels", {"SYLPH_HIP_A10_LEVELS": "2"}),
+                      ("split1", {"SYLPH_HIP_A10_RANGE_SPLIT": "1"}), ("split4_tpb512", {"SYLPH_HIP_A10_RANGE_SPLIT": "4", "SYLPH_HIP_READS_RAGGED_TPB": "512"})):
+        o = d / f"variants_{name}"
+        # two samples per command: the first goes the host feed, the second the device route
+        run("sketch", "-t", "1", "-c", "20", "-1", d / "rg_1.fq", d / "rg_1.fq", "-2", d / "rg_2.fq", d / "rg_2.fq", "-S", "a", "b", "-d", o, accept_exact=False, env_extra=env)
+        got[name] = {f.name: f.read_bytes() for f in sorted(o.iterdir())}
+        assert len(got[name]) == 2
+    for name in got:
+        assert got[name] == got["default"], name
+
+
 def test_damaged_gzip_goes_the_host_way(data):
     """A truncated .fastq.gz: the device's inflate declines it (SYLPH_ERR_FORMAT: the chain of deflate blocks ends before a final block)
     and the host reader takes the file, with the reference's behaviour for it — the same exit code, messages and sketch (if any) as with

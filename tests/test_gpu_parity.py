@@ -409,6 +409,27 @@ def test_filter_dedup_partitioned_pass_and_its_verdict(ctx):
     assert (1, 0) in seen and ((1, 1) in seen or (0, 0) in seen)
 
 
+def test_context_stream_priority_option():
+    """Round 6: a context that owns its stream can have it made again at another priority (ctx option "stream_priority", csrc/capi.hip;
+    the A/B of VERDICT r05 #5).  Results do not depend on it; a context on the caller's stream refuses."""
+    import torch
+    rng = np.random.default_rng(31)
+    genome = random_seq(rng, 50_000)
+    recs = [genome[s:s + 150] for s in rng.integers(0, len(genome) - 150, size=3000)]
+    b, off = concat(recs)
+    e = O.sketch_reads(b, off, c=50, mode=O.MODE_AVX2_COMPAT)
+    own = S.Context(0)
+    for prio in ("high", "low", "normal"):
+        own.set_option("stream_priority", prio)
+        assert_same_sketch(sketch_gpu(own, b, off, c=50), e)
+    with pytest.raises(S.SylphHipError):
+        own.set_option("stream_priority", "urgent")
+    st = torch.cuda.Stream(device=torch.device("cuda", 0))
+    borrowed = S.Context(0, stream=st.cuda_stream)
+    with pytest.raises(S.SylphHipError):
+        borrowed.set_option("stream_priority", "high")
+
+
 def test_read_sketch_deep_coverage_and_cutoff(ctx):
     """Tiny genome, very deep coverage: long per-k-mer occurrence lists, single-end cut-off at 4 (sketch.rs:706,937),
     partial marker overlaps."""
