@@ -191,7 +191,7 @@ json.dump({"hbm_bytes_per_launch": int(reads_fetch + reads_write), "kernel": "re
            "probe_hbm_bytes_per_probe": round((probe_fetch_raw + probe_write) / a_probe.get("probes_per_launch", 1), 1),
            "a10_hbm_bytes_per_sample": int(a10_traffic) if a10_traffic else None,
            "head": head, "csrc_sha": csrc_fingerprint(),
-           "source": "profiles/r05_kernel_stats.md PMC section (FETCH_SIZE x2 gfx950 correction for the streaming reads + WRITE_SIZE, separate --pmc passes)"},
+           "source": "the round's pmc_summary.json + pmc_a10.json under profiles/ (tools/r05_profile.sh / r05_pmc_refresh.sh: FETCH_SIZE x2 gfx950 correction for the streaming reads + WRITE_SIZE, separate --pmc passes)"},
           open(os.path.join(dst, "seeds_traffic.json"), "w"))
 if TRAFFIC_ONLY:
     shutil.copy(os.path.join(dst, "seeds_traffic.json"), os.path.join(src, "seeds_traffic.json"))
