@@ -12,6 +12,7 @@ import sys
 TRAFFIC_ONLY = "--traffic-only" in sys.argv          # on the GPU box, between the PMC passes and the bench lines: only profiles/seeds_traffic.json
 src = os.path.join(ROOT, "gpurun_out", "r05_final")
 dst = os.path.join(ROOT, "profiles")
+PREFIX = os.environ.get("SYLPH_PROFILE_ROUND", "r05")     # file-name prefix under profiles/ (round 6 runs the same recipe: SYLPH_PROFILE_ROUND=r06)
 
 
 def load(name):
@@ -36,7 +37,7 @@ for wl in (("c3_pre",) if TRAFFIC_ONLY else ("c3", "c3r", "c2", "c5", "c4", "sma
     try:
         b[wl] = load(f"bench_{wl}.json")
         if not TRAFFIC_ONLY:
-            shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"r05_bench_{wl}.json"))
+            shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{PREFIX}_bench_{wl}.json"))
     except Exception as e:
         print("missing", wl, e)
 if TRAFFIC_ONLY:
@@ -66,7 +67,7 @@ out = [
     "# r05 — rocprofv3 of bench.py C3 (1 Gbp of 2x150 bp reads vs 113,104-genome DB), one MI355X", "",
     f"Code state: `{head}` ({subject}) — the GPU box ran a snapshot of exactly this commit (clean working tree, checked by",
     "`tools/run_r05_profile.sh`); recipe `tools/r05_profile.sh`, assembled by `tools/make_r05_profile_md.py`.", "",
-    f"Un-profiled default run of the same build (profiles/r05_bench_c3.json): mode **{c3['mode']}**, {c3['steps']} steps of {c3['config']['samples_per_gpu_per_step']} samples, timed region "
+    f"Un-profiled default run of the same build (profiles/{PREFIX}_bench_c3.json): mode **{c3['mode']}**, {c3['steps']} steps of {c3['config']['samples_per_gpu_per_step']} samples, timed region "
     f"{c3['timed_region_s']} s: **{c3['ms_per_sample']} ms per sample = {c3['value']} Gbp/s** (per-sample completion interval p50 {c3['sample_interval_ms']['p50']} / p99 {c3['sample_interval_ms']['p99']} / max {c3['sample_interval_ms']['max']} ms;",
     f"step p50 {c3['step_ms']['p50']} / max {c3['step_ms']['max']} ms).  The other mode in the same run: pipelined {pip.get('ms_per_sample')} ms, one sample at a time {seq.get('ms_per_sample')} ms per sample",
     f"({seq.get('value')} Gbp/s; sketch {seq.get('sketch_ms')} ms + profile {seq.get('profile_ms')} ms wall clock).",
@@ -183,7 +184,7 @@ if os.path.exists(fk):
         out += ["", f"Bench line of the same tree: pipelined {fl['pipelined']['value']} Gbp/s ({fl['pipelined']['ms_per_sample']} ms per sample), one at a time "
                     f"{fl['one_step_at_a_time']['ms_per_sample']} ms; the whole table of a 1 Gbp sample equal to the oracle's walk of the filter: {fl.get('verify', {}).get('table_equal')}."]
 if not TRAFFIC_ONLY:
-    open(os.path.join(dst, "r05_kernel_stats.md"), "w").write("\n".join(out) + "\n")
+    open(os.path.join(dst, PREFIX + "_kernel_stats.md"), "w").write("\n".join(out) + "\n")
 json.dump({"hbm_bytes_per_launch": int(reads_fetch + reads_write), "kernel": "reads_kernel<31,1,0>", "valu_per_kmer": round(valu_per_kmer, 1),
            "valu_per_kmer_position_kernel": 38, "valu_busy": round(valu_busy, 3),
            "position_kernel_hbm_bytes_per_launch": int(slots_traffic) if slots_traffic else None,
@@ -200,5 +201,5 @@ if TRAFFIC_ONLY:
 for name in ("feed.txt", "db_load.txt", "stress_shared_kmers.txt", "stress_deep_coverage.txt", "stress_deep_coverage_filter_dedup.txt", "stress_deep_long_reads.txt", "kernel_stats.csv",
              "pytest_gpu.txt", "multi_pipeline_2replicas_one_gpu.json", "pmc_a10.json", "cli_first_sample_trace.txt"):
     if os.path.exists(os.path.join(src, name)):
-        shutil.copy(os.path.join(src, name), os.path.join(dst, "r05_" + name))
+        shutil.copy(os.path.join(src, name), os.path.join(dst, PREFIX + "_" + name))
 print("ok: traffic", reads_fetch + reads_write, "valu/kmer", valu_per_kmer, "busy", valu_busy, "probe B/probe", probe_fetch_raw / a_probe.get("probes_per_launch", 1), "csrc", csrc_fingerprint())
