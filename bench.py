@@ -333,6 +333,19 @@ def end_to_end_from_files(bases, n_pairs_total, read_len, n_pairs):
         env.pop("SYLPH_HIP_INFLATE_DEVICE")
         out["gz_one_sample"]["inflated_on_the_host"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(gbp / dt, 3),
                                                         "what": "the same command with SYLPH_HIP_INFLATE_DEVICE=0: host/pgunzip.cpp on the host's threads (round 5's road)"}
+        # the whole 1 Gbp sample, through the device's inflate and as plain text: the two .sylsp files hold the same table
+        # (types.rs:145-155: u64 length, then (u64 k-mer, u32 count) entries lead the file)
+        def table(path):
+            raw = open(path, "rb").read()
+            n = int.from_bytes(raw[:8], "little")
+            t = np.frombuffer(raw, dtype=np.dtype([("k", "<u8"), ("c", "<u4")]), count=n, offset=8)
+            o = np.argsort(t["k"], kind="stable")
+            return t["k"][o], t["c"][o]
+        try:
+            (ka, ca), (kb, cb) = table(f"{d}/out/s_1.fq.paired.sylsp"), table(f"{d}/out/s_1.fq.gz.paired.sylsp")
+            out["gz_one_sample"]["verify"] = {"table_entries": int(len(ka)), "gz_table_equals_plain_table": bool(len(ka) == len(kb) and (ka == kb).all() and (ca == cb).all())}
+        except Exception as e:
+            out["gz_one_sample"]["verify"] = {"error": str(e)[:200]}
         for i in range(4):
             for m in (1, 2):
                 os.symlink(f"{d}/s_{m}.fq.gz", f"{d}/g{i}_{m}.fq.gz")

@@ -332,6 +332,34 @@ __global__ __launch_bounds__(64) void a10_ops_slots_kernel(OpsIn in, Filter d, u
     const uint32_t b = blockIdx.x, cnt = min(in.blk_count[b], in.slot_cap), g0 = b * in.slot_cap;
     for (uint32_t i = threadIdx.x; i < cnt; i += 64) ops[g0 + i] = op_words(d, in.recs[g0 + i], true, g0 + i);
 }
+// The same for a whole partition TILE of the slots (in.blk_per_tile blocks of the seeding kernel) per workgroup, counting the words per
+// class range on the way: hist[c * n_tiles + t] is what part_hist_kernel would find in a pass of its own over the 64 MB of words
+// (round 6, one-level pass only; eight groups of 32 lanes walk eight blocks at a time, as partition.h's for_tile_entries does)
+__global__ __launch_bounds__(PART_TPB) void a10_ops_tile_kernel(OpsIn in, Filter d, uint32_t blk_per_tile, BucketMap bm, uint32_t n_tiles, ulonglong2* __restrict__ ops,
+                                                                uint32_t* __restrict__ hist, uint32_t* __restrict__ tail) {
+    __shared__ uint32_t s_h[MAX_COARSE];
+    if (blockIdx.x == 0 && threadIdx.x < 2) tail[threadIdx.x] = 0;
+    const uint32_t t = xcd_tile(n_tiles), C = bm.B;
+    if (t >= n_tiles) return;
+    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_h[c] = 0;
+    __syncthreads();
+    const uint32_t grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    for (uint32_t bl = grp; bl < blk_per_tile; bl += PART_TPB / 32) {
+        const uint32_t b = t * blk_per_tile + bl;
+        if (b >= in.n_blk) break;
+        const uint32_t cnt = min(in.blk_count[b], in.slot_cap), g0 = b * in.slot_cap;
+        for (uint32_t i = l; i < cnt; i += 32) {
+            const ulonglong2 w = op_words(d, in.recs[g0 + i], true, g0 + i);
+            ops[g0 + i] = w;
+            if (w.x != INVALID_HASH) {
+                atomicAdd(&s_h[bucket_of_key((uint32_t)(w.x >> 32), bm)], 1u);
+                atomicAdd(&s_h[bucket_of_key((uint32_t)(w.y >> 32), bm)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) hist[(size_t)c * n_tiles + t] = s_h[c];
+}
 __global__ __launch_bounds__(256) void a10_ops_dense_kernel(OpsIn in, Filter d, ulonglong2* __restrict__ ops, uint32_t* __restrict__ tail) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < 2) tail[i] = 0;
@@ -554,13 +582,15 @@ __global__ __launch_bounds__(TPB) void a10_range_kernel(const uint64_t* __restri
             n_over = s_n[1];
         }
         if (over) {
-            if (P == 1) {                                                  // slices of about a quarter of the lists, from the top
-                P = min((n_over + RNG_CAND / 4 - 1) / (RNG_CAND / 4), 4096u);
+            // slices of about half the lists (the slots are uniform: 11 sigma of room), from the top; a slice that is still too full holds
+            // many copies of ONE item — narrower slices twice more (marks set so far are set again: the OR is idempotent), then the verdict
+            if (P < 1024u) {
+                P = P == 1 ? min((n_over + RNG_CAND / 2 - 1) / (RNG_CAND / 2), 4096u) : min(P * 8u, 4096u);
                 p = ~0u;                                                   // (p++ makes it 0)
                 __syncthreads();
                 continue;
             }
-            if (tid == 0) atomicAdd(&tail[0], 1u);                         // a slice fuller than the lists: the walk takes the sample
+            if (tid == 0) atomicAdd(&tail[0], 1u);                         // more copies of one item than the lists take: the walk takes the sample
             return;
         }
         const uint32_t nc = s_n[1];
@@ -632,7 +662,8 @@ static void a10_mark_partitioned(sylph_sketch* sk) {
     // buckets: equal ranges of the words' upper 32 bits, ~bucket_target operations each
     static const int env_levels = [] { const char* e = getenv("SYLPH_HIP_A10_LEVELS"); return e ? atoi(e) : 1; }();
     const bool one_level = env_levels != 2;
-    const uint32_t B = one_level ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2 * n_expect / RNG_WORDS), MAX_COARSE)
+    static const uint32_t env_words = [] { const char* e = getenv("SYLPH_HIP_A10_RANGE_WORDS"); return e ? (uint32_t)std::max(512, std::min(1 << 20, atoi(e))) : RNG_WORDS; }();
+    const uint32_t B = one_level ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2 * n_expect / env_words), MAX_COARSE)
                                  : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2 * n_expect / ctx->bucket_target), 1u << 24);
     BucketMap bm{};
     bm.sh = 32;
@@ -667,11 +698,16 @@ static void a10_mark_partitioned(sylph_sketch* sk) {
     b_hist.reserve(part_hist_words(geom, n_tiles) * 4);
     b_boff.reserve(((size_t)B + 2) * 4);
     ScopedKernelTimer t(ctx, "a10");
-    if (slotted) hipLaunchKernelGGL(a10_ops_slots_kernel, dim3(oin.n_blk), dim3(64), 0, ctx->stream, oin, f0, b_ops.as<ulonglong2>(), tail);
+    static const bool env_fused_hist = [] { const char* e = getenv("SYLPH_HIP_A10_FUSED_HIST"); return !e || atoi(e) != 0; }();
+    const bool fused_hist = slotted && one_level && env_fused_hist;         // the operation words' kernel also counts them per (range, tile)
+    if (fused_hist)
+        hipLaunchKernelGGL(a10_ops_tile_kernel, dim3(((n_tiles + 7) / 8) * 8), dim3(PART_TPB), 0, ctx->stream, oin, f0, in.blk_per_tile, bm, n_tiles, b_ops.as<ulonglong2>(),
+                           b_hist.as<uint32_t>(), tail);
+    else if (slotted) hipLaunchKernelGGL(a10_ops_slots_kernel, dim3(oin.n_blk), dim3(64), 0, ctx->stream, oin, f0, b_ops.as<ulonglong2>(), tail);
     else hipLaunchKernelGGL(a10_ops_dense_kernel, dim3((uint32_t)((sk->n_occ + 255) / 256)), dim3(256), 0, ctx->stream, oin, f0, b_ops.as<ulonglong2>(), tail);
     if (one_level) {
         // words grouped by range where the scatter left them; slot of a word inside its range = (upper half - lowest of the range) x slots / width
-        launch_partition_coarse(ctx, in, bm, n_tiles, b_hist.as<uint32_t>(), b_pairs.as<uint2>());
+        launch_partition_coarse(ctx, in, bm, n_tiles, b_hist.as<uint32_t>(), b_pairs.as<uint2>(), fused_hist);
         static const int env_split = [] { const char* e = getenv("SYLPH_HIP_A10_RANGE_SPLIT"); return e ? std::max(1, std::min(8, atoi(e))) : 2; }();
         static const int env_pad = [] { const char* e = getenv("SYLPH_HIP_A10_RANGE_LDS_PAD"); return e ? atoi(e) : 0; }();     // (A/B: LDS footprint)
         const uint32_t split = (uint32_t)env_split;

@@ -314,14 +314,16 @@ inline void launch_partition(sylph_ctx* ctx, const PartIn& in, const BucketMap& 
 // grouped by range in `pairs`, range c at [cbase[c], cbase[c + 1]) with cbase = part_cbase(hist, C, n_tiles); whoever reads the
 // ranges resolves the rest in LDS.  bm.B = C <= MAX_COARSE.
 inline const uint32_t* part_cbase(const uint32_t* hist, uint32_t C, uint32_t n_tiles) { return hist + (size_t)C * n_tiles + C; }
-inline void launch_partition_coarse(sylph_ctx* ctx, const PartIn& in, const BucketMap& bm, uint32_t n_tiles, uint32_t* hist, uint2* pairs) {
+// have_hist: the caller's own kernel has written hist[c * n_tiles + t] already (a10.hip: while it wrote the words).
+inline void launch_partition_coarse(sylph_ctx* ctx, const PartIn& in, const BucketMap& bm, uint32_t n_tiles, uint32_t* hist, uint2* pairs, bool have_hist = false) {
     const uint32_t C = bm.B;
     SY_REQUIRE(C >= 1 && C <= MAX_COARSE, "internal: %u ranges", C);
     uint32_t* ctotal = hist + (size_t)C * n_tiles;
     uint32_t* cbase = ctotal + C;
     const uint32_t tile_grid = ((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(part_hist_kernel, dim3(tile_grid), dim3(PART_TPB), 0, ctx->stream, in, bm, 0, C, n_tiles, hist, (uint32_t*)nullptr, 0u,
-                       (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    if (!have_hist)
+        hipLaunchKernelGGL(part_hist_kernel, dim3(tile_grid), dim3(PART_TPB), 0, ctx->stream, in, bm, 0, C, n_tiles, hist, (uint32_t*)nullptr, 0u,
+                           (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(part_scan_kernel, dim3(C), dim3(PART_TPB), 0, ctx->stream, hist, n_tiles, ctotal);
     hipLaunchKernelGGL(part_scatter_kernel, dim3(tile_grid), dim3(PART_TPB), (2 * (size_t)C + 2 * (size_t)(in.stage_pairs ? in.stage_pairs : STAGE_PAIRS)) * 4, ctx->stream, in, bm,
                        0, C, n_tiles, hist, ctotal, cbase, pairs);
