@@ -495,9 +495,12 @@ __global__ __launch_bounds__(TPB) void a10_range_kernel(const uint64_t* __restri
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[RNG_SLOTS / 32];
     __shared__ uint32_t s_sec[RNG_CAND], s_up[RNG_TAB], s_list[RNG_CAND];
     __shared__ uint32_t s_n[2];
-    const uint32_t tid = threadIdx.x, c = blockIdx.x / split, part = blockIdx.x % split;
-    const uint32_t lo = cbase[c], hi = cbase[c + 1];
+    // Workgroups go round-robin to the 8 XCDs (each with its own L2): the `split` workgroups of a range are 8 apart in the grid — the
+    // same XCD, one right behind the other — so that the second one's reads of the range's words are L2 hits
+    const uint32_t tid = threadIdx.x, c = (blockIdx.x / (8u * split)) * 8u + (blockIdx.x & 7u), part = (blockIdx.x >> 3) % split;
     if (blockIdx.x == 0 && tid == 0) tail[1] = cbase[C];      // operations found
+    if (c >= C) return;                                       // (padding of the grid to whole groups of 8 ranges)
+    const uint32_t lo = cbase[c], hi = cbase[c + 1];
     if (hi == lo) return;
     const uint32_t lo_key = (uint32_t)((((uint64_t)c << 32) + mult - 1u) / mult);      // smallest upper half of the range
     const uint32_t all_slots = split << RNG_SLOT_BITS;
@@ -713,7 +716,7 @@ static void a10_mark_partitioned(sylph_sketch* sk) {
         const uint32_t split = (uint32_t)env_split;
         const uint64_t all_slots = (uint64_t)split << RNG_SLOT_BITS;
         const uint32_t slot_mult = range > all_slots ? (uint32_t)((all_slots << 32) / range) : 0u;
-        hipLaunchKernelGGL(a10_range_kernel<256>, dim3(B * split), dim3(256), (size_t)env_pad, ctx->stream, b_pairs.as<uint64_t>(),
+        hipLaunchKernelGGL(a10_range_kernel<256>, dim3(((B + 7) / 8) * 8 * split), dim3(256), (size_t)env_pad, ctx->stream, b_pairs.as<uint64_t>(),
                            part_cbase(b_hist.as<uint32_t>(), B, n_tiles), B, bm.mult, slot_mult, split, f0, const_cast<OccRec*>(oin.recs), tail);
     } else {
         launch_partition(ctx, in, bm, geom, n_tiles, 2 * n_expect, b_hist.as<uint32_t>(), b_pairs.as<uint2>(), b_boff.as<uint32_t>(), nullptr,

@@ -152,22 +152,26 @@ __global__ __launch_bounds__(PART_TPB) void part_scatter_kernel(PartIn in, Bucke
     __shared__ uint32_t s_wave[PART_TPB / 64];
     const uint32_t t = xcd_tile(n_tiles), stage = in.stage_pairs ? in.stage_pairs : STAGE_PAIRS;
     if (t >= n_tiles) return;
-    for (uint32_t c = threadIdx.x; c < C; c += PART_TPB) s_cur[c] = 0;
-    __syncthreads();
-    for_tile_entries(in, t, [&](uint32_t key, uint32_t, uint64_t) { atomicAdd(&s_cur[bucket_of_key(key, bm) >> fine_bits], 1u); });
-    __syncthreads();
     uint32_t n_tile = 0;
-    {   // tile order: start[c] = exclusive sum of the tile's counts; cbase = exclusive sum of the range sizes
+    {   // tile order: start[c] = exclusive sum of the tile's counts; cbase = exclusive sum of the range sizes.  The tile's count per range is
+        // what the histogram found — the next tile's offset inside the range minus this tile's (round 6: the tile was read and counted a
+        // second time here before)
         const uint32_t per = (C + PART_TPB - 1) / PART_TPB, a = threadIdx.x * per, b = min(C, a + per);
         uint32_t sum_t = 0, sum_g = 0;
-        for (uint32_t c = a; c < b; c++) { sum_t += s_cur[c]; sum_g += total[c]; }
+        for (uint32_t c = a; c < b; c++) {
+            const uint32_t o0 = offs[(size_t)c * n_tiles + t], tot = total[c], o1 = t + 1 < n_tiles ? offs[(size_t)c * n_tiles + t + 1] : tot;
+            s_cur[c] = o1 - o0;
+            s_gb[c] = o0;
+            sum_t += o1 - o0;
+            sum_g += tot;
+        }
         uint32_t tot_g = 0;
         uint32_t run_t = block_excl_sum<PART_TPB>(sum_t, s_wave, &n_tile);
         uint32_t run_g = block_excl_sum<PART_TPB>(sum_g, s_wave, &tot_g);
         for (uint32_t c = a; c < b; c++) {
             const uint32_t cnt = s_cur[c];
             if (t == 0) cbase[c] = run_g;
-            s_gb[c] = run_g + offs[(size_t)c * n_tiles + t] - run_t;
+            s_gb[c] = run_g + s_gb[c] - run_t;
             s_cur[c] = run_t;
             run_t += cnt;
             run_g += total[c];

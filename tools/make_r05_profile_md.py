@@ -64,7 +64,7 @@ valu_busy = sq["reads.SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)
 a_seeds = rf.get("alone_on_gpu", {})
 a_probe = rp.get("alone_on_gpu", {})
 out = [
-    "# r05 — rocprofv3 of bench.py C3 (1 Gbp of 2x150 bp reads vs 113,104-genome DB), one MI355X", "",
+    f"# {PREFIX} — rocprofv3 of bench.py C3 (1 Gbp of 2x150 bp reads vs 113,104-genome DB), one MI355X", "",
     f"Code state: `{head}` ({subject}) — the GPU box ran a snapshot of exactly this commit (clean working tree, checked by",
     "`tools/run_r05_profile.sh`); recipe `tools/r05_profile.sh`, assembled by `tools/make_r05_profile_md.py`.", "",
     f"Un-profiled default run of the same build (profiles/{PREFIX}_bench_c3.json): mode **{c3['mode']}**, {c3['steps']} steps of {c3['config']['samples_per_gpu_per_step']} samples, timed region "
@@ -152,6 +152,8 @@ try:
         mine = name.startswith("a10_") or (name.startswith("part_") and (len(grids[name]) == 1 or int(grid) == max(grids[name])))
         if name.startswith("part_fine") and any(k.startswith("a10_range_kernel") for k in a10):
             mine = False                                     # round 6: one partition level — the fine level is the replay's alone
+        if name.startswith("part_hist") and any(k.startswith("a10_ops_tile_kernel") for k in a10):
+            mine = False                                     # ... and the histogram comes from the operation words' kernel: part_hist is the replay's alone
         if not mine or name == "part_scan_kernel" and len(grids[name]) > 1 and int(grid) != max(grids[name]):
             continue
         f_b, w_b = v.get("FETCH_SIZE", 0) * 1024 * 2, v.get("WRITE_SIZE", 0) * 1024
@@ -162,8 +164,8 @@ try:
         rows_a.append(f"| `{name}` | {grid} | {f_b * share:.3e} | {w_b * share:.3e} | {v.get('SQ_INSTS_VALU', 0) * share:.3g} | {v.get('SQ_INSTS_SALU', 0) * share:.3g} | {v.get('SQ_LDS_BANK_CONFLICT', 0) * share:.3g} |")
     a10_traffic = tot_f + tot_w
     ra = b["c3"].get("roofline_a10", {})
-    out += ["", "### the filter dedup's partitioned pass (csrc/a10.hip, round 5: `--main-dedup-fpr 1e-4`, every sample behind sylph's default filter)", "",
-            "FETCH_SIZE x 1024 x 2 (coalesced streaming reads: calibrated on part_hist_kernel, which reads the 8.0 M operation words = 64 MB and reports 32.0 MB), WRITE_SIZE x 1024:", "",
+    out += ["", "### the filter dedup's partitioned pass (csrc/a10.hip: `--main-dedup-fpr 1e-4`, every sample behind sylph's default filter)", "",
+            "FETCH_SIZE x 1024 x 2 (coalesced streaming reads: calibrated in round 5 on part_hist_kernel, which read the 8.0 M operation words = 64 MB and reported 32.0 MB), WRITE_SIZE x 1024:", "",
             "| kernel | grid | read bytes | written bytes | VALU wave-instr | SALU | LDS bank conflicts |", "|---|---|---|---|---|---|---|"] + rows_a
     out += ["", f"Per sample: **{a10_traffic:.4e} B of HBM traffic** for {ra.get('algorithmic_bytes_per_launch', 0):.4e} algorithmic bytes (the 32 B record of every occurrence) = "
                 f"{a10_traffic / max(1, ra.get('algorithmic_bytes_per_launch', 1)):.1f}x — 8-byte operation words through one partition level (round 5: two) and an LDS bit table per range, all of it coalesced — in {ra.get('avg_launch_ms')} ms alone on the GPU "
