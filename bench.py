@@ -447,8 +447,8 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the in-library HIP-event kernel timers (no roofline objects)")
     ap.add_argument("--all-kernel-timers", action="store_true", help="time every kernel family inside the timed region too (rounds 1-4 did; costs ~1 %% pipelined, ~4 %% one at a time)")
-    ap.add_argument("--sketch-workers", type=int, default=0, help="sketch worker threads of the pipeline, each with its own context/stream (default 3)")
-    ap.add_argument("--pipeline-depth", type=int, default=0, help="samples in flight in the pipeline (default: workers + 5; sharded: two probe batches)")
+    ap.add_argument("--sketch-workers", type=int, default=int(os.environ.get("SYLPH_BENCH_SKETCH_WORKERS", "0")), help="sketch worker threads of the pipeline, each with its own context/stream (default 3)")
+    ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("SYLPH_BENCH_PIPELINE_DEPTH", "0")), help="samples in flight in the pipeline (default: workers + 5; sharded: two probe batches)")
     ap.add_argument("--no-files-leg", action="store_true", help="skip the leg that runs `sylph-hip sketch` on FASTQ files (plain, gzip)")
     ap.add_argument("--files-leg-pairs", type=int, default=3_333_334, help="read pairs per sample of that leg (default: the workload's own sample, 1 Gbp)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the leg with the reads resident as packed 2-bit")

@@ -190,12 +190,32 @@ Engine::Engine(int dev) : device(dev), gate_(new Gate()) {
             int rc = sylph_sketch_set_option(sk, "dedup_fpr", "0.0001");
             std::vector<uint8_t> b(8 * 150, 'A');
             for (size_t i = 0; i < b.size(); i++) b[i] = "ACGT"[(i * 2654435761u >> 7) & 3];
-            std::vector<uint64_t> off(9);
-            for (size_t i = 0; i < off.size(); i++) off[i] = i * 150;
             uint64_t* k = nullptr; uint32_t* c = nullptr; uint64_t n = 0, dup = 0;
-            rc = rc || sylph_sketch_push(sk, b.data(), off.data(), 8, SYLPH_MEM_HOST) || sylph_sketch_finish(sk, &k, &c, &n, &dup);
+            if (warm_text_route.load() && device_feed_enabled()) {
+                // the process's first sample is a gzip one on the device route: its text is indexed and pushed by the route's own kernels
+                // (csrc/fastq.hip) — the warm-up pairs go THAT way, as FASTQ text, so that those kernels' first launches (~20 ms of host-side
+                // binding between the sample's inflate and its push otherwise) happen here; the seeding / dedup kernels behind them are the same
+                std::string fq[2];
+                for (int m = 0; m < 2; m++) {
+                    fq[m] = std::string(16, '\n');
+                    for (int r = 0; r < 4; r++) fq[m] += "@w\n" + std::string((const char*)b.data() + (size_t)(m * 4 + r) * 150, 150) + "\n+\n" + std::string(150, 'I') + "\n";
+                    fq[m] += std::string(32, '\n');                                         // (readable 16 bytes either side of the text)
+                }
+                sylph_fastq *fa = nullptr, *fb = nullptr;
+                rc = rc || sylph_fastq_index(ctx_, fq[0].data() + 16, fq[0].size() - 48, SYLPH_MEM_HOST, &fa) ||
+                     sylph_fastq_index(ctx_, fq[1].data() + 16, fq[1].size() - 48, SYLPH_MEM_HOST, &fb) ||
+                     sylph_sketch_set_option(sk, "borrow_until_finish", "1") || sylph_sketch_push_fastq(sk, fa, fb, 0, 4) ||
+                     sylph_sketch_finish(sk, &k, &c, &n, &dup);
+                sylph_sketch_destroy(sk);
+                sk = nullptr;
+                sylph_fastq_destroy(fa); sylph_fastq_destroy(fb);
+            } else {
+                std::vector<uint64_t> off(9);
+                for (size_t i = 0; i < off.size(); i++) off[i] = i * 150;
+                rc = rc || sylph_sketch_push(sk, b.data(), off.data(), 8, SYLPH_MEM_HOST) || sylph_sketch_finish(sk, &k, &c, &n, &dup);
+            }
             sylph_free(k); sylph_free(c);
-            sylph_sketch_destroy(sk);
+            if (sk) sylph_sketch_destroy(sk);
             if (rc) hip_check(rc, "warm-up");
             trace_mark("engine: sketch kernels loaded (warm-up sample done)");
             open_gate();             // sessions may be opened from here on ...
@@ -969,7 +989,7 @@ int sketch(Engine& e, const SketchArgs& args) {
         else if (!dev) pre = ahead.get(j);
         // (a gzip sample on the device route needs none of the page-locked feed buffers: an engine still in its bring-up leaves them to
         //  whoever wants them first — ~80 ms of hipHostMalloc that would run beside the sample's own allocations and copies)
-        if (gz_dev && !eng.ready()) eng.defer_pinned.store(true);
+        if (gz_dev && !eng.ready()) { eng.defer_pinned.store(true); eng.warm_text_route.store(true); }
         trace_mark(dev ? "sketch: the sample goes the device route" : "sketch: the sample's files are indexed (or not indexable)");
         if (++indexes_obtained == n_jobs) set_no_more_inflates(true);   // nobody will want a recycled inflate buffer any more
         // the index goes (2 x 1 GB of mappings to unmap / inflated copies to hand back: 30-60 ms per sample) on a thread of its own, behind the sample

@@ -256,6 +256,7 @@ struct Engine {   // one GPU context shared by the drivers
     int device = -1;
     PinnedBatch batch;   // reused by every sample sketched through this engine
     TextUploader text;   // ... and the uploader of the device-side FASTQ route (commands.cpp sketch_fastq_on_device)
+    std::atomic<bool> warm_text_route{false};   // set before the bring-up's warm-up sample: it goes the device FASTQ route's way (the first sample will)
     std::atomic<bool> defer_pinned{false};   // set before the bring-up reaches them: `batch` and `text` page-lock their buffers at first use instead
     // GPU bring-up (runtime initialisation, context, page-locked batch, first-use loading of the sketch kernels: ~0.3 s) runs on a
     // background thread from the moment the engine exists, so that it overlaps with argument handling and the indexing of the
