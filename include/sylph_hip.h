@@ -106,7 +106,8 @@ void sylph_upload_destroy(sylph_upload *u);
  * family costs two event records per launch group on its stream — 1 % of a pipelined sample, 4 % of a sample run alone, with all of
  * them on (profiles/r05_ab_timers.txt): bench.py times only the dominant kernel inside its timed region.
  * "reads_tail_pct" = "0".."50": inside a pipeline's seeding turn (one seeding kernel at a time), the share of a sample's blocks of reads
- * that is launched separately BEHIND the turn's event, so that the next sample's seeding kernel starts while they run ("0" = one launch).
+ * that is launched separately BEHIND the turn's event, so that the next sample's seeding kernel starts while they run ("0" = one launch;
+ * default "10" since round 6: profiles/r06_ab_latency.txt).
  * "reads_hash" = "0" | "1" | "2" | "-1": how the read-per-lane kernel spells the hash and the threshold test in its k-mer loop —
  * the compiler's own lowering, the hand-scheduled 64-bit one, or the last hash step and the test on the high word only (a superset of
  * the seeds; the kernel's second pass, which hashes every candidate exactly anyway, prunes it); same tables all three, "-1" = the
@@ -493,7 +494,7 @@ uint32_t sylph_pipeline_outstanding(sylph_pipeline *p);
  * The pipeline's own knobs — "serialize_seeding" (default 1: one seeding kernel at a time on the GPU — a worker's stream waits
  * for the event behind the previous worker's seeding kernel, no host blocks — while the other samples are in their dedup/count tails;
  * two VALU-bound seeding kernels side by side only slow each other, +3 % in r04), "min_batch" +
- * "batch_wait_us" (default 2 / 400: the profile thread waits up to batch_wait_us for min_batch ready tables while more samples are
+ * "batch_wait_us" (default 1 / 400 — 2 / 400 until round 6, when tables probed one by one became faster and bound the completion intervals: the profile thread waits up to batch_wait_us for min_batch ready tables while more samples are
  * being sketched — never for samples nobody has submitted; unsharded pipelines only; +1.2 % in r04) — else sylph_ctx_set_option on every worker context.  sylph_ctx_profile /
  * sylph_ctx_kernel_stats summed over the workers' and the database's contexts.
  * sylph_pipeline_next on a sharded pipeline returns SYLPH_ERR_STATE instead of blocking when fewer than max_batch samples are

@@ -133,7 +133,7 @@ struct KernelStat { double ms = 0; uint64_t launches = 0; };
 }  // namespace sylph
 
 #ifndef SYLPH_READS_TAIL_PCT
-#define SYLPH_READS_TAIL_PCT 0
+#define SYLPH_READS_TAIL_PCT 10     // (round 6; 0 until then: profiles/r06_ab_latency.txt — 5, 15, 20, 30 are all slower on the exact pair set)
 #endif
 struct sylph_ctx {
     int device = 0;

@@ -93,7 +93,10 @@ struct sylph_pipeline {
     std::atomic<uint32_t> serialize_seeding{1};  // 1 (default, r04: +3 %, profiles/r04_ab_pipeline_sweep.txt): one worker at a time runs its seeding kernel —
                                                  // two VALU-bound seeding kernels side by side only slow each other; the others are in their dedup/count tails
     std::string dedup_fpr, dedup_capacity;       // "dedup_fpr" / "dedup_capacity": handed to every session the pipeline opens (sylph_sketch_set_option; a10.hip)
-    uint32_t min_batch = 2, batch_wait_us = 400; // the profile thread waits up to batch_wait_us for min_batch ready tables while more are being sketched (r04: +1.2 %)
+    // the profile thread waits up to batch_wait_us for min_batch ready tables while more are being sketched.  r04: 2 (+1.2 %).  Round 6: 1 — with
+    // the seeding tail below, tables probed one by one are 0.5 % (default flags: 2.4 %) FASTER, and the samples no longer complete in pairs:
+    // completion intervals p99 2.0 -> 1.3 ms (profiles/r06_ab_latency.txt)
+    uint32_t min_batch = 1, batch_wait_us = 400;
     std::mutex seed_mu;
     // serialize_seeding on the DEVICE: a push with a deferred verdict returns as soon as its kernels are queued, so holding a
     // mutex around it orders nothing on the GPU — the next worker's stream waits for the event the previous worker recorded
