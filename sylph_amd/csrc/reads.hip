@@ -648,17 +648,24 @@ bool push_short_reads(sylph_sketch* sk, const uint8_t* d_bases, uint32_t phase, 
         }
         ctx->seed_gate();
         {
-            ScopedKernelTimer t(ctx, "seeds");
             // In a pipeline's turn the sample's last positions are a launch of their own and the turn's event sits in front of it: the next
             // sample's kernel starts while this one's last workgroups drain (two seeding kernels share the chip for those few per cent of
             // one — the work is the same, the event-to-wait latency and the drain of a 26,000-workgroup grid are not paid between them).
+            // (The tail is a launch of its own for the timers too: one pair of events around both would count the time the tail waits behind
+            //  the turn's event — the next sample's kernel is running then — as this kernel's duration.)
             const uint32_t n_round = ((n_blk + 7) / 8) * 8;
             uint32_t cut = n_round;
             if (ctx->turn.done && !ctx->turn.recorded && ctx->reads_tail_pct && n_round >= 64)
                 cut = (uint32_t)((uint64_t)n_round * (100 - ctx->reads_tail_pct) / 100) & ~7u;
-            launch(n_blk, 0, cut, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
+            {
+                ScopedKernelTimer t(ctx, "seeds");
+                launch(n_blk, 0, cut, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
+            }
             ctx->seed_done();
-            launch(n_blk, cut, n_round, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
+            if (cut < n_round) {
+                ScopedKernelTimer t(ctx, "seeds");
+                launch(n_blk, cut, n_round, slot_cap, sk->slot_rec.as<OccRec>(), sk->slot_key.as<uint32_t>(), nullptr);
+            }
         }
         // deferred verdict (sketch_session.h PendingSlots): the caller keeps the batch valid until finish, this is the session's first
         // batch and nothing forces the dense arrays — no block total, no read-back, no wait; finish reads the flags with its own tail
