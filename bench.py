@@ -974,20 +974,37 @@ def main():
         n_rec = float(np.mean([r["n_records"] for r in read_sets]))
         n_occ = float(np.mean(last["occ"]))
         launches_per_sample = max(1, round(seeds_launches / (args.steps * sps)))
-        alg_bytes = (n_bases + 8 * n_rec + 8 * n_occ) / launches_per_sample   # a sample > 2^32 bases is pushed in batches
-        avg_ms = seeds_ms / seeds_launches
+        # a sample > 2^32 bases is pushed in batches (long reads: every launch is a batch of its own, bytes and time per batch); a short-read
+        # sample in a pipeline is ONE batch whose last tenth of blocks is a second launch of the same kernel behind the turn's event
+        # (reads_tail_pct, round 6): its two launches are one "launch" here — all the sample's bytes, the SUM of the two durations
+        groups = launches_per_sample if long_mode else 1
+        alg_bytes = (n_bases + 8 * n_rec + 8 * n_occ) / groups
+        avg_ms = seeds_ms / seeds_launches * (launches_per_sample / groups)
+        seeds_launches = seeds_launches * groups / launches_per_sample
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = meta.get("hbm_bytes_per_launch") if (meta_ok and wl in ("c2", "c3", "c4")) else None
         if meta_ok and long_mode:
             traffic = meta.get("position_kernel_hbm_bytes_per_launch")   # the C5 position kernel's own PMC pass (tools/r04_profile.sh)
         ipk = (meta.get("valu_per_kmer_position_kernel") if long_mode else meta.get("valu_per_kmer")) if meta_ok else None
-        hashed = (n_bases if long_mode else max(0.0, n_bases - n_rec * (k - 1))) / launches_per_sample
+        hashed = (n_bases if long_mode else max(0.0, n_bases - n_rec * (k - 1))) / groups
         out["roofline"] = {"bound": "hbm", "kernel": "seeds_slots_kernel<31,1>" if long_mode else "reads_kernel<31,1>", "achieved": round(achieved, 1),
                            "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                            "traffic_source": tsrc if traffic is not None else f"none: no PMC figures for these kernel sources (csrc {fp}; profiles/seeds_traffic.json holds {meta.get('csrc_sha', 'nothing')})",
                            "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4), "launches": int(seeds_launches),
                            "note": "integer-VALU issue bound (SQ counters in profiles/)" +
                                    (f"; pipelined: launch durations include time shared with the other streams' kernels (alone on the GPU: alone_on_gpu)" if mode == "pipelined" else "")}
+        if not long_mode and launches_per_sample > 1:
+            # Since round 6 a pipeline launches the last tenth of a sample's blocks behind its turn's event, so consecutive samples' seeding
+            # kernels OVERLAP on purpose (+0.9 % samples per second): each runs longer than it would behind the other, and the sum of a sample's
+            # two launch durations exceeds the time between two samples.  What the chip does with this kernel's bytes per second of wall
+            # clock is bytes per sample / sample period:
+            period_ms = elapsed / (args.steps * sps) * 1e3
+            out["roofline"]["launches_per_sample"] = int(launches_per_sample)
+            out["roofline"]["overlapping_launches"] = {
+                "sum_of_a_samples_launch_ms": round(avg_ms, 4), "sample_period_ms": round(period_ms, 4),
+                "achieved_per_wall_time": round(alg_bytes / (period_ms * 1e-3) / 1e9, 1), "frac_per_wall_time": round(alg_bytes / (period_ms * 1e-3) / 1e9 / 8000.0, 4),
+                "note": "avg_launch_ms is the SUM of a sample's two launches of this kernel (head + tail, reads_tail_pct = 10); consecutive samples' kernels overlap, "
+                        "so `frac` (bytes / that sum) fell from 0.148 to ~0.12 while the sample rate rose: frac_per_wall_time = bytes per sample / sample period"}
         if ipk:
             # secondary ceiling: VALU issue = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s, i.e. 4 cycles per
             # wave-instruction; plain VOP2 integer ops issue faster than that on this chip (profiles/r02_valu_rates.txt),
