@@ -354,6 +354,12 @@ def end_to_end_from_files(bases, n_pairs_total, read_len, n_pairs):
         dt, per = run(["-1", *[f"{d}/g{i}_1.fq.gz" for i in range(4)], "-2", *[f"{d}/g{i}_2.fq.gz" for i in range(4)], "-t", "1"])
         out["gz_four_samples_one_command"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(4 * gbp / dt, 3),
                                               "sample_gbp_per_s_in_order": [round(gbp / x, 2) for x in per]}
+        # the same four samples over two sample threads (`-t 2`: a second engine — context, stream, warm-up — comes up beside the first; the
+        # reference's default is 3 threads, sketch.rs:313)
+        dt, per = run(["-1", *[f"{d}/g{i}_1.fq.gz" for i in range(4)], "-2", *[f"{d}/g{i}_2.fq.gz" for i in range(4)], "-t", "2"])
+        out["gz_four_samples_one_command"]["two_sample_threads"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(4 * gbp / dt, 3)}
+        dt, per = run(["-1", *[f"{d}/p{i}_1.fq" for i in range(4)], "-2", *[f"{d}/p{i}_2.fq" for i in range(4)], "-t", "2"])
+        out["plain_four_samples_one_command"]["two_sample_threads"] = {"command_seconds": round(dt, 3), "command_gbp_per_s": round(4 * gbp / dt, 3)}
         # The same files through the CPU path as the reference runs it (sketch.rs:313, :371: one rayon worker per sample; needletail +
         # flate2 on that thread): oracle/'s fast seeding + its model of the default pair dedup behind a zlib reader, ONE thread per
         # sample, as many samples side by side as the box may use CPUs.  kind = "port": the oracle, timed, never the product.
