@@ -120,7 +120,13 @@ bool ends_with(const std::string& s, const char* suf) {
 void write_sylsp(const std::string& path, const SequencesSketch& s) {
     Writer w(path);
     w.u64(s.kmers.size());
-    for (size_t i = 0; i < s.kmers.size(); i++) { w.u64(s.kmers[i]); w.u32(s.counts[i]); }
+    {   // the table as one block of 12-byte entries (a 1 Gbp sample: 1.9 M entries; per-field appends cost 26-35 ms of a 250 ms command)
+        const size_t n = s.kmers.size();
+        std::vector<char> packed(n * 12);
+        char* out = packed.data();
+        for (size_t i = 0; i < n; i++, out += 12) { memcpy(out, &s.kmers[i], 8); memcpy(out + 8, &s.counts[i], 4); }
+        w.raw(packed.data(), packed.size());
+    }
     w.u64(s.c);
     w.u64(s.k);
     w.str(s.file_name);
