@@ -260,6 +260,40 @@ def test_bench_two_ranks_on_one_gpu_small_workload(db_mode):
     assert any("exchange" in leg and leg["exchange"]["probe_batches"] > 0 and leg["exchange"]["hit_bytes_sent_per_batch"] > 0 for leg in legs)
 
 
+def test_bench_line_contract_one_gpu_small_workload():
+    """`python bench.py` at N = 1 on a small workload: ONE JSON line with the driver's fields, the `roofline` object of the dominant kernel
+    (bound, achieved, peak, frac, traffic key; since round 6 a pipeline's sample has two launches of the seeding kernel — head and tail — which
+    the line says and prices), the `cpu_baseline` object (kind "port": the oracle, timed on the host), the side-by-side `rates_gbp_per_s`,
+    a verify leg without mismatches, and sylph's default pair dedup beside the exact set."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "small", "--steps", "3", "--warmup", "1", "--min-seconds", "0.3",
+                        "--cpu-baseline-bounded", "--no-files-leg", "--no-packed-leg"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["value"] > 0
+    assert d["config"]["workload"] and d["data"].startswith("synthetic")
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and "traffic" in roof
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["avg_launch_ms"] > 0 and roof["launches"] > 0
+    if roof.get("launches_per_sample", 1) > 1:                                   # the tail launch of a pipeline's turn (reads_tail_pct)
+        ov = roof["overlapping_launches"]
+        assert ov["sum_of_a_samples_launch_ms"] == roof["avg_launch_ms"] and ov["frac_per_wall_time"] > 0
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert d["verify"]["mismatches"] == 0 and d["verify"]["genomes_checked"] > 0
+    assert d["rates_gbp_per_s"]["gpu_inputs_resident_exact_dedup"] == d["value"]
+    if "default_pair_dedup" in d:
+        assert d["value_default_flags"] > 0 and d["default_pair_dedup"]["verify"]["table_equal"] is True
+
+
 def test_bench_two_ranks_genome_sharded_arm_composed_outside_the_library():
     """`bench.py --gpus 2 --db-mode genome-py`: round 4's composition of the cut by genome (sylph_amd/shard.py: unsharded index per rank,
     torch.distributed all-gathers of tables, counts and coverage values) — kept beside the library mode for the A/B."""
